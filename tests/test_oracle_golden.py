@@ -1,0 +1,142 @@
+"""Pin the CPU oracle (oracle/neunet_oracle.py) against golden vectors produced by the REAL
+reference (tools/gen_golden.py, run in the build container).  CPU-only."""
+import numpy as np
+import pytest
+
+from oracle import neunet_oracle as O
+
+TOL = dict(rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["linear_2d", "linear_3d", "linear_nobias"])
+def test_linear(golden, name):
+    g = golden(name)
+    b = g.get("b")
+    np.testing.assert_allclose(O.linear_forward(g["X"], g["W"], b), g["O"], **TOL)
+    dX, dW, db = O.linear_backward(g["X"], g["W"], b, g["dO"])
+    np.testing.assert_allclose(dX, g["dX"], **TOL)
+    np.testing.assert_allclose(dW, g["dW"], rtol=1e-5, atol=1e-5)
+    assert dW.shape == g["W"].shape
+    if b is not None:
+        assert db.shape == (1, 40)
+        np.testing.assert_allclose(db, g["db"], rtol=1e-5, atol=1e-5)
+
+
+def test_relu(golden):
+    g = golden("relu")
+    y = O.relu_forward(g["X"])
+    np.testing.assert_array_equal(y, g["Y"])
+    np.testing.assert_array_equal(O.relu_backward(y, g["dY"]), g["dX"])
+
+
+@pytest.mark.parametrize("name", ["swish_b1.0", "swish_b1.5"])
+def test_swish(golden, name):
+    g = golden(name)
+    beta = float(g["beta"])
+    np.testing.assert_allclose(O.swish_forward(g["X"], beta), g["Y"], **TOL)
+    np.testing.assert_allclose(O.swish_backward(g["X"], g["dY"], beta), g["dX"], **TOL)
+
+
+@pytest.mark.parametrize("name", ["swiglu_2d", "swiglu_3d"])
+def test_swiglu(golden, name):
+    g = golden(name)
+    beta = float(g["beta"])
+    np.testing.assert_allclose(O.swiglu_forward(g["X"], beta), g["Y"], **TOL)
+    np.testing.assert_allclose(O.swiglu_backward(g["X"], g["dY"], beta), g["dX"], **TOL)
+
+
+@pytest.mark.parametrize("name", ["softmax_last", "softmax_axis1_4d", "softmax_axis1_2d"])
+def test_softmax(golden, name):
+    g = golden(name)
+    ax = int(g["axis"])
+    y = O.softmax_forward(g["X"], ax)
+    np.testing.assert_allclose(y, g["Y"], **TOL)
+    np.testing.assert_allclose(O.softmax_backward(y, g["dY"], ax), g["dX"], **TOL)
+
+
+@pytest.mark.parametrize("name", ["ce_mean", "ce_sum", "ce_none", "ce_mean_ign", "ce_sum_ign",
+                                  "ce_none_ign", "ce_mean_pad0", "ce_mean_small"])
+def test_cross_entropy(golden, name):
+    g = golden(name)
+    loss, dl = O.cross_entropy_forward_backward(g["logits"], g["labels"], None, int(g["ignore_index"]),
+                                                str(g["reduction"]))
+    np.testing.assert_allclose(np.reshape(loss, g["loss"].shape), g["loss"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(dl, g["dlogits"], rtol=1e-5, atol=1e-7)
+    ign = g["labels"] == int(g["ignore_index"])
+    assert np.all(dl[ign] == 0)
+
+
+@pytest.mark.parametrize("name", ["rmsnorm_2d", "rmsnorm_3d_bias"])
+def test_rmsnorm(golden, name):
+    g = golden(name)
+    b = g.get("b")
+    Y, _, _ = O.rmsnorm_forward(g["X"], g["w"], b, float(g["eps"]))
+    np.testing.assert_allclose(Y, g["Y"], **TOL)
+    dX, dw, db = O.rmsnorm_backward(g["X"], g["w"], b is not None, g["dY"], float(g["eps"]))
+    np.testing.assert_allclose(dX, g["dX"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(dw, g["dw"], rtol=1e-5, atol=1e-5)
+    if b is not None:
+        np.testing.assert_allclose(db, g["db"], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["conv2d_s2p1d2", "conv2d_s2_uncovered", "conv2d_pad4", "conv2d_c5_l1",
+                                  "conv2d_c5_l2"])
+def test_conv2d(golden, name):
+    g = golden(name)
+    st, pad, dil = tuple(g["stride"]), tuple(int(p) for p in g["padding"]), tuple(g["dilation"])
+    geo = O.conv2d_geometry(g["X"].shape[2:], g["W"].shape[2:], st, pad, dil)
+    assert tuple(geo["pad"]) == tuple(g["padding4"])
+    out = O.conv2d_forward(g["X"], g["W"], g["b"], st, pad, dil)
+    assert out.shape == g["O"].shape
+    np.testing.assert_allclose(out, g["O"], rtol=1e-5, atol=1e-5)
+    dX, dW, db = O.conv2d_backward(g["X"], g["W"], True, g["dO"], st, pad, dil)
+    np.testing.assert_allclose(dX, g["dX"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(dW, g["dW"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(db, g["db"], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["adam_wd0", "adam_wd1e-2", "adamw_wd0", "adamw_wd1e-2"])
+def test_adam(golden, name):
+    g = golden(name)
+    fn = O.adamw_step if name.startswith("adamw") else O.adam_step
+    n = int(g["n_tensors"])
+    p = [g[f"p0_{i}"].copy() for i in range(n)]
+    m = [np.zeros_like(a) for a in p]
+    v = [np.zeros_like(a) for a in p]
+    for s in range(3):
+        for i in range(n):
+            m[i], v[i] = fn(p[i], g[f"g{s}_{i}"], m[i], v[i], s + 1, float(g["lr"]), (0.9, 0.999), 1e-8,
+                            float(g["wd"]))
+            np.testing.assert_allclose(p[i], g[f"p{s + 1}_{i}"], rtol=1e-6, atol=1e-7)
+            np.testing.assert_allclose(m[i], g[f"m{s + 1}_{i}"], rtol=1e-6, atol=1e-8)
+            np.testing.assert_allclose(v[i], g[f"v{s + 1}_{i}"], rtol=1e-6, atol=1e-9)
+
+
+def test_linear_swish(golden):
+    g = golden("linear_swish")
+    beta = float(g["beta"])
+    y, _ = O.linear_swish_forward(g["X"], g["W"], g["b"], beta)
+    np.testing.assert_allclose(y, g["Y"], **TOL)
+    dX, dW, db = O.linear_swish_backward(g["X"], g["W"], g["b"], g["dY"], beta)
+    np.testing.assert_allclose(dX, g["dX"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(dW, g["dW"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(db, g["db"], rtol=1e-5, atol=1e-5)
+
+
+def test_mlp_c1_trajectory(golden):
+    """README quick-start loop (C1): losses, argmax (bit-exact), grads and weights after 3 Adam steps."""
+    g = golden("mlp_c1")
+    st = O.MLPState(g["W1"], g["b1"], g["W2"], g["b2"], lr=1e-3)
+    for s in range(3):
+        loss, logits, grads = st.step(g["X"][s], g["Y"][s])
+        assert abs(float(loss) - g["losses"][s]) < 1e-5
+        np.testing.assert_array_equal(np.argmax(logits, axis=1).astype(np.int32), g["argmax"][s])
+        if s == 0:
+            np.testing.assert_allclose(grads[0][::8], g["dW1_step0_rows"], rtol=1e-4, atol=1e-6)
+            np.testing.assert_allclose(grads[1], g["db1_step0"], rtol=1e-4, atol=1e-6)
+            np.testing.assert_allclose(grads[2], g["dW2_step0"], rtol=1e-4, atol=1e-6)
+            np.testing.assert_allclose(grads[3], g["db2_step0"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(st.p[0][::8], g["W1_final_rows"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(st.p[1], g["b1_final"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(st.p[2], g["W2_final"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(st.p[3], g["b2_final"], rtol=1e-5, atol=1e-6)

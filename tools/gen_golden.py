@@ -1,0 +1,280 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REAL reference (imported from /root/reference).
+
+Run in the build container only (the reference never travels to the GPU box):
+
+    python tools/gen_golden.py            # writes tests/golden/*.npz
+
+The reference does `import cupy` unconditionally (neunet/autograd.py:3), so a stub
+package from tools/oracle_stub/ is put on sys.path first.  Every fixture stores explicit
+input arrays AND the reference's outputs/gradients; tests never re-derive inputs from
+RNG state.  Fixtures are data only -- no reference source is copied.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(HERE, "oracle_stub"))
+sys.path.insert(0, "/root/reference")
+
+import neunet  # noqa: E402
+import neunet.nn as nn  # noqa: E402
+from neunet.autograd import Tensor  # noqa: E402
+from neunet.optim import Adam, AdamW  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+F32 = np.float32
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name:28s} {os.path.getsize(path) / 1024:8.1f} KiB")
+
+
+def T(a, **kw):
+    return Tensor(a, **kw)
+
+
+def set_linear(layer, W, b):
+    layer.weight.data[...] = W
+    if b is not None:
+        layer.bias.data[...] = b
+
+
+# --------------------------------------------------------------------------- Linear
+def gen_linear():
+    rng = np.random.default_rng(11)
+    for name, xshape, bias in [("linear_2d", (16, 24), True), ("linear_3d", (4, 6, 24), True),
+                               ("linear_nobias", (16, 24), False)]:
+        X = rng.uniform(-1, 1, xshape).astype(F32)
+        W = rng.uniform(-0.2, 0.2, (40, 24)).astype(F32)
+        b = rng.uniform(-0.2, 0.2, (1, 40)).astype(F32) if bias else None
+        dO = rng.uniform(-1, 1, xshape[:-1] + (40,)).astype(F32)
+        layer = nn.Linear(24, 40, bias=bias)
+        set_linear(layer, W, b)
+        x = T(X)
+        out = layer(x)
+        out.backward(dO)
+        arrs = dict(X=X, W=W, dO=dO, O=out.data, dX=x.grad, dW=layer.weight.grad)
+        if bias:
+            arrs.update(b=b, db=layer.bias.grad)
+        save(name, **arrs)
+
+
+# --------------------------------------------------------------------------- activations
+def gen_activations():
+    rng = np.random.default_rng(12)
+    X = (rng.standard_normal((8, 64)) * 2).astype(F32)
+    dY = rng.standard_normal((8, 64)).astype(F32)
+    x = T(X)
+    y = nn.ReLU()(x)
+    y.backward(dY)
+    save("relu", X=X, dY=dY, Y=y.data, dX=x.grad)
+
+    for beta in (1.0, 1.5):
+        x = T(X)
+        y = nn.Swish(beta)(x)
+        y.backward(dY)
+        save(f"swish_b{beta}", X=X, dY=dY, Y=y.data, dX=x.grad, beta=np.float64(beta))
+
+    # SwiGLU gate: the reference has no CPU class; compose it on the reference tape.
+    for tag, shape, h, beta in [("swiglu_2d", (8, 64), 32, 1.0), ("swiglu_3d", (2, 5, 48), 24, 1.5)]:
+        Xg = rng.standard_normal(shape).astype(F32)
+        dYg = rng.standard_normal(shape[:-1] + (h,)).astype(F32)
+        x = T(Xg)
+        gate = x[..., :h]
+        up = x[..., h:]
+        y = nn.Swish(beta)(gate) * up
+        y.backward(dYg)
+        save(tag, X=Xg, dY=dYg, Y=y.data, dX=x.grad, beta=np.float64(beta))
+
+    for tag, shape, axis in [("softmax_last", (8, 64), -1), ("softmax_axis1_4d", (2, 5, 3, 4), 1),
+                             ("softmax_axis1_2d", (6, 50), 1)]:
+        Xs = (rng.standard_normal(shape) * 3).astype(F32)
+        dYs = rng.standard_normal(shape).astype(F32)
+        x = T(Xs)
+        y = nn.Softmax(axis=axis)(x)
+        y.backward(dYs)
+        save(tag, X=Xs, dY=dYs, Y=y.data, dX=x.grad, axis=np.int64(axis))
+
+
+# --------------------------------------------------------------------------- CrossEntropy
+def gen_ce():
+    rng = np.random.default_rng(13)
+    cases = [("ce_mean", (16, 128), -100, "mean", 0), ("ce_sum", (16, 128), -100, "sum", 0),
+             ("ce_none", (16, 128), -100, "none", 0),
+             ("ce_mean_ign", (16, 128), -100, "mean", 5), ("ce_sum_ign", (16, 128), -100, "sum", 5),
+             ("ce_none_ign", (16, 128), -100, "none", 5),
+             ("ce_mean_pad0", (24, 40), 0, "mean", 7), ("ce_mean_small", (32, 10), -1000, "mean", 0)]
+    for tag, (rows, C), ign, red, n_ign in cases:
+        logits = (rng.standard_normal((rows, C)) * 2).astype(F32)
+        lo = 1 if ign == 0 else 0
+        labels = rng.integers(lo, C, rows).astype(np.int32)
+        if n_ign:
+            labels[rng.choice(rows, n_ign, replace=False)] = ign
+        if tag == "ce_mean_small":
+            # ignore_index out of python-negative-index range would raise only if present; none are.
+            pass
+        x = T(logits)
+        loss_fn = nn.CrossEntropyLoss(ignore_index=ign, reduction=red)
+        loss = loss_fn(x, T(labels, dtype=np.int32, requires_grad=False))
+        loss.backward()
+        save(tag, logits=logits, labels=labels, loss=np.asarray(loss.data), dlogits=x.grad,
+             ignore_index=np.int64(ign), reduction=np.array(red))
+
+
+# --------------------------------------------------------------------------- RMSNorm
+def gen_rmsnorm():
+    rng = np.random.default_rng(14)
+    for tag, shape, bias in [("rmsnorm_2d", (8, 64), False), ("rmsnorm_3d_bias", (2, 4, 64), True)]:
+        X = rng.standard_normal(shape).astype(F32)
+        w = rng.uniform(0.5, 1.5, shape[-1]).astype(F32)
+        b = rng.uniform(-0.5, 0.5, shape[-1]).astype(F32) if bias else None
+        dY = rng.standard_normal(shape).astype(F32)
+        layer = nn.RMSNorm(shape[-1], eps=1e-6, bias=bias)
+        layer.weight.data[...] = w
+        if bias:
+            layer.bias.data[...] = b
+        x = T(X)
+        y = layer(x)
+        y.backward(dY)
+        arrs = dict(X=X, w=w, dY=dY, Y=y.data, dX=x.grad, dw=layer.weight.grad, eps=np.float64(1e-6))
+        if bias:
+            arrs.update(b=b, db=layer.bias.grad)
+        save(tag, **arrs)
+
+
+# --------------------------------------------------------------------------- Conv2d
+def gen_conv():
+    rng = np.random.default_rng(15)
+    cases = [
+        ("conv2d_s2p1d2", (2, 3, 9, 9), 4, 3, (2, 2), (1, 1), (2, 2)),
+        ("conv2d_s2_uncovered", (2, 2, 8, 7), 3, (3, 2), (2, 3), (0, 1), (1, 1)),
+        # string paddings ("same"/"valid") are unreachable in the reference: __init__ wraps a str
+        # into a 2-tuple (conv2d.py:164) so build() never sees the bare string -> TypeError.
+        ("conv2d_pad4", (1, 2, 6, 6), 3, 3, (1, 1), (1, 2, 0, 1), (1, 1)),
+        ("conv2d_c5_l1", (2, 1, 28, 28), 8, 3, (1, 1), (1, 1), (1, 1)),
+        ("conv2d_c5_l2", (2, 8, 14, 14), 16, 3, (1, 1), (1, 1), (1, 1)),
+    ]
+    for tag, xshape, cout, ks, stride, pad, dil in cases:
+        X = rng.uniform(-1, 1, xshape).astype(F32)
+        layer = nn.Conv2d(xshape[1], cout, ks, stride, pad, dil)
+        W = layer.weight.data.copy()
+        b = rng.uniform(-0.3, 0.3, cout).astype(F32)
+        layer.bias.data[...] = b
+        x = T(X)
+        y = layer(x)
+        dO = rng.uniform(-1, 1, y.shape).astype(F32)
+        y.backward(dO)
+        pad_arr = np.array(pad)
+        save(tag, X=X, W=W, b=b, dO=dO, O=y.data, dX=x.grad, dW=layer.weight.grad, db=layer.bias.grad,
+             stride=np.array(stride), padding=pad_arr, dilation=np.array(dil),
+             padding4=np.array(layer.padding))
+
+
+# --------------------------------------------------------------------------- Adam / AdamW
+def gen_adam():
+    rng = np.random.default_rng(16)
+    shapes = [(8, 16), (1, 16), (5,)]
+    for tag, cls, wd in [("adam_wd0", Adam, 0.0), ("adam_wd1e-2", Adam, 1e-2),
+                         ("adamw_wd0", AdamW, 0.0), ("adamw_wd1e-2", AdamW, 1e-2)]:
+        params = [nn.Parameter(T(rng.standard_normal(s).astype(F32))) for s in shapes]
+        p0 = [p.data.copy() for p in params]
+        opt = cls(params, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=wd)
+        grads, ps, ms, vs = [], [], [], []
+        for step in range(3):
+            gs = [rng.standard_normal(s).astype(F32) for s in shapes]
+            for p, g in zip(params, gs):
+                p.grad = g
+            opt.step()
+            grads.append(gs)
+            ps.append([p.data.copy() for p in params])
+            ms.append([m.copy() for m in opt.m])
+            vs.append([v.copy() for v in opt.v])
+        arrs = {"wd": np.float64(wd), "lr": np.float64(1e-2), "n_tensors": np.int64(len(shapes))}
+        for i in range(len(shapes)):
+            arrs[f"p0_{i}"] = p0[i]
+            for s in range(3):
+                arrs[f"g{s}_{i}"] = grads[s][i]
+                arrs[f"p{s + 1}_{i}"] = ps[s][i]
+                arrs[f"m{s + 1}_{i}"] = ms[s][i]
+                arrs[f"v{s + 1}_{i}"] = vs[s][i]
+        save(tag, **arrs)
+
+
+# --------------------------------------------------------------------------- Linear->Swish
+def gen_linear_swish():
+    rng = np.random.default_rng(17)
+    X = rng.uniform(-1, 1, (16, 24)).astype(F32)
+    W = rng.uniform(-0.4, 0.4, (40, 24)).astype(F32)
+    b = rng.uniform(-0.4, 0.4, (1, 40)).astype(F32)
+    dY = rng.uniform(-1, 1, (16, 40)).astype(F32)
+    layer = nn.Linear(24, 40)
+    set_linear(layer, W, b)
+    x = T(X)
+    y = nn.Swish(1.5)(layer(x))
+    y.backward(dY)
+    save("linear_swish", X=X, W=W, b=b, dY=dY, Y=y.data, dX=x.grad, dW=layer.weight.grad,
+         db=layer.bias.grad, beta=np.float64(1.5))
+
+
+# --------------------------------------------------------------------------- C1 MLP trajectory
+def gen_mlp():
+    """README.md:57-71 quick-start loop: 784->128->10, CE(mean), Adam(lr 1e-3), batch 32, 3 steps."""
+    rng = np.random.default_rng(1001)
+
+    class MLP(nn.Module):
+        def __init__(self):
+            self.l1 = nn.Linear(784, 128)
+            self.relu = nn.ReLU()
+            self.l2 = nn.Linear(128, 10)
+
+        def forward(self, x):
+            return self.l2(self.relu(self.l1(x)))
+
+    W1 = rng.uniform(-1 / 28, 1 / 28, (128, 784)).astype(F32)
+    b1 = rng.uniform(-1 / 28, 1 / 28, (1, 128)).astype(F32)
+    s2 = 1 / np.sqrt(128)
+    W2 = rng.uniform(-s2, s2, (10, 128)).astype(F32)
+    b2 = rng.uniform(-s2, s2, (1, 10)).astype(F32)
+    model = MLP()
+    set_linear(model.l1, W1, b1)
+    set_linear(model.l2, W2, b2)
+    opt = Adam(model.parameters(), lr=1e-3)
+    loss_fn = nn.CrossEntropyLoss()
+    X = rng.uniform(-1, 1, (3, 32, 784)).astype(F32)
+    Y = rng.integers(0, 10, (3, 32)).astype(np.int32)
+    losses, argmaxes, first_grads = [], [], None
+    for s in range(3):
+        opt.zero_grad()
+        out = model(T(X[s]))
+        loss = loss_fn(out, T(Y[s], dtype=np.int32, requires_grad=False))
+        loss.backward()
+        if s == 0:
+            first_grads = [p.grad.copy() for p in model.parameters()]
+        opt.step()
+        losses.append(float(loss.data))
+        argmaxes.append(np.asarray(neunet.argmax(out, axis=1).data))
+    Wf = model.l1.weight.data
+    save("mlp_c1", W1=W1, b1=b1, W2=W2, b2=b2, X=X, Y=Y,
+         losses=np.array(losses, dtype=np.float64), argmax=np.stack(argmaxes).astype(np.int32),
+         W1_final_rows=Wf[::8].copy(), W1_final_sum=np.float64(Wf.astype(np.float64).sum()),
+         b1_final=model.l1.bias.data, W2_final=model.l2.weight.data, b2_final=model.l2.bias.data,
+         dW1_step0_rows=first_grads[0][::8].copy(), db1_step0=first_grads[1],
+         dW2_step0=first_grads[2], db2_step0=first_grads[3])
+
+
+if __name__ == "__main__":
+    gen_linear()
+    gen_activations()
+    gen_ce()
+    gen_rmsnorm()
+    gen_conv()
+    gen_adam()
+    gen_linear_swish()
+    gen_mlp()
