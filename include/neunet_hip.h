@@ -1,0 +1,187 @@
+/* neunet_hip.h -- C ABI of libneunet_hip.so: the MI355X (gfx950) drop-in for the CUDA .so files
+ * that neunet's experimental layer binds through ctypes (reference:
+ * neunet/nn/experimental/utils.py:64-92 -- ctypes.CDLL + getattr + argtypes).
+ *
+ * Conventions (differences from the reference's exports are deliberate and listed here):
+ *   - every entry point returns int: 0 = ok, >0 = hipError_t, <0 = NNHIP_E* argument error
+ *     (the reference returns void and printf+exit()s on failure, e.g.
+ *     linear_cublaslt_no_manual_mem.cu:91-94,117-120; cross_entropy.cu:287-291);
+ *   - every launch takes an explicit stream (hipStream_t passed as void*) as its LAST argument
+ *     (the reference's Linear and CrossEntropy exports implicitly use stream 0);
+ *   - sizes are int64_t (the reference mixes int / size_t: linear.py:46-48 vs .cu:114);
+ *   - all tensor pointers are DEVICE pointers to C-contiguous fp32 (labels: int32); the caller owns
+ *     and pre-allocates every buffer (reference: utils.py:72-82, `xp.empty` before each call);
+ *     optional pointers may be NULL where noted;
+ *   - argument ORDER and MEANING follow the reference export each function replaces (cited).
+ * The library never synchronises the device inside a compute entry point.
+ */
+#ifndef NEUNET_HIP_H
+#define NEUNET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* nnhipStream_t; /* hipStream_t */
+
+#define NNHIP_OK 0
+#define NNHIP_EINVAL (-1)   /* bad argument (null pointer, negative size, bad enum) */
+#define NNHIP_EALIGN (-2)   /* pointer not 4-byte aligned */
+#define NNHIP_ENOMEM (-3)   /* workspace allocation failed */
+
+/* ---- library ------------------------------------------------------------------------------ */
+int nnhipVersion(void);
+/* Human-readable text for the last non-zero status returned on the calling thread. */
+const char* nnhipGetLastErrorString(void);
+/* Free the grow-only device workspace (split-K slabs, column-sum partials).
+ * Replaces cleanupCudaMemory() (linear_cublaslt_no_manual_mem.cu:186, linear_cutlass.cu:107,
+ * linear_swish_cutlass_evt_full.cu:820).  Synchronises the device. */
+int nnhipCleanup(void);
+
+/* ---- a1/a2 Linear  (replaces cudaLinearModuleForward/Backward,
+ *      linear_cublaslt_no_manual_mem.cu:114,142 and linear_cutlass.cu:40,67) ------------------ */
+/* O[rows,out] = X[rows,in] * W[out,in]^T + b[out]      (b may be NULL) */
+int nnhipLinearModuleForward(const float* X, const float* W, const float* b, float* O,
+                             int64_t rows, int64_t in_features, int64_t out_features,
+                             nnhipStream_t stream);
+/* dX[rows,in] = dO*W ; dW[out,in] = dO^T*X ; db[out] = sum_rows dO.  Any of dX/dW/db may be NULL
+ * (skipped). */
+int nnhipLinearModuleBackward(const float* X, const float* W, const float* dO, float* dX,
+                              float* dW, float* db, int64_t rows, int64_t in_features,
+                              int64_t out_features, nnhipStream_t stream);
+
+/* ---- a6 fused Linear -> Swish  (replaces cudaLinearSwishForward/Backward,
+ *      linear_swish_cutlass_evt_full.cu:558-570, 680-695) ------------------------------------- */
+/* z = X*W^T + b ; O = z*sigmoid(beta*z).  If save_preactivation != 0, z is also written to
+ * `preact` (must be non-NULL then). */
+int nnhipLinearSwishForward(const float* X, const float* W, const float* b, float* O, float* preact,
+                            int64_t M, int64_t K, int64_t N, float swish_beta,
+                            int save_preactivation, nnhipStream_t stream);
+/* tmp[M,N]: if recompute_preactivation == 0 it holds z on entry (saved by the forward); otherwise
+ * it is scratch and z is recomputed into it.  On exit tmp holds dZ (reference in-place contract,
+ * ...evt_full.cu:707-711).  dX/dW/db may be NULL. */
+int nnhipLinearSwishBackward(const float* X, const float* W, const float* b, const float* dO,
+                             float* tmp, float* dX, float* dW, float* db, int64_t M, int64_t K,
+                             int64_t N, float swish_beta, int recompute_preactivation,
+                             nnhipStream_t stream);
+
+/* ---- general fp32 MFMA GEMM (net-new; used by the entries above and by the batched matmul of
+ *      SURVEY 8f-1, neunet/autograd.py:192-230) -------------------------------------------------
+ * C[b] (M x N, row-major, ldc) = op(A[b]) * op(B[b]) (+ bias[N]) ;  b = 0..batch-1.
+ *   a_kmajor != 0: A element (m,k) at A[m*lda + k]   (reduction dim contiguous)
+ *   a_kmajor == 0: A element (m,k) at A[k*lda + m]
+ *   b_kmajor != 0: B element (k,n) at B[n*ldb + k]
+ *   b_kmajor == 0: B element (k,n) at B[k*ldb + n]
+ * strideA/B/C: element offsets between consecutive batches (0 = shared operand). */
+int nnhipGemmF32(const float* A, const float* B, float* C, const float* bias, int64_t M, int64_t N,
+                 int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int a_kmajor, int b_kmajor,
+                 int64_t batch, int64_t strideA, int64_t strideB, int64_t strideC,
+                 nnhipStream_t stream);
+
+/* ---- a12 ReLU (net-new export; reference CPU: neunet/nn/activations.py:40-59) --------------- */
+int nnhipReLUForward(float* out, const float* in, int64_t size, nnhipStream_t stream);
+/* dIn = dOut * (out > 0), `out` = forward output */
+int nnhipReLUBackward(float* dIn, const float* dOut, const float* out, int64_t size,
+                      nnhipStream_t stream);
+
+/* ---- a5 Swish  (replaces cudaSwishForward/Backward, swish.cu:50,65) ------------------------- */
+int nnhipSwishForward(float* out, const float* in, float beta, int64_t size, nnhipStream_t stream);
+int nnhipSwishBackward(float* dIn, const float* dOut, const float* in, float beta, int64_t size,
+                       nnhipStream_t stream);
+
+/* ---- a7 fused Swish-and-mul / SwiGLU gate  (replaces cudaFusedSwishAndMul[Backward],
+ *      fused_swish_and_mul.cu:60,76).  in rows = [gate(hidden), up(hidden)], size = #OUTPUT elems */
+int nnhipFusedSwishAndMul(float* out, const float* in, float beta, int64_t hidden, int64_t size,
+                          nnhipStream_t stream);
+int nnhipFusedSwishAndMulBackward(float* dIn, const float* dOut, const float* in, float beta,
+                                  int64_t hidden, int64_t size, nnhipStream_t stream);
+
+/* ---- a8 Softmax  (replaces cudaSoftmaxForward/Backward, softmax.cu:144,229).
+ *      Slice s = outer*stride + inner starts at element outer*slice_size*stride + inner; its
+ *      slice_size elements are `stride` apart (stride == 1: softmax over contiguous rows). */
+int nnhipSoftmaxForward(float* out, const float* in, int64_t num_slices, int64_t slice_size,
+                        int64_t stride, nnhipStream_t stream);
+int nnhipSoftmaxBackward(float* dX, const float* dY, const float* Y, int64_t num_slices,
+                         int64_t slice_size, int64_t stride, nnhipStream_t stream);
+
+/* ---- a9 fused CrossEntropy forward+backward  (replaces cudaCrossEntropyForwardBackward,
+ *      cross_entropy.cu:249-260).
+ *   logits [n_rows, logits_stride]; loss[n_rows], lse[n_rows] outputs; labels int32.
+ *   reduction 'n' | 'm' | 's'.  Gradient scale for 'm' = 1/n_non_ignore, taken from the int
+ *   argument, or -- if n_non_ignore_dev != NULL -- read from that device int (no host sync).
+ *   dlogits: where to write (softmax - onehot)*scale.  NULL = in place over `logits`
+ *   (the reference's behaviour, cross_entropy.cu:211); rows with label == ignore_index get zero
+ *   gradient and zero loss.  dlogits has the same row stride as logits. */
+int nnhipCrossEntropyForwardBackward(float* logits, float* loss, float* lse, const int32_t* labels,
+                                     int64_t logits_stride, int32_t ignore_index, int64_t n_rows,
+                                     int64_t n_cols, char reduction, int64_t n_non_ignore,
+                                     const int32_t* n_non_ignore_dev, float* dlogits,
+                                     nnhipStream_t stream);
+/* out_count[0] = #{i : labels[i] != ignore_index}   (device scalar; replaces the host-side
+ * cp.sum(labels != ignore_index).item() of cross_entropy.py:72) */
+int nnhipCountNotEqual(const int32_t* labels, int64_t n, int32_t ignore_index, int32_t* out_count,
+                       nnhipStream_t stream);
+/* out[0] = sum(loss_rows) ('s'), or sum/count ('m', count from count_dev) -- the device-side
+ * reduction cross_entropy.py:98-101 does with cupy. */
+int nnhipReduceLoss(const float* loss_rows, int64_t n_rows, char reduction,
+                    const int32_t* count_dev, float* out, nnhipStream_t stream);
+
+/* ---- a10 RMSNorm  (replaces RMSNormForward/Backward, rmsnorm.cu:116-140, 282-308) ---------- */
+/* X_std[rows] = sqrt(mean(x^2)+eps) always written.  X_norm[rows,cols] may be NULL (not stored;
+ * the backward recomputes it) -- the reference always stores it. */
+int nnhipRMSNormForward(const float* X, const float* weight, const float* bias_or_null, float* Y,
+                        float* X_std, float* X_norm_or_null, int64_t rows, int64_t cols, float eps,
+                        nnhipStream_t stream);
+/* X_norm is accepted for signature parity and ignored (recomputed from X and X_std). */
+int nnhipRMSNormBackward(const float* dY, const float* X, const float* weight, const float* X_std,
+                         const float* X_norm_unused, float* dX, float* dW, float* db_or_null,
+                         int64_t rows, int64_t cols, nnhipStream_t stream);
+
+/* ---- a11 fused AdamW  (replaces FusedAdamWStep, fused_adamw.cu:58-71 -- one tensor) --------- */
+/* decay_mode 0: decoupled weight decay (AdamW, neunet/optim.py:52-69);
+ * decay_mode 1: L2 decay folded into the gradient (Adam, neunet/optim.py:17-33).
+ * grad_scale multiplies g on load (1.0 = reference behaviour; 1/world after a DP sum-all-reduce).
+ * Bias corrections 1-beta^step are computed on the host in double (as the CPU path does). */
+int nnhipFusedAdamWStep(float* p, const float* g, float* m, float* v, float lr, float beta1,
+                        float beta2, float eps, float weight_decay, int32_t step, int64_t n,
+                        int32_t decay_mode, float grad_scale, nnhipStream_t stream);
+
+/* ---- a11 multi-tensor AdamW  (replaces CreateFusedOptimizer / DestroyFusedOptimizer /
+ *      FusedAdamWStep(void*,...), fused_adamw_multitensor.cu:308-333) -------------------------- */
+void* nnhipCreateFusedOptimizer(void);
+int nnhipDestroyFusedOptimizer(void* opt);
+/* p/g/m/v: HOST arrays of n_tensors DEVICE pointers; sizes: HOST array of element counts.
+ * One kernel launch for all tensors.  Tables are re-uploaded only when they changed. */
+int nnhipFusedAdamWMultiTensorStep(void* opt, int32_t n_tensors, float* const* p,
+                                   const float* const* g, float* const* m, float* const* v,
+                                   const int64_t* sizes, float lr, float beta1, float beta2,
+                                   float eps, float weight_decay, int32_t step, int32_t decay_mode,
+                                   float grad_scale, nnhipStream_t stream);
+
+/* ---- a3/a4 Conv2d  (net-new exports; reference CPU: neunet/nn/layers/conv2d.py:297-355, 16-115)
+ *   X [B,Cin,H,W], W [Cout,Cin,kh,kw], bias [Cout] or NULL, O [B,Cout,Ho,Wo]; NCHW fp32.
+ *   pad = (up, down, left, right) as Conv2d.build resolves it (conv2d.py:237-243);
+ *   Ho = (H+pu+pd-dh*(kh-1)-1)/sh+1 (conv2d.py:245-258), likewise Wo. */
+typedef struct nnhipConv2dDesc {
+    int64_t B, Cin, H, W, Cout, kh, kw;
+    int64_t sh, sw, dh, dw;
+    int64_t pu, pd, pl, pr;
+} nnhipConv2dDesc;
+int nnhipConv2dForward(const float* X, const float* W, const float* bias, float* O,
+                       const nnhipConv2dDesc* d, nnhipStream_t stream);
+/* dX/dW/db may be NULL (skipped). */
+int nnhipConv2dBackward(const float* X, const float* W, const float* dO, float* dX, float* dW,
+                        float* db, const nnhipConv2dDesc* d, nnhipStream_t stream);
+
+/* ---- gradient-bucket helpers for data-parallel training (net-new) ---------------- */
+/* x[i] *= alpha */
+int nnhipScale(float* x, float alpha, int64_t n, nnhipStream_t stream);
+/* out[i] = a[i] + b[i]   (Tensor.apply_grad accumulation, neunet/autograd.py:85-93) */
+int nnhipAdd(float* out, const float* a, const float* b, int64_t n, nnhipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEUNET_HIP_H */

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Build libneunet_hip.so (gfx950) in-tree with hipcc.
+
+    python numpy-nn-model_amd/build.py [--force] [--debug]
+
+hipcc cross-compiles without a GPU.  The .so lands in numpy-nn-model_amd/neunet_hip/lib/ (git-ignored,
+but it travels with the repo snapshot to the GPU box).  Objects are cached under csrc/build/ and
+rebuilt when a source or header is newer.
+"""
+import argparse
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
+LIBDIR = os.path.join(HERE, "neunet_hip", "lib")
+LIB = os.path.join(LIBDIR, "libneunet_hip.so")
+SOURCES = ["runtime.hip", "gemm.hip", "elementwise.hip", "rowops.hip", "optim.hip", "linear.hip", "conv2d.hip"]
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(HERE), "include", "neunet_hip.h")]
+ARCH = "gfx950"
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def newer(a, b):
+    return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
+
+
+def build(force=False, debug=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(LIBDIR, exist_ok=True)
+    cc = hipcc()
+    flags = [f"--offload-arch={ARCH}", "-std=c++17", "-fPIC", "-O3", "-Wall", "-Wno-unused-function"]
+    if debug:
+        flags += ["-g", "-save-temps=obj"]
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    jobs = []
+    for s in srcs:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(OBJ, s.replace(".hip", ".o"))
+        stale = force or newer(src, obj) or any(newer(h, obj) for h in HEADERS) or newer(__file__, obj)
+        jobs.append((src, obj, stale))
+
+    def compile_one(job):
+        src, obj, stale = job
+        if not stale:
+            return obj
+        cmd = [cc, *flags, "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+        objs = list(ex.map(compile_one, jobs))
+    if force or any(j[2] for j in jobs) or not os.path.exists(LIB):
+        cmd = [cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB, *objs]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--debug", action="store_true")
+    a = ap.parse_args()
+    print(build(a.force, a.debug))

@@ -1,0 +1,82 @@
+// common.h -- shared host/device helpers for libneunet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/neunet_hip.h"
+
+namespace nnhip {
+
+constexpr int kWave = 64;  // CDNA wavefront
+
+// ---- status plumbing ---------------------------------------------------------------------------
+void set_last_error(const char* fmt, ...);
+int hip_status(hipError_t e, const char* what);
+
+#define NNHIP_CHECK_ARG(cond, code, ...)      \
+    do {                                       \
+        if (!(cond)) {                         \
+            nnhip::set_last_error(__VA_ARGS__); \
+            return (code);                     \
+        }                                      \
+    } while (0)
+
+// Launch check: catches bad launch configuration without synchronising.
+#define NNHIP_LAUNCH_CHECK(name)                          \
+    do {                                                  \
+        hipError_t _e = hipGetLastError();                \
+        if (_e != hipSuccess) return nnhip::hip_status(_e, name); \
+    } while (0)
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline bool aligned4(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 3u) == 0; }
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Grow-only per-process device workspace (split-K slabs, column-sum partials).  Freed by
+// nnhipCleanup().  Growing it synchronises the device (hipFree) -- it happens at most a few times.
+void* workspace(size_t bytes);
+
+// ---- device helpers ----------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Block-wide sum for blockDim.x = NW*64 threads.  `red` is NW floats of LDS.  All threads get the sum.
+template <int NW>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    if constexpr (NW == 1) return v;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();  // protect `red` against a previous use
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) s += red[i];
+    return s;
+}
+template <int NW>
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    if constexpr (NW == 1) return v;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float s = red[0];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) s = fmaxf(s, red[i]);
+    return s;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+}  // namespace nnhip

@@ -1,0 +1,352 @@
+// conv2d.hip -- Conv2d forward / backward as implicit GEMM on fp32 MFMA (gfx950).
+// CPU semantics: neunet/nn/layers/conv2d.py:297-355 (forward: zero-pad, dilate W, 6-D strided view,
+// einsum "bihwkl,oikl->bohw") and :16-115 (backward: dW / db / dX einsums).  No im2col buffer ever
+// exists in HBM: the B operand of each GEMM is gathered from the NCHW tensor straight into LDS.
+//
+//   forward : O[b,co,ho,wo]  = sum_{ci,r,s} W[co,ci,r,s] * X[b,ci, ho*sh-pu+r*dh, wo*sw-pl+s*dw] + bias[co]
+//             GEMM  M = Cout, K = Cin*kh*kw, N = B*Ho*Wo      (A = W, k-major;  B = gathered X)
+//   dgrad   : dX[b,ci,h,w]   = sum_{co,r,s} W[co,ci,r,s] * dO[b,co,(h+pu-r*dh)/sh,(w+pl-s*dw)/sw]
+//             (terms exist only where the divisions are exact and in range)
+//             GEMM  M = Cin,  K = Cout*kh*kw, N = B*H*W        (A = gathered W;  B = gathered dO)
+//   wgrad   : dW[co,(ci,r,s)] = sum_{b,ho,wo} dO[b,co,ho,wo] * X[b,ci,ho*sh-pu+r*dh, wo*sw-pl+s*dw]
+//             GEMM  M = Cout, N = Cin*kh*kw (+1), K = B*Ho*Wo  -- long reduction, tiny output:
+//             split over K-chunks (one per block), deterministic partials + reduce kernel.
+//             db[co] = sum dO is the same GEMM against an extra all-ones column (column N).
+//
+// Tiles: M-tile 32 (one 32x32x2 MFMA row tile; Cout/Cin > 32 loop over blockIdx.y).  At the C5 shapes
+// (K = 9/72, Cout = 8/16) these kernels are HBM/latency bound, not MFMA bound -- the MFMA
+// just keeps the FMA work off the VALU while the waves gather.
+#include "common.h"
+
+namespace nnhip {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvGeom {
+    int B, Cin, H, W, Cout, kh, kw, sh, sw, dh, dw, pu, pl, Ho, Wo;
+};
+
+// =================================================================================================
+// forward / dgrad
+// =================================================================================================
+constexpr int CF_BK = 16;
+constexpr int CF_BN = 256;
+
+template <bool DGRAD>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict__ Wt,
+                                                         const float* __restrict__ Src,
+                                                         const float* __restrict__ bias,
+                                                         float* __restrict__ Dst, const ConvGeom g) {
+    __shared__ __attribute__((aligned(16))) float As[32 * (CF_BK + 4)];
+    __shared__ __attribute__((aligned(16))) float Bs[CF_BK * CF_BN];
+
+    const int khkw = g.kh * g.kw;
+    const int M = DGRAD ? g.Cin : g.Cout;
+    const int Cs = DGRAD ? g.Cout : g.Cin;          // source channels (reduction)
+    const int Hs = DGRAD ? g.Ho : g.H, Ws = DGRAD ? g.Wo : g.W;
+    const int Hd = DGRAD ? g.H : g.Ho, Wd = DGRAD ? g.W : g.Wo;
+    const int K = Cs * khkw;
+    const int64_t HWd = (int64_t)Hd * Wd, HWs = (int64_t)Hs * Ws;
+    const int64_t N = (int64_t)g.B * HWd;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int m0 = blockIdx.y * 32;
+
+    // this thread gathers column n = blockIdx.x*256 + tid for every k of the tile
+    const int64_t n = (int64_t)blockIdx.x * CF_BN + tid;
+    const bool n_ok = n < N;
+    int b = 0, yd = 0, xd = 0;
+    if (n_ok) {
+        b = (int)(n / HWd);
+        const int rem = (int)(n - (int64_t)b * HWd);
+        yd = rem / Wd;
+        xd = rem - yd * Wd;
+    }
+    const float* src_b = Src + (int64_t)b * Cs * HWs;
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    for (int k0 = 0; k0 < K; k0 += CF_BK) {
+        // ---- A tile: 32 x 16 weights (2 per thread) ----------------------------------------------
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int idx = tid + 256 * p;
+            const int m = idx / CF_BK, kk = idx % CF_BK;
+            const int k = k0 + kk;
+            float v = 0.f;
+            if (m0 + m < M && k < K) {
+                if constexpr (DGRAD) {
+                    const int co = k / khkw, rs = k - co * khkw;
+                    v = Wt[((int64_t)co * g.Cin + (m0 + m)) * khkw + rs];
+                } else {
+                    v = Wt[(int64_t)(m0 + m) * K + k];
+                }
+            }
+            As[m * (CF_BK + 4) + kk] = v;
+        }
+        // ---- B tile: 16 x 256 gathered source pixels (16 per thread, k uniform per step) ----------
+#pragma unroll
+        for (int kk = 0; kk < CF_BK; ++kk) {
+            const int k = k0 + kk;
+            float v = 0.f;
+            if (n_ok && k < K) {
+                const int cs = k / khkw, rs = k - cs * khkw;
+                const int r = rs / g.kw, s = rs - r * g.kw;
+                int ys, xs;
+                bool ok;
+                if constexpr (DGRAD) {
+                    const int ty = yd + g.pu - r * g.dh, tx = xd + g.pl - s * g.dw;
+                    ys = ty / g.sh;
+                    xs = tx / g.sw;
+                    ok = ty >= 0 && tx >= 0 && ys * g.sh == ty && xs * g.sw == tx && ys < Hs && xs < Ws;
+                } else {
+                    ys = yd * g.sh - g.pu + r * g.dh;
+                    xs = xd * g.sw - g.pl + s * g.dw;
+                    ok = ys >= 0 && ys < Hs && xs >= 0 && xs < Ws;
+                }
+                if (ok) v = src_b[(int64_t)cs * HWs + (int64_t)ys * Ws + xs];
+            }
+            Bs[kk * CF_BN + tid] = v;
+        }
+        __syncthreads();
+        // ---- MFMA: wave w owns columns [w*64, w*64+64) = 2 n-tiles ----------------------------------
+#pragma unroll
+        for (int gq = 0; gq < CF_BK / 8; ++gq) {
+            const float4 av = *reinterpret_cast<const float4*>(&As[l31 * (CF_BK + 4) + gq * 8 + lh * 4]);
+            const float a[4] = {av.x, av.y, av.z, av.w};
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float bv = Bs[(gq * 8 + j + 4 * lh) * CF_BN + wave * 64 + nt * 32 + l31];
+                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bv, acc[nt], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: acc[nt][e] -> row m = (e&3)+8*(e>>2)+4*lh, column l31 of n-tile nt ------------------
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int64_t nn = (int64_t)blockIdx.x * CF_BN + wave * 64 + nt * 32 + l31;
+        if (nn >= N) continue;
+        const int bb = (int)(nn / HWd);
+        const int64_t sp = nn - (int64_t)bb * HWd;
+        float* dst = Dst + (int64_t)bb * M * HWd + sp;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = m0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            if (m < M) {
+                float v = acc[nt][e];
+                if (!DGRAD && bias) v += bias[m];
+                dst[(int64_t)m * HWd] = v;
+            }
+        }
+    }
+}
+
+// =================================================================================================
+// wgrad (+ db through an all-ones column)
+// =================================================================================================
+constexpr int CW_BK = 32;
+constexpr int CW_BN = 128;  // 4 n-tiles, one per wave
+
+struct ColInfo {
+    int ci, dy, dx, kind;  // kind: 0 = gather column, 1 = all-ones column (db), 2 = padding (zero)
+};
+
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict__ X,
+                                                         const float* __restrict__ dO,
+                                                         float* __restrict__ part, const ConvGeom g,
+                                                         int64_t k_per_block, int ncols) {
+    __shared__ __attribute__((aligned(16))) float As[32 * (CW_BK + 4)];
+    __shared__ __attribute__((aligned(16))) float Bs[CW_BN * (CW_BK + 4)];
+    __shared__ ColInfo tab[CW_BN];
+
+    const int khkw = g.kh * g.kw;
+    const int Nw = g.Cin * khkw;  // real dW columns; column Nw is the ones column
+    const int64_t HWo = (int64_t)g.Ho * g.Wo, HW = (int64_t)g.H * g.W;
+    const int64_t K = (int64_t)g.B * HWo;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int m0 = blockIdx.y * 32, n0 = blockIdx.z * CW_BN;
+
+    if (tid < CW_BN) {
+        const int n = n0 + tid;
+        ColInfo c;
+        if (n < Nw) {
+            const int ci = n / khkw, rs = n - ci * khkw;
+            const int r = rs / g.kw, s = rs - r * g.kw;
+            c.ci = ci; c.dy = r * g.dh - g.pu; c.dx = s * g.dw - g.pl; c.kind = 0;
+        } else {
+            c.ci = 0; c.dy = 0; c.dx = 0; c.kind = (n == Nw) ? 1 : 2;
+        }
+        tab[tid] = c;
+    }
+    __syncthreads();
+
+    const bool wave_active = n0 + wave * 32 < ncols;  // wave-uniform: does my n-tile hold any column?
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+
+    const int64_t kbeg = (int64_t)blockIdx.x * k_per_block;
+    const int64_t kend = min(K, kbeg + k_per_block);
+    const int kk = tid & 31, rg = tid >> 5;  // thread <-> position kk of the k-step, row group rg (0..7)
+
+    for (int64_t k0 = kbeg; k0 < kend; k0 += CW_BK) {
+        const int64_t k = k0 + kk;
+        const bool k_ok = k < kend;
+        int b = 0, ho = 0, wo = 0;
+        if (k_ok) {
+            b = (int)(k / HWo);
+            const int rem = (int)(k - (int64_t)b * HWo);
+            ho = rem / g.Wo;
+            wo = rem - ho * g.Wo;
+        }
+        // A tile: dO[b, m0+m, ho, wo], rows m = rg + 8 i
+        const float* dO_b = dO + (int64_t)b * g.Cout * HWo + (int64_t)ho * g.Wo + wo;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = rg + 8 * i;
+            As[m * (CW_BK + 4) + kk] = (k_ok && m0 + m < g.Cout) ? dO_b[(int64_t)(m0 + m) * HWo] : 0.f;
+        }
+        // B tile: gathered X, columns c = rg + 8 i
+        const float* X_b = X + (int64_t)b * g.Cin * HW;
+        const int y0 = ho * g.sh, x0 = wo * g.sw;
+#pragma unroll
+        for (int i = 0; i < CW_BN / 8; ++i) {
+            const int c = rg + 8 * i;
+            const ColInfo ci = tab[c];
+            float v = 0.f;
+            if (k_ok) {
+                if (ci.kind == 0) {
+                    const int ys = y0 + ci.dy, xs = x0 + ci.dx;
+                    if (ys >= 0 && ys < g.H && xs >= 0 && xs < g.W) v = X_b[(int64_t)ci.ci * HW + (int64_t)ys * g.W + xs];
+                } else if (ci.kind == 1) {
+                    v = 1.f;
+                }
+            }
+            Bs[c * (CW_BK + 4) + kk] = v;
+        }
+        __syncthreads();
+        if (wave_active) {
+#pragma unroll
+            for (int gq = 0; gq < CW_BK / 8; ++gq) {
+                const float4 av = *reinterpret_cast<const float4*>(&As[l31 * (CW_BK + 4) + gq * 8 + lh * 4]);
+                const float4 bv = *reinterpret_cast<const float4*>(&Bs[(wave * 32 + l31) * (CW_BK + 4) + gq * 8 + lh * 4]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // partial tile -> part[chunk][Cout][ncols]
+    if (wave_active) {
+        const int n = n0 + wave * 32 + l31;
+        if (n < ncols) {
+            float* dst = part + ((int64_t)blockIdx.x * g.Cout) * ncols + n;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (m < g.Cout) dst[(int64_t)m * ncols] = acc[e];
+            }
+        }
+    }
+}
+
+// dW[m][n] = sum_c part[c][m][n] (n < Nw);  db[m] = sum_c part[c][m][Nw]
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ part,
+                                                                float* __restrict__ dW,
+                                                                float* __restrict__ db, int chunks,
+                                                                int Cout, int Nw, int ncols) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int total = Cout * ncols;
+    if (idx >= total) return;
+    const int m = idx / ncols, n = idx - m * ncols;
+    float s = 0.f;
+    for (int c = 0; c < chunks; ++c) s += part[(int64_t)c * total + idx];
+    if (n < Nw) {
+        if (dW) dW[(int64_t)m * Nw + n] = s;
+    } else if (db) {
+        db[m] = s;
+    }
+}
+
+static int make_geom(const nnhipConv2dDesc* d, ConvGeom& g) {
+    NNHIP_CHECK_ARG(d != nullptr, NNHIP_EINVAL, "conv2d: null descriptor");
+    NNHIP_CHECK_ARG(d->B >= 0 && d->Cin > 0 && d->H > 0 && d->W > 0 && d->Cout > 0 && d->kh > 0 && d->kw > 0 &&
+                        d->sh > 0 && d->sw > 0 && d->dh > 0 && d->dw > 0 && d->pu >= 0 && d->pd >= 0 &&
+                        d->pl >= 0 && d->pr >= 0,
+                    NNHIP_EINVAL, "conv2d: bad descriptor");
+    const int64_t Ho = (d->H + d->pu + d->pd - d->dh * (d->kh - 1) - 1) / d->sh + 1;  // conv2d.py:245-258
+    const int64_t Wo = (d->W + d->pl + d->pr - d->dw * (d->kw - 1) - 1) / d->sw + 1;
+    NNHIP_CHECK_ARG(Ho > 0 && Wo > 0, NNHIP_EINVAL, "conv2d: empty output");
+    const int64_t lim = (int64_t)1 << 31;
+    NNHIP_CHECK_ARG(d->B * d->Cin * d->H * d->W < lim * 8 && d->H * d->W < lim && Ho * Wo < lim &&
+                        d->Cin * d->kh * d->kw < lim && d->Cout * d->kh * d->kw < lim,
+                    NNHIP_EINVAL, "conv2d: dimension too large");
+    g.B = (int)d->B; g.Cin = (int)d->Cin; g.H = (int)d->H; g.W = (int)d->W; g.Cout = (int)d->Cout;
+    g.kh = (int)d->kh; g.kw = (int)d->kw; g.sh = (int)d->sh; g.sw = (int)d->sw; g.dh = (int)d->dh; g.dw = (int)d->dw;
+    g.pu = (int)d->pu; g.pl = (int)d->pl; g.Ho = (int)Ho; g.Wo = (int)Wo;
+    return 0;
+}
+
+}  // namespace nnhip
+
+using namespace nnhip;
+
+extern "C" int nnhipConv2dForward(const float* X, const float* W, const float* bias, float* O,
+                                  const nnhipConv2dDesc* d, nnhipStream_t s) {
+    ConvGeom g;
+    if (int rc = make_geom(d, g)) return rc;
+    if (g.B == 0) return 0;
+    NNHIP_CHECK_ARG(X && W && O, NNHIP_EINVAL, "nnhipConv2dForward: null pointer");
+    const int64_t N = (int64_t)g.B * g.Ho * g.Wo;
+    dim3 grid((unsigned)ceil_div(N, CF_BN), (unsigned)ceil_div(g.Cout, 32));
+    hipLaunchKernelGGL(conv_igemm_kernel<false>, grid, dim3(256), 0, (hipStream_t)s, W, X, bias, O, g);
+    NNHIP_LAUNCH_CHECK("conv_igemm_kernel<fwd>");
+    return 0;
+}
+
+extern "C" int nnhipConv2dBackward(const float* X, const float* W, const float* dO, float* dX, float* dW,
+                                   float* db, const nnhipConv2dDesc* d, nnhipStream_t s) {
+    ConvGeom g;
+    if (int rc = make_geom(d, g)) return rc;
+    if (g.B == 0) return 0;
+    NNHIP_CHECK_ARG(X && W && dO, NNHIP_EINVAL, "nnhipConv2dBackward: null pointer");
+    hipStream_t st = (hipStream_t)s;
+    if (dX) {
+        const int64_t N = (int64_t)g.B * g.H * g.W;
+        dim3 grid((unsigned)ceil_div(N, CF_BN), (unsigned)ceil_div(g.Cin, 32));
+        hipLaunchKernelGGL(conv_igemm_kernel<true>, grid, dim3(256), 0, st, W, dO, nullptr, dX, g);
+        NNHIP_LAUNCH_CHECK("conv_igemm_kernel<dgrad>");
+    }
+    if (dW || db) {
+        const int Nw = g.Cin * g.kh * g.kw;
+        const int ncols = Nw + 1;
+        const int64_t K = (int64_t)g.B * g.Ho * g.Wo;
+        int64_t kpb = ceil_div(ceil_div(K, 768), CW_BK) * CW_BK;
+        if (kpb < 256) kpb = 256;
+        const int chunks = (int)ceil_div(K, kpb);
+        float* part = static_cast<float*>(workspace((size_t)chunks * g.Cout * ncols * sizeof(float)));
+        NNHIP_CHECK_ARG(part != nullptr, NNHIP_ENOMEM, "nnhipConv2dBackward: workspace allocation failed");
+        dim3 grid((unsigned)chunks, (unsigned)ceil_div(g.Cout, 32), (unsigned)ceil_div(ncols, CW_BN));
+        hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, st, X, dO, part, g, kpb, ncols);
+        NNHIP_LAUNCH_CHECK("conv_wgrad_kernel");
+        const int total = g.Cout * ncols;
+        hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st,
+                           part, dW, db, chunks, g.Cout, Nw, ncols);
+        NNHIP_LAUNCH_CHECK("conv_wgrad_reduce_kernel");
+    }
+    return 0;
+}

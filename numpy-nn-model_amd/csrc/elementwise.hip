@@ -1,0 +1,260 @@
+// elementwise.hip -- bandwidth-bound elementwise kernels: ReLU, Swish, SwiGLU gate, scale, add.
+// All are float4 grid-stride loops (16 B/lane = 1 KiB per wave instruction), capped at 8 blocks/CU,
+// with a scalar tail; exact expf (the reference's --use_fast_math builds already deviate from
+// NumPy, SURVEY Appendix A.12 -- parity is defined against NumPy).
+#include "common.h"
+
+namespace nnhip {
+
+constexpr int EW_THREADS = 256;
+constexpr int EW_MAX_BLOCKS = 256 * 8;
+
+inline int ew_blocks(int64_t n_vec) {
+    int64_t b = ceil_div(n_vec > 0 ? n_vec : 1, EW_THREADS);
+    return (int)(b < EW_MAX_BLOCKS ? b : EW_MAX_BLOCKS);
+}
+
+// Generic unary/binary maps over float4 with scalar tail -----------------------------------------
+template <class F>
+__global__ __launch_bounds__(EW_THREADS) void map1_kernel(float* out, const float* a, int64_t n,
+                                                          bool vec, F f) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    if (vec) {
+        const int64_t nv = n >> 2;
+        for (int64_t i = gid; i < nv; i += gsz) {
+            const float4 x = reinterpret_cast<const float4*>(a)[i];
+            float4 y;
+            y.x = f(x.x); y.y = f(x.y); y.z = f(x.z); y.w = f(x.w);
+            reinterpret_cast<float4*>(out)[i] = y;
+        }
+        for (int64_t i = (nv << 2) + gid; i < n; i += gsz) out[i] = f(a[i]);
+    } else {
+        for (int64_t i = gid; i < n; i += gsz) out[i] = f(a[i]);
+    }
+}
+
+template <class F>
+__global__ __launch_bounds__(EW_THREADS) void map2_kernel(float* out, const float* a, const float* b, int64_t n,
+                                                          bool vec, F f) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    if (vec) {
+        const int64_t nv = n >> 2;
+        for (int64_t i = gid; i < nv; i += gsz) {
+            const float4 x = reinterpret_cast<const float4*>(a)[i];
+            const float4 z = reinterpret_cast<const float4*>(b)[i];
+            float4 y;
+            y.x = f(x.x, z.x); y.y = f(x.y, z.y); y.z = f(x.z, z.z); y.w = f(x.w, z.w);
+            reinterpret_cast<float4*>(out)[i] = y;
+        }
+        for (int64_t i = (nv << 2) + gid; i < n; i += gsz) out[i] = f(a[i], b[i]);
+    } else {
+        for (int64_t i = gid; i < n; i += gsz) out[i] = f(a[i], b[i]);
+    }
+}
+
+struct ReluF { __device__ float operator()(float x) const { return fmaxf(x, 0.f); } };
+// dIn = dOut * (out > 0)      (neunet/nn/activations.py:44-45)
+struct ReluB { __device__ float operator()(float dy, float y) const { return y > 0.f ? dy : 0.f; } };
+// f = x * sigmoid(beta x)     (neunet/nn/activations.py:225-230)
+struct SwishF {
+    float beta;
+    __device__ float operator()(float x) const { return x * sigmoidf_(beta * x); }
+};
+// dx = dy * (beta f + s (1 - beta f)), s = sigmoid(beta x)   (neunet/nn/activations.py:212-216)
+struct SwishB {
+    float beta;
+    __device__ float operator()(float dy, float x) const {
+        const float s = sigmoidf_(beta * x);
+        const float f = x * s;
+        return dy * (beta * f + s * (1.f - beta * f));
+    }
+};
+struct ScaleF {
+    float alpha;
+    __device__ float operator()(float x) const { return alpha * x; }
+};
+struct AddF { __device__ float operator()(float a, float b) const { return a + b; } };
+
+template <class F>
+static int launch_map1(float* out, const float* a, int64_t n, F f, hipStream_t st, const char* nm) {
+    if (n == 0) return 0;
+    const bool vec = aligned16(out) && aligned16(a);
+    hipLaunchKernelGGL(map1_kernel<F>, dim3(ew_blocks(vec ? n >> 2 : n)), dim3(EW_THREADS), 0, st,
+                       out, a, n, vec, f);
+    NNHIP_LAUNCH_CHECK(nm);
+    return 0;
+}
+template <class F>
+static int launch_map2(float* out, const float* a, const float* b, int64_t n, F f, hipStream_t st,
+                       const char* nm) {
+    if (n == 0) return 0;
+    const bool vec = aligned16(out) && aligned16(a) && aligned16(b);
+    hipLaunchKernelGGL(map2_kernel<F>, dim3(ew_blocks(vec ? n >> 2 : n)), dim3(EW_THREADS), 0, st,
+                       out, a, b, n, vec, f);
+    NNHIP_LAUNCH_CHECK(nm);
+    return 0;
+}
+
+// SwiGLU gate.  in rows = [gate(h) | up(h)] (width 2h), out rows width h.
+// (fused_swish_and_mul.cu:13-57 semantics; oracle = Swish(gate)*up on the reference tape)
+template <bool VEC>
+__global__ __launch_bounds__(EW_THREADS) void swiglu_fwd_kernel(float* __restrict__ out,
+                                                                const float* __restrict__ in,
+                                                                float beta, int64_t h, int64_t size) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    if constexpr (VEC) {  // h % 4 == 0
+        const int64_t hv = h >> 2, nv = size >> 2;
+        for (int64_t i = gid; i < nv; i += gsz) {
+            const int64_t row = i / hv, c = i - row * hv;
+            const float4 g = reinterpret_cast<const float4*>(in)[row * 2 * hv + c];
+            const float4 u = reinterpret_cast<const float4*>(in)[row * 2 * hv + hv + c];
+            float4 y;
+            y.x = g.x * sigmoidf_(beta * g.x) * u.x;
+            y.y = g.y * sigmoidf_(beta * g.y) * u.y;
+            y.z = g.z * sigmoidf_(beta * g.z) * u.z;
+            y.w = g.w * sigmoidf_(beta * g.w) * u.w;
+            reinterpret_cast<float4*>(out)[i] = y;
+        }
+    } else {
+        for (int64_t i = gid; i < size; i += gsz) {
+            const int64_t row = i / h, c = i - row * h;
+            const float g = in[row * 2 * h + c], u = in[row * 2 * h + h + c];
+            out[i] = g * sigmoidf_(beta * g) * u;
+        }
+    }
+}
+
+__device__ __forceinline__ void swiglu_bwd1(float dy, float g, float u, float beta, float& dg,
+                                            float& du) {
+    const float s = sigmoidf_(beta * g);
+    const float f = g * s;
+    du = dy * f;
+    dg = dy * u * (beta * f + s * (1.f - beta * f));
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(EW_THREADS) void swiglu_bwd_kernel(float* __restrict__ din,
+                                                                const float* __restrict__ dout,
+                                                                const float* __restrict__ in,
+                                                                float beta, int64_t h, int64_t size) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
+    if constexpr (VEC) {
+        const int64_t hv = h >> 2, nv = size >> 2;
+        for (int64_t i = gid; i < nv; i += gsz) {
+            const int64_t row = i / hv, c = i - row * hv;
+            const float4 g = reinterpret_cast<const float4*>(in)[row * 2 * hv + c];
+            const float4 u = reinterpret_cast<const float4*>(in)[row * 2 * hv + hv + c];
+            const float4 dy = reinterpret_cast<const float4*>(dout)[i];
+            float4 dg, du;
+            swiglu_bwd1(dy.x, g.x, u.x, beta, dg.x, du.x);
+            swiglu_bwd1(dy.y, g.y, u.y, beta, dg.y, du.y);
+            swiglu_bwd1(dy.z, g.z, u.z, beta, dg.z, du.z);
+            swiglu_bwd1(dy.w, g.w, u.w, beta, dg.w, du.w);
+            reinterpret_cast<float4*>(din)[row * 2 * hv + c] = dg;
+            reinterpret_cast<float4*>(din)[row * 2 * hv + hv + c] = du;
+        }
+    } else {
+        for (int64_t i = gid; i < size; i += gsz) {
+            const int64_t row = i / h, c = i - row * h;
+            float dg, du;
+            swiglu_bwd1(dout[i], in[row * 2 * h + c], in[row * 2 * h + h + c], beta, dg, du);
+            din[row * 2 * h + c] = dg;
+            din[row * 2 * h + h + c] = du;
+        }
+    }
+}
+
+// internal: used by linear.hip for dZ = dY * swish'(z), in place over z
+int swish_backward_inplace(float* z_inout, const float* dY, float beta, int64_t n, hipStream_t st) {
+    return launch_map2(z_inout, dY, z_inout, n, SwishB{beta}, st, "swish_backward(inplace)");
+}
+
+}  // namespace nnhip
+
+using namespace nnhip;
+
+#define NNHIP_PTRS(fn, ...)                                                        \
+    do {                                                                           \
+        const void* _ps[] = {__VA_ARGS__};                                         \
+        for (const void* _p : _ps) {                                               \
+            NNHIP_CHECK_ARG(_p != nullptr, NNHIP_EINVAL, fn ": null pointer");      \
+            NNHIP_CHECK_ARG(aligned4(_p), NNHIP_EALIGN, fn ": misaligned pointer"); \
+        }                                                                          \
+    } while (0)
+
+extern "C" int nnhipReLUForward(float* out, const float* in, int64_t size, nnhipStream_t s) {
+    NNHIP_CHECK_ARG(size >= 0, NNHIP_EINVAL, "nnhipReLUForward: negative size");
+    if (size == 0) return 0;
+    NNHIP_PTRS("nnhipReLUForward", out, in);
+    return launch_map1(out, in, size, ReluF{}, (hipStream_t)s, "relu_forward");
+}
+extern "C" int nnhipReLUBackward(float* dIn, const float* dOut, const float* out, int64_t size,
+                                 nnhipStream_t s) {
+    NNHIP_CHECK_ARG(size >= 0, NNHIP_EINVAL, "nnhipReLUBackward: negative size");
+    if (size == 0) return 0;
+    NNHIP_PTRS("nnhipReLUBackward", dIn, dOut, out);
+    return launch_map2(dIn, dOut, out, size, ReluB{}, (hipStream_t)s, "relu_backward");
+}
+extern "C" int nnhipSwishForward(float* out, const float* in, float beta, int64_t size,
+                                 nnhipStream_t s) {
+    NNHIP_CHECK_ARG(size >= 0, NNHIP_EINVAL, "nnhipSwishForward: negative size");
+    if (size == 0) return 0;
+    NNHIP_PTRS("nnhipSwishForward", out, in);
+    return launch_map1(out, in, size, SwishF{beta}, (hipStream_t)s, "swish_forward");
+}
+extern "C" int nnhipSwishBackward(float* dIn, const float* dOut, const float* in, float beta,
+                                  int64_t size, nnhipStream_t s) {
+    NNHIP_CHECK_ARG(size >= 0, NNHIP_EINVAL, "nnhipSwishBackward: negative size");
+    if (size == 0) return 0;
+    NNHIP_PTRS("nnhipSwishBackward", dIn, dOut, in);
+    return launch_map2(dIn, dOut, in, size, SwishB{beta}, (hipStream_t)s, "swish_backward");
+}
+extern "C" int nnhipFusedSwishAndMul(float* out, const float* in, float beta, int64_t hidden,
+                                     int64_t size, nnhipStream_t s) {
+    NNHIP_CHECK_ARG(size >= 0 && hidden > 0 && size % hidden == 0, NNHIP_EINVAL,
+                    "nnhipFusedSwishAndMul: size must be a non-negative multiple of hidden > 0");
+    if (size == 0) return 0;
+    NNHIP_PTRS("nnhipFusedSwishAndMul", out, in);
+    const bool vec = (hidden % 4 == 0) && aligned16(out) && aligned16(in);
+    if (vec)
+        hipLaunchKernelGGL(swiglu_fwd_kernel<true>, dim3(ew_blocks(size >> 2)), dim3(EW_THREADS), 0,
+                           (hipStream_t)s, out, in, beta, hidden, size);
+    else
+        hipLaunchKernelGGL(swiglu_fwd_kernel<false>, dim3(ew_blocks(size)), dim3(EW_THREADS), 0,
+                           (hipStream_t)s, out, in, beta, hidden, size);
+    NNHIP_LAUNCH_CHECK("swiglu_fwd_kernel");
+    return 0;
+}
+extern "C" int nnhipFusedSwishAndMulBackward(float* dIn, const float* dOut, const float* in,
+                                             float beta, int64_t hidden, int64_t size,
+                                             nnhipStream_t s) {
+    NNHIP_CHECK_ARG(size >= 0 && hidden > 0 && size % hidden == 0, NNHIP_EINVAL,
+                    "nnhipFusedSwishAndMulBackward: size must be a non-negative multiple of hidden > 0");
+    if (size == 0) return 0;
+    NNHIP_PTRS("nnhipFusedSwishAndMulBackward", dIn, dOut, in);
+    const bool vec = (hidden % 4 == 0) && aligned16(dIn) && aligned16(dOut) && aligned16(in);
+    if (vec)
+        hipLaunchKernelGGL(swiglu_bwd_kernel<true>, dim3(ew_blocks(size >> 2)), dim3(EW_THREADS), 0,
+                           (hipStream_t)s, dIn, dOut, in, beta, hidden, size);
+    else
+        hipLaunchKernelGGL(swiglu_bwd_kernel<false>, dim3(ew_blocks(size)), dim3(EW_THREADS), 0,
+                           (hipStream_t)s, dIn, dOut, in, beta, hidden, size);
+    NNHIP_LAUNCH_CHECK("swiglu_bwd_kernel");
+    return 0;
+}
+extern "C" int nnhipScale(float* x, float alpha, int64_t n, nnhipStream_t s) {
+    NNHIP_CHECK_ARG(n >= 0, NNHIP_EINVAL, "nnhipScale: negative size");
+    if (n == 0) return 0;
+    NNHIP_PTRS("nnhipScale", x);
+    return launch_map1(x, x, n, ScaleF{alpha}, (hipStream_t)s, "scale");
+}
+extern "C" int nnhipAdd(float* out, const float* a, const float* b, int64_t n, nnhipStream_t s) {
+    NNHIP_CHECK_ARG(n >= 0, NNHIP_EINVAL, "nnhipAdd: negative size");
+    if (n == 0) return 0;
+    NNHIP_PTRS("nnhipAdd", out, a, b);
+    return launch_map2(out, a, b, n, AddF{}, (hipStream_t)s, "add");
+}

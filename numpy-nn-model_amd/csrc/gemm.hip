@@ -1,0 +1,363 @@
+// gemm.hip -- fp32 MFMA GEMM for gfx950 (MI355X), the engine behind Linear fwd/bwd
+// (reference semantics: neunet/nn/layers/linear.py:48-58, 17-24) and fused Linear->Swish.
+//
+// C[M,N] = op(A) * op(B) (+bias[N]) (act), exact fp32 (v_mfma_f32_32x32x2_f32: a k-ordered fmaf
+// chain -- no TF32 on gfx950; the reference's CUDA LinearSwish path is TF32 and only 1e-3 accurate).
+//
+// Structure (MI355X-first, not a CUTLASS translation):
+//   * block = 256 threads = 4 wave64 in a 2x2 grid; block tile 128x128; wave tile 64x64 =
+//     2x2 MFMA 32x32 tiles -> 4 x f32x16 accumulators (64 acc registers / lane);
+//   * K is walked in BK-deep tiles, global -> registers -> LDS with a 2-stage LDS ring:
+//     the global loads of tile t+1 are issued before the MFMAs of tile t and written to the
+//     other LDS stage after them -> one __syncthreads per tile, HBM/L2 latency hidden under
+//     64-cycle MFMAs; 2 blocks/CU (2 waves/SIMD) cover each other's barrier/LDS phases;
+//   * each operand is either "k-major" (reduction dim contiguous in memory) or "outer-major";
+//     k-major tiles live in LDS as [128][BK+4] (row stride 36 floats = conflict-free
+//     ds_read_b128 of 4 consecutive k per lane), outer-major tiles as [BK][128] (ds_read_b32, the
+//     two half-waves read two k rows).  Both feed the same k permutation to A and B:
+//     MFMA j of k-group g consumes k = 8g + j (lanes 0-31) and 8g + 4 + j (lanes 32-63);
+//   * 1-D grid with an XCD-aware, grouped tile order: block b runs on XCD b%8 (observed, used for
+//     speed only); each XCD gets a contiguous run of logical tile ids, walked 8 tile-rows at a time,
+//     so the 64 tiles resident on one XCD share A/B panels in that XCD's private 4 MiB L2;
+//   * split-K (deterministic: fp32 slabs + a reduce kernel, no atomics) when M*N has too few
+//     tiles to fill 256 CUs (e.g. dW = dO^T X with a 16384-long reduction at GPT-tiny).
+#include "common.h"
+
+namespace nnhip {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { ACT_NONE = 0, ACT_SWISH = 1, ACT_RELU = 2 };
+
+struct GemmParams {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;   // [N] or null
+    float* preact;       // [M, ldc] or null: pre-activation (z) output for ACT_SWISH
+    int64_t M, N, K, lda, ldb, ldc, sA, sB, sC;
+    int tiles_m, tiles_n, splitk;
+    int64_t k_per_split;  // multiple of BK
+    float* slab;          // split-K partials [splitk][M][N] (dense)
+    int act;
+    float beta;
+};
+
+constexpr int BM = 128, BN = 128, NT = 256;
+
+template <int BK, bool KC>
+struct Tile {
+    static constexpr int LD = KC ? (BK + 4) : 128;
+    static constexpr int SIZE = KC ? 128 * (BK + 4) : BK * 128;  // floats
+    static constexpr int NV = BK / 8;                             // float4 per thread per tile
+};
+
+// global -> registers.  R = extent of the operand's outer dim, r0/k0 = tile origin.
+template <int BK, bool KC, bool VEC>
+__device__ __forceinline__ void g2r(float4 (&r)[BK / 8], const float* __restrict__ P, int64_t ld,
+                                    int64_t R, int64_t Kend, int64_t r0, int64_t k0, int tid) {
+#pragma unroll
+    for (int p = 0; p < BK / 8; ++p) {
+        const int idx = tid + NT * p;
+        if constexpr (KC) {
+            const int rr = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
+            const int64_t gr = r0 + rr, gk = k0 + k4;
+            const float* src = P + gr * ld + gk;
+            if constexpr (VEC) {
+                r[p] = (gr < R && gk < Kend) ? *reinterpret_cast<const float4*>(src)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                const bool ok = gr < R;
+                r[p].x = (ok && gk + 0 < Kend) ? src[0] : 0.f;
+                r[p].y = (ok && gk + 1 < Kend) ? src[1] : 0.f;
+                r[p].z = (ok && gk + 2 < Kend) ? src[2] : 0.f;
+                r[p].w = (ok && gk + 3 < Kend) ? src[3] : 0.f;
+            }
+        } else {
+            const int kk = idx / 32, r4 = (idx % 32) * 4;
+            const int64_t gk = k0 + kk, gr = r0 + r4;
+            const float* src = P + gk * ld + gr;
+            if constexpr (VEC) {
+                r[p] = (gk < Kend && gr < R) ? *reinterpret_cast<const float4*>(src)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                const bool ok = gk < Kend;
+                r[p].x = (ok && gr + 0 < R) ? src[0] : 0.f;
+                r[p].y = (ok && gr + 1 < R) ? src[1] : 0.f;
+                r[p].z = (ok && gr + 2 < R) ? src[2] : 0.f;
+                r[p].w = (ok && gr + 3 < R) ? src[3] : 0.f;
+            }
+        }
+    }
+}
+
+// registers -> LDS stage
+template <int BK, bool KC>
+__device__ __forceinline__ void r2s(const float4 (&r)[BK / 8], float* __restrict__ S, int tid) {
+#pragma unroll
+    for (int p = 0; p < BK / 8; ++p) {
+        const int idx = tid + NT * p;
+        if constexpr (KC) {
+            const int rr = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
+            *reinterpret_cast<float4*>(&S[rr * (BK + 4) + k4]) = r[p];
+        } else {
+            const int kk = idx / 32, r4 = (idx % 32) * 4;
+            *reinterpret_cast<float4*>(&S[kk * 128 + r4]) = r[p];
+        }
+    }
+}
+
+// Read the 4 MFMA operands (k = 8g+j [+4 for the upper half-wave], j = 0..3) of one 32-row subtile.
+template <int BK, bool KC>
+__device__ __forceinline__ void frag(float (&f)[4], const float* __restrict__ S, int row, int g,
+                                     int lh) {
+    if constexpr (KC) {
+        const float4 v = *reinterpret_cast<const float4*>(&S[row * (BK + 4) + g * 8 + lh * 4]);
+        f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[j] = S[(g * 8 + j + 4 * lh) * 128 + row];
+    }
+}
+
+template <int BK, bool AKC, bool BKC, bool VEC>
+__global__ __launch_bounds__(NT, 2) void gemm_f32_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    using TA = Tile<BK, AKC>;
+    using TB = Tile<BK, BKC>;
+    constexpr int STAGE = TA::SIZE + TB::SIZE;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lh = lane >> 5;
+
+    // ---- block id -> (split, tile_m, tile_n): XCD-aware grouped order --------------------------
+    const int nwg = gridDim.x;
+    int L;
+    {
+        const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);  // bijective
+    }
+    const int tiles = p.tiles_m * p.tiles_n;
+    const int split = L / tiles;
+    const int t = L - split * tiles;
+    constexpr int GM = 8;
+    const int in_group = GM * p.tiles_n;
+    const int grp = t / in_group;
+    const int first_m = grp * GM;
+    const int gsz = min(p.tiles_m - first_m, GM);
+    const int tm = first_m + (t % in_group) % gsz;
+    const int tn = (t % in_group) / gsz;
+
+    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
+    const int64_t kbeg = (int64_t)split * p.k_per_split;
+    const int64_t kend = min(p.K, kbeg + p.k_per_split);
+    const int bz = blockIdx.y;
+    const float* __restrict__ A = p.A + (int64_t)bz * p.sA;
+    const float* __restrict__ B = p.B + (int64_t)bz * p.sB;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    float4 ra[BK / 8], rb[BK / 8];
+    const int nk = (int)((kend - kbeg + BK - 1) / BK);
+
+    if (nk > 0) {
+        g2r<BK, AKC, VEC>(ra, A, p.lda, p.M, kend, m0, kbeg, tid);
+        g2r<BK, BKC, VEC>(rb, B, p.ldb, p.N, kend, n0, kbeg, tid);
+        r2s<BK, AKC>(ra, smem, tid);
+        r2s<BK, BKC>(rb, smem + TA::SIZE, tid);
+    }
+    __syncthreads();
+
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) {
+            const int64_t k0 = kbeg + (int64_t)(kt + 1) * BK;
+            g2r<BK, AKC, VEC>(ra, A, p.lda, p.M, kend, m0, k0, tid);
+            g2r<BK, BKC, VEC>(rb, B, p.ldb, p.N, kend, n0, k0, tid);
+        }
+        const float* As = smem + cur * STAGE;
+        const float* Bs = As + TA::SIZE;
+#pragma unroll
+        for (int g = 0; g < BK / 8; ++g) {
+            float a[2][4], b[2][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                frag<BK, AKC>(a[i], As, wm * 64 + i * 32 + l31, g, lh);
+                frag<BK, BKC>(b[i], Bs, wn * 64 + i * 32 + l31, g, lh);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[n][j], acc[i][n],
+                                                                         0, 0, 0);
+        }
+        if (more) {
+            float* Sn = smem + (cur ^ 1) * STAGE;
+            r2s<BK, AKC>(ra, Sn, tid);
+            r2s<BK, BKC>(rb, Sn + TA::SIZE, tid);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: acc reg e of a 32x32 tile -> row (e&3) + 8*(e>>2) + 4*lh, col l31 -----------
+    const bool to_slab = p.splitk > 1;
+    float* __restrict__ C = to_slab ? p.slab + (int64_t)split * p.M * p.N : p.C + (int64_t)bz * p.sC;
+    const int64_t ldc = to_slab ? p.N : p.ldc;
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int64_t col = n0 + wn * 64 + n * 32 + l31;
+        if (col >= p.N) continue;
+        const float bv = (!to_slab && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int64_t rbase = m0 + wm * 64 + i * 32 + 4 * lh;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t row = rbase + (e & 3) + 8 * (e >> 2);
+                if (row >= p.M) continue;
+                float v = acc[i][n][e] + bv;
+                if (!to_slab) {
+                    if (p.act == ACT_SWISH) {
+                        if (p.preact) p.preact[(int64_t)bz * p.sC + row * ldc + col] = v;
+                        v = v * sigmoidf_(p.beta * v);
+                    } else if (p.act == ACT_RELU) {
+                        v = fmaxf(v, 0.f);
+                    }
+                }
+                C[row * ldc + col] = v;
+            }
+        }
+    }
+}
+
+// C[m,n] = sum_s slab[s][m][n] (+bias)(act).  One thread per float4 of a row (N%4 handled).
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab,
+                                                            float* __restrict__ C,
+                                                            float* __restrict__ preact,
+                                                            const float* __restrict__ bias,
+                                                            int64_t M, int64_t N, int64_t ldc,
+                                                            int splitk, int act, float beta) {
+    const int64_t total = M * N;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        float s = 0.f;
+        for (int k = 0; k < splitk; ++k) s += slab[(int64_t)k * total + i];
+        const int64_t m = i / N, n = i - m * N;
+        if (bias) s += bias[n];
+        if (act == ACT_SWISH) {
+            if (preact) preact[m * ldc + n] = s;
+            s = s * sigmoidf_(beta * s);
+        } else if (act == ACT_RELU) {
+            s = fmaxf(s, 0.f);
+        }
+        C[m * ldc + n] = s;
+    }
+}
+
+template <int BK, bool AKC, bool BKC, bool VEC>
+static int launch_variant(const GemmParams& p, int64_t batch, hipStream_t st) {
+    constexpr size_t lds = 2 * (Tile<BK, AKC>::SIZE + Tile<BK, BKC>::SIZE) * sizeof(float);
+    auto kern = gemm_f32_kernel<BK, AKC, BKC, VEC>;
+    static bool attr_set = false;  // per instantiation
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return hip_status(e, "hipFuncSetAttribute(gemm)");
+        attr_set = true;
+    }
+    dim3 grid((unsigned)(p.tiles_m * p.tiles_n * p.splitk), (unsigned)batch);
+    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, p);
+    NNHIP_LAUNCH_CHECK("gemm_f32_kernel");
+    return 0;
+}
+
+// Host-side GEMM dispatcher (internal API used by linear.hip / api).
+int gemm_f32(const float* A, const float* B, float* C, const float* bias, float* preact, int64_t M,
+             int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, bool a_kmajor,
+             bool b_kmajor, int64_t batch, int64_t sA, int64_t sB, int64_t sC, int act, float beta,
+             hipStream_t st) {
+    if (M <= 0 || N <= 0 || batch <= 0) return 0;
+    constexpr int BK = 32;
+    GemmParams p;
+    p.A = A; p.B = B; p.C = C; p.bias = bias; p.preact = preact;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.sA = sA; p.sB = sB; p.sC = sC;
+    p.tiles_m = (int)ceil_div(M, BM);
+    p.tiles_n = (int)ceil_div(N, BN);
+    p.act = act; p.beta = beta;
+    p.splitk = 1; p.k_per_split = ceil_div(K > 0 ? K : 1, BK) * BK; p.slab = nullptr;
+
+    // split-K: few tiles, long reduction (deterministic slabs + reduce)
+    const int64_t tiles = (int64_t)p.tiles_m * p.tiles_n * batch;
+    if (batch == 1 && tiles < 192 && K >= 1024) {
+        int64_t s = 512 / tiles;
+        const int64_t max_by_k = K / 256;
+        if (s > max_by_k) s = max_by_k;
+        if (s > 32) s = 32;
+        if (s >= 2) {
+            p.k_per_split = ceil_div(ceil_div(K, s), BK) * BK;
+            p.splitk = (int)ceil_div(K, p.k_per_split);
+            if (p.splitk >= 2) {
+                p.slab = static_cast<float*>(workspace((size_t)p.splitk * M * N * sizeof(float)));
+                if (!p.slab) { set_last_error("split-K workspace allocation failed"); return NNHIP_ENOMEM; }
+            } else {
+                p.splitk = 1; p.k_per_split = ceil_div(K, BK) * BK;
+            }
+        }
+    }
+
+    // float4 global loads need 16-B aligned rows along the contiguous dim
+    auto vec_ok = [&](const float* P, int64_t ld, int64_t stride_b, bool kmajor, int64_t outer) {
+        if (!aligned16(P) || (ld & 3) || (batch > 1 && (stride_b & 3))) return false;
+        return kmajor ? ((K & 3) == 0) : ((outer & 3) == 0);
+    };
+    const bool vec = vec_ok(A, lda, sA, a_kmajor, M) && vec_ok(B, ldb, sB, b_kmajor, N);
+
+    int rc;
+#define NNHIP_GEMM_CASE(AK, BKM)                                                   \
+    rc = vec ? launch_variant<BK, AK, BKM, true>(p, batch, st)                    \
+             : launch_variant<BK, AK, BKM, false>(p, batch, st)
+    if (a_kmajor && b_kmajor) { NNHIP_GEMM_CASE(true, true); }
+    else if (a_kmajor && !b_kmajor) { NNHIP_GEMM_CASE(true, false); }
+    else if (!a_kmajor && b_kmajor) { NNHIP_GEMM_CASE(false, true); }
+    else { NNHIP_GEMM_CASE(false, false); }
+#undef NNHIP_GEMM_CASE
+    if (rc) return rc;
+
+    if (p.splitk > 1) {
+        const int64_t total = M * N;
+        int blocks = (int)(ceil_div(total, 256) < 2048 ? ceil_div(total, 256) : 2048);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.slab, C, preact,
+                           bias, M, N, ldc, p.splitk, act, beta);
+        NNHIP_LAUNCH_CHECK("splitk_reduce_kernel");
+    }
+    return 0;
+}
+
+}  // namespace nnhip
+
+extern "C" int nnhipGemmF32(const float* A, const float* B, float* C, const float* bias, int64_t M,
+                            int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                            int a_kmajor, int b_kmajor, int64_t batch, int64_t strideA,
+                            int64_t strideB, int64_t strideC, nnhipStream_t stream) {
+    NNHIP_CHECK_ARG(A && B && C, NNHIP_EINVAL, "nnhipGemmF32: null operand");
+    NNHIP_CHECK_ARG(M >= 0 && N >= 0 && K >= 0 && batch >= 0, NNHIP_EINVAL, "nnhipGemmF32: negative size");
+    NNHIP_CHECK_ARG(nnhip::aligned4(A) && nnhip::aligned4(B) && nnhip::aligned4(C), NNHIP_EALIGN,
+                    "nnhipGemmF32: pointers must be 4-byte aligned");
+    return nnhip::gemm_f32(A, B, C, bias, nullptr, M, N, K, lda, ldb, ldc, a_kmajor != 0,
+                           b_kmajor != 0, batch, strideA, strideB, strideC, nnhip::ACT_NONE, 1.f,
+                           static_cast<hipStream_t>(stream));
+}

@@ -1,0 +1,81 @@
+// linear.hip -- Linear and fused Linear->Swish entry points on top of the MFMA GEMM.
+// CPU semantics: neunet/nn/layers/linear.py:48-58 (fwd), :17-24 (bwd); fused path = Swish(Linear(x)),
+// neunet/nn/activations.py:208-233.
+#include "common.h"
+
+namespace nnhip {
+int gemm_f32(const float* A, const float* B, float* C, const float* bias, float* preact, int64_t M,
+             int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, bool a_kmajor,
+             bool b_kmajor, int64_t batch, int64_t sA, int64_t sB, int64_t sC, int act, float beta,
+             hipStream_t st);
+int colsum(const float* X, int64_t rows, int64_t cols, int64_t ld, float* out, hipStream_t st);
+int swish_backward_inplace(float* z_inout, const float* dY, float beta, int64_t n, hipStream_t st);
+enum { ACT_NONE = 0, ACT_SWISH = 1, ACT_RELU = 2 };
+
+static int linear_backward(const float* X, const float* W, const float* dO, float* dX, float* dW,
+                           float* db, int64_t rows, int64_t in, int64_t out, hipStream_t st) {
+    int rc = 0;
+    // dX[rows,in] = dO[rows,out] * W[out,in]         A k-major (k = out), B outer-major
+    if (dX) rc = gemm_f32(dO, W, dX, nullptr, nullptr, rows, in, out, out, in, in, true, false, 1, 0, 0, 0, ACT_NONE, 1.f, st);
+    if (rc) return rc;
+    // dW[out,in] = dO^T[out,rows] * X[rows,in]        both outer-major (k = rows)
+    if (dW) rc = gemm_f32(dO, X, dW, nullptr, nullptr, out, in, rows, out, in, in, false, false, 1, 0, 0, 0, ACT_NONE, 1.f, st);
+    if (rc) return rc;
+    // db[out] = sum_rows dO
+    if (db) rc = colsum(dO, rows, out, out, db, st);
+    return rc;
+}
+}  // namespace nnhip
+
+using namespace nnhip;
+
+static int check_linear(const char* fn, const void* X, const void* W, int64_t rows, int64_t in, int64_t out) {
+    NNHIP_CHECK_ARG(rows >= 0 && in >= 0 && out >= 0, NNHIP_EINVAL, "%s: negative size", fn);
+    NNHIP_CHECK_ARG(X && W, NNHIP_EINVAL, "%s: null X/W", fn);
+    NNHIP_CHECK_ARG(aligned4(X) && aligned4(W), NNHIP_EALIGN, "%s: misaligned pointer", fn);
+    return 0;
+}
+
+extern "C" int nnhipLinearModuleForward(const float* X, const float* W, const float* b, float* O,
+                                        int64_t rows, int64_t in_features, int64_t out_features,
+                                        nnhipStream_t stream) {
+    if (int rc = check_linear("nnhipLinearModuleForward", X, W, rows, in_features, out_features)) return rc;
+    NNHIP_CHECK_ARG(O != nullptr, NNHIP_EINVAL, "nnhipLinearModuleForward: null output");
+    return gemm_f32(X, W, O, b, nullptr, rows, out_features, in_features, in_features, in_features,
+                    out_features, true, true, 1, 0, 0, 0, ACT_NONE, 1.f, (hipStream_t)stream);
+}
+
+extern "C" int nnhipLinearModuleBackward(const float* X, const float* W, const float* dO, float* dX,
+                                         float* dW, float* db, int64_t rows, int64_t in_features,
+                                         int64_t out_features, nnhipStream_t stream) {
+    if (int rc = check_linear("nnhipLinearModuleBackward", X, W, rows, in_features, out_features)) return rc;
+    NNHIP_CHECK_ARG(dO != nullptr, NNHIP_EINVAL, "nnhipLinearModuleBackward: null dO");
+    return linear_backward(X, W, dO, dX, dW, db, rows, in_features, out_features, (hipStream_t)stream);
+}
+
+extern "C" int nnhipLinearSwishForward(const float* X, const float* W, const float* b, float* O,
+                                       float* preact, int64_t M, int64_t K, int64_t N, float swish_beta,
+                                       int save_preactivation, nnhipStream_t stream) {
+    if (int rc = check_linear("nnhipLinearSwishForward", X, W, M, K, N)) return rc;
+    NNHIP_CHECK_ARG(O != nullptr, NNHIP_EINVAL, "nnhipLinearSwishForward: null output");
+    NNHIP_CHECK_ARG(!save_preactivation || preact, NNHIP_EINVAL,
+                    "nnhipLinearSwishForward: save_preactivation set but preact is null");
+    return gemm_f32(X, W, O, b, save_preactivation ? preact : nullptr, M, N, K, K, K, N, true, true, 1, 0,
+                    0, 0, ACT_SWISH, swish_beta, (hipStream_t)stream);
+}
+
+extern "C" int nnhipLinearSwishBackward(const float* X, const float* W, const float* b, const float* dO,
+                                        float* tmp, float* dX, float* dW, float* db, int64_t M, int64_t K,
+                                        int64_t N, float swish_beta, int recompute_preactivation,
+                                        nnhipStream_t stream) {
+    if (int rc = check_linear("nnhipLinearSwishBackward", X, W, M, K, N)) return rc;
+    NNHIP_CHECK_ARG(dO && tmp, NNHIP_EINVAL, "nnhipLinearSwishBackward: null dO/tmp");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = 0;
+    if (recompute_preactivation)  // z = X W^T + b into tmp
+        rc = gemm_f32(X, W, tmp, b, nullptr, M, N, K, K, K, N, true, true, 1, 0, 0, 0, ACT_NONE, 1.f, st);
+    if (rc) return rc;
+    rc = swish_backward_inplace(tmp, dO, swish_beta, M * N, st);  // tmp <- dZ = dO * swish'(z)
+    if (rc) return rc;
+    return linear_backward(X, W, tmp, dX, dW, db, M, K, N, st);
+}

@@ -1,0 +1,69 @@
+// runtime.hip -- error strings, grow-only workspace, library entry points.
+#include <stdarg.h>
+#include <string.h>
+
+#include <mutex>
+
+#include "common.h"
+
+namespace nnhip {
+
+static thread_local char g_err[512] = "";
+
+void set_last_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int hip_status(hipError_t e, const char* what) {
+    if (e == hipSuccess) return 0;
+    set_last_error("%s: %s (%d)", what, hipGetErrorString(e), (int)e);
+    return (int)e;
+}
+
+static std::mutex g_ws_mu;
+static void* g_ws = nullptr;
+static size_t g_ws_bytes = 0;
+
+void* workspace(size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    if (bytes <= g_ws_bytes) return g_ws;
+    if (g_ws) {
+        (void)hipDeviceSynchronize();  // kernels may still read the old block
+        (void)hipFree(g_ws);
+        g_ws = nullptr;
+        g_ws_bytes = 0;
+    }
+    size_t want = bytes + (bytes >> 2);  // 25 % head-room: fewer regrowths
+    want = (want + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+    if (hipMalloc(&g_ws, want) != hipSuccess) {
+        g_ws = nullptr;
+        if (hipMalloc(&g_ws, bytes) != hipSuccess) {
+            g_ws = nullptr;
+            return nullptr;
+        }
+        want = bytes;
+    }
+    g_ws_bytes = want;
+    return g_ws;
+}
+
+}  // namespace nnhip
+
+extern "C" int nnhipVersion(void) { return 100; }
+
+extern "C" const char* nnhipGetLastErrorString(void) { return nnhip::g_err; }
+
+extern "C" int nnhipCleanup(void) {
+    std::lock_guard<std::mutex> lk(nnhip::g_ws_mu);
+    if (nnhip::g_ws) {
+        (void)hipDeviceSynchronize();
+        hipError_t e = hipFree(nnhip::g_ws);
+        nnhip::g_ws = nullptr;
+        nnhip::g_ws_bytes = 0;
+        return nnhip::hip_status(e, "hipFree(workspace)");
+    }
+    return 0;
+}

@@ -1,0 +1,42 @@
+"""neunet_hip -- MI355X (gfx950) backend for the dense hot path of AkiRusProd/numpy-nn-model (`neunet`).
+
+Host side: the reference's Module / Tensor / tape shape (neunet/autograd.py, neunet/nn/modules.py);
+device side: hand-written HIP kernels in libneunet_hip.so behind a flat C ABI (include/neunet_hip.h),
+bound with ctypes exactly where the reference binds its CUDA .so files
+(neunet/nn/experimental/utils.py:64-92).
+"""
+import numpy as np
+
+from . import nn, optim  # noqa: F401
+from ._lib import NeunetHipError, lib_path, load_library  # noqa: F401
+from .autograd import Tensor  # noqa: F401
+
+float32, int32, int64 = np.float32, np.int32, np.int64
+
+
+def tensor(data, requires_grad=True, dtype=np.float32, device="cpu"):
+    """neunet.tensor (neunet/__init__.py:40-47)."""
+    return Tensor(data, requires_grad=requires_grad, dtype=dtype, device=device)
+
+
+def argmax(x: Tensor, axis=None, keepdims=False):
+    """neunet.argmax -> int32 (neunet/__init__.py:132-139); index results must be bit-exact."""
+    if x.device == "cpu":
+        out = np.argmax(x.data, axis=axis, keepdims=keepdims).astype(np.int32)
+        return Tensor(out, dtype=np.int32, requires_grad=False, device="cpu")
+    import torch
+    out = torch.argmax(x.data, dim=axis, keepdim=keepdims).to(torch.int32)
+    return Tensor(out, dtype=np.int32, requires_grad=False, device="cuda")
+
+
+def save(obj, path):
+    """neunet.save = pickle (neunet/__init__.py:26-29)."""
+    import pickle
+    with open(path, "wb") as f:
+        pickle.dump(obj, f)
+
+
+def load(path):
+    import pickle
+    with open(path, "rb") as f:
+        return pickle.load(f)

@@ -1,0 +1,143 @@
+"""ctypes binding of libneunet_hip.so -- the FFI boundary.
+
+Mirrors neunet/nn/experimental/utils.py:64-92 of the reference (load_cuda_function / to_pointer /
+call_cuda_function / get_current_stream_ptr), with two deliberate differences: the library path is
+resolved relative to this package (the reference's paths are CWD-relative constants, utils.py:4-62)
+and every export returns an int status that is turned into a Python exception here.
+
+There is NO CPU fallback: if the shared library is missing or a launch fails, the call raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char, c_float, c_int32, c_int64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_ENV = "NEUNET_HIP_LIB"
+DEFAULT_LIB = os.path.join(_HERE, "lib", "libneunet_hip.so")
+
+
+class NeunetHipError(RuntimeError):
+    """Raised for any non-zero status from libneunet_hip.so."""
+
+
+class Conv2dDesc(ctypes.Structure):
+    """struct nnhipConv2dDesc (include/neunet_hip.h)."""
+    _fields_ = [(n, c_int64) for n in ("B", "Cin", "H", "W", "Cout", "kh", "kw", "sh", "sw", "dh", "dw",
+                                       "pu", "pd", "pl", "pr")]
+
+
+P = c_void_p  # device pointers travel as void*
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    "nnhipVersion": (ctypes.c_int, []),
+    "nnhipGetLastErrorString": (ctypes.c_char_p, []),
+    "nnhipCleanup": (ctypes.c_int, []),
+    "nnhipLinearModuleForward": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_void_p]),
+    "nnhipLinearModuleBackward": (ctypes.c_int, [P, P, P, P, P, P, c_int64, c_int64, c_int64, c_void_p]),
+    "nnhipLinearSwishForward": (ctypes.c_int, [P, P, P, P, P, c_int64, c_int64, c_int64, c_float, ctypes.c_int, c_void_p]),
+    "nnhipLinearSwishBackward": (ctypes.c_int, [P, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_float, ctypes.c_int, c_void_p]),
+    "nnhipGemmF32": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, ctypes.c_int, ctypes.c_int,
+                                    c_int64, c_int64, c_int64, c_int64, c_void_p]),
+    "nnhipReLUForward": (ctypes.c_int, [P, P, c_int64, c_void_p]),
+    "nnhipReLUBackward": (ctypes.c_int, [P, P, P, c_int64, c_void_p]),
+    "nnhipSwishForward": (ctypes.c_int, [P, P, c_float, c_int64, c_void_p]),
+    "nnhipSwishBackward": (ctypes.c_int, [P, P, P, c_float, c_int64, c_void_p]),
+    "nnhipFusedSwishAndMul": (ctypes.c_int, [P, P, c_float, c_int64, c_int64, c_void_p]),
+    "nnhipFusedSwishAndMulBackward": (ctypes.c_int, [P, P, P, c_float, c_int64, c_int64, c_void_p]),
+    "nnhipSoftmaxForward": (ctypes.c_int, [P, P, c_int64, c_int64, c_int64, c_void_p]),
+    "nnhipSoftmaxBackward": (ctypes.c_int, [P, P, P, c_int64, c_int64, c_int64, c_void_p]),
+    "nnhipCrossEntropyForwardBackward": (ctypes.c_int, [P, P, P, P, c_int64, c_int32, c_int64, c_int64, c_char, c_int64, P, P, c_void_p]),
+    "nnhipCountNotEqual": (ctypes.c_int, [P, c_int64, c_int32, P, c_void_p]),
+    "nnhipReduceLoss": (ctypes.c_int, [P, c_int64, c_char, P, P, c_void_p]),
+    "nnhipRMSNormForward": (ctypes.c_int, [P, P, P, P, P, P, c_int64, c_int64, c_float, c_void_p]),
+    "nnhipRMSNormBackward": (ctypes.c_int, [P, P, P, P, P, P, P, P, c_int64, c_int64, c_void_p]),
+    "nnhipFusedAdamWStep": (ctypes.c_int, [P, P, P, P, c_float, c_float, c_float, c_float, c_float, c_int32, c_int64, c_int32, c_float, c_void_p]),
+    "nnhipCreateFusedOptimizer": (c_void_p, []),
+    "nnhipDestroyFusedOptimizer": (ctypes.c_int, [c_void_p]),
+    "nnhipFusedAdamWMultiTensorStep": (ctypes.c_int, [c_void_p, c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
+                                                      POINTER(c_void_p), POINTER(c_int64), c_float, c_float, c_float, c_float, c_float,
+                                                      c_int32, c_int32, c_float, c_void_p]),
+    "nnhipConv2dForward": (ctypes.c_int, [P, P, P, P, POINTER(Conv2dDesc), c_void_p]),
+    "nnhipConv2dBackward": (ctypes.c_int, [P, P, P, P, P, P, POINTER(Conv2dDesc), c_void_p]),
+    "nnhipScale": (ctypes.c_int, [P, c_float, c_int64, c_void_p]),
+    "nnhipAdd": (ctypes.c_int, [P, P, P, c_int64, c_void_p]),
+}
+_NO_STATUS = {"nnhipVersion", "nnhipGetLastErrorString", "nnhipCreateFusedOptimizer"}
+
+_dll = None
+_funcs: dict = {}
+
+
+def lib_path() -> str:
+    return os.environ.get(LIB_ENV, DEFAULT_LIB)
+
+
+def load_library():
+    """ctypes.CDLL(path, RTLD_GLOBAL) like utils.py:64-70 -- but a missing library is an error, not a print."""
+    global _dll
+    if _dll is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise NeunetHipError(
+                f"libneunet_hip.so not found at {path!r}; build it with "
+                f"`python numpy-nn-model_amd/build.py` (or set ${LIB_ENV}). There is no CPU fallback.")
+        _dll = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    return _dll
+
+
+def load_hip_function(name: str):
+    """getattr + argtypes (utils.py:64-70)."""
+    f = _funcs.get(name)
+    if f is None:
+        dll = load_library()
+        try:
+            f = getattr(dll, name)
+        except AttributeError as exc:
+            raise NeunetHipError(f"libneunet_hip.so does not export {name}") from exc
+        restype, argtypes = _SIGNATURES[name]
+        f.restype = restype
+        f.argtypes = argtypes
+        _funcs[name] = f
+    return f
+
+
+def to_pointer(obj):
+    """Device array -> raw pointer (utils.py:72-82).  torch CUDA tensors play the role of CuPy arrays.
+    NumPy arrays are rejected exactly like the reference does (utils.py:75-76)."""
+    if obj is None:
+        return None
+    if hasattr(obj, "ctypes") and hasattr(obj, "__array_interface__"):
+        raise TypeError("NumPy arrays are not supported here.")
+    if hasattr(obj, "data_ptr"):
+        if not obj.is_cuda:
+            raise TypeError("Only device (cuda) tensors can be passed to HIP kernels.")
+        if not obj.is_contiguous():
+            raise ValueError("Device tensors passed to HIP kernels must be C-contiguous.")
+        return obj.data_ptr()
+    return obj
+
+
+def get_current_stream_ptr():
+    """Raw hipStream_t of torch's current stream (utils.py:87-92 took CuPy's current stream)."""
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def last_error() -> str:
+    s = load_hip_function("nnhipGetLastErrorString")()
+    return s.decode() if s else ""
+
+
+def call_hip_function(name: str, *args):
+    """call_cuda_function (utils.py:84-85) + status check."""
+    f = load_hip_function(name)
+    rc = f(*[to_pointer(a) for a in args])
+    if name not in _NO_STATUS and rc != 0:
+        raise NeunetHipError(f"{name} failed with status {rc}: {last_error()}")
+    return rc
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)

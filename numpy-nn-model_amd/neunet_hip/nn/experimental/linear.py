@@ -1,0 +1,113 @@
+"""HIPLinear -- drop-in for CUDALinear (neunet/nn/experimental/linear/linear.py:122-215).
+
+O = X W^T + b on the fp32 MFMA GEMM; backward = two GEMMs + a column sum, one C-ABI call.
+N-D inputs are flattened to rows = prod(shape[:-1]) exactly like the reference's CUDA path
+(linear.py:193), which equals the CPU path's batched-dW-then-reverse-broadcast result
+(neunet/nn/layers/linear.py:17-24 + autograd.py:948-962).
+"""
+from typing import Union
+
+import numpy as np
+
+from ...autograd import Tensor
+from ..modules import Module
+from ..parameter import Parameter
+from .utils import call_hip_function, get_current_stream_ptr
+
+
+def hip_linear_module_forward(X, weights, bias, O, input_rows, input_cols, output_cols):
+    """cuda_linear_module_forward (linear.py:70-92) -> nnhipLinearModuleForward."""
+    return call_hip_function("nnhipLinearModuleForward", X, weights, bias, O, input_rows, input_cols,
+                             output_cols, get_current_stream_ptr())
+
+
+def hip_linear_module_backward(X, weights, grad_O, grad_X, grad_weight, grad_bias, input_rows, input_cols,
+                               output_cols):
+    """cuda_linear_module_backward (linear.py:95-120) -> nnhipLinearModuleBackward.
+    grad_X / grad_weight / grad_bias may be None (skipped)."""
+    return call_hip_function("nnhipLinearModuleBackward", X, weights, grad_O, grad_X, grad_weight, grad_bias,
+                             input_rows, input_cols, output_cols, get_current_stream_ptr())
+
+
+def _grad_out(param, shape_like):
+    """Where a parameter gradient is written: straight into its slot of a flat DP gradient bucket when
+    one is attached and this is the first gradient of the step (no pack copy), else a fresh buffer."""
+    buf = getattr(param, "_grad_slot", None)
+    if buf is not None and param.grad is None:
+        return buf
+    return param.xp.empty_like(shape_like, dtype=np.float32)
+
+
+class _HIPLinearTensor(Tensor):
+    def __init__(self, data, args, op, device):
+        super().__init__(data, args, op, device=device, _nocopy=True)
+
+        def grad_fn(X: Tensor, weight: Tensor, bias, in_rows_num, in_features, out_features, grad):
+            grad = grad if grad.is_contiguous() else grad.contiguous()
+            grad_X = X.xp.empty_like(X.data, dtype=np.float32) if X.requires_grad else None
+            grad_weight = _grad_out(weight, weight.data)
+            grad_bias = _grad_out(bias, bias.data) if bias is not None else None
+            hip_linear_module_backward(X.data, weight.data, grad, grad_X, grad_weight, grad_bias,
+                                       in_rows_num, in_features, out_features)
+            if grad_X is not None:
+                X.apply_grad(grad_X)
+            weight.apply_grad(grad_weight)
+            if bias is not None:
+                bias.apply_grad(grad_bias)
+
+        self.grad_fn = grad_fn
+
+
+class HIPLinear(Module):
+    def __init__(self, in_features, out_features, bias: bool = True, device="cuda", backend="mfma"):
+        super().__init__()
+        if backend not in ("mfma", "cublaslt", "cutlass"):  # the reference's names are accepted and ignored
+            raise ValueError(f"Unknown backend: {backend}")
+        self.in_features = in_features
+        self.out_features = out_features
+        self.backend = "mfma"
+        stdv = 1.0 / np.sqrt(in_features)  # init as neunet/nn/layers/linear.py:34-45
+        self.weight = Parameter(Tensor(np.random.uniform(-stdv, stdv, (out_features, in_features)), dtype=np.float32))
+        if bias:
+            self.bias: Union[Tensor, None] = Parameter(
+                Tensor(np.random.uniform(-stdv, stdv, (1, out_features)), dtype=np.float32))
+        else:
+            self.bias = None
+        self.to(device)
+
+    def forward(self, X: Tensor) -> Tensor:
+        if not isinstance(X, Tensor):
+            raise TypeError("Input must be a tensor")
+        if X.device != self.device:
+            raise ValueError(f"Input tensor must be on {self.device}")
+        if X.device != "cuda":
+            raise NotImplementedError("HIPLinear runs on the HIP device only (no CPU fallback)")
+        if X.dtype != "float32":
+            raise NotImplementedError(f"Only float32 is supported, got {X.dtype} instead.")
+        if X.shape[-1] != self.in_features:
+            raise ValueError(f"Expected last dim {self.in_features}, got {X.shape[-1]}")
+        xdata = X.data if X.data.is_contiguous() else X.data.contiguous()
+        output = X.xp.empty(X.shape[:-1] + (self.out_features,), dtype=np.float32)
+        input_rows = int(np.prod(X.shape[:-1]))
+        hip_linear_module_forward(xdata, self.weight.data, self.bias.data if self.bias is not None else None,
+                                  output, input_rows, self.in_features, self.out_features)
+        if xdata is not X.data:
+            X = _ContiguousView(X, xdata)
+        return _HIPLinearTensor(output, (X, self.weight, self.bias, input_rows, self.in_features,
+                                         self.out_features), "linear", device=self.device)
+
+
+class _ContiguousView(Tensor):
+    """A contiguous copy of a non-contiguous parent that forwards its gradient to the parent."""
+
+    def __init__(self, parent: Tensor, data):
+        super().__init__(data, (parent,), "contiguous", requires_grad=parent.requires_grad,
+                         device=parent.device, _nocopy=True)
+
+        def grad_fn(p, grad):
+            p.apply_grad(grad)
+
+        self.grad_fn = grad_fn
+
+
+CUDALinear = HIPLinear  # drop-in alias for code written against the reference

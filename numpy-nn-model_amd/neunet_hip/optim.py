@@ -1,0 +1,130 @@
+"""Fused optimizers -- drop-ins for CUDAFusedAdamW (experimental/optim/fused_adamw/fused_adamw.py:45-113)
+and CUDAFusedMultiTensorAdamW (.../fused_adamw_multitensor.py:47-148), plus `Adam` / `AdamW` names that
+select the L2-on-gradient (neunet/optim.py:17-33) or decoupled (optim.py:52-69) decay mode of the same
+fused kernel."""
+import ctypes
+from ctypes import c_int64, c_void_p
+
+from ._lib import call_hip_function, get_current_stream_ptr, load_hip_function
+
+DECOUPLED, L2_ON_GRAD = 0, 1
+
+
+def _check_params(params):
+    import torch
+    for p in params:
+        if p.device != "cuda":
+            raise ValueError("Fused AdamW only supports parameters on the HIP device ('cuda').")
+        if p.data.dtype != torch.float32:
+            raise ValueError(f"Fused AdamW only supports float32 parameters, got {p.data.dtype}")
+
+
+class HIPFusedAdamW:
+    """One launch per tensor (fused_adamw.py:64-109)."""
+    decay_mode = DECOUPLED
+
+    def __init__(self, params, lr: float = 0.01, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.01):
+        import torch
+        self.params = list(params)
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        _check_params(self.params)
+        self.m = [torch.zeros_like(p.data) for p in self.params]
+        self.v = [torch.zeros_like(p.data) for p in self.params]
+        self.t = 0
+        self.grad_scale = 1.0
+
+    def step(self):
+        self.t += 1
+        stream = get_current_stream_ptr()
+        for i, p in enumerate(self.params):
+            if p.grad is None:
+                continue
+            g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+            if not p.data.is_contiguous():
+                p.data = p.data.contiguous()
+            call_hip_function("nnhipFusedAdamWStep", p.data, g, self.m[i], self.v[i], self.lr, self.betas[0],
+                              self.betas[1], self.eps, self.weight_decay, self.t, p.data.numel(),
+                              self.decay_mode, self.grad_scale, stream)
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+
+class HIPFusedMultiTensorAdamW:
+    """One launch for all tensors (fused_adamw_multitensor.py:88-144).  Pointer tables are ctypes arrays in
+    host memory whose entries are device pointers -- same contract as the reference."""
+    decay_mode = DECOUPLED
+
+    def __init__(self, params, lr: float = 0.01, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.01):
+        import torch
+        self.params = list(params)
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.t = 0
+        self.grad_scale = 1.0
+        _check_params(self.params)
+        self.m = [torch.zeros_like(p.data) for p in self.params]
+        self.v = [torch.zeros_like(p.data) for p in self.params]
+        self.opt_ptr = load_hip_function("nnhipCreateFusedOptimizer")()
+        if not self.opt_ptr:
+            raise RuntimeError("nnhipCreateFusedOptimizer failed")
+        n = len(self.params)
+        self.c_params = (c_void_p * n)()
+        self.c_grads = (c_void_p * n)()
+        self.c_exp_avgs = (c_void_p * n)()
+        self.c_exp_avg_sqs = (c_void_p * n)()
+        self.c_sizes = (c_int64 * n)()
+
+    def __del__(self):
+        ptr = getattr(self, "opt_ptr", None)
+        if ptr:
+            try:
+                load_hip_function("nnhipDestroyFusedOptimizer")(ptr)
+            except Exception:
+                pass
+            self.opt_ptr = None
+
+    def step(self):
+        self.t += 1
+        idx = 0
+        for i, p in enumerate(self.params):
+            if p.grad is None:  # fused_adamw_multitensor.py:92-96: skip params without a gradient
+                continue
+            g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+            if not p.data.is_contiguous():
+                p.data = p.data.contiguous()
+            self.c_params[idx] = p.data.data_ptr()
+            self.c_grads[idx] = g.data_ptr()
+            self.c_exp_avgs[idx] = self.m[i].data_ptr()
+            self.c_exp_avg_sqs[idx] = self.v[i].data_ptr()
+            self.c_sizes[idx] = p.data.numel()
+            idx += 1
+        if idx == 0:
+            return
+        call_hip_function("nnhipFusedAdamWMultiTensorStep", self.opt_ptr, idx,
+                          ctypes.cast(self.c_params, ctypes.POINTER(c_void_p)),
+                          ctypes.cast(self.c_grads, ctypes.POINTER(c_void_p)),
+                          ctypes.cast(self.c_exp_avgs, ctypes.POINTER(c_void_p)),
+                          ctypes.cast(self.c_exp_avg_sqs, ctypes.POINTER(c_void_p)),
+                          ctypes.cast(self.c_sizes, ctypes.POINTER(c_int64)),
+                          self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.t,
+                          self.decay_mode, self.grad_scale, get_current_stream_ptr())
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+
+class AdamW(HIPFusedMultiTensorAdamW):
+    """neunet.optim.AdamW (optim.py:39-73) on the fused multi-tensor kernel."""
+
+
+class Adam(HIPFusedMultiTensorAdamW):
+    """neunet.optim.Adam (optim.py:4-37): weight decay is L2-on-gradient; default weight_decay=0."""
+    decay_mode = L2_ON_GRAD
+
+    def __init__(self, params, lr: float = 0.01, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0):
+        super().__init__(params, lr, betas, eps, weight_decay)
+
+
+CUDAFusedAdamW, CUDAFusedMultiTensorAdamW = HIPFusedAdamW, HIPFusedMultiTensorAdamW

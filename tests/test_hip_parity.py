@@ -1,0 +1,578 @@
+"""GPU parity tests: every HIP kernel, called through the ctypes C-ABI, against the CPU oracle on the
+same seeded inputs and against the committed golden vectors (generated from the real reference).
+
+Mirrors the reference's CUDA tests one-to-one: same shapes, tolerances tightened where the
+fp32 MFMA path allows (LinearSwish 1e-4 instead of the reference's TF32 1e-3).
+Tolerances: fp32 outputs rtol=atol=1e-4 (north_star) unless a tighter one is written; argmax bit-exact.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from oracle import neunet_oracle as O  # noqa: E402  (checker only)
+
+
+@pytest.fixture(scope="module")
+def hip():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no HIP device is visible")
+    import neunet_hip
+    neunet_hip.load_library()  # fail loudly if the extension is missing
+    return neunet_hip
+
+
+def dev(a, dtype=None):
+    return torch.from_numpy(np.ascontiguousarray(a if dtype is None else a.astype(dtype))).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def T(hip, a, **kw):
+    return hip.Tensor(a, device="cuda", **kw)
+
+
+TOL = dict(rtol=1e-4, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------- Linear
+@pytest.mark.parametrize("name", ["linear_2d", "linear_3d", "linear_nobias"])
+def test_linear_golden(hip, golden, name):
+    g = golden(name)
+    from neunet_hip.nn.experimental import HIPLinear
+    layer = HIPLinear(24, 40, bias="b" in g)
+    layer.weight.data.copy_(dev(g["W"]))
+    if "b" in g:
+        layer.bias.data.copy_(dev(g["b"]))
+    x = T(hip, g["X"])
+    out = layer(x)
+    np.testing.assert_allclose(host(out.data), g["O"], rtol=1e-5, atol=1e-5)
+    out.backward(g["dO"])
+    np.testing.assert_allclose(host(x.grad), g["dX"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(host(layer.weight.grad), g["dW"], rtol=1e-5, atol=1e-5)
+    if "b" in g:
+        assert tuple(layer.bias.grad.shape) == (1, 40)
+        np.testing.assert_allclose(host(layer.bias.grad), g["db"], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("rows,inf,outf,bias", [
+    (128, 256, 512, True),     # tests/test_linear_cuda.py:15-89
+    (32, 784, 128, True),      # C1 layer 1
+    (32, 128, 10, True),       # C1 layer 2: N=10 -> scalar-load edge path
+    (200, 130, 70, False),     # nothing is a tile multiple, K%4 != 0
+    (1, 8, 8, True),
+    (513, 512, 300, True),     # M/N edges on a vector path
+    (2048, 64, 64, True),      # dW reduction long enough to take split-K
+])
+def test_linear_vs_oracle(hip, rows, inf, outf, bias):
+    from neunet_hip.nn.experimental import HIPLinear
+    rng = np.random.default_rng(rows * 7 + inf)
+    X = rng.uniform(-1, 1, (rows, inf)).astype(np.float32)
+    W = rng.uniform(-0.1, 0.1, (outf, inf)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, (1, outf)).astype(np.float32) if bias else None
+    dO = rng.uniform(-1, 1, (rows, outf)).astype(np.float32)
+    layer = HIPLinear(inf, outf, bias=bias)
+    layer.weight.data.copy_(dev(W))
+    if bias:
+        layer.bias.data.copy_(dev(b))
+    x = T(hip, X)
+    out = layer(x)
+    np.testing.assert_allclose(host(out.data), O.linear_forward(X, W, b), **TOL)
+    out.backward(dO)
+    dX, dW, db = O.linear_backward(X, W, b, dO)
+    np.testing.assert_allclose(host(x.grad), dX, **TOL)
+    np.testing.assert_allclose(host(layer.weight.grad), dW, rtol=1e-4, atol=2e-4)
+    if bias:
+        np.testing.assert_allclose(host(layer.bias.grad), db, rtol=1e-4, atol=2e-4)
+
+
+def test_linear_transpose_detecting(hip):
+    """A = I against an asymmetric B catches a swapped C-write (guide rule 16)."""
+    from neunet_hip.nn.experimental import HIPLinear
+    n = 160
+    layer = HIPLinear(n, n, bias=False)
+    W = (np.arange(n * n, dtype=np.float32).reshape(n, n) % 97) / 97.0
+    layer.weight.data.copy_(dev(W))
+    out = layer(T(hip, np.eye(n, dtype=np.float32)))
+    np.testing.assert_allclose(host(out.data), W.T, rtol=0, atol=0)
+
+
+def test_linear_3d_input_flattens(hip):
+    from neunet_hip.nn.experimental import HIPLinear
+    rng = np.random.default_rng(5)
+    X = rng.uniform(-1, 1, (4, 16, 512)).astype(np.float32)
+    W = rng.uniform(-0.05, 0.05, (2048, 512)).astype(np.float32)
+    b = rng.uniform(-0.05, 0.05, (1, 2048)).astype(np.float32)
+    dO = rng.uniform(-1, 1, (4, 16, 2048)).astype(np.float32)
+    layer = HIPLinear(512, 2048)
+    layer.weight.data.copy_(dev(W))
+    layer.bias.data.copy_(dev(b))
+    x = T(hip, X)
+    out = layer(x)
+    assert out.shape == (4, 16, 2048)
+    np.testing.assert_allclose(host(out.data), O.linear_forward(X, W, b), **TOL)
+    out.backward(dO)
+    dX, dW, db = O.linear_backward(X, W, b, dO)
+    np.testing.assert_allclose(host(x.grad), dX, **TOL)
+    np.testing.assert_allclose(host(layer.weight.grad), dW, rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(host(layer.bias.grad), db, rtol=1e-4, atol=2e-4)
+
+
+def test_gemm_batched_all_layouts(hip):
+    """nnhipGemmF32: 4 operand-layout combinations, batched, odd sizes."""
+    from neunet_hip._lib import call_hip_function, get_current_stream_ptr
+    rng = np.random.default_rng(9)
+    Bt, M, N, K = 3, 70, 45, 52
+    A = rng.standard_normal((Bt, M, K)).astype(np.float32)
+    Bm = rng.standard_normal((Bt, K, N)).astype(np.float32)
+    ref = np.matmul(A, Bm)
+    for akm in (1, 0):
+        for bkm in (1, 0):
+            a = A if akm else np.ascontiguousarray(A.transpose(0, 2, 1))      # (M,K) or (K,M)
+            b = np.ascontiguousarray(Bm.transpose(0, 2, 1)) if bkm else Bm    # (N,K) or (K,N)
+            da, db_, dc = dev(a), dev(b), torch.empty(Bt, M, N, device="cuda")
+            call_hip_function("nnhipGemmF32", da, db_, dc, None, M, N, K, a.shape[2], b.shape[2], N, akm, bkm,
+                              Bt, a.shape[1] * a.shape[2], b.shape[1] * b.shape[2], M * N,
+                              get_current_stream_ptr())
+            np.testing.assert_allclose(host(dc), ref, rtol=1e-4, atol=1e-4, err_msg=f"akm={akm} bkm={bkm}")
+
+
+# ------------------------------------------------------------------------------------ Linear -> Swish
+@pytest.mark.parametrize("rows,inf,outf,beta,save", [
+    (128, 256, 512, 1.0, True), (128, 256, 512, 1.5, False),   # tests/test_linear_swish_cutlass_cuda.py
+    (64, 128, 256, 1.5, True), (64, 128, 256, 1.0, False),
+])
+def test_linear_swish_vs_oracle(hip, rows, inf, outf, beta, save):
+    from neunet_hip.nn.experimental import HIPLinearSwish
+    rng = np.random.default_rng(rows + outf)
+    X = rng.uniform(-1, 1, (rows, inf)).astype(np.float32)
+    W = rng.uniform(-0.2, 0.2, (outf, inf)).astype(np.float32)
+    b = rng.uniform(-0.2, 0.2, (1, outf)).astype(np.float32)
+    dY = rng.uniform(-1, 1, (rows, outf)).astype(np.float32)
+    layer = HIPLinearSwish(inf, outf, swish_beta=beta, save_preactivation=save)
+    layer.weight.data.copy_(dev(W))
+    layer.bias.data.copy_(dev(b))
+    x = T(hip, X)
+    y = layer(x)
+    yr, _ = O.linear_swish_forward(X, W, b, beta)
+    np.testing.assert_allclose(host(y.data), yr, **TOL)      # reference tolerance here is 1e-3 (TF32)
+    y.backward(dY)
+    dX, dW, db = O.linear_swish_backward(X, W, b, dY, beta)
+    np.testing.assert_allclose(host(x.grad), dX, **TOL)
+    np.testing.assert_allclose(host(layer.weight.grad), dW, rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(host(layer.bias.grad), db, rtol=1e-4, atol=2e-4)
+
+
+def test_linear_swish_golden(hip, golden):
+    g = golden("linear_swish")
+    from neunet_hip.nn.experimental import HIPLinearSwish
+    layer = HIPLinearSwish(24, 40, swish_beta=float(g["beta"]))
+    layer.weight.data.copy_(dev(g["W"]))
+    layer.bias.data.copy_(dev(g["b"]))
+    x = T(hip, g["X"])
+    y = layer(x)
+    np.testing.assert_allclose(host(y.data), g["Y"], rtol=1e-5, atol=1e-5)
+    y.backward(g["dY"])
+    np.testing.assert_allclose(host(x.grad), g["dX"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(host(layer.weight.grad), g["dW"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(host(layer.bias.grad), g["db"], rtol=1e-5, atol=1e-5)
+
+
+# -------------------------------------------------------------------------------------- activations
+def test_relu(hip, golden):
+    g = golden("relu")
+    from neunet_hip.nn.experimental import HIPReLU
+    x = T(hip, g["X"])
+    y = HIPReLU()(x)
+    np.testing.assert_array_equal(host(y.data), g["Y"])
+    y.backward(g["dY"])
+    np.testing.assert_array_equal(host(x.grad), g["dX"])
+
+
+@pytest.mark.parametrize("name", ["swish_b1.0", "swish_b1.5"])
+def test_swish_golden(hip, golden, name):
+    g = golden(name)
+    from neunet_hip.nn.experimental import HIPSwish
+    x = T(hip, g["X"])
+    y = HIPSwish(float(g["beta"]))(x)
+    np.testing.assert_allclose(host(y.data), g["Y"], rtol=1e-5, atol=1e-5)
+    y.backward(g["dY"])
+    np.testing.assert_allclose(host(x.grad), g["dX"], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("shape", [(32, 128), (7, 33), (1, 1), (4096, 1030)])
+def test_swish_vs_oracle(hip, shape):
+    from neunet_hip.nn.experimental import HIPSwish
+    rng = np.random.default_rng(42)
+    X = (rng.standard_normal(shape) * 3).astype(np.float32)
+    dY = rng.standard_normal(shape).astype(np.float32)
+    x = T(hip, X)
+    y = HIPSwish(1.5)(x)
+    np.testing.assert_allclose(host(y.data), O.swish_forward(X, 1.5), rtol=1e-5, atol=1e-5)
+    y.backward(dY)
+    np.testing.assert_allclose(host(x.grad), O.swish_backward(X, dY, 1.5), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["swiglu_2d", "swiglu_3d"])
+def test_swiglu_golden(hip, golden, name):
+    g = golden(name)
+    from neunet_hip.nn.experimental import HIPFusedSwishAndMul
+    x = T(hip, g["X"])
+    y = HIPFusedSwishAndMul(float(g["beta"]))(x)
+    np.testing.assert_allclose(host(y.data), g["Y"], rtol=1e-5, atol=1e-5)
+    y.backward(g["dY"])
+    np.testing.assert_allclose(host(x.grad), g["dX"], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("shape,h,beta", [((32, 256), 128, 1.0), ((8, 16, 128), 64, 1.5), ((16, 128), 64, 1.0),
+                                          ((5, 14), 7, 1.0)])
+def test_swiglu_vs_oracle(hip, shape, h, beta):
+    """tests/test_fused_swish_and_mul_cuda.py shapes, module + raw kernels."""
+    from neunet_hip.nn.experimental.activations import (HIPFusedSwishAndMul, hip_fused_swish_and_mul,
+                                                        hip_fused_swish_and_mul_backward)
+    rng = np.random.default_rng(123)
+    X = rng.standard_normal(shape).astype(np.float32)
+    dY = rng.standard_normal(shape[:-1] + (h,)).astype(np.float32)
+    x = T(hip, X)
+    y = HIPFusedSwishAndMul(beta)(x)
+    np.testing.assert_allclose(host(y.data), O.swiglu_forward(X, beta), rtol=1e-5, atol=1e-5)
+    y.backward(dY)
+    np.testing.assert_allclose(host(x.grad), O.swiglu_backward(X, dY, beta), rtol=1e-5, atol=1e-5)
+    out = torch.empty(shape[:-1] + (h,), device="cuda")
+    hip_fused_swish_and_mul(dev(X), out, beta)
+    np.testing.assert_allclose(host(out), O.swiglu_forward(X, beta), rtol=1e-5, atol=1e-5)
+    gin = torch.empty(shape, device="cuda")
+    hip_fused_swish_and_mul_backward(gin, dev(dY), dev(X), beta)
+    np.testing.assert_allclose(host(gin), O.swiglu_backward(X, dY, beta), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["softmax_last", "softmax_axis1_4d", "softmax_axis1_2d"])
+def test_softmax_golden(hip, golden, name):
+    g = golden(name)
+    from neunet_hip.nn.experimental import HIPSoftmax
+    x = T(hip, g["X"])
+    y = HIPSoftmax(axis=int(g["axis"]))(x)
+    np.testing.assert_allclose(host(y.data), g["Y"], rtol=1e-5, atol=1e-6)
+    y.backward(g["dY"])
+    np.testing.assert_allclose(host(x.grad), g["dX"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("shape,axis", [
+    ((32, 128), -1), ((16, 256), 1),               # tests/test_softmax_cuda.py
+    ((4, 8, 64, 64), -1),                          # attention scores layout
+    ((64, 4096), -1), ((8, 8192), -1), ((3, 15000), -1), ((2, 20000), -1),   # each row-width bucket + looped
+    ((5, 10), 1), ((6, 1023), -1), ((3, 7, 5), 1), ((3, 7, 5), 0),
+])
+def test_softmax_vs_oracle(hip, shape, axis):
+    from neunet_hip.nn.experimental import HIPSoftmax
+    rng = np.random.default_rng(42)
+    X = (rng.standard_normal(shape) * 2).astype(np.float32)
+    dY = rng.standard_normal(shape).astype(np.float32)
+    x = T(hip, X)
+    y = HIPSoftmax(axis=axis)(x)
+    yr = O.softmax_forward(X, axis)
+    np.testing.assert_allclose(host(y.data), yr, rtol=1e-5, atol=1e-6)
+    y.backward(dY)
+    np.testing.assert_allclose(host(x.grad), O.softmax_backward(yr, dY, axis), rtol=1e-4, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------- RMSNorm
+@pytest.mark.parametrize("name", ["rmsnorm_2d", "rmsnorm_3d_bias"])
+def test_rmsnorm_golden(hip, golden, name):
+    g = golden(name)
+    from neunet_hip.nn.experimental import HIPRMSNorm
+    layer = HIPRMSNorm(g["X"].shape[-1], eps=float(g["eps"]), bias="b" in g)
+    layer.weight.data.copy_(dev(g["w"]))
+    if "b" in g:
+        layer.bias.data.copy_(dev(g["b"]))
+    x = T(hip, g["X"])
+    y = layer(x)
+    np.testing.assert_allclose(host(y.data), g["Y"], rtol=1e-5, atol=1e-5)
+    y.backward(g["dY"])
+    np.testing.assert_allclose(host(x.grad), g["dX"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(host(layer.weight.grad), g["dw"], rtol=1e-4, atol=1e-5)
+    if "b" in g:
+        np.testing.assert_allclose(host(layer.bias.grad), g["db"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("shape,bias", [((32, 128), False), ((16, 256), False),   # tests/test_rmsnorm_cuda.py
+                                        ((4, 64, 512), True), ((2100, 4096), True), ((9, 8192), False),
+                                        ((5, 12000), True), ((7, 130), True), ((3, 6), False)])
+def test_rmsnorm_vs_oracle(hip, shape, bias):
+    from neunet_hip.nn.experimental import HIPRMSNorm
+    rng = np.random.default_rng(42)
+    X = rng.standard_normal(shape).astype(np.float32)
+    w = rng.uniform(0.5, 1.5, shape[-1]).astype(np.float32)
+    b = rng.uniform(-0.5, 0.5, shape[-1]).astype(np.float32) if bias else None
+    dY = rng.standard_normal(shape).astype(np.float32)
+    layer = HIPRMSNorm(shape[-1], eps=1e-6, bias=bias)
+    layer.weight.data.copy_(dev(w))
+    if bias:
+        layer.bias.data.copy_(dev(b))
+    x = T(hip, X)
+    y = layer(x)
+    Yr, _, _ = O.rmsnorm_forward(X, w, b, 1e-6)
+    np.testing.assert_allclose(host(y.data), Yr, **TOL)
+    y.backward(dY)
+    dX, dw, db = O.rmsnorm_backward(X, w, bias, dY, 1e-6)
+    np.testing.assert_allclose(host(x.grad), dX, **TOL)
+    rows = int(np.prod(shape[:-1]))
+    np.testing.assert_allclose(host(layer.weight.grad), dw, rtol=1e-4, atol=1e-4 * max(1.0, np.sqrt(rows)))
+    if bias:
+        np.testing.assert_allclose(host(layer.bias.grad), db, rtol=1e-4, atol=1e-4 * max(1.0, np.sqrt(rows)))
+
+
+# ------------------------------------------------------------------------------------ CrossEntropy
+@pytest.mark.parametrize("name", ["ce_mean", "ce_sum", "ce_none", "ce_mean_ign", "ce_sum_ign", "ce_none_ign",
+                                  "ce_mean_pad0", "ce_mean_small"])
+@pytest.mark.parametrize("inplace", [False, True])
+def test_cross_entropy_golden(hip, golden, name, inplace):
+    g = golden(name)
+    from neunet_hip.nn.experimental import HIPCrossEntropyLoss
+    x = T(hip, g["logits"])
+    y = T(hip, g["labels"], dtype=np.int32, requires_grad=False)
+    loss = HIPCrossEntropyLoss(reduction=str(g["reduction"]), ignore_index=int(g["ignore_index"]), inplace=inplace)(x, y)
+    np.testing.assert_allclose(host(loss.data).reshape(g["loss"].shape), g["loss"], rtol=1e-5, atol=1e-5)
+    loss.backward()
+    np.testing.assert_allclose(host(x.grad), g["dlogits"], rtol=1e-5, atol=1e-6)
+    if not inplace:
+        np.testing.assert_array_equal(host(x.data), g["logits"])  # CPU semantics: logits survive
+
+
+@pytest.mark.parametrize("rows,C", [(32, 128), (16, 256), (8, 64),            # tests/test_crossentropyloss_cuda.py
+                                    (32, 10), (64, 15000), (5, 4099), (3, 20001), (40, 1000)])
+@pytest.mark.parametrize("reduction", ["none", "mean", "sum"])
+def test_cross_entropy_vs_oracle(hip, rows, C, reduction):
+    from neunet_hip.nn.experimental import HIPCrossEntropyLoss
+    rng = np.random.default_rng(42)
+    logits = (rng.standard_normal((rows, C)) * 3).astype(np.float32)
+    labels = rng.integers(1, C, rows).astype(np.int32)
+    labels[:: 5] = 0                      # PAD=0 is the ignored label (GPT config)
+    x = T(hip, logits)
+    loss = HIPCrossEntropyLoss(reduction=reduction, ignore_index=0)(x, T(hip, labels, dtype=np.int32, requires_grad=False))
+    lr, dl = O.cross_entropy_forward_backward(logits, labels, None, 0, reduction)
+    np.testing.assert_allclose(host(loss.data), lr, rtol=1e-5, atol=1e-5)
+    loss.backward()
+    np.testing.assert_allclose(host(x.grad), dl, rtol=1e-4, atol=1e-6)
+    assert np.all(host(x.grad)[labels == 0] == 0)
+
+
+# ------------------------------------------------------------------------------------------- Conv2d
+@pytest.mark.parametrize("name", ["conv2d_s2p1d2", "conv2d_s2_uncovered", "conv2d_pad4", "conv2d_c5_l1",
+                                  "conv2d_c5_l2"])
+def test_conv2d_golden(hip, golden, name):
+    g = golden(name)
+    from neunet_hip.nn.experimental import HIPConv2d
+    Cout, Cin, kh, kw = g["W"].shape
+    pad = tuple(int(p) for p in g["padding"])
+    layer = HIPConv2d(Cin, Cout, (kh, kw), tuple(int(s) for s in g["stride"]), pad,
+                      tuple(int(d) for d in g["dilation"]))
+    assert tuple(layer.padding) == tuple(int(p) for p in g["padding4"])
+    layer.weight.data.copy_(dev(g["W"]))
+    layer.bias.data.copy_(dev(g["b"]))
+    x = T(hip, g["X"])
+    y = layer(x)
+    assert y.shape == g["O"].shape
+    np.testing.assert_allclose(host(y.data), g["O"], rtol=1e-5, atol=1e-5)
+    y.backward(g["dO"])
+    np.testing.assert_allclose(host(x.grad), g["dX"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(host(layer.weight.grad), g["dW"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(host(layer.bias.grad), g["db"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_array_equal(host(layer.weight.data), g["W"])  # never mutated (Appendix A.2)
+
+
+@pytest.mark.parametrize("xshape,cout,ks,stride,pad,dil", [
+    ((16, 1, 28, 28), 8, 3, (1, 1), (1, 1), (1, 1)),       # C5 layer 1
+    ((16, 8, 14, 14), 16, 3, (1, 1), (1, 1), (1, 1)),      # C5 layer 2
+    ((3, 5, 17, 13), 40, (3, 2), (2, 1), (2, 0), (1, 2)),  # Cout > 32 (two m-tiles), odd everything
+    ((2, 40, 9, 9), 6, 3, (1, 1), (0, 0), (1, 1)),         # Cin*kh*kw + 1 = 361 columns > 128 (3 n-groups)
+    ((1, 1, 5, 5), 1, 1, (1, 1), (0, 0), (1, 1)),
+])
+def test_conv2d_vs_oracle(hip, xshape, cout, ks, stride, pad, dil):
+    from neunet_hip.nn.experimental import HIPConv2d
+    rng = np.random.default_rng(15)
+    X = rng.uniform(-1, 1, xshape).astype(np.float32)
+    layer = HIPConv2d(xshape[1], cout, ks, stride, pad, dil)
+    W = host(layer.weight.data)
+    b = rng.uniform(-0.3, 0.3, cout).astype(np.float32)
+    layer.bias.data.copy_(dev(b))
+    x = T(hip, X)
+    y = layer(x)
+    Or = O.conv2d_forward(X, W, b, stride, pad, dil)
+    assert y.shape == Or.shape
+    np.testing.assert_allclose(host(y.data), Or, **TOL)
+    dO = rng.uniform(-1, 1, Or.shape).astype(np.float32)
+    y.backward(dO)
+    dX, dW, db = O.conv2d_backward(X, W, True, dO, stride, pad, dil)
+    np.testing.assert_allclose(host(x.grad), dX, **TOL)
+    scale = max(1.0, np.sqrt(Or.size / cout))
+    np.testing.assert_allclose(host(layer.weight.grad), dW, rtol=1e-4, atol=1e-5 * scale)
+    np.testing.assert_allclose(host(layer.bias.grad), db, rtol=1e-4, atol=1e-5 * scale)
+
+
+# -------------------------------------------------------------------------------------- optimizers
+@pytest.mark.parametrize("name", ["adam_wd0", "adam_wd1e-2", "adamw_wd0", "adamw_wd1e-2"])
+@pytest.mark.parametrize("multi", [False, True])
+def test_adam_golden(hip, golden, name, multi):
+    g = golden(name)
+    from neunet_hip.nn import Parameter
+    from neunet_hip.optim import Adam, AdamW, HIPFusedAdamW
+    n = int(g["n_tensors"])
+    params = [Parameter(T(hip, g[f"p0_{i}"])) for i in range(n)]
+    is_w = name.startswith("adamw")
+    if multi:
+        opt = (AdamW if is_w else Adam)(params, lr=float(g["lr"]), weight_decay=float(g["wd"]))
+    else:
+        opt = HIPFusedAdamW(params, lr=float(g["lr"]), weight_decay=float(g["wd"]))
+        opt.decay_mode = 0 if is_w else 1
+    for s in range(3):
+        for i, p in enumerate(params):
+            p.grad = dev(g[f"g{s}_{i}"])
+        opt.step()
+        for i, p in enumerate(params):
+            np.testing.assert_allclose(host(p.data), g[f"p{s + 1}_{i}"], rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(host(opt.m[i]), g[f"m{s + 1}_{i}"], rtol=1e-5, atol=1e-7)
+            np.testing.assert_allclose(host(opt.v[i]), g[f"v{s + 1}_{i}"], rtol=1e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("shapes", [[(128, 256)], [(64, 128)] * 3, [(32, 64)] * 5, [(1000, 333), (7,), (16385,)]])
+@pytest.mark.parametrize("wd", [1e-2, 0.0])
+def test_fused_adamw_vs_oracle(hip, shapes, wd):
+    """tests/test_fusedadamw_cuda.py: one step of both fused optimizers vs AdamW; then 2 more steps with
+    some gradients missing (skipped params) and changing pointers."""
+    from neunet_hip.nn import Parameter
+    from neunet_hip.optim import HIPFusedAdamW, HIPFusedMultiTensorAdamW
+    rng = np.random.default_rng(123)
+    p0 = [rng.standard_normal(s).astype(np.float32) for s in shapes]
+    for cls in (HIPFusedAdamW, HIPFusedMultiTensorAdamW):
+        params = [Parameter(T(hip, a)) for a in p0]
+        opt = cls(params, lr=1e-3, weight_decay=wd)
+        ref_p = [a.copy() for a in p0]
+        ref_m = [np.zeros_like(a) for a in p0]
+        ref_v = [np.zeros_like(a) for a in p0]
+        for step in range(1, 4):
+            gs = [rng.standard_normal(s).astype(np.float32) for s in shapes]
+            for i, p in enumerate(params):
+                skip = step == 2 and i == 0 and len(shapes) > 1
+                p.grad = None if skip else dev(gs[i])
+                if not skip:
+                    ref_m[i], ref_v[i] = O.adamw_step(ref_p[i], gs[i], ref_m[i], ref_v[i], step, 1e-3,
+                                                      (0.9, 0.999), 1e-8, wd)
+            opt.step()
+            for i, p in enumerate(params):
+                np.testing.assert_allclose(host(p.data), ref_p[i], rtol=1e-4, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------- C1 end-to-end trajectory
+def test_mlp_c1_trajectory_golden(hip, golden):
+    """README quick-start loop on the HIP path vs the REAL reference's trajectory:
+    losses, argmax (bit-exact), first-step grads, weights after 3 Adam steps."""
+    g = golden("mlp_c1")
+    import neunet_hip.nn as nn
+    from neunet_hip.optim import Adam
+
+    class MLP(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.l1 = nn.Linear(784, 128)
+            self.relu = nn.ReLU()
+            self.l2 = nn.Linear(128, 10)
+
+        def forward(self, x):
+            return self.l2(self.relu(self.l1(x)))
+
+    model = MLP()
+    model.l1.weight.data.copy_(dev(g["W1"]))
+    model.l1.bias.data.copy_(dev(g["b1"]))
+    model.l2.weight.data.copy_(dev(g["W2"]))
+    model.l2.bias.data.copy_(dev(g["b2"]))
+    opt = Adam(model.parameters(), lr=1e-3)
+    loss_fn = nn.CrossEntropyLoss()
+    for s in range(3):
+        opt.zero_grad()
+        out = model(T(hip, g["X"][s], requires_grad=False))
+        loss = loss_fn(out, T(hip, g["Y"][s], dtype=np.int32, requires_grad=False))
+        loss.backward()
+        if s == 0:
+            ps = model.parameters()
+            np.testing.assert_allclose(host(ps[0].grad)[::8], g["dW1_step0_rows"], rtol=1e-4, atol=1e-6)
+            np.testing.assert_allclose(host(ps[1].grad), g["db1_step0"], rtol=1e-4, atol=1e-6)
+            np.testing.assert_allclose(host(ps[2].grad), g["dW2_step0"], rtol=1e-4, atol=1e-6)
+            np.testing.assert_allclose(host(ps[3].grad), g["db2_step0"], rtol=1e-4, atol=1e-6)
+        opt.step()
+        assert abs(loss.item() - g["losses"][s]) < 1e-4
+        np.testing.assert_array_equal(host(hip.argmax(out, axis=1).data), g["argmax"][s])
+    np.testing.assert_allclose(host(model.l1.weight.data)[::8], g["W1_final_rows"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(host(model.l1.bias.data), g["b1_final"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(host(model.l2.weight.data), g["W2_final"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(host(model.l2.bias.data), g["b2_final"], rtol=1e-4, atol=1e-5)
+
+
+# ------------------------------------------------------------- full-size, size-independent properties
+def test_linear_c2_full_size_properties(hip):
+    """BASELINE C2 (4096x4096x4096) is too slow for the oracle; check sampled rows against float64 dot
+    products and linearity:  L(x1 + x2) - b = (L(x1) - b) + (L(x2) - b)."""
+    from neunet_hip.nn.experimental import HIPLinear
+    rng = np.random.default_rng(1002)
+    n = 4096
+    X = rng.uniform(-1, 1, (n, n)).astype(np.float32)
+    layer = HIPLinear(n, n)
+    W, b = host(layer.weight.data), host(layer.bias.data)
+    x = T(hip, X)
+    out = layer(x)
+    o = host(out.data)
+    rows = rng.choice(n, 16, replace=False)
+    ref = X[rows].astype(np.float64) @ W.T.astype(np.float64) + b
+    np.testing.assert_allclose(o[rows], ref, rtol=1e-4, atol=1e-4)
+    dO = rng.uniform(-1, 1, (n, n)).astype(np.float32)
+    out.backward(dO)
+    dX, dW, db = host(x.grad), host(layer.weight.grad), host(layer.bias.grad)
+    np.testing.assert_allclose(dX[rows], dO[rows].astype(np.float64) @ W.astype(np.float64), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(dW[rows], dO[:, rows].T.astype(np.float64) @ X.astype(np.float64), rtol=1e-4, atol=2e-3)
+    np.testing.assert_allclose(db[0], dO.astype(np.float64).sum(0), rtol=1e-4, atol=1e-3)
+    X2 = rng.uniform(-1, 1, (n, n)).astype(np.float32)
+    o2 = host(layer(T(hip, X2)).data)
+    o12 = host(layer(T(hip, X + X2)).data)
+    np.testing.assert_allclose(o12 - b, (o - b) + (o2 - b), rtol=1e-3, atol=2e-3)
+
+
+def test_fused_c3_full_size_properties(hip):
+    """C3 sizes (8192 x 4096): softmax rows sum to 1 / grads sum to 0; RMSNorm output has unit RMS;
+    CE gradient rows sum to 0 and sum(loss)/count == mean; Swish matches the oracle on a row sample."""
+    from neunet_hip.nn.experimental import HIPCrossEntropyLoss, HIPRMSNorm, HIPSoftmax, HIPSwish
+    rng = np.random.default_rng(1003)
+    R, D = 8192, 4096
+    X = rng.standard_normal((R, D)).astype(np.float32)
+    x = T(hip, X)
+    y = HIPSoftmax(axis=-1)(x)
+    s = y.data.sum(dim=1)
+    assert torch.allclose(s, torch.ones_like(s), atol=1e-5)
+    y.backward(X)
+    assert float(x.grad.sum(dim=1).abs().max()) < 1e-4
+    rows = rng.choice(R, 8, replace=False)
+    np.testing.assert_allclose(host(y.data)[rows], O.softmax_forward(X[rows], -1), rtol=1e-5, atol=1e-7)
+
+    x = T(hip, X)
+    yn = HIPRMSNorm(D)(x)
+    rms = (yn.data ** 2).mean(dim=1).sqrt()
+    assert torch.allclose(rms, torch.ones_like(rms), atol=1e-4)
+
+    x = T(hip, X)
+    ys = HIPSwish(1.0)(x)
+    np.testing.assert_allclose(host(ys.data)[rows], O.swish_forward(X[rows], 1.0), rtol=1e-5, atol=1e-6)
+
+    labels = rng.integers(1, D, R).astype(np.int32)
+    labels[::10] = 0
+    x = T(hip, X)
+    loss = HIPCrossEntropyLoss(reduction="mean", ignore_index=0)(x, T(hip, labels, dtype=np.int32, requires_grad=False))
+    loss.backward()
+    assert float(x.grad.sum(dim=1).abs().max()) < 1e-6
+    lr, dl = O.cross_entropy_forward_backward(X[rows], labels[rows], None, 0, "sum")
+    cnt = int((labels != 0).sum())
+    np.testing.assert_allclose(host(x.grad)[rows], dl / cnt, rtol=1e-4, atol=1e-9)
+    ref_mean = O.cross_entropy_forward_backward(X, labels, None, 0, "mean")[0]
+    assert abs(loss.item() - float(ref_mean)) < 1e-4
