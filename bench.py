@@ -1,0 +1,412 @@
+#!/usr/bin/env python3
+"""bench.py -- training-step throughput of the neunet dense hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload c2|c1|c3]
+
+Default workload = BASELINE.json configs[1] ("C2"): one data-parallel training step of a single
+Linear(4096->4096) layer on a batch of 4096 rows per GPU (weak scaling):
+    zero_grad -> forward (MFMA GEMM + bias) -> backward (dX, dW GEMMs + db) ->
+    flat-bucket gradient all-reduce (RCCL; no-op at N=1) -> fused AdamW (grad_scale = 1/N).
+Inputs (X, dO, weights) are resident in HBM before the timed region.  One JSON line on rank 0.
+
+`roofline`   : dominant kernel = the fp32 MFMA GEMM (forward variant), HIP-event timed inside the timed
+               region on the launch stream; peak = 157.3 TFLOP/s fp32 MFMA (MI355X_MICROARCH.md).
+`cpu_baseline`: the NumPy oracle (the reference's CPU algorithm, kind "port") timed on this box's host
+               cores on the same workload, bounded to ~15 s.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "numpy-nn-model_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md "HBM3E peak BW" (spec; ~6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def timed_region(step_fn, steps, warmup, world):
+    """W untimed steps, then EXACTLY K steps bracketed by barrier + synchronize; max over ranks."""
+    import torch
+    import torch.distributed as dist
+    for _ in range(warmup):
+        step_fn(False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+class EventTimer:
+    """HIP-event pairs on the launch stream (torch's current stream == the stream handed to the C ABI)."""
+
+    def __init__(self):
+        self.pairs = []
+
+    def span(self):
+        import torch
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.pairs.append((a, b))
+        return a, b
+
+    def mean_ms(self):
+        return float(np.mean([a.elapsed_time(b) for a, b in self.pairs])) if self.pairs else float("nan")
+
+
+def read_traffic(tag):
+    """HBM bytes per launch from the committed PMC pass (profiles/r01_pmc.json), or None."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(path):
+        try:
+            return json.load(open(path)).get(tag)
+        except Exception:
+            return None
+    return None
+
+
+# ------------------------------------------------------------------------------------------------ C2
+def workload_c2(args, rank, world):
+    import torch
+    import neunet_hip
+    from neunet_hip.distributed import GradBucket
+    from neunet_hip.nn.experimental import HIPLinear
+    from neunet_hip.optim import HIPFusedMultiTensorAdamW
+    Bsz, D = 4096, 4096
+    rng = np.random.default_rng(1002)                     # same weights on every rank
+    layer = HIPLinear(D, D)
+    layer.weight.data.copy_(torch.from_numpy(rng.uniform(-1 / 64, 1 / 64, (D, D)).astype(np.float32)))
+    layer.bias.data.copy_(torch.from_numpy(rng.uniform(-1 / 64, 1 / 64, (1, D)).astype(np.float32)))
+    drng = np.random.default_rng(2000 + rank)             # a different shard per rank
+    X = neunet_hip.Tensor(drng.uniform(-1, 1, (Bsz, D)).astype(np.float32), device="cuda", requires_grad=True)
+    dO = torch.from_numpy(drng.uniform(-1, 1, (Bsz, D)).astype(np.float32)).cuda()
+    params = layer.parameters()
+    bucket = GradBucket(params)
+    opt = HIPFusedMultiTensorAdamW(params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    opt.grad_scale = 1.0 / world
+    fwd_t, bwd_t = EventTimer(), EventTimer()
+
+    def step(timed):
+        opt.zero_grad()
+        X.grad = None
+        if timed:
+            a, b = fwd_t.span()
+            a.record()
+        out = layer(X)
+        if timed:
+            b.record()
+            c, d = bwd_t.span()
+            c.record()
+        out.backward(dO)
+        if timed:
+            d.record()
+        bucket.all_reduce()
+        opt.step()
+
+    dt = timed_region(step, args.steps, args.warmup, world)
+    flops = 2.0 * Bsz * D * D
+    fwd_ms, bwd_ms = fwd_t.mean_ms(), bwd_t.mean_ms()
+    ach = flops / (fwd_ms * 1e-3) / 1e12
+    res = {
+        "samples_per_step": Bsz * world,
+        "dt": dt,
+        "config": {"workload": "C2: Linear(4096->4096) training step (fwd + bwd + grad all-reduce + fused AdamW), "
+                               "batch 4096 per GPU, fp32 MFMA", "global_batch": Bsz * world,
+                   "parallelism": f"dp{world}"},
+        "roofline": {"kernel": "gemm_f32_kernel<32,k-major,k-major> (Linear forward, 1 launch/step)",
+                     "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": read_traffic("gemm_fwd_c2"),
+                     "flops_per_launch": flops, "avg_launch_ms": round(fwd_ms, 4)},
+        "extra": {"linear_fwd_tflops": round(ach, 2),
+                  "linear_bwd_tflops": round(2 * flops / (bwd_ms * 1e-3) / 1e12, 2),
+                  "linear_bwd_ms": round(bwd_ms, 4),
+                  "note": "bwd = dX GEMM + dW GEMM + db column-sum (2 small kernels)"},
+    }
+    return res
+
+
+def cpu_c2(seconds):
+    """The same step through the NumPy oracle (= the reference's CPU algorithm) on the host cores."""
+    from oracle import neunet_oracle as O
+    Bsz, D = 4096, 4096
+    rng = np.random.default_rng(1002)
+    W = rng.uniform(-1 / 64, 1 / 64, (D, D)).astype(np.float32)
+    b = rng.uniform(-1 / 64, 1 / 64, (1, D)).astype(np.float32)
+    X = rng.uniform(-1, 1, (Bsz, D)).astype(np.float32)
+    dO = rng.uniform(-1, 1, (Bsz, D)).astype(np.float32)
+    mW, vW, mb, vb = np.zeros_like(W), np.zeros_like(W), np.zeros_like(b), np.zeros_like(b)
+
+    def step(t):
+        nonlocal mW, vW, mb, vb
+        O.linear_forward(X, W, b)
+        _, dW, db = O.linear_backward(X, W, b, dO)
+        mW, vW = O.adamw_step(W, dW, mW, vW, t, 1e-3, (0.9, 0.999), 1e-8, 1e-2)
+        mb, vb = O.adamw_step(b, db, mb, vb, t, 1e-3, (0.9, 0.999), 1e-8, 1e-2)
+
+    step(1)
+    times, t, t_start = [], 2, time.perf_counter()
+    while time.perf_counter() - t_start < seconds and len(times) < 50:
+        t0 = time.perf_counter()
+        step(t)
+        times.append(time.perf_counter() - t0)
+        t += 1
+    best = min(times)
+    return {"value": round(Bsz / best, 2), "unit": "samples/s", "cores": blas_threads(), "kind": "port",
+            "sample": f"{len(times)} full C2 steps (Linear 4096x4096x4096 fwd+bwd+AdamW) via the NumPy oracle, "
+                      f"min step {best * 1e3:.1f} ms, OpenBLAS threads={blas_threads()}, host cpus={os.cpu_count()}"}
+
+
+# ------------------------------------------------------------------------------------------------ C1
+def workload_c1(args, rank, world):
+    """README quick-start MLP 784->128->10, batch 32 per GPU, CE(mean) + Adam(1e-3): launch-latency bound."""
+    import torch
+    import neunet_hip
+    import neunet_hip.nn as nn
+    from neunet_hip.distributed import GradBucket
+    from neunet_hip.optim import Adam
+    Bsz = 32
+    np.random.seed(1001)
+
+    class MLP(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.l1 = nn.Linear(784, 128)
+            self.relu = nn.ReLU()
+            self.l2 = nn.Linear(128, 10)
+
+        def forward(self, x):
+            return self.l2(self.relu(self.l1(x)))
+
+    model = MLP()
+    params = model.parameters()
+    bucket = GradBucket(params)
+    opt = Adam(params, lr=1e-3)
+    opt.grad_scale = 1.0 / world
+    loss_fn = nn.CrossEntropyLoss()
+    drng = np.random.default_rng(3000 + rank)
+    X = neunet_hip.Tensor(drng.uniform(-1, 1, (Bsz, 784)).astype(np.float32), device="cuda", requires_grad=False)
+    Y = neunet_hip.Tensor(drng.integers(0, 10, Bsz).astype(np.int32), dtype=np.int32, requires_grad=False, device="cuda")
+    ev = EventTimer()
+
+    def step(timed):
+        opt.zero_grad()
+        if timed:
+            a, b = ev.span()
+            a.record()
+        out = model(X)
+        loss = loss_fn(out, Y)
+        loss.backward()
+        bucket.all_reduce()
+        opt.step()
+        if timed:
+            b.record()
+
+    dt = timed_region(step, args.steps, args.warmup, world)
+    dev_ms = ev.mean_ms()
+    flops = 2.0 * 3 * Bsz * (784 * 128 + 128 * 10)
+    return {
+        "samples_per_step": Bsz * world, "dt": dt,
+        "config": {"workload": "C1: MNIST-MLP 784->128->10 training step (Linear+ReLU+CrossEntropy+Adam), batch 32 per GPU",
+                   "global_batch": Bsz * world, "parallelism": f"dp{world}"},
+        "roofline": {"kernel": "whole step (13 launches, launch-latency bound)", "bound": "mfma",
+                     "achieved": round(flops / (dev_ms * 1e-3) / 1e12, 5), "peak": PEAK_F32_MFMA_TFLOPS,
+                     "unit": "TFLOP/s", "frac": round(flops / (dev_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 6),
+                     "traffic": None, "avg_step_device_ms": round(dev_ms, 4)},
+        "extra": {},
+    }
+
+
+def cpu_c1(seconds):
+    from oracle import neunet_oracle as O
+    rng = np.random.default_rng(1001)
+    W1 = rng.uniform(-1 / 28, 1 / 28, (128, 784)).astype(np.float32)
+    b1 = rng.uniform(-1 / 28, 1 / 28, (1, 128)).astype(np.float32)
+    s2 = 1 / np.sqrt(128)
+    W2 = rng.uniform(-s2, s2, (10, 128)).astype(np.float32)
+    b2 = rng.uniform(-s2, s2, (1, 10)).astype(np.float32)
+    st = O.MLPState(W1, b1, W2, b2, lr=1e-3)
+    X = rng.uniform(-1, 1, (32, 784)).astype(np.float32)
+    Y = rng.integers(0, 10, 32).astype(np.int32)
+    for _ in range(3):
+        st.step(X, Y)
+    times, t_start = [], time.perf_counter()
+    while time.perf_counter() - t_start < min(seconds, 5.0):
+        t0 = time.perf_counter()
+        st.step(X, Y)
+        times.append(time.perf_counter() - t0)
+    best = min(times)
+    return {"value": round(32 / best, 1), "unit": "samples/s", "cores": blas_threads(), "kind": "port",
+            "sample": f"{len(times)} C1 MLP steps via the NumPy oracle, min step {best * 1e3:.3f} ms"}
+
+
+# ------------------------------------------------------------------------------------------------ C3
+def workload_c3(args, rank, world):
+    """Fused micro-bench, rows 8192 x d 4096 per GPU: Swish, RMSNorm, Softmax fwd+bwd, fused CE fwd+bwd,
+    multi-tensor AdamW on one 8192x4096 tensor.  A 'step' is one pass over all of them; the roofline entry
+    is the Swish forward kernel (HBM bound), per-op GB/s in `extra`."""
+    import torch
+    import neunet_hip
+    from neunet_hip.nn.experimental import HIPCrossEntropyLoss, HIPRMSNorm, HIPSoftmax, HIPSwish
+    from neunet_hip.nn import Parameter
+    from neunet_hip.optim import HIPFusedMultiTensorAdamW
+    R, D = 8192, 4096
+    rng = np.random.default_rng(1003 + rank)
+    Xn = rng.standard_normal((R, D)).astype(np.float32)
+    x = neunet_hip.Tensor(Xn, device="cuda")
+    dY = torch.from_numpy(rng.standard_normal((R, D)).astype(np.float32)).cuda()
+    labels = neunet_hip.Tensor(rng.integers(0, D, R).astype(np.int32), dtype=np.int32, requires_grad=False, device="cuda")
+    swish, norm, soft = HIPSwish(1.0), HIPRMSNorm(D), HIPSoftmax(-1)
+    ce = HIPCrossEntropyLoss(reduction="mean")
+    p = Parameter(neunet_hip.Tensor(Xn, device="cuda"))
+    opt = HIPFusedMultiTensorAdamW([p], lr=1e-3, weight_decay=1e-2)
+    timers = {k: EventTimer() for k in ["swish_fwd", "swish_bwd", "rmsnorm_fwd", "rmsnorm_bwd", "softmax_fwd",
+                                        "softmax_bwd", "ce_fwd_bwd", "adamw"]}
+    n = R * D
+    bytes_per = {"swish_fwd": 8 * n, "swish_bwd": 12 * n, "rmsnorm_fwd": 8 * n + 4 * R + 4 * D,
+                 "rmsnorm_bwd": 12 * n + 4 * R + 8 * D, "softmax_fwd": 8 * n, "softmax_bwd": 12 * n,
+                 "ce_fwd_bwd": 8 * n + 12 * R, "adamw": 28 * n}
+
+    def fb(mod, kf, kb, timed):
+        x.grad = None
+        if timed:
+            a, b = timers[kf].span()
+            a.record()
+        y = mod(x)
+        if timed:
+            b.record()
+        y.grad = dY
+        if timed:
+            c, d = timers[kb].span()
+            c.record()
+        y.grad_fn(*y.args, grad=dY)
+        if timed:
+            d.record()
+
+    def step(timed):
+        fb(swish, "swish_fwd", "swish_bwd", timed)
+        fb(norm, "rmsnorm_fwd", "rmsnorm_bwd", timed)
+        norm.weight.grad = None
+        fb(soft, "softmax_fwd", "softmax_bwd", timed)
+        if timed:
+            a, b = timers["ce_fwd_bwd"].span()
+            a.record()
+        ce(x, labels)
+        if timed:
+            b.record()
+        p.grad = dY
+        if timed:
+            a, b = timers["adamw"].span()
+            a.record()
+        opt.step()
+        if timed:
+            b.record()
+
+    dt = timed_region(step, args.steps, args.warmup, world)
+    ops = {k: {"ms": round(t.mean_ms(), 4), "GBps": round(bytes_per[k] / (t.mean_ms() * 1e-3) / 1e9, 1),
+               "frac_of_8TBps": round(bytes_per[k] / (t.mean_ms() * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+           for k, t in timers.items()}
+    sw = ops["swish_fwd"]
+    return {
+        "samples_per_step": R * world, "dt": dt,
+        "config": {"workload": "C3: fused micro-bench rows 8192 x d 4096 per GPU (Swish, RMSNorm, Softmax fwd+bwd, "
+                               "fused CrossEntropy, multi-tensor AdamW)", "global_batch": R * world,
+                   "parallelism": f"dp{world}"},
+        "roofline": {"kernel": "map1_kernel<SwishF> (Swish forward)", "bound": "hbm", "achieved": sw["GBps"],
+                     "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": sw["frac_of_8TBps"],
+                     "traffic": read_traffic("swish_fwd_c3"), "bytes_per_launch": bytes_per["swish_fwd"],
+                     "avg_launch_ms": sw["ms"]},
+        "extra": {"ops": ops},
+    }
+
+
+def cpu_c3(seconds):
+    from oracle import neunet_oracle as O
+    R, D = 8192, 4096
+    rng = np.random.default_rng(1003)
+    X = rng.standard_normal((R, D)).astype(np.float32)
+    dY = rng.standard_normal((R, D)).astype(np.float32)
+    w = np.ones(D, np.float32)
+    labels = rng.integers(0, D, R).astype(np.int32)
+    P = X.copy()
+    m, v = np.zeros_like(P), np.zeros_like(P)
+    t0 = time.perf_counter()
+    O.swish_forward(X, 1.0); O.swish_backward(X, dY, 1.0)
+    O.rmsnorm_forward(X, w, None); O.rmsnorm_backward(X, w, False, dY)
+    y = O.softmax_forward(X, -1); O.softmax_backward(y, dY, -1)
+    O.cross_entropy_forward_backward(X, labels, ignore_index=-100, reduction="mean")
+    O.adamw_step(P, dY, m, v, 1, 1e-3, (0.9, 0.999), 1e-8, 1e-2)
+    dt = time.perf_counter() - t0
+    return {"value": round(R / dt, 1), "unit": "samples/s", "cores": blas_threads(), "kind": "port",
+            "sample": f"1 full C3 pass (all ops, 8192x4096) via the NumPy oracle: {dt:.2f} s"}
+
+
+def blas_threads():
+    try:
+        from threadpoolctl import threadpool_info
+        return max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
+    except Exception:
+        return os.cpu_count() or 1
+
+
+def main():
+    args = parse()
+    import torch
+    from neunet_hip.distributed import init_process_group
+    import neunet_hip
+    rank, world = init_process_group()
+    if world != args.gpus and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    neunet_hip.load_library()
+    wl = {"c1": workload_c1, "c2": workload_c2, "c3": workload_c3}[args.workload]
+    res = wl(args, rank, world)
+    dt = res["dt"]
+    value = res["samples_per_step"] * args.steps / dt
+    out = {
+        "metric": "samples/sec training step", "value": round(value, 2), "unit": "samples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": res["config"],
+        "roofline": res["roofline"],
+    }
+    out.update(res.get("extra", {}))
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = {"c1": cpu_c1, "c2": cpu_c2, "c3": cpu_c3}[args.workload](args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -143,9 +143,11 @@ int nnhipRMSNormBackward(const float* dY, const float* X, const float* weight, c
 /* decay_mode 0: decoupled weight decay (AdamW, neunet/optim.py:52-69);
  * decay_mode 1: L2 decay folded into the gradient (Adam, neunet/optim.py:17-33).
  * grad_scale multiplies g on load (1.0 = reference behaviour; 1/world after a DP sum-all-reduce).
- * Bias corrections 1-beta^step are computed on the host in double (as the CPU path does). */
-int nnhipFusedAdamWStep(float* p, const float* g, float* m, float* v, float lr, float beta1,
-                        float beta2, float eps, float weight_decay, int32_t step, int64_t n,
+ * Hyper-parameters are DOUBLE (the reference passes float): the CPU path forms (1-beta) and
+ * 1-beta^step from Python doubles (optim.py:27-31); (float)0.999 would put a 1.3e-5 relative error
+ * into (1-beta2) and hence into v.  They are rounded to fp32 exactly where NumPy rounds them. */
+int nnhipFusedAdamWStep(float* p, const float* g, float* m, float* v, double lr, double beta1,
+                        double beta2, double eps, double weight_decay, int32_t step, int64_t n,
                         int32_t decay_mode, float grad_scale, nnhipStream_t stream);
 
 /* ---- a11 multi-tensor AdamW  (replaces CreateFusedOptimizer / DestroyFusedOptimizer /
@@ -156,8 +158,8 @@ int nnhipDestroyFusedOptimizer(void* opt);
  * One kernel launch for all tensors.  Tables are re-uploaded only when they changed. */
 int nnhipFusedAdamWMultiTensorStep(void* opt, int32_t n_tensors, float* const* p,
                                    const float* const* g, float* const* m, float* const* v,
-                                   const int64_t* sizes, float lr, float beta1, float beta2,
-                                   float eps, float weight_decay, int32_t step, int32_t decay_mode,
+                                   const int64_t* sizes, double lr, double beta1, double beta2,
+                                   double eps, double weight_decay, int32_t step, int32_t decay_mode,
                                    float grad_scale, nnhipStream_t stream);
 
 /* ---- a3/a4 Conv2d  (net-new exports; reference CPU: neunet/nn/layers/conv2d.py:297-355, 16-115)

@@ -14,16 +14,19 @@ struct AdamHyper {
     int decay_mode;  // 0 decoupled (AdamW), 1 L2-on-grad (Adam)
 };
 
-static AdamHyper make_hyper(float lr, float b1, float b2, float eps, float wd, int step, int mode,
+static AdamHyper make_hyper(double lr, double b1, double b2, double eps, double wd, int step, int mode,
                             float grad_scale) {
     AdamHyper h;
-    h.lr = lr; h.b1 = b1; h.b2 = b2; h.eps = eps; h.wd = wd; h.grad_scale = grad_scale;
-    h.one_m_b1 = (float)(1.0 - (double)b1);
-    h.one_m_b2 = (float)(1.0 - (double)b2);
+    // NumPy weak-scalar promotion: every python-double hyper-parameter is rounded to fp32 at the point
+    // it meets an fp32 array -- (1 - beta) is formed in double FIRST, then rounded.
+    h.lr = (float)lr; h.b1 = (float)b1; h.b2 = (float)b2; h.eps = (float)eps; h.wd = (float)wd;
+    h.grad_scale = grad_scale;
+    h.one_m_b1 = (float)(1.0 - b1);
+    h.one_m_b2 = (float)(1.0 - b2);
     // bias corrections in double on the host, as the CPU path's python floats (optim.py:30-31);
     // the reference kernel used powf in-kernel (fused_adamw_multitensor.cu:145-146)
-    h.bc1 = (float)(1.0 - pow((double)b1, (double)step));
-    h.bc2 = (float)(1.0 - pow((double)b2, (double)step));
+    h.bc1 = (float)(1.0 - pow(b1, (double)step));
+    h.bc2 = (float)(1.0 - pow(b2, (double)step));
     h.decay_mode = mode;
     return h;
 }
@@ -132,8 +135,8 @@ struct FusedOptimizer {
 
 using namespace nnhip;
 
-extern "C" int nnhipFusedAdamWStep(float* p, const float* g, float* m, float* v, float lr, float beta1,
-                                   float beta2, float eps, float weight_decay, int32_t step, int64_t n,
+extern "C" int nnhipFusedAdamWStep(float* p, const float* g, float* m, float* v, double lr, double beta1,
+                                   double beta2, double eps, double weight_decay, int32_t step, int64_t n,
                                    int32_t decay_mode, float grad_scale, nnhipStream_t s) {
     NNHIP_CHECK_ARG(n >= 0 && step >= 1, NNHIP_EINVAL, "nnhipFusedAdamWStep: n >= 0 and step >= 1 required");
     NNHIP_CHECK_ARG(decay_mode == 0 || decay_mode == 1, NNHIP_EINVAL, "nnhipFusedAdamWStep: decay_mode must be 0 or 1");
@@ -157,8 +160,8 @@ extern "C" int nnhipDestroyFusedOptimizer(void* opt) {
 
 extern "C" int nnhipFusedAdamWMultiTensorStep(void* opt, int32_t n_tensors, float* const* p,
                                               const float* const* g, float* const* m, float* const* v,
-                                              const int64_t* sizes, float lr, float beta1, float beta2,
-                                              float eps, float weight_decay, int32_t step,
+                                              const int64_t* sizes, double lr, double beta1, double beta2,
+                                              double eps, double weight_decay, int32_t step,
                                               int32_t decay_mode, float grad_scale, nnhipStream_t s) {
     NNHIP_CHECK_ARG(opt != nullptr, NNHIP_EINVAL, "nnhipFusedAdamWMultiTensorStep: null optimizer handle");
     NNHIP_CHECK_ARG(n_tensors >= 0 && step >= 1, NNHIP_EINVAL, "nnhipFusedAdamWMultiTensorStep: bad n_tensors/step");

@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, c_char, c_float, c_int32, c_int64, c_void_p
+from ctypes import POINTER, c_char, c_double, c_float, c_int32, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_ENV = "NEUNET_HIP_LIB"
@@ -53,11 +53,11 @@ _SIGNATURES = {
     "nnhipReduceLoss": (ctypes.c_int, [P, c_int64, c_char, P, P, c_void_p]),
     "nnhipRMSNormForward": (ctypes.c_int, [P, P, P, P, P, P, c_int64, c_int64, c_float, c_void_p]),
     "nnhipRMSNormBackward": (ctypes.c_int, [P, P, P, P, P, P, P, P, c_int64, c_int64, c_void_p]),
-    "nnhipFusedAdamWStep": (ctypes.c_int, [P, P, P, P, c_float, c_float, c_float, c_float, c_float, c_int32, c_int64, c_int32, c_float, c_void_p]),
+    "nnhipFusedAdamWStep": (ctypes.c_int, [P, P, P, P, c_double, c_double, c_double, c_double, c_double, c_int32, c_int64, c_int32, c_float, c_void_p]),
     "nnhipCreateFusedOptimizer": (c_void_p, []),
     "nnhipDestroyFusedOptimizer": (ctypes.c_int, [c_void_p]),
     "nnhipFusedAdamWMultiTensorStep": (ctypes.c_int, [c_void_p, c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
-                                                      POINTER(c_void_p), POINTER(c_int64), c_float, c_float, c_float, c_float, c_float,
+                                                      POINTER(c_void_p), POINTER(c_int64), c_double, c_double, c_double, c_double, c_double,
                                                       c_int32, c_int32, c_float, c_void_p]),
     "nnhipConv2dForward": (ctypes.c_int, [P, P, P, P, POINTER(Conv2dDesc), c_void_p]),
     "nnhipConv2dBackward": (ctypes.c_int, [P, P, P, P, P, P, POINTER(Conv2dDesc), c_void_p]),

@@ -1,0 +1,195 @@
+"""CPU-only tests of the host logic: tape order / accumulation semantics, Module.parameters() order,
+state_dict round trip, the no-CPU-fallback rule, and the flat gradient bucket + all-reduce over a
+world_size-2 gloo group (checked against the oracle's full-batch gradients)."""
+import os
+import pickle
+import socket
+
+import numpy as np
+import pytest
+
+import neunet_hip
+import neunet_hip.nn as nn
+from neunet_hip.autograd import Tensor
+
+
+class _Scale(Tensor):
+    """Tiny CPU op used to exercise the tape."""
+
+    def __init__(self, parent, k, log):
+        super().__init__(parent.data * k, (parent, k), "scale", device="cpu")
+
+        def grad_fn(p, kk, grad):
+            log.append(("scale", kk))
+            p.apply_grad(grad * kk)
+
+        self.grad_fn = grad_fn
+
+
+class _Add(Tensor):
+    def __init__(self, a, b, log):
+        super().__init__(a.data + b.data, (a, b), "add", device="cpu")
+
+        def grad_fn(x, y, grad):
+            log.append(("add",))
+            x.apply_grad(grad)
+            y.apply_grad(grad)
+
+        self.grad_fn = grad_fn
+
+
+def test_tape_toposort_and_accumulation():
+    log = []
+    x = Tensor(np.array([1.0, 2.0, 3.0]))
+    a = _Scale(x, 2.0, log)
+    b = _Scale(x, 3.0, log)
+    y = _Add(a, b, log)
+    y.backward()
+    np.testing.assert_allclose(x.grad, [5.0, 5.0, 5.0])   # two uses accumulate (autograd.py:85-93)
+    assert log[0] == ("add",) and sorted(log[1:]) == [("scale", 2.0), ("scale", 3.0)]
+
+
+def test_apply_grad_reverse_broadcast():
+    p = Tensor(np.zeros((1, 4)))
+    p.apply_grad(np.ones((3, 4), np.float32))       # same ndim -> keepdims sum (autograd.py:952-954)
+    np.testing.assert_allclose(p.grad, np.full((1, 4), 3.0))
+    q = Tensor(np.zeros((4,)))
+    q.apply_grad(np.ones((2, 3, 4), np.float32))    # lower ndim -> sum leading axes (autograd.py:955-958)
+    np.testing.assert_allclose(q.grad, np.full((4,), 6.0))
+
+
+def test_requires_grad_false_is_skipped():
+    x = Tensor(np.ones(3), requires_grad=False)
+    x.apply_grad(np.ones(3))
+    assert x.grad is None
+
+
+def test_parameters_order_and_dedup():
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = nn.Parameter(Tensor(np.zeros(2)))
+            self.seq = nn.Sequential(_Leaf(3), _Leaf(4))
+            self.b = nn.Parameter(Tensor(np.zeros(5)))
+            self.alias = self.a                     # same object: listed once (modules.py:27-33)
+            self.frozen = nn.Parameter(Tensor(np.zeros(6)), requires_grad=False)
+
+    class _Leaf(nn.Module):
+        def __init__(self, n):
+            super().__init__()
+            self.w = nn.Parameter(Tensor(np.zeros(n)))
+
+    net = Net()
+    assert [p.shape[0] for p in net.parameters()] == [2, 3, 4, 5]
+    sd = net.state_dict()
+    assert list(sd) == ["a", "seq.0.w", "seq.1.w", "b", "alias", "frozen"]
+    blob = pickle.dumps(sd)                          # neunet.save/load = pickle of host arrays
+    net2 = Net()
+    sd2 = pickle.loads(blob)
+    sd2["b"] = np.arange(5, dtype=np.float32)
+    net2.load_state_dict(sd2)
+    np.testing.assert_array_equal(net2.b.data, np.arange(5))
+
+
+def test_no_cpu_fallback():
+    """The dense ops refuse CPU tensors instead of silently computing on the host."""
+    from neunet_hip.nn.experimental import HIPSoftmax, HIPSwish
+    x = Tensor(np.ones((2, 4)))
+    for mod in (HIPSwish(), HIPSoftmax()):
+        with pytest.raises(NotImplementedError):
+            mod(x)
+
+
+def test_argmax_int32_bit_exact():
+    x = Tensor(np.array([[0.1, 0.9, 0.3], [2.0, -1.0, 2.0]]), requires_grad=False)
+    out = neunet_hip.argmax(x, axis=1)
+    assert out.dtype == np.int32
+    np.testing.assert_array_equal(out.data, [1, 0])  # first maximum wins, like np.argmax
+
+
+def test_conv_padding_resolution():
+    from neunet_hip.nn.experimental.conv2d import resolve_padding
+    assert resolve_padding(1) == (1, 1, 1, 1)
+    assert resolve_padding((2, 3)) == (2, 2, 3, 3)
+    assert resolve_padding((1, 2, 0, 1)) == (1, 2, 0, 1)
+    with pytest.raises(ValueError):
+        resolve_padding("same")
+
+
+def test_shard_batch():
+    from neunet_hip.distributed import shard_batch
+    spans = [shard_batch(10, r, 4) for r in range(4)]
+    assert spans == [(0, 3), (3, 6), (6, 8), (8, 10)]
+
+
+# ------------------------------------------------------------------------ world_size-2 gloo all-reduce
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _dp_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    from neunet_hip.distributed import GradBucket, shard_batch
+    from oracle import neunet_oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(7)
+        X = rng.uniform(-1, 1, (12, 6)).astype(np.float32)
+        Y = rng.integers(1, 5, 12).astype(np.int32)
+        Y[3] = 0                                              # ignore_index = 0 (PAD), as in the GPT config
+        W = rng.uniform(-0.5, 0.5, (5, 6)).astype(np.float32)
+        b = rng.uniform(-0.5, 0.5, (1, 5)).astype(np.float32)
+
+        class P:  # parameter stand-in: .data (torch), .grad
+            def __init__(self, a):
+                self.data = torch.from_numpy(a.copy())
+                self.grad = None
+
+        params = [P(W), P(b), P(np.zeros(3, np.float32))]   # the last one never gets a gradient
+        bucket = GradBucket(params, extra_scalars=1)
+        lo, hi = shard_batch(12, rank, world)
+        logits = O.linear_forward(X[lo:hi], W, b)
+        # local SUM loss; the global non-ignored count rides in the same bucket (SURVEY 8e scaling rule)
+        _, dlogits = O.cross_entropy_forward_backward(logits, Y[lo:hi], ignore_index=0, reduction="sum")
+        _, dW, db = O.linear_backward(X[lo:hi], W, b, dlogits)
+        params[0].grad = torch.from_numpy(dW)                 # copied into its slot by collect()
+        params[1]._grad_slot.copy_(torch.from_numpy(db))      # written in place, like the HIP layers do
+        params[1].grad = params[1]._grad_slot
+        bucket.extra[0] = float((Y[lo:hi] != 0).sum())
+        bucket.all_reduce()
+        count = float(bucket.extra[0])
+        full_logits = O.linear_forward(X, W, b)
+        _, dl_full = O.cross_entropy_forward_backward(full_logits, Y, ignore_index=0, reduction="mean")
+        _, dW_full, db_full = O.linear_backward(X, W, b, dl_full)
+        ok = (count == 11.0 and params[2].grad is None
+              and np.allclose(params[0].grad.numpy() / count, dW_full, rtol=1e-5, atol=1e-6)
+              and np.allclose(params[1].grad.numpy() / count, db_full, rtol=1e-5, atol=1e-6)
+              and params[0].grad.data_ptr() == bucket.views[0].data_ptr())
+        q.put((rank, bool(ok)))
+    except Exception as exc:  # report instead of leaving the parent waiting on the queue
+        q.put((rank, repr(exc)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_bucket_allreduce_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(results) == [(0, True), (1, True)]
