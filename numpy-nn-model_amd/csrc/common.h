@@ -63,6 +63,22 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     for (int i = 0; i < NW; ++i) s += red[i];
     return s;
 }
+// Two sums with one pair of barriers.  `red` is 2*NW floats.
+template <int NW>
+__device__ __forceinline__ void block_sum2(float& a, float& b, float* red) {
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if constexpr (NW == 1) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) { red[w] = a; red[NW + w] = b; }
+    __syncthreads();
+    float sa = 0.f, sb = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) { sa += red[i]; sb += red[NW + i]; }
+    a = sa;
+    b = sb;
+}
 template <int NW>
 __device__ __forceinline__ float block_max(float v, float* red) {
     v = wave_max(v);

@@ -9,12 +9,16 @@ namespace nnhip {
 constexpr int EW_THREADS = 256;
 constexpr int EW_MAX_BLOCKS = 256 * 8;
 
-inline int ew_blocks(int64_t n_vec) {
-    int64_t b = ceil_div(n_vec > 0 ? n_vec : 1, EW_THREADS);
+inline int ew_blocks(int64_t n_items) {
+    int64_t b = ceil_div(n_items > 0 ? n_items : 1, EW_THREADS);
     return (int)(b < EW_MAX_BLOCKS ? b : EW_MAX_BLOCKS);
 }
 
 // Generic unary/binary maps over float4 with scalar tail -----------------------------------------
+// Each block walks contiguous 256*EW_U-float4 spans; the EW_U loads of a span are issued together
+// (EW_U x 16 B in flight per lane) before any math, then EW_U stores.
+constexpr int EW_U = 4;
+
 template <class F>
 __global__ __launch_bounds__(EW_THREADS) void map1_kernel(float* out, const float* a, int64_t n,
                                                           bool vec, F f) {
@@ -22,11 +26,24 @@ __global__ __launch_bounds__(EW_THREADS) void map1_kernel(float* out, const floa
     const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
     if (vec) {
         const int64_t nv = n >> 2;
-        for (int64_t i = gid; i < nv; i += gsz) {
-            const float4 x = reinterpret_cast<const float4*>(a)[i];
-            float4 y;
-            y.x = f(x.x); y.y = f(x.y); y.z = f(x.z); y.w = f(x.w);
-            reinterpret_cast<float4*>(out)[i] = y;
+        const float4* a4 = reinterpret_cast<const float4*>(a);
+        float4* o4 = reinterpret_cast<float4*>(out);
+        for (int64_t base = (int64_t)blockIdx.x * (EW_THREADS * EW_U); base < nv; base += gsz * EW_U) {
+            float4 x[EW_U];
+#pragma unroll
+            for (int u = 0; u < EW_U; ++u) {
+                const int64_t i = base + u * EW_THREADS + threadIdx.x;
+                if (i < nv) x[u] = a4[i];
+            }
+#pragma unroll
+            for (int u = 0; u < EW_U; ++u) {
+                const int64_t i = base + u * EW_THREADS + threadIdx.x;
+                if (i < nv) {
+                    float4 y;
+                    y.x = f(x[u].x); y.y = f(x[u].y); y.z = f(x[u].z); y.w = f(x[u].w);
+                    o4[i] = y;
+                }
+            }
         }
         for (int64_t i = (nv << 2) + gid; i < n; i += gsz) out[i] = f(a[i]);
     } else {
@@ -41,12 +58,25 @@ __global__ __launch_bounds__(EW_THREADS) void map2_kernel(float* out, const floa
     const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
     if (vec) {
         const int64_t nv = n >> 2;
-        for (int64_t i = gid; i < nv; i += gsz) {
-            const float4 x = reinterpret_cast<const float4*>(a)[i];
-            const float4 z = reinterpret_cast<const float4*>(b)[i];
-            float4 y;
-            y.x = f(x.x, z.x); y.y = f(x.y, z.y); y.z = f(x.z, z.z); y.w = f(x.w, z.w);
-            reinterpret_cast<float4*>(out)[i] = y;
+        const float4* a4 = reinterpret_cast<const float4*>(a);
+        const float4* b4 = reinterpret_cast<const float4*>(b);
+        float4* o4 = reinterpret_cast<float4*>(out);
+        for (int64_t base = (int64_t)blockIdx.x * (EW_THREADS * EW_U); base < nv; base += gsz * EW_U) {
+            float4 x[EW_U], z[EW_U];
+#pragma unroll
+            for (int u = 0; u < EW_U; ++u) {
+                const int64_t i = base + u * EW_THREADS + threadIdx.x;
+                if (i < nv) { x[u] = a4[i]; z[u] = b4[i]; }
+            }
+#pragma unroll
+            for (int u = 0; u < EW_U; ++u) {
+                const int64_t i = base + u * EW_THREADS + threadIdx.x;
+                if (i < nv) {
+                    float4 y;
+                    y.x = f(x[u].x, z[u].x); y.y = f(x[u].y, z[u].y); y.z = f(x[u].z, z[u].z); y.w = f(x[u].w, z[u].w);
+                    o4[i] = y;
+                }
+            }
         }
         for (int64_t i = (nv << 2) + gid; i < n; i += gsz) out[i] = f(a[i], b[i]);
     } else {
@@ -81,7 +111,7 @@ template <class F>
 static int launch_map1(float* out, const float* a, int64_t n, F f, hipStream_t st, const char* nm) {
     if (n == 0) return 0;
     const bool vec = aligned16(out) && aligned16(a);
-    hipLaunchKernelGGL(map1_kernel<F>, dim3(ew_blocks(vec ? n >> 2 : n)), dim3(EW_THREADS), 0, st,
+    hipLaunchKernelGGL(map1_kernel<F>, dim3(ew_blocks(vec ? ceil_div(n >> 2, EW_U) : n)), dim3(EW_THREADS), 0, st,
                        out, a, n, vec, f);
     NNHIP_LAUNCH_CHECK(nm);
     return 0;
@@ -91,7 +121,7 @@ static int launch_map2(float* out, const float* a, const float* b, int64_t n, F 
                        const char* nm) {
     if (n == 0) return 0;
     const bool vec = aligned16(out) && aligned16(a) && aligned16(b);
-    hipLaunchKernelGGL(map2_kernel<F>, dim3(ew_blocks(vec ? n >> 2 : n)), dim3(EW_THREADS), 0, st,
+    hipLaunchKernelGGL(map2_kernel<F>, dim3(ew_blocks(vec ? ceil_div(n >> 2, EW_U) : n)), dim3(EW_THREADS), 0, st,
                        out, a, b, n, vec, f);
     NNHIP_LAUNCH_CHECK(nm);
     return 0;

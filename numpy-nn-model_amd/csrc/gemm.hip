@@ -21,6 +21,8 @@
 //     so the 64 tiles resident on one XCD share A/B panels in that XCD's private 4 MiB L2;
 //   * split-K (deterministic: fp32 slabs + a reduce kernel, no atomics) when M*N has too few
 //     tiles to fill 256 CUs (e.g. dW = dO^T X with a 16384-long reduction at GPT-tiny).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace nnhip {
@@ -121,7 +123,7 @@ __device__ __forceinline__ void frag(float (&f)[4], const float* __restrict__ S,
 }
 
 template <int BK, bool AKC, bool BKC, bool VEC>
-__global__ __launch_bounds__(NT, 2) void gemm_f32_kernel(const GemmParams p) {
+__global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using TA = Tile<BK, AKC>;
     using TB = Tile<BK, BKC>;
@@ -290,7 +292,8 @@ int gemm_f32(const float* A, const float* B, float* C, const float* bias, float*
              bool b_kmajor, int64_t batch, int64_t sA, int64_t sB, int64_t sC, int act, float beta,
              hipStream_t st) {
     if (M <= 0 || N <= 0 || batch <= 0) return 0;
-    constexpr int BK = 32;
+    static const int bk_sel = []() { const char* e = getenv("NNHIP_GEMM_BK"); return e ? atoi(e) : 32; }();
+    const int BK = (bk_sel == 16) ? 16 : 32;
     GemmParams p;
     p.A = A; p.B = B; p.C = C; p.bias = bias; p.preact = preact;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
@@ -327,9 +330,11 @@ int gemm_f32(const float* A, const float* B, float* C, const float* bias, float*
     const bool vec = vec_ok(A, lda, sA, a_kmajor, M) && vec_ok(B, ldb, sB, b_kmajor, N);
 
     int rc;
-#define NNHIP_GEMM_CASE(AK, BKM)                                                   \
-    rc = vec ? launch_variant<BK, AK, BKM, true>(p, batch, st)                    \
-             : launch_variant<BK, AK, BKM, false>(p, batch, st)
+#define NNHIP_GEMM_CASE(AK, BKM)                                                                   \
+    rc = (BK == 16) ? (vec ? launch_variant<16, AK, BKM, true>(p, batch, st)                      \
+                           : launch_variant<16, AK, BKM, false>(p, batch, st))                    \
+                    : (vec ? launch_variant<32, AK, BKM, true>(p, batch, st)                      \
+                           : launch_variant<32, AK, BKM, false>(p, batch, st))
     if (a_kmajor && b_kmajor) { NNHIP_GEMM_CASE(true, true); }
     else if (a_kmajor && !b_kmajor) { NNHIP_GEMM_CASE(true, false); }
     else if (!a_kmajor && b_kmajor) { NNHIP_GEMM_CASE(false, true); }

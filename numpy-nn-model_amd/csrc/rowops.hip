@@ -213,17 +213,19 @@ __global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void rmsnorm_fwd_rows(
     r.store(Y + row * cols, cols, t);
 }
 
-// Backward: each block walks rows blockIdx.x*RPB + k*gridDim.x*RPB, keeps per-thread column partials
-// of dw = sum dy*x/std and db = sum dy in registers (a thread always owns the same columns), and
-// writes them once at the end to part[(blockIdx.x*RPB + rslot)][cols]; a column-sum pass finishes
-// dw/db.  dx needs one row reduction: S = sum(w dy x / std).
+// Backward: block b walks rows b*RPB+rslot + k*gridDim.x*RPB, TWO rows per iteration (both rows' loads
+// are in flight together and their row reductions share one pair of barriers), keeps per-thread column
+// partials of dw = sum dy*x/std and db = sum dy in registers (a thread always owns the same columns),
+// and writes them once at the end to part[(b*RPB + rslot)][cols]; a column-sum pass finishes dw/db.
+// dx needs one row reduction: S = sum(w dy x / std).
 template <int TPR, int NV, bool VEC>
 __global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void rmsnorm_bwd_rows(
     const float* __restrict__ dY, const float* __restrict__ X, const float* __restrict__ w,
     const float* __restrict__ Xstd, float* __restrict__ dX, float* __restrict__ part_dw,
     float* __restrict__ part_db, int64_t rows, int64_t cols) {
-    __shared__ float red[16];
+    __shared__ float red[32];
     constexpr int RPB = (TPR >= 256) ? 1 : 256 / TPR;
+    constexpr int NW = TPR / 64;
     const int t = threadIdx.x % TPR;
     const int rslot = threadIdx.x / TPR;
     RowTile<TPR, NV, VEC> wt, adw, adb;
@@ -231,26 +233,44 @@ __global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void rmsnorm_bwd_rows(
 #pragma unroll
     for (int e = 0; e < wt.NE; ++e) adw.x[e] = adb.x[e] = 0.f;
     const float invN = 1.0f / (float)cols;
-    // all waves of a block iterate the same number of times when TPR >= 256 (block barriers inside)
-    for (int64_t row = (int64_t)blockIdx.x * RPB + rslot; row < rows; row += (int64_t)gridDim.x * RPB) {
-        RowTile<TPR, NV, VEC> x, g;
-        x.load(X + row * cols, cols, t, 0.f);
-        g.load(dY + row * cols, cols, t, 0.f);
-        const float sd = Xstd[row];
-        const float inv = 1.0f / sd;
-        float s = 0.f;
+    const int64_t step = (int64_t)gridDim.x * RPB;
+    // when TPR >= 256 every thread of the block runs the same trip count (block barriers inside)
+    for (int64_t r0 = (int64_t)blockIdx.x * RPB + rslot; r0 < rows; r0 += 2 * step) {
+        const int64_t r1 = r0 + step;
+        const bool has1 = r1 < rows;
+        RowTile<TPR, NV, VEC> x0, g0, x1, g1;
+        x0.load(X + r0 * cols, cols, t, 0.f);
+        g0.load(dY + r0 * cols, cols, t, 0.f);
+        if (has1) {
+            x1.load(X + r1 * cols, cols, t, 0.f);
+            g1.load(dY + r1 * cols, cols, t, 0.f);
+        } else {
 #pragma unroll
-        for (int e = 0; e < x.NE; ++e) {
-            adb.x[e] += g.x[e];
-            adw.x[e] += g.x[e] * (x.x[e] * inv);
-            g.x[e] *= wt.x[e];              // dX_hat = w * dy
-            s += g.x[e] * x.x[e] * inv;
+            for (int e = 0; e < x1.NE; ++e) x1.x[e] = g1.x[e] = 0.f;
         }
-        s = row_sum<TPR>(s, red) * invN;
-        const float inv2 = inv * inv;
+        const float sd0 = Xstd[r0], sd1 = has1 ? Xstd[r1] : 1.f;
+        const float i0 = 1.0f / sd0, i1 = 1.0f / sd1;
+        float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-        for (int e = 0; e < x.NE; ++e) g.x[e] = (g.x[e] * sd - x.x[e] * s) * inv2;
-        g.store(dX + row * cols, cols, t);
+        for (int e = 0; e < x0.NE; ++e) {
+            adb.x[e] += g0.x[e] + g1.x[e];
+            adw.x[e] += g0.x[e] * (x0.x[e] * i0) + g1.x[e] * (x1.x[e] * i1);
+            g0.x[e] *= wt.x[e];  // dX_hat = w * dy
+            g1.x[e] *= wt.x[e];
+            s0 += g0.x[e] * x0.x[e] * i0;
+            s1 += g1.x[e] * x1.x[e] * i1;
+        }
+        block_sum2<NW>(s0, s1, red);
+        s0 *= invN;
+        s1 *= invN;
+        const float q0 = i0 * i0, q1 = i1 * i1;
+#pragma unroll
+        for (int e = 0; e < x0.NE; ++e) {
+            g0.x[e] = (g0.x[e] * sd0 - x0.x[e] * s0) * q0;
+            g1.x[e] = (g1.x[e] * sd1 - x1.x[e] * s1) * q1;
+        }
+        g0.store(dX + r0 * cols, cols, t);
+        if (has1) g1.store(dX + r1 * cols, cols, t);
     }
     const int64_t prow = (int64_t)blockIdx.x * RPB + rslot;
     adw.store(part_dw + prow * cols, cols, t);
@@ -520,10 +540,11 @@ extern "C" int nnhipRMSNormBackward(const float* dY, const float* X, const float
     NNHIP_CHECK_ARG(cols <= kMaxRegRow, NNHIP_EINVAL,
                     "nnhipRMSNormBackward: cols > 16384 not supported");
     hipStream_t st = (hipStream_t)s;
-    // persistent-ish grid: <= 512 blocks, each accumulating dw/db partials over its rows
+    // persistent-ish grid: <= 1024 blocks (4 per CU), each accumulating dw/db partials over its rows,
+    // two rows in flight per iteration
     const int rpb = cols <= 1024 ? 4 : 1;
-    int64_t nblk = ceil_div(rows > 0 ? rows : 1, rpb);
-    if (nblk > 512) nblk = 512;
+    int64_t nblk = ceil_div(ceil_div(rows > 0 ? rows : 1, rpb), 2);
+    if (nblk > 1024) nblk = 1024;
     const int64_t prow = nblk * rpb;
     const size_t part_floats = (size_t)prow * cols;
     // layout: [dw partials | db partials | (colsum scratch is a separate workspace() call ordering

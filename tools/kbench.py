@@ -1,0 +1,148 @@
+#!/usr/bin/env python3
+"""Per-kernel micro-benchmark through the C ABI (HIP events on the launch stream).  Developer tool for A/B
+work on the GPU box:   python tools/kbench.py [--only gemm,swish,...] [--iters 30]
+Prints one line per op: median / min ms and the algorithmic TFLOP/s or GB/s (SURVEY 8d figures)."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "numpy-nn-model_amd"))
+
+import torch  # noqa: E402
+
+from neunet_hip import _lib  # noqa: E402
+from neunet_hip._lib import Conv2dDesc, call_hip_function as call  # noqa: E402
+import ctypes  # noqa: E402
+
+
+def bench(fn, iters, warmup=5):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(iters):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        ts.append((a, b))
+    torch.cuda.synchronize()
+    ms = np.array([a.elapsed_time(b) for a, b in ts])
+    return float(np.median(ms)), float(ms.min())
+
+
+def report(name, med, mn, flops=None, nbytes=None):
+    s = f"{name:34s} med {med:9.4f} ms  min {mn:9.4f} ms"
+    if flops:
+        s += f"  {flops / (med * 1e-3) / 1e12:8.2f} TFLOP/s ({flops / (med * 1e-3) / 1e12 / 157.3 * 100:5.1f}% of 157.3)"
+    if nbytes:
+        s += f"  {nbytes / (med * 1e-3) / 1e9:8.1f} GB/s ({nbytes / (med * 1e-3) / 1e9 / 8000 * 100:5.1f}% of 8 TB/s)"
+    print(s, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    ap.add_argument("--iters", type=int, default=30)
+    args = ap.parse_args()
+    only = set(filter(None, args.only.split(",")))
+    want = lambda k: not only or k in only  # noqa: E731
+    st = _lib.get_current_stream_ptr()
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(0)
+    rnd = lambda *s: (torch.rand(*s, device=dev, generator=g) * 2 - 1)  # noqa: E731
+    randn = lambda *s: torch.randn(*s, device=dev, generator=g)  # noqa: E731
+
+    if want("gemm"):
+        for (M, N, K) in [(4096, 4096, 4096), (8192, 4096, 4096), (16384, 512, 512), (16384, 2048, 512),
+                          (16384, 15000, 512)]:
+            X, W, b = rnd(M, K), rnd(N, K) / 64, rnd(N)
+            O_, dO, dX, dW, db = torch.empty(M, N, device=dev), rnd(M, N), torch.empty(M, K, device=dev), \
+                torch.empty(N, K, device=dev), torch.empty(N, device=dev)
+            fl = 2.0 * M * N * K
+            tag = f"{M}x{K}->{N}"
+            report(f"linear fwd {tag}", *bench(lambda: call("nnhipLinearModuleForward", X, W, b, O_, M, K, N, st), args.iters), flops=fl)
+            report(f"linear dX  {tag}", *bench(lambda: call("nnhipLinearModuleBackward", X, W, dO, dX, None, None, M, K, N, st), args.iters), flops=fl)
+            report(f"linear dW  {tag}", *bench(lambda: call("nnhipLinearModuleBackward", X, W, dO, None, dW, None, M, K, N, st), args.iters), flops=fl)
+            report(f"linear db  {tag}", *bench(lambda: call("nnhipLinearModuleBackward", X, W, dO, None, None, db, M, K, N, st), args.iters), nbytes=4.0 * M * N)
+            del X, W, O_, dO, dX, dW
+
+    R, D = 8192, 4096
+    n = R * D
+    if want("lswish"):
+        X, W, b = rnd(R, D), rnd(D, D) / 64, rnd(D)
+        O_, Z = torch.empty(R, D, device=dev), torch.empty(R, D, device=dev)
+        report("linear_swish fwd (save z)", *bench(lambda: call("nnhipLinearSwishForward", X, W, b, O_, Z, R, D, D, 1.0, 1, st), args.iters), flops=2.0 * R * D * D)
+        report("linear_swish fwd (no z)", *bench(lambda: call("nnhipLinearSwishForward", X, W, b, O_, None, R, D, D, 1.0, 0, st), args.iters), flops=2.0 * R * D * D)
+        del X, W, O_, Z
+    x, dy, y, dx = randn(R, D), randn(R, D), torch.empty(R, D, device=dev), torch.empty(R, D, device=dev)
+    if want("swish"):
+        report("swish fwd 8192x4096", *bench(lambda: call("nnhipSwishForward", y, x, 1.0, n, st), args.iters), nbytes=8.0 * n)
+        report("swish bwd 8192x4096", *bench(lambda: call("nnhipSwishBackward", dx, dy, x, 1.0, n, st), args.iters), nbytes=12.0 * n)
+        report("relu fwd 8192x4096", *bench(lambda: call("nnhipReLUForward", y, x, n, st), args.iters), nbytes=8.0 * n)
+        report("add 8192x4096", *bench(lambda: call("nnhipAdd", y, x, dy, n, st), args.iters), nbytes=12.0 * n)
+    if want("swiglu"):
+        o2, d2 = torch.empty(R, D // 2, device=dev), randn(R, D // 2)
+        report("swiglu fwd 8192x(2x2048)", *bench(lambda: call("nnhipFusedSwishAndMul", o2, x, 1.0, D // 2, n // 2, st), args.iters), nbytes=12.0 * n / 2)
+        report("swiglu bwd 8192x(2x2048)", *bench(lambda: call("nnhipFusedSwishAndMulBackward", dx, d2, x, 1.0, D // 2, n // 2, st), args.iters), nbytes=20.0 * n / 2)
+    if want("softmax"):
+        report("softmax fwd 8192x4096", *bench(lambda: call("nnhipSoftmaxForward", y, x, R, D, 1, st), args.iters), nbytes=8.0 * n)
+        report("softmax bwd 8192x4096", *bench(lambda: call("nnhipSoftmaxBackward", dx, dy, y, R, D, 1, st), args.iters), nbytes=12.0 * n)
+        xs = randn(64 * 8 * 256, 256)
+        ys = torch.empty_like(xs)
+        report("softmax fwd (64,8,256,256)", *bench(lambda: call("nnhipSoftmaxForward", ys, xs, xs.shape[0], 256, 1, st), args.iters), nbytes=8.0 * xs.numel())
+    if want("rmsnorm"):
+        w, std = torch.ones(D, device=dev), torch.empty(R, device=dev)
+        dw = torch.empty(D, device=dev)
+        report("rmsnorm fwd 8192x4096", *bench(lambda: call("nnhipRMSNormForward", x, w, None, y, std, None, R, D, 1e-6, st), args.iters), nbytes=8.0 * n)
+        report("rmsnorm bwd 8192x4096", *bench(lambda: call("nnhipRMSNormBackward", dy, x, w, std, None, dx, dw, None, R, D, st), args.iters), nbytes=12.0 * n)
+        x5, y5, dy5, dx5 = randn(16384, 512), torch.empty(16384, 512, device=dev), randn(16384, 512), torch.empty(16384, 512, device=dev)
+        w5, s5, dw5 = torch.ones(512, device=dev), torch.empty(16384, device=dev), torch.empty(512, device=dev)
+        report("rmsnorm fwd 16384x512", *bench(lambda: call("nnhipRMSNormForward", x5, w5, None, y5, s5, None, 16384, 512, 1e-6, st), args.iters), nbytes=8.0 * x5.numel())
+        report("rmsnorm bwd 16384x512", *bench(lambda: call("nnhipRMSNormBackward", dy5, x5, w5, s5, None, dx5, dw5, None, 16384, 512, st), args.iters), nbytes=12.0 * x5.numel())
+    if want("ce"):
+        labels = torch.randint(0, D, (R,), device=dev, dtype=torch.int32)
+        loss, lse = torch.empty(R, device=dev), torch.empty(R, device=dev)
+        report("ce fwd+bwd 8192x4096", *bench(lambda: call("nnhipCrossEntropyForwardBackward", x, loss, lse, labels, D, -100, R, D, b"m", R, None, dx, st), args.iters), nbytes=8.0 * n)
+        V = 15000
+        xl, dxl = randn(16384, V), torch.empty(16384, V, device=dev)
+        lab = torch.randint(0, V, (16384,), device=dev, dtype=torch.int32)
+        l2, s2 = torch.empty(16384, device=dev), torch.empty(16384, device=dev)
+        report("ce fwd+bwd 16384x15000", *bench(lambda: call("nnhipCrossEntropyForwardBackward", xl, l2, s2, lab, V, 0, 16384, V, b"m", 16384, None, dxl, st), args.iters), nbytes=8.0 * xl.numel())
+        del xl, dxl
+    if want("adamw"):
+        p, m, v = randn(R, D), torch.zeros(R, D, device=dev), torch.zeros(R, D, device=dev)
+        report("adamw single 8192x4096", *bench(lambda: call("nnhipFusedAdamWStep", p, dy, m, v, 1e-3, 0.9, 0.999, 1e-8, 1e-2, 3, n, 0, 1.0, st), args.iters), nbytes=28.0 * n)
+        opt = _lib.load_hip_function("nnhipCreateFusedOptimizer")()
+        nt = 200
+        ps = [randn(512, 1024) for _ in range(nt)]
+        gs = [randn(512, 1024) for _ in range(nt)]
+        ms = [torch.zeros(512, 1024, device=dev) for _ in range(nt)]
+        vs = [torch.zeros(512, 1024, device=dev) for _ in range(nt)]
+        arr = lambda ts: (ctypes.c_void_p * nt)(*[t.data_ptr() for t in ts])  # noqa: E731
+        cp, cg, cm, cv = arr(ps), arr(gs), arr(ms), arr(vs)
+        cs = (ctypes.c_int64 * nt)(*[t.numel() for t in ps])
+        cast = lambda a, t: ctypes.cast(a, ctypes.POINTER(t))  # noqa: E731
+        report("adamw multi 200x(512,1024)", *bench(lambda: call(
+            "nnhipFusedAdamWMultiTensorStep", opt, nt, cast(cp, ctypes.c_void_p), cast(cg, ctypes.c_void_p),
+            cast(cm, ctypes.c_void_p), cast(cv, ctypes.c_void_p), cast(cs, ctypes.c_int64), 1e-3, 0.9, 0.999, 1e-8, 1e-2,
+            3, 0, 1.0, st), args.iters), nbytes=28.0 * nt * 512 * 1024)
+    if want("conv"):
+        for (B, Cin, H, Cout) in [(256, 1, 28, 8), (256, 8, 14, 16)]:
+            X = rnd(B, Cin, H, H)
+            W = rnd(Cout, Cin, 3, 3)
+            bb = rnd(Cout)
+            O_ = torch.empty(B, Cout, H, H, device=dev)
+            dO = rnd(B, Cout, H, H)
+            dX, dW, db = torch.empty_like(X), torch.empty_like(W), torch.empty_like(bb)
+            d = Conv2dDesc(B, Cin, H, H, Cout, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1)
+            by = 4.0 * (X.numel() + O_.numel() + W.numel())
+            report(f"conv fwd {B}x{Cin}x{H}x{H}->{Cout}", *bench(lambda: call("nnhipConv2dForward", X, W, bb, O_, ctypes.byref(d), st), args.iters), nbytes=by)
+            report(f"conv bwd {B}x{Cin}x{H}x{H}->{Cout}", *bench(lambda: call("nnhipConv2dBackward", X, W, dO, dX, dW, db, ctypes.byref(d), st), args.iters), nbytes=by * 2)
+
+
+if __name__ == "__main__":
+    main()
