@@ -264,21 +264,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
     }
 }
 
-// dW[m][n] = sum_c part[c][m][n] (n < Nw);  db[m] = sum_c part[c][m][Nw]
+// dW[m][n] = sum_c part[c][m][n] (n < Nw);  db[m] = sum_c part[c][m][Nw].  One wave per output element:
+// the 64 lanes stride over the chunks and meet in a shuffle reduction (fixed order: deterministic).
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ part,
                                                                 float* __restrict__ dW,
                                                                 float* __restrict__ db, int chunks,
                                                                 int Cout, int Nw, int ncols) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     const int total = Cout * ncols;
     if (idx >= total) return;
     const int m = idx / ncols, n = idx - m * ncols;
     float s = 0.f;
-    for (int c = 0; c < chunks; ++c) s += part[(int64_t)c * total + idx];
-    if (n < Nw) {
-        if (dW) dW[(int64_t)m * Nw + n] = s;
-    } else if (db) {
-        db[m] = s;
+    for (int c = lane; c < chunks; c += 64) s += part[(int64_t)c * total + idx];
+    s = wave_sum(s);
+    if (lane == 0) {
+        if (n < Nw) {
+            if (dW) dW[(int64_t)m * Nw + n] = s;
+        } else if (db) {
+            db[m] = s;
+        }
     }
 }
 
@@ -344,7 +349,7 @@ extern "C" int nnhipConv2dBackward(const float* X, const float* W, const float* 
         hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, st, X, dO, part, g, kpb, ncols);
         NNHIP_LAUNCH_CHECK("conv_wgrad_kernel");
         const int total = g.Cout * ncols;
-        hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st,
+        hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)ceil_div(total, 4)), dim3(256), 0, st,
                            part, dW, db, chunks, g.Cout, Nw, ncols);
         NNHIP_LAUNCH_CHECK("conv_wgrad_reduce_kernel");
     }

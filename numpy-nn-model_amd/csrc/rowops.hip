@@ -386,63 +386,109 @@ __global__ __launch_bounds__(1024) void reduce_loss_kernel(const float* __restri
 }
 
 // =================================================================================================
-// Column sums:  out[c] = sum_r X[r*ld + c]     (Linear db: neunet/nn/layers/linear.py:24)
-// grid (col_blocks, row_blocks); row_blocks > 1 writes partials [row_blocks][cols].
+// Column sums:  out[c] = sum_r X[r*ld + c]     (Linear db: neunet/nn/layers/linear.py:24; RMSNorm dw/db)
+// Block = 4 waves; lane <-> one float4 column group (256 columns per block) or one column (scalar path,
+// 64 columns per block); wave w sums rows w, w+4, ... of the block's row range (1 KiB coalesced per
+// wave-load); the 4 waves meet in LDS.  grid (col_blocks, row_blocks); row_blocks > 1 writes partials
+// [row_blocks][cols] that a second, single-row-block launch finishes.
 // =================================================================================================
 template <bool VEC>
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int64_t rows,
-                                                     int64_t cols, int64_t ld,
+                                                     int64_t cols, int64_t ld, int64_t rows_per_block,
                                                      float* __restrict__ out) {
+    __shared__ float4 red[3][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t rbeg = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t rend = min(rows, rbeg + rows_per_block);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    int64_t c;
     if constexpr (VEC) {
-        const int64_t c = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-        if (c >= cols) return;
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
-            const float4 v = *reinterpret_cast<const float4*>(X + r * ld + c);
+        c = ((int64_t)blockIdx.x * 64 + lane) * 4;
+        if (c < cols) {
+            int64_t r = rbeg + w;
+            for (; r + 12 < rend; r += 16) {  // 4 loads in flight per lane
+                const float4 v0 = *reinterpret_cast<const float4*>(X + r * ld + c);
+                const float4 v1 = *reinterpret_cast<const float4*>(X + (r + 4) * ld + c);
+                const float4 v2 = *reinterpret_cast<const float4*>(X + (r + 8) * ld + c);
+                const float4 v3 = *reinterpret_cast<const float4*>(X + (r + 12) * ld + c);
+                a.x += (v0.x + v1.x) + (v2.x + v3.x);
+                a.y += (v0.y + v1.y) + (v2.y + v3.y);
+                a.z += (v0.z + v1.z) + (v2.z + v3.z);
+                a.w += (v0.w + v1.w) + (v2.w + v3.w);
+            }
+            for (; r < rend; r += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(X + r * ld + c);
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+        }
+    } else {
+        c = (int64_t)blockIdx.x * 64 + lane;
+        if (c < cols)
+            for (int64_t r = rbeg + w; r < rend; r += 4) a.x += X[r * ld + c];
+    }
+    if (w > 0) red[w - 1][lane] = a;
+    __syncthreads();
+    if (w == 0 && c < cols) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float4 v = red[i][lane];
             a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
         }
-        *reinterpret_cast<float4*>(out + (int64_t)blockIdx.y * cols + c) = a;
-    } else {
-        const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-        if (c >= cols) return;
-        float a = 0.f;
-        for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) a += X[r * ld + c];
-        out[(int64_t)blockIdx.y * cols + c] = a;
+        float* o = out + (int64_t)blockIdx.y * cols + c;
+        if constexpr (VEC) *reinterpret_cast<float4*>(o) = a;
+        else *o = a.x;
     }
 }
 
 // internal API ------------------------------------------------------------------------------------
-// `ws` must hold row_blocks*cols floats when row_blocks > 1 (see colsum_ws_floats).
-static inline int colsum_row_blocks(int64_t rows, int64_t cols, bool vec) {
-    const int64_t cb = ceil_div(cols, vec ? 1024 : 256);
-    int64_t rb = 2048 / cb;
-    if (rb > rows / 8) rb = rows / 8;  // >= 8 rows per block
+struct ColsumPlan {
+    bool vec;
+    int64_t col_blocks, rows_per_block;
+    int row_blocks;
+    size_t scratch_floats;  // partials needed when row_blocks > 1
+};
+
+static ColsumPlan colsum_plan(const float* X, const float* out, int64_t rows, int64_t cols, int64_t ld) {
+    ColsumPlan p;
+    p.vec = aligned16(X) && aligned16(out) && (ld % 4 == 0) && (cols % 4 == 0);
+    p.col_blocks = ceil_div(cols, p.vec ? 256 : 64);
+    int64_t rb = 2048 / p.col_blocks;             // aim for ~2k blocks in stage 1
+    if (rb > ceil_div(rows, 16)) rb = ceil_div(rows, 16);  // >= 16 rows per block
+    if (rb > 512) rb = 512;                        // stage 2 sums <= 512 partial rows in one block row
     if (rb < 1) rb = 1;
-    if (rb > 1024) rb = 1024;
-    return (int)rb;
+    p.rows_per_block = ceil_div(rows > 0 ? rows : 1, rb);
+    p.row_blocks = (int)ceil_div(rows > 0 ? rows : 1, p.rows_per_block);
+    p.scratch_floats = p.row_blocks > 1 ? (size_t)p.row_blocks * cols : 0;
+    return p;
+}
+
+// `scratch` must hold plan.scratch_floats floats (16-B aligned) when plan.row_blocks > 1.
+static int colsum_run(const ColsumPlan& p, const float* X, int64_t rows, int64_t cols, int64_t ld, float* out,
+                      float* scratch, hipStream_t st) {
+    float* stage1 = p.row_blocks > 1 ? scratch : out;
+    dim3 grid((unsigned)p.col_blocks, (unsigned)p.row_blocks);
+    if (p.vec) hipLaunchKernelGGL(colsum_kernel<true>, grid, dim3(256), 0, st, X, rows, cols, ld, p.rows_per_block, stage1);
+    else hipLaunchKernelGGL(colsum_kernel<false>, grid, dim3(256), 0, st, X, rows, cols, ld, p.rows_per_block, stage1);
+    NNHIP_LAUNCH_CHECK("colsum_kernel");
+    if (p.row_blocks > 1) {
+        const bool v2 = p.vec && aligned16(stage1);
+        dim3 g2((unsigned)ceil_div(cols, v2 ? 256 : 64), 1);
+        if (v2) hipLaunchKernelGGL(colsum_kernel<true>, g2, dim3(256), 0, st, stage1, (int64_t)p.row_blocks, cols, cols, (int64_t)p.row_blocks, out);
+        else hipLaunchKernelGGL(colsum_kernel<false>, g2, dim3(256), 0, st, stage1, (int64_t)p.row_blocks, cols, cols, (int64_t)p.row_blocks, out);
+        NNHIP_LAUNCH_CHECK("colsum_kernel(stage2)");
+    }
+    return 0;
 }
 
 int colsum(const float* X, int64_t rows, int64_t cols, int64_t ld, float* out, hipStream_t st) {
     if (cols <= 0) return 0;
-    const bool vec = aligned16(X) && aligned16(out) && (ld % 4 == 0) && (cols % 4 == 0);
-    const int rb = colsum_row_blocks(rows, cols, vec);
-    const int64_t cb = ceil_div(cols, vec ? 1024 : 256);
-    float* stage1 = out;
-    if (rb > 1) {
-        stage1 = static_cast<float*>(workspace((size_t)rb * cols * sizeof(float)));
-        if (!stage1) { set_last_error("colsum workspace allocation failed"); return NNHIP_ENOMEM; }
+    const ColsumPlan p = colsum_plan(X, out, rows, cols, ld);
+    float* scratch = nullptr;
+    if (p.scratch_floats) {
+        scratch = static_cast<float*>(workspace(p.scratch_floats * sizeof(float)));
+        if (!scratch) { set_last_error("colsum workspace allocation failed"); return NNHIP_ENOMEM; }
     }
-    if (vec) hipLaunchKernelGGL(colsum_kernel<true>, dim3((unsigned)cb, rb), dim3(256), 0, st, X, rows, cols, ld, stage1);
-    else hipLaunchKernelGGL(colsum_kernel<false>, dim3((unsigned)cb, rb), dim3(256), 0, st, X, rows, cols, ld, stage1);
-    NNHIP_LAUNCH_CHECK("colsum_kernel");
-    if (rb > 1) {
-        const bool v2 = vec && aligned16(stage1);
-        const int64_t cb2 = ceil_div(cols, v2 ? 1024 : 256);
-        if (v2) hipLaunchKernelGGL(colsum_kernel<true>, dim3((unsigned)cb2, 1), dim3(256), 0, st, stage1, (int64_t)rb, cols, cols, out);
-        else hipLaunchKernelGGL(colsum_kernel<false>, dim3((unsigned)cb2, 1), dim3(256), 0, st, stage1, (int64_t)rb, cols, cols, out);
-        NNHIP_LAUNCH_CHECK("colsum_kernel(stage2)");
-    }
-    return 0;
+    return colsum_run(p, X, rows, cols, ld, out, scratch, st);
 }
 
 // Row-kernel dispatch: pick (TPR, NV) from the row width.
@@ -546,13 +592,17 @@ extern "C" int nnhipRMSNormBackward(const float* dY, const float* X, const float
     int64_t nblk = ceil_div(ceil_div(rows > 0 ? rows : 1, rpb), 2);
     if (nblk > 1024) nblk = 1024;
     const int64_t prow = nblk * rpb;
-    const size_t part_floats = (size_t)prow * cols;
-    // layout: [dw partials | db partials | (colsum scratch is a separate workspace() call ordering
-    // hazard) ] -> we reduce partials with our own single-stage kernel below, no nested workspace use.
-    float* part = static_cast<float*>(workspace(part_floats * (db ? 2 : 1) * sizeof(float)));
+    const size_t part_floats = ((size_t)prow * cols + 3) / 4 * 4;
+    // One workspace block: [dw partials | db partials | column-sum scratch for dw | ... for db]
+    const ColsumPlan cp = colsum_plan(nullptr, dW, prow, cols, cols);
+    const size_t scr = (cp.scratch_floats + 3) / 4 * 4;
+    const int nred = db ? 2 : 1;
+    float* part = static_cast<float*>(workspace((part_floats + scr) * nred * sizeof(float)));
     NNHIP_CHECK_ARG(part != nullptr, NNHIP_ENOMEM, "nnhipRMSNormBackward: workspace allocation failed");
     float* part_dw = part;
     float* part_db = db ? part + part_floats : nullptr;
+    float* scr_dw = part + part_floats * nred;
+    float* scr_db = scr_dw + scr;
     const bool vec = aligned16(dY) && aligned16(X) && aligned16(weight) && aligned16(dX) && cols % 4 == 0;
     {
         const int64_t rows_ = rows;
@@ -560,18 +610,13 @@ extern "C" int nnhipRMSNormBackward(const float* dY, const float* X, const float
         ROW_DISPATCH(rmsnorm_bwd_rows, cols, vec, prow, st, dY, X, weight, X_std, dX, part_dw, part_db, rows_, cols);
     }
     NNHIP_LAUNCH_CHECK("rmsnorm_backward");
-    // finish dw/db: single-stage column sums over `prow` partial rows (tiny: prow <= 2048)
-    const bool v2 = aligned16(part_dw) && aligned16(dW) && cols % 4 == 0 && (!db || aligned16(db)) &&
-                    (part_floats % 4 == 0);
-    const unsigned cb = (unsigned)ceil_div(cols, v2 ? 1024 : 256);
-    if (v2) {
-        hipLaunchKernelGGL(colsum_kernel<true>, dim3(cb, 1), dim3(256), 0, st, part_dw, prow, cols, cols, dW);
-        if (db) hipLaunchKernelGGL(colsum_kernel<true>, dim3(cb, 1), dim3(256), 0, st, part_db, prow, cols, cols, db);
-    } else {
-        hipLaunchKernelGGL(colsum_kernel<false>, dim3(cb, 1), dim3(256), 0, st, part_dw, prow, cols, cols, dW);
-        if (db) hipLaunchKernelGGL(colsum_kernel<false>, dim3(cb, 1), dim3(256), 0, st, part_db, prow, cols, cols, db);
+    // finish dw/db: column sums over the `prow` partial rows
+    ColsumPlan cdw = colsum_plan(part_dw, dW, prow, cols, cols);
+    if (int rc = colsum_run(cdw, part_dw, prow, cols, cols, dW, scr_dw, st)) return rc;
+    if (db) {
+        ColsumPlan cdb = colsum_plan(part_db, db, prow, cols, cols);
+        if (int rc = colsum_run(cdb, part_db, prow, cols, cols, db, scr_db, st)) return rc;
     }
-    NNHIP_LAUNCH_CHECK("rmsnorm_backward(colsum)");
     return 0;
 }
 
