@@ -271,70 +271,61 @@ def cpu_c1(seconds):
 # ------------------------------------------------------------------------------------------------ C3
 def workload_c3(args, rank, world):
     """Fused micro-bench, rows 8192 x d 4096 per GPU: Swish, RMSNorm, Softmax fwd+bwd, fused CE fwd+bwd,
-    multi-tensor AdamW on one 8192x4096 tensor.  A 'step' is one pass over all of them; the roofline entry
-    is the Swish forward kernel (HBM bound), per-op GB/s in `extra`."""
+    multi-tensor AdamW on one 8192x4096 tensor -- each called through the functional C-ABI wrappers on
+    pre-allocated buffers (the shape of the reference's scripts/benchmark_swish_cuda.py).  A 'step' is one
+    pass over all of them; the roofline entry is the Swish forward kernel (HBM bound), per-op GB/s in `ops`."""
     import torch
     import neunet_hip
-    from neunet_hip.nn.experimental import HIPCrossEntropyLoss, HIPRMSNorm, HIPSoftmax, HIPSwish
     from neunet_hip.nn import Parameter
+    from neunet_hip.nn.experimental.activations import (hip_softmax_backward, hip_softmax_forward,
+                                                        hip_swish_backward, hip_swish_forward)
+    from neunet_hip.nn.experimental.losses import cross_entropy_forward_backward
+    from neunet_hip.nn.experimental.rmsnorm import rmsnorm_backward, rmsnorm_forward
     from neunet_hip.optim import HIPFusedMultiTensorAdamW
     R, D = 8192, 4096
     rng = np.random.default_rng(1003 + rank)
     Xn = rng.standard_normal((R, D)).astype(np.float32)
-    x = neunet_hip.Tensor(Xn, device="cuda")
+    x = torch.from_numpy(Xn).cuda()
     dY = torch.from_numpy(rng.standard_normal((R, D)).astype(np.float32)).cuda()
-    labels = neunet_hip.Tensor(rng.integers(0, D, R).astype(np.int32), dtype=np.int32, requires_grad=False, device="cuda")
-    swish, norm, soft = HIPSwish(1.0), HIPRMSNorm(D), HIPSoftmax(-1)
-    ce = HIPCrossEntropyLoss(reduction="mean")
+    y, dx = torch.empty_like(x), torch.empty_like(x)
+    logits = x.clone()
+    labels = torch.from_numpy(rng.integers(0, D, R).astype(np.int32)).cuda()
+    w, std, dw = torch.ones(D, device="cuda"), torch.empty(R, device="cuda"), torch.empty(D, device="cuda")
     p = Parameter(neunet_hip.Tensor(Xn, device="cuda"))
+    p.grad = dY
     opt = HIPFusedMultiTensorAdamW([p], lr=1e-3, weight_decay=1e-2)
-    timers = {k: EventTimer() for k in ["swish_fwd", "swish_bwd", "rmsnorm_fwd", "rmsnorm_bwd", "softmax_fwd",
-                                        "softmax_bwd", "ce_fwd_bwd", "adamw"]}
+    ops = [
+        ("swish_fwd", lambda: hip_swish_forward(x, y, 1.0)),
+        ("swish_bwd", lambda: hip_swish_backward(dx, dY, x, 1.0)),
+        ("rmsnorm_fwd", lambda: rmsnorm_forward(x, w, None, None, std, y, 1e-6)),
+        ("rmsnorm_bwd", lambda: rmsnorm_backward(x, w, None, dY, dx, dw, None, None, std)),
+        ("softmax_fwd", lambda: hip_softmax_forward(x, y, -1)),
+        ("softmax_bwd", lambda: hip_softmax_backward(dx, dY, y, -1)),
+        ("ce_fwd_bwd", lambda: cross_entropy_forward_backward(logits, labels, "mean", -100, inplace=False)),
+        ("adamw", lambda: opt.step()),
+    ]
+    timers = {k: EventTimer() for k, _ in ops}
     n = R * D
     bytes_per = {"swish_fwd": 8 * n, "swish_bwd": 12 * n, "rmsnorm_fwd": 8 * n + 4 * R + 4 * D,
                  "rmsnorm_bwd": 12 * n + 4 * R + 8 * D, "softmax_fwd": 8 * n, "softmax_bwd": 12 * n,
                  "ce_fwd_bwd": 8 * n + 12 * R, "adamw": 28 * n}
 
-    def fb(mod, kf, kb, timed):
-        x.grad = None
-        if timed:
-            a, b = timers[kf].span()
-            a.record()
-        y = mod(x)
-        if timed:
-            b.record()
-        y.grad = dY
-        if timed:
-            c, d = timers[kb].span()
-            c.record()
-        y.grad_fn(*y.args, grad=dY)
-        if timed:
-            d.record()
-
     def step(timed):
-        fb(swish, "swish_fwd", "swish_bwd", timed)
-        fb(norm, "rmsnorm_fwd", "rmsnorm_bwd", timed)
-        norm.weight.grad = None
-        fb(soft, "softmax_fwd", "softmax_bwd", timed)
-        if timed:
-            a, b = timers["ce_fwd_bwd"].span()
-            a.record()
-        ce(x, labels)
-        if timed:
-            b.record()
-        p.grad = dY
-        if timed:
-            a, b = timers["adamw"].span()
-            a.record()
-        opt.step()
-        if timed:
-            b.record()
+        for k, fn in ops:
+            if timed:
+                a, b = timers[k].span()
+                a.record()
+                fn()
+                b.record()
+            else:
+                fn()
 
     dt = timed_region(step, args.steps, args.warmup, world)
-    ops = {k: {"ms": round(t.mean_ms(), 4), "GBps": round(bytes_per[k] / (t.mean_ms() * 1e-3) / 1e9, 1),
-               "frac_of_8TBps": round(bytes_per[k] / (t.mean_ms() * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
-           for k, t in timers.items()}
-    sw = ops["swish_fwd"]
+    res_ops = {k: {"ms": round(t.mean_ms(), 4), "GBps": round(bytes_per[k] / (t.mean_ms() * 1e-3) / 1e9, 1),
+                   "frac_of_8TBps": round(bytes_per[k] / (t.mean_ms() * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                   "hbm_traffic_pmc": read_traffic(k.replace("_fwd_bwd", "") + "_c3")}
+               for k, t in timers.items()}
+    sw = res_ops["swish_fwd"]
     return {
         "samples_per_step": R * world, "dt": dt,
         "config": {"workload": "C3: fused micro-bench rows 8192 x d 4096 per GPU (Swish, RMSNorm, Softmax fwd+bwd, "
@@ -344,7 +335,7 @@ def workload_c3(args, rank, world):
                      "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": sw["frac_of_8TBps"],
                      "traffic": read_traffic("swish_fwd_c3"), "bytes_per_launch": bytes_per["swish_fwd"],
                      "avg_launch_ms": sw["ms"]},
-        "extra": {"ops": ops},
+        "extra": {"ops": res_ops},
     }
 
 
