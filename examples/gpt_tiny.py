@@ -1,0 +1,111 @@
+"""GPT-tiny on the HIP path -- user-level model code with the module graph of the reference's
+examples/gpt.ipynb (cells 2-7, 11-12): Embedding*sqrt(d) + sinusoidal PE -> N x [RMSNorm -> masked
+multi-head self-attention -> residual -> RMSNorm -> Linear -> Swish -> Linear -> residual] -> Linear ->
+CrossEntropy(ignore_index=PAD) -> Adam.  Same attribute names / creation order, so Module.parameters()
+lists parameters in the notebook's order (including the never-called cross_attn of every DecoderLayer,
+whose 8 parameters never receive a gradient -- SURVEY 3.4).
+
+Used by bench.py (--workload c4) and the tests; BASELINE C4 = d_model 512, 6 layers, 8 heads, d_ff 2048,
+vocab 15000, batch 64 x seq 256.
+"""
+import math
+
+import numpy as np
+
+import neunet_hip
+import neunet_hip.nn as nn
+from neunet_hip import Tensor
+
+
+class PositionwiseFeedForward(nn.Module):
+    def __init__(self, d_model, d_ff, dropout=0.0, fused=True):
+        super().__init__()
+        self.fused = fused
+        if fused:   # fc_1 + Swish in one GEMM epilogue (fused Linear->Swish, a6); same parameters
+            self.fc_1 = nn.LinearSwish(d_model, d_ff, swish_beta=1.0, save_preactivation=True)
+        else:
+            self.fc_1 = nn.Linear(d_model, d_ff)
+        self.fc_2 = nn.Linear(d_ff, d_model)
+        self.dropout = nn.Dropout(dropout)
+        self.activation = nn.Swish()
+
+    def forward(self, x):
+        x = self.fc_1(x)
+        if not self.fused:
+            x = self.activation(x)
+        x = self.dropout(x)
+        return self.fc_2(x)
+
+
+class DecoderLayer(nn.Module):
+    def __init__(self, d_model, n_heads, d_ff, dropout=0.0, fused=True):
+        super().__init__()
+        self.self_attn = nn.MultiHeadAttention(d_model, n_heads, dropout)
+        self.cross_attn = nn.MultiHeadAttention(d_model, n_heads, dropout)   # constructed, never called
+        self.ffn = PositionwiseFeedForward(d_model, d_ff, dropout, fused)
+        self.norm1 = nn.RMSNorm(d_model)
+        self.norm2 = nn.RMSNorm(d_model)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, x, key_valid):
+        nx1 = self.norm1(x)
+        _x, attn = self.self_attn(nx1, nx1, nx1, key_valid, causal=True)
+        x = x + self.dropout(_x)
+        nx2 = self.norm2(x)
+        _x = self.ffn(nx2)
+        x = x + self.dropout(_x)
+        return x, attn
+
+
+class Decoder(nn.Module):
+    def __init__(self, tgt_vocab_size, d_model, n_heads, d_ff, n_layers, dropout=0.0, max_len=5000, fused=True):
+        super().__init__()
+        self.token_embedding = nn.Embedding(tgt_vocab_size, d_model)
+        self.position_embedding = nn.PositionalEncoding(d_model, max_len)
+        self.layers = nn.ModuleList([DecoderLayer(d_model, n_heads, d_ff, dropout, fused) for _ in range(n_layers)])
+        self.fc_out = nn.Linear(d_model, tgt_vocab_size)
+        self.dropout = nn.Dropout(dropout)
+        self.scale = math.sqrt(d_model)
+
+    def forward(self, ids, key_valid):
+        # emb * sqrt(d) + pe[:, :T] fused into the gather
+        x = self.token_embedding(ids, scale=self.scale, pe=self.position_embedding.table)
+        x = self.dropout(x)
+        attn = None
+        for layer in self.layers:
+            x, attn = layer(x, key_valid)
+        return self.fc_out(x), attn
+
+
+class GPT(nn.Module):
+    def __init__(self, decoder: Decoder, pad_idx: int):
+        super().__init__()
+        self.decoder = decoder
+        self.pad_idx = pad_idx
+
+    def forward(self, x):
+        """x: host int array (batch, seq) or a device int32 Tensor.  The notebook's dense mask
+        get_pad_mask(x) & get_sub_mask(x) is carried as (key_valid = x != pad, causal=True)."""
+        import torch
+        ids = x if isinstance(x, Tensor) else Tensor(np.asarray(x), dtype=np.int32, requires_grad=False, device="cuda")
+        key_valid = (ids.data != self.pad_idx).to(torch.int32)
+        return self.decoder(ids, key_valid)
+
+
+def build_gpt(vocab=15000, d_model=512, n_heads=8, d_ff=2048, n_layers=6, pad_idx=0, max_len=1024, fused=True):
+    dec = Decoder(vocab, d_model, n_heads, d_ff, n_layers, dropout=0.0, max_len=max_len, fused=fused)
+    return GPT(dec, pad_idx)
+
+
+def train_step(model, optimizer, loss_fn, batch_ids, bucket=None):
+    """cell 12's loop body: forward on batch[:, :-1], CE against batch[:, 1:], backward, step, zero_grad."""
+    output, _ = model.forward(batch_ids[:, :-1])
+    output = output.reshape(output.shape[0] * output.shape[1], output.shape[2])
+    targets = Tensor(np.ascontiguousarray(batch_ids[:, 1:]).reshape(-1), dtype=np.int32, requires_grad=False, device="cuda")
+    loss = loss_fn(output, targets)
+    loss.backward()
+    if bucket is not None:
+        bucket.all_reduce()
+    optimizer.step()
+    optimizer.zero_grad()
+    return loss

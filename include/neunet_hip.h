@@ -80,6 +80,15 @@ int nnhipGemmF32(const float* A, const float* B, float* C, const float* bias, in
                  int64_t batch, int64_t strideA, int64_t strideB, int64_t strideC,
                  nnhipStream_t stream);
 
+/* Same, with an output scale and a two-level batch: batch index z = z1*batch2 + z2 addresses
+ * A + z1*sA1 + z2*sA2 (likewise B, C):  C = alpha * op(A) op(B) (+ bias).  Lets attention read Q/K/V
+ * straight out of their [B,T,H*dh] projection buffers and write the context back in that layout -- no
+ * transpose copies (examples/gpt.ipynb cell 2 transposes/reshapes on the host side instead). */
+int nnhipGemmF32Ex(const float* A, const float* B, float* C, const float* bias, int64_t M, int64_t N,
+                   int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int a_kmajor, int b_kmajor,
+                   int64_t batch1, int64_t sA1, int64_t sB1, int64_t sC1, int64_t batch2, int64_t sA2,
+                   int64_t sB2, int64_t sC2, float alpha, nnhipStream_t stream);
+
 /* ---- a12 ReLU (net-new export; reference CPU: neunet/nn/activations.py:40-59) --------------- */
 int nnhipReLUForward(float* out, const float* in, int64_t size, nnhipStream_t stream);
 /* dIn = dOut * (out > 0), `out` = forward output */
@@ -105,6 +114,16 @@ int nnhipSoftmaxForward(float* out, const float* in, int64_t num_slices, int64_t
                         int64_t stride, nnhipStream_t stream);
 int nnhipSoftmaxBackward(float* dX, const float* dY, const float* Y, int64_t num_slices,
                          int64_t slice_size, int64_t stride, nnhipStream_t stream);
+
+/* Attention-score softmax with scale and mask fused (examples/gpt.ipynb cell 2):
+ *   y = softmax_j( masked(b,i,j) ? -1e9 : scale * x[b,h,i,j] ),  x,y: [B,H,Tq,Tk]
+ *   masked = (key_valid && key_valid[b*Tk + j] == 0) || (causal && j > i + Tk - Tq).   key_valid may be NULL.
+ * Backward: dX = masked ? 0 : scale * (dY - sum_j dY*Y) * Y. */
+int nnhipMaskedSoftmaxForward(float* out, const float* in, const int32_t* key_valid, int64_t B, int64_t H,
+                              int64_t Tq, int64_t Tk, float scale, int causal, nnhipStream_t stream);
+int nnhipMaskedSoftmaxBackward(float* dX, const float* dY, const float* Y, const int32_t* key_valid,
+                               int64_t B, int64_t H, int64_t Tq, int64_t Tk, float scale, int causal,
+                               nnhipStream_t stream);
 
 /* ---- a9 fused CrossEntropy forward+backward  (replaces cudaCrossEntropyForwardBackward,
  *      cross_entropy.cu:249-260).
@@ -177,11 +196,24 @@ int nnhipConv2dForward(const float* X, const float* W, const float* bias, float*
 int nnhipConv2dBackward(const float* X, const float* W, const float* dO, float* dX, float* dW,
                         float* db, const nnhipConv2dDesc* d, nnhipStream_t stream);
 
+/* ---- Embedding (reference CPU: neunet/nn/layers/embedding.py:61-75 via
+ *      Tensor.__getitem__, neunet/autograd.py:895-916) ------------------------------------------------
+ * out[p,:] = weight[ids[p],:] * scale + (pe ? pe[p % seq_len,:] : 0);  ids int32 (negative = from the end).
+ * Backward reproduces the reference's ASSIGNMENT semantics (autograd.py:909-910): for repeated ids only
+ * the last occurrence contributes:  dW[v,:] = scale * grad_out[last_pos(v),:], 0 for unused rows. */
+int nnhipEmbeddingForward(float* out, const float* weight, const int32_t* ids, const float* pe,
+                          int64_t n_ids, int64_t dim, int64_t seq_len, int64_t vocab, float scale,
+                          nnhipStream_t stream);
+int nnhipEmbeddingBackward(float* dW, const float* grad_out, const int32_t* ids, int64_t n_ids,
+                           int64_t dim, int64_t vocab, float scale, nnhipStream_t stream);
+
 /* ---- gradient-bucket helpers for data-parallel training (net-new) ---------------- */
 /* x[i] *= alpha */
 int nnhipScale(float* x, float alpha, int64_t n, nnhipStream_t stream);
 /* out[i] = a[i] + b[i]   (Tensor.apply_grad accumulation, neunet/autograd.py:85-93) */
 int nnhipAdd(float* out, const float* a, const float* b, int64_t n, nnhipStream_t stream);
+/* out[i] = a[i] * b[i]   (Dropout mask application, neunet/nn/layers/dropout.py:17-37) */
+int nnhipMul(float* out, const float* a, const float* b, int64_t n, nnhipStream_t stream);
 
 #ifdef __cplusplus
 }

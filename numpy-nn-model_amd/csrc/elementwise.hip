@@ -106,6 +106,7 @@ struct ScaleF {
     __device__ float operator()(float x) const { return alpha * x; }
 };
 struct AddF { __device__ float operator()(float a, float b) const { return a + b; } };
+struct MulF { __device__ float operator()(float a, float b) const { return a * b; } };
 
 template <class F>
 static int launch_map1(float* out, const float* a, int64_t n, F f, hipStream_t st, const char* nm) {
@@ -287,4 +288,10 @@ extern "C" int nnhipAdd(float* out, const float* a, const float* b, int64_t n, n
     if (n == 0) return 0;
     NNHIP_PTRS("nnhipAdd", out, a, b);
     return launch_map2(out, a, b, n, AddF{}, (hipStream_t)s, "add");
+}
+extern "C" int nnhipMul(float* out, const float* a, const float* b, int64_t n, nnhipStream_t s) {
+    NNHIP_CHECK_ARG(n >= 0, NNHIP_EINVAL, "nnhipMul: negative size");
+    if (n == 0) return 0;
+    NNHIP_PTRS("nnhipMul", out, a, b);
+    return launch_map2(out, a, b, n, MulF{}, (hipStream_t)s, "mul");
 }

@@ -1,0 +1,120 @@
+// embedding.hip -- Embedding gather and its last-write-wins gradient.
+// CPU semantics: Embedding.forward = weight[ids] (neunet/nn/layers/embedding.py:71-72) through
+// Tensor.__getitem__, whose backward ASSIGNS into zeros -- `_grad[index] = grad`
+// (neunet/autograd.py:905-912): for repeated token ids only the LAST occurrence (C order) survives.
+// That is reproduced exactly and deterministically here (atomicMax of positions, then one copy per
+// vocabulary row); it is the reference's behaviour, not the mathematical gradient.
+// The decoder's `emb * sqrt(d_model) + pe[:, :T]` (examples/gpt.ipynb cells 5-6) is fused into the gather.
+#include "common.h"
+
+namespace nnhip {
+
+// out[p, :] = W[ids[p], :] * scale + (pe ? pe[(p % T), :] : 0)        one wave per row, float4 lanes
+template <bool VEC>
+__global__ __launch_bounds__(256) void embedding_fwd_kernel(float* __restrict__ out,
+                                                            const float* __restrict__ W,
+                                                            const int32_t* __restrict__ ids,
+                                                            const float* __restrict__ pe, int64_t n,
+                                                            int64_t dim, int64_t T, int64_t vocab, float scale) {
+    const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (p >= n) return;
+    int64_t id = ids[p];
+    if (id < 0) id += vocab;                      // python negative indexing
+    const bool ok = id >= 0 && id < vocab;        // out-of-range ids read as zero rows
+    const float* src = W + id * dim;
+    const float* per = pe ? pe + (p % T) * dim : nullptr;
+    float* dst = out + p * dim;
+    if constexpr (VEC) {
+        for (int64_t c = lane * 4; c < dim; c += 256) {
+            float4 v = ok ? *reinterpret_cast<const float4*>(src + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+            if (per) {
+                const float4 q = *reinterpret_cast<const float4*>(per + c);
+                v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+            }
+            *reinterpret_cast<float4*>(dst + c) = v;
+        }
+    } else {
+        for (int64_t c = lane; c < dim; c += 64) {
+            float v = (ok ? src[c] : 0.f) * scale;
+            if (per) v += per[c];
+            dst[c] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void embedding_last_kernel(const int32_t* __restrict__ ids, int64_t n,
+                                                             int64_t vocab, int32_t* __restrict__ last) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    int64_t id = ids[p];
+    if (id < 0) id += vocab;
+    if (id >= 0 && id < vocab) atomicMax(&last[id], (int32_t)p);
+}
+
+// dW[v, :] = last[v] >= 0 ? scale * g[last[v], :] : 0        one wave per vocabulary row
+template <bool VEC>
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(float* __restrict__ dW,
+                                                            const float* __restrict__ g,
+                                                            const int32_t* __restrict__ last, int64_t vocab,
+                                                            int64_t dim, float scale) {
+    const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (v >= vocab) return;
+    const int32_t src = last[v];
+    float* dst = dW + v * dim;
+    if constexpr (VEC) {
+        for (int64_t c = lane * 4; c < dim; c += 256) {
+            float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (src >= 0) {
+                q = *reinterpret_cast<const float4*>(g + (int64_t)src * dim + c);
+                q.x *= scale; q.y *= scale; q.z *= scale; q.w *= scale;
+            }
+            *reinterpret_cast<float4*>(dst + c) = q;
+        }
+    } else {
+        for (int64_t c = lane; c < dim; c += 64) dst[c] = src >= 0 ? g[(int64_t)src * dim + c] * scale : 0.f;
+    }
+}
+
+}  // namespace nnhip
+
+using namespace nnhip;
+
+extern "C" int nnhipEmbeddingForward(float* out, const float* weight, const int32_t* ids, const float* pe,
+                                     int64_t n_ids, int64_t dim, int64_t seq_len, int64_t vocab, float scale,
+                                     nnhipStream_t s) {
+    NNHIP_CHECK_ARG(n_ids >= 0 && dim >= 0 && vocab > 0 && seq_len > 0, NNHIP_EINVAL, "nnhipEmbeddingForward: bad sizes");
+    if (n_ids == 0 || dim == 0) return 0;
+    NNHIP_CHECK_ARG(out && weight && ids, NNHIP_EINVAL, "nnhipEmbeddingForward: null pointer");
+    const bool vec = dim % 4 == 0 && aligned16(out) && aligned16(weight) && (!pe || aligned16(pe));
+    const unsigned grid = (unsigned)ceil_div(n_ids, 4);
+    if (vec) hipLaunchKernelGGL(embedding_fwd_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)s, out, weight, ids, pe, n_ids, dim, seq_len, vocab, scale);
+    else hipLaunchKernelGGL(embedding_fwd_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)s, out, weight, ids, pe, n_ids, dim, seq_len, vocab, scale);
+    NNHIP_LAUNCH_CHECK("embedding_fwd_kernel");
+    return 0;
+}
+
+extern "C" int nnhipEmbeddingBackward(float* dW, const float* grad_out, const int32_t* ids, int64_t n_ids,
+                                      int64_t dim, int64_t vocab, float scale, nnhipStream_t s) {
+    NNHIP_CHECK_ARG(n_ids >= 0 && dim >= 0 && vocab > 0, NNHIP_EINVAL, "nnhipEmbeddingBackward: bad sizes");
+    NNHIP_CHECK_ARG(n_ids < ((int64_t)1 << 31), NNHIP_EINVAL, "nnhipEmbeddingBackward: too many ids");
+    if (dim == 0) return 0;
+    NNHIP_CHECK_ARG(dW && (n_ids == 0 || (grad_out && ids)), NNHIP_EINVAL, "nnhipEmbeddingBackward: null pointer");
+    hipStream_t st = (hipStream_t)s;
+    int32_t* last = static_cast<int32_t*>(workspace((size_t)vocab * sizeof(int32_t)));
+    NNHIP_CHECK_ARG(last != nullptr, NNHIP_ENOMEM, "nnhipEmbeddingBackward: workspace allocation failed");
+    hipError_t e = hipMemsetAsync(last, 0xFF, (size_t)vocab * sizeof(int32_t), st);  // -1
+    if (e != hipSuccess) return hip_status(e, "hipMemsetAsync(embedding last)");
+    if (n_ids > 0) {
+        hipLaunchKernelGGL(embedding_last_kernel, dim3((unsigned)ceil_div(n_ids, 256)), dim3(256), 0, st, ids, n_ids, vocab, last);
+        NNHIP_LAUNCH_CHECK("embedding_last_kernel");
+    }
+    const bool vec = dim % 4 == 0 && aligned16(dW) && aligned16(grad_out);
+    const unsigned grid = (unsigned)ceil_div(vocab, 4);
+    if (vec) hipLaunchKernelGGL(embedding_bwd_kernel<true>, dim3(grid), dim3(256), 0, st, dW, grad_out, last, vocab, dim, scale);
+    else hipLaunchKernelGGL(embedding_bwd_kernel<false>, dim3(grid), dim3(256), 0, st, dW, grad_out, last, vocab, dim, scale);
+    NNHIP_LAUNCH_CHECK("embedding_bwd_kernel");
+    return 0;
+}

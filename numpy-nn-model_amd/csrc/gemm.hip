@@ -38,6 +38,9 @@ struct GemmParams {
     const float* bias;   // [N] or null
     float* preact;       // [M, ldc] or null: pre-activation (z) output for ACT_SWISH
     int64_t M, N, K, lda, ldb, ldc, sA, sB, sC;
+    int64_t sA2, sB2, sC2;  // inner batch level: batch index z -> (z / batch2, z % batch2)
+    int batch2;
+    float alpha;            // C = alpha * (A B) + bias
     int tiles_m, tiles_n, splitk;
     int64_t k_per_split;  // multiple of BK
     float* slab;          // split-K partials [splitk][M][N] (dense)
@@ -155,9 +158,10 @@ __global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const 
     const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
     const int64_t kbeg = (int64_t)split * p.k_per_split;
     const int64_t kend = min(p.K, kbeg + p.k_per_split);
-    const int bz = blockIdx.y;
-    const float* __restrict__ A = p.A + (int64_t)bz * p.sA;
-    const float* __restrict__ B = p.B + (int64_t)bz * p.sB;
+    const int bz1 = blockIdx.y / p.batch2, bz2 = blockIdx.y - bz1 * p.batch2;
+    const float* __restrict__ A = p.A + (int64_t)bz1 * p.sA + (int64_t)bz2 * p.sA2;
+    const float* __restrict__ B = p.B + (int64_t)bz1 * p.sB + (int64_t)bz2 * p.sB2;
+    const int64_t c_off = (int64_t)bz1 * p.sC + (int64_t)bz2 * p.sC2;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const 
 
     // ---- epilogue: acc reg e of a 32x32 tile -> row (e&3) + 8*(e>>2) + 4*lh, col l31 -----------
     const bool to_slab = p.splitk > 1;
-    float* __restrict__ C = to_slab ? p.slab + (int64_t)split * p.M * p.N : p.C + (int64_t)bz * p.sC;
+    float* __restrict__ C = to_slab ? p.slab + (int64_t)split * p.M * p.N : p.C + c_off;
     const int64_t ldc = to_slab ? p.N : p.ldc;
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
@@ -230,10 +234,10 @@ __global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const 
             for (int e = 0; e < 16; ++e) {
                 const int64_t row = rbase + (e & 3) + 8 * (e >> 2);
                 if (row >= p.M) continue;
-                float v = acc[i][n][e] + bv;
+                float v = to_slab ? acc[i][n][e] : p.alpha * acc[i][n][e] + bv;
                 if (!to_slab) {
                     if (p.act == ACT_SWISH) {
-                        if (p.preact) p.preact[(int64_t)bz * p.sC + row * ldc + col] = v;
+                        if (p.preact) p.preact[c_off + row * ldc + col] = v;
                         v = v * sigmoidf_(p.beta * v);
                     } else if (p.act == ACT_RELU) {
                         v = fmaxf(v, 0.f);
@@ -251,12 +255,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
                                                             float* __restrict__ preact,
                                                             const float* __restrict__ bias,
                                                             int64_t M, int64_t N, int64_t ldc,
-                                                            int splitk, int act, float beta) {
+                                                            int splitk, int act, float beta, float alpha) {
     const int64_t total = M * N;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         float s = 0.f;
         for (int k = 0; k < splitk; ++k) s += slab[(int64_t)k * total + i];
+        s *= alpha;
         const int64_t m = i / N, n = i - m * N;
         if (bias) s += bias[n];
         if (act == ACT_SWISH) {
@@ -287,10 +292,24 @@ static int launch_variant(const GemmParams& p, int64_t batch, hipStream_t st) {
 }
 
 // Host-side GEMM dispatcher (internal API used by linear.hip / api).
+int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, float* preact, int64_t M,
+                int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, bool a_kmajor, bool b_kmajor,
+                int64_t batch1, int64_t sA, int64_t sB, int64_t sC, int64_t batch2, int64_t sA2,
+                int64_t sB2, int64_t sC2, float alpha, int act, float beta, hipStream_t st);
+
 int gemm_f32(const float* A, const float* B, float* C, const float* bias, float* preact, int64_t M,
              int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, bool a_kmajor,
              bool b_kmajor, int64_t batch, int64_t sA, int64_t sB, int64_t sC, int act, float beta,
              hipStream_t st) {
+    return gemm_f32_ex(A, B, C, bias, preact, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, batch, sA, sB, sC, 1,
+                       0, 0, 0, 1.0f, act, beta, st);
+}
+
+int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, float* preact, int64_t M,
+                int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, bool a_kmajor, bool b_kmajor,
+                int64_t batch1, int64_t sA, int64_t sB, int64_t sC, int64_t batch2, int64_t sA2,
+                int64_t sB2, int64_t sC2, float alpha, int act, float beta, hipStream_t st) {
+    const int64_t batch = batch1 * batch2;
     if (M <= 0 || N <= 0 || batch <= 0) return 0;
     static const int bk_sel = []() { const char* e = getenv("NNHIP_GEMM_BK"); return e ? atoi(e) : 32; }();
     const int BK = (bk_sel == 16) ? 16 : 32;
@@ -298,6 +317,7 @@ int gemm_f32(const float* A, const float* B, float* C, const float* bias, float*
     p.A = A; p.B = B; p.C = C; p.bias = bias; p.preact = preact;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.sA = sA; p.sB = sB; p.sC = sC;
+    p.sA2 = sA2; p.sB2 = sB2; p.sC2 = sC2; p.batch2 = (int)batch2; p.alpha = alpha;
     p.tiles_m = (int)ceil_div(M, BM);
     p.tiles_n = (int)ceil_div(N, BN);
     p.act = act; p.beta = beta;
@@ -323,11 +343,11 @@ int gemm_f32(const float* A, const float* B, float* C, const float* bias, float*
     }
 
     // float4 global loads need 16-B aligned rows along the contiguous dim
-    auto vec_ok = [&](const float* P, int64_t ld, int64_t stride_b, bool kmajor, int64_t outer) {
-        if (!aligned16(P) || (ld & 3) || (batch > 1 && (stride_b & 3))) return false;
+    auto vec_ok = [&](const float* P, int64_t ld, int64_t s1, int64_t s2, bool kmajor, int64_t outer) {
+        if (!aligned16(P) || (ld & 3) || (batch1 > 1 && (s1 & 3)) || (batch2 > 1 && (s2 & 3))) return false;
         return kmajor ? ((K & 3) == 0) : ((outer & 3) == 0);
     };
-    const bool vec = vec_ok(A, lda, sA, a_kmajor, M) && vec_ok(B, ldb, sB, b_kmajor, N);
+    const bool vec = vec_ok(A, lda, sA, sA2, a_kmajor, M) && vec_ok(B, ldb, sB, sB2, b_kmajor, N);
 
     int rc;
 #define NNHIP_GEMM_CASE(AK, BKM)                                                                   \
@@ -346,7 +366,7 @@ int gemm_f32(const float* A, const float* B, float* C, const float* bias, float*
         const int64_t total = M * N;
         int blocks = (int)(ceil_div(total, 256) < 2048 ? ceil_div(total, 256) : 2048);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.slab, C, preact,
-                           bias, M, N, ldc, p.splitk, act, beta);
+                           bias, M, N, ldc, p.splitk, act, beta, alpha);
         NNHIP_LAUNCH_CHECK("splitk_reduce_kernel");
     }
     return 0;
@@ -354,12 +374,28 @@ int gemm_f32(const float* A, const float* B, float* C, const float* bias, float*
 
 }  // namespace nnhip
 
+extern "C" int nnhipGemmF32Ex(const float* A, const float* B, float* C, const float* bias, int64_t M,
+                              int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int a_kmajor,
+                              int b_kmajor, int64_t batch1, int64_t sA1, int64_t sB1, int64_t sC1,
+                              int64_t batch2, int64_t sA2, int64_t sB2, int64_t sC2, float alpha,
+                              nnhipStream_t stream) {
+    NNHIP_CHECK_ARG(A && B && C, NNHIP_EINVAL, "nnhipGemmF32Ex: null operand");
+    NNHIP_CHECK_ARG(M >= 0 && N >= 0 && K >= 0 && batch1 >= 0 && batch2 >= 1, NNHIP_EINVAL, "nnhipGemmF32Ex: bad size");
+    NNHIP_CHECK_ARG(batch1 * batch2 <= 65535, NNHIP_EINVAL, "nnhipGemmF32Ex: batch1*batch2 must be <= 65535");
+    NNHIP_CHECK_ARG(nnhip::aligned4(A) && nnhip::aligned4(B) && nnhip::aligned4(C), NNHIP_EALIGN,
+                    "nnhipGemmF32Ex: pointers must be 4-byte aligned");
+    return nnhip::gemm_f32_ex(A, B, C, bias, nullptr, M, N, K, lda, ldb, ldc, a_kmajor != 0, b_kmajor != 0,
+                              batch1, sA1, sB1, sC1, batch2, sA2, sB2, sC2, alpha, nnhip::ACT_NONE, 1.f,
+                              static_cast<hipStream_t>(stream));
+}
+
 extern "C" int nnhipGemmF32(const float* A, const float* B, float* C, const float* bias, int64_t M,
                             int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
                             int a_kmajor, int b_kmajor, int64_t batch, int64_t strideA,
                             int64_t strideB, int64_t strideC, nnhipStream_t stream) {
     NNHIP_CHECK_ARG(A && B && C, NNHIP_EINVAL, "nnhipGemmF32: null operand");
     NNHIP_CHECK_ARG(M >= 0 && N >= 0 && K >= 0 && batch >= 0, NNHIP_EINVAL, "nnhipGemmF32: negative size");
+    NNHIP_CHECK_ARG(batch <= 65535, NNHIP_EINVAL, "nnhipGemmF32: batch must be <= 65535");
     NNHIP_CHECK_ARG(nnhip::aligned4(A) && nnhip::aligned4(B) && nnhip::aligned4(C), NNHIP_EALIGN,
                     "nnhipGemmF32: pointers must be 4-byte aligned");
     return nnhip::gemm_f32(A, B, C, bias, nullptr, M, N, K, lda, ldb, ldc, a_kmajor != 0,

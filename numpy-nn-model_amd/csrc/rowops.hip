@@ -127,6 +127,72 @@ __global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void softmax_bwd_rows(
     g.store(dx + row * cols, cols, t);
 }
 
+// Attention-score softmax with the scale and the mask fused in (examples/gpt.ipynb cell 2:
+// scores = QK^T / sqrt(d_model); scores = where(mask == 0, -1e9, scores); attn = Softmax(-1)(scores)).
+// Row r <-> (b, h, i); column j is masked when key j of batch b is padding (key_valid[b,j] == 0) or, if
+// `causal`, j > i + (cols - Tq).  Masked scores are REPLACED by -1e9 (not -inf), exactly like the reference.
+template <int TPR, int NV, bool VEC>
+__global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void softmax_masked_fwd_rows(
+    float* out, const float* in, const int32_t* __restrict__ key_valid,  // out may alias in
+    int64_t rows, int64_t cols, int64_t HTq, int64_t Tq, float scale, int causal) {
+    ROW_PROLOGUE(TPR)
+    RowTile<TPR, NV, VEC> r;
+    r.load(in + row * cols, cols, t, -INFINITY);
+    const int64_t b = row / HTq;
+    const int64_t i = row % Tq;
+    const int64_t lim = causal ? i + (cols - Tq) : cols;  // last visible column
+    const int32_t* kv = key_valid ? key_valid + b * cols : nullptr;
+    float m = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < r.NE; ++e) {
+        const int64_t c = r.col(t, e);
+        if (c < cols) {
+            const bool masked = c > lim || (kv && kv[c] == 0);
+            r.x[e] = masked ? -1e9f : r.x[e] * scale;
+        }
+        m = fmaxf(m, r.x[e]);
+    }
+    m = row_max<TPR>(m, red);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < r.NE; ++e) {
+        r.x[e] = expf(r.x[e] - m);
+        s += r.x[e];
+    }
+    s = row_sum<TPR>(s, red);
+    const float inv = 1.0f / s;
+#pragma unroll
+    for (int e = 0; e < r.NE; ++e) r.x[e] *= inv;
+    r.store(out + row * cols, cols, t);
+}
+
+// d(raw scores) = where(mask, 0, (dy - sum(dy*y)) * y) * scale
+template <int TPR, int NV, bool VEC>
+__global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void softmax_masked_bwd_rows(
+    float* dx, const float* dy, const float* __restrict__ y,  // dx may alias dy
+    const int32_t* __restrict__ key_valid, int64_t rows, int64_t cols, int64_t HTq, int64_t Tq,
+    float scale, int causal) {
+    ROW_PROLOGUE(TPR)
+    RowTile<TPR, NV, VEC> g, f;
+    g.load(dy + row * cols, cols, t, 0.f);
+    f.load(y + row * cols, cols, t, 0.f);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < g.NE; ++e) s += g.x[e] * f.x[e];
+    s = row_sum<TPR>(s, red);
+    const int64_t b = row / HTq;
+    const int64_t i = row % Tq;
+    const int64_t lim = causal ? i + (cols - Tq) : cols;
+    const int32_t* kv = key_valid ? key_valid + b * cols : nullptr;
+#pragma unroll
+    for (int e = 0; e < g.NE; ++e) {
+        const int64_t c = g.col(t, e);
+        const bool masked = c < cols && (c > lim || (kv && kv[c] == 0));
+        g.x[e] = masked ? 0.f : (g.x[e] - s) * f.x[e] * scale;
+    }
+    g.store(dx + row * cols, cols, t);
+}
+
 // Fallback: arbitrary slice length / stride.  One thread per slice when stride > 1 (adjacent slices
 // are adjacent in memory -> coalesced across threads); one block per slice when stride == 1.
 __global__ __launch_bounds__(256) void softmax_fwd_strided(float* __restrict__ out,
@@ -668,5 +734,36 @@ extern "C" int nnhipReduceLoss(const float* loss_rows, int64_t n_rows, char redu
     hipLaunchKernelGGL(reduce_loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)s, loss_rows, n_rows,
                        reduction == 'm' ? 1 : 0, count_dev, out);
     NNHIP_LAUNCH_CHECK("reduce_loss_kernel");
+    return 0;
+}
+
+// ---- attention-score softmax (scale + pad/causal mask fused) --------------------------------------------
+extern "C" int nnhipMaskedSoftmaxForward(float* out, const float* in, const int32_t* key_valid, int64_t B,
+                                         int64_t H, int64_t Tq, int64_t Tk, float scale, int causal,
+                                         nnhipStream_t s) {
+    NNHIP_CHECK_ARG(B >= 0 && H >= 0 && Tq >= 0 && Tk >= 0, NNHIP_EINVAL, "nnhipMaskedSoftmaxForward: negative size");
+    const int64_t rows = B * H * Tq;
+    if (rows == 0 || Tk == 0) return 0;
+    NNHIP_CHECK_ARG(out && in, NNHIP_EINVAL, "nnhipMaskedSoftmaxForward: null pointer");
+    NNHIP_CHECK_ARG(Tk <= kMaxRegRow, NNHIP_EINVAL, "nnhipMaskedSoftmaxForward: Tk > 16384 not supported");
+    hipStream_t st = (hipStream_t)s;
+    const bool vec = aligned16(out) && aligned16(in) && Tk % 4 == 0;
+    ROW_DISPATCH(softmax_masked_fwd_rows, Tk, vec, rows, st, out, in, key_valid, rows, Tk, H * Tq, Tq, scale, causal);
+    NNHIP_LAUNCH_CHECK("softmax_masked_fwd_rows");
+    return 0;
+}
+
+extern "C" int nnhipMaskedSoftmaxBackward(float* dX, const float* dY, const float* Y, const int32_t* key_valid,
+                                          int64_t B, int64_t H, int64_t Tq, int64_t Tk, float scale, int causal,
+                                          nnhipStream_t s) {
+    NNHIP_CHECK_ARG(B >= 0 && H >= 0 && Tq >= 0 && Tk >= 0, NNHIP_EINVAL, "nnhipMaskedSoftmaxBackward: negative size");
+    const int64_t rows = B * H * Tq;
+    if (rows == 0 || Tk == 0) return 0;
+    NNHIP_CHECK_ARG(dX && dY && Y, NNHIP_EINVAL, "nnhipMaskedSoftmaxBackward: null pointer");
+    NNHIP_CHECK_ARG(Tk <= kMaxRegRow, NNHIP_EINVAL, "nnhipMaskedSoftmaxBackward: Tk > 16384 not supported");
+    hipStream_t st = (hipStream_t)s;
+    const bool vec = aligned16(dX) && aligned16(dY) && aligned16(Y) && Tk % 4 == 0;
+    ROW_DISPATCH(softmax_masked_bwd_rows, Tk, vec, rows, st, dX, dY, Y, key_valid, rows, Tk, H * Tq, Tq, scale, causal);
+    NNHIP_LAUNCH_CHECK("softmax_masked_bwd_rows");
     return 0;
 }

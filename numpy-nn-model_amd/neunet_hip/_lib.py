@@ -40,6 +40,13 @@ _SIGNATURES = {
     "nnhipLinearSwishBackward": (ctypes.c_int, [P, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_float, ctypes.c_int, c_void_p]),
     "nnhipGemmF32": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, ctypes.c_int, ctypes.c_int,
                                     c_int64, c_int64, c_int64, c_int64, c_void_p]),
+    "nnhipGemmF32Ex": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, ctypes.c_int, ctypes.c_int,
+                                      c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_float, c_void_p]),
+    "nnhipMaskedSoftmaxForward": (ctypes.c_int, [P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, ctypes.c_int, c_void_p]),
+    "nnhipMaskedSoftmaxBackward": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, ctypes.c_int, c_void_p]),
+    "nnhipEmbeddingForward": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, c_void_p]),
+    "nnhipEmbeddingBackward": (ctypes.c_int, [P, P, P, c_int64, c_int64, c_int64, c_float, c_void_p]),
+    "nnhipMul": (ctypes.c_int, [P, P, P, c_int64, c_void_p]),
     "nnhipReLUForward": (ctypes.c_int, [P, P, c_int64, c_void_p]),
     "nnhipReLUBackward": (ctypes.c_int, [P, P, P, c_int64, c_void_p]),
     "nnhipSwishForward": (ctypes.c_int, [P, P, c_float, c_int64, c_void_p]),

@@ -256,5 +256,28 @@ class Tensor:
         out.grad_fn = grad_fn
         return out
 
+    def add(self, t: "Tensor") -> "Tensor":
+        """Residual add (neunet/autograd.py:96-116): out = self + t, both parents receive the gradient."""
+        if not isinstance(t, Tensor):
+            raise TypeError("only Tensor + Tensor is provided on the hot path")
+        if t.device != self.device:
+            raise ValueError("Tensors must be on the same device")
+        if tuple(t.shape) != tuple(self.shape):
+            raise ValueError("broadcasting adds are host glue and out of scope; shapes must match")
+        rg = self.requires_grad or t.requires_grad
+        out = Tensor(add_arrays(self.data, t.data), (self, t) if rg else None, "add", requires_grad=rg,
+                     device=self.device, _nocopy=True)
+
+        def grad_fn(a, b, grad):
+            if a.requires_grad:
+                a.apply_grad(grad)
+            if b.requires_grad:
+                b.apply_grad(grad)
+
+        out.grad_fn = grad_fn
+        return out
+
+    __add__ = add
+
     def __repr__(self):
         return f"Tensor(shape={self.shape}, dtype={self.dtype}, device={self.device}, op={self.op})"

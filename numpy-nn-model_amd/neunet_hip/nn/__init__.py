@@ -5,7 +5,9 @@ from .parameter import Parameter  # noqa: F401
 from . import experimental  # noqa: F401
 from .experimental import (HIPConv2d as Conv2d, HIPCrossEntropyLoss, HIPLinear as Linear,  # noqa: F401
                            HIPLinearSwish as LinearSwish, HIPReLU as ReLU, HIPRMSNorm as RMSNorm,
-                           HIPSoftmax as Softmax, HIPSwish as Swish, HIPFusedSwishAndMul as FusedSwishAndMul)
+                           HIPSoftmax as Softmax, HIPSwish as Swish, HIPFusedSwishAndMul as FusedSwishAndMul,
+                           HIPEmbedding as Embedding, HIPDropout as Dropout, HIPMultiHeadAttention as MultiHeadAttention,
+                           HIPPositionalEncoding as PositionalEncoding)
 
 
 class CrossEntropyLoss(HIPCrossEntropyLoss):

@@ -7,3 +7,5 @@ from .linear_swish import CUDALinearSwish, HIPLinearSwish  # noqa: F401
 from .losses import CUDACrossEntropyLoss, HIPCrossEntropyLoss  # noqa: F401
 from .rmsnorm import CUDARMSNorm, HIPRMSNorm  # noqa: F401
 from .conv2d import HIPConv2d  # noqa: F401
+from .attention import HIPMultiHeadAttention  # noqa: F401
+from .embedding import HIPDropout, HIPEmbedding, HIPPositionalEncoding  # noqa: F401

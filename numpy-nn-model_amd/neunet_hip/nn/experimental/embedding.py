@@ -1,0 +1,127 @@
+"""HIPEmbedding / HIPDropout / HIPPositionalEncoding (the callers either side of the hot path in
+the GPT step, examples/gpt.ipynb cells 5-6).
+
+Embedding: forward = weight[ids] (neunet/nn/layers/embedding.py:61-75); the gradient reproduces the
+reference's assignment semantics -- for repeated ids the LAST occurrence wins (neunet/autograd.py:905-912).
+`scale` and a positional-encoding table can be fused into the gather (cell 6: emb * sqrt(d) + pe[:, :T])."""
+import math
+
+import numpy as np
+
+from ...autograd import Tensor
+from ..modules import Module
+from ..parameter import Parameter
+from .linear import _grad_out
+from .utils import call_hip_function, get_current_stream_ptr
+
+
+def hip_embedding_forward(out, weight, ids, pe, seq_len, scale):
+    n_ids, dim = ids.numel(), weight.shape[1]
+    call_hip_function("nnhipEmbeddingForward", out, weight, ids, pe, n_ids, dim, seq_len, weight.shape[0],
+                      float(scale), get_current_stream_ptr())
+    return out
+
+
+def hip_embedding_backward(grad_weight, grad_out, ids, scale):
+    call_hip_function("nnhipEmbeddingBackward", grad_weight, grad_out, ids, ids.numel(), grad_weight.shape[1],
+                      grad_weight.shape[0], float(scale), get_current_stream_ptr())
+    return grad_weight
+
+
+class _HIPEmbeddingTensor(Tensor):
+    def __init__(self, data, args, op, device):
+        super().__init__(data, args, op, device=device, _nocopy=True)
+
+        def grad_fn(weight: Tensor, ids, scale, grad):
+            grad = grad if grad.is_contiguous() else grad.contiguous()
+            grad_weight = _grad_out(weight, weight.data)
+            hip_embedding_backward(grad_weight, grad, ids, scale)
+            weight.apply_grad(grad_weight)
+
+        self.grad_fn = grad_fn
+
+
+class HIPEmbedding(Module):
+    def __init__(self, num_embeddings: int, embedding_dim: int, device="cuda"):
+        super().__init__()
+        self.num_embeddings, self.embedding_dim = num_embeddings, embedding_dim
+        self.weight = Parameter(Tensor(np.random.randn(num_embeddings, embedding_dim), dtype=np.float32))
+        self.to(device)
+
+    def forward(self, X: Tensor, scale: float = 1.0, pe=None) -> Tensor:
+        """X: int32 ids of any shape (..., T).  Optional fused `* scale + pe[:T]` (pe: device array (max_len, dim))."""
+        import torch
+        if X.device != "cuda":
+            raise NotImplementedError("HIPEmbedding runs on the HIP device only (no CPU fallback)")
+        ids = X.data
+        if ids.dtype != torch.int32:
+            ids = ids.to(torch.int32)
+        ids = ids.contiguous()
+        T = ids.shape[-1] if ids.ndim else 1
+        if pe is not None and pe.shape[0] < T:
+            raise ValueError("positional table shorter than the sequence")
+        out = torch.empty(tuple(ids.shape) + (self.embedding_dim,), dtype=torch.float32, device=ids.device)
+        hip_embedding_forward(out, self.weight.data, ids, pe, max(T, 1), scale)
+        return _HIPEmbeddingTensor(out, (self.weight, ids, scale), "embedding", device="cuda")
+
+
+class HIPPositionalEncoding(Module):
+    """examples/gpt.ipynb cell 5: sinusoidal table built on the host in fp32, resident on the device."""
+
+    def __init__(self, d_model, max_len=5000, device="cuda"):
+        super().__init__()
+        import torch
+        pe = np.zeros((max_len, d_model), dtype=np.float32)
+        position = np.arange(0, max_len, dtype=np.float32)[:, None]
+        div_term = np.exp(np.arange(0, d_model, 2, dtype=np.float32) * np.float32(-math.log(10000.0) / d_model)).astype(np.float32)
+        pe[:, 0::2] = np.sin(position * div_term)
+        pe[:, 1::2] = np.cos(position * div_term)
+        self.table = torch.from_numpy(pe).to("cuda" if device == "cuda" else "cpu")
+
+    def to(self, device):
+        self.table = self.table.to("cuda" if device == "cuda" else "cpu")
+        return self
+
+
+class _HIPDropoutTensor(Tensor):
+    def __init__(self, data, args, op, device):
+        super().__init__(data, args, op, device=device, _nocopy=True)
+
+        def grad_fn(X: Tensor, mask, grad):
+            if mask is None:
+                X.apply_grad(grad)
+                return
+            g = X.xp.empty_like(X.data)
+            call_hip_function("nnhipMul", g, grad if grad.is_contiguous() else grad.contiguous(), mask, g.numel(),
+                              get_current_stream_ptr())
+            X.apply_grad(g)
+
+        self.grad_fn = grad_fn
+
+
+class HIPDropout(Module):
+    """neunet/nn/layers/dropout.py:17-37.  p == 0 or eval: identity (no kernel, no mask tensor).  p > 0 in
+    training: mask = Bernoulli(1-p)/(1-p) drawn with the device RNG (the reference draws it with the host
+    NumPy RNG, so streams cannot match; `forward(X, mask=...)` injects a mask for parity tests)."""
+
+    def __init__(self, p: float = 0.5):
+        super().__init__()
+        self.p = p
+        self.scale = 1 / (1 - p) if p < 1 else 0.0
+
+    def forward(self, X: Tensor, mask=None) -> Tensor:
+        import torch
+        if mask is None and (not self.training or self.p == 0):
+            return X
+        if mask is None:
+            mask = (torch.rand_like(X.data) >= self.p).to(torch.float32) * self.scale
+        out = X.xp.empty_like(X.data)
+        call_hip_function("nnhipMul", out, X.data if X.data.is_contiguous() else X.data.contiguous(), mask,
+                          out.numel(), get_current_stream_ptr())
+        return _HIPDropoutTensor(out, (X, mask), "dropout", device=X.device)
+
+    def train(self, mode=True):
+        self.training = mode
+
+    def eval(self):
+        self.training = False

@@ -576,3 +576,119 @@ def test_fused_c3_full_size_properties(hip):
     np.testing.assert_allclose(host(x.grad)[rows], dl / cnt, rtol=1e-4, atol=1e-9)
     ref_mean = O.cross_entropy_forward_backward(X, labels, None, 0, "mean")[0]
     assert abs(loss.item() - float(ref_mean)) < 1e-4
+
+
+# =============================================================================================================
+# Embedding (last-write-wins gradient), attention (strided-batched GEMM + fused masked softmax),
+# GPT-tiny training step -- against golden vectors produced by EXECUTING the notebook's own model cells.
+# =============================================================================================================
+def test_embedding_golden(hip, golden):
+    g = golden("embedding")
+    import neunet_hip.nn as nn
+    emb = nn.Embedding(*g["W"].shape)
+    emb.weight.data.copy_(dev(g["W"]))
+    out = emb(T(hip, g["ids"], dtype=np.int32, requires_grad=False))
+    np.testing.assert_array_equal(host(out.data), g["out"])
+    out.backward(g["grad"])
+    np.testing.assert_array_equal(host(emb.weight.grad), g["dW"])      # bit-exact: it is a row copy
+
+
+def test_embedding_scale_pe_vs_oracle(hip):
+    import neunet_hip.nn as nn
+    rng = np.random.default_rng(3)
+    V, D, B, Tn = 97, 48, 5, 33
+    emb = nn.Embedding(V, D)
+    pe = nn.PositionalEncoding(D, max_len=64)
+    W = host(emb.weight.data)
+    ids = rng.integers(0, V, (B, Tn)).astype(np.int32)
+    ids[:, 5] = ids[:, 4]
+    out = emb(T(hip, ids, dtype=np.int32, requires_grad=False), scale=np.sqrt(D), pe=pe.table)
+    ref = O.embedding_forward(W, ids) * np.float32(np.sqrt(D)) + O.positional_encoding(64, D)[None, :Tn]
+    np.testing.assert_allclose(host(out.data), ref, rtol=1e-6, atol=1e-6)
+    gr = rng.standard_normal(ref.shape).astype(np.float32)
+    out.backward(gr)
+    np.testing.assert_allclose(host(emb.weight.grad), O.embedding_backward(W.shape, ids, gr * np.float32(np.sqrt(D))),
+                               rtol=1e-6, atol=1e-6)
+
+
+def test_mha_golden(hip, golden):
+    g = golden("mha")
+    import neunet_hip.nn as nn
+    B, Tn, D = g["X"].shape
+    mha = nn.MultiHeadAttention(D, int(g["n_heads"]))
+    for name, lin in zip("qkvo", [mha.wq, mha.wk, mha.wv, mha.fc]):
+        lin.weight.data.copy_(dev(g[f"W{name}"]))
+        lin.bias.data.copy_(dev(g[f"b{name}"]))
+    x = T(hip, g["X"])
+    y, attn = mha(x, x, x, dev(g["key_valid"]), causal=True)
+    np.testing.assert_allclose(host(attn), g["attn"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(host(y.data), g["Y"], rtol=1e-4, atol=1e-5)
+    y.backward(g["dY"])
+    np.testing.assert_allclose(host(x.grad), g["dX"], rtol=1e-4, atol=1e-5)
+    for name, lin in zip("qkvo", [mha.wq, mha.wk, mha.wv, mha.fc]):
+        np.testing.assert_allclose(host(lin.weight.grad), g[f"dW{name}"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(host(lin.bias.grad), g[f"db{name}"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,Tn,D,H", [(3, 100, 64, 4), (2, 256, 512, 8), (1, 7, 24, 3)])
+def test_mha_vs_oracle(hip, B, Tn, D, H):
+    import neunet_hip.nn as nn
+    rng = np.random.default_rng(B * Tn)
+    mha = nn.MultiHeadAttention(D, H)
+    ps = []
+    for lin in (mha.wq, mha.wk, mha.wv, mha.fc):
+        ps += [host(lin.weight.data), host(lin.bias.data)]
+    X = rng.standard_normal((B, Tn, D)).astype(np.float32)
+    tok = rng.integers(1, 9, (B, Tn))
+    tok[0, -max(1, Tn // 5):] = 0
+    mask = O.attention_mask(tok, 0)
+    ref = O.MHA(*ps, n_heads=H)
+    yr, ar = ref.forward(X, mask)
+    x = T(hip, X)
+    y, attn = mha(x, x, x, dev((tok != 0).astype(np.int32)), causal=True)
+    np.testing.assert_allclose(host(attn), ar, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(host(y.data), yr, **TOL)
+    dY = rng.standard_normal(yr.shape).astype(np.float32)
+    y.backward(dY)
+    dxr, gr = ref.backward(dY)
+    np.testing.assert_allclose(host(x.grad), dxr, rtol=1e-4, atol=2e-4)
+    for lin, dW, db in zip((mha.wq, mha.wk, mha.wv, mha.fc), gr[0::2], gr[1::2]):
+        np.testing.assert_allclose(host(lin.weight.grad), dW, rtol=1e-4, atol=5e-4)
+        np.testing.assert_allclose(host(lin.bias.grad), db, rtol=1e-4, atol=5e-4)
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_gpt_tiny_step_golden(hip, golden, fused):
+    """One full training step of the notebook's GPT (2 layers, d 32, 4 heads, vocab 50, repeated ids, PAD tail):
+    logits, loss, every gradient (incl. None for the never-called cross_attn) and every parameter after Adam."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import gpt_tiny
+    import neunet_hip.nn as nn
+    from neunet_hip.optim import Adam
+    g = golden("gpt_tiny")
+    V, D, H, F, L = [int(v) for v in g["cfg"]]
+    model = gpt_tiny.build_gpt(V, D, H, F, L, pad_idx=0, max_len=64, fused=fused)
+    params = model.parameters()
+    assert len(params) == int(g["n_params"])
+    for i, p in enumerate(params):
+        assert tuple(p.shape) == g[f"p{i}"].shape, (i, p.shape, g[f"p{i}"].shape)
+        p.data.copy_(dev(g[f"p{i}"]))
+    opt = Adam(params, lr=1.5e-4, betas=(0.9, 0.98), eps=1e-9)
+    loss_fn = nn.CrossEntropyLoss(ignore_index=0)
+    batch = g["batch"]
+    output, _ = model.forward(batch[:, :-1])
+    np.testing.assert_allclose(host(output.data), g["logits"], rtol=1e-4, atol=1e-4)
+    out2 = output.reshape(output.shape[0] * output.shape[1], output.shape[2])
+    loss = loss_fn(out2, T(hip, np.ascontiguousarray(batch[:, 1:]).reshape(-1), dtype=np.int32, requires_grad=False))
+    assert abs(loss.item() - float(g["loss"])) < 1e-4
+    loss.backward()
+    for i, p in enumerate(params):
+        if bool(g[f"has_grad{i}"]):
+            np.testing.assert_allclose(host(p.grad), g[f"g{i}"], rtol=1e-3, atol=2e-6, err_msg=f"grad {i}")
+        else:
+            assert p.grad is None, i
+    opt.step()
+    for i, p in enumerate(params):
+        ref = g[f"p_after{i}"] if bool(g[f"has_grad{i}"]) else g[f"p{i}"]
+        np.testing.assert_allclose(host(p.data), ref, rtol=1e-4, atol=2e-5, err_msg=f"param {i}")

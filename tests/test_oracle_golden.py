@@ -140,3 +140,62 @@ def test_mlp_c1_trajectory(golden):
     np.testing.assert_allclose(st.p[1], g["b1_final"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(st.p[2], g["W2_final"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(st.p[3], g["b2_final"], rtol=1e-5, atol=1e-6)
+
+
+# ---- embedding (last-write-wins grad), multi-head attention, GPT-tiny step -----------------
+def test_embedding(golden):
+    g = golden("embedding")
+    np.testing.assert_array_equal(O.embedding_forward(g["W"], g["ids"]), g["out"])
+    np.testing.assert_array_equal(O.embedding_backward(g["W"].shape, g["ids"], g["grad"]), g["dW"])
+
+
+def test_mha(golden):
+    g = golden("mha")
+    m = O.MHA(g["Wq"], g["bq"], g["Wk"], g["bk"], g["Wv"], g["bv"], g["Wo"], g["bo"], int(g["n_heads"]))
+    y, attn = m.forward(g["X"], g["mask"])
+    np.testing.assert_allclose(attn, g["attn"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(y, g["Y"], rtol=1e-5, atol=1e-5)
+    dx, grads = m.backward(g["dY"])
+    np.testing.assert_allclose(dx, g["dX"], rtol=1e-4, atol=1e-5)
+    for name, dW, db in zip("qkvo", grads[0::2], grads[1::2]):
+        np.testing.assert_allclose(dW, g[f"dW{name}"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(db, g[f"db{name}"], rtol=1e-4, atol=1e-5)
+    # the structured mask (key padding + causal) used by the HIP path equals the notebook's dense mask
+    kv = g["key_valid"]
+    T = kv.shape[1]
+    dense = (kv[:, None, :] & np.tril(np.ones((T, T), dtype=np.int32))[None]).astype(np.int32)
+    np.testing.assert_array_equal(dense, g["mask"])
+
+
+def gpt_from_golden(g):
+    """Map the notebook's Module.parameters() order onto the oracle's GPTTiny (22 params per layer)."""
+    V, D, H, F, L = [int(v) for v in g["cfg"]]
+    P = lambda i: g[f"p{i}"]  # noqa: E731
+    layers, idx = [], 1
+    for _ in range(L):
+        attn = [P(idx + j) for j in range(8)]
+        ffn = [P(idx + 16 + j) for j in range(4)]
+        layers.append({"attn": attn, "ffn": ffn, "norm1": P(idx + 20), "norm2": P(idx + 21), "base": idx})
+        idx += 22
+    return O.GPTTiny(P(0), layers, P(idx), P(idx + 1), H, pad_idx=0, max_len=64), idx
+
+
+def test_gpt_tiny_step(golden):
+    g = golden("gpt_tiny")
+    model, out_idx = gpt_from_golden(g)
+    batch = g["batch"]
+    loss, logits, grads = model.forward_backward(batch[:, :-1], batch[:, 1:])
+    np.testing.assert_allclose(logits, g["logits"], rtol=1e-4, atol=1e-4)
+    assert abs(float(loss) - float(g["loss"])) < 1e-5
+    np.testing.assert_allclose(grads["emb"], g["g0"], rtol=1e-4, atol=1e-6)
+    for L, gl in zip(model.layers, grads["layers"]):
+        b = L["base"]
+        for j in range(8):
+            np.testing.assert_allclose(gl["attn"][j], g[f"g{b + j}"], rtol=1e-3, atol=1e-6)
+            assert not bool(g[f"has_grad{b + 8 + j}"])       # cross_attn is never called (SURVEY 3.4)
+        for j in range(4):
+            np.testing.assert_allclose(gl["ffn"][j], g[f"g{b + 16 + j}"], rtol=1e-3, atol=1e-6)
+        np.testing.assert_allclose(gl["norm1"], g[f"g{b + 20}"], rtol=1e-3, atol=1e-6)
+        np.testing.assert_allclose(gl["norm2"], g[f"g{b + 21}"], rtol=1e-3, atol=1e-6)
+    np.testing.assert_allclose(grads["Wout"], g[f"g{out_idx}"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(grads["bout"], g[f"g{out_idx + 1}"], rtol=1e-4, atol=1e-6)

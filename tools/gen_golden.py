@@ -269,6 +269,81 @@ def gen_mlp():
          dW2_step0=first_grads[2], db2_step0=first_grads[3])
 
 
+# --------------------------------------------------------------------------- GPT (examples/gpt.ipynb)
+def _notebook_namespace():
+    """exec() the notebook's model cells (2-7) straight from /root/reference/examples/gpt.ipynb -- nothing of
+    the notebook is copied into this repository."""
+    import json
+    import math
+    from typing import Optional
+    nb = json.load(open("/root/reference/examples/gpt.ipynb"))
+    ns = {"nn": nn, "neunet": neunet, "Tensor": Tensor, "math": math, "np": np, "Optional": Optional, "device": "cpu"}
+    for idx in (2, 3, 4, 5, 6, 7):
+        exec("".join(nb["cells"][idx]["source"]), ns)
+    return ns
+
+
+def gen_gpt():
+    ns = _notebook_namespace()
+    rng = np.random.default_rng(18)
+    # --- embedding with repeated ids (last-write-wins gradient)
+    emb = nn.Embedding(11, 8)
+    W = emb.weight.data.copy()
+    ids = np.array([[1, 4, 4, 2], [4, 0, 1, 1]], dtype=np.int32)
+    out = emb(Tensor(ids, dtype=np.int32, requires_grad=False))
+    g = rng.standard_normal(out.shape).astype(F32)
+    out.backward(g)
+    save("embedding", W=W, ids=ids, out=out.data, grad=g, dW=emb.weight.grad)
+
+    # --- multi-head self-attention with pad + causal mask
+    B, T, D, H = 2, 8, 32, 4
+    mha = ns["MultiHeadAttention"](D, H, dropout=0.0)
+    X = rng.standard_normal((B, T, D)).astype(F32)
+    tok = rng.integers(1, 20, (B, T))
+    tok[1, -3:] = 0
+    gpt_helper = ns["GPT"](decoder=None, pad_idx=0)
+    mask = (gpt_helper.get_pad_mask(tok) & gpt_helper.get_sub_mask(tok)).astype(np.int32)
+    x = Tensor(X)
+    y, attn = mha(x, x, x, Tensor(mask, dtype=np.int32, requires_grad=False))
+    dY = rng.standard_normal(y.shape).astype(F32)
+    y.backward(dY)
+    ps = [mha.wq, mha.wk, mha.wv, mha.fc]
+    arrs = dict(X=X, mask=mask, key_valid=(tok != 0).astype(np.int32), Y=y.data, attn=attn.data, dY=dY, dX=x.grad,
+                n_heads=np.int64(H))
+    for name, lin in zip("qkvo", ps):
+        arrs[f"W{name}"], arrs[f"b{name}"] = lin.weight.data, lin.bias.data
+        arrs[f"dW{name}"], arrs[f"db{name}"] = lin.weight.grad, lin.bias.grad
+    save("mha", **arrs)
+
+    # --- GPT-tiny: 2 layers, d=32, 4 heads, d_ff=64, vocab 50, B=2, T=8, dropout 0, one training step
+    V, D, H, F, L, B, T = 50, 32, 4, 64, 2, 2, 9
+    dec = ns["Decoder"](tgt_vocab_size=V, d_model=D, n_heads=H, d_ff=F, n_layers=L, dropout=0.0, max_len=64)
+    model = ns["GPT"](decoder=dec, pad_idx=0)
+    batch = rng.integers(3, V, (B, T)).astype(np.int64)
+    batch[1, -3:] = 0
+    batch[0, 2] = batch[0, 5]                       # repeated token ids inside one batch
+    params = model.parameters()
+    p0 = [p.data.copy() for p in params]
+    opt = Adam(params, lr=1.5e-4, betas=(0.9, 0.98), eps=1e-9)
+    loss_fn = nn.CrossEntropyLoss(ignore_index=0)
+    output, _ = model.forward(batch[:, :-1])
+    logits = output.data.copy()
+    output = output.reshape(output.shape[0] * output.shape[1], output.shape[2])
+    loss = loss_fn(output, neunet.tensor(batch[:, 1:].flatten(), dtype=neunet.int32))
+    loss.backward()
+    grads = [None if p.grad is None else p.grad.copy() for p in params]
+    opt.step()
+    arrs = dict(batch=batch, loss=np.float64(loss.data), logits=logits, n_params=np.int64(len(params)),
+                cfg=np.array([V, D, H, F, L]))
+    for i, (a, g, p) in enumerate(zip(p0, grads, params)):
+        arrs[f"p{i}"] = a
+        arrs[f"has_grad{i}"] = np.bool_(g is not None)
+        if g is not None:
+            arrs[f"g{i}"] = g
+            arrs[f"p_after{i}"] = p.data
+    save("gpt_tiny", **arrs)
+
+
 if __name__ == "__main__":
     gen_linear()
     gen_activations()
@@ -278,3 +353,4 @@ if __name__ == "__main__":
     gen_adam()
     gen_linear_swish()
     gen_mlp()
+    gen_gpt()
