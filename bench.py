@@ -36,7 +36,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3"])
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4"])
+    ap.add_argument("--c4-batch", type=int, default=64, help="sequences per GPU for the GPT-tiny workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -360,6 +361,110 @@ def cpu_c3(seconds):
             "sample": f"1 full C3 pass (all ops, 8192x4096) via the NumPy oracle: {dt:.2f} s"}
 
 
+# ------------------------------------------------------------------------------------------------ C4
+C4 = dict(vocab=15000, d_model=512, n_heads=8, d_ff=2048, n_layers=6, seq=256)
+
+
+def c4_flops(B, T, c=C4):
+    rows, D, F, V, L, H = B * T, c["d_model"], c["d_ff"], c["vocab"], c["n_layers"], c["n_heads"]
+    lin = L * (4 * 2 * rows * D * D + 2 * 2 * rows * D * F) + 2 * rows * D * V
+    att = L * 2 * (2 * B * H * T * T * (D // H))
+    return 3 * (lin + att)          # fwd + bwd (dX and dW GEMMs)
+
+
+def c4_batch(rng, B, T, vocab):
+    ids = rng.integers(3, vocab, (B, T + 1)).astype(np.int32)
+    for r in rng.choice(B, max(1, B // 10), replace=False):     # ~10 % of rows PAD-tailed
+        ids[r, -int(rng.integers(8, T // 4)):] = 0
+    return ids
+
+
+def workload_c4(args, rank, world):
+    """BASELINE C4: GPT-tiny (d_model 512, 6 layers, 8 heads, d_ff 2048, vocab 15000) training step on
+    batch 64 x seq 256 per GPU: embedding -> 6 x [RMSNorm, attention, RMSNorm, FFN] -> vocab projection ->
+    CrossEntropy(ignore PAD) -> backward -> flat-bucket all-reduce -> fused Adam (lr 1.5e-4, betas .9/.98, eps 1e-9)."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import gpt_tiny
+    import neunet_hip
+    import neunet_hip.nn as nn
+    from neunet_hip.distributed import GradBucket
+    from neunet_hip.optim import Adam
+    B, T = args.c4_batch, C4["seq"]
+    np.random.seed(1004)                                          # identical init on every rank
+    model = gpt_tiny.build_gpt(C4["vocab"], C4["d_model"], C4["n_heads"], C4["d_ff"], C4["n_layers"], pad_idx=0,
+                               max_len=1024, fused=True)
+    params = model.parameters()
+    opt = Adam(params, lr=1.5e-4, betas=(0.9, 0.98), eps=1e-9)
+    batch = c4_batch(np.random.default_rng(4000 + rank), B, T, C4["vocab"])
+    ids = neunet_hip.Tensor(np.ascontiguousarray(batch[:, :-1]), dtype=np.int32, requires_grad=False, device="cuda")
+    tgt_host = np.ascontiguousarray(batch[:, 1:]).reshape(-1)
+    tgt = neunet_hip.Tensor(tgt_host, dtype=np.int32, requires_grad=False, device="cuda")
+    local_count = float((tgt_host != 0).sum())
+    loss_fn = nn.CrossEntropyLoss(ignore_index=0, reduction="mean" if world == 1 else "sum")
+    state = {"bucket": None}
+    ev = EventTimer()
+
+    def step(timed):
+        if timed:
+            a, b = ev.span()
+            a.record()
+        out, _ = model.forward(ids)
+        out = out.reshape(out.shape[0] * out.shape[1], out.shape[2])
+        loss = loss_fn(out, tgt)
+        loss.backward()
+        if world > 1:
+            if state["bucket"] is None:                           # bucket only the parameters that get gradients
+                active = [p for p in params if p.grad is not None]
+                state["bucket"] = GradBucket(active, extra_scalars=1)
+            bk = state["bucket"]
+            bk.extra[0] = local_count                             # global non-ignored count rides along
+            bk.all_reduce()
+            opt.grad_scale = 1.0 / float(bk.extra[0].item())      # mean over ALL ranks' non-ignored tokens
+        opt.step()
+        opt.zero_grad()
+        if timed:
+            b.record()
+
+    dt = timed_region(step, args.steps, args.warmup, world)
+    dev_ms = ev.mean_ms()
+    fl = c4_flops(B, T)
+    ach = fl / (dev_ms * 1e-3) / 1e12
+    n_grad = sum(int(np.prod(p.shape)) for p in params if True)
+    return {
+        "samples_per_step": B * world, "dt": dt,
+        "config": {"workload": f"C4: GPT-tiny d512 L6 H8 d_ff2048 vocab15000 training step, batch {B} x seq {T} per GPU, "
+                               "Adam(1.5e-4), dropout 0", "global_batch": B * world, "seq_len": T,
+                   "parallelism": f"dp{world}"},
+        "roofline": {"kernel": "whole step, GEMM flops only (fp32 MFMA gemm_f32_kernel family: Linear fwd/dX/dW + attention)",
+                     "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "flops_per_step": fl,
+                     "avg_step_device_ms": round(dev_ms, 4)},
+        "extra": {"tokens_per_s": round(B * world * T * args.steps / dt, 1), "param_floats": n_grad},
+    }
+
+
+def cpu_c4(seconds):
+    """One GPT-tiny step of the NumPy oracle on a bounded sample: 2 sequences x 256 tokens (1/32 of the GPU batch)."""
+    from oracle import neunet_oracle as O
+    c = C4
+    rng = np.random.default_rng(1004)
+    D, F, V, L = c["d_model"], c["d_ff"], c["vocab"], c["n_layers"]
+    u = lambda *s: rng.uniform(-1, 1, s).astype(np.float32) / np.float32(np.sqrt(s[-1]))  # noqa: E731
+    layers = [{"attn": [u(D, D), u(1, D), u(D, D), u(1, D), u(D, D), u(1, D), u(D, D), u(1, D)],
+               "ffn": [u(F, D), u(1, F), u(D, F), u(1, D)], "norm1": np.ones(D, np.float32), "norm2": np.ones(D, np.float32)}
+              for _ in range(L)]
+    model = O.GPTTiny(rng.standard_normal((V, D)).astype(np.float32), layers, u(V, D), u(1, V), c["n_heads"], 0, 1024)
+    Bs = 2
+    batch = c4_batch(rng, Bs, c["seq"], V)
+    t0 = time.perf_counter()
+    model.forward_backward(batch[:, :-1], batch[:, 1:])
+    dt = time.perf_counter() - t0
+    return {"value": round(Bs / dt, 3), "unit": "samples/s", "cores": blas_threads(), "kind": "port",
+            "sample": f"1 forward+backward of the NumPy-oracle GPT-tiny on {Bs} sequences x {c['seq']} tokens "
+                      f"(optimizer step excluded): {dt:.2f} s"}
+
+
 def blas_threads():
     try:
         from threadpoolctl import threadpool_info
@@ -377,7 +482,7 @@ def main():
     if world != args.gpus and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     neunet_hip.load_library()
-    wl = {"c1": workload_c1, "c2": workload_c2, "c3": workload_c3}[args.workload]
+    wl = {"c1": workload_c1, "c2": workload_c2, "c3": workload_c3, "c4": workload_c4}[args.workload]
     res = wl(args, rank, world)
     dt = res["dt"]
     value = res["samples_per_step"] * args.steps / dt
@@ -391,7 +496,7 @@ def main():
     out.update(res.get("extra", {}))
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = {"c1": cpu_c1, "c2": cpu_c2, "c3": cpu_c3}[args.workload](args.cpu_seconds)
+            out["cpu_baseline"] = {"c1": cpu_c1, "c2": cpu_c2, "c3": cpu_c3, "c4": cpu_c4}[args.workload](args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist
