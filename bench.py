@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4"])
     ap.add_argument("--c4-batch", type=int, default=64, help="sequences per GPU for the GPT-tiny workload")
+    ap.add_argument("--graph", type=int, default=1, help="c1/c4: replay the step as a captured hipGraph (1) or launch eagerly (0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -217,19 +218,34 @@ def workload_c1(args, rank, world):
     X = neunet_hip.Tensor(drng.uniform(-1, 1, (Bsz, 784)).astype(np.float32), device="cuda", requires_grad=False)
     Y = neunet_hip.Tensor(drng.integers(0, 10, Bsz).astype(np.int32), dtype=np.int32, requires_grad=False, device="cuda")
     ev = EventTimer()
+    from neunet_hip.graph import GraphedTrainStep
 
-    def step(timed):
-        opt.zero_grad()
-        if timed:
-            a, b = ev.span()
-            a.record()
-        out = model(X)
-        loss = loss_fn(out, Y)
+    def fwd_bwd():
+        loss = loss_fn(model(X), Y)
         loss.backward()
-        bucket.all_reduce()
-        opt.step()
-        if timed:
-            b.record()
+        return loss
+
+    if args.graph:
+        gstep = GraphedTrainStep(fwd_bwd, opt, bucket, warmup=3, world=world)
+
+        def step(timed):
+            if timed:
+                a, b = ev.span()
+                a.record()
+            gstep()
+            if timed:
+                b.record()
+    else:
+        def step(timed):
+            if timed:
+                a, b = ev.span()
+                a.record()
+            opt.zero_grad()
+            fwd_bwd()
+            bucket.all_reduce()
+            opt.step()
+            if timed:
+                b.record()
 
     dt = timed_region(step, args.steps, args.warmup, world)
     dev_ms = ev.mean_ms()
@@ -237,7 +253,8 @@ def workload_c1(args, rank, world):
     return {
         "samples_per_step": Bsz * world, "dt": dt,
         "config": {"workload": "C1: MNIST-MLP 784->128->10 training step (Linear+ReLU+CrossEntropy+Adam), batch 32 per GPU",
-                   "global_batch": Bsz * world, "parallelism": f"dp{world}"},
+                   "global_batch": Bsz * world, "parallelism": f"dp{world}",
+                   "launch": "hipGraph replay" if args.graph else "eager"},
         "roofline": {"kernel": "whole step (13 launches, launch-latency bound)", "bound": "mfma",
                      "achieved": round(flops / (dev_ms * 1e-3) / 1e12, 5), "peak": PEAK_F32_MFMA_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(flops / (dev_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 6),
@@ -402,29 +419,53 @@ def workload_c4(args, rank, world):
     tgt = neunet_hip.Tensor(tgt_host, dtype=np.int32, requires_grad=False, device="cuda")
     local_count = float((tgt_host != 0).sum())
     loss_fn = nn.CrossEntropyLoss(ignore_index=0, reduction="mean" if world == 1 else "sum")
-    state = {"bucket": None}
     ev = EventTimer()
+    from neunet_hip._lib import call_hip_function, get_current_stream_ptr
+    from neunet_hip.graph import GraphedTrainStep
 
-    def step(timed):
-        if timed:
-            a, b = ev.span()
-            a.record()
+    def fwd_bwd():
         out, _ = model.forward(ids)
         out = out.reshape(out.shape[0] * out.shape[1], out.shape[2])
         loss = loss_fn(out, tgt)
         loss.backward()
-        if world > 1:
-            if state["bucket"] is None:                           # bucket only the parameters that get gradients
-                active = [p for p in params if p.grad is not None]
-                state["bucket"] = GradBucket(active, extra_scalars=1)
-            bk = state["bucket"]
-            bk.extra[0] = local_count                             # global non-ignored count rides along
-            bk.all_reduce()
-            opt.grad_scale = 1.0 / float(bk.extra[0].item())      # mean over ALL ranks' non-ignored tokens
-        opt.step()
-        opt.zero_grad()
-        if timed:
-            b.record()
+        return loss
+
+    # one throw-away step discovers which parameters receive gradients (cross_attn never does)
+    fwd_bwd()
+    active = [p for p in params if p.grad is not None]
+    opt.zero_grad()
+    bucket = GradBucket(active, extra_scalars=1)
+
+    def pre_optim():          # world > 1: grads are SUMs of per-rank 'sum' losses -> divide by the global count
+        total = float(bucket.extra[0].item())
+        call_hip_function("nnhipScale", bucket.flat, 1.0 / total, bucket.flat.numel(), get_current_stream_ptr())
+
+    if args.graph:
+        bucket.extra[0] = local_count
+        gstep = GraphedTrainStep(fwd_bwd, opt, bucket, warmup=2, world=world, pre_optim=pre_optim if world > 1 else None)
+
+        def step(timed):
+            if timed:
+                a, b = ev.span()
+                a.record()
+            bucket.extra[0] = local_count          # (re)written every step: the all-reduce sums it in place
+            gstep()
+            if timed:
+                b.record()
+    else:
+        def step(timed):
+            if timed:
+                a, b = ev.span()
+                a.record()
+            opt.zero_grad()
+            fwd_bwd()
+            bucket.extra[0] = local_count
+            bucket.all_reduce()
+            if world > 1:
+                pre_optim()
+            opt.step()
+            if timed:
+                b.record()
 
     dt = timed_region(step, args.steps, args.warmup, world)
     dev_ms = ev.mean_ms()
@@ -435,7 +476,7 @@ def workload_c4(args, rank, world):
         "samples_per_step": B * world, "dt": dt,
         "config": {"workload": f"C4: GPT-tiny d512 L6 H8 d_ff2048 vocab15000 training step, batch {B} x seq {T} per GPU, "
                                "Adam(1.5e-4), dropout 0", "global_batch": B * world, "seq_len": T,
-                   "parallelism": f"dp{world}"},
+                   "parallelism": f"dp{world}", "launch": "hipGraph replay" if args.graph else "eager"},
         "roofline": {"kernel": "whole step, GEMM flops only (fp32 MFMA gemm_f32_kernel family: Linear fwd/dX/dW + attention)",
                      "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "flops_per_step": fl,

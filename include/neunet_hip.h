@@ -181,6 +181,11 @@ int nnhipFusedAdamWMultiTensorStep(void* opt, int32_t n_tensors, float* const* p
                                    double eps, double weight_decay, int32_t step, int32_t decay_mode,
                                    float grad_scale, nnhipStream_t stream);
 
+/* Device-driven stepping for hipGraph replay: after nnhipFusedOptimizerSetStep(opt, t), calls of
+ * nnhipFusedAdamWMultiTensorStep with step == 0 advance a step counter that lives in device memory and take
+ * 1-beta^step from it, so a captured step replays with the right bias corrections.  (Synchronises the stream.) */
+int nnhipFusedOptimizerSetStep(void* opt, int32_t step, nnhipStream_t stream);
+
 /* ---- a3/a4 Conv2d  (net-new exports; reference CPU: neunet/nn/layers/conv2d.py:297-355, 16-115)
  *   X [B,Cin,H,W], W [Cout,Cin,kh,kw], bias [Cout] or NULL, O [B,Cout,Ho,Wo]; NCHW fp32.
  *   pad = (up, down, left, right) as Conv2d.build resolves it (conv2d.py:237-243);

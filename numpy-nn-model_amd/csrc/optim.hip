@@ -81,8 +81,19 @@ constexpr int64_t MT_CHUNK = 16384;  // elements per block
 
 // Device blob layout (one upload): [p*][g*][m*][v*] (n pointers each) [sizes int64 n]
 // [blk_tensor int32 nblk][blk_chunk int32 nblk]
+// Device-side step state for hipGraph replay: state[0] = step (int bits), state[1] = 1-b1^step, state[2] = 1-b2^step.
+__global__ void adam_advance_kernel(float* __restrict__ state, double b1, double b2) {
+    int* si = reinterpret_cast<int*>(state);
+    const int step = si[0] + 1;
+    si[0] = step;
+    state[1] = (float)(1.0 - pow(b1, (double)step));
+    state[2] = (float)(1.0 - pow(b2, (double)step));
+}
+
 __global__ __launch_bounds__(256) void adamw_multi_kernel(const unsigned char* __restrict__ blob, int n,
-                                                          int nblk, const AdamHyper h) {
+                                                          int nblk, AdamHyper h,
+                                                          const float* __restrict__ dev_state) {
+    if (dev_state) { h.bc1 = dev_state[1]; h.bc2 = dev_state[2]; }
     float* const* P = reinterpret_cast<float* const*>(blob);
     const float* const* G = reinterpret_cast<const float* const*>(blob + sizeof(void*) * n);
     float* const* M = reinterpret_cast<float* const*>(blob + sizeof(void*) * 2 * n);
@@ -120,10 +131,12 @@ struct FusedOptimizer {
     bool ev_pending[kRing] = {false, false, false, false};
     int ring = 0;
     int nblk = 0;
+    float* dev_state = nullptr;  // {step, 1-b1^step, 1-b2^step} for device-driven stepping (graph replay)
 
     ~FusedOptimizer() {
         (void)hipDeviceSynchronize();
         if (dev) (void)hipFree(dev);
+        if (dev_state) (void)hipFree(dev_state);
         for (int i = 0; i < kRing; ++i) {
             if (pinned[i]) (void)hipHostFree(pinned[i]);
             if (ev[i]) (void)hipEventDestroy(ev[i]);
@@ -164,7 +177,7 @@ extern "C" int nnhipFusedAdamWMultiTensorStep(void* opt, int32_t n_tensors, floa
                                               double eps, double weight_decay, int32_t step,
                                               int32_t decay_mode, float grad_scale, nnhipStream_t s) {
     NNHIP_CHECK_ARG(opt != nullptr, NNHIP_EINVAL, "nnhipFusedAdamWMultiTensorStep: null optimizer handle");
-    NNHIP_CHECK_ARG(n_tensors >= 0 && step >= 1, NNHIP_EINVAL, "nnhipFusedAdamWMultiTensorStep: bad n_tensors/step");
+    NNHIP_CHECK_ARG(n_tensors >= 0 && step >= 0, NNHIP_EINVAL, "nnhipFusedAdamWMultiTensorStep: bad n_tensors/step");
     NNHIP_CHECK_ARG(decay_mode == 0 || decay_mode == 1, NNHIP_EINVAL, "nnhipFusedAdamWMultiTensorStep: decay_mode must be 0 or 1");
     if (n_tensors == 0) return 0;
     NNHIP_CHECK_ARG(p && g && m && v && sizes, NNHIP_EINVAL, "nnhipFusedAdamWMultiTensorStep: null table");
@@ -228,8 +241,29 @@ extern "C" int nnhipFusedAdamWMultiTensorStep(void* opt, int32_t n_tensors, floa
         fo->nblk = (int)nblk;
     }
 
-    const AdamHyper h = make_hyper(lr, beta1, beta2, eps, weight_decay, step, decay_mode, grad_scale);
-    hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)nblk), dim3(256), 0, st, fo->dev, n, (int)nblk, h);
+    const AdamHyper h = make_hyper(lr, beta1, beta2, eps, weight_decay, step > 0 ? step : 1, decay_mode, grad_scale);
+    const float* dstate = nullptr;
+    if (step == 0) {  // device-driven step counter (set with nnhipFusedOptimizerSetStep): graph-replay safe
+        NNHIP_CHECK_ARG(fo->dev_state != nullptr, NNHIP_EINVAL,
+                        "nnhipFusedAdamWMultiTensorStep: step == 0 needs nnhipFusedOptimizerSetStep first");
+        hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, st, fo->dev_state, beta1, beta2);
+        NNHIP_LAUNCH_CHECK("adam_advance_kernel");
+        dstate = fo->dev_state;
+    }
+    hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)nblk), dim3(256), 0, st, fo->dev, n, (int)nblk, h, dstate);
     NNHIP_LAUNCH_CHECK("adamw_multi_kernel");
     return 0;
+}
+
+extern "C" int nnhipFusedOptimizerSetStep(void* opt, int32_t step, nnhipStream_t s) {
+    NNHIP_CHECK_ARG(opt != nullptr && step >= 0, NNHIP_EINVAL, "nnhipFusedOptimizerSetStep: bad arguments");
+    FusedOptimizer* fo = static_cast<FusedOptimizer*>(opt);
+    if (!fo->dev_state) {
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&fo->dev_state), 4 * sizeof(float));
+        if (e != hipSuccess) { fo->dev_state = nullptr; return hip_status(e, "hipMalloc(optimizer step state)"); }
+    }
+    int32_t host[4] = {step, 0, 0, 0};
+    hipError_t e = hipMemcpyAsync(fo->dev_state, host, sizeof(host), hipMemcpyHostToDevice, (hipStream_t)s);
+    if (e != hipSuccess) return hip_status(e, "hipMemcpyAsync(optimizer step state)");
+    return hip_status(hipStreamSynchronize((hipStream_t)s), "hipStreamSynchronize(optimizer step state)");
 }

@@ -66,6 +66,7 @@ _SIGNATURES = {
     "nnhipFusedAdamWMultiTensorStep": (ctypes.c_int, [c_void_p, c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_void_p),
                                                       POINTER(c_void_p), POINTER(c_int64), c_double, c_double, c_double, c_double, c_double,
                                                       c_int32, c_int32, c_float, c_void_p]),
+    "nnhipFusedOptimizerSetStep": (ctypes.c_int, [c_void_p, c_int32, c_void_p]),
     "nnhipConv2dForward": (ctypes.c_int, [P, P, P, P, POINTER(Conv2dDesc), c_void_p]),
     "nnhipConv2dBackward": (ctypes.c_int, [P, P, P, P, P, P, POINTER(Conv2dDesc), c_void_p]),
     "nnhipScale": (ctypes.c_int, [P, c_float, c_int64, c_void_p]),

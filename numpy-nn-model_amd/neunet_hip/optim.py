@@ -65,6 +65,7 @@ class HIPFusedMultiTensorAdamW:
         _check_params(self.params)
         self.m = [torch.zeros_like(p.data) for p in self.params]
         self.v = [torch.zeros_like(p.data) for p in self.params]
+        self.device_step = False      # True: the step counter lives on the device (hipGraph replay)
         self.opt_ptr = load_hip_function("nnhipCreateFusedOptimizer")()
         if not self.opt_ptr:
             raise RuntimeError("nnhipCreateFusedOptimizer failed")
@@ -107,8 +108,16 @@ class HIPFusedMultiTensorAdamW:
                           ctypes.cast(self.c_exp_avgs, ctypes.POINTER(c_void_p)),
                           ctypes.cast(self.c_exp_avg_sqs, ctypes.POINTER(c_void_p)),
                           ctypes.cast(self.c_sizes, ctypes.POINTER(c_int64)),
-                          self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.t,
-                          self.decay_mode, self.grad_scale, get_current_stream_ptr())
+                          self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                          0 if self.device_step else self.t, self.decay_mode, self.grad_scale,
+                          get_current_stream_ptr())
+
+    def use_device_step(self, enable: bool = True):
+        """Move the step counter to device memory (needed before capturing step() into a hipGraph: the host
+        value of `t` would be frozen into the captured kernel arguments)."""
+        if enable:
+            call_hip_function("nnhipFusedOptimizerSetStep", self.opt_ptr, self.t, get_current_stream_ptr())
+        self.device_step = enable
 
     def zero_grad(self):
         for p in self.params:

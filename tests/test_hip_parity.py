@@ -704,3 +704,64 @@ def test_gpt_tiny_step_golden(hip, golden, fused):
         #     softmax is shift-invariant -- turns rounding noise into a full +-lr step in BOTH implementations)
         sig = np.abs(g[f"g{i}"]) > 1e-5
         np.testing.assert_allclose(got[sig], g[f"p_after{i}"][sig], rtol=1e-4, atol=2e-5, err_msg=f"param {i}")
+
+
+def test_graphed_step_equals_eager(hip):
+    """A hipGraph-replayed GPT step (neunet_hip.graph.GraphedTrainStep, device-side Adam step counter) produces
+    the same parameters as the eager step, step after step, with fresh data copied into the static buffers."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import gpt_tiny
+    import neunet_hip.nn as nn
+    from neunet_hip.distributed import GradBucket
+    from neunet_hip.graph import GraphedTrainStep
+    from neunet_hip.optim import Adam
+    V, D, H, F, L, B, Tn = 61, 32, 4, 64, 2, 3, 12
+    rng = np.random.default_rng(77)
+    batches = [rng.integers(1, V, (B, Tn + 1)).astype(np.int32) for _ in range(6)]
+    for b in batches:
+        b[0, -3:] = 0
+
+    def make():
+        np.random.seed(5)
+        model = gpt_tiny.build_gpt(V, D, H, F, L, pad_idx=0, max_len=32)
+        ids = hip.Tensor(batches[0][:, :-1], dtype=np.int32, requires_grad=False, device="cuda")
+        tgt = hip.Tensor(np.ascontiguousarray(batches[0][:, 1:]).reshape(-1), dtype=np.int32, requires_grad=False, device="cuda")
+        loss_fn = nn.CrossEntropyLoss(ignore_index=0)
+
+        def fb():
+            out, _ = model.forward(ids)
+            loss = loss_fn(out.reshape(B * Tn, V), tgt)
+            loss.backward()
+            return loss
+
+        fb()
+        active = [p for p in model.parameters() if p.grad is not None]
+        for p in model.parameters():
+            p.grad = None
+        opt = Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.98), eps=1e-9)
+        return model, ids, tgt, fb, opt, GradBucket(active)
+
+    def feed(ids, tgt, b):
+        ids.data.copy_(dev(np.ascontiguousarray(b[:, :-1])))
+        tgt.data.copy_(dev(np.ascontiguousarray(b[:, 1:]).reshape(-1)))
+
+    m1, ids1, tgt1, fb1, opt1, bk1 = make()
+    losses1 = []
+    for b in batches:
+        feed(ids1, tgt1, b)
+        opt1.zero_grad()
+        losses1.append(fb1().item())
+        bk1.all_reduce()
+        opt1.step()
+
+    m2, ids2, tgt2, fb2, opt2, bk2 = make()
+    feed(ids2, tgt2, batches[0])
+    g = GraphedTrainStep(fb2, opt2, bk2, warmup=0)       # no warm-up steps: both runs see 6 optimizer steps
+    losses2 = []
+    for b in batches:
+        feed(ids2, tgt2, b)
+        losses2.append(g().item())
+    np.testing.assert_allclose(losses2, losses1, rtol=1e-5, atol=1e-6)
+    for p1, p2 in zip(m1.parameters(), m2.parameters()):
+        np.testing.assert_allclose(host(p2.data), host(p1.data), rtol=1e-5, atol=1e-6)
