@@ -44,6 +44,12 @@ __global__ __launch_bounds__(256) void embedding_fwd_kernel(float* __restrict__ 
     }
 }
 
+// (a plain kernel rather than hipMemsetAsync: memset nodes misbehave under hipGraph replay on ROCm 7.2)
+__global__ __launch_bounds__(256) void fill_i32_kernel(int32_t* __restrict__ p, int64_t n, int32_t v) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
 __global__ __launch_bounds__(256) void embedding_last_kernel(const int32_t* __restrict__ ids, int64_t n,
                                                              int64_t vocab, int32_t* __restrict__ last) {
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -105,8 +111,8 @@ extern "C" int nnhipEmbeddingBackward(float* dW, const float* grad_out, const in
     hipStream_t st = (hipStream_t)s;
     int32_t* last = static_cast<int32_t*>(workspace((size_t)vocab * sizeof(int32_t)));
     NNHIP_CHECK_ARG(last != nullptr, NNHIP_ENOMEM, "nnhipEmbeddingBackward: workspace allocation failed");
-    hipError_t e = hipMemsetAsync(last, 0xFF, (size_t)vocab * sizeof(int32_t), st);  // -1
-    if (e != hipSuccess) return hip_status(e, "hipMemsetAsync(embedding last)");
+    hipLaunchKernelGGL(fill_i32_kernel, dim3((unsigned)ceil_div(vocab, 256)), dim3(256), 0, st, last, vocab, -1);
+    NNHIP_LAUNCH_CHECK("fill_i32_kernel");
     if (n_ids > 0) {
         hipLaunchKernelGGL(embedding_last_kernel, dim3((unsigned)ceil_div(n_ids, 256)), dim3(256), 0, st, ids, n_ids, vocab, last);
         NNHIP_LAUNCH_CHECK("embedding_last_kernel");

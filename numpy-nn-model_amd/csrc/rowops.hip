@@ -301,9 +301,10 @@ __global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void rmsnorm_bwd_rows(
     const float invN = 1.0f / (float)cols;
     const int64_t step = (int64_t)gridDim.x * RPB;
     // when TPR >= 256 every thread of the block runs the same trip count (block barriers inside)
-    for (int64_t r0 = (int64_t)blockIdx.x * RPB + rslot; r0 < rows; r0 += 2 * step) {
+    constexpr bool TWO = TPR < 1024;  // 1024-thread blocks have 128 VGPRs/lane: one row in flight, no spills
+    for (int64_t r0 = (int64_t)blockIdx.x * RPB + rslot; r0 < rows; r0 += (TWO ? 2 : 1) * step) {
         const int64_t r1 = r0 + step;
-        const bool has1 = r1 < rows;
+        const bool has1 = TWO && r1 < rows;
         RowTile<TPR, NV, VEC> x0, g0, x1, g1;
         x0.load(X + r0 * cols, cols, t, 0.f);
         g0.load(dY + r0 * cols, cols, t, 0.f);

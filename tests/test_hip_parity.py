@@ -748,7 +748,7 @@ def test_graphed_step_equals_eager(hip):
 
     m1, ids1, tgt1, fb1, opt1, bk1 = make()
     losses1 = []
-    for b in batches:
+    for b in [batches[0], batches[0]] + batches:      # the graphed run warms up twice on batch 0 first
         feed(ids1, tgt1, b)
         opt1.zero_grad()
         losses1.append(fb1().item())
@@ -757,11 +757,11 @@ def test_graphed_step_equals_eager(hip):
 
     m2, ids2, tgt2, fb2, opt2, bk2 = make()
     feed(ids2, tgt2, batches[0])
-    g = GraphedTrainStep(fb2, opt2, bk2, warmup=0)       # no warm-up steps: both runs see 6 optimizer steps
+    g = GraphedTrainStep(fb2, opt2, bk2, warmup=2)       # warm-up (eager) grows the workspace / uploads the plan
     losses2 = []
     for b in batches:
         feed(ids2, tgt2, b)
         losses2.append(g().item())
-    np.testing.assert_allclose(losses2, losses1, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(losses2, losses1[2:], rtol=1e-5, atol=1e-6)
     for p1, p2 in zip(m1.parameters(), m2.parameters()):
         np.testing.assert_allclose(host(p2.data), host(p1.data), rtol=1e-5, atol=1e-6)
