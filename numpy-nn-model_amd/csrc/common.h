@@ -36,6 +36,8 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // Grow-only per-process device workspace (split-K slabs, column-sum partials).  Freed by
 // nnhipCleanup().  Growing it synchronises the device (hipFree) -- it happens at most a few times.
 void* workspace(size_t bytes);
+// 256 bytes of device zeros, allocated once per process (never freed): where out-of-range GEMM lanes load from.
+const float* zero_block();
 
 // ---- device helpers ----------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {

@@ -44,6 +44,7 @@ struct GemmParams {
     int tiles_m, tiles_n, splitk;
     int64_t k_per_split;  // multiple of BK
     float* slab;          // split-K partials [splitk][M][N] (dense)
+    const float* zeros;   // >= 16 bytes of zeros: the load target of out-of-range lanes
     int act;
     float beta;
 };
@@ -58,40 +59,39 @@ struct Tile {
 };
 
 // global -> registers.  R = extent of the operand's outer dim, r0/k0 = tile origin.
+// Branch-free: an out-of-range lane loads from a 16-byte block of zeros (`Z`, library-owned) instead of
+// being masked or zeroed afterwards, so the whole K-loop body is one basic block, the loads can be
+// interleaved with MFMAs, and nothing consumes a loaded value before the LDS store at the end of the tile.
 template <int BK, bool KC, bool VEC>
 __device__ __forceinline__ void g2r(float4 (&r)[BK / 8], const float* __restrict__ P, int64_t ld,
-                                    int64_t R, int64_t Kend, int64_t r0, int64_t k0, int tid) {
+                                    int64_t R, int64_t Kend, int64_t r0, int64_t k0, int tid, bool live,
+                                    const float* __restrict__ Z) {
 #pragma unroll
     for (int p = 0; p < BK / 8; ++p) {
         const int idx = tid + NT * p;
+        int64_t gr, gk;
+        const float* src;
         if constexpr (KC) {
             const int rr = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
-            const int64_t gr = r0 + rr, gk = k0 + k4;
-            const float* src = P + gr * ld + gk;
-            if constexpr (VEC) {
-                r[p] = (gr < R && gk < Kend) ? *reinterpret_cast<const float4*>(src)
-                                             : make_float4(0.f, 0.f, 0.f, 0.f);
-            } else {
-                const bool ok = gr < R;
-                r[p].x = (ok && gk + 0 < Kend) ? src[0] : 0.f;
-                r[p].y = (ok && gk + 1 < Kend) ? src[1] : 0.f;
-                r[p].z = (ok && gk + 2 < Kend) ? src[2] : 0.f;
-                r[p].w = (ok && gk + 3 < Kend) ? src[3] : 0.f;
-            }
+            gr = r0 + rr; gk = k0 + k4;
+            src = P + gr * ld + gk;
         } else {
             const int kk = idx / 32, r4 = (idx % 32) * 4;
-            const int64_t gk = k0 + kk, gr = r0 + r4;
-            const float* src = P + gk * ld + gr;
-            if constexpr (VEC) {
-                r[p] = (gk < Kend && gr < R) ? *reinterpret_cast<const float4*>(src)
-                                             : make_float4(0.f, 0.f, 0.f, 0.f);
-            } else {
-                const bool ok = gk < Kend;
-                r[p].x = (ok && gr + 0 < R) ? src[0] : 0.f;
-                r[p].y = (ok && gr + 1 < R) ? src[1] : 0.f;
-                r[p].z = (ok && gr + 2 < R) ? src[2] : 0.f;
-                r[p].w = (ok && gr + 3 < R) ? src[3] : 0.f;
+            gk = k0 + kk; gr = r0 + r4;
+            src = P + gk * ld + gr;
+        }
+        if constexpr (VEC) {
+            const bool ok = live && gr < R && gk < Kend;
+            r[p] = *reinterpret_cast<const float4*>(ok ? src : Z);
+        } else {
+            // scalar path: element e steps along the contiguous dim (k for k-major, outer otherwise)
+            float t[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool ok = live && (KC ? (gr < R && gk + e < Kend) : (gk < Kend && gr + e < R));
+                t[e] = *(ok ? src + e : Z);
             }
+            r[p] = make_float4(t[0], t[1], t[2], t[3]);
         }
     }
 }
@@ -174,22 +174,25 @@ __global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const 
     float4 ra[BK / 8], rb[BK / 8];
     const int nk = (int)((kend - kbeg + BK - 1) / BK);
 
-    if (nk > 0) {
-        g2r<BK, AKC, VEC>(ra, A, p.lda, p.M, kend, m0, kbeg, tid);
-        g2r<BK, BKC, VEC>(rb, B, p.ldb, p.N, kend, n0, kbeg, tid);
-        r2s<BK, AKC>(ra, smem, tid);
-        r2s<BK, BKC>(rb, smem + TA::SIZE, tid);
-    }
+    const float* __restrict__ Z = p.zeros;
+    g2r<BK, AKC, VEC>(ra, A, p.lda, p.M, kend, m0, kbeg, tid, nk > 0, Z);
+    g2r<BK, BKC, VEC>(rb, B, p.ldb, p.N, kend, n0, kbeg, tid, nk > 0, Z);
+    r2s<BK, AKC>(ra, smem, tid);
+    r2s<BK, BKC>(rb, smem + TA::SIZE, tid);
     __syncthreads();
 
+    // K loop.  One basic block per iteration; the issue order is pinned with sched_group_barrier so that the
+    // 2*BK/8 global loads of tile t+1 ride in the shadow of the first MFMAs of tile t (one load per 64-cycle
+    // MFMA) and the 2*BK/8 LDS stores in the shadow of the last ones -- the ablation (profiles/) showed the
+    // un-interleaved load + store phases costing 13 % of the loop while ds_reads and the barrier were free.
+    constexpr int NLD = 2 * (BK / 8);          // float4 loads (= LDS stores) per thread per tile
+    constexpr int NMF = 16 * (BK / 8);         // MFMAs per wave per tile
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + 1 < nk;
-        if (more) {
-            const int64_t k0 = kbeg + (int64_t)(kt + 1) * BK;
-            g2r<BK, AKC, VEC>(ra, A, p.lda, p.M, kend, m0, k0, tid);
-            g2r<BK, BKC, VEC>(rb, B, p.ldb, p.N, kend, n0, k0, tid);
-        }
+        const int64_t k0 = kbeg + (int64_t)(kt + 1) * BK;
+        g2r<BK, AKC, VEC>(ra, A, p.lda, p.M, kend, m0, k0, tid, more, Z);
+        g2r<BK, BKC, VEC>(rb, B, p.ldb, p.N, kend, n0, k0, tid, more, Z);
         const float* As = smem + cur * STAGE;
         const float* Bs = As + TA::SIZE;
 #pragma unroll
@@ -209,10 +212,22 @@ __global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const 
                         acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[n][j], acc[i][n],
                                                                          0, 0, 0);
         }
-        if (more) {
+        {   // next tile -> other LDS stage (stores of zeros on the last iteration are harmless)
             float* Sn = smem + (cur ^ 1) * STAGE;
             r2s<BK, AKC>(ra, Sn, tid);
             r2s<BK, BKC>(rb, Sn + TA::SIZE, tid);
+        }
+        // ---- issue-order pipeline for this iteration's scheduling region --------------------------------
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NMF - 2 * NLD, 0);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // 1 DS write
         }
         __syncthreads();
         cur ^= 1;
@@ -322,6 +337,8 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
     p.tiles_n = (int)ceil_div(N, BN);
     p.act = act; p.beta = beta;
     p.splitk = 1; p.k_per_split = ceil_div(K > 0 ? K : 1, BK) * BK; p.slab = nullptr;
+    p.zeros = zero_block();
+    if (!p.zeros) { set_last_error("zero block allocation failed"); return NNHIP_ENOMEM; }
 
     // split-K: few tiles, long reduction (deterministic slabs + reduce)
     const int64_t tiles = (int64_t)p.tiles_m * p.tiles_n * batch;

@@ -302,42 +302,65 @@ __global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void rmsnorm_bwd_rows(
     const int64_t step = (int64_t)gridDim.x * RPB;
     // when TPR >= 256 every thread of the block runs the same trip count (block barriers inside)
     constexpr bool TWO = TPR < 1024;  // 1024-thread blocks have 128 VGPRs/lane: one row in flight, no spills
-    for (int64_t r0 = (int64_t)blockIdx.x * RPB + rslot; r0 < rows; r0 += (TWO ? 2 : 1) * step) {
-        const int64_t r1 = r0 + step;
-        const bool has1 = TWO && r1 < rows;
-        RowTile<TPR, NV, VEC> x0, g0, x1, g1;
-        x0.load(X + r0 * cols, cols, t, 0.f);
-        g0.load(dY + r0 * cols, cols, t, 0.f);
-        if (has1) {
-            x1.load(X + r1 * cols, cols, t, 0.f);
-            g1.load(dY + r1 * cols, cols, t, 0.f);
-        } else {
+    if constexpr (TWO) {
+        for (int64_t r0 = (int64_t)blockIdx.x * RPB + rslot; r0 < rows; r0 += 2 * step) {
+            const int64_t r1 = r0 + step;
+            const bool has1 = r1 < rows;
+            RowTile<TPR, NV, VEC> x0, g0, x1, g1;
+            x0.load(X + r0 * cols, cols, t, 0.f);
+            g0.load(dY + r0 * cols, cols, t, 0.f);
+            if (has1) {
+                x1.load(X + r1 * cols, cols, t, 0.f);
+                g1.load(dY + r1 * cols, cols, t, 0.f);
+            } else {
 #pragma unroll
-            for (int e = 0; e < x1.NE; ++e) x1.x[e] = g1.x[e] = 0.f;
-        }
-        const float sd0 = Xstd[r0], sd1 = has1 ? Xstd[r1] : 1.f;
-        const float i0 = 1.0f / sd0, i1 = 1.0f / sd1;
-        float s0 = 0.f, s1 = 0.f;
+                for (int e = 0; e < x1.NE; ++e) x1.x[e] = g1.x[e] = 0.f;
+            }
+            const float sd0 = Xstd[r0], sd1 = has1 ? Xstd[r1] : 1.f;
+            const float i0 = 1.0f / sd0, i1 = 1.0f / sd1;
+            float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-        for (int e = 0; e < x0.NE; ++e) {
-            adb.x[e] += g0.x[e] + g1.x[e];
-            adw.x[e] += g0.x[e] * (x0.x[e] * i0) + g1.x[e] * (x1.x[e] * i1);
-            g0.x[e] *= wt.x[e];  // dX_hat = w * dy
-            g1.x[e] *= wt.x[e];
-            s0 += g0.x[e] * x0.x[e] * i0;
-            s1 += g1.x[e] * x1.x[e] * i1;
-        }
-        block_sum2<NW>(s0, s1, red);
-        s0 *= invN;
-        s1 *= invN;
-        const float q0 = i0 * i0, q1 = i1 * i1;
+            for (int e = 0; e < x0.NE; ++e) {
+                adb.x[e] += g0.x[e] + g1.x[e];
+                adw.x[e] += g0.x[e] * (x0.x[e] * i0) + g1.x[e] * (x1.x[e] * i1);
+                g0.x[e] *= wt.x[e];  // dX_hat = w * dy
+                g1.x[e] *= wt.x[e];
+                s0 += g0.x[e] * x0.x[e] * i0;
+                s1 += g1.x[e] * x1.x[e] * i1;
+            }
+            block_sum2<NW>(s0, s1, red);
+            s0 *= invN;
+            s1 *= invN;
+            const float q0 = i0 * i0, q1 = i1 * i1;
 #pragma unroll
-        for (int e = 0; e < x0.NE; ++e) {
-            g0.x[e] = (g0.x[e] * sd0 - x0.x[e] * s0) * q0;
-            g1.x[e] = (g1.x[e] * sd1 - x1.x[e] * s1) * q1;
+            for (int e = 0; e < x0.NE; ++e) {
+                g0.x[e] = (g0.x[e] * sd0 - x0.x[e] * s0) * q0;
+                g1.x[e] = (g1.x[e] * sd1 - x1.x[e] * s1) * q1;
+            }
+            g0.store(dX + r0 * cols, cols, t);
+            if (has1) g1.store(dX + r1 * cols, cols, t);
         }
-        g0.store(dX + r0 * cols, cols, t);
-        if (has1) g1.store(dX + r1 * cols, cols, t);
+    } else {
+        for (int64_t r0 = (int64_t)blockIdx.x * RPB + rslot; r0 < rows; r0 += step) {
+            RowTile<TPR, NV, VEC> x0, g0;
+            x0.load(X + r0 * cols, cols, t, 0.f);
+            g0.load(dY + r0 * cols, cols, t, 0.f);
+            const float sd0 = Xstd[r0];
+            const float i0 = 1.0f / sd0;
+            float s0 = 0.f;
+#pragma unroll
+            for (int e = 0; e < x0.NE; ++e) {
+                adb.x[e] += g0.x[e];
+                adw.x[e] += g0.x[e] * (x0.x[e] * i0);
+                g0.x[e] *= wt.x[e];
+                s0 += g0.x[e] * x0.x[e] * i0;
+            }
+            s0 = block_sum<NW>(s0, red) * invN;
+            const float q0 = i0 * i0;
+#pragma unroll
+            for (int e = 0; e < x0.NE; ++e) g0.x[e] = (g0.x[e] * sd0 - x0.x[e] * s0) * q0;
+            g0.store(dX + r0 * cols, cols, t);
+        }
     }
     const int64_t prow = (int64_t)blockIdx.x * RPB + rslot;
     adw.store(part_dw + prow * cols, cols, t);
@@ -656,7 +679,7 @@ extern "C" int nnhipRMSNormBackward(const float* dY, const float* X, const float
     // persistent-ish grid: <= 1024 blocks (4 per CU), each accumulating dw/db partials over its rows,
     // two rows in flight per iteration
     const int rpb = cols <= 1024 ? 4 : 1;
-    int64_t nblk = ceil_div(ceil_div(rows > 0 ? rows : 1, rpb), 2);
+    int64_t nblk = ceil_div(ceil_div(rows > 0 ? rows : 1, rpb), cols > 8192 ? 1 : 2);
     if (nblk > 1024) nblk = 1024;
     const int64_t prow = nblk * rpb;
     const size_t part_floats = ((size_t)prow * cols + 3) / 4 * 4;

@@ -50,6 +50,16 @@ void* workspace(size_t bytes) {
     return g_ws;
 }
 
+const float* zero_block() {
+    static float* z = nullptr;
+    static std::once_flag once;
+    std::call_once(once, []() {
+        float* p = nullptr;
+        if (hipMalloc(reinterpret_cast<void**>(&p), 256) == hipSuccess && hipMemset(p, 0, 256) == hipSuccess) z = p;
+    });
+    return z;
+}
+
 }  // namespace nnhip
 
 extern "C" int nnhipVersion(void) { return 100; }
