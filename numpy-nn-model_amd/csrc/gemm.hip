@@ -45,6 +45,7 @@ struct GemmParams {
     int64_t k_per_split;  // multiple of BK
     float* slab;          // split-K partials [splitk][M][N] (dense)
     const float* zeros;   // >= 16 bytes of zeros: the load target of out-of-range lanes
+    int cvec;             // 1: C/bias/preact rows are 16-B aligned and N % 4 == 0 -> float4 epilogue
     int act;
     float beta;
 };
@@ -233,10 +234,55 @@ __global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const 
         cur ^= 1;
     }
 
-    // ---- epilogue: acc reg e of a 32x32 tile -> row (e&3) + 8*(e>>2) + 4*lh, col l31 -----------
+    // ---- epilogue ------------------------------------------------------------------------------------------
+    // acc register e of a 32x32 MFMA tile holds row (e&3) + 8*(e>>2) + 4*lh, column l31: a lane owns a strided
+    // COLUMN, so direct stores are 64 dword stores per lane (2 rows x 128 B per instruction) and the tail is
+    // store-issue bound (~15 us per generation of tiles, measured by a K sweep).  Instead each wave transposes
+    // its tile through its own LDS region, 32 rows at a time, and stores float4 rows: 4x fewer instructions,
+    // 4 rows x 256 B each.  (Scalar path kept for unaligned / N % 4 != 0 outputs.)
     const bool to_slab = p.splitk > 1;
     float* __restrict__ C = to_slab ? p.slab + (int64_t)split * p.M * p.N : p.C + c_off;
     const int64_t ldc = to_slab ? p.N : p.ldc;
+    if (p.cvec) {
+        constexpr int ELD = 68;                              // 64 + 4 floats: rows stay 16-B aligned
+        float* E = smem + wave * (32 * ELD);                 // the K loop ended with a barrier: LDS is free
+        const int er = lane >> 4, ec = (lane & 15) * 4;      // read side: row-in-group, column of the float4
+        const int64_t col = n0 + wn * 64 + ec;
+        const bool col_ok = col < p.N;                       // N % 4 == 0 on this path
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!to_slab && p.bias && col_ok) bv = *reinterpret_cast<const float4*>(p.bias + col);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    E[((e & 3) + 8 * (e >> 2) + 4 * lh) * ELD + n * 32 + l31] = acc[i][n][e];
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int rl = it * 4 + er;
+                const int64_t row = m0 + wm * 64 + i * 32 + rl;
+                float4 v = *reinterpret_cast<const float4*>(&E[rl * ELD + ec]);
+                if (row < p.M && col_ok) {
+                    if (!to_slab) {
+                        v.x = p.alpha * v.x + bv.x; v.y = p.alpha * v.y + bv.y;
+                        v.z = p.alpha * v.z + bv.z; v.w = p.alpha * v.w + bv.w;
+                        if (p.act == ACT_SWISH) {
+                            if (p.preact) *reinterpret_cast<float4*>(p.preact + c_off + row * ldc + col) = v;
+                            v.x *= sigmoidf_(p.beta * v.x); v.y *= sigmoidf_(p.beta * v.y);
+                            v.z *= sigmoidf_(p.beta * v.z); v.w *= sigmoidf_(p.beta * v.w);
+                        } else if (p.act == ACT_RELU) {
+                            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                        }
+                    }
+                    *reinterpret_cast<float4*>(C + row * ldc + col) = v;
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const int64_t col = n0 + wn * 64 + n * 32 + l31;
@@ -365,6 +411,14 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
         return kmajor ? ((K & 3) == 0) : ((outer & 3) == 0);
     };
     const bool vec = vec_ok(A, lda, sA, sA2, a_kmajor, M) && vec_ok(B, ldb, sB, sB2, b_kmajor, N);
+    {
+        const bool slab = p.splitk > 1;
+        bool ok = (N & 3) == 0;
+        if (slab) ok = ok && aligned16(p.slab);
+        else ok = ok && aligned16(C) && (ldc & 3) == 0 && (batch1 <= 1 || (sC & 3) == 0) && (batch2 <= 1 || (sC2 & 3) == 0) &&
+                  (!bias || aligned16(bias)) && (!preact || aligned16(preact));
+        p.cvec = ok ? 1 : 0;
+    }
 
     int rc;
 #define NNHIP_GEMM_CASE(AK, BKM)                                                                   \
