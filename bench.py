@@ -312,14 +312,17 @@ def workload_c3(args, rank, world):
     p = Parameter(neunet_hip.Tensor(Xn, device="cuda"))
     p.grad = dY
     opt = HIPFusedMultiTensorAdamW([p], lr=1e-3, weight_decay=1e-2)
+    # Order matters for cold-cache timing: a kernel that follows AdamW also pays for the write-back of AdamW's
+    # 402 MB of dirty lines (+12 us measured on ANY streaming kernel placed there, tools/order_test.py), so
+    # AdamW goes last and the fused CE -- whose predecessor in a real step is the vocabulary GEMM -- first.
     ops = [
+        ("ce_fwd_bwd", lambda: cross_entropy_forward_backward(logits, labels, "mean", -100, inplace=False)),
         ("swish_fwd", lambda: hip_swish_forward(x, y, 1.0)),
         ("swish_bwd", lambda: hip_swish_backward(dx, dY, x, 1.0)),
         ("rmsnorm_fwd", lambda: rmsnorm_forward(x, w, None, None, std, y, 1e-6)),
         ("rmsnorm_bwd", lambda: rmsnorm_backward(x, w, None, dY, dx, dw, None, None, std)),
         ("softmax_fwd", lambda: hip_softmax_forward(x, y, -1)),
         ("softmax_bwd", lambda: hip_softmax_backward(dx, dY, y, -1)),
-        ("ce_fwd_bwd", lambda: cross_entropy_forward_backward(logits, labels, "mean", -100, inplace=False)),
         ("adamw", lambda: opt.step()),
     ]
     timers = {k: EventTimer() for k, _ in ops}

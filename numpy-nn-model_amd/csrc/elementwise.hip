@@ -7,7 +7,7 @@
 namespace nnhip {
 
 constexpr int EW_THREADS = 256;
-constexpr int EW_MAX_BLOCKS = 256 * 8;
+constexpr int EW_MAX_BLOCKS = 1 << 20;  // one 4-float4 span per thread at any realistic size; the loop is a backstop
 
 inline int ew_blocks(int64_t n_items) {
     int64_t b = ceil_div(n_items > 0 ? n_items : 1, EW_THREADS);

@@ -390,7 +390,10 @@ __global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void ce_fwd_bwd_rows(
     m = row_max<TPR>(m, red);
     float d = 0.f;
 #pragma unroll
-    for (int e = 0; e < r.NE; ++e) d += expf(r.x[e] - m);
+    for (int e = 0; e < r.NE; ++e) {
+        r.x[e] = expf(r.x[e] - m);   // keep exp(x - m): softmax = e / d, no second exp pass
+        d += r.x[e];
+    }
     d = row_sum<TPR>(d, red);
     const float lse = m + logf(d);
     float scale = scale_host;
@@ -400,11 +403,10 @@ __global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void ce_fwd_bwd_rows(
         loss[row] = valid ? (lse - xl) : 0.f;
     }
     if (valid) {
+        const float invd = 1.0f / d;
 #pragma unroll
-        for (int e = 0; e < r.NE; ++e) {
-            const float p = expf(r.x[e] - lse);
-            r.x[e] = (p - ((int64_t)label == r.col(t, e) ? 1.f : 0.f)) * scale;
-        }
+        for (int e = 0; e < r.NE; ++e)
+            r.x[e] = (r.x[e] * invd - ((int64_t)label == r.col(t, e) ? 1.f : 0.f)) * scale;
     } else {
 #pragma unroll
         for (int e = 0; e < r.NE; ++e) r.x[e] = 0.f;
