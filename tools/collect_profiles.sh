@@ -1,0 +1,22 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun): benches + rocprofv3 kernel stats + PMC passes into gpurun_out/.
+# Post-process locally with tools/prof_summary.py into profiles/.
+R=${GRAFT_REPO_ROOT:-/root/repo}
+mkdir -p $R/gpurun_out
+cd $R
+python tools/kbench.py > gpurun_out/kbench.log 2>&1
+python bench.py --steps 20 --warmup 5 > gpurun_out/bench_c2.json 2> gpurun_out/bench_c2.err
+python bench.py --workload c3 --steps 20 --warmup 5 > gpurun_out/bench_c3.json 2> gpurun_out/bench_c3.err
+python bench.py --workload c1 --steps 500 --warmup 50 > gpurun_out/bench_c1.json 2> gpurun_out/bench_c1.err
+python bench.py --workload c4 --steps 10 --warmup 3 > gpurun_out/bench_c4.json 2> gpurun_out/bench_c4.err
+cd /tmp && export TMPDIR=/tmp
+for W in c2 c3 c4; do
+  S=10; [ $W = c4 ] && S=5
+  rocprofv3 --kernel-trace --stats -f csv -d $R/gpurun_out/prof_$W -o $W -- python $R/bench.py --workload $W --steps $S --warmup 3 --no-cpu-baseline > $R/gpurun_out/prof_$W.log 2>&1
+done
+for W in c2 c3; do
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $R/gpurun_out/pmc_fetch_$W -o f -- python $R/bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_fetch_$W.log 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $R/gpurun_out/pmc_write_$W -o w -- python $R/bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_write_$W.log 2>&1
+done
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -f csv -d $R/gpurun_out/pmc_sq_c2 -o sq -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_sq_c2.log 2>&1
+ls $R/gpurun_out
