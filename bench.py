@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4"])
+    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4", "c5"])
     ap.add_argument("--c4-batch", type=int, default=64, help="sequences per GPU for the GPT-tiny workload")
     ap.add_argument("--graph", type=int, default=1, help="c1/c4: replay the step as a captured hipGraph (1) or launch eagerly (0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -509,6 +509,98 @@ def cpu_c4(seconds):
                       f"(optimizer step excluded): {dt:.2f} s"}
 
 
+# ------------------------------------------------------------------------------------------------ C5
+def workload_c5(args, rank, world):
+    """BASELINE C5: Conv2d MNIST classifier (examples/convolutional_digits_classifier.ipynb) training step,
+    28x28x1, batch 256 per GPU: conv(1->8) LeakyReLU MaxPool conv(8->16) LeakyReLU MaxPool BatchNorm2d Linear Sigmoid,
+    MSE, Adam(1e-3).  BatchNorm statistics are per replica under DP."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import conv_classifier
+    import neunet_hip
+    import neunet_hip.nn as nn
+    from neunet_hip.distributed import GradBucket
+    from neunet_hip.graph import GraphedTrainStep
+    from neunet_hip.optim import Adam
+    Bsz = 256
+    np.random.seed(1005)
+    model = conv_classifier.Conv2dClassifier()
+    params = model.parameters()
+    bucket = GradBucket(params)
+    opt = Adam(params, lr=1e-3)
+    opt.grad_scale = 1.0 / world
+    rng = np.random.default_rng(5000 + rank)
+    X = neunet_hip.Tensor(rng.uniform(-1, 1, (Bsz, 1, 28, 28)).astype(np.float32), device="cuda", requires_grad=False)
+    Tt = neunet_hip.Tensor(np.eye(10, dtype=np.float32)[rng.integers(0, 10, Bsz)], device="cuda", requires_grad=False)
+    loss_fn = nn.MSELoss()
+    ev = EventTimer()
+
+    def fwd_bwd():
+        loss = loss_fn(model(X), Tt)
+        loss.backward()
+        return loss
+
+    if args.graph:
+        gstep = GraphedTrainStep(fwd_bwd, opt, bucket, warmup=3, world=world)
+
+        def step(timed):
+            if timed:
+                a, b = ev.span()
+                a.record()
+            gstep()
+            if timed:
+                b.record()
+    else:
+        def step(timed):
+            if timed:
+                a, b = ev.span()
+                a.record()
+            opt.zero_grad()
+            fwd_bwd()
+            bucket.all_reduce()
+            opt.step()
+            if timed:
+                b.record()
+
+    dt = timed_region(step, args.steps, args.warmup, world)
+    dev_ms = ev.mean_ms()
+    # algorithmic HBM bytes of the two conv layers fwd + bwd (SURVEY 8d): 4*(|X|+|O|+|W|) forward, x2 backward
+    conv_bytes = 3 * 4.0 * ((Bsz * 784 + Bsz * 8 * 784 + 72) + (Bsz * 8 * 196 + Bsz * 16 * 196 + 1152))
+    return {
+        "samples_per_step": Bsz * world, "dt": dt,
+        "config": {"workload": "C5: Conv2d MNIST classifier training step (conv-LeakyReLU-MaxPool x2, BatchNorm2d, Linear, "
+                               "Sigmoid, MSE, Adam), 28x28x1, batch 256 per GPU, implicit-GEMM MFMA conv",
+                   "global_batch": Bsz * world, "parallelism": f"dp{world}",
+                   "launch": "hipGraph replay" if args.graph else "eager"},
+        "roofline": {"kernel": "whole step vs the conv layers' algorithmic HBM bytes (K<=72, Cout<=16: HBM/latency bound)",
+                     "bound": "hbm", "achieved": round(conv_bytes / (dev_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
+                     "unit": "GB/s", "frac": round(conv_bytes / (dev_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 5), "traffic": None,
+                     "avg_step_device_ms": round(dev_ms, 4)},
+        "extra": {},
+    }
+
+
+def cpu_c5(seconds):
+    from oracle import neunet_oracle as O
+    rng = np.random.default_rng(1005)
+    u = lambda s, fan: rng.uniform(-1, 1, s).astype(np.float32) / np.float32(np.sqrt(fan))  # noqa: E731
+    params = [u((8, 1, 3, 3), 9), np.zeros(8, np.float32), u((16, 8, 3, 3), 72), np.zeros(16, np.float32),
+              np.ones((1, 16), np.float32), np.zeros((1, 16), np.float32), u((10, 784), 784), u((1, 10), 784)]
+    model = O.ConvClassifier(params)
+    X = rng.uniform(-1, 1, (256, 1, 28, 28)).astype(np.float32)
+    Tt = np.eye(10, dtype=np.float32)[rng.integers(0, 10, 256)]
+    model.forward_backward(X, Tt)
+    times, t0 = [], time.perf_counter()
+    while time.perf_counter() - t0 < min(seconds, 10.0) and len(times) < 20:
+        t1 = time.perf_counter()
+        model.forward_backward(X, Tt)
+        times.append(time.perf_counter() - t1)
+    best = min(times)
+    return {"value": round(256 / best, 1), "unit": "samples/s", "cores": blas_threads(), "kind": "port",
+            "sample": f"{len(times)} forward+backward passes of the NumPy-oracle conv classifier at batch 256 "
+                      f"(optimizer excluded), min {best * 1e3:.1f} ms"}
+
+
 def blas_threads():
     try:
         from threadpoolctl import threadpool_info
@@ -526,7 +618,7 @@ def main():
     if world != args.gpus and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     neunet_hip.load_library()
-    wl = {"c1": workload_c1, "c2": workload_c2, "c3": workload_c3, "c4": workload_c4}[args.workload]
+    wl = {"c1": workload_c1, "c2": workload_c2, "c3": workload_c3, "c4": workload_c4, "c5": workload_c5}[args.workload]
     res = wl(args, rank, world)
     dt = res["dt"]
     value = res["samples_per_step"] * args.steps / dt
@@ -540,7 +632,7 @@ def main():
     out.update(res.get("extra", {}))
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = {"c1": cpu_c1, "c2": cpu_c2, "c3": cpu_c3, "c4": cpu_c4}[args.workload](args.cpu_seconds)
+            out["cpu_baseline"] = {"c1": cpu_c1, "c2": cpu_c2, "c3": cpu_c3, "c4": cpu_c4, "c5": cpu_c5}[args.workload](args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -212,6 +212,38 @@ int nnhipEmbeddingForward(float* out, const float* weight, const int32_t* ids, c
 int nnhipEmbeddingBackward(float* dW, const float* grad_out, const int32_t* ids, int64_t n_ids,
                            int64_t dim, int64_t vocab, float scale, nnhipStream_t stream);
 
+/* ---- the rest of the conv-classifier step (examples/convolutional_digits_classifier.ipynb) ----
+ * LeakyReLU (neunet/nn/activations.py:60-84): f = x <= 0 ? alpha*x : x ; dx = dy * (f <= 0 ? alpha : 1). */
+int nnhipLeakyReLUForward(float* out, const float* in, float alpha, int64_t size, nnhipStream_t stream);
+int nnhipLeakyReLUBackward(float* dIn, const float* dOut, const float* out, float alpha, int64_t size,
+                           nnhipStream_t stream);
+/* Sigmoid (activations.py:9-28): f = 1/(1+exp(-x)) ; dx = dy * f * (1 - f), `out` = forward output. */
+int nnhipSigmoidForward(float* out, const float* in, int64_t size, nnhipStream_t stream);
+int nnhipSigmoidBackward(float* dIn, const float* dOut, const float* out, int64_t size, nnhipStream_t stream);
+/* MaxPool2d (neunet/nn/layers/maxpool2d.py:85-249), NCHW, dilation 1.  pad = (up, down, left, right), padded
+ * with -inf; argmax[b,c,ho,wo] = r*kw + s of the FIRST maximum (np.nanargmax).  Backward gathers, so
+ * overlapping windows accumulate deterministically. */
+typedef struct nnhipPool2dDesc {
+    int64_t B, C, H, W, kh, kw, sh, sw, pu, pd, pl, pr;
+} nnhipPool2dDesc;
+int nnhipMaxPool2dForward(float* out, int32_t* argmax, const float* X, const nnhipPool2dDesc* d,
+                          nnhipStream_t stream);
+int nnhipMaxPool2dBackward(float* dX, const float* dY, const int32_t* argmax, const nnhipPool2dDesc* d,
+                           nnhipStream_t stream);
+/* BatchNorm2d (neunet/nn/layers/batchnorm2d.py:57-115, 11-54), X [B,C,HW].  training != 0: batch mean / biased
+ * variance per channel, running = momentum*running + (1-momentum)*stat (the reference's convention; running_*
+ * may be NULL); else the running statistics are used.  save_mean / save_inv [C] feed the backward.
+ * weight / bias [C] may both be NULL (affine = False). */
+int nnhipBatchNorm2dForward(const float* X, const float* weight, const float* bias, float* Y, float* save_mean,
+                            float* save_inv, float* running_mean, float* running_var, int64_t B, int64_t C,
+                            int64_t HW, float eps, float momentum, int training, nnhipStream_t stream);
+int nnhipBatchNorm2dBackward(const float* dY, const float* X, const float* weight, const float* save_mean,
+                             const float* save_inv, float* dX, float* dW, float* db, int64_t B, int64_t C,
+                             int64_t HW, nnhipStream_t stream);
+/* MSELoss (neunet/nn/losses.py:9-22): loss[0] = sum((pred-target)^2)/n ; dpred = 2 (pred-target)/n (may be NULL). */
+int nnhipMSELossForwardBackward(const float* pred, const float* target, float* loss, float* dpred, int64_t n,
+                                nnhipStream_t stream);
+
 /* ---- gradient-bucket helpers for data-parallel training (net-new) ---------------- */
 /* x[i] *= alpha */
 int nnhipScale(float* x, float alpha, int64_t n, nnhipStream_t stream);

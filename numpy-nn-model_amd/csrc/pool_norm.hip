@@ -1,0 +1,361 @@
+// pool_norm.hip -- the remaining ops of the conv-classifier step (BASELINE config 5;
+// examples/convolutional_digits_classifier.ipynb cell 2): LeakyReLU, Sigmoid, MaxPool2d, BatchNorm2d, MSELoss.
+// All are small, HBM/latency-bound kernels on NCHW fp32.
+#include <math.h>
+
+#include "common.h"
+
+namespace nnhip {
+
+// ---- generic float4 maps (same shape as elementwise.hip) -----------------------------------------------------
+template <class F>
+__global__ __launch_bounds__(256) void pn_map1(float* out, const float* a, int64_t n, bool vec, F f) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x, gsz = (int64_t)gridDim.x * 256;
+    if (vec) {
+        const int64_t nv = n >> 2;
+        for (int64_t i = gid; i < nv; i += gsz) {
+            const float4 x = reinterpret_cast<const float4*>(a)[i];
+            reinterpret_cast<float4*>(out)[i] = make_float4(f(x.x), f(x.y), f(x.z), f(x.w));
+        }
+        for (int64_t i = (nv << 2) + gid; i < n; i += gsz) out[i] = f(a[i]);
+    } else {
+        for (int64_t i = gid; i < n; i += gsz) out[i] = f(a[i]);
+    }
+}
+template <class F>
+__global__ __launch_bounds__(256) void pn_map2(float* out, const float* a, const float* b, int64_t n, bool vec, F f) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x, gsz = (int64_t)gridDim.x * 256;
+    if (vec) {
+        const int64_t nv = n >> 2;
+        for (int64_t i = gid; i < nv; i += gsz) {
+            const float4 x = reinterpret_cast<const float4*>(a)[i], z = reinterpret_cast<const float4*>(b)[i];
+            reinterpret_cast<float4*>(out)[i] = make_float4(f(x.x, z.x), f(x.y, z.y), f(x.z, z.z), f(x.w, z.w));
+        }
+        for (int64_t i = (nv << 2) + gid; i < n; i += gsz) out[i] = f(a[i], b[i]);
+    } else {
+        for (int64_t i = gid; i < n; i += gsz) out[i] = f(a[i], b[i]);
+    }
+}
+static inline unsigned pn_blocks(int64_t n) {
+    int64_t b = ceil_div(n > 0 ? n : 1, 1024);
+    return (unsigned)(b < 65535 ? b : 65535);
+}
+
+// f = x <= 0 ? alpha x : x                       (neunet/nn/activations.py:79-81)
+struct LeakyF { float alpha; __device__ float operator()(float x) const { return x <= 0.f ? alpha * x : x; } };
+// dx = dy * (f <= 0 ? alpha : 1)                 (activations.py:64-68)
+struct LeakyB { float alpha; __device__ float operator()(float dy, float f) const { return f <= 0.f ? dy * alpha : dy; } };
+// f = 1 / (1 + exp(-x))                          (activations.py:24-25)
+struct SigmoidF { __device__ float operator()(float x) const { return 1.0f / (1.0f + expf(-x)); } };
+// dx = dy * f * (1 - f)                          (activations.py:12-13)
+struct SigmoidB { __device__ float operator()(float dy, float f) const { return dy * f * (1.0f - f); } };
+
+// ---- MaxPool2d (neunet/nn/layers/maxpool2d.py:85-249; dilation 1) ----------------------------------------------
+// Forward: one thread per output; windows read -inf outside the padded input; the FIRST maximum in (r, s)
+// row-major order is remembered (np.nanargmax, maxpool2d.py:37).  Backward is a gather over the windows that
+// cover an input pixel (deterministic, also correct for overlapping windows).
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(float* __restrict__ out, int32_t* __restrict__ arg,
+                                                          const float* __restrict__ x, int64_t BC, int H, int W,
+                                                          int Ho, int Wo, int kh, int kw, int sh, int sw, int pu,
+                                                          int pl) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = BC * Ho * Wo;
+    if (i >= total) return;
+    const int wo = (int)(i % Wo), ho = (int)((i / Wo) % Ho);
+    const int64_t bc = i / ((int64_t)Ho * Wo);
+    const float* p = x + bc * H * W;
+    float best = -INFINITY;
+    int bi = 0;
+    for (int r = 0; r < kh; ++r)
+        for (int s = 0; s < kw; ++s) {
+            const int y = ho * sh - pu + r, xx = wo * sw - pl + s;
+            const float v = (y >= 0 && y < H && xx >= 0 && xx < W) ? p[(int64_t)y * W + xx] : -INFINITY;
+            if (v > best) { best = v; bi = r * kw + s; }
+        }
+    out[i] = best;
+    arg[i] = bi;
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(float* __restrict__ dx, const float* __restrict__ dy,
+                                                          const int32_t* __restrict__ arg, int64_t BC, int H, int W,
+                                                          int Ho, int Wo, int kh, int kw, int sh, int sw, int pu,
+                                                          int pl) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t total = BC * H * W;
+    if (i >= total) return;
+    const int xx = (int)(i % W), y = (int)((i / W) % H);
+    const int64_t bc = i / ((int64_t)H * W);
+    float g = 0.f;
+    for (int r = 0; r < kh; ++r) {
+        const int ty = y + pu - r;
+        if (ty < 0 || ty % sh) continue;
+        const int ho = ty / sh;
+        if (ho >= Ho) continue;
+        for (int s = 0; s < kw; ++s) {
+            const int tx = xx + pl - s;
+            if (tx < 0 || tx % sw) continue;
+            const int wo = tx / sw;
+            if (wo >= Wo) continue;
+            const int64_t o = (bc * Ho + ho) * Wo + wo;
+            if (arg[o] == r * kw + s) g += dy[o];
+        }
+    }
+    dx[i] = g;
+}
+
+// ---- BatchNorm2d (neunet/nn/layers/batchnorm2d.py:57-115 fwd, 11-54 bwd) --------------------------------------
+// Statistics: one block per channel, two passes (mean, then mean of squared deviations = np.var, biased).
+// stats[c] = {mean, var};  running = momentum*running + (1-momentum)*stat  (the reference's convention, :84-85).
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, float* __restrict__ mean_out,
+                                                       float* __restrict__ inv_out, float* __restrict__ run_mean,
+                                                       float* __restrict__ run_var, int B, int C, int HW, float eps,
+                                                       float momentum) {
+    __shared__ float red[4];
+    const int c = blockIdx.x;
+    const int64_t n = (int64_t)B * HW;
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        const int b = (int)(i / HW), hw = (int)(i - (int64_t)b * HW);
+        s += x[((int64_t)b * C + c) * HW + hw];
+    }
+    const float mean = block_sum<4>(s, red) / (float)n;
+    float q = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        const int b = (int)(i / HW), hw = (int)(i - (int64_t)b * HW);
+        const float d = x[((int64_t)b * C + c) * HW + hw] - mean;
+        q += d * d;
+    }
+    const float var = block_sum<4>(q, red) / (float)n;
+    if (threadIdx.x == 0) {
+        mean_out[c] = mean;
+        inv_out[c] = 1.0f / sqrtf(var + eps);
+        if (run_mean) {
+            run_mean[c] = momentum * run_mean[c] + (1.0f - momentum) * mean;
+            run_var[c] = momentum * run_var[c] + (1.0f - momentum) * var;
+        }
+    }
+}
+// eval mode: mean = running_mean, inv = 1/sqrt(running_var + eps)
+__global__ void bn_eval_stats_kernel(const float* __restrict__ run_mean, const float* __restrict__ run_var,
+                                     float* __restrict__ mean_out, float* __restrict__ inv_out, int C, float eps) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c < C) { mean_out[c] = run_mean[c]; inv_out[c] = 1.0f / sqrtf(run_var[c] + eps); }
+}
+// y = (x - mean[c]) * inv[c] * w[c] + b[c]
+__global__ __launch_bounds__(256) void bn_apply_kernel(float* __restrict__ y, const float* __restrict__ x,
+                                                       const float* __restrict__ mean, const float* __restrict__ inv,
+                                                       const float* __restrict__ w, const float* __restrict__ b,
+                                                       int64_t total, int C, int HW) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)((i / HW) % C);
+    float v = (x[i] - mean[c]) * inv[c];
+    if (w) v = w[c] * v + b[c];
+    y[i] = v;
+}
+// per-channel sums for the backward: sums[c] = {sum dxh*xc, sum dxh, sum g*xhat, sum g},  dxh = w*g
+__global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ inv, const float* __restrict__ w,
+                                                           float* __restrict__ sums, int B, int C, int HW) {
+    __shared__ float red[8];
+    const int c = blockIdx.x;
+    const int64_t n = (int64_t)B * HW;
+    const float m = mean[c], iv = inv[c], wc = w ? w[c] : 1.f;
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        const int b = (int)(i / HW), hw = (int)(i - (int64_t)b * HW);
+        const int64_t o = ((int64_t)b * C + c) * HW + hw;
+        const float gg = g[o], xc = x[o] - m;
+        s1 += wc * gg * xc;
+        s2 += wc * gg;
+        s3 += gg * (xc * iv);
+        s4 += gg;
+    }
+    block_sum2<4>(s1, s2, red);
+    block_sum2<4>(s3, s4, red);
+    if (threadIdx.x == 0) { sums[4 * c] = s1; sums[4 * c + 1] = s2; sums[4 * c + 2] = s3; sums[4 * c + 3] = s4; }
+}
+// grad_X = dxh*inv + dvar + dmean ;  dstd_inv = -0.5 inv^3 s1 ; dvar = dstd_inv*2*xc/N ; dmean = -(s2*inv)/N
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ dx, const float* __restrict__ g,
+                                                           const float* __restrict__ x, const float* __restrict__ mean,
+                                                           const float* __restrict__ inv, const float* __restrict__ w,
+                                                           const float* __restrict__ sums, float* __restrict__ dw,
+                                                           float* __restrict__ db, int64_t total, int C, int HW,
+                                                           float invN) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < C && dw) { dw[i] = sums[4 * i + 2]; db[i] = sums[4 * i + 3]; }
+    if (i >= total) return;
+    const int c = (int)((i / HW) % C);
+    const float iv = inv[c], wc = w ? w[c] : 1.f;
+    const float xc = x[i] - mean[c];
+    const float dstd = -0.5f * (iv * iv * iv) * sums[4 * c];
+    dx[i] = wc * g[i] * iv + dstd * 2.0f * xc * invN + sums[4 * c + 1] * iv * (-1.0f) * invN;
+}
+
+// ---- MSELoss (neunet/nn/losses.py:9-22): loss = sum((p - t)^2) / N ; dp = 2 (p - t) / N -------------------------
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ p, const float* __restrict__ t,
+                                                  float* __restrict__ dp, float* __restrict__ part, int64_t n,
+                                                  float invN) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float d = p[i] - t[i];
+        s += d * d;
+        if (dp) dp[i] = 2.0f * d * invN;
+    }
+    s = block_sum<4>(s, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void mse_final_kernel(const float* __restrict__ part, int nparts, float invN,
+                                                        float* __restrict__ loss) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) s += part[i];
+    s = block_sum<4>(s, red);
+    if (threadIdx.x == 0) loss[0] = s * invN;
+}
+
+}  // namespace nnhip
+
+using namespace nnhip;
+
+#define PN_MAP1(name, F, fobj)                                                                         \
+    extern "C" int name(float* out, const float* in, int64_t size, nnhipStream_t s) {                   \
+        NNHIP_CHECK_ARG(size >= 0, NNHIP_EINVAL, #name ": negative size");                              \
+        if (size == 0) return 0;                                                                        \
+        NNHIP_CHECK_ARG(out && in, NNHIP_EINVAL, #name ": null pointer");                               \
+        const bool vec = aligned16(out) && aligned16(in);                                               \
+        hipLaunchKernelGGL((pn_map1<F>), dim3(pn_blocks(size)), dim3(256), 0, (hipStream_t)s, out, in, size, vec, fobj); \
+        NNHIP_LAUNCH_CHECK(#name);                                                                      \
+        return 0;                                                                                       \
+    }
+
+extern "C" int nnhipLeakyReLUForward(float* out, const float* in, float alpha, int64_t size, nnhipStream_t s) {
+    NNHIP_CHECK_ARG(size >= 0, NNHIP_EINVAL, "nnhipLeakyReLUForward: negative size");
+    if (size == 0) return 0;
+    NNHIP_CHECK_ARG(out && in, NNHIP_EINVAL, "nnhipLeakyReLUForward: null pointer");
+    const bool vec = aligned16(out) && aligned16(in);
+    hipLaunchKernelGGL((pn_map1<LeakyF>), dim3(pn_blocks(size)), dim3(256), 0, (hipStream_t)s, out, in, size, vec, LeakyF{alpha});
+    NNHIP_LAUNCH_CHECK("leaky_relu_forward");
+    return 0;
+}
+extern "C" int nnhipLeakyReLUBackward(float* dIn, const float* dOut, const float* out, float alpha, int64_t size,
+                                      nnhipStream_t s) {
+    NNHIP_CHECK_ARG(size >= 0, NNHIP_EINVAL, "nnhipLeakyReLUBackward: negative size");
+    if (size == 0) return 0;
+    NNHIP_CHECK_ARG(dIn && dOut && out, NNHIP_EINVAL, "nnhipLeakyReLUBackward: null pointer");
+    const bool vec = aligned16(dIn) && aligned16(dOut) && aligned16(out);
+    hipLaunchKernelGGL((pn_map2<LeakyB>), dim3(pn_blocks(size)), dim3(256), 0, (hipStream_t)s, dIn, dOut, out, size, vec, LeakyB{alpha});
+    NNHIP_LAUNCH_CHECK("leaky_relu_backward");
+    return 0;
+}
+PN_MAP1(nnhipSigmoidForward, SigmoidF, SigmoidF{})
+extern "C" int nnhipSigmoidBackward(float* dIn, const float* dOut, const float* out, int64_t size, nnhipStream_t s) {
+    NNHIP_CHECK_ARG(size >= 0, NNHIP_EINVAL, "nnhipSigmoidBackward: negative size");
+    if (size == 0) return 0;
+    NNHIP_CHECK_ARG(dIn && dOut && out, NNHIP_EINVAL, "nnhipSigmoidBackward: null pointer");
+    const bool vec = aligned16(dIn) && aligned16(dOut) && aligned16(out);
+    hipLaunchKernelGGL((pn_map2<SigmoidB>), dim3(pn_blocks(size)), dim3(256), 0, (hipStream_t)s, dIn, dOut, out, size, vec, SigmoidB{});
+    NNHIP_LAUNCH_CHECK("sigmoid_backward");
+    return 0;
+}
+
+static int pool_check(const nnhipPool2dDesc* d, int& Ho, int& Wo) {
+    NNHIP_CHECK_ARG(d != nullptr, NNHIP_EINVAL, "maxpool2d: null descriptor");
+    NNHIP_CHECK_ARG(d->B >= 0 && d->C > 0 && d->H > 0 && d->W > 0 && d->kh > 0 && d->kw > 0 && d->sh > 0 && d->sw > 0 &&
+                        d->pu >= 0 && d->pd >= 0 && d->pl >= 0 && d->pr >= 0,
+                    NNHIP_EINVAL, "maxpool2d: bad descriptor");
+    const int64_t ho = (d->H + d->pu + d->pd - (d->kh - 1) - 1) / d->sh + 1;   // maxpool2d.py:170-183 (dilation 1)
+    const int64_t wo = (d->W + d->pl + d->pr - (d->kw - 1) - 1) / d->sw + 1;
+    NNHIP_CHECK_ARG(ho > 0 && wo > 0 && d->H * d->W < ((int64_t)1 << 31), NNHIP_EINVAL, "maxpool2d: bad geometry");
+    Ho = (int)ho; Wo = (int)wo;
+    return 0;
+}
+
+extern "C" int nnhipMaxPool2dForward(float* out, int32_t* argmax, const float* X, const nnhipPool2dDesc* d,
+                                     nnhipStream_t s) {
+    int Ho, Wo;
+    if (int rc = pool_check(d, Ho, Wo)) return rc;
+    const int64_t total = d->B * d->C * Ho * Wo;
+    if (total == 0) return 0;
+    NNHIP_CHECK_ARG(out && argmax && X, NNHIP_EINVAL, "nnhipMaxPool2dForward: null pointer");
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)s, out, argmax, X,
+                       d->B * d->C, (int)d->H, (int)d->W, Ho, Wo, (int)d->kh, (int)d->kw, (int)d->sh, (int)d->sw,
+                       (int)d->pu, (int)d->pl);
+    NNHIP_LAUNCH_CHECK("maxpool_fwd_kernel");
+    return 0;
+}
+extern "C" int nnhipMaxPool2dBackward(float* dX, const float* dY, const int32_t* argmax, const nnhipPool2dDesc* d,
+                                      nnhipStream_t s) {
+    int Ho, Wo;
+    if (int rc = pool_check(d, Ho, Wo)) return rc;
+    const int64_t total = d->B * d->C * d->H * d->W;
+    if (total == 0) return 0;
+    NNHIP_CHECK_ARG(dX && dY && argmax, NNHIP_EINVAL, "nnhipMaxPool2dBackward: null pointer");
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)s, dX, dY, argmax,
+                       d->B * d->C, (int)d->H, (int)d->W, Ho, Wo, (int)d->kh, (int)d->kw, (int)d->sh, (int)d->sw,
+                       (int)d->pu, (int)d->pl);
+    NNHIP_LAUNCH_CHECK("maxpool_bwd_kernel");
+    return 0;
+}
+
+extern "C" int nnhipBatchNorm2dForward(const float* X, const float* weight, const float* bias, float* Y,
+                                       float* save_mean, float* save_inv, float* running_mean, float* running_var,
+                                       int64_t B, int64_t C, int64_t HW, float eps, float momentum, int training,
+                                       nnhipStream_t s) {
+    NNHIP_CHECK_ARG(B >= 0 && C > 0 && HW > 0 && B * HW < ((int64_t)1 << 31), NNHIP_EINVAL, "nnhipBatchNorm2dForward: bad sizes");
+    if (B == 0) return 0;
+    NNHIP_CHECK_ARG(X && Y && save_mean && save_inv, NNHIP_EINVAL, "nnhipBatchNorm2dForward: null pointer");
+    NNHIP_CHECK_ARG((weight == nullptr) == (bias == nullptr), NNHIP_EINVAL, "nnhipBatchNorm2dForward: weight and bias go together");
+    NNHIP_CHECK_ARG(training || (running_mean && running_var), NNHIP_EINVAL, "nnhipBatchNorm2dForward: eval needs running stats");
+    hipStream_t st = (hipStream_t)s;
+    if (training)
+        hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)C), dim3(256), 0, st, X, save_mean, save_inv, running_mean, running_var,
+                           (int)B, (int)C, (int)HW, eps, momentum);
+    else
+        hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((unsigned)ceil_div(C, 64)), dim3(64), 0, st, running_mean, running_var,
+                           save_mean, save_inv, (int)C, eps);
+    NNHIP_LAUNCH_CHECK("bn_stats");
+    const int64_t total = B * C * HW;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, st, Y, X, save_mean, save_inv, weight,
+                       bias, total, (int)C, (int)HW);
+    NNHIP_LAUNCH_CHECK("bn_apply_kernel");
+    return 0;
+}
+extern "C" int nnhipBatchNorm2dBackward(const float* dY, const float* X, const float* weight, const float* save_mean,
+                                        const float* save_inv, float* dX, float* dW, float* db, int64_t B, int64_t C,
+                                        int64_t HW, nnhipStream_t s) {
+    NNHIP_CHECK_ARG(B >= 0 && C > 0 && HW > 0 && B * HW < ((int64_t)1 << 31), NNHIP_EINVAL, "nnhipBatchNorm2dBackward: bad sizes");
+    if (B == 0) return 0;
+    NNHIP_CHECK_ARG(dY && X && save_mean && save_inv && dX, NNHIP_EINVAL, "nnhipBatchNorm2dBackward: null pointer");
+    NNHIP_CHECK_ARG((dW == nullptr) == (db == nullptr), NNHIP_EINVAL, "nnhipBatchNorm2dBackward: dW and db go together");
+    hipStream_t st = (hipStream_t)s;
+    float* sums = static_cast<float*>(workspace((size_t)C * 4 * sizeof(float)));
+    NNHIP_CHECK_ARG(sums != nullptr, NNHIP_ENOMEM, "nnhipBatchNorm2dBackward: workspace allocation failed");
+    hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3((unsigned)C), dim3(256), 0, st, dY, X, save_mean, save_inv, weight, sums, (int)B,
+                       (int)C, (int)HW);
+    NNHIP_LAUNCH_CHECK("bn_bwd_stats_kernel");
+    const int64_t total = B * C * HW;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)ceil_div(total > C ? total : C, 256)), dim3(256), 0, st, dX, dY, X,
+                       save_mean, save_inv, weight, sums, dW, db, total, (int)C, (int)HW, 1.0f / (float)(B * HW));
+    NNHIP_LAUNCH_CHECK("bn_bwd_apply_kernel");
+    return 0;
+}
+
+extern "C" int nnhipMSELossForwardBackward(const float* pred, const float* target, float* loss, float* dpred,
+                                           int64_t n, nnhipStream_t s) {
+    NNHIP_CHECK_ARG(n > 0, NNHIP_EINVAL, "nnhipMSELossForwardBackward: n must be > 0");
+    NNHIP_CHECK_ARG(pred && target && loss, NNHIP_EINVAL, "nnhipMSELossForwardBackward: null pointer");
+    hipStream_t st = (hipStream_t)s;
+    int64_t blocks = ceil_div(n, 1024);
+    if (blocks > 1024) blocks = 1024;
+    float* part = static_cast<float*>(workspace((size_t)blocks * sizeof(float)));
+    NNHIP_CHECK_ARG(part != nullptr, NNHIP_ENOMEM, "nnhipMSELossForwardBackward: workspace allocation failed");
+    const float invN = 1.0f / (float)n;
+    hipLaunchKernelGGL(mse_kernel, dim3((unsigned)blocks), dim3(256), 0, st, pred, target, dpred, part, n, invN);
+    NNHIP_LAUNCH_CHECK("mse_kernel");
+    hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(256), 0, st, part, (int)blocks, invN, loss);
+    NNHIP_LAUNCH_CHECK("mse_final_kernel");
+    return 0;
+}

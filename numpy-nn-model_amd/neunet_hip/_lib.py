@@ -28,6 +28,11 @@ class Conv2dDesc(ctypes.Structure):
                                        "pu", "pd", "pl", "pr")]
 
 
+class Pool2dDesc(ctypes.Structure):
+    """struct nnhipPool2dDesc (include/neunet_hip.h)."""
+    _fields_ = [(n, c_int64) for n in ("B", "C", "H", "W", "kh", "kw", "sh", "sw", "pu", "pd", "pl", "pr")]
+
+
 P = c_void_p  # device pointers travel as void*
 _SIGNATURES = {
     # name: (restype, argtypes)
@@ -69,6 +74,15 @@ _SIGNATURES = {
     "nnhipFusedOptimizerSetStep": (ctypes.c_int, [c_void_p, c_int32, c_void_p]),
     "nnhipConv2dForward": (ctypes.c_int, [P, P, P, P, POINTER(Conv2dDesc), c_void_p]),
     "nnhipConv2dBackward": (ctypes.c_int, [P, P, P, P, P, P, POINTER(Conv2dDesc), c_void_p]),
+    "nnhipLeakyReLUForward": (ctypes.c_int, [P, P, c_float, c_int64, c_void_p]),
+    "nnhipLeakyReLUBackward": (ctypes.c_int, [P, P, P, c_float, c_int64, c_void_p]),
+    "nnhipSigmoidForward": (ctypes.c_int, [P, P, c_int64, c_void_p]),
+    "nnhipSigmoidBackward": (ctypes.c_int, [P, P, P, c_int64, c_void_p]),
+    "nnhipMaxPool2dForward": (ctypes.c_int, [P, P, P, POINTER(Pool2dDesc), c_void_p]),
+    "nnhipMaxPool2dBackward": (ctypes.c_int, [P, P, P, POINTER(Pool2dDesc), c_void_p]),
+    "nnhipBatchNorm2dForward": (ctypes.c_int, [P, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_float, c_float, ctypes.c_int, c_void_p]),
+    "nnhipBatchNorm2dBackward": (ctypes.c_int, [P, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_void_p]),
+    "nnhipMSELossForwardBackward": (ctypes.c_int, [P, P, P, P, c_int64, c_void_p]),
     "nnhipScale": (ctypes.c_int, [P, c_float, c_int64, c_void_p]),
     "nnhipAdd": (ctypes.c_int, [P, P, P, c_int64, c_void_p]),
 }

@@ -7,7 +7,9 @@ from .experimental import (HIPConv2d as Conv2d, HIPCrossEntropyLoss, HIPLinear a
                            HIPLinearSwish as LinearSwish, HIPReLU as ReLU, HIPRMSNorm as RMSNorm,
                            HIPSoftmax as Softmax, HIPSwish as Swish, HIPFusedSwishAndMul as FusedSwishAndMul,
                            HIPEmbedding as Embedding, HIPDropout as Dropout, HIPMultiHeadAttention as MultiHeadAttention,
-                           HIPPositionalEncoding as PositionalEncoding)
+                           HIPPositionalEncoding as PositionalEncoding, HIPBatchNorm2d as BatchNorm2d,
+                           HIPLeakyReLU as LeakyReLU, HIPMaxPool2d as MaxPool2d, HIPMSELoss as MSELoss,
+                           HIPSigmoid as Sigmoid)
 
 
 class CrossEntropyLoss(HIPCrossEntropyLoss):

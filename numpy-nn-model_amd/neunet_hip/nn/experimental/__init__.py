@@ -9,3 +9,4 @@ from .rmsnorm import CUDARMSNorm, HIPRMSNorm  # noqa: F401
 from .conv2d import HIPConv2d  # noqa: F401
 from .attention import HIPMultiHeadAttention  # noqa: F401
 from .embedding import HIPDropout, HIPEmbedding, HIPPositionalEncoding  # noqa: F401
+from .vision import HIPBatchNorm2d, HIPLeakyReLU, HIPMaxPool2d, HIPMSELoss, HIPSigmoid  # noqa: F401

@@ -1,0 +1,218 @@
+"""The remaining modules of the conv-classifier step (examples/convolutional_digits_classifier.ipynb
+cell 2): HIPLeakyReLU, HIPSigmoid, HIPMaxPool2d, HIPBatchNorm2d, HIPMSELoss -- same constructor arguments,
+`args` layout and gradient formulas as the reference classes they stand in for."""
+import ctypes
+from typing import Union
+
+import numpy as np
+
+from ..._lib import Pool2dDesc
+from ...autograd import Tensor
+from ..modules import Module
+from ..parameter import Parameter
+from .linear import _grad_out
+from .utils import call_hip_function, contiguous, get_current_stream_ptr, require_device_f32
+
+
+def _pair(v):
+    return v if isinstance(v, tuple) else (v, v)
+
+
+# ------------------------------------------------------------------------------------------ LeakyReLU / Sigmoid
+class _HIPLeakyReLUTensor(Tensor):
+    def __init__(self, data, args, op, device):
+        super().__init__(data, args, op, device=device, _nocopy=True)
+
+        def grad_fn(t: Tensor, f_x, alpha, grad):
+            g = t.xp.empty_like(t.data)
+            call_hip_function("nnhipLeakyReLUBackward", g, contiguous(grad), f_x, float(alpha), f_x.numel(),
+                              get_current_stream_ptr())
+            t.apply_grad(g)
+
+        self.grad_fn = grad_fn
+
+
+class HIPLeakyReLU(Module):
+    """neunet/nn/activations.py:72-84."""
+
+    def __init__(self, alpha=0.01):
+        super().__init__()
+        self.alpha = alpha
+
+    def forward(self, x: Tensor):
+        require_device_f32(x)
+        f_x = x.xp.empty_like(x.data)
+        call_hip_function("nnhipLeakyReLUForward", f_x, contiguous(x.data), float(self.alpha), f_x.numel(),
+                          get_current_stream_ptr())
+        return _HIPLeakyReLUTensor(f_x, [x, f_x, self.alpha], "leakyrelu", device=x.device)
+
+
+class _HIPSigmoidTensor(Tensor):
+    def __init__(self, data, args, op, device):
+        super().__init__(data, args, op, device=device, _nocopy=True)
+
+        def grad_fn(x: Tensor, f_x, grad):
+            g = x.xp.empty_like(x.data)
+            call_hip_function("nnhipSigmoidBackward", g, contiguous(grad), f_x, f_x.numel(), get_current_stream_ptr())
+            x.apply_grad(g)
+
+        self.grad_fn = grad_fn
+
+
+class HIPSigmoid(Module):
+    """neunet/nn/activations.py:19-28."""
+
+    def __init__(self):
+        super().__init__()
+
+    def forward(self, x: Tensor):
+        require_device_f32(x)
+        f_x = x.xp.empty_like(x.data)
+        call_hip_function("nnhipSigmoidForward", f_x, contiguous(x.data), f_x.numel(), get_current_stream_ptr())
+        return _HIPSigmoidTensor(f_x, [x, f_x], "sigmoid", device=x.device)
+
+
+# ----------------------------------------------------------------------------------------------- MaxPool2d
+class _HIPMaxPool2dTensor(Tensor):
+    def __init__(self, data, args, op, device):
+        super().__init__(data, args, op, device=device, _nocopy=True)
+
+        def grad_fn(X: Tensor, argmax, desc, grad):
+            grad_X = X.xp.empty_like(X.data)
+            call_hip_function("nnhipMaxPool2dBackward", grad_X, contiguous(grad), argmax, ctypes.byref(desc),
+                              get_current_stream_ptr())
+            X.apply_grad(grad_X)
+
+        self.grad_fn = grad_fn
+
+
+class HIPMaxPool2d(Module):
+    """neunet/nn/layers/maxpool2d.py:85-249 (dilation 1 only)."""
+
+    def __init__(self, kernel_size, stride=None, padding=0, dilation=1):
+        super().__init__()
+        self.kernel_size = _pair(kernel_size)
+        self.stride = _pair(stride) if stride else self.kernel_size
+        p = _pair(padding)
+        self.padding = (p[0], p[0], p[1], p[1]) if len(p) == 2 else tuple(p)
+        if _pair(dilation) != (1, 1):
+            raise NotImplementedError("HIPMaxPool2d supports dilation 1 only")
+
+    def forward(self, X: Tensor) -> Tensor:
+        import torch
+        if not isinstance(X, Tensor):
+            raise TypeError("Input must be a tensor")
+        require_device_f32(X)
+        if X.ndim != 4:
+            raise ValueError("MaxPool2d expects a (B, C, H, W) input")
+        B, C, H, W = X.shape
+        kh, kw = self.kernel_size
+        sh, sw = self.stride
+        pu, pd, pl, pr = self.padding
+        Ho = (H + pu + pd - (kh - 1) - 1) // sh + 1      # maxpool2d.py:170-183
+        Wo = (W + pl + pr - (kw - 1) - 1) // sw + 1
+        desc = Pool2dDesc(B, C, H, W, kh, kw, sh, sw, pu, pd, pl, pr)
+        O = X.xp.empty((B, C, Ho, Wo), dtype=np.float32)
+        argmax = torch.empty((B, C, Ho, Wo), dtype=torch.int32, device=O.device)
+        call_hip_function("nnhipMaxPool2dForward", O, argmax, contiguous(X.data), ctypes.byref(desc),
+                          get_current_stream_ptr())
+        return _HIPMaxPool2dTensor(O, (X, argmax, desc), "maxpool2d", device=X.device)
+
+
+# --------------------------------------------------------------------------------------------- BatchNorm2d
+class _HIPBatchNorm2dTensor(Tensor):
+    def __init__(self, data, args, op, device):
+        super().__init__(data, args, op, device=device, _nocopy=True)
+
+        def grad_fn(X: Tensor, weight, bias, save_mean, save_inv, affine, grad):
+            B, C = X.shape[0], X.shape[1]
+            HW = X.shape[2] * X.shape[3]
+            grad_X = X.xp.empty_like(X.data)
+            gw = _grad_out(weight, weight.data) if affine else None
+            gb = _grad_out(bias, bias.data) if affine else None
+            call_hip_function("nnhipBatchNorm2dBackward", contiguous(grad), X.data, weight.data if affine else None,
+                              save_mean, save_inv, grad_X, gw, gb, B, C, HW, get_current_stream_ptr())
+            X.apply_grad(grad_X)
+            if affine:
+                weight.apply_grad(gw)
+                bias.apply_grad(gb)
+
+        self.grad_fn = grad_fn
+
+
+class HIPBatchNorm2d(Module):
+    """neunet/nn/layers/batchnorm2d.py:57-115.  weight/bias/running stats keep the reference's (1, C) shape;
+    running_mean / running_var are Parameters with requires_grad=False (in state_dict, not in parameters())."""
+
+    def __init__(self, num_features: int, eps: float = 1e-5, momentum: float = 0.1, affine: bool = True, device="cuda"):
+        super().__init__()
+        self.num_features, self.eps, self.momentum, self.affine = num_features, eps, momentum, affine
+        self.running_mean = Parameter(Tensor(np.zeros((1, num_features)), dtype=np.float32), requires_grad=False)
+        self.running_var = Parameter(Tensor(np.ones((1, num_features)), dtype=np.float32), requires_grad=False)
+        self.weight: Union[Tensor, None] = Parameter(Tensor(np.ones((1, num_features)), dtype=np.float32)) if affine else None
+        self.bias: Union[Tensor, None] = Parameter(Tensor(np.zeros((1, num_features)), dtype=np.float32)) if affine else None
+        self.training = True
+        self.to(device)
+
+    def forward(self, X: Tensor) -> Tensor:
+        if not isinstance(X, Tensor):
+            raise TypeError("Input must be a tensor")
+        if X.device != self.device:
+            raise ValueError("Tensors must be on the same device")
+        require_device_f32(X)
+        if X.ndim != 4 or X.shape[1] != self.num_features:
+            raise ValueError("BatchNorm2d expects a (B, C, H, W) input with C == num_features")
+        B, C, H, W = X.shape
+        xd = contiguous(X.data)
+        O = X.xp.empty_like(xd)
+        save_mean = X.xp.empty((C,), dtype=np.float32)
+        save_inv = X.xp.empty((C,), dtype=np.float32)
+        call_hip_function("nnhipBatchNorm2dForward", xd, self.weight.data if self.affine else None,
+                          self.bias.data if self.affine else None, O, save_mean, save_inv, self.running_mean.data,
+                          self.running_var.data, B, C, H * W, float(self.eps), float(self.momentum),
+                          int(bool(self.training)), get_current_stream_ptr())
+        return _HIPBatchNorm2dTensor(O, (X, self.weight, self.bias, save_mean, save_inv, self.affine), "batchnorm2d",
+                                     device=self.device)
+
+    def train(self, mode=True):
+        self.training = mode
+
+    def eval(self):
+        self.training = False
+
+
+# ------------------------------------------------------------------------------------------------- MSELoss
+class _HIPMSETensor(Tensor):
+    def __init__(self, data, args, op, device):
+        super().__init__(data, args, op, device=device, _nocopy=True)
+        out = self
+
+        def grad_fn(y_pred: Tensor, grad_pred, grad):
+            if getattr(out, "_seeded_with_ones", False):
+                y_pred.apply_grad(grad_pred)
+            else:
+                y_pred.apply_grad(grad_pred * grad)
+
+        self.grad_fn = grad_fn
+
+
+class HIPMSELoss(Module):
+    """neunet/nn/losses.py:9-22 -- sum((pred - true)^2) / numel, loss and d(pred) in one pass."""
+
+    def __init__(self):
+        super().__init__()
+
+    def forward(self, y_pred: Tensor, y_true: Tensor) -> Tensor:
+        import torch
+        if not isinstance(y_pred, Tensor) or not isinstance(y_true, Tensor):
+            raise TypeError("Input values must be tensors")
+        if y_pred.device != y_true.device:
+            raise ValueError("Tensors must be on the same device")
+        require_device_f32(y_pred, y_true)
+        if y_pred.shape != y_true.shape:
+            raise ValueError("MSELoss on the HIP path needs equal shapes")
+        p, t = contiguous(y_pred.data), contiguous(y_true.data)
+        loss = torch.empty((), dtype=torch.float32, device=p.device)
+        dpred = torch.empty_like(p)
+        call_hip_function("nnhipMSELossForwardBackward", p, t, loss, dpred, p.numel(), get_current_stream_ptr())
+        return _HIPMSETensor(loss, (y_pred, dpred), "mse", device="cuda")

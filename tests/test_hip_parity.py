@@ -765,3 +765,103 @@ def test_graphed_step_equals_eager(hip):
     np.testing.assert_allclose(losses2, losses1[2:], rtol=1e-5, atol=1e-6)
     for p1, p2 in zip(m1.parameters(), m2.parameters()):
         np.testing.assert_allclose(host(p2.data), host(p1.data), rtol=1e-5, atol=1e-6)
+
+
+# =============================================================================================================
+# LeakyReLU / Sigmoid / MaxPool2d / BatchNorm2d / MSELoss and the full config-5 classifier step
+# =============================================================================================================
+def test_vision_ops_golden(hip, golden):
+    g = golden("vision_ops")
+    import neunet_hip.nn as nn
+    X = g["X"]
+    for name, mod in [("leaky", nn.LeakyReLU(0.01)), ("sigmoid", nn.Sigmoid())]:
+        x = T(hip, X)
+        y = mod(x)
+        np.testing.assert_allclose(host(y.data), g[f"{name}_Y"], rtol=1e-5, atol=1e-6)
+        y.backward(g[f"{name}_dY"])
+        np.testing.assert_allclose(host(x.grad), g[f"{name}_dX"], rtol=1e-5, atol=1e-6)
+    for tag in ("pool22", "pool32p1", "pool21_overlap"):
+        ks, st, pad = [int(v) for v in g[f"{tag}_cfg"]]
+        x = T(hip, X)
+        y = nn.MaxPool2d(ks, st, pad)(x)
+        np.testing.assert_array_equal(host(y.data), g[f"{tag}_Y"])
+        y.backward(g[f"{tag}_dY"])
+        np.testing.assert_allclose(host(x.grad), g[f"{tag}_dX"], rtol=1e-6, atol=1e-6)
+    bn = nn.BatchNorm2d(3)
+    bn.weight.data.copy_(dev(g["bn_w"]))
+    bn.bias.data.copy_(dev(g["bn_b"]))
+    x = T(hip, X)
+    y = bn(x)
+    np.testing.assert_allclose(host(y.data), g["bn_Y"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(host(bn.running_mean.data), g["bn_rm"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(host(bn.running_var.data), g["bn_rv"], rtol=1e-5, atol=1e-6)
+    y.backward(g["bn_dY"])
+    np.testing.assert_allclose(host(x.grad), g["bn_dX"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(host(bn.weight.grad), g["bn_dw"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(host(bn.bias.grad), g["bn_db"], rtol=1e-5, atol=1e-5)
+    bn.eval()
+    np.testing.assert_allclose(host(bn(T(hip, X)).data), g["bn_Yeval"], rtol=1e-5, atol=1e-5)
+    bn2 = nn.BatchNorm2d(3, affine=False)
+    x = T(hip, X)
+    y = bn2(x)
+    np.testing.assert_allclose(host(y.data), g["bn_noaffine_Y"], rtol=1e-5, atol=1e-5)
+    y.backward(g["bn_noaffine_dY"])
+    np.testing.assert_allclose(host(x.grad), g["bn_noaffine_dX"], rtol=1e-4, atol=1e-5)
+    p = T(hip, g["mse_P"])
+    loss = nn.MSELoss()(p, T(hip, g["mse_T"], requires_grad=False))
+    assert abs(loss.item() - float(g["mse_loss"])) < 1e-6
+    loss.backward()
+    np.testing.assert_allclose(host(p.grad), g["mse_dP"], rtol=1e-5, atol=1e-7)
+
+
+def test_conv_classifier_golden(hip, golden):
+    """Config-5 model (notebook cell 2) on the HIP path vs the REAL reference: step-1 outputs / loss / every gradient
+    tight; step 2 (after one Adam update) to the +-lr noise level explained in test_oracle_golden.py."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import conv_classifier
+    import neunet_hip.nn as nn
+    from neunet_hip.optim import Adam
+    g = golden("conv_classifier")
+    model = conv_classifier.Conv2dClassifier()
+    params = model.parameters()
+    assert len(params) == int(g["n_params"])
+    for i, p in enumerate(params):
+        assert tuple(p.shape) == g[f"p{i}"].shape
+        p.data.copy_(dev(g[f"p{i}"]))
+    opt = Adam(params, lr=0.001)
+    for s in range(2):
+        opt.zero_grad()
+        out = model(T(hip, g["X"][s]))
+        loss = nn.MSELoss()(out, T(hip, g["T"][s], requires_grad=False))
+        loss.backward()
+        assert abs(loss.item() - g["losses"][s]) < (1e-6 if s == 0 else 2e-4)
+        np.testing.assert_allclose(host(out.data), g["outs"][s], rtol=1e-4, atol=1e-5 if s == 0 else 1e-3)
+        if s == 0:
+            for i, p in enumerate(params):
+                np.testing.assert_allclose(host(p.grad), g[f"g{i}"], rtol=1e-3, atol=1e-6, err_msg=f"grad {i}")
+        opt.step()
+    np.testing.assert_allclose(host(model.bnorm.running_mean.data), g["rm"], rtol=1e-3, atol=2e-3)
+
+
+def test_conv_classifier_c5_batch_vs_oracle(hip):
+    """Batch 256 (BASELINE config 5) forward+backward against the oracle."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import conv_classifier
+    import neunet_hip.nn as nn
+    rng = np.random.default_rng(1005)
+    model = conv_classifier.Conv2dClassifier()
+    params = model.parameters()
+    model.conv1.bias.data.copy_(dev(rng.uniform(-0.1, 0.1, 8).astype(np.float32)))
+    ref = O.ConvClassifier([host(p.data) for p in params])
+    X = rng.uniform(-1, 1, (256, 1, 28, 28)).astype(np.float32)
+    Tt = np.eye(10, dtype=np.float32)[rng.integers(0, 10, 256)]
+    out = model(T(hip, X))
+    loss = nn.MSELoss()(out, T(hip, Tt, requires_grad=False))
+    loss.backward()
+    rl, ro, rg = ref.forward_backward(X, Tt)
+    assert abs(loss.item() - float(rl)) < 1e-5
+    np.testing.assert_allclose(host(out.data), ro, rtol=1e-4, atol=1e-5)
+    for i, p in enumerate(params):
+        np.testing.assert_allclose(host(p.grad), rg[i], rtol=2e-3, atol=2e-6, err_msg=f"grad {i}")

@@ -199,3 +199,63 @@ def test_gpt_tiny_step(golden):
         np.testing.assert_allclose(gl["norm2"], g[f"g{b + 21}"], rtol=1e-3, atol=1e-6)
     np.testing.assert_allclose(grads["Wout"], g[f"g{out_idx}"], rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(grads["bout"], g[f"g{out_idx + 1}"], rtol=1e-4, atol=1e-6)
+
+
+# ---- the remaining conv-classifier ops and the full config-5 step -----------------------------------
+def test_vision_ops(golden):
+    g = golden("vision_ops")
+    X = g["X"]
+    f = O.leaky_relu_forward(X)
+    np.testing.assert_allclose(f, g["leaky_Y"], **TOL)
+    np.testing.assert_allclose(O.leaky_relu_backward(f, g["leaky_dY"]), g["leaky_dX"], **TOL)
+    f = O.sigmoid_forward(X)
+    np.testing.assert_allclose(f, g["sigmoid_Y"], **TOL)
+    np.testing.assert_allclose(O.sigmoid_backward(f, g["sigmoid_dY"]), g["sigmoid_dX"], **TOL)
+    for tag in ("pool22", "pool32p1", "pool21_overlap"):
+        ks, st, pad = [int(v) for v in g[f"{tag}_cfg"]]
+        y, arg = O.maxpool2d_forward(X, (ks, ks), (st, st), (pad, pad))
+        np.testing.assert_array_equal(y, g[f"{tag}_Y"])
+        np.testing.assert_allclose(O.maxpool2d_backward(X.shape, arg, g[f"{tag}_dY"], (ks, ks), (st, st), (pad, pad)),
+                                   g[f"{tag}_dX"], rtol=1e-6, atol=1e-6)
+    rm0, rv0 = np.zeros((1, 3), np.float32), np.ones((1, 3), np.float32)
+    y, cache, rm, rv = O.batchnorm2d_forward(X, g["bn_w"], g["bn_b"], rm0, rv0)
+    np.testing.assert_allclose(y, g["bn_Y"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(rm, g["bn_rm"], **TOL)
+    np.testing.assert_allclose(rv, g["bn_rv"], **TOL)
+    dX, dw, db = O.batchnorm2d_backward(X, g["bn_w"], cache, g["bn_dY"])
+    np.testing.assert_allclose(dX, g["bn_dX"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(dw, g["bn_dw"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(db, g["bn_db"], rtol=1e-5, atol=1e-5)
+    ye, _, _, _ = O.batchnorm2d_forward(X, g["bn_w"], g["bn_b"], rm, rv, training=False)
+    np.testing.assert_allclose(ye, g["bn_Yeval"], rtol=1e-5, atol=1e-5)
+    y, cache, _, _ = O.batchnorm2d_forward(X, None, None, rm0, rv0)
+    np.testing.assert_allclose(y, g["bn_noaffine_Y"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(O.batchnorm2d_backward(X, None, cache, g["bn_noaffine_dY"])[0], g["bn_noaffine_dX"],
+                               rtol=1e-4, atol=1e-5)
+    loss, dP = O.mse_forward_backward(g["mse_P"], g["mse_T"])
+    assert abs(float(loss) - float(g["mse_loss"])) < 1e-6
+    np.testing.assert_allclose(dP, g["mse_dP"], **TOL)
+
+
+def test_conv_classifier_step(golden):
+    g = golden("conv_classifier")
+    n = int(g["n_params"])
+    model = O.ConvClassifier([g[f"p{i}"] for i in range(n)])
+    m = [np.zeros_like(a) for a in model.p]
+    v = [np.zeros_like(a) for a in model.p]
+    for s in range(2):
+        loss, out, grads = model.forward_backward(g["X"][s], g["T"][s])
+        # step 2 runs on parameters that went through one Adam step: Adam's first update is lr*sign(g), so
+        # gradients at rounding-noise level (e.g. parts of conv biases) move by a full +-lr in either
+        # implementation and the second forward agrees only to ~lr
+        assert abs(float(loss) - g["losses"][s]) < (1e-6 if s == 0 else 2e-4)
+        np.testing.assert_allclose(out, g["outs"][s], rtol=1e-4, atol=1e-5 if s == 0 else 1e-3)
+        if s == 0:
+            for i in range(n):
+                np.testing.assert_allclose(grads[i], g[f"g{i}"], rtol=1e-3, atol=1e-6, err_msg=f"grad {i}")
+        for i in range(n):
+            m[i], v[i] = O.adam_step(model.p[i], grads[i].astype(np.float32), m[i], v[i], s + 1, 1e-3)
+    # running statistics after step 2 inherit the same +-lr noise through the conv biases (a bias shift moves the
+    # channel mean one-for-one); step-1 statistics are pinned exactly by test_vision_ops
+    np.testing.assert_allclose(model.rm, g["rm"], rtol=1e-3, atol=2e-3)
+    np.testing.assert_allclose(model.rv, g["rv"], rtol=1e-3, atol=2e-3)

@@ -344,6 +344,80 @@ def gen_gpt():
     save("gpt_tiny", **arrs)
 
 
+# --------------------------------------------------------------------------- conv classifier (config 5)
+def gen_vision():
+    import json
+    rng = np.random.default_rng(19)
+    X = (rng.standard_normal((2, 3, 7, 6)) * 2).astype(F32)
+    X[0, 0, 0, 0] = X[0, 0, 0, 1] = 3.5            # a tie inside one pooling window -> first maximum wins
+    arrs = {"X": X}
+    for name, mod in [("leaky", nn.LeakyReLU(0.01)), ("sigmoid", nn.Sigmoid())]:
+        x = T(X)
+        y = mod(x)
+        dY = rng.standard_normal(y.shape).astype(F32)
+        y.backward(dY)
+        arrs.update({f"{name}_Y": y.data, f"{name}_dY": dY, f"{name}_dX": x.grad})
+    for tag, ks, st, pad in [("pool22", 2, 2, 0), ("pool32p1", 3, 2, 1), ("pool21_overlap", 2, 1, 0)]:
+        x = T(X)
+        y = nn.MaxPool2d(ks, st, pad)(x)
+        dY = rng.standard_normal(y.shape).astype(F32)
+        y.backward(dY)
+        arrs.update({f"{tag}_Y": y.data, f"{tag}_dY": dY, f"{tag}_dX": x.grad, f"{tag}_cfg": np.array([ks, st, pad])})
+    for tag, affine in [("bn", True), ("bn_noaffine", False)]:
+        bn = nn.BatchNorm2d(3, affine=affine)
+        if affine:
+            bn.weight.data[...] = rng.uniform(0.5, 1.5, (1, 3))
+            bn.bias.data[...] = rng.uniform(-0.5, 0.5, (1, 3))
+            arrs[f"{tag}_w"], arrs[f"{tag}_b"] = bn.weight.data.copy(), bn.bias.data.copy()
+        x = T(X)
+        y = bn(x)
+        dY = rng.standard_normal(y.shape).astype(F32)
+        y.backward(dY)
+        arrs.update({f"{tag}_Y": y.data, f"{tag}_dY": dY, f"{tag}_dX": x.grad, f"{tag}_rm": bn.running_mean.data,
+                     f"{tag}_rv": bn.running_var.data})
+        if affine:
+            arrs.update({f"{tag}_dw": bn.weight.grad, f"{tag}_db": bn.bias.grad})
+            bn.eval()
+            arrs[f"{tag}_Yeval"] = bn(T(X)).data
+    P_, T_ = rng.uniform(0, 1, (5, 10)).astype(F32), rng.uniform(0, 1, (5, 10)).astype(F32)
+    p = T(P_)
+    loss = nn.MSELoss()(p, T(T_, requires_grad=False))
+    loss.backward()
+    arrs.update(mse_P=P_, mse_T=T_, mse_loss=np.float64(loss.data), mse_dP=p.grad)
+    save("vision_ops", **arrs)
+
+    # full classifier: exec the notebook's own class (cell 2 up to the instantiation), batch 4, 2 Adam steps
+    nb = json.load(open("/root/reference/examples/convolutional_digits_classifier.ipynb"))
+    src = "".join(nb["cells"][2]["source"]).split("classifier = Conv2dClassifier()")[0].replace('device = "cuda"', 'device = "cpu"')
+    ns = {"nn": nn, "nnet": neunet, "np": np}
+    exec(src, ns)
+    model = ns["Conv2dClassifier"]()
+    params = model.parameters()
+    p0 = [q.data.copy() for q in params]
+    opt = Adam(params, lr=0.001)
+    Xb = rng.uniform(-1, 1, (2, 4, 1, 28, 28)).astype(F32)
+    lab = rng.integers(0, 10, (2, 4))
+    Tb = np.zeros((2, 4, 10), F32)
+    for s in range(2):
+        Tb[s, np.arange(4), lab[s]] = 1
+    losses, outs, grads0 = [], [], None
+    for s in range(2):
+        opt.zero_grad()
+        out = model(T(Xb[s]))
+        loss = nn.MSELoss()(out, T(Tb[s], requires_grad=False))
+        loss.backward()
+        if s == 0:
+            grads0 = [q.grad.copy() for q in params]
+        opt.step()
+        losses.append(float(loss.data))
+        outs.append(out.data.copy())
+    arrs = dict(X=Xb, T=Tb, losses=np.array(losses), outs=np.stack(outs), n_params=np.int64(len(params)),
+                rm=model.bnorm.running_mean.data, rv=model.bnorm.running_var.data)
+    for i, (a, g, q) in enumerate(zip(p0, grads0, params)):
+        arrs[f"p{i}"], arrs[f"g{i}"], arrs[f"pf{i}"] = a, g, q.data
+    save("conv_classifier", **arrs)
+
+
 if __name__ == "__main__":
     gen_linear()
     gen_activations()
@@ -354,3 +428,4 @@ if __name__ == "__main__":
     gen_linear_swish()
     gen_mlp()
     gen_gpt()
+    gen_vision()
