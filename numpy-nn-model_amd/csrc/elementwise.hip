@@ -199,6 +199,16 @@ __global__ __launch_bounds__(EW_THREADS) void swiglu_bwd_kernel(float* __restric
     }
 }
 
+struct FillF {
+    float v;
+    __device__ float operator()(float) const { return v; }
+};
+int fill_f32(float* p, float v, int64_t n, hipStream_t st) {
+    if (n <= 0) return 0;
+    if (!p) { set_last_error("fill_f32: null pointer"); return NNHIP_EINVAL; }
+    return launch_map1(p, p, n, FillF{v}, st, "fill");
+}
+
 // internal: used by linear.hip for dZ = dY * swish'(z), in place over z
 int swish_backward_inplace(float* z_inout, const float* dY, float beta, int64_t n, hipStream_t st) {
     return launch_map2(z_inout, dY, z_inout, n, SwishB{beta}, st, "swish_backward(inplace)");

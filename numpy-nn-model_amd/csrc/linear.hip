@@ -10,11 +10,17 @@ int gemm_f32(const float* A, const float* B, float* C, const float* bias, float*
              hipStream_t st);
 int colsum(const float* X, int64_t rows, int64_t cols, int64_t ld, float* out, hipStream_t st);
 int swish_backward_inplace(float* z_inout, const float* dY, float beta, int64_t n, hipStream_t st);
+int fill_f32(float* p, float v, int64_t n, hipStream_t st);
 enum { ACT_NONE = 0, ACT_SWISH = 1, ACT_RELU = 2 };
 
 static int linear_backward(const float* X, const float* W, const float* dO, float* dX, float* dW,
                            float* db, int64_t rows, int64_t in, int64_t out, hipStream_t st) {
     int rc = 0;
+    if (rows == 0) {  // empty batch: sums over nothing are zero (X / dO / dX may be null pointers of empty arrays)
+        if (dW) rc = fill_f32(dW, 0.f, out * in, st);
+        if (!rc && db) rc = fill_f32(db, 0.f, out, st);
+        return rc;
+    }
     // dX[rows,in] = dO[rows,out] * W[out,in]         A k-major (k = out), B outer-major
     if (dX) rc = gemm_f32(dO, W, dX, nullptr, nullptr, rows, in, out, out, in, in, true, false, 1, 0, 0, 0, ACT_NONE, 1.f, st);
     if (rc) return rc;
@@ -31,6 +37,7 @@ using namespace nnhip;
 
 static int check_linear(const char* fn, const void* X, const void* W, int64_t rows, int64_t in, int64_t out) {
     NNHIP_CHECK_ARG(rows >= 0 && in >= 0 && out >= 0, NNHIP_EINVAL, "%s: negative size", fn);
+    if (rows == 0) return 0;  // empty batch: pointers of empty arrays may be null
     NNHIP_CHECK_ARG(X && W, NNHIP_EINVAL, "%s: null X/W", fn);
     NNHIP_CHECK_ARG(aligned4(X) && aligned4(W), NNHIP_EALIGN, "%s: misaligned pointer", fn);
     return 0;
@@ -40,6 +47,7 @@ extern "C" int nnhipLinearModuleForward(const float* X, const float* W, const fl
                                         int64_t rows, int64_t in_features, int64_t out_features,
                                         nnhipStream_t stream) {
     if (int rc = check_linear("nnhipLinearModuleForward", X, W, rows, in_features, out_features)) return rc;
+    if (rows == 0) return 0;
     NNHIP_CHECK_ARG(O != nullptr, NNHIP_EINVAL, "nnhipLinearModuleForward: null output");
     return gemm_f32(X, W, O, b, nullptr, rows, out_features, in_features, in_features, in_features,
                     out_features, true, true, 1, 0, 0, 0, ACT_NONE, 1.f, (hipStream_t)stream);
@@ -49,7 +57,7 @@ extern "C" int nnhipLinearModuleBackward(const float* X, const float* W, const f
                                          float* dW, float* db, int64_t rows, int64_t in_features,
                                          int64_t out_features, nnhipStream_t stream) {
     if (int rc = check_linear("nnhipLinearModuleBackward", X, W, rows, in_features, out_features)) return rc;
-    NNHIP_CHECK_ARG(dO != nullptr, NNHIP_EINVAL, "nnhipLinearModuleBackward: null dO");
+    NNHIP_CHECK_ARG(rows == 0 || dO != nullptr, NNHIP_EINVAL, "nnhipLinearModuleBackward: null dO");
     return linear_backward(X, W, dO, dX, dW, db, rows, in_features, out_features, (hipStream_t)stream);
 }
 
@@ -57,6 +65,7 @@ extern "C" int nnhipLinearSwishForward(const float* X, const float* W, const flo
                                        float* preact, int64_t M, int64_t K, int64_t N, float swish_beta,
                                        int save_preactivation, nnhipStream_t stream) {
     if (int rc = check_linear("nnhipLinearSwishForward", X, W, M, K, N)) return rc;
+    if (M == 0) return 0;
     NNHIP_CHECK_ARG(O != nullptr, NNHIP_EINVAL, "nnhipLinearSwishForward: null output");
     NNHIP_CHECK_ARG(!save_preactivation || preact, NNHIP_EINVAL,
                     "nnhipLinearSwishForward: save_preactivation set but preact is null");
@@ -69,8 +78,9 @@ extern "C" int nnhipLinearSwishBackward(const float* X, const float* W, const fl
                                         int64_t N, float swish_beta, int recompute_preactivation,
                                         nnhipStream_t stream) {
     if (int rc = check_linear("nnhipLinearSwishBackward", X, W, M, K, N)) return rc;
-    NNHIP_CHECK_ARG(dO && tmp, NNHIP_EINVAL, "nnhipLinearSwishBackward: null dO/tmp");
     hipStream_t st = (hipStream_t)stream;
+    if (M == 0) return linear_backward(X, W, dO, dX, dW, db, M, K, N, st);
+    NNHIP_CHECK_ARG(dO && tmp, NNHIP_EINVAL, "nnhipLinearSwishBackward: null dO/tmp");
     int rc = 0;
     if (recompute_preactivation)  // z = X W^T + b into tmp
         rc = gemm_f32(X, W, tmp, b, nullptr, M, N, K, K, K, N, true, true, 1, 0, 0, 0, ACT_NONE, 1.f, st);

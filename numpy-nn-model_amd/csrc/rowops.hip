@@ -611,9 +611,9 @@ using namespace nnhip;
 // ---- Softmax ------------------------------------------------------------------------------------
 extern "C" int nnhipSoftmaxForward(float* out, const float* in, int64_t num_slices,
                                    int64_t slice_size, int64_t stride, nnhipStream_t s) {
-    NNHIP_CHECK_ARG(num_slices >= 0 && slice_size >= 0 && stride >= 1, NNHIP_EINVAL,
-                    "nnhipSoftmaxForward: bad sizes");
+    NNHIP_CHECK_ARG(num_slices >= 0 && slice_size >= 0, NNHIP_EINVAL, "nnhipSoftmaxForward: negative size");
     if (num_slices == 0 || slice_size == 0) return 0;
+    NNHIP_CHECK_ARG(stride >= 1, NNHIP_EINVAL, "nnhipSoftmaxForward: stride must be >= 1");
     NNHIP_CHECK_ARG(out && in, NNHIP_EINVAL, "nnhipSoftmaxForward: null pointer");
     hipStream_t st = (hipStream_t)s;
     if (stride != 1) {
@@ -631,9 +631,9 @@ extern "C" int nnhipSoftmaxForward(float* out, const float* in, int64_t num_slic
 
 extern "C" int nnhipSoftmaxBackward(float* dX, const float* dY, const float* Y, int64_t num_slices,
                                     int64_t slice_size, int64_t stride, nnhipStream_t s) {
-    NNHIP_CHECK_ARG(num_slices >= 0 && slice_size >= 0 && stride >= 1, NNHIP_EINVAL,
-                    "nnhipSoftmaxBackward: bad sizes");
+    NNHIP_CHECK_ARG(num_slices >= 0 && slice_size >= 0, NNHIP_EINVAL, "nnhipSoftmaxBackward: negative size");
     if (num_slices == 0 || slice_size == 0) return 0;
+    NNHIP_CHECK_ARG(stride >= 1, NNHIP_EINVAL, "nnhipSoftmaxBackward: stride must be >= 1");
     NNHIP_CHECK_ARG(dX && dY && Y, NNHIP_EINVAL, "nnhipSoftmaxBackward: null pointer");
     hipStream_t st = (hipStream_t)s;
     if (stride != 1) {

@@ -865,3 +865,84 @@ def test_conv_classifier_c5_batch_vs_oracle(hip):
     np.testing.assert_allclose(host(out.data), ro, rtol=1e-4, atol=1e-5)
     for i, p in enumerate(params):
         np.testing.assert_allclose(host(p.grad), rg[i], rtol=2e-3, atol=2e-6, err_msg=f"grad {i}")
+
+
+# =============================================================================================================
+# Edge cases: empty inputs, > 2^31 elements (64-bit indexing), NULL-skipped outputs, error statuses on the GPU
+# =============================================================================================================
+def test_empty_inputs(hip):
+    import neunet_hip.nn as nn
+    lin = nn.Linear(8, 4)
+    x = T(hip, np.zeros((0, 8), np.float32))
+    y = lin(x)
+    assert y.shape == (0, 4)
+    y.backward(np.zeros((0, 4), np.float32))
+    assert float(lin.weight.grad.abs().sum()) == 0.0 and tuple(lin.weight.grad.shape) == (4, 8)
+    assert float(lin.bias.grad.abs().sum()) == 0.0
+    for mod in (nn.Swish(), nn.ReLU(), nn.Softmax(axis=-1), nn.RMSNorm(8)):
+        out = mod(T(hip, np.zeros((0, 8), np.float32)))
+        assert out.shape == (0, 8)
+
+
+def test_more_than_2_31_elements(hip):
+    """64-bit indexing: elementwise over 2^31 + 4096 + 3 floats (the reference's `int size` would overflow)."""
+    from neunet_hip.nn.experimental.activations import hip_swish_forward
+    n = (1 << 31) + 4096 + 3
+    x = torch.empty(n, dtype=torch.float32, device="cuda")
+    x.fill_(0.5)
+    idx = torch.tensor([0, 1, (1 << 31) - 1, 1 << 31, (1 << 31) + 4097, n - 1], device="cuda")
+    vals = torch.tensor([-2.0, 3.0, 1.5, -0.25, 4.0, -1.0], device="cuda")
+    x[idx] = vals
+    y = torch.empty_like(x)
+    hip_swish_forward(x, y, 1.0)
+    got = host(y[idx])
+    np.testing.assert_allclose(got, O.swish_forward(host(vals), 1.0), rtol=1e-6, atol=1e-7)
+    mid = host(y[(1 << 31) - 8: (1 << 31) + 8])
+    assert np.isfinite(mid).all()
+    del x, y
+
+
+def test_null_outputs_are_skipped(hip):
+    """dX / dW / db may be NULL in nnhipLinearModuleBackward: only the requested gradients are produced."""
+    from neunet_hip._lib import call_hip_function, get_current_stream_ptr
+    rng = np.random.default_rng(1)
+    X, W, dO = [dev(rng.standard_normal(s).astype(np.float32)) for s in ((96, 40), (24, 40), (96, 24))]
+    dW = torch.full((24, 40), 7.0, device="cuda")
+    call_hip_function("nnhipLinearModuleBackward", X, W, dO, None, dW, None, 96, 40, 24, get_current_stream_ptr())
+    np.testing.assert_allclose(host(dW), host(dO).T @ host(X), rtol=1e-4, atol=1e-4)
+
+
+def test_error_status_not_exit(hip):
+    from neunet_hip._lib import NeunetHipError, call_hip_function, get_current_stream_ptr
+    a = torch.zeros(16, device="cuda")
+    with pytest.raises(NeunetHipError, match="multiple of hidden"):
+        call_hip_function("nnhipFusedSwishAndMul", a, a, 1.0, 3, 16, get_current_stream_ptr())
+    with pytest.raises(NeunetHipError, match="16384"):
+        call_hip_function("nnhipRMSNormForward", a, a, None, a, a, None, 1, 20000, 1e-6, get_current_stream_ptr())
+    # the library is still usable afterwards
+    call_hip_function("nnhipScale", a, 2.0, 16, get_current_stream_ptr())
+
+
+def test_dropout_mask_and_rng(hip):
+    """Dropout: identity at p=0/eval; an injected mask reproduces dropout.py:17-37; the device RNG keeps ~(1-p)."""
+    import neunet_hip.nn as nn
+    rng = np.random.default_rng(2)
+    X = rng.standard_normal((64, 256)).astype(np.float32)
+    d0 = nn.Dropout(0.0)
+    x = T(hip, X)
+    assert d0(x) is x
+    d = nn.Dropout(0.25)
+    mask = (rng.random(X.shape) >= 0.25).astype(np.float32) / 0.75
+    x = T(hip, X)
+    y = d(x, mask=dev(mask))
+    np.testing.assert_allclose(host(y.data), X * mask, rtol=1e-6, atol=1e-7)
+    g = rng.standard_normal(X.shape).astype(np.float32)
+    y.backward(g)
+    np.testing.assert_allclose(host(x.grad), g * mask, rtol=1e-6, atol=1e-7)
+    y2 = d(T(hip, np.ones_like(X)))
+    kept = float((y2.data != 0).float().mean())
+    assert abs(kept - 0.75) < 0.03
+    assert abs(float(y2.data.max()) - 1 / 0.75) < 1e-6
+    d.eval()
+    x = T(hip, X)
+    assert d(x) is x
