@@ -38,8 +38,9 @@ class PositionwiseFeedForward(nn.Module):
 
 
 class DecoderLayer(nn.Module):
-    def __init__(self, d_model, n_heads, d_ff, dropout=0.0, fused=True):
+    def __init__(self, d_model, n_heads, d_ff, dropout=0.0, fused=True, fused_attention=True):
         super().__init__()
+        self.need_weights = not fused_attention   # fused flash-style attention never materialises the map
         self.self_attn = nn.MultiHeadAttention(d_model, n_heads, dropout)
         self.cross_attn = nn.MultiHeadAttention(d_model, n_heads, dropout)   # constructed, never called
         self.ffn = PositionwiseFeedForward(d_model, d_ff, dropout, fused)
@@ -49,7 +50,7 @@ class DecoderLayer(nn.Module):
 
     def forward(self, x, key_valid):
         nx1 = self.norm1(x)
-        _x, attn = self.self_attn(nx1, nx1, nx1, key_valid, causal=True)
+        _x, attn = self.self_attn(nx1, nx1, nx1, key_valid, causal=True, need_weights=self.need_weights)
         x = x + self.dropout(_x)
         nx2 = self.norm2(x)
         _x = self.ffn(nx2)
@@ -58,11 +59,12 @@ class DecoderLayer(nn.Module):
 
 
 class Decoder(nn.Module):
-    def __init__(self, tgt_vocab_size, d_model, n_heads, d_ff, n_layers, dropout=0.0, max_len=5000, fused=True):
+    def __init__(self, tgt_vocab_size, d_model, n_heads, d_ff, n_layers, dropout=0.0, max_len=5000, fused=True,
+                 fused_attention=True):
         super().__init__()
         self.token_embedding = nn.Embedding(tgt_vocab_size, d_model)
         self.position_embedding = nn.PositionalEncoding(d_model, max_len)
-        self.layers = nn.ModuleList([DecoderLayer(d_model, n_heads, d_ff, dropout, fused) for _ in range(n_layers)])
+        self.layers = nn.ModuleList([DecoderLayer(d_model, n_heads, d_ff, dropout, fused, fused_attention) for _ in range(n_layers)])
         self.fc_out = nn.Linear(d_model, tgt_vocab_size)
         self.dropout = nn.Dropout(dropout)
         self.scale = math.sqrt(d_model)
@@ -92,8 +94,14 @@ class GPT(nn.Module):
         return self.decoder(ids, key_valid)
 
 
-def build_gpt(vocab=15000, d_model=512, n_heads=8, d_ff=2048, n_layers=6, pad_idx=0, max_len=1024, fused=True):
-    dec = Decoder(vocab, d_model, n_heads, d_ff, n_layers, dropout=0.0, max_len=max_len, fused=fused)
+def build_gpt(vocab=15000, d_model=512, n_heads=8, d_ff=2048, n_layers=6, pad_idx=0, max_len=1024, fused=True,
+              fused_attention=None):
+    """fused: Linear->Swish epilogue fusion in the FFN.  fused_attention (default = fused): flash-style attention
+    kernels (head_dim 64 only; other head sizes keep the GEMM + masked-softmax path); the model then returns
+    attn=None, which the training loop of cell 12 never reads."""
+    fused_attention = fused if fused_attention is None else fused_attention
+    dec = Decoder(vocab, d_model, n_heads, d_ff, n_layers, dropout=0.0, max_len=max_len, fused=fused,
+                  fused_attention=fused_attention)
     return GPT(dec, pad_idx)
 
 

@@ -1,0 +1,679 @@
+// attention.hip -- fused (flash-style) masked multi-head attention for gfx950, fp32 MFMA, head dim 64.
+// Semantics = examples/gpt.ipynb cell 2:  scores = QK^T / sqrt(d_model); scores = where(mask == 0, -1e9, scores);
+// attn = Softmax(-1)(scores); ctx = attn V -- with mask = key padding (key_valid) AND causal, exactly what
+// nnhipMaskedSoftmaxForward implements unfused.  The [B,H,T,T] score / attention matrices are never written: the
+// forward keeps a running (max, sum) per query row and stores only LSE[B,H,T,2] = (max, log2 sum) in log2 units;
+// the backward recomputes P from it.
+//
+// Register layout trick (all three kernels): every product is arranged so that the softmax axis lands on the
+// LANE index of the 32x32 MFMA accumulator (col = lane & 31) and the other axis on the register index:
+//   S^T[key, q] = K Q^T     -> lane <-> query q, registers <-> keys: row max / row sum are in-lane reductions
+//                              plus ONE cross-half exchange (lanes l and l+32 hold the two key halves);
+//   O^T[d, q]  += V^T P^T   -> the B operand of step e is exactly accumulator register e of P^T (lanes 0-31
+//                              carry key (e&3)+8(e>>2), lanes 32-63 that key + 4), so P feeds the next MFMA
+//                              straight from registers, and the per-query rescale factor is per-lane.
+// The MFMA phases read their A operands from LDS one step ahead of the MFMAs that consume them and pin that issue
+// order with sched_group_barrier (left alone, hipcc re-uses one register pair and waits lgkmcnt(0) before every
+// MFMA pair -- measured 2.3x off the MFMA bound).  K/V (Q/dO) tiles are fetched into registers one tile ahead.
+// Q, K, V, ctx live in the [B, T, H*64] layout of the projections (row stride D = H*64).
+#include <math.h>
+
+#include "common.h"
+
+namespace nnhip {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int AT_DH = 64;    // head dim
+constexpr int AT_BQ = 128;   // queries (keys in the dK/dV kernel) per block: 4 waves x 32
+constexpr int AT_BK = 64;    // keys (queries in the dK/dV kernel) per tile
+constexpr int AT_KLD = 68;   // tile row stride (floats): conflict-free ds_read_b128 of 4 consecutive d
+constexpr float AT_MASKED = -1e9f;
+constexpr float AT_LOG2E = 1.4426950408889634f;
+constexpr float AT_MASKED2 = AT_MASKED * AT_LOG2E;   // the -1e9 fill in log2 units (scores are carried as s*log2(e))
+
+#define AT_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#define AT_SCHED_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, (n), 0)
+#define AT_SCHED_DSRD(n) __builtin_amdgcn_sched_group_barrier(0x100, (n), 0)
+
+struct AttnParams {
+    const float* Q; const float* K; const float* V;   // [B, T, D]
+    float* O;                                         // [B, Tq, D]
+    float* LSE;                                       // [B, H, Tq, 2] = (max, log2 sum), log2 units
+    const int32_t* key_valid;                         // [B, Tk] or null
+    int B, H, Tq, Tk;
+    int64_t D;                                        // H * 64
+    float scale;                                      // multiplies QK^T (1/sqrt(d_model))
+    int causal;
+};
+
+struct AttnBwdParams {
+    const float* Q; const float* K; const float* V; const float* dO;   // [B, T, D]
+    const float* LSE; const float* Dsum;                               // [B, H, Tq, 2], [B, H, Tq]
+    float* dQ; float* dK; float* dV;                                   // [B, T, D]
+    const int32_t* key_valid;
+    int B, H, Tq, Tk;
+    int64_t D;
+    float scale;
+    int causal;
+};
+
+// row (within a 32-row tile) carried by accumulator register e, for half-wave lh
+__device__ __forceinline__ int acc_row(int e, int lh) { return (e & 3) + 8 * (e >> 2) + 4 * lh; }
+
+// A [64 x 64] tile staged through registers: fetch early (the loads stay in flight during the MFMA phase), commit
+// to LDS (row stride LD) at the top of the next iteration.  Rows past nrows are zero-filled.
+struct TileRegs { float4 v[4]; };
+__device__ __forceinline__ void tile_fetch(TileRegs& r, const float* __restrict__ base, int64_t D, int row0, int nrows, int tid) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int idx = tid + 256 * p;
+        const int rr = idx >> 4, c4 = (idx & 15) * 4;
+        r.v[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row0 + rr < nrows) r.v[p] = *reinterpret_cast<const float4*>(base + (int64_t)(row0 + rr) * D + c4);
+    }
+}
+template <int LD>
+__device__ __forceinline__ void tile_commit(float* __restrict__ S, const TileRegs& r, int tid) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int idx = tid + 256 * p;
+        *reinterpret_cast<float4*>(&S[(idx >> 4) * LD + (idx & 15) * 4]) = r.v[p];
+    }
+}
+// padding flag of key kv0 + lane (1 = real token); the wave ballots it into a 64-bit mask per tile
+__device__ __forceinline__ int key_flag(const int32_t* __restrict__ kv, int kv0, int Tk, int lane) {
+    if (!kv) return 1;
+    return kv0 + lane < Tk ? kv[kv0 + lane] : 0;
+}
+
+// first key index of batch b that is not padding (block-wide min; Tk if none) -- decides where causal skipping is legal:
+// a query q has a visible unmasked key iff first_valid <= q + shift; a row without one is uniform over ALL keys.
+__device__ __forceinline__ int first_valid_key(const int32_t* __restrict__ kv, int Tk, int tid, int* sh) {
+    if (!kv) return 0;
+    int best = Tk;
+    for (int j = tid; j < Tk; j += 256)
+        if (kv[j] != 0) { best = j; break; }
+    if (tid == 0) *sh = Tk;
+    __syncthreads();
+    atomicMin(sh, best);
+    __syncthreads();
+    return *sh;
+}
+
+// Block -> (batch*head, tile block) map.  Hardware deals consecutive blockIdx round-robin over the 8 XCDs, so a plain
+// (bh, blk) = (id / nblk, id % nblk) order puts every light causal block on the even XCDs and every heavy one on the
+// odd XCDs (measured: causal ran as slow as non-causal).  Here the blocks of one (b,h) stay on ONE XCD (they share
+// K/V in its L2) and each XCD walks them heaviest first.  Grid = ceil(BH/8)*8*nblk; returns false for padding blocks.
+__device__ __forceinline__ bool map_block(int id, int BH, int nblk, bool heavy_is_high, int& bh, int& blk) {
+    const int x = id & 7, r = id >> 3;
+    const int j = r % nblk;
+    bh = (r / nblk) * 8 + x;
+    blk = heavy_is_high ? nblk - 1 - j : j;
+    return bh < BH;
+}
+__host__ inline unsigned mapped_grid(int64_t BH, int64_t nblk) { return (unsigned)(ceil_div(BH, 8) * 8 * nblk); }
+
+// ---- MFMA phases -------------------------------------------------------------------------------------------------
+// accA += TA_rows . fA^T and accB += TB_rows . fB^T (64 MFMAs): the A operands are 32 rows of a k-major LDS tile
+// (ta / tb = this lane's row pointer, &T[(r0 + l31) * AT_KLD + 4 * lh]), the B operands per-lane register fragments
+// f[g][j] = X[lane's row][8g + 4lh + j].  One ds_read_b128 per product per g, issued one g ahead of its 4 MFMAs.
+__device__ __forceinline__ void mma2_rows(f32x16& accA, const float* __restrict__ ta, const float (&fA)[8][4],
+                                          f32x16& accB, const float* __restrict__ tb, const float (&fB)[8][4]) {
+    float4 a[2], c[2];
+    a[0] = *reinterpret_cast<const float4*>(ta);
+    c[0] = *reinterpret_cast<const float4*>(tb);
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        if (g + 1 < 8) {
+            a[(g + 1) & 1] = *reinterpret_cast<const float4*>(ta + 8 * (g + 1));
+            c[(g + 1) & 1] = *reinterpret_cast<const float4*>(tb + 8 * (g + 1));
+        }
+        const float4 x = a[g & 1], y = c[g & 1];
+        accA = AT_MFMA(x.x, fA[g][0], accA);
+        accB = AT_MFMA(y.x, fB[g][0], accB);
+        accA = AT_MFMA(x.y, fA[g][1], accA);
+        accB = AT_MFMA(y.y, fB[g][1], accB);
+        accA = AT_MFMA(x.z, fA[g][2], accA);
+        accB = AT_MFMA(y.z, fB[g][2], accB);
+        accA = AT_MFMA(x.w, fA[g][3], accA);
+        accB = AT_MFMA(y.w, fB[g][3], accB);
+    }
+    AT_SCHED_DSRD(2);
+#pragma unroll
+    for (int g = 0; g < 7; ++g) {
+        AT_SCHED_MFMA(4);
+        AT_SCHED_DSRD(1);
+        AT_SCHED_MFMA(4);
+        AT_SCHED_DSRD(1);
+    }
+    AT_SCHED_MFMA(8);
+}
+
+// acc[dt] += T^T[d = 32dt + l31][row(e)] * P[e] over the 32 rows carried by accumulator P (32 MFMAs): the A operand
+// of step e is T[(r0 + acc_row(e, lh)) * LD + 32dt + l31] (tl = &T[(r0 + 4lh) * LD + l31]), the B operand register e
+// of P.  LDS values are read 4 e-steps ahead.
+template <int LD>
+__device__ __forceinline__ void mma_cols(f32x16 (&acc)[2], const float* __restrict__ tl, const f32x16& P) {
+    float v[2][4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[0][i][0] = tl[((i & 3) + 8 * (i >> 2)) * LD];
+        v[0][i][1] = tl[((i & 3) + 8 * (i >> 2)) * LD + 32];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (c + 1 < 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = 4 * (c + 1) + i;
+                v[(c + 1) & 1][i][0] = tl[((e & 3) + 8 * (e >> 2)) * LD];
+                v[(c + 1) & 1][i][1] = tl[((e & 3) + 8 * (e >> 2)) * LD + 32];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc[0] = AT_MFMA(v[c & 1][i][0], P[4 * c + i], acc[0]);
+            acc[1] = AT_MFMA(v[c & 1][i][1], P[4 * c + i], acc[1]);
+        }
+    }
+    AT_SCHED_DSRD(4);                 // each (d, d+32) pair is one ds_read2_b32
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            AT_SCHED_MFMA(2);
+            AT_SCHED_DSRD(1);
+        }
+    AT_SCHED_MFMA(8);
+}
+
+// two such products sharing the pipeline (64 MFMAs): accA += TA^T PA, accB += TB^T PB; LDS read 2 e-steps ahead.
+template <int LD>
+__device__ __forceinline__ void mma2_cols(f32x16 (&accA)[2], const float* __restrict__ ta, const f32x16& PA,
+                                          f32x16 (&accB)[2], const float* __restrict__ tb, const f32x16& PB) {
+    float va[2][2][2], vb[2][2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        va[0][i][0] = ta[i * LD]; va[0][i][1] = ta[i * LD + 32];
+        vb[0][i][0] = tb[i * LD]; vb[0][i][1] = tb[i * LD + 32];
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        if (c + 1 < 8) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int e = 2 * (c + 1) + i;
+                const int off = ((e & 3) + 8 * (e >> 2)) * LD;
+                va[(c + 1) & 1][i][0] = ta[off]; va[(c + 1) & 1][i][1] = ta[off + 32];
+                vb[(c + 1) & 1][i][0] = tb[off]; vb[(c + 1) & 1][i][1] = tb[off + 32];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            accA[0] = AT_MFMA(va[c & 1][i][0], PA[2 * c + i], accA[0]);
+            accB[0] = AT_MFMA(vb[c & 1][i][0], PB[2 * c + i], accB[0]);
+            accA[1] = AT_MFMA(va[c & 1][i][1], PA[2 * c + i], accA[1]);
+            accB[1] = AT_MFMA(vb[c & 1][i][1], PB[2 * c + i], accB[1]);
+        }
+    }
+    AT_SCHED_DSRD(4);
+#pragma unroll
+    for (int c = 0; c < 7; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            AT_SCHED_MFMA(2);
+            AT_SCHED_DSRD(1);
+        }
+    AT_SCHED_MFMA(8);
+}
+
+// per-wave transposed store: acc[dt][e] = X^T[d = 32dt + acc_row(e, lh)][row = l31]  ->  dst rows of 64 contiguous floats
+__device__ __forceinline__ void store_transposed(float* __restrict__ E, const f32x16 (&acc)[2], float mul, float* __restrict__ dst,
+                                                 int64_t D, int row0, int nrows, int lane) {
+    const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) E[l31 * AT_KLD + dt * 32 + acc_row(e, lh)] = acc[dt][e] * mul;
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the staging area is private to the wave
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int r = it * 4 + (lane >> 4), c4 = (lane & 15) * 4;
+        if (row0 + r < nrows)
+            *reinterpret_cast<float4*>(dst + (int64_t)(row0 + r) * D + c4) = *reinterpret_cast<const float4*>(&E[r * AT_KLD + c4]);
+    }
+}
+
+// =====================================================================================================
+// forward: block = 128 queries (4 waves x 32), loop over 64-key tiles
+// =====================================================================================================
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
+    // one LDS block: [K tile 64 x 68 | V tile 64 x 68]; the epilogue re-uses it as [4 waves][32 q][68]
+    constexpr int SM_FLOATS = 2 * AT_BK * AT_KLD > 4 * 32 * AT_KLD ? 2 * AT_BK * AT_KLD : 4 * 32 * AT_KLD;
+    __shared__ __attribute__((aligned(16))) float smem[SM_FLOATS];
+    __shared__ int sh_fv;
+    float* Ks = smem;
+    float* Vs = smem + AT_BK * AT_KLD;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int qblocks = (p.Tq + AT_BQ - 1) / AT_BQ;
+    int bh, qb;
+    if (!map_block(blockIdx.x, p.B * p.H, qblocks, true, bh, qb)) return;
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int q0 = qb * AT_BQ + wave * 32;           // this wave's first query
+    const int q = q0 + l31;                           // this lane's query
+    const float* Qb = p.Q + ((int64_t)b * p.Tq) * p.D + (int64_t)h * AT_DH;
+    const float* Kb = p.K + ((int64_t)b * p.Tk) * p.D + (int64_t)h * AT_DH;
+    const float* Vb = p.V + ((int64_t)b * p.Tk) * p.D + (int64_t)h * AT_DH;
+    const int32_t* kv = p.key_valid ? p.key_valid + (int64_t)b * p.Tk : nullptr;
+    const int shift = p.Tk - p.Tq;                    // causal: key j visible to query i iff j <= i + shift
+
+    // Q fragments, pre-scaled by scale*log2(e) (softmax runs on exp2): lane (q, lh) holds Q[q][8g + 4lh + j]
+    float qf[8][4];
+    const float qs = p.scale * AT_LOG2E;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < p.Tq) v = *reinterpret_cast<const float4*>(Qb + (int64_t)q * p.D + 8 * g + 4 * lh);
+        qf[g][0] = v.x * qs; qf[g][1] = v.y * qs; qf[g][2] = v.z * qs; qf[g][3] = v.w * qs;
+    }
+
+    // How many key tiles does this block visit?  Causal tiles above the block's last query contribute exp(-1e9-m)=0
+    // and are skipped -- unless some query of the block has NO visible unmasked key: then the reference's softmax is
+    // uniform over ALL keys (every score is the same -1e9) and nothing may be skipped.
+    const int fv = first_valid_key(kv, p.Tk, tid, &sh_fv);
+    int n_tiles = (p.Tk + AT_BK - 1) / AT_BK;
+    const bool skip_ok = p.causal && fv <= qb * AT_BQ + shift;   // every query of the block sees a non-padding key
+    if (skip_ok) {
+        const int last_key = min(p.Tk - 1, qb * AT_BQ + AT_BQ - 1 + shift);
+        n_tiles = last_key < 0 ? 0 : last_key / AT_BK + 1;
+    }
+
+    f32x16 o[2];                                        // O^T: o[dt][e] <-> d = 32dt + acc_row(e, lh), query = lane
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
+    float m = -INFINITY, l = 0.f;                       // running max (log2 units, shared by the lane pair), partial sum
+
+    TileRegs kr, vr;
+    int kflag = 1;
+    if (n_tiles > 0) {
+        tile_fetch(kr, Kb, p.D, 0, p.Tk, tid);
+        tile_fetch(vr, Vb, p.D, 0, p.Tk, tid);
+        kflag = key_flag(kv, 0, p.Tk, lane);
+    }
+    for (int t = 0; t < n_tiles; ++t) {
+        const int kv0 = t * AT_BK;
+        __syncthreads();                                // previous tile fully consumed
+        tile_commit<AT_KLD>(Ks, kr, tid);
+        tile_commit<AT_KLD>(Vs, vr, tid);
+        const unsigned long long valid = __ballot(kflag != 0) >> (4 * lh);   // bit j: key kv0 + j + 4lh is a real token
+        __syncthreads();
+        if (t + 1 < n_tiles) {                          // next tile's loads fly during this tile's MFMAs
+            tile_fetch(kr, Kb, p.D, kv0 + AT_BK, p.Tk, tid);
+            tile_fetch(vr, Vb, p.D, kv0 + AT_BK, p.Tk, tid);
+            kflag = key_flag(kv, kv0 + AT_BK, p.Tk, lane);
+        }
+        // wave-uniform skip: every key of this tile is above the diagonal for all 32 queries of the wave
+        if (!(skip_ok && kv0 > q0 + 31 + shift)) {
+            // ---- S^T = K Q^T (2 key sub-tiles of 32) -------------------------------------------------------
+            f32x16 s[2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s[kt][e] = 0.f;
+            mma2_rows(s[0], &Ks[l31 * AT_KLD + 4 * lh], qf, s[1], &Ks[(32 + l31) * AT_KLD + 4 * lh], qf);
+            // ---- mask + online softmax (lane <-> query); local key of register (kt, e) = kt*32 + rc(e) + 4lh ------
+            const int lim_causal = p.causal ? q + shift - kv0 - 4 * lh : 1 << 30;   // masked iff local index > lim
+            const int lim_range = p.Tk - 1 - kv0 - 4 * lh;                            // not a key at all iff local index > lim
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int kl = kt * 32 + (e & 3) + 8 * (e >> 2);
+                    float v = s[kt][e];
+                    if (kl > lim_causal || !((valid >> kl) & 1ull)) v = AT_MASKED2;
+                    if (kl > lim_range) v = -INFINITY;
+                    s[kt][e] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m - m_new);   // exp2(-inf) = 0 on the first tile
+            float ps = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float pv = __builtin_amdgcn_exp2f(s[kt][e] - m_new);
+                    s[kt][e] = pv;
+                    ps += pv;
+                }
+            l = l * alpha + ps;
+            m = m_new;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;
+            // ---- O^T += V^T P^T ------------------------------------------------------------------------------
+            mma_cols<AT_KLD>(o, &Vs[(4 * lh) * AT_KLD + l31], s[0]);
+            mma_cols<AT_KLD>(o, &Vs[(32 + 4 * lh) * AT_KLD + l31], s[1]);
+        }
+    }
+
+    // ---- finish: O = O^T / l; (max, log2 sum) in log2 units are kept apart: a fully-masked row has m = -1e9*log2e,
+    // where fp32 cannot hold m + log2 l ------------------------------------------------------------------------
+    const float lt = l + __shfl_xor(l, 32, 64);
+    const float inv = lt > 0.f ? 1.0f / lt : 0.f;
+    if (lh == 0 && q < p.Tq)
+        *reinterpret_cast<float2*>(p.LSE + 2 * (((int64_t)b * p.H + h) * p.Tq + q)) = make_float2(m, log2f(lt));
+    __syncthreads();                                     // K/V tiles are dead: reuse the block as [4 waves][32 q][68]
+    store_transposed(smem + wave * (32 * AT_KLD), o, inv, p.O + ((int64_t)b * p.Tq) * p.D + (int64_t)h * AT_DH, p.D, q0, p.Tq, lane);
+}
+
+// Dsum[b,h,q] = sum_d dO[b,q,h,d] * O[b,q,h,d]   (= sum_k dP*P, the softmax-backward row term).  One wave per row.
+__global__ __launch_bounds__(256) void attn_bwd_dsum_kernel(const float* __restrict__ dO, const float* __restrict__ O,
+                                                            float* __restrict__ Dsum, int B, int H, int Tq, int64_t D) {
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);       // over B*H*Tq
+    const int lane = threadIdx.x & 63;
+    if (row >= (int64_t)B * H * Tq) return;
+    const int q = (int)(row % Tq);
+    const int64_t bh = row / Tq;
+    const int h = (int)(bh % H);
+    const int64_t b = bh / H;
+    const int64_t off = (b * Tq + q) * D + (int64_t)h * AT_DH + lane;
+    const float v = wave_sum(dO[off] * O[off]);
+    if (lane == 0) Dsum[row] = v;
+}
+
+// =====================================================================================================
+// dK, dV: block = 128 keys (4 waves x 32), loop over 64-query tiles (two 32-query halves each)
+// S[q,key] = Q K^T (A = Q tile rows from LDS, B = K fragments in registers; lane <-> key, registers <-> queries),
+// P = exp2(S - m[q] - l[q]), dP = dO V^T (B = V fragments in registers), dS = P (dP - Dsum[q]) * scale (0 where
+// masked), dV^T[d,key] += dO^T P, dK^T[d,key] += Q^T dS -- P and dS feed those MFMAs as B operands straight from
+// their accumulator registers.
+// =====================================================================================================
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const AttnBwdParams p) {
+    constexpr int SM_FLOATS = 2 * 64 * AT_KLD + 192;          // Q tile, dO tile (stride 68), max[64], log2sum[64], Dsum[64]
+    static_assert(SM_FLOATS >= 4 * 32 * AT_KLD, "epilogue staging must fit");
+    __shared__ __attribute__((aligned(16))) float smem[SM_FLOATS];
+    __shared__ int sh_fv;
+    float* Qs = smem;
+    float* dOs = smem + 64 * AT_KLD;
+    float* Ms = smem + 2 * 64 * AT_KLD;
+    float* Ls = Ms + 64;
+    float* Ds = Ls + 64;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int kblocks = (p.Tk + 127) / 128;
+    int bh, kb;
+    if (!map_block(blockIdx.x, p.B * p.H, kblocks, false, bh, kb)) return;
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int k0w = kb * 128 + wave * 32;
+    const int key = k0w + l31;                                  // this lane's key
+    const float* Qb = p.Q + ((int64_t)b * p.Tq) * p.D + (int64_t)h * AT_DH;
+    const float* dOb = p.dO + ((int64_t)b * p.Tq) * p.D + (int64_t)h * AT_DH;
+    const float* Kb = p.K + ((int64_t)b * p.Tk) * p.D + (int64_t)h * AT_DH;
+    const float* Vb = p.V + ((int64_t)b * p.Tk) * p.D + (int64_t)h * AT_DH;
+    const float2* LSEb = reinterpret_cast<const float2*>(p.LSE) + ((int64_t)b * p.H + h) * p.Tq;
+    const float* Dsb = p.Dsum + ((int64_t)b * p.H + h) * p.Tq;
+    const int32_t* kv = p.key_valid ? p.key_valid + (int64_t)b * p.Tk : nullptr;
+    const int shift = p.Tk - p.Tq;
+    const int fv = first_valid_key(kv, p.Tk, tid, &sh_fv);
+    const bool key_in = key < p.Tk;
+    const bool key_pad = kv && key_in && kv[key] == 0;
+
+    // K (pre-scaled by scale*log2e: scores in log2 units, as the forward saved them) and V fragments of this lane's key
+    float kf[8][4], vf[8][4];
+    const float sl2 = p.scale * AT_LOG2E;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
+        if (key_in) {
+            a = *reinterpret_cast<const float4*>(Kb + (int64_t)key * p.D + 8 * g + 4 * lh);
+            c = *reinterpret_cast<const float4*>(Vb + (int64_t)key * p.D + 8 * g + 4 * lh);
+        }
+        kf[g][0] = a.x * sl2; kf[g][1] = a.y * sl2; kf[g][2] = a.z * sl2; kf[g][3] = a.w * sl2;
+        vf[g][0] = c.x; vf[g][1] = c.y; vf[g][2] = c.z; vf[g][3] = c.w;
+    }
+    f32x16 dk[2], dv[2];                                        // dK^T / dV^T: [dt][e] <-> d = 32dt + acc_row(e,lh), key = lane
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { dk[dt][e] = 0.f; dv[dt][e] = 0.f; }
+
+    // query tiles this block must visit: tile qt may be skipped iff every query of it sees a real key (fv <= qs + shift)
+    // AND the whole key block lies above its diagonal; both conditions are monotone in qt, so the visited tiles are
+    // [0, qt_lo) (rows that may be fully masked) and [qt_hi, n_qt) (on / below the diagonal).
+    const int n_qt = (p.Tq + 63) / 64;
+    auto tile_skipped = [&](int qt) { return p.causal && fv <= qt * 64 + shift && kb * 128 > qt * 64 + 63 + shift; };
+    auto next_tile = [&](int qt) { while (qt < n_qt && tile_skipped(qt)) ++qt; return qt; };
+
+    TileRegs qr, gr;
+    float2 ml = make_float2(0.f, 0.f);
+    float dsv = 0.f;
+    int qt = next_tile(0);
+    if (qt < n_qt) {
+        tile_fetch(qr, Qb, p.D, qt * 64, p.Tq, tid);
+        tile_fetch(gr, dOb, p.D, qt * 64, p.Tq, tid);
+        if (tid < 64 && qt * 64 + tid < p.Tq) { ml = LSEb[qt * 64 + tid]; dsv = Dsb[qt * 64 + tid]; }
+    }
+    while (qt < n_qt) {
+        const int qs = qt * 64;
+        __syncthreads();
+        tile_commit<AT_KLD>(Qs, qr, tid);
+        tile_commit<AT_KLD>(dOs, gr, tid);
+        if (tid < 64) { Ms[tid] = ml.x; Ls[tid] = ml.y; Ds[tid] = dsv; }
+        __syncthreads();
+        const int qn = next_tile(qt + 1);
+        if (qn < n_qt) {
+            tile_fetch(qr, Qb, p.D, qn * 64, p.Tq, tid);
+            tile_fetch(gr, dOb, p.D, qn * 64, p.Tq, tid);
+            ml = make_float2(0.f, 0.f); dsv = 0.f;
+            if (tid < 64 && qn * 64 + tid < p.Tq) { ml = LSEb[qn * 64 + tid]; dsv = Dsb[qn * 64 + tid]; }
+        }
+        // wave-uniform skip: this wave's 32 keys are above the diagonal for all 64 queries (which all see a real key)
+        if (!(p.causal && fv <= qs + shift && k0w > qs + 63 + shift)) {
+            const int lim_causal = p.causal ? key - shift - qs - 4 * lh : -(1 << 30);   // masked iff local query < lim
+            const int lim_range = p.Tq - qs - 4 * lh;                                     // a query iff local index < lim
+#pragma unroll
+            for (int t2 = 0; t2 < 2; ++t2) {
+                f32x16 s, dp;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+                mma2_rows(s, &Qs[(t2 * 32 + l31) * AT_KLD + 4 * lh], kf, dp, &dOs[(t2 * 32 + l31) * AT_KLD + 4 * lh], vf);
+                // ---- P = exp2(S_masked - m[q] - l[q]);  dS = P (dP - Dsum[q]) scale, zero where masked ---------------
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    const float4 M4 = *reinterpret_cast<const float4*>(&Ms[t2 * 32 + 8 * e4 + 4 * lh]);
+                    const float4 L4 = *reinterpret_cast<const float4*>(&Ls[t2 * 32 + 8 * e4 + 4 * lh]);
+                    const float4 D4 = *reinterpret_cast<const float4*>(&Ds[t2 * 32 + 8 * e4 + 4 * lh]);
+                    const float Mr[4] = {M4.x, M4.y, M4.z, M4.w}, Lr[4] = {L4.x, L4.y, L4.z, L4.w}, Dr[4] = {D4.x, D4.y, D4.z, D4.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int e = e4 * 4 + r;
+                        const int ql = t2 * 32 + 8 * e4 + r;                // local query index minus 4lh
+                        const bool masked = ql < lim_causal || key_pad;
+                        float arg = ((masked ? AT_MASKED2 : s[e]) - Mr[r]) - Lr[r];
+                        if (!(key_in && ql < lim_range)) arg = -INFINITY;
+                        const float pv = __builtin_amdgcn_exp2f(arg);
+                        s[e] = pv;
+                        dp[e] = (masked ? 0.f : pv) * ((dp[e] - Dr[r]) * p.scale);
+                    }
+                }
+                // ---- dV^T += dO^T P ; dK^T += Q^T dS ------------------------------------------------------------
+                mma2_cols<AT_KLD>(dv, &dOs[(t2 * 32 + 4 * lh) * AT_KLD + l31], s, dk, &Qs[(t2 * 32 + 4 * lh) * AT_KLD + l31], dp);
+            }
+        }
+        qt = qn;
+    }
+
+    // ---- store dK, dV rows (transpose through LDS) --------------------------------------------------------------
+    __syncthreads();
+    float* E = smem + wave * (32 * AT_KLD);
+    store_transposed(E, dk, 1.0f, p.dK + ((int64_t)b * p.Tk) * p.D + (int64_t)h * AT_DH, p.D, k0w, p.Tk, lane);
+    __builtin_amdgcn_wave_barrier();
+    store_transposed(E, dv, 1.0f, p.dV + ((int64_t)b * p.Tk) * p.D + (int64_t)h * AT_DH, p.D, k0w, p.Tk, lane);
+}
+
+// =====================================================================================================
+// dQ: block = 128 queries (4 waves x 32), loop over 64-key tiles (mirror of the forward)
+// S^T = K Q^T, P^T = exp2(S^T - m[q] - l[q]) (lane <-> query), dP^T = V dO^T (B = dO fragments in registers),
+// dS^T = P^T (dP^T - Dsum[q]) scale, dQ^T[d,q] += K^T dS^T.
+// =====================================================================================================
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdParams p) {
+    constexpr int SM_FLOATS = 2 * AT_BK * AT_KLD > 4 * 32 * AT_KLD ? 2 * AT_BK * AT_KLD : 4 * 32 * AT_KLD;
+    __shared__ __attribute__((aligned(16))) float smem[SM_FLOATS];
+    __shared__ int sh_fv;
+    float* Ks = smem;
+    float* Vs = smem + AT_BK * AT_KLD;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int qblocks = (p.Tq + AT_BQ - 1) / AT_BQ;
+    int bh, qb;
+    if (!map_block(blockIdx.x, p.B * p.H, qblocks, true, bh, qb)) return;
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int q0 = qb * AT_BQ + wave * 32;
+    const int q = q0 + l31;
+    const float* Qb = p.Q + ((int64_t)b * p.Tq) * p.D + (int64_t)h * AT_DH;
+    const float* dOb = p.dO + ((int64_t)b * p.Tq) * p.D + (int64_t)h * AT_DH;
+    const float* Kb = p.K + ((int64_t)b * p.Tk) * p.D + (int64_t)h * AT_DH;
+    const float* Vb = p.V + ((int64_t)b * p.Tk) * p.D + (int64_t)h * AT_DH;
+    const int32_t* kv = p.key_valid ? p.key_valid + (int64_t)b * p.Tk : nullptr;
+    const int shift = p.Tk - p.Tq;
+    const int fv = first_valid_key(kv, p.Tk, tid, &sh_fv);
+    const bool q_in = q < p.Tq;
+    const float2 ml = q_in ? reinterpret_cast<const float2*>(p.LSE)[((int64_t)b * p.H + h) * p.Tq + q] : make_float2(0.f, 0.f);
+    const float dsum = q_in ? p.Dsum[((int64_t)b * p.H + h) * p.Tq + q] : 0.f;
+
+    float qf[8][4], gf[8][4];                                   // Q (pre-scaled, log2 units) and dO fragments of this lane's query
+    const float sl2 = p.scale * AT_LOG2E;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
+        if (q_in) {
+            a = *reinterpret_cast<const float4*>(Qb + (int64_t)q * p.D + 8 * g + 4 * lh);
+            c = *reinterpret_cast<const float4*>(dOb + (int64_t)q * p.D + 8 * g + 4 * lh);
+        }
+        qf[g][0] = a.x * sl2; qf[g][1] = a.y * sl2; qf[g][2] = a.z * sl2; qf[g][3] = a.w * sl2;
+        gf[g][0] = c.x; gf[g][1] = c.y; gf[g][2] = c.z; gf[g][3] = c.w;
+    }
+    int n_tiles = (p.Tk + AT_BK - 1) / AT_BK;
+    const bool skip_ok = p.causal && fv <= qb * AT_BQ + shift;
+    if (skip_ok) {
+        const int last_key = min(p.Tk - 1, qb * AT_BQ + AT_BQ - 1 + shift);
+        n_tiles = last_key < 0 ? 0 : last_key / AT_BK + 1;
+    }
+    f32x16 dq[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) dq[dt][e] = 0.f;
+
+    TileRegs kr, vr;
+    int kflag = 1;
+    if (n_tiles > 0) {
+        tile_fetch(kr, Kb, p.D, 0, p.Tk, tid);
+        tile_fetch(vr, Vb, p.D, 0, p.Tk, tid);
+        kflag = key_flag(kv, 0, p.Tk, lane);
+    }
+    for (int t = 0; t < n_tiles; ++t) {
+        const int kv0 = t * AT_BK;
+        __syncthreads();
+        tile_commit<AT_KLD>(Ks, kr, tid);
+        tile_commit<AT_KLD>(Vs, vr, tid);
+        const unsigned long long valid = __ballot(kflag != 0) >> (4 * lh);
+        __syncthreads();
+        if (t + 1 < n_tiles) {
+            tile_fetch(kr, Kb, p.D, kv0 + AT_BK, p.Tk, tid);
+            tile_fetch(vr, Vb, p.D, kv0 + AT_BK, p.Tk, tid);
+            kflag = key_flag(kv, kv0 + AT_BK, p.Tk, lane);
+        }
+        if (!(skip_ok && kv0 > q0 + 31 + shift)) {
+            const int lim_causal = p.causal ? q + shift - kv0 - 4 * lh : 1 << 30;
+            const int lim_range = q_in ? p.Tk - 1 - kv0 - 4 * lh : -1;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                f32x16 s, dp;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+                mma2_rows(s, &Ks[(kt * 32 + l31) * AT_KLD + 4 * lh], qf, dp, &Vs[(kt * 32 + l31) * AT_KLD + 4 * lh], gf);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int kl = kt * 32 + (e & 3) + 8 * (e >> 2);
+                    const bool live = kl <= lim_range && kl <= lim_causal && ((valid >> kl) & 1ull);
+                    const float arg = live ? (s[e] - ml.x) - ml.y : -INFINITY;
+                    dp[e] = __builtin_amdgcn_exp2f(arg) * ((dp[e] - dsum) * p.scale);
+                }
+                mma_cols<AT_KLD>(dq, &Ks[(kt * 32 + 4 * lh) * AT_KLD + l31], dp);      // dQ^T += K^T dS^T
+            }
+        }
+    }
+    __syncthreads();
+    store_transposed(smem + wave * (32 * AT_KLD), dq, 1.0f, p.dQ + ((int64_t)b * p.Tq) * p.D + (int64_t)h * AT_DH, p.D, q0, p.Tq, lane);
+}
+
+}  // namespace nnhip
+
+using namespace nnhip;
+
+static int attn_check(const char* fn, const void* Q, const void* K, const void* V, int64_t B, int64_t H, int64_t Tq,
+                      int64_t Tk, int64_t dh) {
+    NNHIP_CHECK_ARG(B >= 0 && H > 0 && Tq >= 0 && Tk >= 0, NNHIP_EINVAL, "%s: bad sizes", fn);
+    NNHIP_CHECK_ARG(dh == AT_DH, NNHIP_EINVAL, "%s: only head_dim 64 is supported by the fused kernel", fn);
+    NNHIP_CHECK_ARG(Tq < (1 << 24) && Tk < (1 << 24) && B * H < (1 << 24), NNHIP_EINVAL, "%s: sizes too large", fn);
+    if (B == 0 || Tq == 0) return 0;
+    NNHIP_CHECK_ARG(Q && K && V, NNHIP_EINVAL, "%s: null pointer", fn);
+    NNHIP_CHECK_ARG(aligned16(Q) && aligned16(K) && aligned16(V), NNHIP_EALIGN, "%s: Q/K/V must be 16-byte aligned", fn);
+    return 0;
+}
+
+extern "C" int nnhipAttentionForward(const float* Q, const float* K, const float* V, const int32_t* key_valid,
+                                     float* O, float* LSE, int64_t B, int64_t H, int64_t Tq, int64_t Tk,
+                                     int64_t head_dim, float scale, int causal, nnhipStream_t s) {
+    if (int rc = attn_check("nnhipAttentionForward", Q, K, V, B, H, Tq, Tk, head_dim)) return rc;
+    if (B == 0 || Tq == 0) return 0;
+    NNHIP_CHECK_ARG(Tk > 0, NNHIP_EINVAL, "nnhipAttentionForward: Tk must be > 0");
+    NNHIP_CHECK_ARG(O && LSE && aligned16(O), NNHIP_EINVAL, "nnhipAttentionForward: null / misaligned output");
+    AttnParams p;
+    p.Q = Q; p.K = K; p.V = V; p.O = O; p.LSE = LSE; p.key_valid = key_valid;
+    p.B = (int)B; p.H = (int)H; p.Tq = (int)Tq; p.Tk = (int)Tk; p.D = H * AT_DH; p.scale = scale; p.causal = causal;
+    const int64_t qblocks = ceil_div(Tq, AT_BQ);
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(mapped_grid(B * H, qblocks)), dim3(256), 0, (hipStream_t)s, p);
+    NNHIP_LAUNCH_CHECK("attn_fwd_kernel");
+    return 0;
+}
+
+extern "C" int nnhipAttentionBackward(const float* Q, const float* K, const float* V, const int32_t* key_valid,
+                                      const float* O, const float* dO, const float* LSE, float* dQ, float* dK,
+                                      float* dV, int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t head_dim,
+                                      float scale, int causal, nnhipStream_t s) {
+    if (int rc = attn_check("nnhipAttentionBackward", Q, K, V, B, H, Tq, Tk, head_dim)) return rc;
+    if (B == 0 || Tq == 0 || Tk == 0) return 0;
+    NNHIP_CHECK_ARG(O && dO && LSE && dQ && dK && dV, NNHIP_EINVAL, "nnhipAttentionBackward: null pointer");
+    NNHIP_CHECK_ARG(aligned16(dO) && aligned16(dQ) && aligned16(dK) && aligned16(dV), NNHIP_EALIGN,
+                    "nnhipAttentionBackward: dO/dQ/dK/dV must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)s;
+    float* dsum = static_cast<float*>(workspace((size_t)B * H * Tq * sizeof(float)));
+    NNHIP_CHECK_ARG(dsum != nullptr, NNHIP_ENOMEM, "nnhipAttentionBackward: workspace allocation failed");
+    const int64_t rows = B * H * Tq;
+    hipLaunchKernelGGL(attn_bwd_dsum_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, st, dO, O, dsum, (int)B, (int)H,
+                       (int)Tq, H * AT_DH);
+    NNHIP_LAUNCH_CHECK("attn_bwd_dsum_kernel");
+    AttnBwdParams p;
+    p.Q = Q; p.K = K; p.V = V; p.dO = dO; p.LSE = LSE; p.Dsum = dsum; p.dQ = dQ; p.dK = dK; p.dV = dV;
+    p.key_valid = key_valid; p.B = (int)B; p.H = (int)H; p.Tq = (int)Tq; p.Tk = (int)Tk; p.D = H * AT_DH;
+    p.scale = scale; p.causal = causal;
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3(mapped_grid(B * H, ceil_div(Tk, 128))), dim3(256), 0, st, p);
+    NNHIP_LAUNCH_CHECK("attn_bwd_dkdv_kernel");
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(mapped_grid(B * H, ceil_div(Tq, AT_BQ))), dim3(256), 0, st, p);
+    NNHIP_LAUNCH_CHECK("attn_bwd_dq_kernel");
+    return 0;
+}

@@ -49,6 +49,8 @@ _SIGNATURES = {
                                       c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_float, c_void_p]),
     "nnhipMaskedSoftmaxForward": (ctypes.c_int, [P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, ctypes.c_int, c_void_p]),
     "nnhipMaskedSoftmaxBackward": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, ctypes.c_int, c_void_p]),
+    "nnhipAttentionForward": (ctypes.c_int, [P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int64, c_float, ctypes.c_int, c_void_p]),
+    "nnhipAttentionBackward": (ctypes.c_int, [P, P, P, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int64, c_float, ctypes.c_int, c_void_p]),
     "nnhipEmbeddingForward": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, c_void_p]),
     "nnhipEmbeddingBackward": (ctypes.c_int, [P, P, P, c_int64, c_int64, c_int64, c_float, c_void_p]),
     "nnhipMul": (ctypes.c_int, [P, P, P, c_int64, c_void_p]),

@@ -41,6 +41,30 @@ def attention_forward(q, k, v, key_valid, n_heads, scale, causal):
     return ctx, attn
 
 
+def fused_attention_forward(q, k, v, key_valid, n_heads, scale, causal):
+    """Flash-style forward (nnhipAttentionForward, head_dim 64): returns (ctx [B,Tq,D], lse [B,H,Tq,2]); the score
+    matrix is never materialised."""
+    import torch
+    B, Tq, D = q.shape
+    Tk = k.shape[1]
+    ctx = torch.empty((B, Tq, D), dtype=torch.float32, device=q.device)
+    lse = torch.empty((B, n_heads, Tq, 2), dtype=torch.float32, device=q.device)   # (row max, log row sum)
+    call_hip_function("nnhipAttentionForward", q, k, v, key_valid, ctx, lse, B, n_heads, Tq, Tk, D // n_heads,
+                      1.0 / scale, int(causal), get_current_stream_ptr())
+    return ctx, lse
+
+
+def fused_attention_backward(q, k, v, key_valid, ctx, lse, n_heads, scale, causal, dctx):
+    """Flash-style backward (nnhipAttentionBackward): (dq, dk, dv) from the saved ctx and row log-sum-exp."""
+    import torch
+    B, Tq, D = q.shape
+    Tk = k.shape[1]
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    call_hip_function("nnhipAttentionBackward", q, k, v, key_valid, ctx, dctx, lse, dq, dk, dv, B, n_heads, Tq, Tk,
+                      D // n_heads, 1.0 / scale, int(causal), get_current_stream_ptr())
+    return dq, dk, dv
+
+
 def attention_backward(q, k, v, attn, key_valid, n_heads, scale, causal, dctx, need=(True, True, True)):
     """Returns (dq, dk, dv) in the [B,T,D] layout of the projections."""
     import torch
@@ -87,6 +111,27 @@ class _HIPAttentionTensor(Tensor):
         self.grad_fn = grad_fn
 
 
+class _HIPFusedAttentionTensor(Tensor):
+    def __init__(self, data, args, op, device):
+        super().__init__(data, args, op, device=device, _nocopy=True)
+
+        def grad_fn(q: Tensor, k: Tensor, v: Tensor, lse, key_valid, n_heads, scale, causal, grad):
+            grad = grad if grad.is_contiguous() else grad.contiguous()
+            dq, dk, dv = fused_attention_backward(q.data, k.data, v.data, key_valid, self.data, lse, n_heads, scale,
+                                                  causal, grad)
+            if q.requires_grad:
+                q.apply_grad(dq)
+            if k.requires_grad:
+                k.apply_grad(dk)
+            if v.requires_grad:
+                v.apply_grad(dv)
+
+        self.grad_fn = grad_fn
+
+
+FUSED_HEAD_DIM = 64
+
+
 class HIPMultiHeadAttention(Module):
     def __init__(self, d_model, n_heads, dropout=0.0, device="cuda"):
         super().__init__()
@@ -101,12 +146,20 @@ class HIPMultiHeadAttention(Module):
         self.wv = HIPLinear(d_model, d_model, device=device)
         self.fc = HIPLinear(d_model, d_model, device=device)
 
-    def forward(self, q: Tensor, k: Tensor, v: Tensor, key_valid=None, causal=True):
+    def forward(self, q: Tensor, k: Tensor, v: Tensor, key_valid=None, causal=True, need_weights=True):
         """key_valid: int32 device array [B,Tk] (1 = real token, 0 = padding) or None.  The notebook's dense
-        mask get_pad_mask(x) & get_sub_mask(x) (cell 7) is exactly (key_valid, causal=True)."""
+        mask get_pad_mask(x) & get_sub_mask(x) (cell 7) is exactly (key_valid, causal=True).
+
+        need_weights=False (training steps that never look at the attention map) takes the fused flash-style
+        kernels when head_dim == 64 and returns (out, None): scores/attn/dattn are never written to HBM."""
         if self.dropout.p != 0 and self.dropout.training:
             raise NotImplementedError("attention dropout > 0 is not implemented on the HIP path yet")
         qp, kp, vp = self.wq(q), self.wk(k), self.wv(v)
+        if not need_weights and self.depth == FUSED_HEAD_DIM:
+            ctx, lse = fused_attention_forward(qp.data, kp.data, vp.data, key_valid, self.n_heads, self.scale, causal)
+            ctx_t = _HIPFusedAttentionTensor(ctx, (qp, kp, vp, lse, key_valid, self.n_heads, self.scale, causal),
+                                             "fused_attention", device="cuda")
+            return self.fc(ctx_t), None
         ctx, attn = attention_forward(qp.data, kp.data, vp.data, key_valid, self.n_heads, self.scale, causal)
         ctx_t = _HIPAttentionTensor(ctx, (qp, kp, vp, attn, key_valid, self.n_heads, self.scale, causal),
                                     "attention", device="cuda")

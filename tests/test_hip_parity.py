@@ -657,6 +657,90 @@ def test_mha_vs_oracle(hip, B, Tn, D, H):
         np.testing.assert_allclose(host(lin.bias.grad), db, rtol=1e-4, atol=5e-4)
 
 
+@pytest.mark.parametrize("B,Tn,D,H,causal", [(2, 256, 512, 8, True), (3, 100, 256, 4, True), (1, 7, 64, 1, True),
+                                              (2, 130, 128, 2, True), (2, 257, 128, 2, False), (1, 64, 64, 1, True)])
+def test_fused_attention_vs_oracle(hip, B, Tn, D, H, causal):
+    """need_weights=False takes nnhipAttentionForward/Backward (flash-style, head_dim 64): same output and
+    gradients as the oracle MHA (and therefore as the GEMM + masked-softmax path), incl. padded keys."""
+    import neunet_hip.nn as nn
+    rng = np.random.default_rng(B * Tn + D)
+    mha = nn.MultiHeadAttention(D, H)
+    ps = []
+    for lin in (mha.wq, mha.wk, mha.wv, mha.fc):
+        lin.weight.data.mul_(3.0)          # sharper softmax than the default init gives
+        ps += [host(lin.weight.data), host(lin.bias.data)]
+    X = rng.standard_normal((B, Tn, D)).astype(np.float32)
+    tok = rng.integers(1, 9, (B, Tn))
+    tok[0, -max(1, Tn // 5):] = 0
+    tok[-1, Tn // 2] = 0
+    mask = O.attention_mask(tok, 0) if causal else np.broadcast_to((tok != 0)[:, None, :], (B, Tn, Tn)).astype(np.int32)
+    ref = O.MHA(*ps, n_heads=H)
+    yr, _ = ref.forward(X, mask)
+    x = T(hip, X)
+    y, attn = mha(x, x, x, dev((tok != 0).astype(np.int32)), causal=causal, need_weights=False)
+    assert attn is None
+    np.testing.assert_allclose(host(y.data), yr, **TOL)
+    dY = rng.standard_normal(yr.shape).astype(np.float32)
+    y.backward(dY)
+    dxr, gr = ref.backward(dY)
+    np.testing.assert_allclose(host(x.grad), dxr, rtol=1e-4, atol=2e-4)
+    for lin, dW, db in zip((mha.wq, mha.wk, mha.wv, mha.fc), gr[0::2], gr[1::2]):
+        np.testing.assert_allclose(host(lin.weight.grad), dW, rtol=1e-4, atol=5e-4)
+        np.testing.assert_allclose(host(lin.bias.grad), db, rtol=1e-4, atol=5e-4)
+
+
+def test_fused_attention_fully_masked_rows(hip):
+    """Queries whose every visible key is padding: the reference's where(mask, scores, -1e9) makes their softmax
+    uniform over ALL keys (incl. future ones) -- the fused kernels must reproduce that and its gradient, so the
+    causal tile skipping is disabled for such blocks."""
+    from neunet_hip.nn.experimental import attention as A
+    import torch
+    rng = np.random.default_rng(3)
+    B, Tn, H, D = 2, 200, 2, 128
+    q, k, v, do = [dev(rng.standard_normal((B, Tn, D)).astype(np.float32)) for _ in range(4)]
+    kvh = np.ones((B, Tn), np.int32)
+    kvh[0, :70] = 0            # leading padding: queries 0..69 of batch 0 see no valid key
+    kvh[1, 5:9] = 0
+    kv = dev(kvh)
+    scale = float(np.sqrt(D))
+    ctx_u, attn = A.attention_forward(q, k, v, kv, H, scale, True)
+    dq_u, dk_u, dv_u = A.attention_backward(q, k, v, attn, kv, H, scale, True, do)
+    ctx_f, lse = A.fused_attention_forward(q, k, v, kv, H, scale, True)
+    dq_f, dk_f, dv_f = A.fused_attention_backward(q, k, v, kv, ctx_f, lse, H, scale, True, do)
+    for a, b, name in ((ctx_f, ctx_u, "ctx"), (dq_f, dq_u, "dq"), (dk_f, dk_u, "dk"), (dv_f, dv_u, "dv")):
+        np.testing.assert_allclose(host(a), host(b), rtol=1e-4, atol=1e-5, err_msg=name)
+
+
+def test_gpt_step_fused_attention_equals_unfused(hip):
+    """A GPT step (d 128, 2 heads of 64) with the fused attention kernels gives the same loss and gradients as
+    the GEMM + masked-softmax path (which the gpt_tiny golden pins to the reference)."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import gpt_tiny
+    import neunet_hip.nn as nn
+    V, D, H, F, L, B, Tn = 97, 128, 2, 256, 2, 3, 70
+    rng = np.random.default_rng(11)
+    batch = rng.integers(1, V, (B, Tn + 1)).astype(np.int32)
+    batch[0, -9:] = 0
+    grads, losses = [], []
+    for fa in (False, True):
+        np.random.seed(21)
+        model = gpt_tiny.build_gpt(V, D, H, F, L, pad_idx=0, max_len=128, fused=True, fused_attention=fa)
+        loss_fn = nn.CrossEntropyLoss(ignore_index=0)
+        out, attn = model.forward(batch[:, :-1])
+        assert (attn is None) == fa
+        loss = loss_fn(out.reshape(B * Tn, V), T(hip, np.ascontiguousarray(batch[:, 1:]).reshape(-1), dtype=np.int32,
+                                                 requires_grad=False))
+        loss.backward()
+        losses.append(loss.item())
+        grads.append([None if p.grad is None else host(p.grad) for p in model.parameters()])
+    assert abs(losses[0] - losses[1]) < 1e-5
+    for i, (a, b) in enumerate(zip(*grads)):
+        assert (a is None) == (b is None)
+        if a is not None:
+            np.testing.assert_allclose(b, a, rtol=1e-3, atol=2e-6, err_msg=f"grad {i}")
+
+
 @pytest.mark.parametrize("fused", [False, True])
 def test_gpt_tiny_step_golden(hip, golden, fused):
     """One full training step of the notebook's GPT (2 layers, d 32, 4 heads, vocab 50, repeated ids, PAD tail):
