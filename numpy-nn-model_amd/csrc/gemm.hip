@@ -48,6 +48,8 @@ struct GemmParams {
     int cvec;             // 1: C/bias/preact rows are 16-B aligned and N % 4 == 0 -> float4 epilogue
     int act;
     float beta;
+    float* asum;          // CS variants: asum[m] = sum_k A[m,k] (Linear: db = column sums of dO, fused into dW = dO^T X)
+    float* asum_slab;     // split-K partials [splitk][M]
 };
 
 constexpr int BM = 128, BN = 128, NT = 256;
@@ -126,8 +128,11 @@ __device__ __forceinline__ void frag(float (&f)[4], const float* __restrict__ S,
     }
 }
 
-template <int BK, bool AKC, bool BKC, bool VEC>
+// CS (outer-major A only): every thread also accumulates the A elements it stages -- with the [BK][128] tile layout a
+// thread owns the same 4 A rows (m) in every k-tile -- and the tile_n == 0 blocks reduce them to asum[m] = sum_k A[m,k].
+template <int BK, bool AKC, bool BKC, bool VEC, bool CS = false>
 __global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const GemmParams p) {
+    static_assert(!CS || !AKC, "row sums of A are only implemented for an outer-major A");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using TA = Tile<BK, AKC>;
     using TB = Tile<BK, BKC>;
@@ -180,6 +185,11 @@ __global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const 
     g2r<BK, BKC, VEC>(rb, B, p.ldb, p.N, kend, n0, kbeg, tid, nk > 0, Z);
     r2s<BK, AKC>(ra, smem, tid);
     r2s<BK, BKC>(rb, smem + TA::SIZE, tid);
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (CS) {
+#pragma unroll
+        for (int q = 0; q < BK / 8; ++q) { cs.x += ra[q].x; cs.y += ra[q].y; cs.z += ra[q].z; cs.w += ra[q].w; }
+    }
     __syncthreads();
 
     // K loop.  One basic block per iteration; the issue order is pinned with sched_group_barrier so that the
@@ -217,6 +227,10 @@ __global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const 
             float* Sn = smem + (cur ^ 1) * STAGE;
             r2s<BK, AKC>(ra, Sn, tid);
             r2s<BK, BKC>(rb, Sn + TA::SIZE, tid);
+            if constexpr (CS) {
+#pragma unroll
+                for (int q = 0; q < BK / 8; ++q) { cs.x += ra[q].x; cs.y += ra[q].y; cs.z += ra[q].z; cs.w += ra[q].w; }
+            }
         }
         // ---- issue-order pipeline for this iteration's scheduling region --------------------------------
 #pragma unroll
@@ -241,6 +255,19 @@ __global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const 
     // its tile through its own LDS region, 32 rows at a time, and stores float4 rows: 4x fewer instructions,
     // 4 rows x 256 B each.  (Scalar path kept for unaligned / N % 4 != 0 outputs.)
     const bool to_slab = p.splitk > 1;
+    if constexpr (CS) {
+        if (p.asum && tn == 0) {                             // the K loop ended with a barrier: LDS is free
+            *reinterpret_cast<float4*>(&smem[(tid >> 5) * 128 + (tid & 31) * 4]) = cs;
+            __syncthreads();
+            if (tid < 128) {
+                float t = 0.f;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) t += smem[r * 128 + tid];
+                if (m0 + tid < p.M) (to_slab ? p.asum_slab + (int64_t)split * p.M : p.asum)[m0 + tid] = t;
+            }
+            __syncthreads();
+        }
+    }
     float* __restrict__ C = to_slab ? p.slab + (int64_t)split * p.M * p.N : p.C + c_off;
     const int64_t ldc = to_slab ? p.N : p.ldc;
     if (p.cvec) {
@@ -316,9 +343,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
                                                             float* __restrict__ preact,
                                                             const float* __restrict__ bias,
                                                             int64_t M, int64_t N, int64_t ldc,
-                                                            int splitk, int act, float beta, float alpha) {
+                                                            int splitk, int act, float beta, float alpha,
+                                                            const float* __restrict__ asum_slab, float* __restrict__ asum) {
     const int64_t total = M * N;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if (asum)
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += stride) {
+            float s = 0.f;
+            for (int k = 0; k < splitk; ++k) s += asum_slab[(int64_t)k * M + i];
+            asum[i] = s;
+        }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
         float s = 0.f;
         for (int k = 0; k < splitk; ++k) s += slab[(int64_t)k * total + i];
@@ -335,10 +369,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
-template <int BK, bool AKC, bool BKC, bool VEC>
+template <int BK, bool AKC, bool BKC, bool VEC, bool CS = false>
 static int launch_variant(const GemmParams& p, int64_t batch, hipStream_t st) {
     constexpr size_t lds = 2 * (Tile<BK, AKC>::SIZE + Tile<BK, BKC>::SIZE) * sizeof(float);
-    auto kern = gemm_f32_kernel<BK, AKC, BKC, VEC>;
+    auto kern = gemm_f32_kernel<BK, AKC, BKC, VEC, CS>;
     static bool attr_set = false;  // per instantiation
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -356,7 +390,7 @@ static int launch_variant(const GemmParams& p, int64_t batch, hipStream_t st) {
 int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, float* preact, int64_t M,
                 int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, bool a_kmajor, bool b_kmajor,
                 int64_t batch1, int64_t sA, int64_t sB, int64_t sC, int64_t batch2, int64_t sA2,
-                int64_t sB2, int64_t sC2, float alpha, int act, float beta, hipStream_t st);
+                int64_t sB2, int64_t sC2, float alpha, int act, float beta, hipStream_t st, float* asum = nullptr);
 
 int gemm_f32(const float* A, const float* B, float* C, const float* bias, float* preact, int64_t M,
              int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, bool a_kmajor,
@@ -366,12 +400,21 @@ int gemm_f32(const float* A, const float* B, float* C, const float* bias, float*
                        0, 0, 0, 1.0f, act, beta, st);
 }
 
+// C = A^T-view * B with asum[m] = sum_k A[m,k] produced by the same kernel (A outer-major, no batch):
+// Linear backward's dW = dO^T X and db = column sums of dO in one pass over dO.
+int gemm_f32_asum(const float* A, const float* B, float* C, float* asum, int64_t M, int64_t N, int64_t K, int64_t lda,
+                  int64_t ldb, int64_t ldc, bool b_kmajor, hipStream_t st) {
+    return gemm_f32_ex(A, B, C, nullptr, nullptr, M, N, K, lda, ldb, ldc, false, b_kmajor, 1, 0, 0, 0, 1, 0, 0, 0, 1.0f,
+                       ACT_NONE, 1.f, st, asum);
+}
+
 int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, float* preact, int64_t M,
                 int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, bool a_kmajor, bool b_kmajor,
                 int64_t batch1, int64_t sA, int64_t sB, int64_t sC, int64_t batch2, int64_t sA2,
-                int64_t sB2, int64_t sC2, float alpha, int act, float beta, hipStream_t st) {
+                int64_t sB2, int64_t sC2, float alpha, int act, float beta, hipStream_t st, float* asum) {
     const int64_t batch = batch1 * batch2;
     if (M <= 0 || N <= 0 || batch <= 0) return 0;
+    if (asum && (a_kmajor || batch != 1 || K <= 0)) { set_last_error("gemm: asum needs an outer-major, unbatched A"); return NNHIP_EINVAL; }
     static const int bk_sel = []() { const char* e = getenv("NNHIP_GEMM_BK"); return e ? atoi(e) : 32; }();
     const int BK = (bk_sel == 16) ? 16 : 32;
     GemmParams p;
@@ -383,6 +426,7 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
     p.tiles_n = (int)ceil_div(N, BN);
     p.act = act; p.beta = beta;
     p.splitk = 1; p.k_per_split = ceil_div(K > 0 ? K : 1, BK) * BK; p.slab = nullptr;
+    p.asum = asum; p.asum_slab = nullptr;
     p.zeros = zero_block();
     if (!p.zeros) { set_last_error("zero block allocation failed"); return NNHIP_ENOMEM; }
 
@@ -397,8 +441,9 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
             p.k_per_split = ceil_div(ceil_div(K, s), BK) * BK;
             p.splitk = (int)ceil_div(K, p.k_per_split);
             if (p.splitk >= 2) {
-                p.slab = static_cast<float*>(workspace((size_t)p.splitk * M * N * sizeof(float)));
+                p.slab = static_cast<float*>(workspace((size_t)p.splitk * (M * N + (asum ? M : 0)) * sizeof(float)));
                 if (!p.slab) { set_last_error("split-K workspace allocation failed"); return NNHIP_ENOMEM; }
+                if (asum) p.asum_slab = p.slab + (int64_t)p.splitk * M * N;
             } else {
                 p.splitk = 1; p.k_per_split = ceil_div(K, BK) * BK;
             }
@@ -426,6 +471,12 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
                            : launch_variant<16, AK, BKM, false>(p, batch, st))                    \
                     : (vec ? launch_variant<32, AK, BKM, true>(p, batch, st)                      \
                            : launch_variant<32, AK, BKM, false>(p, batch, st))
+    if (asum) {
+        rc = (BK == 16) ? (b_kmajor ? (vec ? launch_variant<16, false, true, true, true>(p, batch, st) : launch_variant<16, false, true, false, true>(p, batch, st))
+                                    : (vec ? launch_variant<16, false, false, true, true>(p, batch, st) : launch_variant<16, false, false, false, true>(p, batch, st)))
+                        : (b_kmajor ? (vec ? launch_variant<32, false, true, true, true>(p, batch, st) : launch_variant<32, false, true, false, true>(p, batch, st))
+                                    : (vec ? launch_variant<32, false, false, true, true>(p, batch, st) : launch_variant<32, false, false, false, true>(p, batch, st)));
+    } else
     if (a_kmajor && b_kmajor) { NNHIP_GEMM_CASE(true, true); }
     else if (a_kmajor && !b_kmajor) { NNHIP_GEMM_CASE(true, false); }
     else if (!a_kmajor && b_kmajor) { NNHIP_GEMM_CASE(false, true); }
@@ -437,7 +488,7 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
         const int64_t total = M * N;
         int blocks = (int)(ceil_div(total, 256) < 2048 ? ceil_div(total, 256) : 2048);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.slab, C, preact,
-                           bias, M, N, ldc, p.splitk, act, beta, alpha);
+                           bias, M, N, ldc, p.splitk, act, beta, alpha, p.asum_slab, asum);
         NNHIP_LAUNCH_CHECK("splitk_reduce_kernel");
     }
     return 0;

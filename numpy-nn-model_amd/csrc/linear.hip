@@ -8,6 +8,8 @@ int gemm_f32(const float* A, const float* B, float* C, const float* bias, float*
              int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, bool a_kmajor,
              bool b_kmajor, int64_t batch, int64_t sA, int64_t sB, int64_t sC, int act, float beta,
              hipStream_t st);
+int gemm_f32_asum(const float* A, const float* B, float* C, float* asum, int64_t M, int64_t N, int64_t K, int64_t lda,
+                  int64_t ldb, int64_t ldc, bool b_kmajor, hipStream_t st);
 int colsum(const float* X, int64_t rows, int64_t cols, int64_t ld, float* out, hipStream_t st);
 int swish_backward_inplace(float* z_inout, const float* dY, float beta, int64_t n, hipStream_t st);
 int fill_f32(float* p, float v, int64_t n, hipStream_t st);
@@ -25,9 +27,8 @@ static int linear_backward(const float* X, const float* W, const float* dO, floa
     if (dX) rc = gemm_f32(dO, W, dX, nullptr, nullptr, rows, in, out, out, in, in, true, false, 1, 0, 0, 0, ACT_NONE, 1.f, st);
     if (rc) return rc;
     // dW[out,in] = dO^T[out,rows] * X[rows,in]        both outer-major (k = rows)
-    if (dW) rc = gemm_f32(dO, X, dW, nullptr, nullptr, out, in, rows, out, in, in, false, false, 1, 0, 0, 0, ACT_NONE, 1.f, st);
-    if (rc) return rc;
-    // db[out] = sum_rows dO
+    // db[out] = sum_rows dO rides in the same kernel (each thread sums the dO elements it stages): one pass over dO
+    if (dW) return gemm_f32_asum(dO, X, dW, db, out, in, rows, out, in, in, false, st);
     if (db) rc = colsum(dO, rows, out, out, db, st);
     return rc;
 }
