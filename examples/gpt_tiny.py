@@ -29,18 +29,19 @@ class PositionwiseFeedForward(nn.Module):
         self.dropout = nn.Dropout(dropout)
         self.activation = nn.Swish()
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
         x = self.fc_1(x)
         if not self.fused:
             x = self.activation(x)
         x = self.dropout(x)
-        return self.fc_2(x)
+        return self.fc_2(x) if residual is None else self.fc_2(x, residual=residual)
 
 
 class DecoderLayer(nn.Module):
     def __init__(self, d_model, n_heads, d_ff, dropout=0.0, fused=True, fused_attention=True):
         super().__init__()
         self.need_weights = not fused_attention   # fused flash-style attention never materialises the map
+        self.fused = fused
         self.self_attn = nn.MultiHeadAttention(d_model, n_heads, dropout)
         self.cross_attn = nn.MultiHeadAttention(d_model, n_heads, dropout)   # constructed, never called
         self.ffn = PositionwiseFeedForward(d_model, d_ff, dropout, fused)
@@ -50,6 +51,11 @@ class DecoderLayer(nn.Module):
 
     def forward(self, x, key_valid):
         nx1 = self.norm1(x)
+        if self.fused and self.dropout.p == 0:
+            # x + sublayer(norm(x)) with the add folded into the sublayer's last GEMM (dropout p = 0 is the identity)
+            x, attn = self.self_attn(nx1, nx1, nx1, key_valid, causal=True, need_weights=self.need_weights, residual=x)
+            x = self.ffn(self.norm2(x), residual=x)
+            return x, attn
         _x, attn = self.self_attn(nx1, nx1, nx1, key_valid, causal=True, need_weights=self.need_weights)
         x = x + self.dropout(_x)
         nx2 = self.norm2(x)

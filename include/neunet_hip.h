@@ -51,6 +51,16 @@ int nnhipLinearModuleForward(const float* X, const float* W, const float* b, flo
 int nnhipLinearModuleBackward(const float* X, const float* W, const float* dO, float* dX,
                               float* dW, float* db, int64_t rows, int64_t in_features,
                               int64_t out_features, nnhipStream_t stream);
+/* Extensions with an addend folded into the GEMM epilogue (both NULL-able; NULL == the plain entry points):
+ *   forward : O  = X*W^T + b + addend        (addend [rows,out]: the residual of `x + linear(h)`, neunet/autograd.py add)
+ *   backward: dX = dO*W + dX_addend          (dX_addend [rows,in]: a gradient X has already received -- replaces the
+ *                                             separate accumulation of Tensor.apply_grad, neunet/autograd.py:85-93)
+ * The addend is read once per output float4 (may alias nothing that is written). db is produced by the dW GEMM itself. */
+int nnhipLinearModuleForwardEx(const float* X, const float* W, const float* b, const float* addend, float* O,
+                               int64_t rows, int64_t in_features, int64_t out_features, nnhipStream_t stream);
+int nnhipLinearModuleBackwardEx(const float* X, const float* W, const float* dO, const float* dX_addend, float* dX,
+                                float* dW, float* db, int64_t rows, int64_t in_features, int64_t out_features,
+                                nnhipStream_t stream);
 
 /* ---- a6 fused Linear -> Swish  (replaces cudaLinearSwishForward/Backward,
  *      linear_swish_cutlass_evt_full.cu:558-570, 680-695) ------------------------------------- */
@@ -170,6 +180,10 @@ int nnhipRMSNormForward(const float* X, const float* weight, const float* bias_o
 int nnhipRMSNormBackward(const float* dY, const float* X, const float* weight, const float* X_std,
                          const float* X_norm_unused, float* dX, float* dW, float* db_or_null,
                          int64_t rows, int64_t cols, nnhipStream_t stream);
+/* dX = RMSNorm gradient + dX_addend (NULL-able): folds the accumulation onto a gradient X already holds. */
+int nnhipRMSNormBackwardEx(const float* dY, const float* X, const float* weight, const float* X_std,
+                           const float* X_norm_unused, const float* dX_addend, float* dX, float* dW,
+                           float* db_or_null, int64_t rows, int64_t cols, nnhipStream_t stream);
 
 /* ---- a11 fused AdamW  (replaces FusedAdamWStep, fused_adamw.cu:58-71 -- one tensor) --------- */
 /* decay_mode 0: decoupled weight decay (AdamW, neunet/optim.py:52-69);

@@ -48,6 +48,7 @@ struct GemmParams {
     int cvec;             // 1: C/bias/preact rows are 16-B aligned and N % 4 == 0 -> float4 epilogue
     int act;
     float beta;
+    const float* addend;  // [M, ldc] or null: C = act(alpha*AB + bias + addend)  (residual / gradient accumulation)
     float* asum;          // CS variants: asum[m] = sum_k A[m,k] (Linear: db = column sums of dO, fused into dW = dO^T X)
     float* asum_slab;     // split-K partials [splitk][M]
 };
@@ -295,6 +296,10 @@ __global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const 
                     if (!to_slab) {
                         v.x = p.alpha * v.x + bv.x; v.y = p.alpha * v.y + bv.y;
                         v.z = p.alpha * v.z + bv.z; v.w = p.alpha * v.w + bv.w;
+                        if (p.addend) {
+                            const float4 r = *reinterpret_cast<const float4*>(p.addend + c_off + row * ldc + col);
+                            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                        }
                         if (p.act == ACT_SWISH) {
                             if (p.preact) *reinterpret_cast<float4*>(p.preact + c_off + row * ldc + col) = v;
                             v.x *= sigmoidf_(p.beta * v.x); v.y *= sigmoidf_(p.beta * v.y);
@@ -324,6 +329,7 @@ __global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const 
                 if (row >= p.M) continue;
                 float v = to_slab ? acc[i][n][e] : p.alpha * acc[i][n][e] + bv;
                 if (!to_slab) {
+                    if (p.addend) v += p.addend[c_off + row * ldc + col];
                     if (p.act == ACT_SWISH) {
                         if (p.preact) p.preact[c_off + row * ldc + col] = v;
                         v = v * sigmoidf_(p.beta * v);
@@ -344,7 +350,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
                                                             const float* __restrict__ bias,
                                                             int64_t M, int64_t N, int64_t ldc,
                                                             int splitk, int act, float beta, float alpha,
-                                                            const float* __restrict__ asum_slab, float* __restrict__ asum) {
+                                                            const float* __restrict__ asum_slab, float* __restrict__ asum,
+                                                            const float* __restrict__ addend) {
     const int64_t total = M * N;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     if (asum)
@@ -359,6 +366,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         s *= alpha;
         const int64_t m = i / N, n = i - m * N;
         if (bias) s += bias[n];
+        if (addend) s += addend[m * ldc + n];
         if (act == ACT_SWISH) {
             if (preact) preact[m * ldc + n] = s;
             s = s * sigmoidf_(beta * s);
@@ -390,7 +398,8 @@ static int launch_variant(const GemmParams& p, int64_t batch, hipStream_t st) {
 int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, float* preact, int64_t M,
                 int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, bool a_kmajor, bool b_kmajor,
                 int64_t batch1, int64_t sA, int64_t sB, int64_t sC, int64_t batch2, int64_t sA2,
-                int64_t sB2, int64_t sC2, float alpha, int act, float beta, hipStream_t st, float* asum = nullptr);
+                int64_t sB2, int64_t sC2, float alpha, int act, float beta, hipStream_t st, float* asum = nullptr,
+                const float* addend = nullptr);
 
 int gemm_f32(const float* A, const float* B, float* C, const float* bias, float* preact, int64_t M,
              int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, bool a_kmajor,
@@ -402,6 +411,13 @@ int gemm_f32(const float* A, const float* B, float* C, const float* bias, float*
 
 // C = A^T-view * B with asum[m] = sum_k A[m,k] produced by the same kernel (A outer-major, no batch):
 // Linear backward's dW = dO^T X and db = column sums of dO in one pass over dO.
+// C = A B + bias + addend (addend laid out like C): forward residual / dX accumulation onto an existing gradient.
+int gemm_f32_add(const float* A, const float* B, float* C, const float* bias, const float* addend, int64_t M, int64_t N,
+                 int64_t K, int64_t lda, int64_t ldb, int64_t ldc, bool a_kmajor, bool b_kmajor, hipStream_t st) {
+    return gemm_f32_ex(A, B, C, bias, nullptr, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, 1, 0, 0, 0, 1, 0, 0, 0, 1.0f,
+                       ACT_NONE, 1.f, st, nullptr, addend);
+}
+
 int gemm_f32_asum(const float* A, const float* B, float* C, float* asum, int64_t M, int64_t N, int64_t K, int64_t lda,
                   int64_t ldb, int64_t ldc, bool b_kmajor, hipStream_t st) {
     return gemm_f32_ex(A, B, C, nullptr, nullptr, M, N, K, lda, ldb, ldc, false, b_kmajor, 1, 0, 0, 0, 1, 0, 0, 0, 1.0f,
@@ -411,7 +427,8 @@ int gemm_f32_asum(const float* A, const float* B, float* C, float* asum, int64_t
 int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, float* preact, int64_t M,
                 int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, bool a_kmajor, bool b_kmajor,
                 int64_t batch1, int64_t sA, int64_t sB, int64_t sC, int64_t batch2, int64_t sA2,
-                int64_t sB2, int64_t sC2, float alpha, int act, float beta, hipStream_t st, float* asum) {
+                int64_t sB2, int64_t sC2, float alpha, int act, float beta, hipStream_t st, float* asum,
+                const float* addend) {
     const int64_t batch = batch1 * batch2;
     if (M <= 0 || N <= 0 || batch <= 0) return 0;
     if (asum && (a_kmajor || batch != 1 || K <= 0)) { set_last_error("gemm: asum needs an outer-major, unbatched A"); return NNHIP_EINVAL; }
@@ -426,7 +443,7 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
     p.tiles_n = (int)ceil_div(N, BN);
     p.act = act; p.beta = beta;
     p.splitk = 1; p.k_per_split = ceil_div(K > 0 ? K : 1, BK) * BK; p.slab = nullptr;
-    p.asum = asum; p.asum_slab = nullptr;
+    p.asum = asum; p.asum_slab = nullptr; p.addend = addend;
     p.zeros = zero_block();
     if (!p.zeros) { set_last_error("zero block allocation failed"); return NNHIP_ENOMEM; }
 
@@ -461,7 +478,7 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
         bool ok = (N & 3) == 0;
         if (slab) ok = ok && aligned16(p.slab);
         else ok = ok && aligned16(C) && (ldc & 3) == 0 && (batch1 <= 1 || (sC & 3) == 0) && (batch2 <= 1 || (sC2 & 3) == 0) &&
-                  (!bias || aligned16(bias)) && (!preact || aligned16(preact));
+                  (!bias || aligned16(bias)) && (!preact || aligned16(preact)) && (!addend || aligned16(addend));
         p.cvec = ok ? 1 : 0;
     }
 
@@ -488,7 +505,7 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
         const int64_t total = M * N;
         int blocks = (int)(ceil_div(total, 256) < 2048 ? ceil_div(total, 256) : 2048);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.slab, C, preact,
-                           bias, M, N, ldc, p.splitk, act, beta, alpha, p.asum_slab, asum);
+                           bias, M, N, ldc, p.splitk, act, beta, alpha, p.asum_slab, asum, addend);
         NNHIP_LAUNCH_CHECK("splitk_reduce_kernel");
     }
     return 0;

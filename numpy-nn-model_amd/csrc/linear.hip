@@ -8,6 +8,8 @@ int gemm_f32(const float* A, const float* B, float* C, const float* bias, float*
              int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, bool a_kmajor,
              bool b_kmajor, int64_t batch, int64_t sA, int64_t sB, int64_t sC, int act, float beta,
              hipStream_t st);
+int gemm_f32_add(const float* A, const float* B, float* C, const float* bias, const float* addend, int64_t M, int64_t N,
+                 int64_t K, int64_t lda, int64_t ldb, int64_t ldc, bool a_kmajor, bool b_kmajor, hipStream_t st);
 int gemm_f32_asum(const float* A, const float* B, float* C, float* asum, int64_t M, int64_t N, int64_t K, int64_t lda,
                   int64_t ldb, int64_t ldc, bool b_kmajor, hipStream_t st);
 int colsum(const float* X, int64_t rows, int64_t cols, int64_t ld, float* out, hipStream_t st);
@@ -16,7 +18,7 @@ int fill_f32(float* p, float v, int64_t n, hipStream_t st);
 enum { ACT_NONE = 0, ACT_SWISH = 1, ACT_RELU = 2 };
 
 static int linear_backward(const float* X, const float* W, const float* dO, float* dX, float* dW,
-                           float* db, int64_t rows, int64_t in, int64_t out, hipStream_t st) {
+                           float* db, int64_t rows, int64_t in, int64_t out, hipStream_t st, const float* dX_addend = nullptr) {
     int rc = 0;
     if (rows == 0) {  // empty batch: sums over nothing are zero (X / dO / dX may be null pointers of empty arrays)
         if (dW) rc = fill_f32(dW, 0.f, out * in, st);
@@ -24,7 +26,7 @@ static int linear_backward(const float* X, const float* W, const float* dO, floa
         return rc;
     }
     // dX[rows,in] = dO[rows,out] * W[out,in]         A k-major (k = out), B outer-major
-    if (dX) rc = gemm_f32(dO, W, dX, nullptr, nullptr, rows, in, out, out, in, in, true, false, 1, 0, 0, 0, ACT_NONE, 1.f, st);
+    if (dX) rc = gemm_f32_add(dO, W, dX, nullptr, dX_addend, rows, in, out, out, in, in, true, false, st);
     if (rc) return rc;
     // dW[out,in] = dO^T[out,rows] * X[rows,in]        both outer-major (k = rows)
     // db[out] = sum_rows dO rides in the same kernel (each thread sums the dO elements it stages): one pass over dO
@@ -47,19 +49,33 @@ static int check_linear(const char* fn, const void* X, const void* W, int64_t ro
 extern "C" int nnhipLinearModuleForward(const float* X, const float* W, const float* b, float* O,
                                         int64_t rows, int64_t in_features, int64_t out_features,
                                         nnhipStream_t stream) {
+    return nnhipLinearModuleForwardEx(X, W, b, nullptr, O, rows, in_features, out_features, stream);
+}
+
+extern "C" int nnhipLinearModuleForwardEx(const float* X, const float* W, const float* b, const float* addend,
+                                          float* O, int64_t rows, int64_t in_features, int64_t out_features,
+                                          nnhipStream_t stream) {
     if (int rc = check_linear("nnhipLinearModuleForward", X, W, rows, in_features, out_features)) return rc;
     if (rows == 0) return 0;
     NNHIP_CHECK_ARG(O != nullptr, NNHIP_EINVAL, "nnhipLinearModuleForward: null output");
-    return gemm_f32(X, W, O, b, nullptr, rows, out_features, in_features, in_features, in_features,
-                    out_features, true, true, 1, 0, 0, 0, ACT_NONE, 1.f, (hipStream_t)stream);
+    NNHIP_CHECK_ARG(aligned4(addend), NNHIP_EALIGN, "nnhipLinearModuleForward: misaligned addend");
+    return gemm_f32_add(X, W, O, b, addend, rows, out_features, in_features, in_features, in_features,
+                        out_features, true, true, (hipStream_t)stream);
 }
 
 extern "C" int nnhipLinearModuleBackward(const float* X, const float* W, const float* dO, float* dX,
                                          float* dW, float* db, int64_t rows, int64_t in_features,
                                          int64_t out_features, nnhipStream_t stream) {
+    return nnhipLinearModuleBackwardEx(X, W, dO, nullptr, dX, dW, db, rows, in_features, out_features, stream);
+}
+
+extern "C" int nnhipLinearModuleBackwardEx(const float* X, const float* W, const float* dO, const float* dX_addend,
+                                           float* dX, float* dW, float* db, int64_t rows, int64_t in_features,
+                                           int64_t out_features, nnhipStream_t stream) {
     if (int rc = check_linear("nnhipLinearModuleBackward", X, W, rows, in_features, out_features)) return rc;
     NNHIP_CHECK_ARG(rows == 0 || dO != nullptr, NNHIP_EINVAL, "nnhipLinearModuleBackward: null dO");
-    return linear_backward(X, W, dO, dX, dW, db, rows, in_features, out_features, (hipStream_t)stream);
+    NNHIP_CHECK_ARG(aligned4(dX_addend), NNHIP_EALIGN, "nnhipLinearModuleBackward: misaligned dX_addend");
+    return linear_backward(X, W, dO, dX, dW, db, rows, in_features, out_features, (hipStream_t)stream, dX_addend);
 }
 
 extern "C" int nnhipLinearSwishForward(const float* X, const float* W, const float* b, float* O,

@@ -288,7 +288,7 @@ template <int TPR, int NV, bool VEC>
 __global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void rmsnorm_bwd_rows(
     const float* __restrict__ dY, const float* __restrict__ X, const float* __restrict__ w,
     const float* __restrict__ Xstd, float* __restrict__ dX, float* __restrict__ part_dw,
-    float* __restrict__ part_db, int64_t rows, int64_t cols) {
+    float* __restrict__ part_db, int64_t rows, int64_t cols, const float* __restrict__ dXadd) {
     __shared__ float red[32];
     constexpr int RPB = (TPR >= 256) ? 1 : 256 / TPR;
     constexpr int NW = TPR / 64;
@@ -337,6 +337,12 @@ __global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void rmsnorm_bwd_rows(
                 g0.x[e] = (g0.x[e] * sd0 - x0.x[e] * s0) * q0;
                 g1.x[e] = (g1.x[e] * sd1 - x1.x[e] * s1) * q1;
             }
+            if (dXadd) {   // dX = rmsnorm gradient + an already accumulated gradient of X (x0/x1 are dead: reuse them)
+                x0.load(dXadd + r0 * cols, cols, t, 0.f);
+                if (has1) x1.load(dXadd + r1 * cols, cols, t, 0.f);
+#pragma unroll
+                for (int e = 0; e < x0.NE; ++e) { g0.x[e] += x0.x[e]; g1.x[e] += x1.x[e]; }
+            }
             g0.store(dX + r0 * cols, cols, t);
             if (has1) g1.store(dX + r1 * cols, cols, t);
         }
@@ -359,6 +365,11 @@ __global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void rmsnorm_bwd_rows(
             const float q0 = i0 * i0;
 #pragma unroll
             for (int e = 0; e < x0.NE; ++e) g0.x[e] = (g0.x[e] * sd0 - x0.x[e] * s0) * q0;
+            if (dXadd) {
+                x0.load(dXadd + r0 * cols, cols, t, 0.f);
+#pragma unroll
+                for (int e = 0; e < x0.NE; ++e) g0.x[e] += x0.x[e];
+            }
             g0.store(dX + r0 * cols, cols, t);
         }
     }
@@ -670,6 +681,13 @@ extern "C" int nnhipRMSNormBackward(const float* dY, const float* X, const float
                                     const float* X_std, const float* X_norm_unused, float* dX,
                                     float* dW, float* db, int64_t rows, int64_t cols,
                                     nnhipStream_t s) {
+    return nnhipRMSNormBackwardEx(dY, X, weight, X_std, X_norm_unused, nullptr, dX, dW, db, rows, cols, s);
+}
+
+extern "C" int nnhipRMSNormBackwardEx(const float* dY, const float* X, const float* weight,
+                                      const float* X_std, const float* X_norm_unused, const float* dX_addend,
+                                      float* dX, float* dW, float* db, int64_t rows, int64_t cols,
+                                      nnhipStream_t s) {
     (void)X_norm_unused;
     NNHIP_CHECK_ARG(rows >= 0 && cols >= 0, NNHIP_EINVAL, "nnhipRMSNormBackward: negative size");
     if (cols == 0) return 0;
@@ -695,11 +713,11 @@ extern "C" int nnhipRMSNormBackward(const float* dY, const float* X, const float
     float* part_db = db ? part + part_floats : nullptr;
     float* scr_dw = part + part_floats * nred;
     float* scr_db = scr_dw + scr;
-    const bool vec = aligned16(dY) && aligned16(X) && aligned16(weight) && aligned16(dX) && cols % 4 == 0;
+    const bool vec = aligned16(dY) && aligned16(X) && aligned16(weight) && aligned16(dX) && aligned16(dX_addend) && cols % 4 == 0;
     {
         const int64_t rows_ = rows;
         // ROW_LAUNCH computes its grid from `rows`; we want exactly nblk blocks -> pass nblk*rpb.
-        ROW_DISPATCH(rmsnorm_bwd_rows, cols, vec, prow, st, dY, X, weight, X_std, dX, part_dw, part_db, rows_, cols);
+        ROW_DISPATCH(rmsnorm_bwd_rows, cols, vec, prow, st, dY, X, weight, X_std, dX, part_dw, part_db, rows_, cols, dX_addend);
     }
     NNHIP_LAUNCH_CHECK("rmsnorm_backward");
     // finish dw/db: column sums over the `prow` partial rows

@@ -41,6 +41,8 @@ _SIGNATURES = {
     "nnhipCleanup": (ctypes.c_int, []),
     "nnhipLinearModuleForward": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_void_p]),
     "nnhipLinearModuleBackward": (ctypes.c_int, [P, P, P, P, P, P, c_int64, c_int64, c_int64, c_void_p]),
+    "nnhipLinearModuleForwardEx": (ctypes.c_int, [P, P, P, P, P, c_int64, c_int64, c_int64, c_void_p]),
+    "nnhipLinearModuleBackwardEx": (ctypes.c_int, [P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_void_p]),
     "nnhipLinearSwishForward": (ctypes.c_int, [P, P, P, P, P, c_int64, c_int64, c_int64, c_float, ctypes.c_int, c_void_p]),
     "nnhipLinearSwishBackward": (ctypes.c_int, [P, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_float, ctypes.c_int, c_void_p]),
     "nnhipGemmF32": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, ctypes.c_int, ctypes.c_int,
@@ -67,6 +69,7 @@ _SIGNATURES = {
     "nnhipReduceLoss": (ctypes.c_int, [P, c_int64, c_char, P, P, c_void_p]),
     "nnhipRMSNormForward": (ctypes.c_int, [P, P, P, P, P, P, c_int64, c_int64, c_float, c_void_p]),
     "nnhipRMSNormBackward": (ctypes.c_int, [P, P, P, P, P, P, P, P, c_int64, c_int64, c_void_p]),
+    "nnhipRMSNormBackwardEx": (ctypes.c_int, [P, P, P, P, P, P, P, P, P, c_int64, c_int64, c_void_p]),
     "nnhipFusedAdamWStep": (ctypes.c_int, [P, P, P, P, c_double, c_double, c_double, c_double, c_double, c_int32, c_int64, c_int32, c_float, c_void_p]),
     "nnhipCreateFusedOptimizer": (c_void_p, []),
     "nnhipDestroyFusedOptimizer": (ctypes.c_int, [c_void_p]),

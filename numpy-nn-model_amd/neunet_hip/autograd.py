@@ -210,6 +210,14 @@ class Tensor:
         else:
             self.grad = add_arrays(self.grad, grad)
 
+    def foldable_grad(self):
+        """The gradient this tensor already holds, if a kernel can fold it into the next one it produces
+        (out = new + held, written to a fresh buffer): same shape, contiguous.  None otherwise."""
+        g = self.grad
+        if g is None or isinstance(g, np.ndarray) or tuple(g.shape) != tuple(self.data.shape) or not g.is_contiguous():
+            return None
+        return g
+
     def backward(self, grad=None):
         """autograd.py:965-1002."""
         if not self.requires_grad:

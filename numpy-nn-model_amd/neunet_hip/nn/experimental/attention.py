@@ -146,12 +146,13 @@ class HIPMultiHeadAttention(Module):
         self.wv = HIPLinear(d_model, d_model, device=device)
         self.fc = HIPLinear(d_model, d_model, device=device)
 
-    def forward(self, q: Tensor, k: Tensor, v: Tensor, key_valid=None, causal=True, need_weights=True):
+    def forward(self, q: Tensor, k: Tensor, v: Tensor, key_valid=None, causal=True, need_weights=True, residual=None):
         """key_valid: int32 device array [B,Tk] (1 = real token, 0 = padding) or None.  The notebook's dense
         mask get_pad_mask(x) & get_sub_mask(x) (cell 7) is exactly (key_valid, causal=True).
 
         need_weights=False (training steps that never look at the attention map) takes the fused flash-style
-        kernels when head_dim == 64 and returns (out, None): scores/attn/dattn are never written to HBM."""
+        kernels when head_dim == 64 and returns (out, None): scores/attn/dattn are never written to HBM.
+        residual (extension): out = residual + fc(ctx), folded into the output projection's epilogue."""
         if self.dropout.p != 0 and self.dropout.training:
             raise NotImplementedError("attention dropout > 0 is not implemented on the HIP path yet")
         qp, kp, vp = self.wq(q), self.wk(k), self.wv(v)
@@ -159,8 +160,8 @@ class HIPMultiHeadAttention(Module):
             ctx, lse = fused_attention_forward(qp.data, kp.data, vp.data, key_valid, self.n_heads, self.scale, causal)
             ctx_t = _HIPFusedAttentionTensor(ctx, (qp, kp, vp, lse, key_valid, self.n_heads, self.scale, causal),
                                              "fused_attention", device="cuda")
-            return self.fc(ctx_t), None
+            return self.fc(ctx_t, residual=residual), None
         ctx, attn = attention_forward(qp.data, kp.data, vp.data, key_valid, self.n_heads, self.scale, causal)
         ctx_t = _HIPAttentionTensor(ctx, (qp, kp, vp, attn, key_valid, self.n_heads, self.scale, causal),
                                     "attention", device="cuda")
-        return self.fc(ctx_t), attn
+        return self.fc(ctx_t, residual=residual), attn

@@ -15,18 +15,25 @@ from ..parameter import Parameter
 from .utils import call_hip_function, get_current_stream_ptr
 
 
-def hip_linear_module_forward(X, weights, bias, O, input_rows, input_cols, output_cols):
-    """cuda_linear_module_forward (linear.py:70-92) -> nnhipLinearModuleForward."""
-    return call_hip_function("nnhipLinearModuleForward", X, weights, bias, O, input_rows, input_cols,
+def hip_linear_module_forward(X, weights, bias, O, input_rows, input_cols, output_cols, addend=None):
+    """cuda_linear_module_forward (linear.py:70-92) -> nnhipLinearModuleForward[Ex].
+    addend (same shape as O): O = X W^T + b + addend, folded into the GEMM epilogue."""
+    if addend is None:
+        return call_hip_function("nnhipLinearModuleForward", X, weights, bias, O, input_rows, input_cols,
+                                 output_cols, get_current_stream_ptr())
+    return call_hip_function("nnhipLinearModuleForwardEx", X, weights, bias, addend, O, input_rows, input_cols,
                              output_cols, get_current_stream_ptr())
 
 
 def hip_linear_module_backward(X, weights, grad_O, grad_X, grad_weight, grad_bias, input_rows, input_cols,
-                               output_cols):
-    """cuda_linear_module_backward (linear.py:95-120) -> nnhipLinearModuleBackward.
-    grad_X / grad_weight / grad_bias may be None (skipped)."""
-    return call_hip_function("nnhipLinearModuleBackward", X, weights, grad_O, grad_X, grad_weight, grad_bias,
-                             input_rows, input_cols, output_cols, get_current_stream_ptr())
+                               output_cols, grad_X_addend=None):
+    """cuda_linear_module_backward (linear.py:95-120) -> nnhipLinearModuleBackward[Ex].
+    grad_X / grad_weight / grad_bias may be None (skipped); grad_X_addend: grad_X = dO W + addend."""
+    if grad_X_addend is None:
+        return call_hip_function("nnhipLinearModuleBackward", X, weights, grad_O, grad_X, grad_weight, grad_bias,
+                                 input_rows, input_cols, output_cols, get_current_stream_ptr())
+    return call_hip_function("nnhipLinearModuleBackwardEx", X, weights, grad_O, grad_X_addend, grad_X, grad_weight,
+                             grad_bias, input_rows, input_cols, output_cols, get_current_stream_ptr())
 
 
 def _grad_out(param, shape_like):
@@ -42,15 +49,23 @@ class _HIPLinearTensor(Tensor):
     def __init__(self, data, args, op, device):
         super().__init__(data, args, op, device=device, _nocopy=True)
 
-        def grad_fn(X: Tensor, weight: Tensor, bias, in_rows_num, in_features, out_features, grad):
+        def grad_fn(X: Tensor, weight: Tensor, bias, in_rows_num, in_features, out_features, residual, grad):
             grad = grad if grad.is_contiguous() else grad.contiguous()
+            if residual is not None:
+                residual.apply_grad(grad)       # d(x + linear(h))/dx = 1: the same buffer, by reference
             grad_X = X.xp.empty_like(X.data, dtype=np.float32) if X.requires_grad else None
+            # a gradient X already received (e.g. q/k/v projections sharing one input) is folded into the dX GEMM's
+            # epilogue instead of a separate accumulation pass (neunet/autograd.py:85-93 allocates and adds)
+            held = X.foldable_grad() if grad_X is not None else None
             grad_weight = _grad_out(weight, weight.data)
             grad_bias = _grad_out(bias, bias.data) if bias is not None else None
             hip_linear_module_backward(X.data, weight.data, grad, grad_X, grad_weight, grad_bias,
-                                       in_rows_num, in_features, out_features)
+                                       in_rows_num, in_features, out_features, grad_X_addend=held)
             if grad_X is not None:
-                X.apply_grad(grad_X)
+                if held is not None:
+                    X.grad = grad_X
+                else:
+                    X.apply_grad(grad_X)
             weight.apply_grad(grad_weight)
             if bias is not None:
                 bias.apply_grad(grad_bias)
@@ -75,7 +90,9 @@ class HIPLinear(Module):
             self.bias = None
         self.to(device)
 
-    def forward(self, X: Tensor) -> Tensor:
+    def forward(self, X: Tensor, residual: Union[Tensor, None] = None) -> Tensor:
+        """residual (extension, same shape as the output): returns residual + linear(X) from one kernel -- the
+        `x = x + sublayer(...)` of a pre-norm block without the separate add pass."""
         if not isinstance(X, Tensor):
             raise TypeError("Input must be a tensor")
         if X.device != self.device:
@@ -89,12 +106,22 @@ class HIPLinear(Module):
         xdata = X.data if X.data.is_contiguous() else X.data.contiguous()
         output = X.xp.empty(X.shape[:-1] + (self.out_features,), dtype=np.float32)
         input_rows = int(np.prod(X.shape[:-1]))
+        addend = None
+        if residual is not None:
+            if not isinstance(residual, Tensor) or tuple(residual.shape) != tuple(output.shape) or residual.dtype != "float32":
+                raise ValueError("residual must be a float32 tensor of the output's shape")
+            addend = residual.data if residual.data.is_contiguous() else residual.data.contiguous()
         hip_linear_module_forward(xdata, self.weight.data, self.bias.data if self.bias is not None else None,
-                                  output, input_rows, self.in_features, self.out_features)
+                                  output, input_rows, self.in_features, self.out_features, addend=addend)
         if xdata is not X.data:
             X = _ContiguousView(X, xdata)
-        return _HIPLinearTensor(output, (X, self.weight, self.bias, input_rows, self.in_features,
-                                         self.out_features), "linear", device=self.device)
+        if residual is not None and not residual.requires_grad:
+            residual = None
+        args = (X, self.weight, self.bias, input_rows, self.in_features, self.out_features, residual)
+        out = _HIPLinearTensor(output, args, "linear", device=self.device)
+        if residual is not None:
+            out.requires_grad = True
+        return out
 
 
 class _ContiguousView(Tensor):

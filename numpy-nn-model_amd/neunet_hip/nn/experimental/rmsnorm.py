@@ -27,8 +27,8 @@ def rmsnorm_forward(X, weight, bias, X_norm, X_std, O, eps: float):
     return O, X_norm, X_std
 
 
-def rmsnorm_backward(X, weight, bias, grad_O, grad_X, grad_weight, grad_bias, X_norm, X_std):
-    """rmsnorm.py:100-153."""
+def rmsnorm_backward(X, weight, bias, grad_O, grad_X, grad_weight, grad_bias, X_norm, X_std, grad_X_addend=None):
+    """rmsnorm.py:100-153.  grad_X_addend (extension): grad_X = rmsnorm gradient + addend in the same pass."""
     if X.shape != grad_O.shape:
         raise ValueError("Input and output shapes must match")
     if grad_X.shape != X.shape:
@@ -39,8 +39,13 @@ def rmsnorm_backward(X, weight, bias, grad_O, grad_X, grad_weight, grad_bias, X_
         raise ValueError("Bias and bias gradient shapes must match")
     n_cols = X.shape[-1]
     n_rows = X.numel() // n_cols if n_cols else 0
-    call_hip_function("nnhipRMSNormBackward", contiguous(grad_O), contiguous(X), contiguous(weight), X_std,
-                      X_norm, grad_X, grad_weight, grad_bias, n_rows, n_cols, get_current_stream_ptr())
+    if grad_X_addend is None:
+        call_hip_function("nnhipRMSNormBackward", contiguous(grad_O), contiguous(X), contiguous(weight), X_std,
+                          X_norm, grad_X, grad_weight, grad_bias, n_rows, n_cols, get_current_stream_ptr())
+    else:
+        call_hip_function("nnhipRMSNormBackwardEx", contiguous(grad_O), contiguous(X), contiguous(weight), X_std,
+                          X_norm, grad_X_addend, grad_X, grad_weight, grad_bias, n_rows, n_cols,
+                          get_current_stream_ptr())
     return grad_X, grad_weight, grad_bias
 
 
@@ -52,9 +57,13 @@ class _HIPRMSNormTensor(Tensor):
             grad_X = X.xp.empty_like(X.data, dtype=np.float32)
             grad_weight = _grad_out(weight, weight.data)
             grad_bias = _grad_out(bias, bias.data) if bias is not None else None
+            held = X.foldable_grad() if X.requires_grad else None   # e.g. the residual branch's gradient
             rmsnorm_backward(X.data, weight.data, bias.data if bias is not None else None, grad, grad_X,
-                             grad_weight, grad_bias, X_norm, X_std)
-            X.apply_grad(grad_X)
+                             grad_weight, grad_bias, X_norm, X_std, grad_X_addend=held)
+            if held is not None:
+                X.grad = grad_X
+            else:
+                X.apply_grad(grad_X)
             weight.apply_grad(grad_weight)
             if bias is not None:
                 bias.apply_grad(grad_bias)

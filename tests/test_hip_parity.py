@@ -90,6 +90,50 @@ def test_linear_vs_oracle(hip, rows, inf, outf, bias):
         np.testing.assert_allclose(host(layer.bias.grad), db, rtol=1e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize("rows,inf,outf", [(300, 96, 200), (128, 512, 512), (37, 50, 33), (4096, 1024, 128)])
+def test_linear_addend_extensions(hip, rows, inf, outf):
+    """nnhipLinearModuleForwardEx / BackwardEx: O = XW^T + b + R and dX = dO W + G from the GEMM epilogue (also through
+    the split-K reduce and the scalar epilogue), db produced by the dW GEMM; host level: residual= and the folding of a
+    gradient X already holds give exactly what `x + linear(h)` and Tensor.apply_grad's accumulation give."""
+    import neunet_hip.nn as nn
+    rng = np.random.default_rng(rows + inf)
+    lin = nn.Linear(inf, outf)
+    W, b = host(lin.weight.data), host(lin.bias.data)
+    X = rng.standard_normal((rows, inf)).astype(np.float32)
+    R = rng.standard_normal((rows, outf)).astype(np.float32)
+    dY = rng.standard_normal((rows, outf)).astype(np.float32)
+    G = rng.standard_normal((rows, inf)).astype(np.float32)
+    x, r = T(hip, X), T(hip, R)
+    x.grad = dev(G)                                   # a gradient x received earlier in the backward pass
+    y = lin(x, residual=r)
+    np.testing.assert_allclose(host(y.data), O.linear_forward(X, W, b) + R, **TOL)
+    y.backward(dY)
+    dX, dW, db = O.linear_backward(X, W, b, dY)
+    np.testing.assert_allclose(host(x.grad), dX + G, rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(host(r.grad), dY, rtol=0, atol=0)
+    np.testing.assert_allclose(host(lin.weight.grad), dW, rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(host(lin.bias.grad), db.reshape(1, -1), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("rows,cols", [(64, 512), (33, 100), (16, 4096), (8, 12000)])
+def test_rmsnorm_backward_addend(hip, rows, cols):
+    import neunet_hip.nn as nn
+    rng = np.random.default_rng(rows + cols)
+    X = rng.standard_normal((rows, cols)).astype(np.float32)
+    dY = rng.standard_normal((rows, cols)).astype(np.float32)
+    G = rng.standard_normal((rows, cols)).astype(np.float32)
+    norm = nn.RMSNorm(cols)
+    norm.weight.data.copy_(dev(rng.standard_normal(cols).astype(np.float32)))
+    w = host(norm.weight.data)
+    x = T(hip, X)
+    x.grad = dev(G)
+    y = norm(x)
+    y.backward(dY)
+    dX, dw, _ = O.rmsnorm_backward(X, w, False, dY, 1e-6)
+    np.testing.assert_allclose(host(x.grad), dX + G, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(host(norm.weight.grad), dw, rtol=1e-4, atol=1e-3)
+
+
 def test_linear_transpose_detecting(hip):
     """A = I against an asymmetric B catches a swapped C-write (guide rule 16)."""
     from neunet_hip.nn.experimental import HIPLinear
