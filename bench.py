@@ -112,7 +112,8 @@ def workload_c2(args, rank, world):
     X = neunet_hip.Tensor(drng.uniform(-1, 1, (Bsz, D)).astype(np.float32), device="cuda", requires_grad=True)
     dO = torch.from_numpy(drng.uniform(-1, 1, (Bsz, D)).astype(np.float32)).cuda()
     params = layer.parameters()
-    bucket = GradBucket(params)
+    # N > 1: dW/db are computed first and their all-reduce is launched asynchronously, under the dX GEMM
+    bucket = GradBucket(params, overlap=world > 1)
     opt = HIPFusedMultiTensorAdamW(params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
     opt.grad_scale = 1.0 / world
     fwd_t, bwd_t = EventTimer(), EventTimer()

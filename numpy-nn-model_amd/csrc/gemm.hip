@@ -23,6 +23,8 @@
 //     tiles to fill 256 CUs (e.g. dW = dO^T X with a 16384-long reduction at GPT-tiny).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace nnhip {
@@ -129,6 +131,76 @@ __device__ __forceinline__ void frag(float (&f)[4], const float* __restrict__ S,
     }
 }
 
+// K loop.  One basic block per iteration; the issue order is pinned with sched_group_barrier so that the
+// 2*BK/8 global loads of tile t+1 ride in the shadow of the first MFMAs of tile t (one load per 64-cycle
+// MFMA) and the 2*BK/8 LDS stores in the shadow of the last ones -- the ablation (profiles/) showed the
+// un-interleaved load + store phases costing 13 % of the loop while ds_reads and the barrier were free.
+// SUM: also accumulate the staged A elements into cs (row sums of A).
+// (A generic lambda here cost 30 %: the accumulators left their registers.  Keep it a forceinline function.)
+template <int BK, bool AKC, bool BKC, bool VEC, bool SUM>
+__device__ __forceinline__ void gemm_k_loop(f32x16 (&acc)[2][2], float4 (&ra)[BK / 8], float4 (&rb)[BK / 8], float4& cs,
+                                            float* __restrict__ smem, const float* __restrict__ A,
+                                            const float* __restrict__ B, const GemmParams& p, int nk, int64_t kbeg,
+                                            int64_t kend, int64_t m0, int64_t n0, int tid, int wm, int wn, int l31,
+                                            int lh, const float* __restrict__ Z) {
+    using TA = Tile<BK, AKC>;
+    using TB = Tile<BK, BKC>;
+    constexpr int STAGE = TA::SIZE + TB::SIZE;
+    constexpr int NLD = 2 * (BK / 8);          // float4 loads (= LDS stores) per thread per tile
+    constexpr int NMF = 16 * (BK / 8);         // MFMAs per wave per tile
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        const int64_t k0 = kbeg + (int64_t)(kt + 1) * BK;
+        if constexpr (SUM) {
+            // ra still holds tile kt (its LDS store at the end of the previous iteration already waited for the
+            // loads): summing it HERE costs no extra vmcnt wait; summing it next to the loads stalled the MFMA pipe.
+#pragma unroll
+            for (int q = 0; q < BK / 8; ++q) { cs.x += ra[q].x; cs.y += ra[q].y; cs.z += ra[q].z; cs.w += ra[q].w; }
+        }
+        g2r<BK, AKC, VEC>(ra, A, p.lda, p.M, kend, m0, k0, tid, more, Z);
+        g2r<BK, BKC, VEC>(rb, B, p.ldb, p.N, kend, n0, k0, tid, more, Z);
+        const float* As = smem + cur * STAGE;
+        const float* Bs = As + TA::SIZE;
+#pragma unroll
+        for (int g = 0; g < BK / 8; ++g) {
+            float a[2][4], b[2][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                frag<BK, AKC>(a[i], As, wm * 64 + i * 32 + l31, g, lh);
+                frag<BK, BKC>(b[i], Bs, wn * 64 + i * 32 + l31, g, lh);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[n][j], acc[i][n],
+                                                                         0, 0, 0);
+        }
+        {   // next tile -> other LDS stage (stores of zeros on the last iteration are harmless)
+            float* Sn = smem + (cur ^ 1) * STAGE;
+            r2s<BK, AKC>(ra, Sn, tid);
+            r2s<BK, BKC>(rb, Sn + TA::SIZE, tid);
+        }
+        // ---- issue-order pipeline for this iteration's scheduling region --------------------------------
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NMF - 2 * NLD, 0);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // 1 DS write
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
 // CS (outer-major A only): every thread also accumulates the A elements it stages -- with the [BK][128] tile layout a
 // thread owns the same 4 A rows (m) in every k-tile -- and the tile_n == 0 blocks reduce them to asum[m] = sum_k A[m,k].
 template <int BK, bool AKC, bool BKC, bool VEC, bool CS = false>
@@ -136,8 +208,6 @@ __global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const 
     static_assert(!CS || !AKC, "row sums of A are only implemented for an outer-major A");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     using TA = Tile<BK, AKC>;
-    using TB = Tile<BK, BKC>;
-    constexpr int STAGE = TA::SIZE + TB::SIZE;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -187,67 +257,12 @@ __global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const 
     r2s<BK, AKC>(ra, smem, tid);
     r2s<BK, BKC>(rb, smem + TA::SIZE, tid);
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
-    if constexpr (CS) {
-#pragma unroll
-        for (int q = 0; q < BK / 8; ++q) { cs.x += ra[q].x; cs.y += ra[q].y; cs.z += ra[q].z; cs.w += ra[q].w; }
-    }
     __syncthreads();
 
-    // K loop.  One basic block per iteration; the issue order is pinned with sched_group_barrier so that the
-    // 2*BK/8 global loads of tile t+1 ride in the shadow of the first MFMAs of tile t (one load per 64-cycle
-    // MFMA) and the 2*BK/8 LDS stores in the shadow of the last ones -- the ablation (profiles/) showed the
-    // un-interleaved load + store phases costing 13 % of the loop while ds_reads and the barrier were free.
-    constexpr int NLD = 2 * (BK / 8);          // float4 loads (= LDS stores) per thread per tile
-    constexpr int NMF = 16 * (BK / 8);         // MFMAs per wave per tile
-    int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = kt + 1 < nk;
-        const int64_t k0 = kbeg + (int64_t)(kt + 1) * BK;
-        g2r<BK, AKC, VEC>(ra, A, p.lda, p.M, kend, m0, k0, tid, more, Z);
-        g2r<BK, BKC, VEC>(rb, B, p.ldb, p.N, kend, n0, k0, tid, more, Z);
-        const float* As = smem + cur * STAGE;
-        const float* Bs = As + TA::SIZE;
-#pragma unroll
-        for (int g = 0; g < BK / 8; ++g) {
-            float a[2][4], b[2][4];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                frag<BK, AKC>(a[i], As, wm * 64 + i * 32 + l31, g, lh);
-                frag<BK, BKC>(b[i], Bs, wn * 64 + i * 32 + l31, g, lh);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n)
-                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[n][j], acc[i][n],
-                                                                         0, 0, 0);
-        }
-        {   // next tile -> other LDS stage (stores of zeros on the last iteration are harmless)
-            float* Sn = smem + (cur ^ 1) * STAGE;
-            r2s<BK, AKC>(ra, Sn, tid);
-            r2s<BK, BKC>(rb, Sn + TA::SIZE, tid);
-            if constexpr (CS) {
-#pragma unroll
-                for (int q = 0; q < BK / 8; ++q) { cs.x += ra[q].x; cs.y += ra[q].y; cs.z += ra[q].z; cs.w += ra[q].w; }
-            }
-        }
-        // ---- issue-order pipeline for this iteration's scheduling region --------------------------------
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, NMF - 2 * NLD, 0);
-#pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // 1 DS write
-        }
-        __syncthreads();
-        cur ^= 1;
-    }
+    // (running a sum-free copy of the loop in the tile_n != 0 blocks was tried: two inlined copies made the CS kernel
+    // 15 % slower; the row sums cost ~4 % of the loop, so linear.hip only asks for them when a separate column-sum
+    // pass over dO would cost more.)
+    gemm_k_loop<BK, AKC, BKC, VEC, CS>(acc, ra, rb, cs, smem, A, B, p, nk, kbeg, kend, m0, n0, tid, wm, wn, l31, lh, Z);
 
     // ---- epilogue ------------------------------------------------------------------------------------------
     // acc register e of a 32x32 MFMA tile holds row (e&3) + 8*(e>>2) + 4*lh, column l31: a lane owns a strided

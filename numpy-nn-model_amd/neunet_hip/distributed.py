@@ -6,6 +6,13 @@ straight into their bucket slot (`param._grad_slot`, see experimental/linear.py:
 is no pack copy; after `all_reduce()` each `param.grad` is a view of the reduced bucket and the fused
 optimizer folds the 1/world (or 1/global_count) scale into its load (`grad_scale`).
 
+With `overlap=True` the bucket is cut into segments (in reverse parameter order, i.e. the order gradients
+arrive in) and each segment's all-reduce is launched asynchronously the moment its last gradient has been
+written: layers compute their parameter gradients BEFORE their input gradient (experimental/linear.py), so
+the exchange of dW rides under the dX GEMM and the rest of the backward pass; `all_reduce()` then only
+launches what is left and waits.  RCCL runs the collective on its own stream, ordered after the producing
+kernels by an event.
+
 Backend: torch.distributed -- "nccl" is RCCL on ROCm (xGMI); "gloo" for the CPU tests.
 """
 from __future__ import annotations
@@ -38,9 +45,12 @@ def init_process_group(backend: str | None = None):
 class GradBucket:
     """Flat gradient bucket over `params` (any objects with .data (torch tensor) and .grad)."""
 
-    def __init__(self, params, extra_scalars: int = 0):
+    def __init__(self, params, extra_scalars: int = 0, overlap: bool = False, segment_bytes: int = 32 << 20,
+                 group=None):
         import torch
         self.params = list(params)
+        self.overlap = overlap
+        self.group = group
         self.sizes = [int(p.data.numel()) for p in self.params]
         # 16-B aligned slots so the float4 kernels stay on their vector path
         self.offsets, off = [], 0
@@ -55,11 +65,66 @@ class GradBucket:
         self.views = [self.flat[o: o + s].view(p.data.shape) for o, s, p in zip(self.offsets, self.sizes, self.params)]
         for p, v in zip(self.params, self.views):
             p._grad_slot = v
+        # ---- overlap: segments of >= segment_bytes, walking the parameters backwards ----------------------
+        self.segments = []        # (lo, hi, [param indices])  -- flat[lo:hi]
+        self._seg_of = {}
+        self._pending, self._works, self._launched = [], [], []
+        if overlap:
+            hi, idxs = self.extra_offset, []
+            for i in range(len(self.params) - 1, -1, -1):
+                idxs.append(i)
+                if (hi - self.offsets[i]) * 4 >= segment_bytes or i == 0:
+                    self.segments.append((self.offsets[i], hi, idxs))
+                    hi, idxs = self.offsets[i], []
+            if extra_scalars:     # the extra scalars (e.g. a global token count) travel with the LAST launched segment
+                lo, hi, idxs = self.segments[-1]
+                self.segments[-1] = (lo, hi, idxs)
+            for k, (_, _, idxs) in enumerate(self.segments):
+                for i in idxs:
+                    self._seg_of[id(self.params[i])] = k
+            for p in self.params:
+                p._grad_hook = self._on_grad
+            self._reset_step()
+
+    def _reset_step(self):
+        self._pending = [len(idxs) for (_, _, idxs) in self.segments]
+        self._launched = [False] * len(self.segments)
+        self._seen = set()
+        self._works = []
+
+    def _world(self):
+        import torch.distributed as dist
+        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+
+    def _launch(self, k):
+        import torch.distributed as dist
+        self._launched[k] = True
+        if self._world() > 1:
+            lo, hi, _ = self.segments[k]
+            self._works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def _on_grad(self, param):
+        """Called by a layer right after it wrote `param`'s gradient (into the slot, or elsewhere -> copied in)."""
+        if id(param) in self._seen:
+            raise RuntimeError("GradBucket(overlap=True): a parameter received a second gradient after its first was "
+                               "handed to the all-reduce; use overlap=False for models that share parameters")
+        self._seen.add(id(param))
+        k = self._seg_of[id(param)]
+        v = param._grad_slot
+        g = param.grad
+        if g is not None and g.data_ptr() != v.data_ptr():
+            v.copy_(g.reshape(v.shape))
+            param.grad = v
+        self._pending[k] -= 1
+        if self._pending[k] == 0 and not self._launched[k]:
+            self._launch(k)
 
     def detach(self):
         for p in self.params:
             if hasattr(p, "_grad_slot"):
                 del p._grad_slot
+            if hasattr(p, "_grad_hook"):
+                del p._grad_hook
 
     def collect(self):
         """Make every slot hold this step's local gradient: gradients already written in place are left
@@ -74,9 +139,40 @@ class GradBucket:
             elif g.data_ptr() != v.data_ptr():
                 v.copy_(g.reshape(v.shape))
 
-    def all_reduce(self, group=None):
-        """One SUM all-reduce of the whole bucket (RCCL over xGMI picks direct/tree on the full mesh)."""
+    def _finish_overlapped(self):
+        """Launch the segments that are still open (parameters without a gradient are zero-filled), exchange the
+        extra scalars, wait for everything (stream-ordered: the host does not block on the GPU)."""
         import torch.distributed as dist
+        self.has_grad = []
+        for p, v in zip(self.params, self.views):
+            hg = p.grad is not None
+            self.has_grad.append(hg)
+            if id(p) not in self._seen:
+                if not hg:
+                    v.zero_()
+                elif p.grad.data_ptr() != v.data_ptr():
+                    v.copy_(p.grad.reshape(v.shape))
+            elif not hg or p.grad.data_ptr() != v.data_ptr():
+                raise RuntimeError("GradBucket(overlap=True): a parameter's gradient changed after it was handed to the "
+                                   "all-reduce (shared parameter?); use overlap=False")
+        for k in range(len(self.segments)):
+            if not self._launched[k]:
+                self._launch(k)
+        if self.extra is not None and self._world() > 1:
+            self._works.append(dist.all_reduce(self.flat[self.extra_offset:], op=dist.ReduceOp.SUM, group=self.group,
+                                               async_op=True))
+        for w in self._works:
+            w.wait()
+        for p, v, hg in zip(self.params, self.views, self.has_grad):
+            p.grad = v if hg else None
+        self._reset_step()
+
+    def all_reduce(self, group=None):
+        """One SUM all-reduce of the whole bucket (RCCL over xGMI picks direct/tree on the full mesh); with
+        overlap=True: launch what the backward pass has not launched yet, then wait."""
+        import torch.distributed as dist
+        if self.overlap:
+            return self._finish_overlapped()
         self.collect()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)

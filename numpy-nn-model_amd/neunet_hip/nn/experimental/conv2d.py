@@ -11,7 +11,7 @@ from ..._lib import Conv2dDesc
 from ...autograd import Tensor
 from ..modules import Module
 from ..parameter import Parameter
-from .linear import _grad_out
+from .linear import _finish_param, _grad_out
 from .utils import call_hip_function, get_current_stream_ptr, require_device_f32
 
 
@@ -66,9 +66,9 @@ class _HIPConv2dTensor(Tensor):
             hip_conv2d_backward(X.data, weight.data, grad, grad_X, grad_W, grad_b, desc)
             if grad_X is not None:
                 X.apply_grad(grad_X)
-            weight.apply_grad(grad_W)
+            _finish_param(weight, grad_W)
             if bias is not None:
-                bias.apply_grad(grad_b)
+                _finish_param(bias, grad_b)
 
         self.grad_fn = grad_fn
 

@@ -11,7 +11,7 @@ import numpy as np
 from ...autograd import Tensor
 from ..modules import Module
 from ..parameter import Parameter
-from .linear import _grad_out
+from .linear import _finish_param, _grad_out
 from .utils import call_hip_function, get_current_stream_ptr
 
 
@@ -36,7 +36,7 @@ class _HIPEmbeddingTensor(Tensor):
             grad = grad if grad.is_contiguous() else grad.contiguous()
             grad_weight = _grad_out(weight, weight.data)
             hip_embedding_backward(grad_weight, grad, ids, scale)
-            weight.apply_grad(grad_weight)
+            _finish_param(weight, grad_weight)
 
         self.grad_fn = grad_fn
 

@@ -45,6 +45,14 @@ def _grad_out(param, shape_like):
     return param.xp.empty_like(shape_like, dtype=np.float32)
 
 
+def _finish_param(param, grad):
+    """apply_grad + the DP bucket's gradient-ready hook (GradBucket(overlap=True))."""
+    param.apply_grad(grad)
+    hook = getattr(param, "_grad_hook", None)
+    if hook is not None:
+        hook(param)
+
+
 class _HIPLinearTensor(Tensor):
     def __init__(self, data, args, op, device):
         super().__init__(data, args, op, device=device, _nocopy=True)
@@ -59,16 +67,28 @@ class _HIPLinearTensor(Tensor):
             held = X.foldable_grad() if grad_X is not None else None
             grad_weight = _grad_out(weight, weight.data)
             grad_bias = _grad_out(bias, bias.data) if bias is not None else None
-            hip_linear_module_backward(X.data, weight.data, grad, grad_X, grad_weight, grad_bias,
-                                       in_rows_num, in_features, out_features, grad_X_addend=held)
+            hook = getattr(weight, "_grad_hook", None)
+            if hook is not None and grad_X is not None:
+                # DP overlap: parameter gradients first, hand them to the bucket (async all-reduce of a finished
+                # segment), THEN the input gradient -- the exchange rides under the dX GEMM
+                hip_linear_module_backward(X.data, weight.data, grad, None, grad_weight, grad_bias,
+                                           in_rows_num, in_features, out_features)
+                _finish_param(weight, grad_weight)
+                if bias is not None:
+                    _finish_param(bias, grad_bias)
+                hip_linear_module_backward(X.data, weight.data, grad, grad_X, None, None,
+                                           in_rows_num, in_features, out_features, grad_X_addend=held)
+            else:
+                hip_linear_module_backward(X.data, weight.data, grad, grad_X, grad_weight, grad_bias,
+                                           in_rows_num, in_features, out_features, grad_X_addend=held)
+                _finish_param(weight, grad_weight)
+                if bias is not None:
+                    _finish_param(bias, grad_bias)
             if grad_X is not None:
                 if held is not None:
                     X.grad = grad_X
                 else:
                     X.apply_grad(grad_X)
-            weight.apply_grad(grad_weight)
-            if bias is not None:
-                bias.apply_grad(grad_bias)
 
         self.grad_fn = grad_fn
 

@@ -11,7 +11,7 @@ import numpy as np
 from ...autograd import Tensor
 from ..modules import Module
 from ..parameter import Parameter
-from .linear import _grad_out
+from .linear import _finish_param, _grad_out
 from .utils import call_hip_function, get_current_stream_ptr
 
 
@@ -51,9 +51,9 @@ class _HIPLinearSwishTensor(Tensor):
                                       out_features, swish_beta, recompute)
             if grad_X is not None:
                 X.apply_grad(grad_X)
-            weight.apply_grad(grad_weight)
+            _finish_param(weight, grad_weight)
             if bias is not None:
-                bias.apply_grad(grad_bias)
+                _finish_param(bias, grad_bias)
 
         self.grad_fn = grad_fn
 

@@ -11,7 +11,7 @@ import numpy as np
 from ...autograd import Tensor
 from ..modules import Module
 from ..parameter import Parameter
-from .linear import _grad_out
+from .linear import _finish_param, _grad_out
 from .utils import call_hip_function, contiguous, get_current_stream_ptr, require_device_f32
 
 
@@ -64,9 +64,9 @@ class _HIPRMSNormTensor(Tensor):
                 X.grad = grad_X
             else:
                 X.apply_grad(grad_X)
-            weight.apply_grad(grad_weight)
+            _finish_param(weight, grad_weight)
             if bias is not None:
-                bias.apply_grad(grad_bias)
+                _finish_param(bias, grad_bias)
 
         self.grad_fn = grad_fn
 

@@ -10,7 +10,7 @@ from ..._lib import Pool2dDesc
 from ...autograd import Tensor
 from ..modules import Module
 from ..parameter import Parameter
-from .linear import _grad_out
+from .linear import _finish_param, _grad_out
 from .utils import call_hip_function, contiguous, get_current_stream_ptr, require_device_f32
 
 
@@ -134,8 +134,8 @@ class _HIPBatchNorm2dTensor(Tensor):
                               save_mean, save_inv, grad_X, gw, gb, B, C, HW, get_current_stream_ptr())
             X.apply_grad(grad_X)
             if affine:
-                weight.apply_grad(gw)
-                bias.apply_grad(gb)
+                _finish_param(weight, gw)
+                _finish_param(bias, gb)
 
         self.grad_fn = grad_fn
 

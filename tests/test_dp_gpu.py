@@ -43,7 +43,7 @@ def _data():
     return rng.uniform(-1, 1, (3, 32, 64)).astype(np.float32), rng.integers(0, 10, (3, 32)).astype(np.int32)
 
 
-def _run(rank, world, port, q):
+def _run(rank, world, port, q, overlap=False):
     import neunet_hip as hip
     import neunet_hip.nn as nn
     from neunet_hip.distributed import GradBucket, shard_batch
@@ -55,7 +55,7 @@ def _run(rank, world, port, q):
     torch.cuda.set_device(0)
     model = _build(hip)
     params = model.parameters()
-    bucket = GradBucket(params)
+    bucket = GradBucket(params, overlap=overlap, segment_bytes=1 << 12)   # overlap: several segments, async all-reduce
     opt = AdamW(params, lr=1e-2, weight_decay=1e-2)
     opt.grad_scale = 1.0 / world
     loss_fn = nn.CrossEntropyLoss()
@@ -63,7 +63,7 @@ def _run(rank, world, port, q):
     lo, hi = shard_batch(32, rank, world)
     for s in range(3):
         opt.zero_grad()
-        out = model(hip.Tensor(X[s, lo:hi], device="cuda", requires_grad=False))
+        out = model(hip.Tensor(X[s, lo:hi], device="cuda", requires_grad=overlap))   # overlap: dW before dX in every Linear
         loss_fn(out, hip.Tensor(Y[s, lo:hi], dtype=np.int32, requires_grad=False, device="cuda")).backward()
         bucket.all_reduce()
         opt.step()
@@ -76,14 +76,15 @@ def _run(rank, world, port, q):
     return res
 
 
-def test_dp2_equals_full_batch():
+@pytest.mark.parametrize("overlap", [False, True])
+def test_dp2_equals_full_batch(overlap):
     if not torch.cuda.is_available():
         pytest.fail("GPU test selected but no HIP device is visible")
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_run, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_run, args=(r, 2, port, q, overlap)) for r in range(2)]
     for p in procs:
         p.start()
     got = dict(q.get(timeout=300) for _ in procs)

@@ -131,7 +131,7 @@ def _free_port():
     return port
 
 
-def _dp_worker(rank, world, port, q):
+def _dp_worker(rank, world, port, q, overlap=False):
     import torch
     import torch.distributed as dist
     from neunet_hip.distributed import GradBucket, shard_batch
@@ -153,7 +153,9 @@ def _dp_worker(rank, world, port, q):
                 self.grad = None
 
         params = [P(W), P(b), P(np.zeros(3, np.float32))]   # the last one never gets a gradient
-        bucket = GradBucket(params, extra_scalars=1)
+        # overlap: 3 one-parameter segments, each all-reduced asynchronously as soon as its gradient is announced
+        bucket = GradBucket(params, extra_scalars=1, overlap=overlap, segment_bytes=4)
+        assert len(bucket.segments) == (3 if overlap else 0)
         lo, hi = shard_batch(12, rank, world)
         logits = O.linear_forward(X[lo:hi], W, b)
         # local SUM loss; the global non-ignored count rides in the same bucket (SURVEY 8e scaling rule)
@@ -162,6 +164,9 @@ def _dp_worker(rank, world, port, q):
         params[0].grad = torch.from_numpy(dW)                 # copied into its slot by collect()
         params[1]._grad_slot.copy_(torch.from_numpy(db))      # written in place, like the HIP layers do
         params[1].grad = params[1]._grad_slot
+        if overlap:                                           # what the HIP layers do through _finish_param
+            params[1]._grad_hook(params[1])
+            params[0]._grad_hook(params[0])
         bucket.extra[0] = float((Y[lo:hi] != 0).sum())
         bucket.all_reduce()
         count = float(bucket.extra[0])
@@ -180,12 +185,13 @@ def _dp_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_grad_bucket_allreduce_gloo_world2():
+@pytest.mark.parametrize("overlap", [False, True])
+def test_grad_bucket_allreduce_gloo_world2(overlap):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, overlap)) for r in range(2)]
     for p in procs:
         p.start()
     results = [q.get(timeout=120) for _ in procs]

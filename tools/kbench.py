@@ -58,7 +58,7 @@ def main():
 
     if want("gemm"):
         for (M, N, K) in [(4096, 4096, 4096), (8192, 4096, 4096), (16384, 512, 512), (16384, 2048, 512),
-                          (16384, 15000, 512)]:
+                          (16384, 512, 2048), (16384, 15000, 512)]:
             X, W, b = rnd(M, K), rnd(N, K) / 64, rnd(N)
             O_, dO, dX, dW, db = torch.empty(M, N, device=dev), rnd(M, N), torch.empty(M, K, device=dev), \
                 torch.empty(N, K, device=dev), torch.empty(N, device=dev)
@@ -67,6 +67,7 @@ def main():
             report(f"linear fwd {tag}", *bench(lambda: call("nnhipLinearModuleForward", X, W, b, O_, M, K, N, st), args.iters), flops=fl)
             report(f"linear dX  {tag}", *bench(lambda: call("nnhipLinearModuleBackward", X, W, dO, dX, None, None, M, K, N, st), args.iters), flops=fl)
             report(f"linear dW  {tag}", *bench(lambda: call("nnhipLinearModuleBackward", X, W, dO, None, dW, None, M, K, N, st), args.iters), flops=fl)
+            report(f"linear dW+db {tag}", *bench(lambda: call("nnhipLinearModuleBackward", X, W, dO, None, dW, db, M, K, N, st), args.iters), flops=fl)
             report(f"linear db  {tag}", *bench(lambda: call("nnhipLinearModuleBackward", X, W, dO, None, None, db, M, K, N, st), args.iters), nbytes=4.0 * M * N)
             del X, W, O_, dO, dX, dW
 
