@@ -366,20 +366,23 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
                                                             int64_t M, int64_t N, int64_t ldc,
                                                             int splitk, int act, float beta, float alpha,
                                                             const float* __restrict__ asum_slab, float* __restrict__ asum,
-                                                            const float* __restrict__ addend) {
+                                                            const float* __restrict__ addend, int asum_blocks, int vec) {
     const int64_t total = M * N;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    if (asum)
-        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += stride) {
+    // the last `asum_blocks` blocks reduce the row-sum partials (their splitk dependent loads must not sit in front of
+    // the main loop of the first blocks: that put +5 us on the critical path of every split-K dW)
+    const int main_blocks = (int)gridDim.x - asum_blocks;
+    if ((int)blockIdx.x >= main_blocks) {
+        const int64_t i = (int64_t)(blockIdx.x - main_blocks) * blockDim.x + threadIdx.x;
+        if (i < M) {
             float s = 0.f;
             for (int k = 0; k < splitk; ++k) s += asum_slab[(int64_t)k * M + i];
             asum[i] = s;
         }
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        float s = 0.f;
-        for (int k = 0; k < splitk; ++k) s += slab[(int64_t)k * total + i];
+        return;
+    }
+    const int64_t stride = (int64_t)main_blocks * blockDim.x;
+    auto finish = [&](float s, int64_t m, int64_t n) {
         s *= alpha;
-        const int64_t m = i / N, n = i - m * N;
         if (bias) s += bias[n];
         if (addend) s += addend[m * ldc + n];
         if (act == ACT_SWISH) {
@@ -388,7 +391,35 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         } else if (act == ACT_RELU) {
             s = fmaxf(s, 0.f);
         }
-        C[m * ldc + n] = s;
+        return s;
+    };
+    if (vec) {   // N % 4 == 0, ldc % 4 == 0, 16-B aligned slab / C: one float4 per thread, 4 slab loads in flight
+        const int64_t total4 = total >> 2;
+        const float4* __restrict__ slab4 = reinterpret_cast<const float4*>(slab);
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            int k = 0;
+            for (; k + 4 <= splitk; k += 4) {
+                const float4 a = slab4[(int64_t)k * total4 + i], b = slab4[(int64_t)(k + 1) * total4 + i];
+                const float4 c = slab4[(int64_t)(k + 2) * total4 + i], d = slab4[(int64_t)(k + 3) * total4 + i];
+                s.x = (((s.x + a.x) + b.x) + c.x) + d.x; s.y = (((s.y + a.y) + b.y) + c.y) + d.y;
+                s.z = (((s.z + a.z) + b.z) + c.z) + d.z; s.w = (((s.w + a.w) + b.w) + c.w) + d.w;
+            }
+            for (; k < splitk; ++k) {
+                const float4 a = slab4[(int64_t)k * total4 + i];
+                s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+            }
+            const int64_t e = i << 2, m = e / N, n = e - m * N;
+            s.x = finish(s.x, m, n); s.y = finish(s.y, m, n + 1); s.z = finish(s.z, m, n + 2); s.w = finish(s.w, m, n + 3);
+            *reinterpret_cast<float4*>(C + m * ldc + n) = s;
+        }
+        return;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        float s = 0.f;
+        for (int k = 0; k < splitk; ++k) s += slab[(int64_t)k * total + i];
+        const int64_t m = i / N, n = i - m * N;
+        C[m * ldc + n] = finish(s, m, n);
     }
 }
 
@@ -518,9 +549,13 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
 
     if (p.splitk > 1) {
         const int64_t total = M * N;
-        int blocks = (int)(ceil_div(total, 256) < 2048 ? ceil_div(total, 256) : 2048);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.slab, C, preact,
-                           bias, M, N, ldc, p.splitk, act, beta, alpha, p.asum_slab, asum, addend);
+        const int rvec = p.cvec && (ldc & 3) == 0 && aligned16(C) && aligned16(p.slab) && (!addend || aligned16(addend)) &&
+                         (!preact || aligned16(preact));
+        const int64_t work = rvec ? total / 4 : total;
+        int blocks = (int)(ceil_div(work, 256) < 2048 ? ceil_div(work, 256) : 2048);
+        const int asum_blocks = asum ? (int)ceil_div(M, 256) : 0;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks + asum_blocks), dim3(256), 0, st, p.slab, C, preact,
+                           bias, M, N, ldc, p.splitk, act, beta, alpha, p.asum_slab, asum, addend, asum_blocks, rvec);
         NNHIP_LAUNCH_CHECK("splitk_reduce_kernel");
     }
     return 0;
