@@ -105,6 +105,13 @@ int nnhipReLUForward(float* out, const float* in, int64_t size, nnhipStream_t st
 int nnhipReLUBackward(float* dIn, const float* dOut, const float* out, int64_t size,
                       nnhipStream_t stream);
 
+/* Input gradient of a Linear whose input was h = swish(z) (the FFN's fc_2 after the fused Linear->Swish fc_1,
+ * examples/gpt.ipynb cell 2): dZ[rows,in] = (dO[rows,out] * W[out,in]) (.) swish'(Z; beta), i.e. the dX GEMM of
+ * nnhipLinearModuleBackward with the element-wise Swish backward (neunet/nn/activations.py:223-232) applied in its
+ * epilogue.  dZ may alias Z (each element is read once, then written).  Feed dZ to nnhipLinearModuleBackward of fc_1. */
+int nnhipLinearInputGradSwish(const float* dO, const float* W, const float* Z, float* dZ, int64_t rows,
+                              int64_t in_features, int64_t out_features, float swish_beta, nnhipStream_t stream);
+
 /* ---- a5 Swish  (replaces cudaSwishForward/Backward, swish.cu:50,65) ------------------------- */
 int nnhipSwishForward(float* out, const float* in, float beta, int64_t size, nnhipStream_t stream);
 int nnhipSwishBackward(float* dIn, const float* dOut, const float* in, float beta, int64_t size,

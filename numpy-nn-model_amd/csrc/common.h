@@ -96,5 +96,16 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// d/dz [z * sigmoid(beta z)] in the reference's form (neunet/nn/activations.py:223-232): beta f + s (1 - beta f), f = z s
+// The GEMM epilogues use the hardware exp2 / rcp (1 ulp each; the library expf + IEEE divide cost ~30 VALU
+// instructions per element and made the epilogue of a K=512 GEMM as expensive as a separate pass over the tensor).
+__device__ __forceinline__ float sigmoid_fast_(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float swish_grad_(float z, float beta) {
+    const float s = sigmoid_fast_(beta * z);
+    const float f = z * s;
+    return beta * f + s * (1.f - beta * f);
+}
 
 }  // namespace nnhip

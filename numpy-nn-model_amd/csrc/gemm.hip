@@ -50,6 +50,7 @@ struct GemmParams {
     int cvec;             // 1: C/bias/preact rows are 16-B aligned and N % 4 == 0 -> float4 epilogue
     int act;
     float beta;
+    const float* dswish;  // [M, ldc] or null: C = (alpha*AB + bias + addend) * swish'(dswish[m,n]; beta)  (may alias C)
     const float* addend;  // [M, ldc] or null: C = act(alpha*AB + bias + addend)  (residual / gradient accumulation)
     float* asum;          // CS variants: asum[m] = sum_k A[m,k] (Linear: db = column sums of dO, fused into dW = dO^T X)
     float* asum_slab;     // split-K partials [splitk][M]
@@ -294,6 +295,21 @@ __global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const 
         const bool col_ok = col < p.N;                       // N % 4 == 0 on this path
         float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (!to_slab && p.bias && col_ok) bv = *reinterpret_cast<const float4*>(p.bias + col);
+        // the one extra epilogue operand (addend or swish' argument; the dispatcher rejects both at once) is fetched one
+        // 32-row group ahead: issued before the LDS transposition of the group that uses it, so its latency hides under
+        // that and under the previous group's stores (loading it inside the store loop cost ~4 us per tile).
+        const float* __restrict__ extra = to_slab ? nullptr : (p.addend ? p.addend : p.dswish);
+        const bool is_add = p.addend != nullptr;
+        float4 ex[8];
+        auto fetch_extra = [&](int i, int it) {
+            const int64_t row = m0 + wm * 64 + i * 32 + it * 4 + er;
+            ex[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < p.M && col_ok) ex[it] = *reinterpret_cast<const float4*>(extra + c_off + row * ldc + col);
+        };
+        if (extra) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) fetch_extra(0, it);
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -301,19 +317,26 @@ __global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const 
 #pragma unroll
                 for (int e = 0; e < 16; ++e)
                     E[((e & 3) + 8 * (e >> 2) + 4 * lh) * ELD + n * 32 + l31] = acc[i][n][e];
-            __syncthreads();
+            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0); E is private to the wave: no block barrier needed
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int rl = it * 4 + er;
                 const int64_t row = m0 + wm * 64 + i * 32 + rl;
                 float4 v = *reinterpret_cast<const float4*>(&E[rl * ELD + ec]);
+                const float4 x = ex[it];
+                if (extra && i == 0) fetch_extra(1, it);
                 if (row < p.M && col_ok) {
                     if (!to_slab) {
                         v.x = p.alpha * v.x + bv.x; v.y = p.alpha * v.y + bv.y;
                         v.z = p.alpha * v.z + bv.z; v.w = p.alpha * v.w + bv.w;
-                        if (p.addend) {
-                            const float4 r = *reinterpret_cast<const float4*>(p.addend + c_off + row * ldc + col);
-                            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                        if (extra) {
+                            if (is_add) {
+                                v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+                            } else {   // gradient through h = swish(z): the dX GEMM of the NEXT layer hands back dz
+                                v.x *= swish_grad_(x.x, p.beta); v.y *= swish_grad_(x.y, p.beta);
+                                v.z *= swish_grad_(x.z, p.beta); v.w *= swish_grad_(x.w, p.beta);
+                            }
                         }
                         if (p.act == ACT_SWISH) {
                             if (p.preact) *reinterpret_cast<float4*>(p.preact + c_off + row * ldc + col) = v;
@@ -326,7 +349,8 @@ __global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const 
                     *reinterpret_cast<float4*>(C + row * ldc + col) = v;
                 }
             }
-            __syncthreads();
+            __builtin_amdgcn_s_waitcnt(0xc07f);   // this group's LDS reads are done before the next group overwrites E
+            __builtin_amdgcn_wave_barrier();
         }
         return;
     }
@@ -345,6 +369,7 @@ __global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const 
                 float v = to_slab ? acc[i][n][e] : p.alpha * acc[i][n][e] + bv;
                 if (!to_slab) {
                     if (p.addend) v += p.addend[c_off + row * ldc + col];
+                    if (p.dswish) v *= swish_grad_(p.dswish[c_off + row * ldc + col], p.beta);
                     if (p.act == ACT_SWISH) {
                         if (p.preact) p.preact[c_off + row * ldc + col] = v;
                         v = v * sigmoidf_(p.beta * v);
@@ -366,7 +391,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
                                                             int64_t M, int64_t N, int64_t ldc,
                                                             int splitk, int act, float beta, float alpha,
                                                             const float* __restrict__ asum_slab, float* __restrict__ asum,
-                                                            const float* __restrict__ addend, int asum_blocks, int vec) {
+                                                            const float* __restrict__ addend, int asum_blocks, int vec,
+                                                            const float* __restrict__ dswish) {
     const int64_t total = M * N;
     // the last `asum_blocks` blocks reduce the row-sum partials (their splitk dependent loads must not sit in front of
     // the main loop of the first blocks: that put +5 us on the critical path of every split-K dW)
@@ -385,6 +411,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         s *= alpha;
         if (bias) s += bias[n];
         if (addend) s += addend[m * ldc + n];
+        if (dswish) s *= swish_grad_(dswish[m * ldc + n], beta);
         if (act == ACT_SWISH) {
             if (preact) preact[m * ldc + n] = s;
             s = s * sigmoidf_(beta * s);
@@ -445,7 +472,7 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
                 int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, bool a_kmajor, bool b_kmajor,
                 int64_t batch1, int64_t sA, int64_t sB, int64_t sC, int64_t batch2, int64_t sA2,
                 int64_t sB2, int64_t sC2, float alpha, int act, float beta, hipStream_t st, float* asum = nullptr,
-                const float* addend = nullptr);
+                const float* addend = nullptr, const float* dswish = nullptr);
 
 int gemm_f32(const float* A, const float* B, float* C, const float* bias, float* preact, int64_t M,
              int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, bool a_kmajor,
@@ -464,6 +491,13 @@ int gemm_f32_add(const float* A, const float* B, float* C, const float* bias, co
                        ACT_NONE, 1.f, st, nullptr, addend);
 }
 
+// C = (A B) * swish'(Z; beta): the input gradient of a Linear whose input is h = swish(z) comes back as dz (C may alias Z).
+int gemm_f32_dswish(const float* A, const float* B, float* C, const float* Z, float beta, int64_t M, int64_t N, int64_t K,
+                    int64_t lda, int64_t ldb, int64_t ldc, bool a_kmajor, bool b_kmajor, hipStream_t st) {
+    return gemm_f32_ex(A, B, C, nullptr, nullptr, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, 1, 0, 0, 0, 1, 0, 0, 0, 1.0f,
+                       ACT_NONE, beta, st, nullptr, nullptr, Z);
+}
+
 int gemm_f32_asum(const float* A, const float* B, float* C, float* asum, int64_t M, int64_t N, int64_t K, int64_t lda,
                   int64_t ldb, int64_t ldc, bool b_kmajor, hipStream_t st) {
     return gemm_f32_ex(A, B, C, nullptr, nullptr, M, N, K, lda, ldb, ldc, false, b_kmajor, 1, 0, 0, 0, 1, 0, 0, 0, 1.0f,
@@ -474,9 +508,10 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
                 int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, bool a_kmajor, bool b_kmajor,
                 int64_t batch1, int64_t sA, int64_t sB, int64_t sC, int64_t batch2, int64_t sA2,
                 int64_t sB2, int64_t sC2, float alpha, int act, float beta, hipStream_t st, float* asum,
-                const float* addend) {
+                const float* addend, const float* dswish) {
     const int64_t batch = batch1 * batch2;
     if (M <= 0 || N <= 0 || batch <= 0) return 0;
+    if (addend && dswish) { set_last_error("gemm: addend and dswish are mutually exclusive"); return NNHIP_EINVAL; }
     if (asum && (a_kmajor || batch != 1 || K <= 0)) { set_last_error("gemm: asum needs an outer-major, unbatched A"); return NNHIP_EINVAL; }
     static const int bk_sel = []() { const char* e = getenv("NNHIP_GEMM_BK"); return e ? atoi(e) : 32; }();
     const int BK = (bk_sel == 16) ? 16 : 32;
@@ -489,7 +524,7 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
     p.tiles_n = (int)ceil_div(N, BN);
     p.act = act; p.beta = beta;
     p.splitk = 1; p.k_per_split = ceil_div(K > 0 ? K : 1, BK) * BK; p.slab = nullptr;
-    p.asum = asum; p.asum_slab = nullptr; p.addend = addend;
+    p.asum = asum; p.asum_slab = nullptr; p.addend = addend; p.dswish = dswish;
     p.zeros = zero_block();
     if (!p.zeros) { set_last_error("zero block allocation failed"); return NNHIP_ENOMEM; }
 
@@ -524,7 +559,7 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
         bool ok = (N & 3) == 0;
         if (slab) ok = ok && aligned16(p.slab);
         else ok = ok && aligned16(C) && (ldc & 3) == 0 && (batch1 <= 1 || (sC & 3) == 0) && (batch2 <= 1 || (sC2 & 3) == 0) &&
-                  (!bias || aligned16(bias)) && (!preact || aligned16(preact)) && (!addend || aligned16(addend));
+                  (!bias || aligned16(bias)) && (!preact || aligned16(preact)) && (!addend || aligned16(addend)) && (!dswish || aligned16(dswish));
         p.cvec = ok ? 1 : 0;
     }
 
@@ -550,12 +585,12 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
     if (p.splitk > 1) {
         const int64_t total = M * N;
         const int rvec = p.cvec && (ldc & 3) == 0 && aligned16(C) && aligned16(p.slab) && (!addend || aligned16(addend)) &&
-                         (!preact || aligned16(preact));
+                         (!preact || aligned16(preact)) && (!dswish || aligned16(dswish));
         const int64_t work = rvec ? total / 4 : total;
         int blocks = (int)(ceil_div(work, 256) < 2048 ? ceil_div(work, 256) : 2048);
         const int asum_blocks = asum ? (int)ceil_div(M, 256) : 0;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks + asum_blocks), dim3(256), 0, st, p.slab, C, preact,
-                           bias, M, N, ldc, p.splitk, act, beta, alpha, p.asum_slab, asum, addend, asum_blocks, rvec);
+                           bias, M, N, ldc, p.splitk, act, beta, alpha, p.asum_slab, asum, addend, asum_blocks, rvec, dswish);
         NNHIP_LAUNCH_CHECK("splitk_reduce_kernel");
     }
     return 0;

@@ -10,6 +10,8 @@ int gemm_f32(const float* A, const float* B, float* C, const float* bias, float*
              hipStream_t st);
 int gemm_f32_add(const float* A, const float* B, float* C, const float* bias, const float* addend, int64_t M, int64_t N,
                  int64_t K, int64_t lda, int64_t ldb, int64_t ldc, bool a_kmajor, bool b_kmajor, hipStream_t st);
+int gemm_f32_dswish(const float* A, const float* B, float* C, const float* Z, float beta, int64_t M, int64_t N, int64_t K,
+                    int64_t lda, int64_t ldb, int64_t ldc, bool a_kmajor, bool b_kmajor, hipStream_t st);
 int gemm_f32_asum(const float* A, const float* B, float* C, float* asum, int64_t M, int64_t N, int64_t K, int64_t lda,
                   int64_t ldb, int64_t ldc, bool b_kmajor, hipStream_t st);
 int colsum(const float* X, int64_t rows, int64_t cols, int64_t ld, float* out, hipStream_t st);
@@ -109,4 +111,18 @@ extern "C" int nnhipLinearSwishBackward(const float* X, const float* W, const fl
     rc = swish_backward_inplace(tmp, dO, swish_beta, M * N, st);  // tmp <- dZ = dO * swish'(z)
     if (rc) return rc;
     return linear_backward(X, W, tmp, dX, dW, db, M, K, N, st);
+}
+
+// dZ[rows,in] = (dO[rows,out] * W[out,in]) (.) swish'(Z[rows,in]; beta): the input gradient of a Linear fed by
+// h = swish(z), with the Swish backward folded into the dX GEMM's epilogue.  dZ may alias Z.
+extern "C" int nnhipLinearInputGradSwish(const float* dO, const float* W, const float* Z, float* dZ, int64_t rows,
+                                         int64_t in_features, int64_t out_features, float swish_beta,
+                                         nnhipStream_t stream) {
+    NNHIP_CHECK_ARG(rows >= 0 && in_features >= 0 && out_features >= 0, NNHIP_EINVAL, "nnhipLinearInputGradSwish: negative size");
+    if (rows == 0 || in_features == 0) return 0;
+    NNHIP_CHECK_ARG(dO && W && Z && dZ, NNHIP_EINVAL, "nnhipLinearInputGradSwish: null pointer");
+    NNHIP_CHECK_ARG(aligned4(dO) && aligned4(W) && aligned4(Z) && aligned4(dZ), NNHIP_EALIGN,
+                    "nnhipLinearInputGradSwish: misaligned pointer");
+    return gemm_f32_dswish(dO, W, dZ, Z, swish_beta, rows, in_features, out_features, out_features, in_features,
+                           in_features, true, false, (hipStream_t)stream);
 }

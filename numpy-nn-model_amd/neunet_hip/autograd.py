@@ -249,6 +249,16 @@ class Tensor:
             for child in reversed(list(v.args)):
                 if isinstance(child, Tensor) and child.requires_grad and id(child) not in visited:
                     stack.append((child, False))
+        # how many tape nodes consume each tensor: lets a grad_fn hand a *transformed* gradient to a sole-consumer
+        # input (experimental/linear.py folds the Swish backward of a LinearSwish input into its dX GEMM)
+        for v in tape:
+            for child in v.args:
+                if isinstance(child, Tensor):
+                    child._consumers = 0
+        for v in tape:
+            for child in v.args:
+                if isinstance(child, Tensor):
+                    child._consumers += 1
         for v in reversed(tape):
             v.grad_fn(*v.args, grad=v.grad)
 

@@ -45,6 +45,23 @@ def _grad_out(param, shape_like):
     return param.xp.empty_like(shape_like, dtype=np.float32)
 
 
+def _fold_swish_backward(X, weight, grad, rows, in_features, out_features):
+    """If this Linear's input is the output of a fused Linear->Swish that saved its pre-activation z and nothing else
+    consumes it (the FFN of examples/gpt.ipynb: fc_2(swish(fc_1(x)))), compute dz = (dO W) * swish'(z) in the dX
+    GEMM's epilogue, in place over z, and hand it to that node marked as 'already dz' -- no separate Swish-backward
+    pass over the [rows, d_ff] tensor.  Returns True when done."""
+    if X.op != "linear_swish" or X.grad is not None or getattr(X, "_consumers", 0) != 1 or not X.requires_grad:
+        return False
+    z, saved = X.args[7], X.args[8]
+    if not saved or z is None:
+        return False
+    call_hip_function("nnhipLinearInputGradSwish", grad, weight.data, z, z, rows, in_features, out_features,
+                      float(X.args[6]), get_current_stream_ptr())
+    X.grad = z.reshape(X.data.shape)
+    X._grad_is_dz = True
+    return True
+
+
 def _finish_param(param, grad):
     """apply_grad + the DP bucket's gradient-ready hook (GradBucket(overlap=True))."""
     param.apply_grad(grad)
@@ -61,7 +78,8 @@ class _HIPLinearTensor(Tensor):
             grad = grad if grad.is_contiguous() else grad.contiguous()
             if residual is not None:
                 residual.apply_grad(grad)       # d(x + linear(h))/dx = 1: the same buffer, by reference
-            grad_X = X.xp.empty_like(X.data, dtype=np.float32) if X.requires_grad else None
+            folded = _fold_swish_backward(X, weight, grad, in_rows_num, in_features, out_features)
+            grad_X = X.xp.empty_like(X.data, dtype=np.float32) if X.requires_grad and not folded else None
             # a gradient X already received (e.g. q/k/v projections sharing one input) is folded into the dX GEMM's
             # epilogue instead of a separate accumulation pass (neunet/autograd.py:85-93 allocates and adds)
             held = X.foldable_grad() if grad_X is not None else None

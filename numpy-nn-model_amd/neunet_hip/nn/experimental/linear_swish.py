@@ -11,7 +11,7 @@ import numpy as np
 from ...autograd import Tensor
 from ..modules import Module
 from ..parameter import Parameter
-from .linear import _finish_param, _grad_out
+from .linear import _finish_param, _grad_out, hip_linear_module_backward
 from .utils import call_hip_function, get_current_stream_ptr
 
 
@@ -42,13 +42,19 @@ class _HIPLinearSwishTensor(Tensor):
             grad_X = X.xp.empty_like(X.data, dtype=np.float32) if X.requires_grad else None
             grad_weight = _grad_out(weight, weight.data)
             grad_bias = _grad_out(bias, bias.data) if bias is not None else None
-            if save_preactivation:
-                d_linear_tmp, recompute = preactivation, False
+            if getattr(self, "_grad_is_dz", False):
+                # the consumer (a HIPLinear) already applied swish'(z) in its dX epilogue: grad IS dz (linear.py)
+                self._grad_is_dz = False
+                hip_linear_module_backward(X.data, weight.data, grad, grad_X, grad_weight, grad_bias, in_rows_num,
+                                           in_features, out_features)
             else:
-                d_linear_tmp, recompute = X.xp.empty((in_rows_num, out_features), dtype=np.float32), True
-            hip_linear_swish_backward(X.data, weight.data, bias.data if bias is not None else None, grad,
-                                      d_linear_tmp, grad_X, grad_weight, grad_bias, in_rows_num, in_features,
-                                      out_features, swish_beta, recompute)
+                if save_preactivation:
+                    d_linear_tmp, recompute = preactivation, False
+                else:
+                    d_linear_tmp, recompute = X.xp.empty((in_rows_num, out_features), dtype=np.float32), True
+                hip_linear_swish_backward(X.data, weight.data, bias.data if bias is not None else None, grad,
+                                          d_linear_tmp, grad_X, grad_weight, grad_bias, in_rows_num, in_features,
+                                          out_features, swish_beta, recompute)
             if grad_X is not None:
                 X.apply_grad(grad_X)
             _finish_param(weight, grad_weight)

@@ -115,6 +115,40 @@ def test_linear_addend_extensions(hip, rows, inf, outf):
     np.testing.assert_allclose(host(lin.bias.grad), db.reshape(1, -1), rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("rows,dm,dff,beta", [(200, 64, 256, 1.0), (16384, 128, 128, 1.0), (50, 30, 70, 1.7)])
+def test_ffn_swish_backward_folded_into_dx(hip, rows, dm, dff, beta):
+    """fc_2(LinearSwish fc_1(x)): fc_2's dX GEMM applies swish'(z) in its epilogue (nnhipLinearInputGradSwish, in place
+    over the saved z; also through split-K and the scalar epilogue) and hands dz to fc_1 -- same gradients as the
+    oracle's Linear -> Swish -> Linear chain; a second consumer of h disables the folding."""
+    import neunet_hip.nn as nn
+    rng = np.random.default_rng(rows + dff)
+    fc1, fc2 = nn.LinearSwish(dm, dff, swish_beta=beta), nn.Linear(dff, dm)
+    W1, b1, W2, b2 = [host(t.data) for t in (fc1.weight, fc1.bias, fc2.weight, fc2.bias)]
+    X = rng.standard_normal((rows, dm)).astype(np.float32)
+    dY = rng.standard_normal((rows, dm)).astype(np.float32)
+    z = O.linear_forward(X, W1, b1)
+    h = O.swish_forward(z, beta)
+    dh, dW2, db2 = O.linear_backward(h, W2, b2, dY)
+    dz = O.swish_backward(z, dh, beta)
+    dX, dW1, db1 = O.linear_backward(X, W1, b1, dz)
+    for second_consumer in (False, True):
+        for p in (fc1.weight, fc1.bias, fc2.weight, fc2.bias):
+            p.grad = None
+        x = T(hip, X)
+        hh = fc1(x)
+        y = fc2(hh)
+        if second_consumer:
+            y2 = fc2(hh)                      # h consumed twice: plain path, gradients accumulate
+            (y + y2).backward(dY * 0.5)
+        else:
+            y.backward(dY)
+        np.testing.assert_allclose(host(x.grad), dX, rtol=1e-4, atol=2e-4)
+        np.testing.assert_allclose(host(fc1.weight.grad), dW1, rtol=1e-4, atol=2e-3)
+        np.testing.assert_allclose(host(fc1.bias.grad), db1.reshape(1, -1), rtol=1e-4, atol=2e-3)
+        np.testing.assert_allclose(host(fc2.weight.grad), dW2, rtol=1e-4, atol=2e-3)
+        np.testing.assert_allclose(host(fc2.bias.grad), db2.reshape(1, -1), rtol=1e-4, atol=2e-3)
+
+
 @pytest.mark.parametrize("rows,cols", [(64, 512), (33, 100), (16, 4096), (8, 12000)])
 def test_rmsnorm_backward_addend(hip, rows, cols):
     import neunet_hip.nn as nn
