@@ -340,8 +340,8 @@ __global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const 
                         }
                         if (p.act == ACT_SWISH) {
                             if (p.preact) *reinterpret_cast<float4*>(p.preact + c_off + row * ldc + col) = v;
-                            v.x *= sigmoidf_(p.beta * v.x); v.y *= sigmoidf_(p.beta * v.y);
-                            v.z *= sigmoidf_(p.beta * v.z); v.w *= sigmoidf_(p.beta * v.w);
+                            v.x *= sigmoid_fast_(p.beta * v.x); v.y *= sigmoid_fast_(p.beta * v.y);
+                            v.z *= sigmoid_fast_(p.beta * v.z); v.w *= sigmoid_fast_(p.beta * v.w);
                         } else if (p.act == ACT_RELU) {
                             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                         }
