@@ -6,7 +6,7 @@ for W in c2 c3 c4; do
 done
 python tools/prof_summary.py pmc $G/pmc_sq_c2/sq_counter_collection.csv $P/${TAG}_c2_pmc_sq.md
 for W in c2 c3; do python tools/prof_summary.py pmc $G/pmc_fetch_$W/f_counter_collection.csv $G/pmc_write_$W/w_counter_collection.csv $P/${TAG}_${W}_pmc_hbm.md; done
-python tools/prof_summary.py traffic $G/pmc_fetch_c2/f_counter_collection.csv $G/pmc_write_c2/w_counter_collection.csv /tmp/t_c2.json "gemm_f32_kernel<32, true, true, true>=gemm_fwd_c2" "gemm_f32_kernel<32, true, false, true>=gemm_dx_c2" "gemm_f32_kernel<32, false, false, true>=gemm_dw_c2" "adamw_multi=adamw_c2" > /dev/null
+python tools/prof_summary.py traffic $G/pmc_fetch_c2/f_counter_collection.csv $G/pmc_write_c2/w_counter_collection.csv /tmp/t_c2.json "gemm_f32_kernel<32, true, true, true, false>=gemm_fwd_c2" "gemm_f32_kernel<32, true, false, true, false>=gemm_dx_c2" "gemm_f32_kernel<32, false, false, true, false>=gemm_dw_c2" "adamw_multi=adamw_c2" > /dev/null
 python tools/prof_summary.py traffic $G/pmc_fetch_c3/f_counter_collection.csv $G/pmc_write_c3/w_counter_collection.csv /tmp/t_c3.json "map1_kernel<SwishF>=swish_fwd_c3" "map2_kernel<SwishB>=swish_bwd_c3" "rmsnorm_fwd_rows=rmsnorm_fwd_c3" "rmsnorm_bwd_rows=rmsnorm_bwd_c3" "softmax_fwd_rows=softmax_fwd_c3" "softmax_bwd_rows=softmax_bwd_c3" "ce_fwd_bwd_rows=ce_c3" "adamw_multi=adamw_c3" > /dev/null
 python - <<PY
 import json
