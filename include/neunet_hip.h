@@ -143,17 +143,20 @@ int nnhipMaskedSoftmaxBackward(float* dX, const float* dY, const float* Y, const
                                nnhipStream_t stream);
 
 /* Fused (flash-style) attention, head_dim 64: same math as  QK^T*scale -> mask(-1e9) -> softmax -> *V  above, but the
- * [B,H,Tq,Tk] score matrix is never written.  Q/K/V/O/dQ/dK/dV are [B,T,H*64] (the projection layout);
- * LSE [B,H,Tq,2] = (row max m, log sum exp(s - m)) of each masked score row, saved by the forward and consumed by the
- * backward; the pair is kept apart because a fully-masked row has m = -1e9, where fp32 cannot hold m + log(sum). */
+ * [B,H,Tq,Tk] score matrix is never written.  O/dO are [B,T,H*64] (the projection layout); Q/K/V/dQ/dK/dV are
+ * [B,T,*] with row stride ld_qkv floats (0 = H*64; 3*H*64 when they are the three column blocks of one fused q|k|v
+ * projection buffer).  LSE [B,H,Tq,2] = (row max, log2 row sum) of each masked score row in log2 units, saved by the
+ * forward and consumed by the backward; the pair is kept apart because a fully-masked row has max = -1e9*log2(e),
+ * where fp32 cannot hold max + log(sum). */
 int nnhipAttentionForward(const float* Q, const float* K, const float* V, const int32_t* key_valid, float* O,
-                          float* LSE, int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t head_dim, float scale,
-                          int causal, nnhipStream_t stream);
+                          float* LSE, int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t head_dim, int64_t ld_qkv,
+                          float scale, int causal, nnhipStream_t stream);
 /* dQ, dK, dV from (Q, K, V, O, dO, LSE): P is recomputed tile by tile; deterministic (no atomics): one kernel owns
  * 128-key blocks (dK, dV), one owns 128-query blocks (dQ). */
 int nnhipAttentionBackward(const float* Q, const float* K, const float* V, const int32_t* key_valid, const float* O,
                            const float* dO, const float* LSE, float* dQ, float* dK, float* dV, int64_t B, int64_t H,
-                           int64_t Tq, int64_t Tk, int64_t head_dim, float scale, int causal, nnhipStream_t stream);
+                           int64_t Tq, int64_t Tk, int64_t head_dim, int64_t ld_qkv, float scale, int causal,
+                           nnhipStream_t stream);
 
 /* ---- a9 fused CrossEntropy forward+backward  (replaces cudaCrossEntropyForwardBackward,
  *      cross_entropy.cu:249-260).

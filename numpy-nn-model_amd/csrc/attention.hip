@@ -42,7 +42,8 @@ struct AttnParams {
     float* LSE;                                       // [B, H, Tq, 2] = (max, log2 sum), log2 units
     const int32_t* key_valid;                         // [B, Tk] or null
     int B, H, Tq, Tk;
-    int64_t D;                                        // H * 64
+    int64_t D;                                        // row stride of O (floats): H * 64
+    int64_t LQ;                                       // row stride of Q, K, V (>= H * 64: 3*H*64 for a fused q|k|v buffer)
     float scale;                                      // multiplies QK^T (1/sqrt(d_model))
     int causal;
 };
@@ -53,7 +54,8 @@ struct AttnBwdParams {
     float* dQ; float* dK; float* dV;                                   // [B, T, D]
     const int32_t* key_valid;
     int B, H, Tq, Tk;
-    int64_t D;
+    int64_t D;                                                         // row stride of dO / O
+    int64_t LQ;                                                        // row stride of Q, K, V, dQ, dK, dV
     float scale;
     int causal;
 };
@@ -271,9 +273,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     const int b = bh / p.H, h = bh - b * p.H;
     const int q0 = qb * AT_BQ + wave * 32;           // this wave's first query
     const int q = q0 + l31;                           // this lane's query
-    const float* Qb = p.Q + ((int64_t)b * p.Tq) * p.D + (int64_t)h * AT_DH;
-    const float* Kb = p.K + ((int64_t)b * p.Tk) * p.D + (int64_t)h * AT_DH;
-    const float* Vb = p.V + ((int64_t)b * p.Tk) * p.D + (int64_t)h * AT_DH;
+    const float* Qb = p.Q + ((int64_t)b * p.Tq) * p.LQ + (int64_t)h * AT_DH;
+    const float* Kb = p.K + ((int64_t)b * p.Tk) * p.LQ + (int64_t)h * AT_DH;
+    const float* Vb = p.V + ((int64_t)b * p.Tk) * p.LQ + (int64_t)h * AT_DH;
     const int32_t* kv = p.key_valid ? p.key_valid + (int64_t)b * p.Tk : nullptr;
     const int shift = p.Tk - p.Tq;                    // causal: key j visible to query i iff j <= i + shift
 
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (q < p.Tq) v = *reinterpret_cast<const float4*>(Qb + (int64_t)q * p.D + 8 * g + 4 * lh);
+        if (q < p.Tq) v = *reinterpret_cast<const float4*>(Qb + (int64_t)q * p.LQ + 8 * g + 4 * lh);
         qf[g][0] = v.x * qs; qf[g][1] = v.y * qs; qf[g][2] = v.z * qs; qf[g][3] = v.w * qs;
     }
 
@@ -308,8 +310,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     TileRegs kr, vr;
     int kflag = 1;
     if (n_tiles > 0) {
-        tile_fetch(kr, Kb, p.D, 0, p.Tk, tid);
-        tile_fetch(vr, Vb, p.D, 0, p.Tk, tid);
+        tile_fetch(kr, Kb, p.LQ, 0, p.Tk, tid);
+        tile_fetch(vr, Vb, p.LQ, 0, p.Tk, tid);
         kflag = key_flag(kv, 0, p.Tk, lane);
     }
     for (int t = 0; t < n_tiles; ++t) {
@@ -320,8 +322,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
         const unsigned long long valid = __ballot(kflag != 0) >> (4 * lh);   // bit j: key kv0 + j + 4lh is a real token
         __syncthreads();
         if (t + 1 < n_tiles) {                          // next tile's loads fly during this tile's MFMAs
-            tile_fetch(kr, Kb, p.D, kv0 + AT_BK, p.Tk, tid);
-            tile_fetch(vr, Vb, p.D, kv0 + AT_BK, p.Tk, tid);
+            tile_fetch(kr, Kb, p.LQ, kv0 + AT_BK, p.Tk, tid);
+            tile_fetch(vr, Vb, p.LQ, kv0 + AT_BK, p.Tk, tid);
             kflag = key_flag(kv, kv0 + AT_BK, p.Tk, lane);
         }
         // wave-uniform skip: every key of this tile is above the diagonal for all 32 queries of the wave
@@ -424,10 +426,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdPara
     const int b = bh / p.H, h = bh - b * p.H;
     const int k0w = kb * 128 + wave * 32;
     const int key = k0w + l31;                                  // this lane's key
-    const float* Qb = p.Q + ((int64_t)b * p.Tq) * p.D + (int64_t)h * AT_DH;
+    const float* Qb = p.Q + ((int64_t)b * p.Tq) * p.LQ + (int64_t)h * AT_DH;
     const float* dOb = p.dO + ((int64_t)b * p.Tq) * p.D + (int64_t)h * AT_DH;
-    const float* Kb = p.K + ((int64_t)b * p.Tk) * p.D + (int64_t)h * AT_DH;
-    const float* Vb = p.V + ((int64_t)b * p.Tk) * p.D + (int64_t)h * AT_DH;
+    const float* Kb = p.K + ((int64_t)b * p.Tk) * p.LQ + (int64_t)h * AT_DH;
+    const float* Vb = p.V + ((int64_t)b * p.Tk) * p.LQ + (int64_t)h * AT_DH;
     const float2* LSEb = reinterpret_cast<const float2*>(p.LSE) + ((int64_t)b * p.H + h) * p.Tq;
     const float* Dsb = p.Dsum + ((int64_t)b * p.H + h) * p.Tq;
     const int32_t* kv = p.key_valid ? p.key_valid + (int64_t)b * p.Tk : nullptr;
@@ -443,8 +445,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdPara
     for (int g = 0; g < 8; ++g) {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
         if (key_in) {
-            a = *reinterpret_cast<const float4*>(Kb + (int64_t)key * p.D + 8 * g + 4 * lh);
-            c = *reinterpret_cast<const float4*>(Vb + (int64_t)key * p.D + 8 * g + 4 * lh);
+            a = *reinterpret_cast<const float4*>(Kb + (int64_t)key * p.LQ + 8 * g + 4 * lh);
+            c = *reinterpret_cast<const float4*>(Vb + (int64_t)key * p.LQ + 8 * g + 4 * lh);
         }
         kf[g][0] = a.x * sl2; kf[g][1] = a.y * sl2; kf[g][2] = a.z * sl2; kf[g][3] = a.w * sl2;
         vf[g][0] = c.x; vf[g][1] = c.y; vf[g][2] = c.z; vf[g][3] = c.w;
@@ -467,7 +469,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdPara
     float dsv = 0.f;
     int qt = next_tile(0);
     if (qt < n_qt) {
-        tile_fetch(qr, Qb, p.D, qt * QT, p.Tq, tid);
+        tile_fetch(qr, Qb, p.LQ, qt * QT, p.Tq, tid);
         tile_fetch(gr, dOb, p.D, qt * QT, p.Tq, tid);
         if (tid < QT && qt * QT + tid < p.Tq) { ml = LSEb[qt * QT + tid]; dsv = Dsb[qt * QT + tid]; }
     }
@@ -480,7 +482,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdPara
         __syncthreads();
         const int qn = next_tile(qt + 1);
         if (qn < n_qt) {
-            tile_fetch(qr, Qb, p.D, qn * QT, p.Tq, tid);
+            tile_fetch(qr, Qb, p.LQ, qn * QT, p.Tq, tid);
             tile_fetch(gr, dOb, p.D, qn * QT, p.Tq, tid);
             ml = make_float2(0.f, 0.f); dsv = 0.f;
             if (tid < QT && qn * QT + tid < p.Tq) { ml = LSEb[qn * QT + tid]; dsv = Dsb[qn * QT + tid]; }
@@ -521,9 +523,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdPara
     // ---- store dK, dV rows (transpose through LDS) --------------------------------------------------------------
     __syncthreads();
     float* E = smem + wave * (32 * AT_KLD);
-    store_transposed(E, dk, 1.0f, p.dK + ((int64_t)b * p.Tk) * p.D + (int64_t)h * AT_DH, p.D, k0w, p.Tk, lane);
+    store_transposed(E, dk, 1.0f, p.dK + ((int64_t)b * p.Tk) * p.LQ + (int64_t)h * AT_DH, p.LQ, k0w, p.Tk, lane);
     __builtin_amdgcn_wave_barrier();
-    store_transposed(E, dv, 1.0f, p.dV + ((int64_t)b * p.Tk) * p.D + (int64_t)h * AT_DH, p.D, k0w, p.Tk, lane);
+    store_transposed(E, dv, 1.0f, p.dV + ((int64_t)b * p.Tk) * p.LQ + (int64_t)h * AT_DH, p.LQ, k0w, p.Tk, lane);
 }
 
 // =====================================================================================================
@@ -546,10 +548,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdParams
     const int b = bh / p.H, h = bh - b * p.H;
     const int q0 = qb * AT_BQ + wave * 32;
     const int q = q0 + l31;
-    const float* Qb = p.Q + ((int64_t)b * p.Tq) * p.D + (int64_t)h * AT_DH;
+    const float* Qb = p.Q + ((int64_t)b * p.Tq) * p.LQ + (int64_t)h * AT_DH;
     const float* dOb = p.dO + ((int64_t)b * p.Tq) * p.D + (int64_t)h * AT_DH;
-    const float* Kb = p.K + ((int64_t)b * p.Tk) * p.D + (int64_t)h * AT_DH;
-    const float* Vb = p.V + ((int64_t)b * p.Tk) * p.D + (int64_t)h * AT_DH;
+    const float* Kb = p.K + ((int64_t)b * p.Tk) * p.LQ + (int64_t)h * AT_DH;
+    const float* Vb = p.V + ((int64_t)b * p.Tk) * p.LQ + (int64_t)h * AT_DH;
     const int32_t* kv = p.key_valid ? p.key_valid + (int64_t)b * p.Tk : nullptr;
     const int shift = p.Tk - p.Tq;
     const int fv = first_valid_key(kv, p.Tk, tid, &sh_fv);
@@ -563,7 +565,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdParams
     for (int g = 0; g < 8; ++g) {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
         if (q_in) {
-            a = *reinterpret_cast<const float4*>(Qb + (int64_t)q * p.D + 8 * g + 4 * lh);
+            a = *reinterpret_cast<const float4*>(Qb + (int64_t)q * p.LQ + 8 * g + 4 * lh);
             c = *reinterpret_cast<const float4*>(dOb + (int64_t)q * p.D + 8 * g + 4 * lh);
         }
         qf[g][0] = a.x * sl2; qf[g][1] = a.y * sl2; qf[g][2] = a.z * sl2; qf[g][3] = a.w * sl2;
@@ -584,8 +586,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdParams
     TileRegs kr, vr;
     int kflag = 1;
     if (n_tiles > 0) {
-        tile_fetch(kr, Kb, p.D, 0, p.Tk, tid);
-        tile_fetch(vr, Vb, p.D, 0, p.Tk, tid);
+        tile_fetch(kr, Kb, p.LQ, 0, p.Tk, tid);
+        tile_fetch(vr, Vb, p.LQ, 0, p.Tk, tid);
         kflag = key_flag(kv, 0, p.Tk, lane);
     }
     for (int t = 0; t < n_tiles; ++t) {
@@ -596,8 +598,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdParams
         const unsigned long long valid = __ballot(kflag != 0) >> (4 * lh);
         __syncthreads();
         if (t + 1 < n_tiles) {
-            tile_fetch(kr, Kb, p.D, kv0 + AT_BK, p.Tk, tid);
-            tile_fetch(vr, Vb, p.D, kv0 + AT_BK, p.Tk, tid);
+            tile_fetch(kr, Kb, p.LQ, kv0 + AT_BK, p.Tk, tid);
+            tile_fetch(vr, Vb, p.LQ, kv0 + AT_BK, p.Tk, tid);
             kflag = key_flag(kv, kv0 + AT_BK, p.Tk, lane);
         }
         if (!(skip_ok && kv0 > q0 + 31 + shift)) {
@@ -621,7 +623,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdParams
         }
     }
     __syncthreads();
-    store_transposed(smem + wave * (32 * AT_KLD), dq, 1.0f, p.dQ + ((int64_t)b * p.Tq) * p.D + (int64_t)h * AT_DH, p.D, q0, p.Tq, lane);
+    store_transposed(smem + wave * (32 * AT_KLD), dq, 1.0f, p.dQ + ((int64_t)b * p.Tq) * p.LQ + (int64_t)h * AT_DH, p.LQ, q0, p.Tq, lane);
 }
 
 }  // namespace nnhip
@@ -629,7 +631,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdParams
 using namespace nnhip;
 
 static int attn_check(const char* fn, const void* Q, const void* K, const void* V, int64_t B, int64_t H, int64_t Tq,
-                      int64_t Tk, int64_t dh) {
+                      int64_t Tk, int64_t dh, int64_t ld_qkv) {
+    NNHIP_CHECK_ARG(ld_qkv == 0 || (ld_qkv >= H * dh && ld_qkv % 4 == 0), NNHIP_EINVAL,
+                    "%s: ld_qkv must be 0 or a multiple of 4 that is >= H * head_dim", fn);
     NNHIP_CHECK_ARG(B >= 0 && H > 0 && Tq >= 0 && Tk >= 0, NNHIP_EINVAL, "%s: bad sizes", fn);
     NNHIP_CHECK_ARG(dh == AT_DH, NNHIP_EINVAL, "%s: only head_dim 64 is supported by the fused kernel", fn);
     NNHIP_CHECK_ARG(Tq < (1 << 24) && Tk < (1 << 24) && B * H < (1 << 24), NNHIP_EINVAL, "%s: sizes too large", fn);
@@ -641,14 +645,14 @@ static int attn_check(const char* fn, const void* Q, const void* K, const void* 
 
 extern "C" int nnhipAttentionForward(const float* Q, const float* K, const float* V, const int32_t* key_valid,
                                      float* O, float* LSE, int64_t B, int64_t H, int64_t Tq, int64_t Tk,
-                                     int64_t head_dim, float scale, int causal, nnhipStream_t s) {
-    if (int rc = attn_check("nnhipAttentionForward", Q, K, V, B, H, Tq, Tk, head_dim)) return rc;
+                                     int64_t head_dim, int64_t ld_qkv, float scale, int causal, nnhipStream_t s) {
+    if (int rc = attn_check("nnhipAttentionForward", Q, K, V, B, H, Tq, Tk, head_dim, ld_qkv)) return rc;
     if (B == 0 || Tq == 0) return 0;
     NNHIP_CHECK_ARG(Tk > 0, NNHIP_EINVAL, "nnhipAttentionForward: Tk must be > 0");
     NNHIP_CHECK_ARG(O && LSE && aligned16(O), NNHIP_EINVAL, "nnhipAttentionForward: null / misaligned output");
     AttnParams p;
     p.Q = Q; p.K = K; p.V = V; p.O = O; p.LSE = LSE; p.key_valid = key_valid;
-    p.B = (int)B; p.H = (int)H; p.Tq = (int)Tq; p.Tk = (int)Tk; p.D = H * AT_DH; p.scale = scale; p.causal = causal;
+    p.B = (int)B; p.H = (int)H; p.Tq = (int)Tq; p.Tk = (int)Tk; p.D = H * AT_DH; p.LQ = ld_qkv ? ld_qkv : p.D; p.scale = scale; p.causal = causal;
     const int64_t qblocks = ceil_div(Tq, AT_BQ);
     hipLaunchKernelGGL(attn_fwd_kernel, dim3(mapped_grid(B * H, qblocks)), dim3(256), 0, (hipStream_t)s, p);
     NNHIP_LAUNCH_CHECK("attn_fwd_kernel");
@@ -658,8 +662,8 @@ extern "C" int nnhipAttentionForward(const float* Q, const float* K, const float
 extern "C" int nnhipAttentionBackward(const float* Q, const float* K, const float* V, const int32_t* key_valid,
                                       const float* O, const float* dO, const float* LSE, float* dQ, float* dK,
                                       float* dV, int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t head_dim,
-                                      float scale, int causal, nnhipStream_t s) {
-    if (int rc = attn_check("nnhipAttentionBackward", Q, K, V, B, H, Tq, Tk, head_dim)) return rc;
+                                      int64_t ld_qkv, float scale, int causal, nnhipStream_t s) {
+    if (int rc = attn_check("nnhipAttentionBackward", Q, K, V, B, H, Tq, Tk, head_dim, ld_qkv)) return rc;
     if (B == 0 || Tq == 0 || Tk == 0) return 0;
     NNHIP_CHECK_ARG(O && dO && LSE && dQ && dK && dV, NNHIP_EINVAL, "nnhipAttentionBackward: null pointer");
     NNHIP_CHECK_ARG(aligned16(dO) && aligned16(dQ) && aligned16(dK) && aligned16(dV), NNHIP_EALIGN,
@@ -674,7 +678,7 @@ extern "C" int nnhipAttentionBackward(const float* Q, const float* K, const floa
     AttnBwdParams p;
     p.Q = Q; p.K = K; p.V = V; p.dO = dO; p.LSE = LSE; p.Dsum = dsum; p.dQ = dQ; p.dK = dK; p.dV = dV;
     p.key_valid = key_valid; p.B = (int)B; p.H = (int)H; p.Tq = (int)Tq; p.Tk = (int)Tk; p.D = H * AT_DH;
-    p.scale = scale; p.causal = causal;
+    p.LQ = ld_qkv ? ld_qkv : p.D; p.scale = scale; p.causal = causal;
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3(mapped_grid(B * H, ceil_div(Tk, 128))), dim3(256), 0, st, p);
     NNHIP_LAUNCH_CHECK("attn_bwd_dkdv_kernel");
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(mapped_grid(B * H, ceil_div(Tq, AT_BQ))), dim3(256), 0, st, p);

@@ -52,8 +52,8 @@ _SIGNATURES = {
                                       c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_float, c_void_p]),
     "nnhipMaskedSoftmaxForward": (ctypes.c_int, [P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, ctypes.c_int, c_void_p]),
     "nnhipMaskedSoftmaxBackward": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, ctypes.c_int, c_void_p]),
-    "nnhipAttentionForward": (ctypes.c_int, [P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int64, c_float, ctypes.c_int, c_void_p]),
-    "nnhipAttentionBackward": (ctypes.c_int, [P, P, P, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int64, c_float, ctypes.c_int, c_void_p]),
+    "nnhipAttentionForward": (ctypes.c_int, [P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_float, ctypes.c_int, c_void_p]),
+    "nnhipAttentionBackward": (ctypes.c_int, [P, P, P, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_float, ctypes.c_int, c_void_p]),
     "nnhipEmbeddingForward": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, c_void_p]),
     "nnhipEmbeddingBackward": (ctypes.c_int, [P, P, P, c_int64, c_int64, c_int64, c_float, c_void_p]),
     "nnhipMul": (ctypes.c_int, [P, P, P, c_int64, c_void_p]),
@@ -131,11 +131,23 @@ def load_hip_function(name: str):
     return f
 
 
+class StridedView:
+    """A device array whose row stride travels as an explicit `ld` argument of the call (a column block of a wider
+    buffer, e.g. q inside a fused q|k|v projection): to_pointer hands over its address without the contiguity check."""
+
+    def __init__(self, tensor):
+        if not tensor.is_cuda or tensor.stride(-1) != 1:
+            raise ValueError("StridedView needs a device tensor with unit stride along its last dim")
+        self.tensor = tensor
+
+
 def to_pointer(obj):
     """Device array -> raw pointer (utils.py:72-82).  torch CUDA tensors play the role of CuPy arrays.
     NumPy arrays are rejected exactly like the reference does (utils.py:75-76)."""
     if obj is None:
         return None
+    if isinstance(obj, StridedView):
+        return obj.tensor.data_ptr()
     if hasattr(obj, "ctypes") and hasattr(obj, "__array_interface__"):
         raise TypeError("NumPy arrays are not supported here.")
     if hasattr(obj, "data_ptr"):

@@ -52,11 +52,24 @@ class GradBucket:
         self.overlap = overlap
         self.group = group
         self.sizes = [int(p.data.numel()) for p in self.params]
+        # Slot layout: `Module.parameters()` order, except that a parameter carrying `_bucket_group` (a list of
+        # parameters, e.g. the q/k/v projection weights of a fused attention block) pulls its group next to itself so a
+        # fused kernel can write all their gradients as one matrix.  Every rank builds the same model -> same layout.
+        index = {id(p): i for i, p in enumerate(self.params)}
+        self.layout, placed = [], set()
+        for i, p in enumerate(self.params):
+            if i in placed:
+                continue
+            group = [index[id(m)] for m in getattr(p, "_bucket_group", ()) if id(m) in index]
+            for j in (group if i in group else [i]):
+                if j not in placed:
+                    placed.add(j)
+                    self.layout.append(j)
         # 16-B aligned slots so the float4 kernels stay on their vector path
-        self.offsets, off = [], 0
-        for s in self.sizes:
-            self.offsets.append(off)
-            off += (s + 3) // 4 * 4
+        self.offsets, off = [0] * len(self.params), 0
+        for i in self.layout:
+            self.offsets[i] = off
+            off += (self.sizes[i] + 3) // 4 * 4
         self.extra_offset = off
         self.numel = off + ((extra_scalars + 3) // 4 * 4 if extra_scalars else 0)
         dev = self.params[0].data.device if self.params else "cpu"
@@ -71,14 +84,11 @@ class GradBucket:
         self._pending, self._works, self._launched = [], [], []
         if overlap:
             hi, idxs = self.extra_offset, []
-            for i in range(len(self.params) - 1, -1, -1):
+            for n, i in enumerate(reversed(self.layout)):
                 idxs.append(i)
-                if (hi - self.offsets[i]) * 4 >= segment_bytes or i == 0:
+                if (hi - self.offsets[i]) * 4 >= segment_bytes or n == len(self.layout) - 1:
                     self.segments.append((self.offsets[i], hi, idxs))
                     hi, idxs = self.offsets[i], []
-            if extra_scalars:     # the extra scalars (e.g. a global token count) travel with the LAST launched segment
-                lo, hi, idxs = self.segments[-1]
-                self.segments[-1] = (lo, hi, idxs)
             for k, (_, _, idxs) in enumerate(self.segments):
                 for i in idxs:
                     self._seg_of[id(self.params[i])] = k

@@ -14,7 +14,8 @@ import numpy as np
 from ...autograd import Tensor
 from ..modules import Module
 from .embedding import HIPDropout
-from .linear import HIPLinear
+from .linear import HIPLinear, _finish_param, hip_linear_module_backward, hip_linear_module_forward
+from ..._lib import StridedView
 from .utils import call_hip_function, get_current_stream_ptr
 
 
@@ -41,27 +42,42 @@ def attention_forward(q, k, v, key_valid, n_heads, scale, causal):
     return ctx, attn
 
 
+def _row_stride(*ts):
+    """Common row stride (floats) of [B,T,D] arrays that are dense tensors or column blocks of one wider buffer."""
+    ld = ts[0].stride(1)
+    for t in ts:
+        if t.stride(2) != 1 or t.stride(1) != ld or t.stride(0) != ld * t.shape[1]:
+            raise ValueError("fused attention needs q, k, v with unit column stride and one common row stride")
+    return ld
+
+
 def fused_attention_forward(q, k, v, key_valid, n_heads, scale, causal):
     """Flash-style forward (nnhipAttentionForward, head_dim 64): returns (ctx [B,Tq,D], lse [B,H,Tq,2]); the score
-    matrix is never materialised."""
+    matrix is never materialised.  q, k, v may be column blocks of one fused [B,T,3D] projection buffer."""
     import torch
     B, Tq, D = q.shape
     Tk = k.shape[1]
     ctx = torch.empty((B, Tq, D), dtype=torch.float32, device=q.device)
-    lse = torch.empty((B, n_heads, Tq, 2), dtype=torch.float32, device=q.device)   # (row max, log row sum)
-    call_hip_function("nnhipAttentionForward", q, k, v, key_valid, ctx, lse, B, n_heads, Tq, Tk, D // n_heads,
-                      1.0 / scale, int(causal), get_current_stream_ptr())
+    lse = torch.empty((B, n_heads, Tq, 2), dtype=torch.float32, device=q.device)   # (row max, log2 row sum)
+    call_hip_function("nnhipAttentionForward", StridedView(q), StridedView(k), StridedView(v), key_valid, ctx, lse, B,
+                      n_heads, Tq, Tk, D // n_heads, _row_stride(q, k, v), 1.0 / scale, int(causal),
+                      get_current_stream_ptr())
     return ctx, lse
 
 
-def fused_attention_backward(q, k, v, key_valid, ctx, lse, n_heads, scale, causal, dctx):
-    """Flash-style backward (nnhipAttentionBackward): (dq, dk, dv) from the saved ctx and row log-sum-exp."""
+def fused_attention_backward(q, k, v, key_valid, ctx, lse, n_heads, scale, causal, dctx, out=None):
+    """Flash-style backward (nnhipAttentionBackward): (dq, dk, dv) from the saved ctx and row statistics.
+    out = (dq, dk, dv) destinations laid out like q, k, v (e.g. column blocks of one [B,T,3D] buffer)."""
     import torch
     B, Tq, D = q.shape
     Tk = k.shape[1]
-    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-    call_hip_function("nnhipAttentionBackward", q, k, v, key_valid, ctx, dctx, lse, dq, dk, dv, B, n_heads, Tq, Tk,
-                      D // n_heads, 1.0 / scale, int(causal), get_current_stream_ptr())
+    dq, dk, dv = out if out is not None else (torch.empty_like(q), torch.empty_like(k), torch.empty_like(v))
+    ld = _row_stride(q, k, v)
+    if _row_stride(dq, dk, dv) != ld:
+        raise ValueError("dq/dk/dv must share the row stride of q/k/v")
+    call_hip_function("nnhipAttentionBackward", StridedView(q), StridedView(k), StridedView(v), key_valid, ctx, dctx,
+                      lse, StridedView(dq), StridedView(dk), StridedView(dv), B, n_heads, Tq, Tk, D // n_heads, ld,
+                      1.0 / scale, int(causal), get_current_stream_ptr())
     return dq, dk, dv
 
 
@@ -129,6 +145,75 @@ class _HIPFusedAttentionTensor(Tensor):
         self.grad_fn = grad_fn
 
 
+class _HIPQKVProjTensor(Tensor):
+    """qkv[B,T,3D] = X [Wq;Wk;Wv]^T + [bq,bk,bv]: the three projections of self-attention as ONE GEMM (three
+    generations of tiles instead of three single-generation launches), one K = 3D dX GEMM and one split-K dW GEMM."""
+
+    def __init__(self, data, args, op, device):
+        super().__init__(data, args, op, device=device, _nocopy=True)
+
+        def grad_fn(X: Tensor, weights, biases, Wqkv, rows, D, grad):
+            import torch
+            grad = grad if grad.is_contiguous() else grad.contiguous()
+            gW = _fused_grad_dest(weights, (3 * D, D))
+            gb = _fused_grad_dest(biases, (3, D))
+            grad_X = torch.empty_like(X.data) if X.requires_grad else None
+            held = X.foldable_grad() if grad_X is not None else None
+            hook = getattr(weights[0], "_grad_hook", None)
+            if hook is not None and grad_X is not None:    # DP overlap: parameter gradients first (see linear.py)
+                hip_linear_module_backward(X.data, Wqkv, grad, None, gW, gb, rows, D, 3 * D)
+            else:
+                hip_linear_module_backward(X.data, Wqkv, grad, grad_X, gW, gb, rows, D, 3 * D, grad_X_addend=held)
+            for i, (w, b) in enumerate(zip(weights, biases)):
+                _finish_param(w, gW[i * D:(i + 1) * D])
+                _finish_param(b, gb[i:i + 1])
+            if hook is not None and grad_X is not None:
+                hip_linear_module_backward(X.data, Wqkv, grad, grad_X, None, None, rows, D, 3 * D, grad_X_addend=held)
+            if grad_X is not None:
+                if held is not None:
+                    X.grad = grad_X
+                else:
+                    X.apply_grad(grad_X)
+
+        self.grad_fn = grad_fn
+
+
+def _adjacent(ts):
+    """Back-to-back views of ONE storage (separately allocated tensors can be neighbours by accident)."""
+    base = ts[0].untyped_storage().data_ptr()
+    return all(t.is_contiguous() and t.untyped_storage().data_ptr() == base for t in ts) and all(
+        ts[i + 1].data_ptr() == ts[i].data_ptr() + ts[i].numel() * 4 for i in range(len(ts) - 1))
+
+
+def _fused_grad_dest(params, shape):
+    """One buffer for the gradients of `params` (in order): their DP bucket slots when those are free and back-to-back
+    (GradBucket keeps a `_bucket_group` adjacent), else a fresh allocation the per-parameter views point into."""
+    import torch
+    slots = [getattr(p, "_grad_slot", None) for p in params]
+    if all(s is not None for s in slots) and all(p.grad is None for p in params) and _adjacent(slots):
+        return torch.as_strided(slots[0], shape, (shape[1], 1))
+    return torch.empty(shape, dtype=torch.float32, device=params[0].data.device)
+
+
+class _HIPFusedSelfAttentionTensor(Tensor):
+    """ctx = attention(q, k, v) with q, k, v the three column blocks of one [B,T,3D] projection tensor."""
+
+    def __init__(self, data, args, op, device):
+        super().__init__(data, args, op, device=device, _nocopy=True)
+
+        def grad_fn(qkv: Tensor, lse, key_valid, n_heads, scale, causal, grad):
+            import torch
+            grad = grad if grad.is_contiguous() else grad.contiguous()
+            D = self.data.shape[-1]
+            x = qkv.data
+            dqkv = torch.empty_like(x)
+            fused_attention_backward(x[..., 0:D], x[..., D:2 * D], x[..., 2 * D:], key_valid, self.data, lse, n_heads,
+                                     scale, causal, grad, out=(dqkv[..., 0:D], dqkv[..., D:2 * D], dqkv[..., 2 * D:]))
+            qkv.apply_grad(dqkv)
+
+        self.grad_fn = grad_fn
+
+
 FUSED_HEAD_DIM = 64
 
 
@@ -145,6 +230,45 @@ class HIPMultiHeadAttention(Module):
         self.wk = HIPLinear(d_model, d_model, device=device)
         self.wv = HIPLinear(d_model, d_model, device=device)
         self.fc = HIPLinear(d_model, d_model, device=device)
+        self.fuse_qkv = True     # self-attention + need_weights=False + head_dim 64: one GEMM for the q|k|v projections
+        if self.depth == FUSED_HEAD_DIM and device == "cuda":
+            self._pack_qkv()     # now, so a GradBucket built before the first forward already sees the slot groups
+
+    def _pack_qkv(self):
+        """Make wq/wk/wv weights (and biases) three views of one [3D,D] ([3,D]) buffer, so the fused projection reads
+        them as one operand.  Values, Parameter objects, their order and state_dict are unchanged; re-packed if someone
+        re-bound .data (e.g. Module.to)."""
+        import torch
+        D = self.d_model
+        lins = (self.wq, self.wk, self.wv)
+        ws, bs = [lin.weight for lin in lins], [lin.bias for lin in lins]
+        if not _adjacent([w.data for w in ws]):
+            buf = torch.empty((3 * D, D), dtype=torch.float32, device=ws[0].data.device)
+            for i, w in enumerate(ws):
+                buf[i * D:(i + 1) * D].copy_(w.data)
+                w.data = buf[i * D:(i + 1) * D]
+        if not _adjacent([b.data for b in bs]):
+            buf = torch.empty((3, D), dtype=torch.float32, device=bs[0].data.device)
+            for i, b in enumerate(bs):
+                buf[i:i + 1].copy_(b.data.reshape(1, D))
+                b.data = buf[i:i + 1]
+        ws[0]._bucket_group, bs[0]._bucket_group = ws, bs      # GradBucket keeps their slots back-to-back
+        return ws, bs, torch.as_strided(ws[0].data, (3 * D, D), (D, 1)), torch.as_strided(bs[0].data, (1, 3 * D), (3 * D, 1))
+
+    def _forward_fused_qkv(self, x: Tensor, key_valid, causal, residual):
+        import torch
+        D = self.d_model
+        ws, bs, Wqkv, bqkv = self._pack_qkv()
+        rows = int(np.prod(x.shape[:-1]))
+        qkv = torch.empty(tuple(x.shape[:-1]) + (3 * D,), dtype=torch.float32, device=x.data.device)
+        hip_linear_module_forward(x.data, Wqkv, bqkv, qkv, rows, D, 3 * D)
+        qkv_t = _HIPQKVProjTensor(qkv, (x, ws, bs, Wqkv, rows, D), "qkv_proj", device="cuda")
+        q3 = qkv.reshape(-1, x.shape[-2], 3 * D) if qkv.dim() != 3 else qkv
+        ctx, lse = fused_attention_forward(q3[..., 0:D], q3[..., D:2 * D], q3[..., 2 * D:], key_valid, self.n_heads,
+                                           self.scale, causal)
+        ctx_t = _HIPFusedSelfAttentionTensor(ctx, (qkv_t, lse, key_valid, self.n_heads, self.scale, causal),
+                                             "fused_self_attention", device="cuda")
+        return self.fc(ctx_t, residual=residual)
 
     def forward(self, q: Tensor, k: Tensor, v: Tensor, key_valid=None, causal=True, need_weights=True, residual=None):
         """key_valid: int32 device array [B,Tk] (1 = real token, 0 = padding) or None.  The notebook's dense
@@ -155,6 +279,9 @@ class HIPMultiHeadAttention(Module):
         residual (extension): out = residual + fc(ctx), folded into the output projection's epilogue."""
         if self.dropout.p != 0 and self.dropout.training:
             raise NotImplementedError("attention dropout > 0 is not implemented on the HIP path yet")
+        if (not need_weights and self.depth == FUSED_HEAD_DIM and q is k and k is v and self.fuse_qkv
+                and self.wq.bias is not None and q.dtype == "float32" and q.data.is_contiguous()):
+            return self._forward_fused_qkv(q, key_valid, causal, residual), None
         qp, kp, vp = self.wq(q), self.wk(k), self.wv(v)
         if not need_weights and self.depth == FUSED_HEAD_DIM:
             ctx, lse = fused_attention_forward(qp.data, kp.data, vp.data, key_valid, self.n_heads, self.scale, causal)

@@ -199,3 +199,32 @@ def test_grad_bucket_allreduce_gloo_world2(overlap):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(results) == [(0, True), (1, True)]
+
+
+def test_grad_bucket_keeps_bucket_groups_adjacent():
+    """Parameters tied by `_bucket_group` (q/k/v projection weights of a fused attention block) get back-to-back
+    slots so one kernel can write their gradients as a single matrix; everything else keeps parameters() order."""
+    import torch
+    from neunet_hip.distributed import GradBucket
+
+    class P:
+        def __init__(self, *shape):
+            self.data = torch.zeros(*shape)
+            self.grad = None
+
+    wq, bq, wk, bk, wv, bv, other = P(8, 8), P(1, 8), P(8, 8), P(1, 8), P(8, 8), P(1, 8), P(5)
+    wq._bucket_group, bq._bucket_group = [wq, wk, wv], [bq, bk, bv]
+    params = [other, wq, bq, wk, bk, wv, bv]
+    for overlap in (False, True):
+        bucket = GradBucket(params, extra_scalars=1, overlap=overlap, segment_bytes=64)
+        assert [params[i] for i in bucket.layout] == [other, wq, wk, wv, bq, bk, bv]
+        off = {id(p): o for p, o in zip(params, bucket.offsets)}
+        assert off[id(wk)] == off[id(wq)] + 64 and off[id(wv)] == off[id(wk)] + 64
+        assert off[id(bk)] == off[id(bq)] + 8 and off[id(bv)] == off[id(bk)] + 8
+        assert wq._grad_slot.data_ptr() + 64 * 4 == wk._grad_slot.data_ptr()
+        if overlap:   # segments tile [0, extra_offset) exactly, in reverse layout order
+            spans = sorted((lo, hi) for lo, hi, _ in bucket.segments)
+            assert spans[0][0] == 0 and spans[-1][1] == bucket.extra_offset
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            assert sorted(i for _, _, idxs in bucket.segments for i in idxs) == list(range(len(params)))
+        bucket.detach()
