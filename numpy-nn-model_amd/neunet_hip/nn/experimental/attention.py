@@ -24,8 +24,9 @@ def _gemm_ex(A, B, C, M, N, K, lda, ldb, ldc, akm, bkm, b1, sA1, sB1, sC1, b2, s
                       b2, sA2, sB2, sC2, float(alpha), get_current_stream_ptr())
 
 
-def attention_forward(q, k, v, key_valid, n_heads, scale, causal):
-    """q,k,v: device arrays [B,T,D] (D = H*dh).  Returns (ctx [B,Tq,D], attn [B,H,Tq,Tk])."""
+def attention_forward(q, k, v, key_valid, n_heads, scale, causal, drop_mask=None):
+    """q,k,v: device arrays [B,T,D] (D = H*dh).  Returns (ctx [B,Tq,D], attn [B,H,Tq,Tk], attn_used) where attn_used is
+    attn * drop_mask (the notebook's `self.dropout(softmax(scores))`, cell 2) or attn itself without dropout."""
     import torch
     B, Tq, D = q.shape
     Tk = k.shape[1]
@@ -36,10 +37,14 @@ def attention_forward(q, k, v, key_valid, n_heads, scale, causal):
     attn = scores  # softmax in place over the scores buffer
     call_hip_function("nnhipMaskedSoftmaxForward", attn, scores, key_valid, B, H, Tq, Tk, 1.0 / scale,
                       int(causal), get_current_stream_ptr())
+    used = attn
+    if drop_mask is not None:
+        used = torch.empty_like(attn)
+        call_hip_function("nnhipMul", used, attn, drop_mask, attn.numel(), get_current_stream_ptr())
     ctx = torch.empty((B, Tq, D), dtype=torch.float32, device=q.device)
-    # ctx[b,:,h,:] = attn[b,h] (Tq x Tk, k-major) x v[b,:,h,:] (Tk x dh, outer-major, ldb=D) -> written in [B,T,D]
-    _gemm_ex(attn, v, ctx, Tq, dh, Tk, Tk, D, D, 1, 0, B, H * Tq * Tk, Tk * D, Tq * D, H, Tq * Tk, dh, dh)
-    return ctx, attn
+    # ctx[b,:,h,:] = used[b,h] (Tq x Tk, k-major) x v[b,:,h,:] (Tk x dh, outer-major, ldb=D) -> written in [B,T,D]
+    _gemm_ex(used, v, ctx, Tq, dh, Tk, Tk, D, D, 1, 0, B, H * Tq * Tk, Tk * D, Tq * D, H, Tq * Tk, dh, dh)
+    return ctx, attn, used
 
 
 def _row_stride(*ts):
@@ -81,8 +86,10 @@ def fused_attention_backward(q, k, v, key_valid, ctx, lse, n_heads, scale, causa
     return dq, dk, dv
 
 
-def attention_backward(q, k, v, attn, key_valid, n_heads, scale, causal, dctx, need=(True, True, True)):
-    """Returns (dq, dk, dv) in the [B,T,D] layout of the projections."""
+def attention_backward(q, k, v, attn, key_valid, n_heads, scale, causal, dctx, need=(True, True, True),
+                       drop_mask=None, attn_used=None):
+    """Returns (dq, dk, dv) in the [B,T,D] layout of the projections.  With attention dropout: attn_used = attn*mask
+    feeds dV, and the gradient of the attention map is multiplied by the same mask before the softmax backward."""
     import torch
     B, Tq, D = q.shape
     Tk = k.shape[1]
@@ -94,7 +101,10 @@ def attention_backward(q, k, v, attn, key_valid, n_heads, scale, causal, dctx, n
     if need[2]:
         dv = torch.empty_like(v)
         # dv[b,:,h,:] = attn[b,h]^T (A outer-major, lda=Tk) x dctx[b,:,h,:] (outer-major, ldb=D)
-        _gemm_ex(attn, dctx, dv, Tk, dh, Tq, Tk, D, D, 0, 0, B, H * Tq * Tk, Tq * D, Tk * D, H, Tq * Tk, dh, dh)
+        _gemm_ex(attn if attn_used is None else attn_used, dctx, dv, Tk, dh, Tq, Tk, D, D, 0, 0, B, H * Tq * Tk, Tq * D,
+                 Tk * D, H, Tq * Tk, dh, dh)
+    if drop_mask is not None:
+        call_hip_function("nnhipMul", dattn, dattn, drop_mask, dattn.numel(), get_current_stream_ptr())
     # dscores (in place over dattn) = where(mask, 0, softmax_bwd(dattn, attn)) / scale
     call_hip_function("nnhipMaskedSoftmaxBackward", dattn, dattn, attn, key_valid, B, H, Tq, Tk, 1.0 / scale,
                       int(causal), get_current_stream_ptr())
@@ -113,10 +123,11 @@ class _HIPAttentionTensor(Tensor):
     def __init__(self, data, args, op, device):
         super().__init__(data, args, op, device=device, _nocopy=True)
 
-        def grad_fn(q: Tensor, k: Tensor, v: Tensor, attn, key_valid, n_heads, scale, causal, grad):
+        def grad_fn(q: Tensor, k: Tensor, v: Tensor, attn, key_valid, n_heads, scale, causal, drop_mask, attn_used,
+                    grad):
             grad = grad if grad.is_contiguous() else grad.contiguous()
             dq, dk, dv = attention_backward(q.data, k.data, v.data, attn, key_valid, n_heads, scale, causal, grad,
-                                            (q.requires_grad, k.requires_grad, v.requires_grad))
+                                            (q.requires_grad, k.requires_grad, v.requires_grad), drop_mask, attn_used)
             if dq is not None:
                 q.apply_grad(dq)
             if dk is not None:
@@ -270,25 +281,32 @@ class HIPMultiHeadAttention(Module):
                                              "fused_self_attention", device="cuda")
         return self.fc(ctx_t, residual=residual)
 
-    def forward(self, q: Tensor, k: Tensor, v: Tensor, key_valid=None, causal=True, need_weights=True, residual=None):
+    def forward(self, q: Tensor, k: Tensor, v: Tensor, key_valid=None, causal=True, need_weights=True, residual=None,
+                drop_mask=None):
         """key_valid: int32 device array [B,Tk] (1 = real token, 0 = padding) or None.  The notebook's dense
         mask get_pad_mask(x) & get_sub_mask(x) (cell 7) is exactly (key_valid, causal=True).
+
+        drop_mask ([B,H,Tq,Tk], entries 0 or 1/(1-p)) injects the attention-dropout mask (parity tests); with
+        dropout p > 0 in training mode one is drawn with the device RNG.  Dropout runs on the GEMM + masked-softmax path.
 
         need_weights=False (training steps that never look at the attention map) takes the fused flash-style
         kernels when head_dim == 64 and returns (out, None): scores/attn/dattn are never written to HBM.
         residual (extension): out = residual + fc(ctx), folded into the output projection's epilogue."""
-        if self.dropout.p != 0 and self.dropout.training:
-            raise NotImplementedError("attention dropout > 0 is not implemented on the HIP path yet")
-        if (not need_weights and self.depth == FUSED_HEAD_DIM and q is k and k is v and self.fuse_qkv
+        dropping = drop_mask is not None or (self.dropout.p != 0 and self.dropout.training)
+        if (not dropping and not need_weights and self.depth == FUSED_HEAD_DIM and q is k and k is v and self.fuse_qkv
                 and self.wq.bias is not None and q.dtype == "float32" and q.data.is_contiguous()):
             return self._forward_fused_qkv(q, key_valid, causal, residual), None
         qp, kp, vp = self.wq(q), self.wk(k), self.wv(v)
-        if not need_weights and self.depth == FUSED_HEAD_DIM:
+        if not dropping and not need_weights and self.depth == FUSED_HEAD_DIM:
             ctx, lse = fused_attention_forward(qp.data, kp.data, vp.data, key_valid, self.n_heads, self.scale, causal)
             ctx_t = _HIPFusedAttentionTensor(ctx, (qp, kp, vp, lse, key_valid, self.n_heads, self.scale, causal),
                                              "fused_attention", device="cuda")
             return self.fc(ctx_t, residual=residual), None
-        ctx, attn = attention_forward(qp.data, kp.data, vp.data, key_valid, self.n_heads, self.scale, causal)
-        ctx_t = _HIPAttentionTensor(ctx, (qp, kp, vp, attn, key_valid, self.n_heads, self.scale, causal),
-                                    "attention", device="cuda")
-        return self.fc(ctx_t, residual=residual), attn
+        if dropping and drop_mask is None:   # attention dropout (cell 2: self.dropout(softmax(scores))), device RNG
+            import torch
+            shape = (qp.shape[0], self.n_heads, qp.shape[1], kp.shape[1])
+            drop_mask = (torch.rand(shape, device=qp.data.device) >= self.dropout.p).to(torch.float32) * self.dropout.scale
+        ctx, attn, used = attention_forward(qp.data, kp.data, vp.data, key_valid, self.n_heads, self.scale, causal, drop_mask)
+        ctx_t = _HIPAttentionTensor(ctx, (qp, kp, vp, attn, key_valid, self.n_heads, self.scale, causal, drop_mask,
+                                          used if drop_mask is not None else None), "attention", device="cuda")
+        return self.fc(ctx_t, residual=residual), used

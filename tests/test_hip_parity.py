@@ -767,6 +767,48 @@ def test_fused_attention_vs_oracle(hip, B, Tn, D, H, causal):
         np.testing.assert_allclose(host(lin.bias.grad), db, rtol=1e-4, atol=5e-4)
 
 
+@pytest.mark.parametrize("B,Tn,D,H", [(2, 50, 64, 4), (2, 128, 128, 2)])
+def test_mha_attention_dropout(hip, B, Tn, D, H):
+    """cell 2's `self.dropout(softmax(scores))` with an injected mask (the reference draws it with the host NumPy RNG):
+    output, returned map and every gradient equal the oracle's; p > 0 in training mode draws a device mask (runs, finite,
+    different from p = 0), eval mode is the identity."""
+    import neunet_hip.nn as nn
+    rng = np.random.default_rng(B * Tn + 5)
+    mha = nn.MultiHeadAttention(D, H, dropout=0.25)
+    ps = []
+    for lin in (mha.wq, mha.wk, mha.wv, mha.fc):
+        ps += [host(lin.weight.data), host(lin.bias.data)]
+    X = rng.standard_normal((B, Tn, D)).astype(np.float32)
+    tok = rng.integers(1, 9, (B, Tn))
+    tok[0, -5:] = 0
+    drop = ((rng.random((B, H, Tn, Tn)) >= 0.25) / 0.75).astype(np.float32)
+    ref = O.MHA(*ps, n_heads=H)
+    yr, ar = ref.forward(X, O.attention_mask(tok, 0), drop_mask=drop)
+    kv = dev((tok != 0).astype(np.int32))
+    x = T(hip, X)
+    y, attn = mha(x, x, x, kv, causal=True, drop_mask=dev(drop))
+    np.testing.assert_allclose(host(attn), ar, rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(host(y.data), yr, **TOL)
+    dY = rng.standard_normal(yr.shape).astype(np.float32)
+    y.backward(dY)
+    dxr, gr = ref.backward(dY)
+    np.testing.assert_allclose(host(x.grad), dxr, rtol=1e-4, atol=2e-4)
+    for lin, dW, db in zip((mha.wq, mha.wk, mha.wv, mha.fc), gr[0::2], gr[1::2]):
+        np.testing.assert_allclose(host(lin.weight.grad), dW, rtol=1e-4, atol=5e-4)
+        np.testing.assert_allclose(host(lin.bias.grad), db, rtol=1e-4, atol=5e-4)
+    # device RNG in training mode; identity in eval mode (fused kernels again when need_weights=False)
+    x2 = T(hip, X)
+    y_train, a_train = mha(x2, x2, x2, kv, causal=True, need_weights=False)
+    assert a_train is not None and np.isfinite(host(y_train.data)).all()
+    assert (host(a_train) == 0).mean() > 0.5          # causal zeros + ~25 % dropped
+    y_train.backward(dY)
+    assert np.isfinite(host(x2.grad)).all()
+    mha.dropout.eval()
+    y_eval, _ = mha(x2, x2, x2, kv, causal=True)
+    ref0 = O.MHA(*ps, n_heads=H)
+    np.testing.assert_allclose(host(y_eval.data), ref0.forward(X, O.attention_mask(tok, 0))[0], **TOL)
+
+
 def test_fused_attention_fully_masked_rows(hip):
     """Queries whose every visible key is padding: the reference's where(mask, scores, -1e9) makes their softmax
     uniform over ALL keys (incl. future ones) -- the fused kernels must reproduce that and its gradient, so the
@@ -781,7 +823,7 @@ def test_fused_attention_fully_masked_rows(hip):
     kvh[1, 5:9] = 0
     kv = dev(kvh)
     scale = float(np.sqrt(D))
-    ctx_u, attn = A.attention_forward(q, k, v, kv, H, scale, True)
+    ctx_u, attn, _ = A.attention_forward(q, k, v, kv, H, scale, True)
     dq_u, dk_u, dv_u = A.attention_backward(q, k, v, attn, kv, H, scale, True, do)
     ctx_f, lse = A.fused_attention_forward(q, k, v, kv, H, scale, True)
     dq_f, dk_f, dv_f = A.fused_attention_backward(q, k, v, kv, ctx_f, lse, H, scale, True, do)

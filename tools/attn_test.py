@@ -11,7 +11,7 @@ for (B, T, H, causal, pad) in [(2, 256, 8, True, True), (3, 100, 4, True, True),
     kv = torch.ones(B, T, dtype=torch.int32, device="cuda")
     if pad: kv[0, -T // 5:] = 0
     scale = float(np.sqrt(D))
-    ref, attn = attention_forward(q, k, v, kv, H, scale, causal)
+    ref, attn, _ = attention_forward(q, k, v, kv, H, scale, causal)
     out, lse = fused_attention_forward(q, k, v, kv, H, scale, causal)
     err = (out - ref).abs().max().item()
     print(f"B{B} T{T} H{H} causal{causal}: max|fused-unfused| = {err:.3e}", flush=True)
@@ -19,7 +19,7 @@ for (B, T, H, causal, pad) in [(2, 256, 8, True, True), (3, 100, 4, True, True),
 B, T, H = 1, 128, 1; D = 64
 q, k, v = [torch.randn(B, T, D, device="cuda") for _ in range(3)]
 kv = torch.ones(B, T, dtype=torch.int32, device="cuda"); kv[0, :3] = 0
-ref, _ = attention_forward(q, k, v, kv, H, 8.0, True)
+ref, _, _ = attention_forward(q, k, v, kv, H, 8.0, True)
 out, _ = fused_attention_forward(q, k, v, kv, H, 8.0, True)
 print("fully-masked rows: ", (out - ref).abs().max().item())
 B, T, H = 64, 256, 8; D = 512
@@ -28,7 +28,7 @@ kv = torch.ones(B, T, dtype=torch.int32, device="cuda")
 print("unfused fwd ms", bench(lambda: attention_forward(q, k, v, kv, H, 22.6, True), 20))
 print("fused   fwd ms", bench(lambda: fused_attention_forward(q, k, v, kv, H, 22.6, True), 20))
 do = torch.randn_like(q)
-ctx_u, attn = attention_forward(q, k, v, kv, H, 22.6, True)
+ctx_u, attn, _ = attention_forward(q, k, v, kv, H, 22.6, True)
 ctx_f, lse = fused_attention_forward(q, k, v, kv, H, 22.6, True)
 gu = attention_backward(q, k, v, attn, kv, H, 22.6, True, do)
 gf = fused_attention_backward(q, k, v, kv, ctx_f, lse, H, 22.6, True, do)
