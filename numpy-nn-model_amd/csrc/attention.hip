@@ -50,7 +50,8 @@ struct AttnParams {
 
 struct AttnBwdParams {
     const float* Q; const float* K; const float* V; const float* dO;   // [B, T, D]
-    const float* LSE; const float* Dsum;                               // [B, H, Tq, 2], [B, H, Tq]
+    const float* LSE; float* Dsum;                                     // [B, H, Tq, 2], [B, H, Tq] (written by the dQ kernel)
+    const float* O;                                                    // [B, Tq, D] forward output
     float* dQ; float* dK; float* dV;                                   // [B, T, D]
     const int32_t* key_valid;
     int B, H, Tq, Tk;
@@ -384,21 +385,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     store_transposed(smem + wave * (32 * AT_KLD), o, inv, p.O + ((int64_t)b * p.Tq) * p.D + (int64_t)h * AT_DH, p.D, q0, p.Tq, lane);
 }
 
-// Dsum[b,h,q] = sum_d dO[b,q,h,d] * O[b,q,h,d]   (= sum_k dP*P, the softmax-backward row term).  One wave per row.
-__global__ __launch_bounds__(256) void attn_bwd_dsum_kernel(const float* __restrict__ dO, const float* __restrict__ O,
-                                                            float* __restrict__ Dsum, int B, int H, int Tq, int64_t D) {
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);       // over B*H*Tq
-    const int lane = threadIdx.x & 63;
-    if (row >= (int64_t)B * H * Tq) return;
-    const int q = (int)(row % Tq);
-    const int64_t bh = row / Tq;
-    const int h = (int)(bh % H);
-    const int64_t b = bh / H;
-    const int64_t off = (b * Tq + q) * D + (int64_t)h * AT_DH + lane;
-    const float v = wave_sum(dO[off] * O[off]);
-    if (lane == 0) Dsum[row] = v;
-}
-
 // =====================================================================================================
 // dK, dV: block = 128 keys (4 waves x 32), loop over 32-query tiles
 // S[q,key] = Q K^T (A = Q tile rows from LDS, B = K fragments in registers; lane <-> key, registers <-> queries),
@@ -557,20 +543,27 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdParams
     const int fv = first_valid_key(kv, p.Tk, tid, &sh_fv);
     const bool q_in = q < p.Tq;
     const float2 ml = q_in ? reinterpret_cast<const float2*>(p.LSE)[((int64_t)b * p.H + h) * p.Tq + q] : make_float2(0.f, 0.f);
-    const float dsum = q_in ? p.Dsum[((int64_t)b * p.H + h) * p.Tq + q] : 0.f;
+    const float* Ob = p.O + ((int64_t)b * p.Tq) * p.D + (int64_t)h * AT_DH;
 
     float qf[8][4], gf[8][4];                                   // Q (pre-scaled, log2 units) and dO fragments of this lane's query
     const float sl2 = p.scale * AT_LOG2E;
+    float dpart = 0.f;                                          // this half-wave's part of Dsum[q] = sum_d dO[q,d] O[q,d]
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a, o4 = a;
         if (q_in) {
             a = *reinterpret_cast<const float4*>(Qb + (int64_t)q * p.LQ + 8 * g + 4 * lh);
             c = *reinterpret_cast<const float4*>(dOb + (int64_t)q * p.D + 8 * g + 4 * lh);
+            o4 = *reinterpret_cast<const float4*>(Ob + (int64_t)q * p.D + 8 * g + 4 * lh);
         }
         qf[g][0] = a.x * sl2; qf[g][1] = a.y * sl2; qf[g][2] = a.z * sl2; qf[g][3] = a.w * sl2;
         gf[g][0] = c.x; gf[g][1] = c.y; gf[g][2] = c.z; gf[g][3] = c.w;
+        dpart += c.x * o4.x + c.y * o4.y + c.z * o4.z + c.w * o4.w;
     }
+    // Dsum (= sum_k dP P, the softmax-backward row term) is produced here -- the dO fragments are already in registers --
+    // and saved for the dK/dV kernel, which runs after this one.
+    const float dsum = dpart + __shfl_xor(dpart, 32, 64);
+    if (lh == 0 && q_in) p.Dsum[((int64_t)b * p.H + h) * p.Tq + q] = dsum;
     int n_tiles = (p.Tk + AT_BK - 1) / AT_BK;
     const bool skip_ok = p.causal && fv <= qb * AT_BQ + shift;
     if (skip_ok) {
@@ -666,22 +659,19 @@ extern "C" int nnhipAttentionBackward(const float* Q, const float* K, const floa
     if (int rc = attn_check("nnhipAttentionBackward", Q, K, V, B, H, Tq, Tk, head_dim, ld_qkv)) return rc;
     if (B == 0 || Tq == 0 || Tk == 0) return 0;
     NNHIP_CHECK_ARG(O && dO && LSE && dQ && dK && dV, NNHIP_EINVAL, "nnhipAttentionBackward: null pointer");
-    NNHIP_CHECK_ARG(aligned16(dO) && aligned16(dQ) && aligned16(dK) && aligned16(dV), NNHIP_EALIGN,
-                    "nnhipAttentionBackward: dO/dQ/dK/dV must be 16-byte aligned");
+    NNHIP_CHECK_ARG(aligned16(dO) && aligned16(O) && aligned16(dQ) && aligned16(dK) && aligned16(dV), NNHIP_EALIGN,
+                    "nnhipAttentionBackward: O/dO/dQ/dK/dV must be 16-byte aligned");
     hipStream_t st = (hipStream_t)s;
     float* dsum = static_cast<float*>(workspace((size_t)B * H * Tq * sizeof(float)));
     NNHIP_CHECK_ARG(dsum != nullptr, NNHIP_ENOMEM, "nnhipAttentionBackward: workspace allocation failed");
-    const int64_t rows = B * H * Tq;
-    hipLaunchKernelGGL(attn_bwd_dsum_kernel, dim3((unsigned)ceil_div(rows, 4)), dim3(256), 0, st, dO, O, dsum, (int)B, (int)H,
-                       (int)Tq, H * AT_DH);
-    NNHIP_LAUNCH_CHECK("attn_bwd_dsum_kernel");
     AttnBwdParams p;
-    p.Q = Q; p.K = K; p.V = V; p.dO = dO; p.LSE = LSE; p.Dsum = dsum; p.dQ = dQ; p.dK = dK; p.dV = dV;
+    p.Q = Q; p.K = K; p.V = V; p.dO = dO; p.LSE = LSE; p.Dsum = dsum; p.O = O; p.dQ = dQ; p.dK = dK; p.dV = dV;
     p.key_valid = key_valid; p.B = (int)B; p.H = (int)H; p.Tq = (int)Tq; p.Tk = (int)Tk; p.D = H * AT_DH;
     p.LQ = ld_qkv ? ld_qkv : p.D; p.scale = scale; p.causal = causal;
-    hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3(mapped_grid(B * H, ceil_div(Tk, 128))), dim3(256), 0, st, p);
-    NNHIP_LAUNCH_CHECK("attn_bwd_dkdv_kernel");
+    // dQ first: it also produces Dsum, which the dK/dV kernel consumes
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(mapped_grid(B * H, ceil_div(Tq, AT_BQ))), dim3(256), 0, st, p);
     NNHIP_LAUNCH_CHECK("attn_bwd_dq_kernel");
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3(mapped_grid(B * H, ceil_div(Tk, 128))), dim3(256), 0, st, p);
+    NNHIP_LAUNCH_CHECK("attn_bwd_dkdv_kernel");
     return 0;
 }

@@ -831,6 +831,43 @@ def test_fused_attention_fully_masked_rows(hip):
         np.testing.assert_allclose(host(a), host(b), rtol=1e-4, atol=1e-5, err_msg=name)
 
 
+@pytest.mark.parametrize("B,Tq,Tk,H,causal,ld3", [(2, 96, 200, 2, True, False), (1, 200, 96, 1, True, False),
+                                                   (2, 130, 257, 2, False, True), (3, 64, 64, 4, True, True)])
+def test_fused_attention_rectangular_and_strided(hip, B, Tq, Tk, H, causal, ld3):
+    """Tq != Tk (the causal diagonal is shifted by Tk - Tq, as nnhipMaskedSoftmax does) and q/k/v given as column blocks
+    of one wider buffer (row stride 3D, the fused q|k|v projection layout): forward and all three gradients equal the
+    GEMM + masked-softmax path."""
+    from neunet_hip.nn.experimental import attention as A
+    import torch
+    rng = np.random.default_rng(Tq + Tk)
+    D = H * 64
+    kvh = np.ones((B, Tk), np.int32)
+    kvh[0, -Tk // 4:] = 0
+    kv = dev(kvh)
+    scale = float(np.sqrt(D))
+    qc = dev(rng.standard_normal((B, Tq, D)).astype(np.float32))
+    kc = dev(rng.standard_normal((B, Tk, D)).astype(np.float32))
+    vc = dev(rng.standard_normal((B, Tk, D)).astype(np.float32))
+    do = dev(rng.standard_normal((B, Tq, D)).astype(np.float32))
+    ctx_u, attn, _ = A.attention_forward(qc, kc, vc, kv, H, scale, causal)
+    dq_u, dk_u, dv_u = A.attention_backward(qc, kc, vc, attn, kv, H, scale, causal, do)
+    q, k, v = qc, kc, vc
+    if ld3:   # column blocks of [B,T,3D] buffers: one common row stride, batch stride = rows * stride
+        qbuf, kbuf = torch.zeros((B, Tq, 3 * D), device="cuda"), torch.zeros((B, Tk, 3 * D), device="cuda")
+        qbuf[:, :, 0:D].copy_(qc)
+        kbuf[:, :, D:2 * D].copy_(kc)
+        kbuf[:, :, 2 * D:].copy_(vc)
+        q, k, v = qbuf[:, :, 0:D], kbuf[:, :, D:2 * D], kbuf[:, :, 2 * D:]
+    ctx_f, lse = A.fused_attention_forward(q, k, v, kv, H, scale, causal)
+    out = None
+    if ld3:
+        gq, gk = torch.zeros((B, Tq, 3 * D), device="cuda"), torch.zeros((B, Tk, 3 * D), device="cuda")
+        out = (gq[:, :, 0:D], gk[:, :, D:2 * D], gk[:, :, 2 * D:])
+    dq_f, dk_f, dv_f = A.fused_attention_backward(q, k, v, kv, ctx_f, lse, H, scale, causal, do, out=out)
+    for a, b, name in ((ctx_f, ctx_u, "ctx"), (dq_f, dq_u, "dq"), (dk_f, dk_u, "dk"), (dv_f, dv_u, "dv")):
+        np.testing.assert_allclose(host(a.contiguous()), host(b), rtol=1e-4, atol=2e-5, err_msg=name)
+
+
 def test_gpt_step_fused_attention_equals_unfused(hip):
     """A GPT step (d 128, 2 heads of 64) with the fused attention kernels gives the same loss and gradients as
     the GEMM + masked-softmax path (which the gpt_tiny golden pins to the reference)."""
