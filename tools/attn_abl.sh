@@ -1,5 +1,6 @@
 #!/bin/bash
-# developer tool: per-kernel durations of tools/attn_abl.py under rocprofv3 for a list of NNHIP_ATTN_ABL values
+# developer tool: per-kernel durations of tools/attn_abl.py under rocprofv3 (the argument list is just a set of run tags;
+# it was used with in-kernel ablation switches while tuning)
 cd /tmp && export TMPDIR=/tmp
 for a in "$@"; do
   rm -rf /tmp/p_$a
