@@ -9,12 +9,15 @@ Used by bench.py (--workload c4) and the tests; BASELINE C4 = d_model 512, 6 lay
 vocab 15000, batch 64 x seq 256.
 """
 import math
+import os
+import sys
 
 import numpy as np
 
-import neunet_hip
-import neunet_hip.nn as nn
-from neunet_hip import Tensor
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "numpy-nn-model_amd"))
+import neunet_hip  # noqa: E402,F401
+import neunet_hip.nn as nn  # noqa: E402
+from neunet_hip import Tensor  # noqa: E402
 
 
 class PositionwiseFeedForward(nn.Module):
@@ -101,12 +104,13 @@ class GPT(nn.Module):
 
 
 def build_gpt(vocab=15000, d_model=512, n_heads=8, d_ff=2048, n_layers=6, pad_idx=0, max_len=1024, fused=True,
-              fused_attention=None):
+              fused_attention=None, dropout=0.0):
     """fused: Linear->Swish epilogue fusion in the FFN.  fused_attention (default = fused): flash-style attention
     kernels (head_dim 64 only; other head sizes keep the GEMM + masked-softmax path); the model then returns
-    attn=None, which the training loop of cell 12 never reads."""
+    attn=None, which the training loop of cell 12 never reads.  dropout > 0 (the notebook trains with 0.1, cell 11) draws
+    its masks with the device RNG and keeps the un-fused residual / attention paths."""
     fused_attention = fused if fused_attention is None else fused_attention
-    dec = Decoder(vocab, d_model, n_heads, d_ff, n_layers, dropout=0.0, max_len=max_len, fused=fused,
+    dec = Decoder(vocab, d_model, n_heads, d_ff, n_layers, dropout=dropout, max_len=max_len, fused=fused,
                   fused_attention=fused_attention)
     return GPT(dec, pad_idx)
 
@@ -123,3 +127,39 @@ def train_step(model, optimizer, loss_fn, batch_ids, bucket=None):
     optimizer.step()
     optimizer.zero_grad()
     return loss
+
+
+def synthetic_batches(vocab, batch, seq, steps, seed=0):
+    """A learnable toy language: x[t+1] = (5 x[t] + 3) mod (vocab - 1) + 1 from a random start token (0 = PAD is never
+    produced; the last 10 % of some rows are padded, as real batches are)."""
+    rng = np.random.default_rng(seed)
+    for _ in range(steps):
+        x = np.empty((batch, seq + 1), np.int32)
+        x[:, 0] = rng.integers(1, vocab, batch)
+        for t in range(seq):
+            x[:, t + 1] = (5 * x[:, t] + 3) % (vocab - 1) + 1
+        x[: max(1, batch // 8), -max(1, seq // 10):] = 0
+        yield x
+
+
+if __name__ == "__main__":
+    import argparse
+    from neunet_hip.optim import Adam
+    ap = argparse.ArgumentParser(description="Train the notebook's GPT on a synthetic next-token task (HIP backend).")
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--vocab", type=int, default=512)
+    ap.add_argument("--d-model", type=int, default=256)
+    ap.add_argument("--heads", type=int, default=4)
+    ap.add_argument("--layers", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--seq", type=int, default=64)
+    ap.add_argument("--dropout", type=float, default=0.1)
+    a = ap.parse_args()
+    np.random.seed(0)
+    model = build_gpt(a.vocab, a.d_model, a.heads, 4 * a.d_model, a.layers, pad_idx=0, max_len=a.seq + 1, dropout=a.dropout)
+    opt = Adam(model.parameters(), lr=1e-3, betas=(0.9, 0.98), eps=1e-9)
+    loss_fn = nn.CrossEntropyLoss(ignore_index=0)
+    for i, batch in enumerate(synthetic_batches(a.vocab, a.batch, a.seq, a.steps)):
+        loss = train_step(model, opt, loss_fn, batch)
+        if i % 20 == 0 or i == a.steps - 1:
+            print(f"step {i:4d}  loss {loss.item():.4f}", flush=True)
