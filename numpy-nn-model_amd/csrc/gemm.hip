@@ -528,13 +528,17 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
     p.zeros = zero_block();
     if (!p.zeros) { set_last_error("zero block allocation failed"); return NNHIP_ENOMEM; }
 
-    // split-K: few tiles, long reduction (deterministic slabs + reduce)
+    // split-K (deterministic slabs + reduce): few tiles and a long reduction -- or a handful of tiles and ANY reduction of
+    // >= 256: a lone block walks its k-tiles at ~2 us each (one 64-MFMA slab, nothing to hide the load latency behind),
+    // so the MNIST-MLP's 32x784x128 forward took 57 us in ONE block; 9 blocks of 3 slabs + the reduce take ~12.
     const int64_t tiles = (int64_t)p.tiles_m * p.tiles_n * batch;
-    if (batch == 1 && tiles < 192 && K >= 1024) {
+    const bool few = tiles <= 16 && K >= 256;
+    if (batch == 1 && tiles < 192 && (K >= 1024 || few)) {
         int64_t s = 512 / tiles;
-        const int64_t max_by_k = K / 256;
+        const int64_t max_by_k = few ? K / 64 : K / 256;
         if (s > max_by_k) s = max_by_k;
         if (s > 32) s = 32;
+        if (few && K < 1024 && s < 4) s = 1;       // not worth the extra launch
         if (s >= 2) {
             p.k_per_split = ceil_div(ceil_div(K, s), BK) * BK;
             p.splitk = (int)ceil_div(K, p.k_per_split);
