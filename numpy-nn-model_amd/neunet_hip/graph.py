@@ -14,7 +14,8 @@ Rules a captured region must obey (all hold for the kernels of libneunet_hip.so)
 no hipMalloc (the library workspace is grow-only and was sized during warm-up), static tensor addresses
 (inputs live in fixed buffers; parameter gradients live in the flat GradBucket), and an optimizer step counter
 in device memory (`use_device_step`).  With world_size > 1 the gradient all-reduce stays outside the graphs:
-[forward+backward graph] -> all_reduce (RCCL) -> [optimizer graph].
+[forward+backward graph] -> all_reduce (RCCL) -> [optimizer graph]; with one process the whole step is ONE graph
+(one launch per step instead of two: at MNIST-MLP scale the seam between the two graphs was ~8 us of a 100 us step).
 """
 from __future__ import annotations
 
@@ -36,13 +37,19 @@ class GraphedTrainStep:
             optimizer.use_device_step(True)
         self.g_fb = torch.cuda.CUDAGraph()
         self.opt.zero_grad()
+        self.single = world == 1 and pre_optim is None
         with torch.cuda.graph(self.g_fb):
             self.loss = self.fb()
             self.bucket.collect()
-        self.g_opt = torch.cuda.CUDAGraph()
-        self._bind_grads()
-        with torch.cuda.graph(self.g_opt):
-            self.opt.step()
+            if self.single:
+                self._bind_grads()
+                self.opt.step()
+        self.g_opt = None
+        if not self.single:
+            self.g_opt = torch.cuda.CUDAGraph()
+            self._bind_grads()
+            with torch.cuda.graph(self.g_opt):
+                self.opt.step()
         torch.cuda.synchronize()
 
     def _bind_grads(self):
@@ -60,6 +67,8 @@ class GraphedTrainStep:
 
     def __call__(self):
         self.g_fb.replay()
+        if self.single:
+            return self.loss
         if self.world > 1:
             import torch.distributed as dist
             dist.all_reduce(self.bucket.flat, op=dist.ReduceOp.SUM)
