@@ -179,6 +179,13 @@ int nnhipCountNotEqual(const int32_t* labels, int64_t n, int32_t ignore_index, i
  * reduction cross_entropy.py:98-101 does with cupy. */
 int nnhipReduceLoss(const float* loss_rows, int64_t n_rows, char reduction,
                     const int32_t* count_dev, float* out, nnhipStream_t stream);
+/* The three calls above as one (reduction 'm' or 's'): d(logits) (NULL = in place), per-row loss, lse, the reduced
+ * loss (device scalar) and, for 'm', the non-ignored count (device int, also the 'mean' denominator).  Small problems
+ * (rows*cols <= 65536, cols <= 4096) run as a single one-block launch -- at the README quick-start's 32 x 10 the three
+ * launches were 3 of the step's ~20 graph nodes. */
+int nnhipCrossEntropyLoss(float* logits, float* dlogits_or_null, float* loss_rows, float* lse, const int32_t* labels,
+                          int64_t logits_stride, int32_t ignore_index, int64_t n_rows, int64_t n_cols, char reduction,
+                          float* loss_out, int32_t* count_out, nnhipStream_t stream);
 
 /* ---- a10 RMSNorm  (replaces RMSNormForward/Backward, rmsnorm.cu:116-140, 282-308) ---------- */
 /* X_std[rows] = sqrt(mean(x^2)+eps) always written.  X_norm[rows,cols] may be NULL (not stored;

@@ -488,6 +488,69 @@ __global__ __launch_bounds__(1024) void reduce_loss_kernel(const float* __restri
     if (threadIdx.x == 0) out[0] = mean ? s / (float)count_dev[0] : s;
 }
 
+// Whole CrossEntropyLoss(mean|sum) of a SMALL problem in one launch (one 1024-thread block): count the non-ignored
+// labels, per-row loss / lse / d(logits), reduce the loss.  Same arithmetic as count_ne + ce_fwd_bwd_rows + reduce_loss
+// (the row sums run over a wave instead of a block, so the last bits of lse can differ by rounding); at MNIST-MLP scale
+// (32 x 10) those were three ~4.6 us graph nodes.
+__global__ __launch_bounds__(1024) void ce_small_kernel(const float* __restrict__ logits, float* __restrict__ dlogits,
+                                                        float* __restrict__ loss_rows, float* __restrict__ lse_out,
+                                                        const int32_t* __restrict__ labels, int64_t stride,
+                                                        int32_t ignore, int64_t rows, int64_t cols, int mean,
+                                                        float* __restrict__ loss_out, int32_t* __restrict__ count_out) {
+    __shared__ int ired[16];
+    __shared__ float fred[16];
+    __shared__ int cnt_sh;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int ci = 0;
+    for (int64_t i = threadIdx.x; i < rows; i += 1024) ci += labels[i] != ignore ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ci += __shfl_xor(ci, o, 64);
+    if (lane == 0) ired[wave] = ci;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int i = 0; i < 16; ++i) t += ired[i];
+        cnt_sh = t;
+        if (count_out) count_out[0] = t;
+    }
+    __syncthreads();
+    const int count = cnt_sh;
+    const float scale = mean ? (count > 0 ? 1.0f / (float)count : 0.0f) : 1.0f;
+    float lsum = 0.f;
+    for (int64_t r = wave; r < rows; r += 16) {
+        const float* x = logits + r * stride;
+        float* dx = dlogits + r * stride;
+        const int32_t y = labels[r];
+        float mx = -INFINITY;
+        for (int64_t c = lane; c < cols; c += 64) mx = fmaxf(mx, x[c]);
+        mx = wave_max(mx);
+        float se = 0.f;
+        for (int64_t c = lane; c < cols; c += 64) se += expf(x[c] - mx);
+        se = wave_sum(se);
+        const float lse = mx + logf(se);
+        const bool live = y != ignore;
+        const float xy = live ? x[y] : 0.f;
+        const float inv = 1.0f / se;
+        for (int64_t c = lane; c < cols; c += 64) {
+            const float pr = expf(x[c] - mx) * inv;
+            dx[c] = live ? (pr - (c == y ? 1.f : 0.f)) * scale : 0.f;
+        }
+        if (lane == 0) {
+            const float l = live ? lse - xy : 0.f;
+            loss_rows[r] = l;
+            lse_out[r] = lse;
+            lsum += l;
+        }
+    }
+    if (lane == 0) fred[wave] = lsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < 16; ++i) t += fred[i];
+        loss_out[0] = mean ? t / (float)count : t;
+    }
+}
+
 // =================================================================================================
 // Column sums:  out[c] = sum_r X[r*ld + c]     (Linear db: neunet/nn/layers/linear.py:24; RMSNorm dw/db)
 // Block = 4 waves; lane <-> one float4 column group (256 columns per block) or one column (scalar path,
@@ -779,6 +842,32 @@ extern "C" int nnhipReduceLoss(const float* loss_rows, int64_t n_rows, char redu
                        reduction == 'm' ? 1 : 0, count_dev, out);
     NNHIP_LAUNCH_CHECK("reduce_loss_kernel");
     return 0;
+}
+
+// CrossEntropyLoss(reduction = 'm' | 's') in one call: d(logits), per-row loss, lse, the reduced loss and (for 'm') the
+// non-ignored count.  Small problems (rows * cols <= 64 K, cols <= 4096) take one single-block launch; anything else
+// runs nnhipCountNotEqual + nnhipCrossEntropyForwardBackward + nnhipReduceLoss with `count_out` as the device count.
+extern "C" int nnhipCrossEntropyLoss(float* logits, float* dlogits_or_null, float* loss_rows, float* lse,
+                                     const int32_t* labels, int64_t logits_stride, int32_t ignore_index,
+                                     int64_t n_rows, int64_t n_cols, char reduction, float* loss_out,
+                                     int32_t* count_out, nnhipStream_t s) {
+    NNHIP_CHECK_ARG(n_rows >= 0 && n_cols >= 0 && logits_stride >= n_cols, NNHIP_EINVAL, "nnhipCrossEntropyLoss: bad sizes");
+    NNHIP_CHECK_ARG(reduction == 'm' || reduction == 's', NNHIP_EINVAL, "nnhipCrossEntropyLoss: reduction must be 'm' or 's'");
+    NNHIP_CHECK_ARG(loss_out && (reduction != 'm' || count_out), NNHIP_EINVAL, "nnhipCrossEntropyLoss: null loss_out / count_out");
+    if (n_rows > 0 && n_cols > 0 && n_rows * n_cols <= 65536 && n_cols <= 4096) {
+        NNHIP_CHECK_ARG(logits && loss_rows && lse && labels, NNHIP_EINVAL, "nnhipCrossEntropyLoss: null pointer");
+        hipLaunchKernelGGL(ce_small_kernel, dim3(1), dim3(1024), 0, (hipStream_t)s, logits, dlogits_or_null ? dlogits_or_null : logits,
+                           loss_rows, lse, labels, logits_stride, ignore_index, n_rows, n_cols, reduction == 'm' ? 1 : 0,
+                           loss_out, count_out);
+        NNHIP_LAUNCH_CHECK("ce_small_kernel");
+        return 0;
+    }
+    if (reduction == 'm')
+        if (int rc = nnhipCountNotEqual(labels, n_rows, ignore_index, count_out, s)) return rc;
+    if (int rc = nnhipCrossEntropyForwardBackward(logits, loss_rows, lse, labels, logits_stride, ignore_index, n_rows, n_cols,
+                                                  reduction, -1, reduction == 'm' ? count_out : nullptr, dlogits_or_null, s))
+        return rc;
+    return nnhipReduceLoss(loss_rows, n_rows, reduction, count_out, loss_out, s);
 }
 
 // ---- attention-score softmax (scale + pad/causal mask fused) --------------------------------------------

@@ -41,6 +41,12 @@ def cross_entropy_forward_backward(logits, labels, reduction: str = "none", igno
     lse = torch.empty(rows, dtype=torch.float32, device=logits.device)
     grad_logits = logits if inplace else torch.empty_like(logits)
     stream = get_current_stream_ptr()
+    if reduction != "none":     # one call: count + rows + reduction (a single launch for small problems)
+        loss = torch.empty((), dtype=torch.float32, device=logits.device)
+        count = torch.empty(1, dtype=torch.int32, device=logits.device) if reduction == "mean" else None
+        call_hip_function("nnhipCrossEntropyLoss", logits, None if inplace else grad_logits, loss_rows, lse, labels,
+                          logits.stride(0), int(ignore_index), rows, vocab, _RED[reduction], loss, count, stream)
+        return loss, grad_logits
     count = None
     if reduction == "mean":
         count = torch.empty(1, dtype=torch.int32, device=logits.device)
