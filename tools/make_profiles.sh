@@ -1,7 +1,7 @@
 #!/bin/bash
 # Local post-processing of gpurun_out/ (rocprofv3 CSVs) into the tracked profiles/ directory.  Usage: tools/make_profiles.sh r01
 TAG=${1:-r01}; G=gpurun_out; P=profiles; mkdir -p $P
-for W in c2 c3 c4; do
+for W in c1 c2 c3 c4 c5; do
   python tools/prof_summary.py stats $G/prof_$W/${W}_kernel_stats.csv $P/${TAG}_${W}_kernel_stats.md "Round ${TAG#r} -- rocprofv3 --kernel-trace --stats -- python bench.py --workload $W --no-cpu-baseline (MI355X)"
 done
 python tools/prof_summary.py pmc $G/pmc_sq_c2/sq_counter_collection.csv $P/${TAG}_c2_pmc_sq.md
@@ -22,5 +22,5 @@ json.dump(out, open('$P/pmc_traffic.json', 'w'), indent=1)
 for k, v in out.items():
     if not k.startswith('_'): print(f"{k:18s} {v/1e6:9.1f} MB")
 PY
-for W in c1 c2 c3 c4; do cp $G/bench_$W.json $P/${TAG}_bench_$W.json; done
+for W in c1 c2 c3 c4 c5; do cp $G/bench_$W.json $P/${TAG}_bench_$W.json; done
 cp $G/kbench.log $P/${TAG}_kbench.txt
