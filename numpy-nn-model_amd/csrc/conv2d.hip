@@ -291,9 +291,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __r
 
 // =================================================================================================
 // Direct kernels for SMALL channel counts (Cin, Cout <= 16, kh*kw <= 25): the implicit GEMM above pads an 8- or
-// 16-row problem to 32-row MFMA tiles and spends its time gathering (C5: dgrad 60 us, fwd 29 us for 58 MFLOP layers; a
-// direct wgrad was tried too -- 1168 outputs x 196 pixels per image is too little parallelism per block: 70-88 us vs 38
-// for the MFMA split-K wgrad, which stays).  Here one thread owns one output (input) pixel and all CO (CI) channels of it in registers; the
+// 16-row problem to 32-row MFMA tiles and spends its time gathering (C5: dgrad 60 us, wgrad 38 us, fwd 29 us for
+// 58 MFLOP layers).  Here one thread owns one output (input) pixel and all CO (CI) channels of it in registers; the
 // weights sit in LDS laid out so that one ds_read_b128 hands a thread 4 channels' weights for the tap it is on (all
 // threads read the same address: broadcast).  Same formulas, same summation order over (ci, r, s).
 // =================================================================================================
@@ -387,6 +386,105 @@ __global__ __launch_bounds__(256) void conv_direct_dgrad_kernel(const float* __r
         if (c < g.Cin) dX[((int64_t)b * g.Cin + c) * HW + p] = acc[c];
 }
 
+// wgrad, 3x3 kernels, <= 16 channels: one block per image (grid-strided) with X[b] and dO[b] staged in LDS.  Thread <->
+// (input channel ci, pixel slice): it owns dW[0..CO)[ci][3x3] for its pixels -- CO*9 accumulators, the 9 taps of a pixel
+// loaded once and used for every co, dO[co][p] a broadcast read shared by the CIP threads of the slice.  The slices lie
+// along the lanes, so the per-image partial sums meet in a shuffle tree + one LDS hop; per-block partials go to
+// conv_wgrad_reduce_kernel.  (Thread <-> output element with a serial loop over the pixels was tried first: 1168 outputs
+// x 196 pixels per image left most lanes idle, 70-88 us; the MFMA split-K wgrad above takes 38 us at C5 -- it gathers
+// every X element 9 times.)
+template <int CO, int CIP>
+__global__ __launch_bounds__(256) void conv_direct_wgrad_kernel(const float* __restrict__ X, const float* __restrict__ dO,
+                                                                float* __restrict__ part, const ConvGeom g, int ncols) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    constexpr int S = 256 / CIP;                       // pixel slices per block
+    constexpr int SW = 64 / CIP;                       // slices per wave (CIP <= 16 -> >= 4)
+    const int HW = g.H * g.W, HWo = g.Ho * g.Wo;
+    float* Xs = wsm;                                   // [Cin][H][W]
+    float* Gs = wsm + g.Cin * HW;                      // [Cout][Ho][Wo]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ci = lane % CIP, slice = wave * SW + lane / CIP;
+    const bool ci_ok = ci < g.Cin;
+    float acc[CO][9], accb[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) {
+        accb[c] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[c][t] = 0.f;
+    }
+    for (int b = blockIdx.x; b < g.B; b += gridDim.x) {
+        __syncthreads();
+        for (int i = tid; i < g.Cin * HW; i += 256) Xs[i] = X[(int64_t)b * g.Cin * HW + i];
+        for (int i = tid; i < g.Cout * HWo; i += 256) Gs[i] = dO[(int64_t)b * g.Cout * HWo + i];
+        __syncthreads();
+        for (int p = slice; p < HWo; p += S) {
+            const int ho = p / g.Wo, wo = p - ho * g.Wo;
+            float x[9];
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int hi = ho * g.sh - g.pu + r * g.dh, wi = wo * g.sw - g.pl + q * g.dw;
+                    const bool ok = ci_ok && hi >= 0 && hi < g.H && wi >= 0 && wi < g.W;
+                    x[r * 3 + q] = ok ? Xs[(ci * g.H + hi) * g.W + wi] : 0.f;
+                }
+#pragma unroll
+            for (int c = 0; c < CO; ++c) {
+                const float gv = c < g.Cout ? Gs[c * HWo + p] : 0.f;
+                accb[c] += gv;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc[c][t] += gv * x[t];
+            }
+        }
+    }
+    // ---- sum over the pixel slices: lanes (stride CIP) within the wave, then the 4 waves through LDS ----------------
+#pragma unroll
+    for (int c = 0; c < CO; ++c) {
+#pragma unroll
+        for (int o = CIP; o < 64; o <<= 1) {
+            accb[c] += __shfl_xor(accb[c], o, 64);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[c][t] += __shfl_xor(acc[c][t], o, 64);
+        }
+    }
+    __syncthreads();                                   // Xs / Gs are dead: reuse as [4 waves][CO][CIP*9 + 1]
+    constexpr int ROW = CIP * 9 + 1;
+    float* R = wsm;
+    if (lane < CIP) {
+#pragma unroll
+        for (int c = 0; c < CO; ++c) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) R[(wave * CO + c) * ROW + ci * 9 + t] = acc[c][t];
+            if (ci == 0) R[(wave * CO + c) * ROW + CIP * 9] = accb[c];
+        }
+    }
+    __syncthreads();
+    const int Nw = g.Cin * 9, total = g.Cout * ncols;
+    for (int idx = tid; idx < total; idx += 256) {
+        const int co = idx / ncols, n = idx - co * ncols;
+        const int col = n == Nw ? CIP * 9 : n;         // the db column sits last in R's rows
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) v += R[(w * CO + co) * ROW + col];
+        part[(int64_t)blockIdx.x * total + idx] = v;
+    }
+}
+
+template <int CO, int CIP>
+static int launch_direct_wgrad(const float* X, const float* dO, float* part, const ConvGeom& g, int ncols, int blocks,
+                               size_t lds, hipStream_t st) {
+    auto kern = conv_direct_wgrad_kernel<CO, CIP>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        if (e != hipSuccess) return hip_status(e, "hipFuncSetAttribute(conv_direct_wgrad_kernel)");
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, X, dO, part, g, ncols);
+    NNHIP_LAUNCH_CHECK("conv_direct_wgrad_kernel");
+    return 0;
+}
+
 static bool conv_direct_ok(const ConvGeom& g) {
     static const bool off = []() { const char* e = getenv("NNHIP_CONV_DIRECT"); return e && atoi(e) == 0; }();
     return !off && g.Cin <= CD_MAXC && g.Cout <= CD_MAXC && g.kh * g.kw <= CD_MAXTAPS;
@@ -456,7 +554,29 @@ extern "C" int nnhipConv2dBackward(const float* X, const float* W, const float* 
         hipLaunchKernelGGL(conv_igemm_kernel<true>, grid, dim3(256), 0, st, W, dO, nullptr, dX, g);
         NNHIP_LAUNCH_CHECK("conv_igemm_kernel<dgrad>");
     }
-    if (dW || db) {
+    size_t wg_lds = ((size_t)g.Cin * g.H * g.W + (size_t)g.Cout * g.Ho * g.Wo) * sizeof(float);
+    if ((dW || db) && direct && g.kh == 3 && g.kw == 3 && wg_lds <= 60 * 1024) {
+        const int Nw = g.Cin * 9, ncols = Nw + 1, total = g.Cout * ncols;
+        const int blocks = g.B < 512 ? g.B : 512;
+        float* part = static_cast<float*>(workspace((size_t)blocks * total * sizeof(float)));
+        NNHIP_CHECK_ARG(part != nullptr, NNHIP_ENOMEM, "nnhipConv2dBackward: workspace allocation failed");
+        const int cip = g.Cin <= 1 ? 1 : g.Cin <= 2 ? 2 : g.Cin <= 4 ? 4 : g.Cin <= 8 ? 8 : 16;
+        const size_t red = (size_t)4 * (g.Cout <= 8 ? 8 : 16) * (cip * 9 + 1) * sizeof(float);
+        if (wg_lds < red) wg_lds = red;
+        int rc;
+#define NNHIP_WG(CO_)                                                                                                        \
+        (cip == 1 ? launch_direct_wgrad<CO_, 1>(X, dO, part, g, ncols, blocks, wg_lds, st)                                      \
+         : cip == 2 ? launch_direct_wgrad<CO_, 2>(X, dO, part, g, ncols, blocks, wg_lds, st)                                    \
+         : cip == 4 ? launch_direct_wgrad<CO_, 4>(X, dO, part, g, ncols, blocks, wg_lds, st)                                    \
+         : cip == 8 ? launch_direct_wgrad<CO_, 8>(X, dO, part, g, ncols, blocks, wg_lds, st)                                    \
+                    : launch_direct_wgrad<CO_, 16>(X, dO, part, g, ncols, blocks, wg_lds, st))
+        rc = g.Cout <= 8 ? NNHIP_WG(8) : NNHIP_WG(16);
+#undef NNHIP_WG
+        if (rc) return rc;
+        hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)ceil_div(total, 4)), dim3(256), 0, st, part, dW, db, blocks,
+                           g.Cout, Nw, ncols);
+        NNHIP_LAUNCH_CHECK("conv_wgrad_reduce_kernel");
+    } else if (dW || db) {
         const int Nw = g.Cin * g.kh * g.kw;
         const int ncols = Nw + 1;
         const int64_t K = (int64_t)g.B * g.Ho * g.Wo;
