@@ -320,6 +320,33 @@ __global__ __launch_bounds__(256) void conv_direct_fwd_kernel(const float* __res
 #pragma unroll
     for (int c = 0; c < CO; ++c) acc[c] = 0.f;
     const float* xb = X + (int64_t)b * g.Cin * g.H * g.W;
+    if (khkw == 9 && g.kw == 3) {
+        // 3x3: the 9 tap offsets are computed once, then every channel issues its 9 loads back to back (independent,
+        // all in flight together) before the FMAs -- the generic loop below has one dependent load per tap
+        int off[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int hi = ho * g.sh - g.pu + r * g.dh, wi = wo * g.sw - g.pl + q * g.dw;
+                off[r * 3 + q] = (hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) ? hi * g.W + wi : -1;
+            }
+        const int HWi = g.H * g.W;
+        for (int ci = 0; ci < g.Cin; ++ci) {
+            float x[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) x[t] = off[t] >= 0 ? xb[(int64_t)ci * HWi + off[t]] : 0.f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float4* w4 = reinterpret_cast<const float4*>(&Wl[(ci * 9 + t) * CO]);
+#pragma unroll
+                for (int c4 = 0; c4 < CO / 4; ++c4) {
+                    const float4 w = w4[c4];
+                    acc[4 * c4] += x[t] * w.x; acc[4 * c4 + 1] += x[t] * w.y; acc[4 * c4 + 2] += x[t] * w.z; acc[4 * c4 + 3] += x[t] * w.w;
+                }
+            }
+        }
+    } else
     for (int ci = 0; ci < g.Cin; ++ci)
         for (int r = 0; r < g.kh; ++r) {
             const int hi = ho * g.sh - g.pu + r * g.dh;
@@ -361,6 +388,31 @@ __global__ __launch_bounds__(256) void conv_direct_dgrad_kernel(const float* __r
 #pragma unroll
     for (int c = 0; c < CI; ++c) acc[c] = 0.f;
     const float* gb = dO + (int64_t)b * g.Cout * HWo;
+    if (khkw == 9 && g.kw == 3) {
+        int off[9];                                     // as in the forward kernel: offsets once, 9 loads in flight per channel
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int th = h + g.pu - r * g.dh, tw = w + g.pl - q * g.dw;
+                const bool ok = th >= 0 && tw >= 0 && th % g.sh == 0 && tw % g.sw == 0 && th / g.sh < g.Ho && tw / g.sw < g.Wo;
+                off[r * 3 + q] = ok ? (th / g.sh) * g.Wo + tw / g.sw : -1;
+            }
+        for (int co = 0; co < g.Cout; ++co) {
+            float v[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) v[t] = off[t] >= 0 ? gb[(int64_t)co * HWo + off[t]] : 0.f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float4* w4 = reinterpret_cast<const float4*>(&Wl[(co * 9 + t) * CI]);
+#pragma unroll
+                for (int c4 = 0; c4 < CI / 4; ++c4) {
+                    const float4 ww = w4[c4];
+                    acc[4 * c4] += v[t] * ww.x; acc[4 * c4 + 1] += v[t] * ww.y; acc[4 * c4 + 2] += v[t] * ww.z; acc[4 * c4 + 3] += v[t] * ww.w;
+                }
+            }
+        }
+    } else
     for (int co = 0; co < g.Cout; ++co)
         for (int r = 0; r < g.kh; ++r) {
             const int th = h + g.pu - r * g.dh;

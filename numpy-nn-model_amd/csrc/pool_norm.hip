@@ -61,8 +61,14 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(float* __restrict__ ou
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t total = BC * Ho * Wo;
     if (i >= total) return;
-    const int wo = (int)(i % Wo), ho = (int)((i / Wo) % Ho);
-    const int64_t bc = i / ((int64_t)Ho * Wo);
+    int wo, ho;
+    int64_t bc;
+    if (total < ((int64_t)1 << 31)) {     // 32-bit index arithmetic: the 64-bit divisions were most of this kernel's time
+        const unsigned u = (unsigned)i, hw = (unsigned)(Ho * Wo), b32 = u / hw, rem = u - b32 * hw;
+        ho = (int)(rem / (unsigned)Wo); wo = (int)(rem - (unsigned)ho * (unsigned)Wo); bc = b32;
+    } else {
+        wo = (int)(i % Wo); ho = (int)((i / Wo) % Ho); bc = i / ((int64_t)Ho * Wo);
+    }
     const float* p = x + bc * H * W;
     float best = -INFINITY;
     int bi = 0;
@@ -83,8 +89,14 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(float* __restrict__ dx
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t total = BC * H * W;
     if (i >= total) return;
-    const int xx = (int)(i % W), y = (int)((i / W) % H);
-    const int64_t bc = i / ((int64_t)H * W);
+    int xx, y;
+    int64_t bc;
+    if (total < ((int64_t)1 << 31)) {
+        const unsigned u = (unsigned)i, hw = (unsigned)(H * W), b32 = u / hw, rem = u - b32 * hw;
+        y = (int)(rem / (unsigned)W); xx = (int)(rem - (unsigned)y * (unsigned)W); bc = b32;
+    } else {
+        xx = (int)(i % W); y = (int)((i / W) % H); bc = i / ((int64_t)H * W);
+    }
     float g = 0.f;
     for (int r = 0; r < kh; ++r) {
         const int ty = y + pu - r;
