@@ -115,6 +115,58 @@ def test_linear_addend_extensions(hip, rows, inf, outf):
     np.testing.assert_allclose(host(lin.bias.grad), db.reshape(1, -1), rtol=1e-4, atol=1e-3)
 
 
+def test_linear_entry_points_fuzz(hip):
+    """40 random (rows, in, out) triples through every Linear entry point and epilogue option -- forward (+addend),
+    backward (dX +addend, dW, db: inside the dW GEMM or by the column-sum pass), the Swish-folding dX -- covering the
+    float4 and scalar epilogues (sizes not divisible by 4), split-K (few tiles, long or short K), single-tile and
+    multi-tile grids.  Reference: float64 NumPy."""
+    from neunet_hip._lib import call_hip_function as call, get_current_stream_ptr
+    import torch
+    rng = np.random.default_rng(2024)
+    st = get_current_stream_ptr()
+    sizes = [1, 2, 3, 4, 7, 8, 31, 32, 33, 64, 100, 128, 129, 200, 256, 300, 512, 640, 1000, 1024, 1500, 2048, 2500]
+    for case in range(40):
+        rows, inf, outf = (int(rng.choice(sizes)) for _ in range(3))
+        if case % 5 == 0:
+            rows = int(rng.choice([4096, 6000]))            # long reductions for dW -> split-K with few tiles
+        X = rng.standard_normal((rows, inf)).astype(np.float32)
+        W = (rng.standard_normal((outf, inf)) / np.sqrt(inf)).astype(np.float32)
+        b = rng.standard_normal((1, outf)).astype(np.float32)
+        R = rng.standard_normal((rows, outf)).astype(np.float32)
+        dO = rng.standard_normal((rows, outf)).astype(np.float32)
+        G = rng.standard_normal((rows, inf)).astype(np.float32)
+        Z = rng.standard_normal((rows, inf)).astype(np.float32)
+        x, w, bb, r, do, gg, zz = (dev(a) for a in (X, W, b, R, dO, G, Z))
+        X64, W64, dO64 = X.astype(np.float64), W.astype(np.float64), dO.astype(np.float64)
+        tag = f"case {case}: rows {rows} in {inf} out {outf}"
+        # forward, with and without addend
+        o = torch.empty((rows, outf), device="cuda")
+        call("nnhipLinearModuleForward", x, w, bb, o, rows, inf, outf, st)
+        ref = X64 @ W64.T + b
+        np.testing.assert_allclose(host(o), ref, rtol=1e-4, atol=1e-4 * np.sqrt(inf), err_msg=tag + " fwd")
+        call("nnhipLinearModuleForwardEx", x, w, None, r, o, rows, inf, outf, st)
+        np.testing.assert_allclose(host(o), ref - b + R, rtol=1e-4, atol=1e-4 * np.sqrt(inf), err_msg=tag + " fwd+addend")
+        # backward: everything, then dX with an addend, then db alone (column-sum pass)
+        dx, dw, db = torch.empty((rows, inf), device="cuda"), torch.empty((outf, inf), device="cuda"), torch.empty((1, outf), device="cuda")
+        call("nnhipLinearModuleBackward", x, w, do, dx, dw, db, rows, inf, outf, st)
+        dXr, dWr, dbr = dO64 @ W64, dO64.T @ X64, dO64.sum(0, keepdims=True)
+        np.testing.assert_allclose(host(dx), dXr, rtol=1e-4, atol=1e-4 * np.sqrt(outf), err_msg=tag + " dX")
+        np.testing.assert_allclose(host(dw), dWr, rtol=1e-4, atol=2e-5 * rows ** 0.5 * 4, err_msg=tag + " dW")
+        np.testing.assert_allclose(host(db), dbr, rtol=1e-4, atol=2e-5 * rows ** 0.5 * 4, err_msg=tag + " db")
+        call("nnhipLinearModuleBackwardEx", x, w, do, gg, dx, None, None, rows, inf, outf, st)
+        np.testing.assert_allclose(host(dx), dXr + G, rtol=1e-4, atol=1e-4 * np.sqrt(outf), err_msg=tag + " dX+addend")
+        db.zero_()
+        call("nnhipLinearModuleBackward", x, w, do, None, None, db, rows, inf, outf, st)
+        np.testing.assert_allclose(host(db), dbr, rtol=1e-4, atol=2e-5 * rows ** 0.5 * 4, err_msg=tag + " db alone")
+        # Swish backward folded into dX, in place over z
+        beta = 1.3
+        sg = 1.0 / (1.0 + np.exp(-beta * Z.astype(np.float64)))
+        f = Z * sg
+        dzr = dXr * (beta * f + sg * (1 - beta * f))
+        call("nnhipLinearInputGradSwish", do, w, zz, zz, rows, inf, outf, beta, st)
+        np.testing.assert_allclose(host(zz), dzr, rtol=2e-4, atol=2e-4 * np.sqrt(outf), err_msg=tag + " dX*swish'")
+
+
 @pytest.mark.parametrize("rows,dm,dff,beta", [(200, 64, 256, 1.0), (16384, 128, 128, 1.0), (50, 30, 70, 1.7)])
 def test_ffn_swish_backward_folded_into_dx(hip, rows, dm, dff, beta):
     """fc_2(LinearSwish fc_1(x)): fc_2's dX GEMM applies swish'(z) in its epilogue (nnhipLinearInputGradSwish, in place
@@ -870,6 +922,36 @@ def test_fused_attention_rectangular_and_strided(hip, B, Tq, Tk, H, causal, ld3)
     dq_f, dk_f, dv_f = A.fused_attention_backward(q, k, v, kv, ctx_f, lse, H, scale, causal, do, out=out)
     for a, b, name in ((ctx_f, ctx_u, "ctx"), (dq_f, dq_u, "dq"), (dk_f, dk_u, "dk"), (dv_f, dv_u, "dv")):
         np.testing.assert_allclose(host(a.contiguous()), host(b), rtol=1e-4, atol=2e-5, err_msg=name)
+
+
+def test_fused_attention_fuzz(hip):
+    """25 random (B, H, Tq, Tk, causal, padding pattern) cases: the fused kernels against the GEMM + masked-softmax path
+    (itself pinned to the oracle and the notebook goldens), forward and all three gradients."""
+    from neunet_hip.nn.experimental import attention as A
+    rng = np.random.default_rng(77)
+    for case in range(25):
+        B, H = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+        Tq = int(rng.choice([1, 5, 31, 32, 33, 64, 100, 128, 129, 200, 256, 300, 385]))
+        Tk = Tq if case % 3 else int(rng.choice([1, 17, 64, 130, 256, 320]))
+        causal = bool(case % 2)
+        D = H * 64
+        q = dev(rng.standard_normal((B, Tq, D)).astype(np.float32) * 2)
+        k = dev(rng.standard_normal((B, Tk, D)).astype(np.float32) * 2)
+        v = dev(rng.standard_normal((B, Tk, D)).astype(np.float32))
+        do = dev(rng.standard_normal((B, Tq, D)).astype(np.float32))
+        kvh = (rng.random((B, Tk)) > (0.0 if case % 4 == 0 else 0.2)).astype(np.int32)
+        if case % 5 == 1:
+            kvh[0, : Tk // 2 + 1] = 0                       # leading padding: fully-masked query rows under the causal mask
+        kv = None if case % 7 == 3 else dev(kvh)
+        scale = float(np.sqrt(D))
+        ctx_u, attn, _ = A.attention_forward(q, k, v, kv, H, scale, causal)
+        gu = A.attention_backward(q, k, v, attn, kv, H, scale, causal, do)
+        ctx_f, lse = A.fused_attention_forward(q, k, v, kv, H, scale, causal)
+        gf = A.fused_attention_backward(q, k, v, kv, ctx_f, lse, H, scale, causal, do)
+        tag = f"case {case}: B{B} H{H} Tq{Tq} Tk{Tk} causal={causal}"
+        np.testing.assert_allclose(host(ctx_f), host(ctx_u), rtol=1e-4, atol=2e-5, err_msg=tag + " ctx")
+        for a, b, n in zip(gf, gu, "qkv"):
+            np.testing.assert_allclose(host(a), host(b), rtol=1e-4, atol=5e-5, err_msg=tag + " d" + n)
 
 
 def test_gpt_step_fused_attention_equals_unfused(hip):
