@@ -12,8 +12,8 @@ python bench.py --workload c4 --steps 10 --warmup 3 > gpurun_out/bench_c4.json 2
 python bench.py --workload c5 --steps 200 --warmup 20 > gpurun_out/bench_c5.json 2> gpurun_out/bench_c5.err
 cd /tmp && export TMPDIR=/tmp
 for W in c1 c2 c3 c4 c5; do
-  S=10; [ $W = c4 ] && S=5; [ $W = c1 ] && S=200; [ $W = c5 ] && S=100
-  rocprofv3 --kernel-trace --stats -f csv -d $R/gpurun_out/prof_$W -o $W -- python $R/bench.py --workload $W --steps $S --warmup 3 --no-cpu-baseline > $R/gpurun_out/prof_$W.log 2>&1
+  S=30; [ $W = c4 ] && S=8; [ $W = c1 ] && S=200; [ $W = c5 ] && S=100
+  rocprofv3 --kernel-trace --stats -f csv -d $R/gpurun_out/prof_$W -o $W -- python $R/bench.py --workload $W --steps $S --warmup 5 --no-cpu-baseline > $R/gpurun_out/prof_$W.log 2>&1
 done
 for W in c2 c3; do
   rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $R/gpurun_out/pmc_fetch_$W -o f -- python $R/bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_fetch_$W.log 2>&1
