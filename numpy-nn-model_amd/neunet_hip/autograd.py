@@ -14,7 +14,7 @@ Tensor is only a container -- the dense ops themselves run on "cuda" exclusively
 """
 from __future__ import annotations
 
-from typing import Any, Callable, Literal, Union
+from typing import Any, Callable, Literal
 
 import numpy as np
 

@@ -19,8 +19,6 @@ from __future__ import annotations
 
 import os
 
-import numpy as np
-
 
 def init_process_group(backend: str | None = None):
     """Initialise torch.distributed from the torchrun env (RANK / WORLD_SIZE / MASTER_*). Returns (rank, world)."""

@@ -9,8 +9,6 @@ path, all on the side of the CPU semantics (neunet/nn/losses.py:59-126):
     forward never synchronises the host (the reference calls `.item()`, cross_entropy.py:72);
   * the 'mean' / 'sum' reduction also runs on the device (nnhipReduceLoss).
 """
-import numpy as np
-
 from ...autograd import Tensor
 from ..modules import Module
 from .utils import call_hip_function, contiguous, get_current_stream_ptr
