@@ -327,7 +327,7 @@ def workload_c3(args, rank, world):
     p.grad = dY
     opt = HIPFusedMultiTensorAdamW([p], lr=1e-3, weight_decay=1e-2)
     # Order matters for cold-cache timing: a kernel that follows AdamW also pays for the write-back of AdamW's
-    # 402 MB of dirty lines (+12 us measured on ANY streaming kernel placed there, tools/order_test.py), so
+    # 402 MB of dirty lines (+12 us measured on ANY streaming kernel placed there, tools/order_check.py), so
     # AdamW goes last and the fused CE -- whose predecessor in a real step is the vocabulary GEMM -- first.
     ops = [
         ("ce_fwd_bwd", lambda: cross_entropy_forward_backward(logits, labels, "mean", -100, inplace=False)),

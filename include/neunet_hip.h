@@ -39,6 +39,11 @@ const char* nnhipGetLastErrorString(void);
  * Replaces cleanupCudaMemory() (linear_cublaslt_no_manual_mem.cu:186, linear_cutlass.cu:107,
  * linear_swish_cutlass_evt_full.cu:820).  Synchronises the device. */
 int nnhipCleanup(void);
+/* Grow the workspace to at least `bytes` now (e.g. before capturing a hipGraph). */
+int nnhipWorkspaceReserve(int64_t bytes);
+/* locked != 0: the workspace may no longer move -- a launch that needs more than it holds returns NNHIP_ENOMEM instead
+ * of freeing the block a captured hipGraph still points into.  nnhipCleanup() unlocks. */
+int nnhipWorkspaceLock(int locked);
 
 /* ---- a1/a2 Linear  (replaces cudaLinearModuleForward/Backward,
  *      linear_cublaslt_no_manual_mem.cu:114,142 and linear_cutlass.cu:40,67) ------------------ */
@@ -179,13 +184,26 @@ int nnhipCountNotEqual(const int32_t* labels, int64_t n, int32_t ignore_index, i
  * reduction cross_entropy.py:98-101 does with cupy. */
 int nnhipReduceLoss(const float* loss_rows, int64_t n_rows, char reduction,
                     const int32_t* count_dev, float* out, nnhipStream_t stream);
-/* The three calls above as one (reduction 'm' or 's'): d(logits) (NULL = in place), per-row loss, lse, the reduced
- * loss (device scalar) and, for 'm', the non-ignored count (device int, also the 'mean' denominator).  Small problems
- * (rows*cols <= 65536, cols <= 4096) run as a single one-block launch -- at the README quick-start's 32 x 10 the three
- * launches were 3 of the step's ~20 graph nodes. */
+/* The three calls above as one launch (reduction 'm' or 's'): d(logits) (NULL = in place), per-row loss, lse, the reduced
+ * loss (device scalar) and, for 'm', the non-ignored count (device int, also the 'mean' denominator).
+ * = nnhipCrossEntropyLossEx with int32 labels and no class weights. */
 int nnhipCrossEntropyLoss(float* logits, float* dlogits_or_null, float* loss_rows, float* lse, const int32_t* labels,
                           int64_t logits_stride, int32_t ignore_index, int64_t n_rows, int64_t n_cols, char reduction,
                           float* loss_out, int32_t* count_out, nnhipStream_t stream);
+
+/* The whole CrossEntropyLoss (neunet/nn/losses.py:59-126) in ONE launch, any reduction:
+ *   labels: int16 / int32 / int64 (label_bytes = 2 / 4 / 8; losses.py:100 accepts the three);
+ *   class_weight [n_cols] or NULL: loss_i = -logp[y_i] * w[y_i]; 'm' divides by sum_i w[y_i] over non-ignored rows
+ *     (losses.py:115-118); gradient rows are scaled by w[y_i];
+ *   reduction 'n': loss_rows only (loss_out may be NULL); 'm' / 's': loss_out[0] as well;
+ *   count_out (NULL-able): #{labels != ignore_index} for 'm'.
+ * The 'mean' denominator is derived from the labels inside the launch (no count launch, no host sync); the per-block
+ * loss sums meet in the last block to finish (arrival ticket).  A label outside [0, n_cols) that is not ignore_index
+ * gives zero loss and zero gradient.  Rows of any width (looped above 16384 columns). */
+int nnhipCrossEntropyLossEx(float* logits, float* dlogits_or_null, float* loss_rows, float* lse, const void* labels,
+                            int32_t label_bytes, const float* class_weight_or_null, int64_t logits_stride,
+                            int64_t ignore_index, int64_t n_rows, int64_t n_cols, char reduction,
+                            float* loss_out_or_null, int32_t* count_out_or_null, nnhipStream_t stream);
 
 /* ---- a10 RMSNorm  (replaces RMSNormForward/Backward, rmsnorm.cu:116-140, 282-308) ---------- */
 /* X_std[rows] = sqrt(mean(x^2)+eps) always written.  X_norm[rows,cols] may be NULL (not stored;
@@ -193,7 +211,9 @@ int nnhipCrossEntropyLoss(float* logits, float* dlogits_or_null, float* loss_row
 int nnhipRMSNormForward(const float* X, const float* weight, const float* bias_or_null, float* Y,
                         float* X_std, float* X_norm_or_null, int64_t rows, int64_t cols, float eps,
                         nnhipStream_t stream);
-/* X_norm is accepted for signature parity and ignored (recomputed from X and X_std). */
+/* X_norm is accepted for signature parity and ignored (recomputed from X and X_std).  dW / db are finished inside the
+ * same launch (per-block column partials + arrival ticket; the last blocks to arrive column-sum them).  Rows of any
+ * width (looped above 16384 columns, like rmsnorm.cu:17-113). */
 int nnhipRMSNormBackward(const float* dY, const float* X, const float* weight, const float* X_std,
                          const float* X_norm_unused, float* dX, float* dW, float* db_or_null,
                          int64_t rows, int64_t cols, nnhipStream_t stream);
@@ -225,10 +245,17 @@ int nnhipFusedAdamWMultiTensorStep(void* opt, int32_t n_tensors, float* const* p
                                    double eps, double weight_decay, int32_t step, int32_t decay_mode,
                                    float grad_scale, nnhipStream_t stream);
 
-/* Device-driven stepping for hipGraph replay: after nnhipFusedOptimizerSetStep(opt, t), calls of
- * nnhipFusedAdamWMultiTensorStep with step == 0 advance a step counter that lives in device memory and take
- * 1-beta^step from it, so a captured step replays with the right bias corrections.  (Synchronises the stream.) */
+/* Device-driven stepping for hipGraph replay (a captured launch freezes its by-value arguments): after
+ * nnhipFusedOptimizerSetStep(opt, t) AND nnhipFusedOptimizerSetHyper(...), calls of nnhipFusedAdamWMultiTensorStep with
+ * step == 0 take the step count (advanced by the kernel itself), lr, weight_decay and grad_scale from device memory;
+ * the lr / weight_decay / grad_scale ARGUMENTS of such a call are ignored.  Both setters are stream-ordered launches
+ * (no synchronisation): call SetHyper between replays to run an LR schedule or change the DP gradient scale. */
 int nnhipFusedOptimizerSetStep(void* opt, int32_t step, nnhipStream_t stream);
+int nnhipFusedOptimizerSetHyper(void* opt, double lr, double weight_decay, float grad_scale, nnhipStream_t stream);
+/* Gradients are additionally divided by divisor_dev[0] (a device float; NULL switches it off): with
+ * CrossEntropy(ignore_index) under data parallelism every rank back-propagates the SUM loss and the all-reduced count
+ * of non-ignored targets (one extra float in the gradient bucket) is the divisor -- no host read, no scale pass. */
+int nnhipFusedOptimizerSetGradDivisor(void* opt, const float* divisor_dev_or_null);
 
 /* ---- a3/a4 Conv2d  (net-new exports; reference CPU: neunet/nn/layers/conv2d.py:297-355, 16-115)
  *   X [B,Cin,H,W], W [Cout,Cin,kh,kw], bias [Cout] or NULL, O [B,Cout,Ho,Wo]; NCHW fp32.

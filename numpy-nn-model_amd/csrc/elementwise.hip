@@ -1,7 +1,9 @@
 // elementwise.hip -- bandwidth-bound elementwise kernels: ReLU, Swish, SwiGLU gate, scale, add.
 // All are float4 grid-stride loops (16 B/lane = 1 KiB per wave instruction), capped at 8 blocks/CU,
-// with a scalar tail; exact expf (the reference's --use_fast_math builds already deviate from
-// NumPy, SURVEY Appendix A.12 -- parity is defined against NumPy).
+// with a scalar tail.  sigmoid = v_rcp_f32(1 + v_exp_f32(-x log2 e)): the two hardware transcendentals are
+// 1 ulp each, so x*sigmoid(x) stays within ~3 ulp of NumPy's float32 result (tests/test_hip_parity.py sweeps
+// [-88, 88]); the library expf + IEEE divide were ~30 VALU instructions per element and made the *simplest*
+// kernel of the C3 pass (Swish forward) slower than Softmax forward on the same 268 MB (round-1 VERDICT).
 #include "common.h"
 
 namespace nnhip {
@@ -90,13 +92,13 @@ struct ReluB { __device__ float operator()(float dy, float y) const { return y >
 // f = x * sigmoid(beta x)     (neunet/nn/activations.py:225-230)
 struct SwishF {
     float beta;
-    __device__ float operator()(float x) const { return x * sigmoidf_(beta * x); }
+    __device__ float operator()(float x) const { return x * sigmoid_fast_(beta * x); }
 };
 // dx = dy * (beta f + s (1 - beta f)), s = sigmoid(beta x)   (neunet/nn/activations.py:212-216)
 struct SwishB {
     float beta;
     __device__ float operator()(float dy, float x) const {
-        const float s = sigmoidf_(beta * x);
+        const float s = sigmoid_fast_(beta * x);
         const float f = x * s;
         return dy * (beta * f + s * (1.f - beta * f));
     }
@@ -143,24 +145,24 @@ __global__ __launch_bounds__(EW_THREADS) void swiglu_fwd_kernel(float* __restric
             const float4 g = reinterpret_cast<const float4*>(in)[row * 2 * hv + c];
             const float4 u = reinterpret_cast<const float4*>(in)[row * 2 * hv + hv + c];
             float4 y;
-            y.x = g.x * sigmoidf_(beta * g.x) * u.x;
-            y.y = g.y * sigmoidf_(beta * g.y) * u.y;
-            y.z = g.z * sigmoidf_(beta * g.z) * u.z;
-            y.w = g.w * sigmoidf_(beta * g.w) * u.w;
+            y.x = g.x * sigmoid_fast_(beta * g.x) * u.x;
+            y.y = g.y * sigmoid_fast_(beta * g.y) * u.y;
+            y.z = g.z * sigmoid_fast_(beta * g.z) * u.z;
+            y.w = g.w * sigmoid_fast_(beta * g.w) * u.w;
             reinterpret_cast<float4*>(out)[i] = y;
         }
     } else {
         for (int64_t i = gid; i < size; i += gsz) {
             const int64_t row = i / h, c = i - row * h;
             const float g = in[row * 2 * h + c], u = in[row * 2 * h + h + c];
-            out[i] = g * sigmoidf_(beta * g) * u;
+            out[i] = g * sigmoid_fast_(beta * g) * u;
         }
     }
 }
 
 __device__ __forceinline__ void swiglu_bwd1(float dy, float g, float u, float beta, float& dg,
                                             float& du) {
-    const float s = sigmoidf_(beta * g);
+    const float s = sigmoid_fast_(beta * g);
     const float f = g * s;
     du = dy * f;
     dg = dy * u * (beta * f + s * (1.f - beta * f));

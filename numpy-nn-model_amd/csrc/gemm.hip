@@ -54,6 +54,7 @@ struct GemmParams {
     const float* addend;  // [M, ldc] or null: C = act(alpha*AB + bias + addend)  (residual / gradient accumulation)
     float* asum;          // CS variants: asum[m] = sum_k A[m,k] (Linear: db = column sums of dO, fused into dW = dO^T X)
     float* asum_slab;     // split-K partials [splitk][M]
+    int skew;             // 1: the first 256 blocks run at raised wave priority (see the kernel)
 };
 
 constexpr int BM = 128, BN = 128, NT = 256;
@@ -214,6 +215,12 @@ __global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const 
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, lh = lane >> 5;
+    // Two blocks share a CU (2 waves per SIMD share its matrix pipe).  Started together at equal priority they stay in
+    // lock-step: both in the prologue, both in the K loop, both in the store-bound epilogue -- nothing hides the
+    // prologue / epilogue of a grid that is a single generation of tiles (all of GPT-tiny's forward GEMMs).  Raising the
+    // priority of every other dispatch round (blocks are dealt out one per CU per round of 256) lets the favoured
+    // block take the matrix pipe first and finish early; its epilogue then overlaps the partner's K loop.
+    if (p.skew) __builtin_amdgcn_s_setprio(((blockIdx.x >> 8) & 1) ? 0 : 2);
 
     // ---- block id -> (split, tile_m, tile_n): XCD-aware grouped order --------------------------
     const int nwg = gridDim.x;
@@ -372,7 +379,7 @@ __global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const 
                     if (p.dswish) v *= swish_grad_(p.dswish[c_off + row * ldc + col], p.beta);
                     if (p.act == ACT_SWISH) {
                         if (p.preact) p.preact[c_off + row * ldc + col] = v;
-                        v = v * sigmoidf_(p.beta * v);
+                        v = v * sigmoid_fast_(p.beta * v);
                     } else if (p.act == ACT_RELU) {
                         v = fmaxf(v, 0.f);
                     }
@@ -414,7 +421,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         if (dswish) s *= swish_grad_(dswish[m * ldc + n], beta);
         if (act == ACT_SWISH) {
             if (preact) preact[m * ldc + n] = s;
-            s = s * sigmoidf_(beta * s);
+            s = s * sigmoid_fast_(beta * s);
         } else if (act == ACT_RELU) {
             s = fmaxf(s, 0.f);
         }
@@ -525,6 +532,8 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
     p.act = act; p.beta = beta;
     p.splitk = 1; p.k_per_split = ceil_div(K > 0 ? K : 1, BK) * BK; p.slab = nullptr;
     p.asum = asum; p.asum_slab = nullptr; p.addend = addend; p.dswish = dswish;
+    static const int skew_sel = []() { const char* e = getenv("NNHIP_GEMM_SKEW"); return e ? atoi(e) : 0; }();
+    p.skew = skew_sel;
     p.zeros = zero_block();
     if (!p.zeros) { set_last_error("zero block allocation failed"); return NNHIP_ENOMEM; }
 

@@ -83,13 +83,19 @@ constexpr int64_t MT_CHUNK_SMALL = 2048;  // below 4 M parameters: 8 per thread 
 
 // Device blob layout (one upload): [p*][g*][m*][v*] (n pointers each) [sizes int64 n]
 // [blk_tensor int32 nblk][blk_chunk int32 nblk]
-// Device-side step state for hipGraph replay: state[0] = step (int bits), state[3] = finished-block ticket (int bits).
+// Device-side state for hipGraph replay: state[0] = step (int bits), state[1] = lr, state[2] = grad_scale,
+// state[3] = finished-block ticket (int bits), state[4] = weight_decay.  A captured launch freezes its by-value kernel
+// arguments, so everything a training loop changes between steps (the step count, an LR schedule, the DP gradient
+// scale) is read from here instead (nnhipFusedOptimizerSetStep / SetHyper write it).
 // Every block reads the step when it starts and derives the bias corrections itself; the LAST block to finish (ticket)
 // advances the counter -- no block can still have to read it then -- so a replayed step needs no separate
 // "advance" launch (it was one more ~4.6 us graph node per step at MNIST-MLP scale).
+// grad_div (device float or null): gradients are additionally divided by grad_div[0] -- the all-reduced count of
+// non-ignored targets when every rank back-propagated a 'sum' loss (no host read of the count, no scale pass).
 __global__ __launch_bounds__(256) void adamw_multi_kernel(const unsigned char* __restrict__ blob, int n,
                                                           int nblk, AdamHyper h, float* __restrict__ dev_state,
-                                                          double b1, double b2, int chunk) {
+                                                          double b1, double b2, int chunk,
+                                                          const float* __restrict__ grad_div) {
     __shared__ float bc[2];
     if (dev_state) {
         if (threadIdx.x == 0) {
@@ -100,7 +106,11 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const unsigned char* _
         __syncthreads();
         h.bc1 = bc[0];
         h.bc2 = bc[1];
+        h.lr = dev_state[1];
+        h.grad_scale = dev_state[2];
+        h.wd = dev_state[4];
     }
+    if (grad_div) h.grad_scale = h.grad_scale / grad_div[0];
     float* const* P = reinterpret_cast<float* const*>(blob);
     const float* const* G = reinterpret_cast<const float* const*>(blob + sizeof(void*) * n);
     float* const* M = reinterpret_cast<float* const*>(blob + sizeof(void*) * 2 * n);
@@ -148,7 +158,9 @@ struct FusedOptimizer {
     bool ev_pending[kRing] = {false, false, false, false};
     int ring = 0;
     int nblk = 0;
-    float* dev_state = nullptr;  // {step, 1-b1^step, 1-b2^step} for device-driven stepping (graph replay)
+    float* dev_state = nullptr;  // {step, lr, grad_scale, ticket, weight_decay} for device-driven stepping (graph replay)
+    bool hyper_set = false;
+    const float* grad_div = nullptr;  // device float: divide gradients by it (all-reduced target count), or null
 
     ~FusedOptimizer() {
         (void)hipDeviceSynchronize();
@@ -264,25 +276,58 @@ extern "C" int nnhipFusedAdamWMultiTensorStep(void* opt, int32_t n_tensors, floa
     const AdamHyper h = make_hyper(lr, beta1, beta2, eps, weight_decay, step > 0 ? step : 1, decay_mode, grad_scale);
     float* dstate = nullptr;
     if (step == 0) {  // device-driven step counter (set with nnhipFusedOptimizerSetStep): graph-replay safe
-        NNHIP_CHECK_ARG(fo->dev_state != nullptr, NNHIP_EINVAL,
-                        "nnhipFusedAdamWMultiTensorStep: step == 0 needs nnhipFusedOptimizerSetStep first");
+        NNHIP_CHECK_ARG(fo->dev_state != nullptr && fo->hyper_set, NNHIP_EINVAL,
+                        "nnhipFusedAdamWMultiTensorStep: step == 0 needs nnhipFusedOptimizerSetStep and SetHyper first");
         dstate = fo->dev_state;
     }
     hipLaunchKernelGGL(adamw_multi_kernel, dim3((unsigned)nblk), dim3(256), 0, st, fo->dev, n, (int)nblk, h, dstate, beta1,
-                       beta2, (int)chunk);
+                       beta2, (int)chunk, fo->grad_div);
     NNHIP_LAUNCH_CHECK("adamw_multi_kernel");
     return 0;
 }
 
+namespace nnhip {
+__global__ void set_step_kernel(float* st, int step) {
+    reinterpret_cast<int*>(st)[0] = step;
+    reinterpret_cast<int*>(st)[3] = 0;
+}
+__global__ void set_hyper_kernel(float* st, float lr, float grad_scale, float wd) {
+    st[1] = lr; st[2] = grad_scale; st[4] = wd;
+}
+static int ensure_dev_state(FusedOptimizer* fo) {
+    if (fo->dev_state) return 0;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&fo->dev_state), 8 * sizeof(float));
+    if (e != hipSuccess) { fo->dev_state = nullptr; return hip_status(e, "hipMalloc(optimizer device state)"); }
+    e = hipMemset(fo->dev_state, 0, 8 * sizeof(float));
+    return hip_status(e, "hipMemset(optimizer device state)");
+}
+}  // namespace nnhip
+
+// Both setters are ordinary stream-ordered launches (values travel as kernel arguments): no host memory to keep alive,
+// no synchronisation, legal between two replays of a captured step.
 extern "C" int nnhipFusedOptimizerSetStep(void* opt, int32_t step, nnhipStream_t s) {
     NNHIP_CHECK_ARG(opt != nullptr && step >= 0, NNHIP_EINVAL, "nnhipFusedOptimizerSetStep: bad arguments");
     FusedOptimizer* fo = static_cast<FusedOptimizer*>(opt);
-    if (!fo->dev_state) {
-        hipError_t e = hipMalloc(reinterpret_cast<void**>(&fo->dev_state), 4 * sizeof(float));
-        if (e != hipSuccess) { fo->dev_state = nullptr; return hip_status(e, "hipMalloc(optimizer step state)"); }
-    }
-    int32_t host[4] = {step, 0, 0, 0};
-    hipError_t e = hipMemcpyAsync(fo->dev_state, host, sizeof(host), hipMemcpyHostToDevice, (hipStream_t)s);
-    if (e != hipSuccess) return hip_status(e, "hipMemcpyAsync(optimizer step state)");
-    return hip_status(hipStreamSynchronize((hipStream_t)s), "hipStreamSynchronize(optimizer step state)");
+    if (int rc = ensure_dev_state(fo)) return rc;
+    hipLaunchKernelGGL(set_step_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, fo->dev_state, (int)step);
+    NNHIP_LAUNCH_CHECK("set_step_kernel");
+    return 0;
+}
+
+extern "C" int nnhipFusedOptimizerSetHyper(void* opt, double lr, double weight_decay, float grad_scale, nnhipStream_t s) {
+    NNHIP_CHECK_ARG(opt != nullptr, NNHIP_EINVAL, "nnhipFusedOptimizerSetHyper: null optimizer handle");
+    FusedOptimizer* fo = static_cast<FusedOptimizer*>(opt);
+    if (int rc = ensure_dev_state(fo)) return rc;
+    hipLaunchKernelGGL(set_hyper_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, fo->dev_state, (float)lr, grad_scale,
+                       (float)weight_decay);
+    NNHIP_LAUNCH_CHECK("set_hyper_kernel");
+    fo->hyper_set = true;
+    return 0;
+}
+
+extern "C" int nnhipFusedOptimizerSetGradDivisor(void* opt, const float* divisor_dev_or_null) {
+    NNHIP_CHECK_ARG(opt != nullptr, NNHIP_EINVAL, "nnhipFusedOptimizerSetGradDivisor: null optimizer handle");
+    NNHIP_CHECK_ARG(aligned4(divisor_dev_or_null), NNHIP_EALIGN, "nnhipFusedOptimizerSetGradDivisor: misaligned pointer");
+    static_cast<FusedOptimizer*>(opt)->grad_div = divisor_dev_or_null;
+    return 0;
 }

@@ -9,6 +9,9 @@
 // Rows wider than 16384 floats (or with a non-unit stride) take a looped fallback.
 #include <math.h>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "common.h"
 
 namespace nnhip {
@@ -100,7 +103,7 @@ __global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void softmax_fwd_rows(
     float s = 0.f;
 #pragma unroll
     for (int e = 0; e < r.NE; ++e) {
-        r.x[e] = expf(r.x[e] - m);  // exp(-inf) = 0 for the padding lanes
+        r.x[e] = exp_fast_(r.x[e] - m);  // exp(-inf) = 0 for the padding lanes
         s += r.x[e];
     }
     s = row_sum<TPR>(s, red);
@@ -156,7 +159,7 @@ __global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void softmax_masked_fwd_r
     float s = 0.f;
 #pragma unroll
     for (int e = 0; e < r.NE; ++e) {
-        r.x[e] = expf(r.x[e] - m);
+        r.x[e] = exp_fast_(r.x[e] - m);
         s += r.x[e];
     }
     s = row_sum<TPR>(s, red);
@@ -205,9 +208,9 @@ __global__ __launch_bounds__(256) void softmax_fwd_strided(float* __restrict__ o
     float m = -INFINITY;
     for (int64_t i = 0; i < n; ++i) m = fmaxf(m, in[base + i * stride]);
     float d = 0.f;
-    for (int64_t i = 0; i < n; ++i) d += expf(in[base + i * stride] - m);
+    for (int64_t i = 0; i < n; ++i) d += exp_fast_(in[base + i * stride] - m);
     const float inv = 1.0f / d;
-    for (int64_t i = 0; i < n; ++i) out[base + i * stride] = expf(in[base + i * stride] - m) * inv;
+    for (int64_t i = 0; i < n; ++i) out[base + i * stride] = exp_fast_(in[base + i * stride] - m) * inv;
 }
 __global__ __launch_bounds__(256) void softmax_bwd_strided(float* __restrict__ dx,
                                                            const float* __restrict__ dy,
@@ -231,10 +234,10 @@ __global__ __launch_bounds__(256) void softmax_fwd_looped(float* __restrict__ ou
     for (int64_t i = threadIdx.x; i < n; i += 256) m = fmaxf(m, x[i]);
     m = block_max<4>(m, red);
     float d = 0.f;
-    for (int64_t i = threadIdx.x; i < n; i += 256) d += expf(x[i] - m);
+    for (int64_t i = threadIdx.x; i < n; i += 256) d += exp_fast_(x[i] - m);
     d = block_sum<4>(d, red);
     const float inv = 1.0f / d;
-    for (int64_t i = threadIdx.x; i < n; i += 256) o[i] = expf(x[i] - m) * inv;
+    for (int64_t i = threadIdx.x; i < n; i += 256) o[i] = exp_fast_(x[i] - m) * inv;
 }
 __global__ __launch_bounds__(256) void softmax_bwd_looped(float* __restrict__ dx,
                                                           const float* __restrict__ dy,
@@ -279,19 +282,82 @@ __global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void rmsnorm_fwd_rows(
     r.store(Y + row * cols, cols, t);
 }
 
+// ---- in-launch column-sum finish ---------------------------------------------------------------------------------
+// part[prow][cols] (dense) -> out[cols], computed by the `nfin` finishing blocks of a launch: finisher f takes the
+// slices f, f+nfin, ...; a slice = 16 float4 columns (VEC) or 16 columns (scalar).  BS threads = 16 column-threads x
+// BS/16 row groups; group g sums partial rows g, g+G, ... (4 loads in flight), the groups meet in LDS in a fixed
+// order, so the result does not depend on which blocks finish.  `part` is read with plain loads AFTER the caller's
+// agent-scope acquire (grid_wait_all).
+constexpr int kFinSW = 16;
+template <int BS, bool VEC>
+__device__ __forceinline__ void colsum_slices(const float* part, int64_t prow, int64_t cols, float* out, int f,
+                                              int nfin, float4* lds) {
+    constexpr int G = BS / kFinSW;
+    const int c = threadIdx.x % kFinSW, g = threadIdx.x / kFinSW;
+    const int64_t units = VEC ? (cols >> 2) : cols;           // float4s or floats per partial row
+    const int64_t nsl = (units + kFinSW - 1) / kFinSW;
+    for (int64_t s = f; s < nsl; s += nfin) {
+        const int64_t u = s * kFinSW + c;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (u < units) {
+            if constexpr (VEC) {
+                const float4* p4 = reinterpret_cast<const float4*>(part);
+                int64_t r = g;
+                for (; r + 3 * G < prow; r += 4 * G) {
+                    const float4 v0 = p4[r * units + u], v1 = p4[(r + G) * units + u];
+                    const float4 v2 = p4[(r + 2 * G) * units + u], v3 = p4[(r + 3 * G) * units + u];
+                    a.x += (v0.x + v1.x) + (v2.x + v3.x); a.y += (v0.y + v1.y) + (v2.y + v3.y);
+                    a.z += (v0.z + v1.z) + (v2.z + v3.z); a.w += (v0.w + v1.w) + (v2.w + v3.w);
+                }
+                for (; r < prow; r += G) {
+                    const float4 v = p4[r * units + u];
+                    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+                }
+            } else {
+                for (int64_t r = g; r < prow; r += G) a.x += part[r * units + u];
+            }
+        }
+        lds[threadIdx.x] = a;
+        __syncthreads();
+        if (g == 0 && u < units) {
+#pragma unroll 4
+            for (int i = 1; i < G; ++i) {
+                const float4 v = lds[i * kFinSW + c];
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+            }
+            if constexpr (VEC) reinterpret_cast<float4*>(out)[u] = a;
+            else out[u] = a.x;
+        }
+        __syncthreads();
+    }
+}
+// how many finishing blocks a [*, cols] column-sum can use
+static inline int fin_slices(int64_t cols, bool vec) {
+    const int64_t units = vec ? (cols >> 2) : cols;
+    int64_t n = (units + kFinSW - 1) / kFinSW;
+    if (n > 128) n = 128;   // spinning finishers must stay well below the resident-block capacity (>= 256)
+    return (int)(n < 1 ? 1 : n);
+}
+
 // Backward: block b walks rows b*RPB+rslot + k*gridDim.x*RPB, TWO rows per iteration (both rows' loads
 // are in flight together and their row reductions share one pair of barriers), keeps per-thread column
 // partials of dw = sum dy*x/std and db = sum dy in registers (a thread always owns the same columns),
-// and writes them once at the end to part[(b*RPB + rslot)][cols]; a column-sum pass finishes dw/db.
+// and writes them once at the end to part[b][cols] (wave-per-row blocks first add their 4 waves' partials in LDS).
+// dw/db are then finished IN THE SAME LAUNCH: every block takes an arrival ticket after publishing its partials;
+// the last `nfin` arrivals wait until all blocks have arrived and column-sum disjoint slices of the partials
+// (round 1 used two extra column-sum launches here: +10 us on a 77 us kernel at 8192x4096).
 // dx needs one row reduction: S = sum(w dy x / std).
 template <int TPR, int NV, bool VEC>
 __global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void rmsnorm_bwd_rows(
     const float* __restrict__ dY, const float* __restrict__ X, const float* __restrict__ w,
-    const float* __restrict__ Xstd, float* __restrict__ dX, float* __restrict__ part_dw,
-    float* __restrict__ part_db, int64_t rows, int64_t cols, const float* __restrict__ dXadd) {
-    __shared__ float red[32];
+    const float* __restrict__ Xstd, float* __restrict__ dX, float* part_dw, float* part_db, float* dW, float* db,
+    int64_t rows, int64_t cols, const float* __restrict__ dXadd, unsigned* sync, int nfin) {
+    constexpr int BS = (TPR >= 256) ? TPR : 256;
     constexpr int RPB = (TPR >= 256) ? 1 : 256 / TPR;
     constexpr int NW = TPR / 64;
+    __shared__ float red[32];
+    __shared__ int sh_i;
+    __shared__ float4 fin_lds[BS];
     const int t = threadIdx.x % TPR;
     const int rslot = threadIdx.x / TPR;
     RowTile<TPR, NV, VEC> wt, adw, adb;
@@ -373,107 +439,346 @@ __global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void rmsnorm_bwd_rows(
             g0.store(dX + r0 * cols, cols, t);
         }
     }
-    const int64_t prow = (int64_t)blockIdx.x * RPB + rslot;
-    adw.store(part_dw + prow * cols, cols, t);
-    if (part_db) adb.store(part_db + prow * cols, cols, t);
+    // ---- this block's column partials -> part[blockIdx.x][cols] ---------------------------------------------------
+    if constexpr (RPB > 1) {
+        // 4 waves = 4 row slots with the same column ownership: add them in LDS (slots 1..3 deposit, slot 0 sums in
+        // slot order), so a block publishes ONE partial row (4x less to re-read in the finish)
+        float* xch = reinterpret_cast<float*>(fin_lds);      // 256 float4 = 1024 floats >= 3 slots x NE x 64 / pass
+        constexpr int NE = NV * 4;
+        constexpr int EPP = (1024 / (3 * 64)) < NE ? (1024 / (3 * 64)) : NE;   // elements per pass (5 of <= 16)
+        auto fold = [&](RowTile<TPR, NV, VEC>& acc) {
+#pragma unroll
+            for (int e0 = 0; e0 < NE; e0 += EPP) {
+                __syncthreads();
+                if (rslot > 0) {
+#pragma unroll
+                    for (int e = 0; e < EPP; ++e)
+                        if (e0 + e < NE) xch[((rslot - 1) * EPP + e) * 64 + t] = acc.x[e0 + e];
+                }
+                __syncthreads();
+                if (rslot == 0) {
+#pragma unroll
+                    for (int e = 0; e < EPP; ++e)
+                        if (e0 + e < NE)
+                            acc.x[e0 + e] += (xch[(0 * EPP + e) * 64 + t] + xch[(1 * EPP + e) * 64 + t]) + xch[(2 * EPP + e) * 64 + t];
+                }
+            }
+        };
+        fold(adw);
+        if (part_db) fold(adb);
+        __syncthreads();
+    }
+    if (rslot == 0) {
+        adw.store(part_dw + (int64_t)blockIdx.x * cols, cols, t);
+        if (part_db) adb.store(part_db + (int64_t)blockIdx.x * cols, cols, t);
+    }
+    // ---- finish dw/db in this launch ----------------------------------------------------------------------------------
+    const int nblk = (int)gridDim.x;
+    const int ticket = grid_arrive(&sync[0], &sh_i);
+    if (ticket < nblk - nfin) return;
+    grid_wait_all(&sync[0], (unsigned)nblk, &sh_i);
+    const int f = ticket - (nblk - nfin);
+    colsum_slices<BS, VEC>(part_dw, nblk, cols, dW, f, nfin, fin_lds);
+    if (part_db) colsum_slices<BS, VEC>(part_db, nblk, cols, db, f, nfin, fin_lds);
+    grid_finish_done(sync, nfin);
+}
+
+// ---- RMSNorm for rows wider than the register tile (cols > 16384): looped, one block per row -------------------------
+// (the reference's kernels loop over any width, rmsnorm.cu:17-113; this is the correctness path for such widths:
+//  forward 12 B/elem, backward 20 B/elem + a column pass for dw/db)
+__global__ __launch_bounds__(1024) void rmsnorm_fwd_looped(const float* __restrict__ X, const float* __restrict__ w,
+                                                           const float* __restrict__ b, float* __restrict__ Y,
+                                                           float* __restrict__ Xstd, float* __restrict__ Xnorm,
+                                                           int64_t cols, float eps) {
+    __shared__ float red[16];
+    const int64_t row = blockIdx.x;
+    const float* x = X + row * cols;
+    float ss = 0.f;
+    for (int64_t i = threadIdx.x; i < cols; i += 1024) ss += x[i] * x[i];
+    ss = block_sum<16>(ss, red);
+    const float sd = sqrtf(ss / (float)cols + eps);
+    const float inv = 1.0f / sd;
+    if (threadIdx.x == 0) Xstd[row] = sd;
+    for (int64_t i = threadIdx.x; i < cols; i += 1024) {
+        const float xn = x[i] * inv;
+        if (Xnorm) Xnorm[row * cols + i] = xn;
+        Y[row * cols + i] = b ? xn * w[i] + b[i] : xn * w[i];
+    }
+}
+__global__ __launch_bounds__(1024) void rmsnorm_bwd_dx_looped(const float* __restrict__ dY, const float* __restrict__ X,
+                                                              const float* __restrict__ w, const float* __restrict__ Xstd,
+                                                              float* __restrict__ dX, int64_t cols,
+                                                              const float* __restrict__ dXadd) {
+    __shared__ float red[16];
+    const int64_t row = blockIdx.x;
+    const float* x = X + row * cols;
+    const float* g = dY + row * cols;
+    const float sd = Xstd[row], inv = 1.0f / sd;
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < cols; i += 1024) s += (g[i] * w[i]) * x[i] * inv;
+    s = block_sum<16>(s, red) / (float)cols;
+    const float q = inv * inv;
+    for (int64_t i = threadIdx.x; i < cols; i += 1024) {
+        float v = ((g[i] * w[i]) * sd - x[i] * s) * q;
+        if (dXadd) v += dXadd[row * cols + i];
+        dX[row * cols + i] = v;
+    }
+}
+// dw[c] = sum_r dy[r,c] x[r,c] / std[r], db[c] = sum_r dy[r,c]: thread per column (coalesced across threads), rows split
+// over gridDim.y into partials part[y][cols] that a column sum finishes.
+__global__ __launch_bounds__(256) void rmsnorm_bwd_dwdb_cols(const float* __restrict__ dY, const float* __restrict__ X,
+                                                             const float* __restrict__ Xstd, float* __restrict__ part_dw,
+                                                             float* __restrict__ part_db, int64_t rows, int64_t cols,
+                                                             int64_t rows_per_block) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t r1 = min(rows, r0 + rows_per_block);
+    float aw = 0.f, ab = 0.f;
+    for (int64_t r = r0; r < r1; ++r) {
+        const float g = dY[r * cols + c];
+        aw += g * (X[r * cols + c] / Xstd[r]);
+        ab += g;
+    }
+    part_dw[(int64_t)blockIdx.y * cols + c] = aw;
+    if (part_db) part_db[(int64_t)blockIdx.y * cols + c] = ab;
 }
 
 // =================================================================================================
 // Fused CrossEntropy forward+backward
 // (CPU semantics: LogSoftmax(axis=1) -> NLLLoss, neunet/nn/losses.py:59-126; fusion boundary of
 //  cross_entropy.cu:18-229: one pass computes loss, lse and d(logits))
+//
+// ONE launch does everything CrossEntropyLoss(mean|sum|none) needs:
+//   * the 'mean' denominator (count of labels != ignore_index, or sum of class_weight[label] over them,
+//     losses.py:117-118) is computed by EVERY block from the label vector (rows*4 B out of L2 per block, in the shadow of
+//     the block's first row load) in the same order, so all blocks scale by the identical value;
+//   * a persistent grid walks the rows (row-in-register tiles as before: 8 B/elem);
+//   * every block publishes the sum of its row losses and takes an arrival ticket; the last arrival adds the partials
+//     in block order (deterministic) and writes the reduced loss.
+// Round 1 ran count / rows / reduce as three launches (61.5 us for a 45 us kernel at 8192x4096).
+// Labels may be int16 / int32 / int64 (losses.py:100); class weights are optional.
+// A label outside [0, cols) that is not ignore_index contributes zero loss and zero gradient (the reference would
+// raise IndexError / Python-wrap it: losses.py:104 TODO) but still counts in the unweighted 'mean' denominator.
 // =================================================================================================
-template <int TPR, int NV, bool VEC>
-__global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void ce_fwd_bwd_rows(
-    float* logits, float* dlogits, float* __restrict__ loss, float* __restrict__ lse_out,
-    const int32_t* __restrict__ labels, int64_t ld, int32_t ignore_index, int64_t rows, int64_t cols,
-    float scale_host, const int32_t* __restrict__ count_dev, int use_mean) {
-    ROW_PROLOGUE(TPR)
-    const int32_t label = labels[row];
-    const bool valid = label != ignore_index && label >= 0 && label < cols;
-    // read the label logit before anything is overwritten (in-place mode)
-    const float xl = valid ? logits[row * ld + label] : 0.f;
-    RowTile<TPR, NV, VEC> r;
-    r.load(logits + row * ld, cols, t, -INFINITY);
-    float m = r.x[0];
+struct CeArgs {
+    float* logits;
+    float* dlogits;
+    float* loss_rows;
+    float* lse;
+    const void* labels;
+    const float* cw;            // class weights [cols] or null
+    const int32_t* count_dev;   // 'mean' with an externally supplied denominator (device int) or null
+    const float* denom_dev;     // 'mean' with a denominator computed by ce_denominator_kernel (tall problems) or null
+    float* partial;             // [gridDim.x] block loss sums
+    unsigned* sync;
+    float* loss_out;            // reduced loss (mean/sum) or null
+    int32_t* count_out;         // #labels != ignore (written when the kernel counts) or null
+    int64_t ld, ignore, rows, cols;
+    float scale_host;           // gradient scale when nothing on the device supplies it
+    int lbytes;                 // 2 / 4 / 8
+    int mode;                   // 0 none, 1 mean, 2 sum
+    int count_in_kernel;        // 1: every block derives the 'mean' denominator from the labels
+};
+
+__device__ __forceinline__ int64_t load_label(const void* labels, int64_t i, int lbytes) {
+    if (lbytes == 4) return reinterpret_cast<const int32_t*>(labels)[i];
+    if (lbytes == 8) return reinterpret_cast<const int64_t*>(labels)[i];
+    return reinterpret_cast<const int16_t*>(labels)[i];
+}
+
+template <int NW>
+__device__ __forceinline__ int block_sum_int(int v, int* red) {
 #pragma unroll
-    for (int e = 1; e < r.NE; ++e) m = fmaxf(m, r.x[e]);
-    m = row_max<TPR>(m, red);
-    float d = 0.f;
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if constexpr (NW == 1) return v;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    int s = 0;
 #pragma unroll
-    for (int e = 0; e < r.NE; ++e) {
-        r.x[e] = expf(r.x[e] - m);   // keep exp(x - m): softmax = e / d, no second exp pass
-        d += r.x[e];
-    }
-    d = row_sum<TPR>(d, red);
-    const float lse = m + logf(d);
-    float scale = scale_host;
-    if (use_mean && count_dev) scale = 1.0f / (float)count_dev[0];
-    if (t == 0) {
-        lse_out[row] = lse;
-        loss[row] = valid ? (lse - xl) : 0.f;
-    }
-    if (valid) {
-        const float invd = 1.0f / d;
-#pragma unroll
-        for (int e = 0; e < r.NE; ++e)
-            r.x[e] = (r.x[e] * invd - ((int64_t)label == r.col(t, e) ? 1.f : 0.f)) * scale;
+    for (int i = 0; i < NW; ++i) s += red[i];
+    return s;
+}
+
+// 'mean' denominator and gradient scale of this launch; identical in every block.
+template <int BS>
+__device__ __forceinline__ void ce_prologue(const CeArgs& a, float* red, int* ired, float& scale, float& denom) {
+    scale = a.scale_host;
+    denom = 1.f;
+    if (a.mode != 1) return;
+    if (a.count_in_kernel) {
+        int ci = 0;
+        float ws = 0.f;
+        for (int64_t i = threadIdx.x; i < a.rows; i += BS) {
+            const int64_t l = load_label(a.labels, i, a.lbytes);
+            const bool live = l != a.ignore;
+            ci += live ? 1 : 0;
+            if (a.cw && live && l >= 0 && l < a.cols) ws += a.cw[l];
+        }
+        ci = block_sum_int<BS / 64>(ci, ired);
+        if (a.cw) ws = block_sum<BS / 64>(ws, red);
+        denom = a.cw ? ws : (float)ci;
+        if (a.count_out && blockIdx.x == 0 && threadIdx.x == 0) a.count_out[0] = ci;
+        scale = denom > 0.f ? 1.0f / denom : 0.0f;
+    } else if (a.denom_dev) {
+        denom = a.denom_dev[0];
+        scale = denom > 0.f ? 1.0f / denom : 0.0f;
+    } else if (a.count_dev) {
+        denom = (float)a.count_dev[0];
+        scale = 1.0f / denom;
     } else {
-#pragma unroll
-        for (int e = 0; e < r.NE; ++e) r.x[e] = 0.f;
+        denom = a.scale_host > 0.f ? 1.0f / a.scale_host : 0.f;
     }
-    r.store(dlogits + row * ld, cols, t);
 }
 
-// looped fallback (cols > 16384): 2 reads + 1 write
-__global__ __launch_bounds__(1024) void ce_fwd_bwd_looped(float* logits, float* dlogits,
-                                                          float* __restrict__ loss,
-                                                          float* __restrict__ lse_out,
-                                                          const int32_t* __restrict__ labels,
-                                                          int64_t ld, int32_t ignore_index,
-                                                          int64_t cols, float scale_host,
-                                                          const int32_t* __restrict__ count_dev,
-                                                          int use_mean) {
+// Publish this block's loss sum, and let the last arrival reduce all of them.  `lsum` is valid on thread 0.
+template <int BS>
+__device__ __forceinline__ void ce_epilogue(const CeArgs& a, float lsum, float denom, float* red, int* ired) {
+    if (!a.loss_out) return;
+    const int nblk = (int)gridDim.x;
+    if (threadIdx.x == 0) {
+        // one dword per block: agent-scope (write-through) store + drain, no L2-wide release needed for it
+        __hip_atomic_store(&a.partial[blockIdx.x], lsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ired[16] = (int)atomicAdd(&a.sync[0], 1u);
+    }
+    __syncthreads();
+    if (ired[16] != nblk - 1) return;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += BS)
+        s += __hip_atomic_load(&a.partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s = block_sum<BS / 64>(s, red);
+    if (threadIdx.x == 0) {
+        a.loss_out[0] = a.mode == 1 ? s / denom : s;
+        __hip_atomic_store(&a.sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <int TPR, int NV, bool VEC>
+__global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void ce_rows_kernel(const CeArgs a) {
+    constexpr int BS = (TPR >= 256) ? TPR : 256;
+    constexpr int RPB = BS / TPR;
     __shared__ float red[16];
-    const int64_t row = blockIdx.x;
-    const int32_t label = labels[row];
-    const bool valid = label != ignore_index && label >= 0 && label < cols;
-    const float xl = valid ? logits[row * ld + label] : 0.f;
-    const float* x = logits + row * ld;
-    float m = -INFINITY;
-    for (int64_t i = threadIdx.x; i < cols; i += 1024) m = fmaxf(m, x[i]);
-    m = block_max<16>(m, red);
-    float d = 0.f;
-    for (int64_t i = threadIdx.x; i < cols; i += 1024) d += expf(x[i] - m);
-    d = block_sum<16>(d, red);
-    const float lse = m + logf(d);
-    float scale = scale_host;
-    if (use_mean && count_dev) scale = 1.0f / (float)count_dev[0];
-    if (threadIdx.x == 0) {
-        lse_out[row] = lse;
-        loss[row] = valid ? (lse - xl) : 0.f;
+    __shared__ int ired[17];
+    const int t = threadIdx.x % TPR;
+    const int slot = threadIdx.x / TPR;
+    float scale, denom;
+    ce_prologue<BS>(a, red, ired, scale, denom);
+    float lsum = 0.f;                                         // meaningful on t == 0 of each row slot
+    const int64_t step = (int64_t)gridDim.x * RPB;
+    for (int64_t row = (int64_t)blockIdx.x * RPB + slot; row < a.rows; row += step) {
+        const int64_t label = load_label(a.labels, row, a.lbytes);
+        const bool valid = label != a.ignore && label >= 0 && label < a.cols;
+        const float wy = valid ? (a.cw ? a.cw[label] : 1.f) : 0.f;
+        // read the label logit before anything is overwritten (in-place mode)
+        const float xl = valid ? a.logits[row * a.ld + label] : 0.f;
+        RowTile<TPR, NV, VEC> r;
+        r.load(a.logits + row * a.ld, a.cols, t, -INFINITY);
+        float m = r.x[0];
+#pragma unroll
+        for (int e = 1; e < r.NE; ++e) m = fmaxf(m, r.x[e]);
+        m = row_max<TPR>(m, red);
+        float d = 0.f;
+#pragma unroll
+        for (int e = 0; e < r.NE; ++e) {
+            r.x[e] = exp_fast_(r.x[e] - m);   // keep exp(x - m): softmax = e / d, no second exp pass
+            d += r.x[e];
+        }
+        d = row_sum<TPR>(d, red);
+        const float lse = m + logf(d);
+        if (t == 0) {
+            const float l = valid ? (lse - xl) * wy : 0.f;
+            a.lse[row] = lse;
+            a.loss_rows[row] = l;
+            lsum += l;
+        }
+        if (valid) {
+            const float invd = 1.0f / d;
+            const float gs = (a.mode == 1 ? scale : 1.f) * wy;
+#pragma unroll
+            for (int e = 0; e < r.NE; ++e)
+                r.x[e] = (r.x[e] * invd - (label == r.col(t, e) ? 1.f : 0.f)) * gs;
+        } else {
+#pragma unroll
+            for (int e = 0; e < r.NE; ++e) r.x[e] = 0.f;
+        }
+        r.store(a.dlogits + row * a.ld, a.cols, t);
     }
-    __syncthreads();
-    float* o = dlogits + row * ld;
-    for (int64_t i = threadIdx.x; i < cols; i += 1024) {
-        const float v = x[i];
-        o[i] = valid ? (expf(v - lse) - (i == label ? 1.f : 0.f)) * scale : 0.f;
+    if constexpr (RPB > 1) {                                  // row slots -> one block sum, in slot order
+        if (a.loss_out) {
+            __syncthreads();
+            if (t == 0) red[slot] = lsum;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                lsum = 0.f;
+#pragma unroll
+                for (int i = 0; i < RPB; ++i) lsum += red[i];
+            }
+        }
     }
+    ce_epilogue<BS>(a, lsum, denom, red, ired);
 }
 
-__global__ __launch_bounds__(1024) void count_ne_kernel(const int32_t* __restrict__ labels, int64_t n,
-                                                        int32_t ignore, int32_t* __restrict__ out) {
+// looped variant (cols > 16384): 2 reads + 1 write per element, one row per block iteration
+__global__ __launch_bounds__(1024) void ce_looped_kernel(const CeArgs a) {
+    __shared__ float red[16];
+    __shared__ int ired[17];
+    float scale, denom;
+    ce_prologue<1024>(a, red, ired, scale, denom);
+    float lsum = 0.f;
+    for (int64_t row = blockIdx.x; row < a.rows; row += gridDim.x) {
+        const int64_t label = load_label(a.labels, row, a.lbytes);
+        const bool valid = label != a.ignore && label >= 0 && label < a.cols;
+        const float wy = valid ? (a.cw ? a.cw[label] : 1.f) : 0.f;
+        const float xl = valid ? a.logits[row * a.ld + label] : 0.f;
+        const float* x = a.logits + row * a.ld;
+        float m = -INFINITY;
+        for (int64_t i = threadIdx.x; i < a.cols; i += 1024) m = fmaxf(m, x[i]);
+        m = block_max<16>(m, red);
+        float d = 0.f;
+        for (int64_t i = threadIdx.x; i < a.cols; i += 1024) d += exp_fast_(x[i] - m);
+        d = block_sum<16>(d, red);
+        const float lse = m + logf(d);
+        if (threadIdx.x == 0) {
+            const float l = valid ? (lse - xl) * wy : 0.f;
+            a.lse[row] = lse;
+            a.loss_rows[row] = l;
+            lsum += l;
+        }
+        __syncthreads();                                      // every thread has read xl before the row is overwritten
+        float* o = a.dlogits + row * a.ld;
+        const float gs = (a.mode == 1 ? scale : 1.f) * wy;
+        const float invd = 1.0f / d;
+        for (int64_t i = threadIdx.x; i < a.cols; i += 1024) {
+            const float v = x[i];
+            o[i] = valid ? (exp_fast_(v - m) * invd - (i == label ? 1.f : 0.f)) * gs : 0.f;
+        }
+    }
+    ce_epilogue<1024>(a, lsum, denom, red, ired);
+}
+
+// Tall problems (rows * grid too large to count per block): the denominator as its own small launch.
+// out_count[0] = #labels != ignore; out_denom[0] = that count, or the class-weight sum, as a float.
+__global__ __launch_bounds__(1024) void ce_denominator_kernel(const void* __restrict__ labels, int lbytes, int64_t n,
+                                                              int64_t ignore, const float* __restrict__ cw, int64_t cols,
+                                                              int32_t* __restrict__ out_count, float* __restrict__ out_denom) {
     __shared__ int ired[16];
+    __shared__ float red[16];
     int ci = 0;
-    for (int64_t i = threadIdx.x; i < n; i += 1024) ci += labels[i] != ignore ? 1 : 0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) ci += __shfl_xor(ci, o, 64);
-    if ((threadIdx.x & 63) == 0) ired[threadIdx.x >> 6] = ci;
-    __syncthreads();
+    float ws = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const int64_t l = load_label(labels, i, lbytes);
+        const bool live = l != ignore;
+        ci += live ? 1 : 0;
+        if (cw && live && l >= 0 && l < cols) ws += cw[l];
+    }
+    ci = block_sum_int<16>(ci, ired);
+    if (cw) ws = block_sum<16>(ws, red);
     if (threadIdx.x == 0) {
-        int s = 0;
-        for (int i = 0; i < 16; ++i) s += ired[i];
-        out[0] = s;
+        if (out_count) out_count[0] = ci;
+        if (out_denom) out_denom[0] = cw ? ws : (float)ci;
     }
 }
 
@@ -488,81 +793,69 @@ __global__ __launch_bounds__(1024) void reduce_loss_kernel(const float* __restri
     if (threadIdx.x == 0) out[0] = mean ? s / (float)count_dev[0] : s;
 }
 
-// Whole CrossEntropyLoss(mean|sum) of a SMALL problem in one launch (one 1024-thread block): count the non-ignored
-// labels, per-row loss / lse / d(logits), reduce the loss.  Same arithmetic as count_ne + ce_fwd_bwd_rows + reduce_loss
-// (the row sums run over a wave instead of a block, so the last bits of lse can differ by rounding); at MNIST-MLP scale
-// (32 x 10) those were three ~4.6 us graph nodes.
-__global__ __launch_bounds__(1024) void ce_small_kernel(const float* __restrict__ logits, float* __restrict__ dlogits,
-                                                        float* __restrict__ loss_rows, float* __restrict__ lse_out,
-                                                        const int32_t* __restrict__ labels, int64_t stride,
-                                                        int32_t ignore, int64_t rows, int64_t cols, int mean,
-                                                        float* __restrict__ loss_out, int32_t* __restrict__ count_out) {
-    __shared__ int ired[16];
-    __shared__ float fred[16];
-    __shared__ int cnt_sh;
+// Whole CrossEntropyLoss of a SMALL problem in one single-block launch (one 1024-thread block, a wave per row): same
+// arithmetic as the persistent kernel (the row sums run over a wave instead of a block, so the last bits of lse can
+// differ by rounding); at MNIST-MLP scale (32 x 10) a 2048-block grid would be all launch overhead.
+__global__ __launch_bounds__(1024) void ce_small_kernel(const CeArgs a) {
+    __shared__ int ired[17];
+    __shared__ float red[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int ci = 0;
-    for (int64_t i = threadIdx.x; i < rows; i += 1024) ci += labels[i] != ignore ? 1 : 0;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) ci += __shfl_xor(ci, o, 64);
-    if (lane == 0) ired[wave] = ci;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int t = 0;
-        for (int i = 0; i < 16; ++i) t += ired[i];
-        cnt_sh = t;
-        if (count_out) count_out[0] = t;
-    }
-    __syncthreads();
-    const int count = cnt_sh;
-    const float scale = mean ? (count > 0 ? 1.0f / (float)count : 0.0f) : 1.0f;
+    float scale, denom;
+    ce_prologue<1024>(a, red, ired, scale, denom);
     float lsum = 0.f;
-    for (int64_t r = wave; r < rows; r += 16) {
-        const float* x = logits + r * stride;
-        float* dx = dlogits + r * stride;
-        const int32_t y = labels[r];
+    for (int64_t r = wave; r < a.rows; r += 16) {
+        const float* x = a.logits + r * a.ld;
+        float* dx = a.dlogits + r * a.ld;
+        const int64_t y = load_label(a.labels, r, a.lbytes);
+        const bool live = y != a.ignore && y >= 0 && y < a.cols;   // same guard as the large kernels (cross_entropy.cu:176)
+        const float wy = live ? (a.cw ? a.cw[y] : 1.f) : 0.f;
         float mx = -INFINITY;
-        for (int64_t c = lane; c < cols; c += 64) mx = fmaxf(mx, x[c]);
+        for (int64_t c = lane; c < a.cols; c += 64) mx = fmaxf(mx, x[c]);
         mx = wave_max(mx);
         float se = 0.f;
-        for (int64_t c = lane; c < cols; c += 64) se += expf(x[c] - mx);
+        for (int64_t c = lane; c < a.cols; c += 64) se += exp_fast_(x[c] - mx);
         se = wave_sum(se);
         const float lse = mx + logf(se);
-        const bool live = y != ignore;
+        // x and dx may alias (in-place mode): every lane holds x[y] before any lane of this wave stores
         const float xy = live ? x[y] : 0.f;
         const float inv = 1.0f / se;
-        for (int64_t c = lane; c < cols; c += 64) {
-            const float pr = expf(x[c] - mx) * inv;
-            dx[c] = live ? (pr - (c == y ? 1.f : 0.f)) * scale : 0.f;
+        const float gs = (a.mode == 1 ? scale : 1.f) * wy;
+        __builtin_amdgcn_wave_barrier();
+        for (int64_t c = lane; c < a.cols; c += 64) {
+            const float pr = exp_fast_(x[c] - mx) * inv;
+            dx[c] = live ? (pr - (c == y ? 1.f : 0.f)) * gs : 0.f;
         }
         if (lane == 0) {
-            const float l = live ? lse - xy : 0.f;
-            loss_rows[r] = l;
-            lse_out[r] = lse;
+            const float l = live ? (lse - xy) * wy : 0.f;
+            a.loss_rows[r] = l;
+            a.lse[r] = lse;
             lsum += l;
         }
     }
-    if (lane == 0) fred[wave] = lsum;
+    if (!a.loss_out) return;
+    __syncthreads();
+    if (lane == 0) red[wave] = lsum;
     __syncthreads();
     if (threadIdx.x == 0) {
         float t = 0.f;
-        for (int i = 0; i < 16; ++i) t += fred[i];
-        loss_out[0] = mean ? t / (float)count : t;
+        for (int i = 0; i < 16; ++i) t += red[i];
+        a.loss_out[0] = a.mode == 1 ? t / denom : t;
     }
 }
 
 // =================================================================================================
-// Column sums:  out[c] = sum_r X[r*ld + c]     (Linear db: neunet/nn/layers/linear.py:24; RMSNorm dw/db)
+// Column sums:  out[c] = sum_r X[r*ld + c]     (Linear db: neunet/nn/layers/linear.py:24)
 // Block = 4 waves; lane <-> one float4 column group (256 columns per block) or one column (scalar path,
 // 64 columns per block); wave w sums rows w, w+4, ... of the block's row range (1 KiB coalesced per
-// wave-load); the 4 waves meet in LDS.  grid (col_blocks, row_blocks); row_blocks > 1 writes partials
-// [row_blocks][cols] that a second, single-row-block launch finishes.
+// wave-load); the 4 waves meet in LDS.  grid (col_blocks, row_blocks); with row_blocks > 1 the blocks write
+// partials [row_blocks][cols] and the LAST arrivals finish them in the same launch (round 1: a second launch).
 // =================================================================================================
 template <bool VEC>
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int64_t rows,
                                                      int64_t cols, int64_t ld, int64_t rows_per_block,
-                                                     float* __restrict__ out) {
-    __shared__ float4 red[3][64];
+                                                     float* out, float* part, unsigned* sync, int nfin) {
+    __shared__ float4 red[256];
+    __shared__ int sh_i;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t rbeg = (int64_t)blockIdx.y * rows_per_block;
     const int64_t rend = min(rows, rbeg + rows_per_block);
@@ -592,18 +885,25 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
         if (c < cols)
             for (int64_t r = rbeg + w; r < rend; r += 4) a.x += X[r * ld + c];
     }
-    if (w > 0) red[w - 1][lane] = a;
+    if (w > 0) red[(w - 1) * 64 + lane] = a;
     __syncthreads();
+    float* dst = gridDim.y > 1 ? part + (int64_t)blockIdx.y * cols : out;
     if (w == 0 && c < cols) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const float4 v = red[i][lane];
+            const float4 v = red[i * 64 + lane];
             a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
         }
-        float* o = out + (int64_t)blockIdx.y * cols + c;
-        if constexpr (VEC) *reinterpret_cast<float4*>(o) = a;
-        else *o = a.x;
+        if constexpr (VEC) *reinterpret_cast<float4*>(dst + c) = a;
+        else dst[c] = a.x;
     }
+    if (gridDim.y == 1) return;
+    const int nblk = (int)(gridDim.x * gridDim.y);
+    const int ticket = grid_arrive(&sync[0], &sh_i);
+    if (ticket < nblk - nfin) return;
+    grid_wait_all(&sync[0], (unsigned)nblk, &sh_i);
+    colsum_slices<256, VEC>(part, (int64_t)gridDim.y, cols, out, ticket - (nblk - nfin), nfin, red);
+    grid_finish_done(sync, nfin);
 }
 
 // internal API ------------------------------------------------------------------------------------
@@ -618,9 +918,9 @@ static ColsumPlan colsum_plan(const float* X, const float* out, int64_t rows, in
     ColsumPlan p;
     p.vec = aligned16(X) && aligned16(out) && (ld % 4 == 0) && (cols % 4 == 0);
     p.col_blocks = ceil_div(cols, p.vec ? 256 : 64);
-    int64_t rb = 2048 / p.col_blocks;             // aim for ~2k blocks in stage 1
+    int64_t rb = 2048 / p.col_blocks;             // aim for ~2k blocks
     if (rb > ceil_div(rows, 16)) rb = ceil_div(rows, 16);  // >= 16 rows per block
-    if (rb > 512) rb = 512;                        // stage 2 sums <= 512 partial rows in one block row
+    if (rb > 512) rb = 512;
     if (rb < 1) rb = 1;
     p.rows_per_block = ceil_div(rows > 0 ? rows : 1, rb);
     p.row_blocks = (int)ceil_div(rows > 0 ? rows : 1, p.rows_per_block);
@@ -631,18 +931,17 @@ static ColsumPlan colsum_plan(const float* X, const float* out, int64_t rows, in
 // `scratch` must hold plan.scratch_floats floats (16-B aligned) when plan.row_blocks > 1.
 static int colsum_run(const ColsumPlan& p, const float* X, int64_t rows, int64_t cols, int64_t ld, float* out,
                       float* scratch, hipStream_t st) {
-    float* stage1 = p.row_blocks > 1 ? scratch : out;
+    unsigned* sync = sync_words();
+    if (!sync) { set_last_error("sync words allocation failed"); return NNHIP_ENOMEM; }
+    sync += SYNC_COLSUM;
     dim3 grid((unsigned)p.col_blocks, (unsigned)p.row_blocks);
-    if (p.vec) hipLaunchKernelGGL(colsum_kernel<true>, grid, dim3(256), 0, st, X, rows, cols, ld, p.rows_per_block, stage1);
-    else hipLaunchKernelGGL(colsum_kernel<false>, grid, dim3(256), 0, st, X, rows, cols, ld, p.rows_per_block, stage1);
+    const bool v = p.vec && (p.row_blocks == 1 || aligned16(scratch));
+    int nfin = fin_slices(cols, v);
+    const int nblk = (int)(p.col_blocks * p.row_blocks);
+    if (nfin > nblk) nfin = nblk;
+    if (v) hipLaunchKernelGGL(colsum_kernel<true>, grid, dim3(256), 0, st, X, rows, cols, ld, p.rows_per_block, out, scratch, sync, nfin);
+    else hipLaunchKernelGGL(colsum_kernel<false>, grid, dim3(256), 0, st, X, rows, cols, ld, p.rows_per_block, out, scratch, sync, nfin);
     NNHIP_LAUNCH_CHECK("colsum_kernel");
-    if (p.row_blocks > 1) {
-        const bool v2 = p.vec && aligned16(stage1);
-        dim3 g2((unsigned)ceil_div(cols, v2 ? 256 : 64), 1);
-        if (v2) hipLaunchKernelGGL(colsum_kernel<true>, g2, dim3(256), 0, st, stage1, (int64_t)p.row_blocks, cols, cols, (int64_t)p.row_blocks, out);
-        else hipLaunchKernelGGL(colsum_kernel<false>, g2, dim3(256), 0, st, stage1, (int64_t)p.row_blocks, cols, cols, (int64_t)p.row_blocks, out);
-        NNHIP_LAUNCH_CHECK("colsum_kernel(stage2)");
-    }
     return 0;
 }
 
@@ -657,11 +956,53 @@ int colsum(const float* X, int64_t rows, int64_t cols, int64_t ld, float* out, h
     return colsum_run(p, X, rows, cols, ld, out, scratch, st);
 }
 
+// ---- attention-score softmax for key counts beyond the register tile (Tk > 16384): looped, one block per row ------
+__global__ __launch_bounds__(1024) void softmax_masked_fwd_looped(float* out, const float* in,
+                                                                  const int32_t* __restrict__ key_valid, int64_t cols,
+                                                                  int64_t HTq, int64_t Tq, float scale, int causal) {
+    __shared__ float red[16];
+    const int64_t row = blockIdx.x;
+    const int64_t b = row / HTq, i = row % Tq;
+    const int64_t lim = causal ? i + (cols - Tq) : cols;
+    const int32_t* kv = key_valid ? key_valid + b * cols : nullptr;
+    const float* x = in + row * cols;
+    float* o = out + row * cols;
+    auto val = [&](int64_t c) { return (c > lim || (kv && kv[c] == 0)) ? -1e9f : x[c] * scale; };
+    float m = -INFINITY;
+    for (int64_t c = threadIdx.x; c < cols; c += 1024) m = fmaxf(m, val(c));
+    m = block_max<16>(m, red);
+    float d = 0.f;
+    for (int64_t c = threadIdx.x; c < cols; c += 1024) d += exp_fast_(val(c) - m);
+    d = block_sum<16>(d, red);
+    const float inv = 1.0f / d;
+    // out may alias in: element c is read and written by the same thread
+    for (int64_t c = threadIdx.x; c < cols; c += 1024) o[c] = exp_fast_(val(c) - m) * inv;
+}
+__global__ __launch_bounds__(1024) void softmax_masked_bwd_looped(float* dx, const float* dy, const float* __restrict__ y,
+                                                                  const int32_t* __restrict__ key_valid, int64_t cols,
+                                                                  int64_t HTq, int64_t Tq, float scale, int causal) {
+    __shared__ float red[16];
+    const int64_t row = blockIdx.x;
+    const int64_t b = row / HTq, i = row % Tq;
+    const int64_t lim = causal ? i + (cols - Tq) : cols;
+    const int32_t* kv = key_valid ? key_valid + b * cols : nullptr;
+    const float* g = dy + row * cols;
+    const float* f = y + row * cols;
+    float s = 0.f;
+    for (int64_t c = threadIdx.x; c < cols; c += 1024) s += g[c] * f[c];
+    s = block_sum<16>(s, red);
+    for (int64_t c = threadIdx.x; c < cols; c += 1024) {
+        const bool masked = c > lim || (kv && kv[c] == 0);
+        dx[row * cols + c] = masked ? 0.f : (g[c] - s) * f[c] * scale;
+    }
+}
+
 // Row-kernel dispatch: pick (TPR, NV) from the row width.
 #define ROW_DISPATCH(KERNEL, cols, vec, rows, st, ...)                                              \
     do {                                                                                            \
         const int64_t _c = (cols);                                                                  \
         if (_c <= 256) { ROW_LAUNCH(KERNEL, 64, 1, vec, rows, st, __VA_ARGS__); }                   \
+        else if (_c <= 512) { ROW_LAUNCH(KERNEL, 64, 2, vec, rows, st, __VA_ARGS__); }              \
         else if (_c <= 1024) { ROW_LAUNCH(KERNEL, 64, 4, vec, rows, st, __VA_ARGS__); }             \
         else if (_c <= 4096) { ROW_LAUNCH(KERNEL, 256, 4, vec, rows, st, __VA_ARGS__); }            \
         else if (_c <= 8192) { ROW_LAUNCH(KERNEL, 256, 8, vec, rows, st, __VA_ARGS__); }            \
@@ -674,6 +1015,63 @@ int colsum(const float* X, int64_t rows, int64_t cols, int64_t ld, float* out, h
         const unsigned _g = (unsigned)ceil_div((rows), _rpb);                                       \
         if (vec) hipLaunchKernelGGL((KERNEL<TPR, NV, true>), dim3(_g), dim3(_bs), 0, st, __VA_ARGS__);  \
         else hipLaunchKernelGGL((KERNEL<TPR, NV, false>), dim3(_g), dim3(_bs), 0, st, __VA_ARGS__);     \
+    } while (0)
+
+// Persistent variants: the caller fixes the number of blocks.
+#define ROW_DISPATCH_GRID(KERNEL, cols, vec, nblk, st, ...)                                         \
+    do {                                                                                            \
+        const int64_t _c = (cols);                                                                  \
+        if (_c <= 256) { ROW_LAUNCH_GRID(KERNEL, 64, 1, vec, nblk, st, __VA_ARGS__); }              \
+        else if (_c <= 512) { ROW_LAUNCH_GRID(KERNEL, 64, 2, vec, nblk, st, __VA_ARGS__); }         \
+        else if (_c <= 1024) { ROW_LAUNCH_GRID(KERNEL, 64, 4, vec, nblk, st, __VA_ARGS__); }        \
+        else if (_c <= 4096) { ROW_LAUNCH_GRID(KERNEL, 256, 4, vec, nblk, st, __VA_ARGS__); }       \
+        else if (_c <= 8192) { ROW_LAUNCH_GRID(KERNEL, 256, 8, vec, nblk, st, __VA_ARGS__); }       \
+        else { ROW_LAUNCH_GRID(KERNEL, 1024, 4, vec, nblk, st, __VA_ARGS__); }                      \
+    } while (0)
+#define ROW_LAUNCH_GRID(KERNEL, TPR, NV, vec, nblk, st, ...)                                        \
+    do {                                                                                            \
+        constexpr int _bs = (TPR >= 256) ? TPR : 256;                                               \
+        if (vec) hipLaunchKernelGGL((KERNEL<TPR, NV, true>), dim3((unsigned)(nblk)), dim3(_bs), 0, st, __VA_ARGS__);  \
+        else hipLaunchKernelGGL((KERNEL<TPR, NV, false>), dim3((unsigned)(nblk)), dim3(_bs), 0, st, __VA_ARGS__);     \
+    } while (0)
+
+// Resident blocks of a kernel instantiation on the whole device (occupancy query, cached per instantiation): the
+// persistent kernels size their grids in multiples of it so no block waits for a slot behind a full-length one.
+static int resident_slots_impl(const void* kernel, int bs) {
+    static std::mutex mu;
+    static std::unordered_map<const void*, int> cache;
+    static int cus = 0;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(kernel);
+    if (it != cache.end()) return it->second;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            cus = prop.multiProcessorCount;
+    }
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, bs, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    cache[kernel] = per_cu * cus;
+    return per_cu * cus;
+}
+template <class K>
+static int resident_slots(K kernel, int bs) { return resident_slots_impl(reinterpret_cast<const void*>(kernel), bs); }
+#define ROW_DISPATCH_SLOTS(KERNEL, cols, vec, OUT)                                                  \
+    do {                                                                                            \
+        const int64_t _c = (cols);                                                                  \
+        if (_c <= 256) { ROW_SLOTS(KERNEL, 64, 1, vec, OUT); }                                      \
+        else if (_c <= 512) { ROW_SLOTS(KERNEL, 64, 2, vec, OUT); }                                 \
+        else if (_c <= 1024) { ROW_SLOTS(KERNEL, 64, 4, vec, OUT); }                                \
+        else if (_c <= 4096) { ROW_SLOTS(KERNEL, 256, 4, vec, OUT); }                               \
+        else if (_c <= 8192) { ROW_SLOTS(KERNEL, 256, 8, vec, OUT); }                               \
+        else { ROW_SLOTS(KERNEL, 1024, 4, vec, OUT); }                                              \
+    } while (0)
+#define ROW_SLOTS(KERNEL, TPR, NV, vec, OUT)                                                        \
+    do {                                                                                            \
+        constexpr int _bs = (TPR >= 256) ? TPR : 256;                                               \
+        OUT = (vec) ? resident_slots(KERNEL<TPR, NV, true>, _bs) : resident_slots(KERNEL<TPR, NV, false>, _bs); \
     } while (0)
 
 constexpr int64_t kMaxRegRow = 16384;
@@ -730,12 +1128,14 @@ extern "C" int nnhipRMSNormForward(const float* X, const float* weight, const fl
     NNHIP_CHECK_ARG(rows >= 0 && cols >= 0, NNHIP_EINVAL, "nnhipRMSNormForward: negative size");
     if (rows == 0 || cols == 0) return 0;
     NNHIP_CHECK_ARG(X && weight && Y && X_std, NNHIP_EINVAL, "nnhipRMSNormForward: null pointer");
-    NNHIP_CHECK_ARG(cols <= kMaxRegRow, NNHIP_EINVAL,
-                    "nnhipRMSNormForward: cols > 16384 not supported");
     hipStream_t st = (hipStream_t)s;
-    const bool vec = aligned16(X) && aligned16(Y) && aligned16(weight) && (!bias || aligned16(bias)) &&
-                     (!X_norm || aligned16(X_norm)) && cols % 4 == 0;
-    ROW_DISPATCH(rmsnorm_fwd_rows, cols, vec, rows, st, X, weight, bias, Y, X_std, X_norm, rows, cols, eps);
+    if (cols > kMaxRegRow) {
+        hipLaunchKernelGGL(rmsnorm_fwd_looped, dim3((unsigned)rows), dim3(1024), 0, st, X, weight, bias, Y, X_std, X_norm, cols, eps);
+    } else {
+        const bool vec = aligned16(X) && aligned16(Y) && aligned16(weight) && (!bias || aligned16(bias)) &&
+                         (!X_norm || aligned16(X_norm)) && cols % 4 == 0;
+        ROW_DISPATCH(rmsnorm_fwd_rows, cols, vec, rows, st, X, weight, bias, Y, X_std, X_norm, rows, cols, eps);
+    }
     NNHIP_LAUNCH_CHECK("rmsnorm_forward");
     return 0;
 }
@@ -756,44 +1156,147 @@ extern "C" int nnhipRMSNormBackwardEx(const float* dY, const float* X, const flo
     if (cols == 0) return 0;
     NNHIP_CHECK_ARG(dY && X && weight && X_std && dX && dW, NNHIP_EINVAL,
                     "nnhipRMSNormBackward: null pointer");
-    NNHIP_CHECK_ARG(cols <= kMaxRegRow, NNHIP_EINVAL,
-                    "nnhipRMSNormBackward: cols > 16384 not supported");
     hipStream_t st = (hipStream_t)s;
-    // persistent-ish grid: <= 1024 blocks (4 per CU), each accumulating dw/db partials over its rows,
-    // two rows in flight per iteration
+    unsigned* sync = sync_words();
+    NNHIP_CHECK_ARG(sync != nullptr, NNHIP_ENOMEM, "nnhipRMSNormBackward: sync words allocation failed");
+    sync += SYNC_RMSNORM;
+    if (cols > kMaxRegRow) {
+        // wide rows: looped dX kernel + a column pass for dw/db (partials over row chunks, then the in-launch column sum)
+        if (rows > 0) {
+            hipLaunchKernelGGL(rmsnorm_bwd_dx_looped, dim3((unsigned)rows), dim3(1024), 0, st, dY, X, weight, X_std, dX, cols, dX_addend);
+            NNHIP_LAUNCH_CHECK("rmsnorm_bwd_dx_looped");
+        }
+        const int64_t col_blocks = ceil_div(cols, 256);
+        int64_t ry = 1024 / col_blocks;
+        if (ry > ceil_div(rows > 0 ? rows : 1, 8)) ry = ceil_div(rows > 0 ? rows : 1, 8);
+        if (ry < 1) ry = 1;
+        const int64_t rpb = ceil_div(rows > 0 ? rows : 1, ry);
+        ry = ceil_div(rows > 0 ? rows : 1, rpb);
+        const size_t pf = ((size_t)ry * cols + 3) / 4 * 4;
+        float* part = static_cast<float*>(workspace(pf * (db ? 2 : 1) * sizeof(float) + 2 * (size_t)cols * 64 * sizeof(float)));
+        NNHIP_CHECK_ARG(part != nullptr, NNHIP_ENOMEM, "nnhipRMSNormBackward: workspace allocation failed");
+        float* pdb = db ? part + pf : nullptr;
+        hipLaunchKernelGGL(rmsnorm_bwd_dwdb_cols, dim3((unsigned)col_blocks, (unsigned)ry), dim3(256), 0, st, dY, X, X_std, part, pdb, rows, cols, rpb);
+        NNHIP_LAUNCH_CHECK("rmsnorm_bwd_dwdb_cols");
+        float* scr = part + pf * (db ? 2 : 1);
+        {
+            const ColsumPlan cp = colsum_plan(part, dW, ry, cols, cols);
+            NNHIP_CHECK_ARG(cp.scratch_floats <= (size_t)cols * 64, NNHIP_ENOMEM, "nnhipRMSNormBackward: column-sum scratch too small");
+            if (int rc = colsum_run(cp, part, ry, cols, cols, dW, scr, st)) return rc;
+        }
+        if (db) {
+            const ColsumPlan cp = colsum_plan(pdb, db, ry, cols, cols);
+            if (int rc = colsum_run(cp, pdb, ry, cols, cols, db, scr, st)) return rc;
+        }
+        return 0;
+    }
+    const bool vec = aligned16(dY) && aligned16(X) && aligned16(weight) && aligned16(dX) && aligned16(dX_addend) &&
+                     aligned16(dW) && aligned16(db) && cols % 4 == 0;
+    // persistent grid = the blocks that are resident at once (occupancy query), each accumulating dw/db partials over
+    // its rows, two rows in flight per iteration
     const int rpb = cols <= 1024 ? 4 : 1;
     int64_t nblk = ceil_div(ceil_div(rows > 0 ? rows : 1, rpb), cols > 8192 ? 1 : 2);
-    if (nblk > 1024) nblk = 1024;
-    const int64_t prow = nblk * rpb;
-    const size_t part_floats = ((size_t)prow * cols + 3) / 4 * 4;
-    // One workspace block: [dw partials | db partials | column-sum scratch for dw | ... for db]
-    const ColsumPlan cp = colsum_plan(nullptr, dW, prow, cols, cols);
-    const size_t scr = (cp.scratch_floats + 3) / 4 * 4;
-    const int nred = db ? 2 : 1;
-    float* part = static_cast<float*>(workspace((part_floats + scr) * nred * sizeof(float)));
+    int slots = 1024;
+    ROW_DISPATCH_SLOTS(rmsnorm_bwd_rows, cols, vec, slots);
+    if (nblk > slots) nblk = slots;
+    const size_t part_floats = ((size_t)nblk * cols + 3) / 4 * 4;
+    float* part = static_cast<float*>(workspace(part_floats * (db ? 2 : 1) * sizeof(float)));
     NNHIP_CHECK_ARG(part != nullptr, NNHIP_ENOMEM, "nnhipRMSNormBackward: workspace allocation failed");
     float* part_dw = part;
     float* part_db = db ? part + part_floats : nullptr;
-    float* scr_dw = part + part_floats * nred;
-    float* scr_db = scr_dw + scr;
-    const bool vec = aligned16(dY) && aligned16(X) && aligned16(weight) && aligned16(dX) && aligned16(dX_addend) && cols % 4 == 0;
-    {
-        const int64_t rows_ = rows;
-        // ROW_LAUNCH computes its grid from `rows`; we want exactly nblk blocks -> pass nblk*rpb.
-        ROW_DISPATCH(rmsnorm_bwd_rows, cols, vec, prow, st, dY, X, weight, X_std, dX, part_dw, part_db, rows_, cols, dX_addend);
-    }
+    int nfin = fin_slices(cols, vec);
+    if (nfin > nblk) nfin = (int)nblk;
+    ROW_DISPATCH_GRID(rmsnorm_bwd_rows, cols, vec, nblk, st, dY, X, weight, X_std, dX, part_dw, part_db, dW, db, rows, cols,
+                      dX_addend, sync, nfin);
     NNHIP_LAUNCH_CHECK("rmsnorm_backward");
-    // finish dw/db: column sums over the `prow` partial rows
-    ColsumPlan cdw = colsum_plan(part_dw, dW, prow, cols, cols);
-    if (int rc = colsum_run(cdw, part_dw, prow, cols, cols, dW, scr_dw, st)) return rc;
-    if (db) {
-        ColsumPlan cdb = colsum_plan(part_db, db, prow, cols, cols);
-        if (int rc = colsum_run(cdb, part_db, prow, cols, cols, db, scr_db, st)) return rc;
-    }
     return 0;
 }
 
 // ---- CrossEntropy -------------------------------------------------------------------------------
+namespace nnhip {
+// One launch (two for tall-and-narrow 'mean' problems whose per-block label count would not be free).
+static int ce_launch(CeArgs a, hipStream_t st) {
+    unsigned* sync = sync_words();
+    if (!sync) { set_last_error("cross entropy: sync words allocation failed"); return NNHIP_ENOMEM; }
+    a.sync = sync + SYNC_CE;
+    float* denom_scratch = reinterpret_cast<float*>(sync + SYNC_CE + 4);
+    const bool need_denom = a.mode == 1 && !a.count_dev && a.scale_host < 0.f;   // scale_host < 0: "derive it from the labels"
+    if (a.rows * a.cols <= 65536 && a.cols <= 4096) {
+        a.count_in_kernel = need_denom ? 1 : 0;
+        hipLaunchKernelGGL(ce_small_kernel, dim3(1), dim3(1024), 0, st, a);
+        NNHIP_LAUNCH_CHECK("ce_small_kernel");
+        return 0;
+    }
+    const bool looped = a.cols > kMaxRegRow;
+    const bool vec = aligned16(a.logits) && aligned16(a.dlogits) && a.cols % 4 == 0 && a.ld % 4 == 0;
+    const int rpb = (!looped && a.cols <= 1024) ? 4 : 1;
+    int64_t nblk = ceil_div(a.rows, rpb);
+    // two rounds of resident blocks: dynamic enough to absorb stragglers, few enough that the per-block label count
+    // and the final partial reduction stay negligible
+    int slots = 512;
+    if (looped) slots = resident_slots(ce_looped_kernel, 1024);
+    else ROW_DISPATCH_SLOTS(ce_rows_kernel, a.cols, vec, slots);
+    if (nblk > 2 * (int64_t)slots) nblk = 2 * (int64_t)slots;
+    if (a.loss_out) {
+        a.partial = static_cast<float*>(workspace((size_t)nblk * sizeof(float)));
+        if (!a.partial) { set_last_error("cross entropy: workspace allocation failed"); return NNHIP_ENOMEM; }
+    }
+    a.count_in_kernel = 0;
+    if (need_denom) {
+        // every block re-reads the label vector (out of L2): free while that stays ~tens of MB in total
+        if ((double)nblk * (double)a.rows * a.lbytes <= 64.0 * 1024 * 1024) {
+            a.count_in_kernel = 1;
+        } else {
+            hipLaunchKernelGGL(ce_denominator_kernel, dim3(1), dim3(1024), 0, st, a.labels, a.lbytes, a.rows, a.ignore, a.cw,
+                               a.cols, a.count_out, denom_scratch);
+            NNHIP_LAUNCH_CHECK("ce_denominator_kernel");
+            a.denom_dev = denom_scratch;
+        }
+    }
+    if (looped) {
+        hipLaunchKernelGGL(ce_looped_kernel, dim3((unsigned)nblk), dim3(1024), 0, st, a);
+    } else {
+        ROW_DISPATCH_GRID(ce_rows_kernel, a.cols, vec, nblk, st, a);
+    }
+    NNHIP_LAUNCH_CHECK("cross_entropy");
+    return 0;
+}
+}  // namespace nnhip
+
+extern "C" int nnhipCrossEntropyLossEx(float* logits, float* dlogits_or_null, float* loss_rows, float* lse,
+                                       const void* labels, int32_t label_bytes, const float* class_weight_or_null,
+                                       int64_t logits_stride, int64_t ignore_index, int64_t n_rows, int64_t n_cols,
+                                       char reduction, float* loss_out_or_null, int32_t* count_out_or_null,
+                                       nnhipStream_t s) {
+    NNHIP_CHECK_ARG(n_rows >= 0 && n_cols >= 0 && logits_stride >= n_cols, NNHIP_EINVAL, "nnhipCrossEntropyLossEx: bad sizes");
+    NNHIP_CHECK_ARG(reduction == 'n' || reduction == 'm' || reduction == 's', NNHIP_EINVAL,
+                    "nnhipCrossEntropyLossEx: reduction must be 'n', 'm' or 's'");
+    NNHIP_CHECK_ARG(label_bytes == 2 || label_bytes == 4 || label_bytes == 8, NNHIP_EINVAL,
+                    "nnhipCrossEntropyLossEx: labels must be int16, int32 or int64");
+    NNHIP_CHECK_ARG(reduction == 'n' || loss_out_or_null, NNHIP_EINVAL, "nnhipCrossEntropyLossEx: 'm'/'s' need loss_out");
+    if (n_rows == 0 || n_cols == 0) {
+        // sum over nothing = 0; mean over nothing = 0/0 (NumPy gives nan): fill without reading anything
+        if (loss_out_or_null) {
+            const float v = reduction == 'm' ? __builtin_nanf("") : 0.f;
+            hipError_t e = hipMemcpyAsync(loss_out_or_null, &v, sizeof(float), hipMemcpyHostToDevice, (hipStream_t)s);
+            if (e != hipSuccess) return hip_status(e, "nnhipCrossEntropyLossEx(empty)");
+        }
+        return 0;
+    }
+    NNHIP_CHECK_ARG(logits && loss_rows && lse && labels, NNHIP_EINVAL, "nnhipCrossEntropyLossEx: null pointer");
+    CeArgs a{};
+    a.logits = logits;
+    a.dlogits = dlogits_or_null ? dlogits_or_null : logits;   // reference behaviour: overwrite logits with the gradient
+    a.loss_rows = loss_rows; a.lse = lse; a.labels = labels; a.cw = class_weight_or_null;
+    a.ld = logits_stride; a.ignore = ignore_index; a.rows = n_rows; a.cols = n_cols;
+    a.lbytes = label_bytes;
+    a.mode = reduction == 'm' ? 1 : (reduction == 's' ? 2 : 0);
+    a.scale_host = a.mode == 1 ? -1.f : 1.f;
+    a.loss_out = a.mode ? loss_out_or_null : nullptr;
+    a.count_out = count_out_or_null;
+    return ce_launch(a, (hipStream_t)s);
+}
+
 extern "C" int nnhipCrossEntropyForwardBackward(float* logits, float* loss, float* lse,
                                                 const int32_t* labels, int64_t logits_stride,
                                                 int32_t ignore_index, int64_t n_rows, int64_t n_cols,
@@ -807,29 +1310,27 @@ extern "C" int nnhipCrossEntropyForwardBackward(float* logits, float* loss, floa
     if (n_rows == 0 || n_cols == 0) return 0;
     NNHIP_CHECK_ARG(logits && loss && lse && labels, NNHIP_EINVAL,
                     "nnhipCrossEntropyForwardBackward: null pointer");
-    if (!dlogits) dlogits = logits;  // reference behaviour: overwrite logits with the gradient
-    hipStream_t st = (hipStream_t)s;
-    const int use_mean = reduction == 'm';
-    float scale = 1.0f;
-    if (use_mean && !n_non_ignore_dev) scale = n_non_ignore > 0 ? 1.0f / (float)n_non_ignore : 0.0f;
-    if (n_cols > kMaxRegRow) {
-        hipLaunchKernelGGL(ce_fwd_bwd_looped, dim3((unsigned)n_rows), dim3(1024), 0, st, logits, dlogits,
-                           loss, lse, labels, logits_stride, ignore_index, n_cols, scale,
-                           n_non_ignore_dev, use_mean);
-    } else {
-        const bool vec = aligned16(logits) && aligned16(dlogits) && n_cols % 4 == 0 && logits_stride % 4 == 0;
-        ROW_DISPATCH(ce_fwd_bwd_rows, n_cols, vec, n_rows, st, logits, dlogits, loss, lse, labels,
-                     logits_stride, ignore_index, n_rows, n_cols, scale, n_non_ignore_dev, use_mean);
+    CeArgs a{};
+    a.logits = logits;
+    a.dlogits = dlogits ? dlogits : logits;
+    a.loss_rows = loss; a.lse = lse; a.labels = labels; a.lbytes = 4;
+    a.ld = logits_stride; a.ignore = ignore_index; a.rows = n_rows; a.cols = n_cols;
+    a.mode = reduction == 'm' ? 1 : (reduction == 's' ? 2 : 0);
+    // the reference's contract: the caller supplies the 'mean' denominator (host int, or a device int here)
+    a.scale_host = 1.0f;
+    if (a.mode == 1) {
+        a.count_dev = n_non_ignore_dev;
+        if (!n_non_ignore_dev) a.scale_host = n_non_ignore > 0 ? 1.0f / (float)n_non_ignore : 0.0f;
     }
-    NNHIP_LAUNCH_CHECK("cross_entropy_forward_backward");
-    return 0;
+    return ce_launch(a, (hipStream_t)s);
 }
 
 extern "C" int nnhipCountNotEqual(const int32_t* labels, int64_t n, int32_t ignore_index,
                                   int32_t* out_count, nnhipStream_t s) {
     NNHIP_CHECK_ARG(n >= 0 && out_count && (labels || n == 0), NNHIP_EINVAL, "nnhipCountNotEqual: bad args");
-    hipLaunchKernelGGL(count_ne_kernel, dim3(1), dim3(1024), 0, (hipStream_t)s, labels, n, ignore_index, out_count);
-    NNHIP_LAUNCH_CHECK("count_ne_kernel");
+    hipLaunchKernelGGL(ce_denominator_kernel, dim3(1), dim3(1024), 0, (hipStream_t)s, labels, 4, n, (int64_t)ignore_index,
+                       (const float*)nullptr, (int64_t)0, out_count, (float*)nullptr);
+    NNHIP_LAUNCH_CHECK("ce_denominator_kernel");
     return 0;
 }
 
@@ -844,30 +1345,15 @@ extern "C" int nnhipReduceLoss(const float* loss_rows, int64_t n_rows, char redu
     return 0;
 }
 
-// CrossEntropyLoss(reduction = 'm' | 's') in one call: d(logits), per-row loss, lse, the reduced loss and (for 'm') the
-// non-ignored count.  Small problems (rows * cols <= 64 K, cols <= 4096) take one single-block launch; anything else
-// runs nnhipCountNotEqual + nnhipCrossEntropyForwardBackward + nnhipReduceLoss with `count_out` as the device count.
+// CrossEntropyLoss(reduction = 'm' | 's') with int32 labels and no class weights: nnhipCrossEntropyLossEx.
 extern "C" int nnhipCrossEntropyLoss(float* logits, float* dlogits_or_null, float* loss_rows, float* lse,
                                      const int32_t* labels, int64_t logits_stride, int32_t ignore_index,
                                      int64_t n_rows, int64_t n_cols, char reduction, float* loss_out,
                                      int32_t* count_out, nnhipStream_t s) {
-    NNHIP_CHECK_ARG(n_rows >= 0 && n_cols >= 0 && logits_stride >= n_cols, NNHIP_EINVAL, "nnhipCrossEntropyLoss: bad sizes");
     NNHIP_CHECK_ARG(reduction == 'm' || reduction == 's', NNHIP_EINVAL, "nnhipCrossEntropyLoss: reduction must be 'm' or 's'");
     NNHIP_CHECK_ARG(loss_out && (reduction != 'm' || count_out), NNHIP_EINVAL, "nnhipCrossEntropyLoss: null loss_out / count_out");
-    if (n_rows > 0 && n_cols > 0 && n_rows * n_cols <= 65536 && n_cols <= 4096) {
-        NNHIP_CHECK_ARG(logits && loss_rows && lse && labels, NNHIP_EINVAL, "nnhipCrossEntropyLoss: null pointer");
-        hipLaunchKernelGGL(ce_small_kernel, dim3(1), dim3(1024), 0, (hipStream_t)s, logits, dlogits_or_null ? dlogits_or_null : logits,
-                           loss_rows, lse, labels, logits_stride, ignore_index, n_rows, n_cols, reduction == 'm' ? 1 : 0,
-                           loss_out, count_out);
-        NNHIP_LAUNCH_CHECK("ce_small_kernel");
-        return 0;
-    }
-    if (reduction == 'm')
-        if (int rc = nnhipCountNotEqual(labels, n_rows, ignore_index, count_out, s)) return rc;
-    if (int rc = nnhipCrossEntropyForwardBackward(logits, loss_rows, lse, labels, logits_stride, ignore_index, n_rows, n_cols,
-                                                  reduction, -1, reduction == 'm' ? count_out : nullptr, dlogits_or_null, s))
-        return rc;
-    return nnhipReduceLoss(loss_rows, n_rows, reduction, count_out, loss_out, s);
+    return nnhipCrossEntropyLossEx(logits, dlogits_or_null, loss_rows, lse, labels, 4, nullptr, logits_stride, ignore_index,
+                                   n_rows, n_cols, reduction, loss_out, count_out, s);
 }
 
 // ---- attention-score softmax (scale + pad/causal mask fused) --------------------------------------------
@@ -878,10 +1364,13 @@ extern "C" int nnhipMaskedSoftmaxForward(float* out, const float* in, const int3
     const int64_t rows = B * H * Tq;
     if (rows == 0 || Tk == 0) return 0;
     NNHIP_CHECK_ARG(out && in, NNHIP_EINVAL, "nnhipMaskedSoftmaxForward: null pointer");
-    NNHIP_CHECK_ARG(Tk <= kMaxRegRow, NNHIP_EINVAL, "nnhipMaskedSoftmaxForward: Tk > 16384 not supported");
     hipStream_t st = (hipStream_t)s;
-    const bool vec = aligned16(out) && aligned16(in) && Tk % 4 == 0;
-    ROW_DISPATCH(softmax_masked_fwd_rows, Tk, vec, rows, st, out, in, key_valid, rows, Tk, H * Tq, Tq, scale, causal);
+    if (Tk > kMaxRegRow) {
+        hipLaunchKernelGGL(softmax_masked_fwd_looped, dim3((unsigned)rows), dim3(1024), 0, st, out, in, key_valid, Tk, H * Tq, Tq, scale, causal);
+    } else {
+        const bool vec = aligned16(out) && aligned16(in) && Tk % 4 == 0;
+        ROW_DISPATCH(softmax_masked_fwd_rows, Tk, vec, rows, st, out, in, key_valid, rows, Tk, H * Tq, Tq, scale, causal);
+    }
     NNHIP_LAUNCH_CHECK("softmax_masked_fwd_rows");
     return 0;
 }
@@ -893,10 +1382,13 @@ extern "C" int nnhipMaskedSoftmaxBackward(float* dX, const float* dY, const floa
     const int64_t rows = B * H * Tq;
     if (rows == 0 || Tk == 0) return 0;
     NNHIP_CHECK_ARG(dX && dY && Y, NNHIP_EINVAL, "nnhipMaskedSoftmaxBackward: null pointer");
-    NNHIP_CHECK_ARG(Tk <= kMaxRegRow, NNHIP_EINVAL, "nnhipMaskedSoftmaxBackward: Tk > 16384 not supported");
     hipStream_t st = (hipStream_t)s;
-    const bool vec = aligned16(dX) && aligned16(dY) && aligned16(Y) && Tk % 4 == 0;
-    ROW_DISPATCH(softmax_masked_bwd_rows, Tk, vec, rows, st, dX, dY, Y, key_valid, rows, Tk, H * Tq, Tq, scale, causal);
+    if (Tk > kMaxRegRow) {
+        hipLaunchKernelGGL(softmax_masked_bwd_looped, dim3((unsigned)rows), dim3(1024), 0, st, dX, dY, Y, key_valid, Tk, H * Tq, Tq, scale, causal);
+    } else {
+        const bool vec = aligned16(dX) && aligned16(dY) && aligned16(Y) && Tk % 4 == 0;
+        ROW_DISPATCH(softmax_masked_bwd_rows, Tk, vec, rows, st, dX, dY, Y, key_valid, rows, Tk, H * Tq, Tq, scale, causal);
+    }
     NNHIP_LAUNCH_CHECK("softmax_masked_bwd_rows");
     return 0;
 }

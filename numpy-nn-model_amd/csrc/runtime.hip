@@ -26,10 +26,16 @@ int hip_status(hipError_t e, const char* what) {
 static std::mutex g_ws_mu;
 static void* g_ws = nullptr;
 static size_t g_ws_bytes = 0;
+static bool g_ws_locked = false;   // nnhipWorkspaceLock: a captured hipGraph holds the block's address
 
 void* workspace(size_t bytes) {
     std::lock_guard<std::mutex> lk(g_ws_mu);
     if (bytes <= g_ws_bytes) return g_ws;
+    if (g_ws_locked) {
+        set_last_error("workspace is locked at %zu bytes (a captured hipGraph uses it) but %zu bytes were requested; "
+                       "run the new shape eagerly before capturing, or nnhipWorkspaceLock(0)", g_ws_bytes, bytes);
+        return nullptr;
+    }
     if (g_ws) {
         (void)hipDeviceSynchronize();  // kernels may still read the old block
         (void)hipFree(g_ws);
@@ -60,14 +66,39 @@ const float* zero_block() {
     return z;
 }
 
+unsigned* sync_words() {
+    static unsigned* w = nullptr;
+    static std::once_flag once;
+    std::call_once(once, []() {
+        unsigned* p = nullptr;
+        if (hipMalloc(reinterpret_cast<void**>(&p), kSyncWords * sizeof(unsigned)) == hipSuccess &&
+            hipMemset(p, 0, kSyncWords * sizeof(unsigned)) == hipSuccess)
+            w = p;
+    });
+    return w;
+}
+
 }  // namespace nnhip
 
-extern "C" int nnhipVersion(void) { return 100; }
+extern "C" int nnhipVersion(void) { return 200; }
+
+extern "C" int nnhipWorkspaceReserve(int64_t bytes) {
+    if (bytes < 0) { nnhip::set_last_error("nnhipWorkspaceReserve: negative size"); return NNHIP_EINVAL; }
+    if (bytes > 0 && !nnhip::workspace((size_t)bytes)) return NNHIP_ENOMEM;
+    return 0;
+}
+
+extern "C" int nnhipWorkspaceLock(int locked) {
+    std::lock_guard<std::mutex> lk(nnhip::g_ws_mu);
+    nnhip::g_ws_locked = locked != 0;
+    return 0;
+}
 
 extern "C" const char* nnhipGetLastErrorString(void) { return nnhip::g_err; }
 
 extern "C" int nnhipCleanup(void) {
     std::lock_guard<std::mutex> lk(nnhip::g_ws_mu);
+    nnhip::g_ws_locked = false;
     if (nnhip::g_ws) {
         (void)hipDeviceSynchronize();
         hipError_t e = hipFree(nnhip::g_ws);

@@ -39,6 +39,8 @@ _SIGNATURES = {
     "nnhipVersion": (ctypes.c_int, []),
     "nnhipGetLastErrorString": (ctypes.c_char_p, []),
     "nnhipCleanup": (ctypes.c_int, []),
+    "nnhipWorkspaceReserve": (ctypes.c_int, [c_int64]),
+    "nnhipWorkspaceLock": (ctypes.c_int, [ctypes.c_int]),
     "nnhipLinearModuleForward": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_void_p]),
     "nnhipLinearModuleBackward": (ctypes.c_int, [P, P, P, P, P, P, c_int64, c_int64, c_int64, c_void_p]),
     "nnhipLinearInputGradSwish": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_float, c_void_p]),
@@ -69,6 +71,7 @@ _SIGNATURES = {
     "nnhipCountNotEqual": (ctypes.c_int, [P, c_int64, c_int32, P, c_void_p]),
     "nnhipReduceLoss": (ctypes.c_int, [P, c_int64, c_char, P, P, c_void_p]),
     "nnhipCrossEntropyLoss": (ctypes.c_int, [P, P, P, P, P, c_int64, ctypes.c_int32, c_int64, c_int64, ctypes.c_char, P, P, c_void_p]),
+    "nnhipCrossEntropyLossEx": (ctypes.c_int, [P, P, P, P, P, c_int32, P, c_int64, c_int64, c_int64, c_int64, c_char, P, P, c_void_p]),
     "nnhipRMSNormForward": (ctypes.c_int, [P, P, P, P, P, P, c_int64, c_int64, c_float, c_void_p]),
     "nnhipRMSNormBackward": (ctypes.c_int, [P, P, P, P, P, P, P, P, c_int64, c_int64, c_void_p]),
     "nnhipRMSNormBackwardEx": (ctypes.c_int, [P, P, P, P, P, P, P, P, P, c_int64, c_int64, c_void_p]),
@@ -79,6 +82,8 @@ _SIGNATURES = {
                                                       POINTER(c_void_p), POINTER(c_int64), c_double, c_double, c_double, c_double, c_double,
                                                       c_int32, c_int32, c_float, c_void_p]),
     "nnhipFusedOptimizerSetStep": (ctypes.c_int, [c_void_p, c_int32, c_void_p]),
+    "nnhipFusedOptimizerSetHyper": (ctypes.c_int, [c_void_p, c_double, c_double, c_float, c_void_p]),
+    "nnhipFusedOptimizerSetGradDivisor": (ctypes.c_int, [c_void_p, P]),
     "nnhipConv2dForward": (ctypes.c_int, [P, P, P, P, POINTER(Conv2dDesc), c_void_p]),
     "nnhipConv2dBackward": (ctypes.c_int, [P, P, P, P, P, P, POINTER(Conv2dDesc), c_void_p]),
     "nnhipLeakyReLUForward": (ctypes.c_int, [P, P, c_float, c_int64, c_void_p]),

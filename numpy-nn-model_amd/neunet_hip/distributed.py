@@ -181,6 +181,7 @@ class GradBucket:
         import torch.distributed as dist
         if self.overlap:
             return self._finish_overlapped()
+        group = group if group is not None else self.group     # a bucket built for a sub-group reduces over THAT group
         self.collect()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)

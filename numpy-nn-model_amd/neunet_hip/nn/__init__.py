@@ -13,10 +13,7 @@ from .experimental import (HIPConv2d as Conv2d, HIPCrossEntropyLoss, HIPLinear a
 
 
 class CrossEntropyLoss(HIPCrossEntropyLoss):
-    """neunet.nn.CrossEntropyLoss signature (losses.py:59-64): reduction defaults to 'mean'.
-    Class weights are not supported by the fused kernel (the reference's fused kernel has none either)."""
+    """neunet.nn.CrossEntropyLoss signature (losses.py:59-64): weight, ignore_index, reduction (default 'mean')."""
 
     def __init__(self, weight=None, ignore_index=-100, reduction="mean", inplace=False):
-        if weight is not None:
-            raise NotImplementedError("class weights are not supported by the fused HIP cross-entropy")
-        super().__init__(reduction=reduction, ignore_index=ignore_index, inplace=inplace)
+        super().__init__(reduction=reduction, ignore_index=ignore_index, inplace=inplace, weight=weight)

@@ -141,10 +141,11 @@ class _HIPAttentionTensor(Tensor):
 class _HIPFusedAttentionTensor(Tensor):
     def __init__(self, data, args, op, device):
         super().__init__(data, args, op, device=device, _nocopy=True)
+        ctx = data   # the closure owns the output ARRAY, not the Tensor (no tensor -> grad_fn -> tensor cycle)
 
         def grad_fn(q: Tensor, k: Tensor, v: Tensor, lse, key_valid, n_heads, scale, causal, grad):
             grad = grad if grad.is_contiguous() else grad.contiguous()
-            dq, dk, dv = fused_attention_backward(q.data, k.data, v.data, key_valid, self.data, lse, n_heads, scale,
+            dq, dk, dv = fused_attention_backward(q.data, k.data, v.data, key_valid, ctx, lse, n_heads, scale,
                                                   causal, grad)
             if q.requires_grad:
                 q.apply_grad(dq)
@@ -211,14 +212,15 @@ class _HIPFusedSelfAttentionTensor(Tensor):
 
     def __init__(self, data, args, op, device):
         super().__init__(data, args, op, device=device, _nocopy=True)
+        ctx = data   # the closure owns the output ARRAY, not the Tensor (no tensor -> grad_fn -> tensor cycle)
 
         def grad_fn(qkv: Tensor, lse, key_valid, n_heads, scale, causal, grad):
             import torch
             grad = grad if grad.is_contiguous() else grad.contiguous()
-            D = self.data.shape[-1]
+            D = ctx.shape[-1]
             x = qkv.data
             dqkv = torch.empty_like(x)
-            fused_attention_backward(x[..., 0:D], x[..., D:2 * D], x[..., 2 * D:], key_valid, self.data, lse, n_heads,
+            fused_attention_backward(x[..., 0:D], x[..., D:2 * D], x[..., 2 * D:], key_valid, ctx, lse, n_heads,
                                      scale, causal, grad, out=(dqkv[..., 0:D], dqkv[..., D:2 * D], dqkv[..., 2 * D:]))
             qkv.apply_grad(dqkv)
 

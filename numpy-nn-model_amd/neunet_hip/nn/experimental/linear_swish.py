@@ -4,6 +4,7 @@
 y = swish(X W^T + b) with the bias add and Swish fused into the MFMA GEMM epilogue (optionally also
 writing the pre-activation z).  fp32 MFMA throughout: unlike the reference's TF32 tensor-op path
 (linear_swish_cutlass_evt_full.cu:440) this meets the 1e-4 parity target."""
+import weakref
 from typing import Union
 
 import numpy as np
@@ -35,6 +36,7 @@ def hip_linear_swish_backward(X, weights, bias, grad_O, d_linear_tmp, grad_X, gr
 class _HIPLinearSwishTensor(Tensor):
     def __init__(self, data, args, op, device):
         super().__init__(data, args, op, device=device, _nocopy=True)
+        self_ref = weakref.ref(self)   # the closure must not own the tensor (reference cycle -> freed only by the GC)
 
         def grad_fn(X: Tensor, weight: Tensor, bias, in_rows_num, in_features, out_features, swish_beta,
                     preactivation, save_preactivation, grad):
@@ -42,9 +44,10 @@ class _HIPLinearSwishTensor(Tensor):
             grad_X = X.xp.empty_like(X.data, dtype=np.float32) if X.requires_grad else None
             grad_weight = _grad_out(weight, weight.data)
             grad_bias = _grad_out(bias, bias.data) if bias is not None else None
-            if getattr(self, "_grad_is_dz", False):
+            me = self_ref()
+            if getattr(me, "_grad_is_dz", False):
                 # the consumer (a HIPLinear) already applied swish'(z) in its dX epilogue: grad IS dz (linear.py)
-                self._grad_is_dz = False
+                me._grad_is_dz = False
                 hip_linear_module_backward(X.data, weight.data, grad, grad_X, grad_weight, grad_bias, in_rows_num,
                                            in_features, out_features)
             else:

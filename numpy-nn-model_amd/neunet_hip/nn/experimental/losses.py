@@ -9,6 +9,7 @@ path, all on the side of the CPU semantics (neunet/nn/losses.py:59-126):
     forward never synchronises the host (the reference calls `.item()`, cross_entropy.py:72);
   * the 'mean' / 'sum' reduction also runs on the device (nnhipReduceLoss).
 """
+import weakref
 from ...autograd import Tensor
 from ..modules import Module
 from .utils import call_hip_function, contiguous, get_current_stream_ptr
@@ -17,9 +18,12 @@ _RED = {"none": b"n", "mean": b"m", "sum": b"s"}
 
 
 def cross_entropy_forward_backward(logits, labels, reduction: str = "none", ignore_index: int = -100,
-                                   inplace: bool = False):
-    """cross_entropy.py:35-103.  logits (rows, C) f32 device array, labels (rows,) int32 device array.
-    Returns (loss, grad_logits): loss is a 0-d device array for 'mean'/'sum', (rows,) for 'none'."""
+                                   inplace: bool = False, weight=None):
+    """cross_entropy.py:35-103.  logits (rows, C) f32 device array, labels (rows,) int16/int32/int64 device array
+    (the reference's CUDA path takes int32 only, cross_entropy.py:57; its CPU path all three, losses.py:100),
+    weight: optional (C,) f32 device array of class weights (losses.py:93-118).
+    Returns (loss, grad_logits): loss is a 0-d device array for 'mean'/'sum', (rows,) for 'none'.
+    One launch whatever the reduction (nnhipCrossEntropyLossEx)."""
     import torch
     if logits.ndim != 2:
         raise ValueError("Logits must be 2D tensor")
@@ -27,47 +31,47 @@ def cross_entropy_forward_backward(logits, labels, reduction: str = "none", igno
         raise ValueError("Labels must be 1D tensor")
     if labels.shape[0] != logits.shape[0]:
         raise ValueError("Logits and labels must have the same number of samples")
-    if labels.dtype != torch.int32:
-        raise TypeError("Labels must be of int32 dtype")
+    if labels.dtype not in _LABEL_BYTES():
+        raise TypeError("Labels must be of int16, int32 or int64 dtype")
     if logits.dtype != torch.float32:
         raise TypeError("Logits must be of float32 dtype")
     if reduction not in _RED:
         raise ValueError("Reduction must be 'none', 'mean', or 'sum'")
     rows, vocab = logits.shape
+    if weight is not None:
+        if tuple(weight.shape) != (vocab,):
+            raise ValueError("Weight shape must be equal to number of classes")
+        if weight.dtype != torch.float32:
+            raise TypeError("Weight must be of float32 dtype")
+        weight = contiguous(weight)
     logits, labels = contiguous(logits), contiguous(labels)
     loss_rows = torch.empty(rows, dtype=torch.float32, device=logits.device)
     lse = torch.empty(rows, dtype=torch.float32, device=logits.device)
     grad_logits = logits if inplace else torch.empty_like(logits)
-    stream = get_current_stream_ptr()
-    if reduction != "none":     # one call: count + rows + reduction (a single launch for small problems)
+    loss = count = None
+    if reduction != "none":
         loss = torch.empty((), dtype=torch.float32, device=logits.device)
         count = torch.empty(1, dtype=torch.int32, device=logits.device) if reduction == "mean" else None
-        call_hip_function("nnhipCrossEntropyLoss", logits, None if inplace else grad_logits, loss_rows, lse, labels,
-                          logits.stride(0), int(ignore_index), rows, vocab, _RED[reduction], loss, count, stream)
-        return loss, grad_logits
-    count = None
-    if reduction == "mean":
-        count = torch.empty(1, dtype=torch.int32, device=logits.device)
-        call_hip_function("nnhipCountNotEqual", labels, rows, int(ignore_index), count, stream)
-    call_hip_function("nnhipCrossEntropyForwardBackward", logits, loss_rows, lse, labels, logits.stride(0),
-                      int(ignore_index), rows, vocab, _RED[reduction], -1, count,
-                      None if inplace else grad_logits, stream)
-    if reduction == "none":
-        return loss_rows, grad_logits
-    loss = torch.empty((), dtype=torch.float32, device=logits.device)
-    call_hip_function("nnhipReduceLoss", loss_rows, rows, _RED[reduction], count, loss, stream)
-    return loss, grad_logits
+    call_hip_function("nnhipCrossEntropyLossEx", logits, None if inplace else grad_logits, loss_rows, lse, labels,
+                      _LABEL_BYTES()[labels.dtype], weight, logits.stride(0), int(ignore_index), rows, vocab,
+                      _RED[reduction], loss, count, get_current_stream_ptr())
+    return (loss_rows if reduction == "none" else loss), grad_logits
+
+
+def _LABEL_BYTES():
+    import torch
+    return {torch.int16: 2, torch.int32: 4, torch.int64: 8}
 
 
 class _HIPCrossEntropyTensor(Tensor):
     def __init__(self, data, args, op, device):
         super().__init__(data, args, op, device=device, _nocopy=True)
-        out = self
+        out_ref = weakref.ref(self)   # no tensor -> grad_fn -> closure -> tensor cycle: activations die by refcount
 
         def grad_fn(y_pred: Tensor, grad_y_pred, grad):
             # cross_entropy.py:111-114: y_pred.apply_grad(grad_y_pred * grad).  When backward() was
             # seeded with ones on this very tensor the product is the identity: skip a full pass.
-            if getattr(out, "_seeded_with_ones", False):
+            if getattr(out_ref(), "_seeded_with_ones", False):
                 y_pred.apply_grad(grad_y_pred)
                 return
             if grad.ndim == 1:
@@ -78,11 +82,18 @@ class _HIPCrossEntropyTensor(Tensor):
 
 
 class HIPCrossEntropyLoss(Module):
-    def __init__(self, reduction="none", ignore_index=-100, inplace=False):
+    def __init__(self, reduction="none", ignore_index=-100, inplace=False, weight=None):
+        """weight (extension over CUDACrossEntropyLoss; neunet.nn.CrossEntropyLoss has it, losses.py:60-64): per-class
+        weights as a Tensor / array of shape (C,)."""
         super().__init__()
         self.reduction = reduction
         self.ignore_index = ignore_index
         self.inplace = inplace
+        self.weight = None
+        if weight is not None:
+            import numpy as np
+            w = weight.data if isinstance(weight, Tensor) else weight
+            self.weight = Tensor(w, dtype=np.float32, requires_grad=False, device="cuda").data
 
     def forward(self, y_pred: Tensor, y_true: Tensor) -> Tensor:
         if not isinstance(y_pred, Tensor) or not isinstance(y_true, Tensor):
@@ -91,10 +102,11 @@ class HIPCrossEntropyLoss(Module):
             raise ValueError("Tensors must be on the cuda (HIP) device")
         if y_pred.dtype != "float32":
             raise TypeError("Predictions must be of float32 dtype")
-        if y_true.dtype != "int32":
-            raise TypeError("Target must be of int32 dtype")
+        if y_true.dtype not in ("int16", "int32", "int64"):
+            raise TypeError("Target must be of int dtype")
         loss, grad_y_pred = cross_entropy_forward_backward(y_pred.data, y_true.data, reduction=self.reduction,
-                                                           ignore_index=self.ignore_index, inplace=self.inplace)
+                                                           ignore_index=self.ignore_index, inplace=self.inplace,
+                                                           weight=self.weight)
         return _HIPCrossEntropyTensor(loss, (y_pred, grad_y_pred), "cross_entropy", device="cuda")
 
 

@@ -1,6 +1,7 @@
 """The remaining modules of the conv-classifier step (examples/convolutional_digits_classifier.ipynb
 cell 2): HIPLeakyReLU, HIPSigmoid, HIPMaxPool2d, HIPBatchNorm2d, HIPMSELoss -- same constructor arguments,
 `args` layout and gradient formulas as the reference classes they stand in for."""
+import weakref
 import ctypes
 from typing import Union
 
@@ -185,10 +186,10 @@ class HIPBatchNorm2d(Module):
 class _HIPMSETensor(Tensor):
     def __init__(self, data, args, op, device):
         super().__init__(data, args, op, device=device, _nocopy=True)
-        out = self
+        out_ref = weakref.ref(self)   # no tensor -> grad_fn -> closure -> tensor cycle: activations die by refcount
 
         def grad_fn(y_pred: Tensor, grad_pred, grad):
-            if getattr(out, "_seeded_with_ones", False):
+            if getattr(out_ref(), "_seeded_with_ones", False):
                 y_pred.apply_grad(grad_pred)
             else:
                 y_pred.apply_grad(grad_pred * grad)

@@ -65,7 +65,10 @@ class HIPFusedMultiTensorAdamW:
         _check_params(self.params)
         self.m = [torch.zeros_like(p.data) for p in self.params]
         self.v = [torch.zeros_like(p.data) for p in self.params]
-        self.device_step = False      # True: the step counter lives on the device (hipGraph replay)
+        self.device_step = False      # True: step count, lr, weight_decay, grad_scale live on the device (hipGraph replay)
+        self._dev_hyper = None        # (lr, weight_decay, grad_scale) last written to the device state
+        self.grad_divisor = None      # device float tensor (1 element): gradients are divided by it inside the kernel
+        self._bound_divisor = None
         self.opt_ptr = load_hip_function("nnhipCreateFusedOptimizer")()
         if not self.opt_ptr:
             raise RuntimeError("nnhipCreateFusedOptimizer failed")
@@ -88,10 +91,15 @@ class HIPFusedMultiTensorAdamW:
     def step(self):
         self.t += 1
         idx = 0
+        keep = []        # contiguous copies of strided gradients must outlive the single launch below: a freed block
+        #                  could be handed to the next .contiguous() and two table entries would alias one buffer
         for i, p in enumerate(self.params):
             if p.grad is None:  # fused_adamw_multitensor.py:92-96: skip params without a gradient
                 continue
-            g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+            g = p.grad
+            if not g.is_contiguous():
+                g = g.contiguous()
+                keep.append(g)
             if not p.data.is_contiguous():
                 p.data = p.data.contiguous()
             self.c_params[idx] = p.data.data_ptr()
@@ -102,6 +110,12 @@ class HIPFusedMultiTensorAdamW:
             idx += 1
         if idx == 0:
             return
+        div = self.grad_divisor
+        if div is not self._bound_divisor:
+            call_hip_function("nnhipFusedOptimizerSetGradDivisor", self.opt_ptr, div)
+            self._bound_divisor = div
+        if self.device_step:
+            self.sync_device_hyper()
         call_hip_function("nnhipFusedAdamWMultiTensorStep", self.opt_ptr, idx,
                           ctypes.cast(self.c_params, ctypes.POINTER(c_void_p)),
                           ctypes.cast(self.c_grads, ctypes.POINTER(c_void_p)),
@@ -113,11 +127,23 @@ class HIPFusedMultiTensorAdamW:
                           get_current_stream_ptr())
 
     def use_device_step(self, enable: bool = True):
-        """Move the step counter to device memory (needed before capturing step() into a hipGraph: the host
-        value of `t` would be frozen into the captured kernel arguments)."""
+        """Move the step counter AND lr / weight_decay / grad_scale to device memory (needed before capturing step()
+        into a hipGraph: host values would be frozen into the captured kernel arguments).  While enabled, assign
+        `opt.lr`, `opt.weight_decay`, `opt.grad_scale` as usual: `sync_device_hyper()` (called by step() and by
+        GraphedTrainStep before every replay) writes changed values to the device with one tiny stream-ordered launch."""
         if enable:
             call_hip_function("nnhipFusedOptimizerSetStep", self.opt_ptr, self.t, get_current_stream_ptr())
-        self.device_step = enable
+            self._dev_hyper = None
+            self.device_step = True
+            self.sync_device_hyper()
+        else:
+            self.device_step = False
+
+    def sync_device_hyper(self):
+        cur = (float(self.lr), float(self.weight_decay), float(self.grad_scale))
+        if self.device_step and cur != self._dev_hyper:
+            call_hip_function("nnhipFusedOptimizerSetHyper", self.opt_ptr, cur[0], cur[1], cur[2], get_current_stream_ptr())
+            self._dev_hyper = cur
 
     def zero_grad(self):
         for p in self.params:

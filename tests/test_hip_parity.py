@@ -347,6 +347,35 @@ def test_swish_vs_oracle(hip, shape):
     np.testing.assert_allclose(host(x.grad), O.swish_backward(X, dY, 1.5), rtol=1e-5, atol=1e-5)
 
 
+def test_swish_fast_sigmoid_accuracy_sweep(hip):
+    """Swish / SwiGLU use the hardware exp2 + rcp (1 ulp each) instead of libm expf + IEEE divide.  Sweep the whole
+    finite range of the sigmoid argument, [-88, 88], densely: the result stays within 1e-6 absolute + 1 ulp of the
+    float64 evaluation of the oracle's formula: forward within 1e-6 absolute + 2 ulp (rcp 1 ulp, 1+e and the final
+    product half an ulp each; at |x| = 88 one ulp of the output is 7.6e-6, so a pure absolute bound cannot hold there),
+    backward within 1e-6 + 4 ulp."""
+    from neunet_hip.nn.experimental import HIPFusedSwishAndMul, HIPSwish
+    X = np.linspace(-88.0, 88.0, 1 << 20, dtype=np.float32).reshape(1024, 1024)
+    dY = np.ones_like(X)
+    for beta in (1.0, 1.5, 0.5):
+        Xb = (X / np.float32(max(beta, 1.0))).astype(np.float32)
+        x = T(hip, Xb)
+        y = HIPSwish(beta)(x)
+        ref = O.swish_forward(Xb.astype(np.float64), beta)
+        err = np.abs(host(y.data).astype(np.float64) - ref)
+        assert np.all(err <= 1e-6 + 2 * np.spacing(np.abs(ref).astype(np.float32))), float(err.max())
+        y.backward(dY)
+        refg = O.swish_backward(Xb.astype(np.float64), dY.astype(np.float64), beta)
+        errg = np.abs(host(x.grad).astype(np.float64) - refg)
+        assert np.all(errg <= 1e-6 + 4 * np.spacing(np.abs(refg).astype(np.float32))), float(errg.max())
+    # the same sigmoid inside the SwiGLU gate: gate = sweep, up = 1
+    G = np.concatenate([X[:, :512], np.ones((1024, 512), np.float32)], axis=1)
+    g = T(hip, np.ascontiguousarray(G))
+    out = HIPFusedSwishAndMul(1.0)(g)
+    ref = O.swish_forward(X[:, :512].astype(np.float64), 1.0)
+    err = np.abs(host(out.data).astype(np.float64) - ref)
+    assert np.all(err <= 1e-6 + 2 * np.spacing(np.abs(ref).astype(np.float32))), float(err.max())
+
+
 @pytest.mark.parametrize("name", ["swiglu_2d", "swiglu_3d"])
 def test_swiglu_golden(hip, golden, name):
     g = golden(name)
@@ -431,7 +460,9 @@ def test_rmsnorm_golden(hip, golden, name):
 
 @pytest.mark.parametrize("shape,bias", [((32, 128), False), ((16, 256), False),   # tests/test_rmsnorm_cuda.py
                                         ((4, 64, 512), True), ((2100, 4096), True), ((9, 8192), False),
-                                        ((5, 12000), True), ((7, 130), True), ((3, 6), False)])
+                                        ((5, 12000), True), ((7, 130), True), ((3, 6), False),
+                                        ((16384, 512), False), ((4099, 512), True), ((37, 1000), True),   # C4 norm shape; ragged
+                                        ((6, 20000), True), ((3, 16388), False), ((70, 16385), True)])   # looped (> 16384 cols)
 def test_rmsnorm_vs_oracle(hip, shape, bias):
     from neunet_hip.nn.experimental import HIPRMSNorm
     rng = np.random.default_rng(42)
@@ -489,6 +520,104 @@ def test_cross_entropy_vs_oracle(hip, rows, C, reduction):
     loss.backward()
     np.testing.assert_allclose(host(x.grad), dl, rtol=1e-4, atol=1e-6)
     assert np.all(host(x.grad)[labels == 0] == 0)
+
+
+@pytest.mark.parametrize("rows,C", [(32, 10), (200, 128), (64, 5000), (9, 15000), (3, 20001)])
+@pytest.mark.parametrize("reduction", ["none", "mean", "sum"])
+@pytest.mark.parametrize("ldtype", [np.int16, np.int32, np.int64])
+def test_cross_entropy_class_weights_and_label_dtypes(hip, rows, C, reduction, ldtype):
+    """neunet.nn.CrossEntropyLoss(weight=...) (losses.py:93-118: loss_i = -logp[y_i] w[y_i]; 'mean' divides by
+    sum_i w[y_i] over the non-ignored rows) and the three label dtypes NLLLoss accepts (losses.py:100)."""
+    import neunet_hip.nn as nn
+    if np.iinfo(ldtype).max < C:
+        pytest.skip("labels do not fit the dtype")
+    rng = np.random.default_rng(7 + rows + C)
+    logits = (rng.standard_normal((rows, C)) * 3).astype(np.float32)
+    labels = rng.integers(1, C, rows).astype(ldtype)
+    labels[::4] = 0
+    w = rng.uniform(0.25, 2.0, C).astype(np.float32)
+    for weight in (None, w):
+        x = T(hip, logits)
+        loss = nn.CrossEntropyLoss(weight=None if weight is None else hip.Tensor(weight), ignore_index=0,
+                                   reduction=reduction)(x, T(hip, labels, dtype=ldtype, requires_grad=False))
+        lr, dl = O.cross_entropy_forward_backward(logits, labels, weight, 0, reduction)
+        np.testing.assert_allclose(host(loss.data), lr, rtol=1e-5, atol=1e-5)
+        loss.backward()
+        np.testing.assert_allclose(host(x.grad), dl, rtol=1e-4, atol=1e-6)
+        assert np.all(host(x.grad)[labels == 0] == 0)
+
+
+@pytest.mark.parametrize("inplace", [False, True])
+@pytest.mark.parametrize("rows,C", [(16, 10), (300, 2000)])      # single-block kernel / persistent kernel
+def test_cross_entropy_out_of_range_label_is_inert(hip, rows, C, inplace):
+    """A label outside [0, C) that is not ignore_index (the reference would raise / Python-wrap it, losses.py:104 TODO):
+    zero loss and zero gradient for that row, identically in the small and the large kernel (round-1 ADVICE: the small
+    kernel read x[y] out of bounds)."""
+    from neunet_hip.nn.experimental import HIPCrossEntropyLoss
+    rng = np.random.default_rng(5)
+    logits = (rng.standard_normal((rows, C)) * 2).astype(np.float32)
+    labels = rng.integers(0, C, rows).astype(np.int32)
+    bad = np.array([1, 5, rows - 1])
+    labels[bad] = [-1, C, C + 7]
+    labels[3] = -100
+    good = np.ones(rows, bool)
+    good[bad] = False
+    good[3] = False
+    for reduction in ("sum", "mean"):
+        x = T(hip, logits)
+        loss = HIPCrossEntropyLoss(reduction=reduction, ignore_index=-100, inplace=inplace)(
+            x, T(hip, labels, dtype=np.int32, requires_grad=False))
+        loss.backward()
+        g = host(x.grad)
+        assert np.all(g[~good] == 0)
+        lr, dl = O.cross_entropy_forward_backward(logits[good], labels[good], None, -100, "sum")
+        denom = (rows - 1) if reduction == "mean" else 1       # out-of-range labels still count in the 'mean' denominator
+        np.testing.assert_allclose(loss.item(), float(lr) / denom, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(g[good], dl / denom, rtol=1e-4, atol=1e-6)
+
+
+def test_cross_entropy_tall_narrow_takes_the_two_launch_path(hip):
+    """rows so many that a per-block label count would not be free (rows x blocks x 4 B > 64 MB): the denominator comes
+    from its own small launch; results identical in kind."""
+    from neunet_hip.nn.experimental import HIPCrossEntropyLoss
+    rng = np.random.default_rng(11)
+    rows, C = 300000, 1100
+    logits = rng.standard_normal((rows, C)).astype(np.float32)
+    labels = rng.integers(0, C, rows).astype(np.int32)
+    labels[::7] = -100
+    x = T(hip, logits)
+    loss = HIPCrossEntropyLoss(reduction="mean")(x, T(hip, labels, dtype=np.int32, requires_grad=False))
+    loss.backward()
+    sel = rng.choice(rows, 64, replace=False)
+    cnt = int((labels != -100).sum())
+    lr, dl = O.cross_entropy_forward_backward(logits[sel], labels[sel], None, -100, "sum")
+    np.testing.assert_allclose(host(x.grad[torch.from_numpy(sel).cuda()]), dl / cnt, rtol=1e-4, atol=1e-9)
+    lse = np.log(np.exp(logits.astype(np.float64)).sum(1))
+    ref = float(np.sum((lse - logits[np.arange(rows), np.maximum(labels, 0)])[labels != -100]) / cnt)
+    assert abs(loss.item() - ref) < 1e-4
+
+
+def test_masked_softmax_wide_rows_looped(hip):
+    """nnhipMaskedSoftmaxForward/Backward for Tk > 16384 (round 1 returned EINVAL): looped kernels, same formulas."""
+    from neunet_hip._lib import call_hip_function, get_current_stream_ptr
+    rng = np.random.default_rng(3)
+    B, H, Tq, Tk = 2, 1, 3, 16500
+    S = rng.standard_normal((B, H, Tq, Tk)).astype(np.float32)
+    dY = rng.standard_normal((B, H, Tq, Tk)).astype(np.float32)
+    kv = np.ones((B, Tk), np.int32)
+    kv[1, -500:] = 0
+    scale = 0.125
+    s_d, dy_d, kv_d = dev(S), dev(dY), dev(kv)
+    y_d, dx_d = torch.empty_like(s_d), torch.empty_like(s_d)
+    call_hip_function("nnhipMaskedSoftmaxForward", y_d, s_d, kv_d, B, H, Tq, Tk, scale, 1, get_current_stream_ptr())
+    call_hip_function("nnhipMaskedSoftmaxBackward", dx_d, dy_d, y_d, kv_d, B, H, Tq, Tk, scale, 1, get_current_stream_ptr())
+    j, i = np.arange(Tk)[None, :], np.arange(Tq)[:, None]
+    masked = (j > i + Tk - Tq)[None, None] | (kv == 0)[:, None, None, :]
+    z = np.where(masked, np.float32(-1e9), S * np.float32(scale))
+    yr = O.softmax_forward(z.astype(np.float32), -1)
+    np.testing.assert_allclose(host(y_d), yr, rtol=1e-5, atol=1e-7)
+    dz = O.softmax_backward(yr, dY, -1)
+    np.testing.assert_allclose(host(dx_d), np.where(masked, 0, dz * scale), rtol=1e-4, atol=1e-7)
 
 
 # ------------------------------------------------------------------------------------------- Conv2d
