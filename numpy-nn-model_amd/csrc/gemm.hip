@@ -220,7 +220,10 @@ __global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const 
     // prologue / epilogue of a grid that is a single generation of tiles (all of GPT-tiny's forward GEMMs).  Raising the
     // priority of every other dispatch round (blocks are dealt out one per CU per round of 256) lets the favoured
     // block take the matrix pipe first and finish early; its epilogue then overlaps the partner's K loop.
-    if (p.skew) __builtin_amdgcn_s_setprio(((blockIdx.x >> 8) & 1) ? 0 : 2);
+    if (p.skew) {
+        if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_setprio(0);
+        else __builtin_amdgcn_s_setprio(2);
+    }
 
     // ---- block id -> (split, tile_m, tile_n): XCD-aware grouped order --------------------------
     const int nwg = gridDim.x;
