@@ -1,18 +1,24 @@
 #!/usr/bin/env python3
 """bench.py -- training-step throughput of the neunet dense hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload c2|c1|c3]
+    python bench.py --gpus N --steps K --warmup W [--workload headline|c1|c2|c3|c4|c5]
 
-Default workload = BASELINE.json configs[1] ("C2"): one data-parallel training step of a single
-Linear(4096->4096) layer on a batch of 4096 rows per GPU (weak scaling):
-    zero_grad -> forward (MFMA GEMM + bias) -> backward (dX, dW GEMMs + db) ->
-    flat-bucket gradient all-reduce (RCCL; no-op at N=1) -> fused AdamW (grad_scale = 1/N).
-Inputs (X, dO, weights) are resident in HBM before the timed region.  One JSON line on rank 0.
+BASELINE.json's metric: "samples/sec training step (MNIST-MLP & GPT-tiny) at 1/2/4/8 GPUs; Linear fwd GFLOP/s vs
+MFMA peak".  The default workload ("headline") therefore measures, in ONE process per GPU and ONE JSON line:
+  * value / ms_per_step : the C4 GPT-tiny training step (d512 L6 H8 d_ff2048 vocab15000, batch 64 x seq 256 per GPU,
+                          weak scaling): the W warm-up + exactly K timed steps of the contract;
+  * roofline            : the C2 Linear(4096->4096) forward GEMM, batch 4096 -- the metric's "Linear fwd vs MFMA peak"
+                          half: HIP-event timed launches of the same gemm_f32_kernel that does 86 % of the C4 step;
+  * also.c1             : MNIST-MLP (784->128->10, batch 32 per GPU) training-step samples/s, sustained over 500 steps;
+  * also.c2             : the whole C2 training step (fwd + bwd + AdamW) and a sustained (>= 2 s) forward figure;
+  * also.c4_gemm        : GEMM-equivalent TFLOP/s of the whole C4 step;
+  * cpu_baseline        : the NumPy oracle's FULL GPT-tiny step (forward, backward, Adam) on a stated fraction of the batch.
+`--workload c1..c5` runs one BASELINE config on its own with the per-config detail (C3: per-op HBM fractions).
 
-`roofline`   : dominant kernel = the fp32 MFMA GEMM (forward variant), HIP-event timed inside the timed
-               region on the launch stream; peak = 157.3 TFLOP/s fp32 MFMA (MI355X_MICROARCH.md).
-`cpu_baseline`: the NumPy oracle (the reference's CPU algorithm, kind "port") timed on this box's host
-               cores on the same workload, bounded to ~15 s.
+`--gpus N` with no torchrun environment re-executes itself under torch.distributed.run with N ranks (one per GPU,
+backend nccl = RCCL); under torchrun (the driver's launch) it reads RANK / LOCAL_RANK / WORLD_SIZE.  `rccl_ranks` in
+the JSON is dist.get_world_size() after a real all-reduce.
+Inputs and weights are resident in HBM before any timed region.  One JSON line on rank 0.
 """
 import argparse
 import json
@@ -36,7 +42,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="c2", choices=["c1", "c2", "c3", "c4", "c5"])
+    ap.add_argument("--workload", default="headline", choices=["headline", "c1", "c2", "c3", "c4", "c5"])
+    ap.add_argument("--c1-steps", type=int, default=500, help="headline: sustained MNIST-MLP steps")
+    ap.add_argument("--overlap", type=int, default=1, help="N>1: overlap the gradient exchange with the backward pass")
     ap.add_argument("--c4-batch", type=int, default=64, help="sequences per GPU for the GPT-tiny workload")
     ap.add_argument("--graph", type=int, default=1, help="c1/c4: replay the step as a captured hipGraph (1) or launch eagerly (0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -416,13 +424,20 @@ def c4_batch(rng, B, T, vocab):
 def workload_c4(args, rank, world):
     """BASELINE C4: GPT-tiny (d_model 512, 6 layers, 8 heads, d_ff 2048, vocab 15000) training step on
     batch 64 x seq 256 per GPU: embedding -> 6 x [RMSNorm, attention, RMSNorm, FFN] -> vocab projection ->
-    CrossEntropy(ignore PAD) -> backward -> flat-bucket all-reduce -> fused Adam (lr 1.5e-4, betas .9/.98, eps 1e-9)."""
+    CrossEntropy(ignore PAD) -> backward -> gradient exchange -> fused Adam (lr 1.5e-4, betas .9/.98, eps 1e-9).
+    N > 1: every rank back-propagates the SUM loss; the count of non-PAD targets is written by a kernel into the extra
+    slot of the gradient bucket, all-reduced with the gradients, and the optimizer divides by it on load
+    (grad_divisor) -- the global mean without a host read or a scale pass.  The bucket is cut into segments whose
+    all-reduces (RCCL, own stream) overlap the rest of the backward pass; under hipGraph replay the backward pass is
+    one graph per segment."""
     import torch
     sys.path.insert(0, os.path.join(ROOT, "examples"))
     import gpt_tiny
     import neunet_hip
     import neunet_hip.nn as nn
+    from neunet_hip._lib import call_hip_function, get_current_stream_ptr
     from neunet_hip.distributed import GradBucket
+    from neunet_hip.graph import GraphedTrainStep
     from neunet_hip.optim import Adam
     B, T = args.c4_batch, C4["seq"]
     np.random.seed(1004)                                          # identical init on every rank
@@ -434,16 +449,18 @@ def workload_c4(args, rank, world):
     ids = neunet_hip.Tensor(np.ascontiguousarray(batch[:, :-1]), dtype=np.int32, requires_grad=False, device="cuda")
     tgt_host = np.ascontiguousarray(batch[:, 1:]).reshape(-1)
     tgt = neunet_hip.Tensor(tgt_host, dtype=np.int32, requires_grad=False, device="cuda")
-    local_count = float((tgt_host != 0).sum())
     loss_fn = nn.CrossEntropyLoss(ignore_index=0, reduction="mean" if world == 1 else "sum")
     ev = EventTimer()
-    from neunet_hip._lib import call_hip_function, get_current_stream_ptr
-    from neunet_hip.graph import GraphedTrainStep
+    state = {"bucket": None}
 
     def fwd_bwd():
         out, _ = model.forward(ids)
         out = out.reshape(out.shape[0] * out.shape[1], out.shape[2])
         loss = loss_fn(out, tgt)
+        bk = state["bucket"]
+        if world > 1 and bk is not None:    # this rank's non-PAD count -> the bucket's extra slot (device side)
+            call_hip_function("nnhipCrossEntropyDenominator", tgt.data, 4, tgt.data.numel(), 0, None, C4["vocab"], None,
+                              bk.extra, get_current_stream_ptr())
         loss.backward()
         return loss
 
@@ -451,21 +468,19 @@ def workload_c4(args, rank, world):
     fwd_bwd()
     active = [p for p in params if p.grad is not None]
     opt.zero_grad()
-    bucket = GradBucket(active, extra_scalars=1)
-
-    def pre_optim():          # world > 1: grads are SUMs of per-rank 'sum' losses -> divide by the global count
-        total = float(bucket.extra[0].item())
-        call_hip_function("nnhipScale", bucket.flat, 1.0 / total, bucket.flat.numel(), get_current_stream_ptr())
+    overlap = world > 1 and bool(args.overlap) and os.environ.get("NNHIP_DP_OVERLAP", "1") != "0"
+    bucket = GradBucket(active, extra_scalars=1, overlap=overlap)
+    state["bucket"] = bucket
+    if world > 1:
+        opt.grad_divisor = bucket.extra              # g / (all-reduced non-PAD count), inside the Adam kernel
 
     if args.graph:
-        bucket.extra[0] = local_count
-        gstep = GraphedTrainStep(fwd_bwd, opt, bucket, warmup=2, world=world, pre_optim=pre_optim if world > 1 else None)
+        gstep = GraphedTrainStep(fwd_bwd, opt, bucket, warmup=2, world=world)
 
         def step(timed):
             if timed:
                 a, b = ev.span()
                 a.record()
-            bucket.extra[0] = local_count          # (re)written every step: the all-reduce sums it in place
             gstep()
             if timed:
                 b.record()
@@ -476,10 +491,7 @@ def workload_c4(args, rank, world):
                 a.record()
             opt.zero_grad()
             fwd_bwd()
-            bucket.extra[0] = local_count
             bucket.all_reduce()
-            if world > 1:
-                pre_optim()
             opt.step()
             if timed:
                 b.record()
@@ -488,7 +500,8 @@ def workload_c4(args, rank, world):
     dev_ms = ev.mean_ms()
     fl = c4_flops(B, T)
     ach = fl / (dev_ms * 1e-3) / 1e12
-    n_grad = sum(int(np.prod(p.shape)) for p in params if True)
+    n_grad = sum(int(np.prod(p.shape)) for p in active)
+    pieces = len(getattr(gstep, "pieces", [])) if args.graph else 0
     return {
         "samples_per_step": B * world, "dt": dt,
         "config": {"workload": f"C4: GPT-tiny d512 L6 H8 d_ff2048 vocab15000 training step, batch {B} x seq {T} per GPU, "
@@ -498,12 +511,17 @@ def workload_c4(args, rank, world):
                      "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "flops_per_step": fl,
                      "avg_step_device_ms": round(dev_ms, 4)},
-        "extra": {"tokens_per_s": round(B * world * T * args.steps / dt, 1), "param_floats": n_grad},
+        "extra": {"tokens_per_s": round(B * world * T * args.steps / dt, 1), "grad_floats": n_grad,
+                  "dp_exchange": ("none" if world == 1 else
+                                  (f"{len(bucket.segments)} bucket segments, async all-reduce overlapped with backward"
+                                   + (f" ({pieces} graph pieces)" if args.graph else "") if overlap
+                                   else "one blocking all-reduce of the flat bucket"))},
     }
 
 
 def cpu_c4(seconds):
-    """One GPT-tiny step of the NumPy oracle on a bounded sample: 2 sequences x 256 tokens (1/32 of the GPU batch)."""
+    """FULL GPT-tiny training step (forward, backward, Adam on every parameter that has a gradient) of the NumPy oracle on
+    a bounded sample of the workload: 2 sequences x 256 tokens = 1/32 of one GPU's batch."""
     from oracle import neunet_oracle as O
     c = C4
     rng = np.random.default_rng(1004)
@@ -515,12 +533,36 @@ def cpu_c4(seconds):
     model = O.GPTTiny(rng.standard_normal((V, D)).astype(np.float32), layers, u(V, D), u(1, V), c["n_heads"], 0, 1024)
     Bs = 2
     batch = c4_batch(rng, Bs, c["seq"], V)
-    t0 = time.perf_counter()
-    model.forward_backward(batch[:, :-1], batch[:, 1:])
-    dt = time.perf_counter() - t0
-    return {"value": round(Bs / dt, 3), "unit": "samples/s", "cores": blas_threads(), "kind": "port",
-            "sample": f"1 forward+backward of the NumPy-oracle GPT-tiny on {Bs} sequences x {c['seq']} tokens "
-                      f"(optimizer step excluded): {dt:.2f} s"}
+
+    def flat_params(m):
+        ps = [m.emb]
+        for Ly in m.layers:
+            ps += Ly["attn"] + Ly["ffn"] + [Ly["norm1"], Ly["norm2"]]
+        return ps + [m.Wout, m.bout]
+
+    def flat_grads(g):
+        gs = [g["emb"]]
+        for Ly in g["layers"]:
+            gs += Ly["attn"] + Ly["ffn"] + [Ly["norm1"], Ly["norm2"]]
+        return gs + [g["Wout"], g["bout"]]
+
+    ps = flat_params(model)
+    ms, vs = [np.zeros_like(p) for p in ps], [np.zeros_like(p) for p in ps]
+    times = []
+    t_all = time.perf_counter()
+    for step in range(1, 4):
+        t0 = time.perf_counter()
+        _, _, grads = model.forward_backward(batch[:, :-1], batch[:, 1:])
+        for i, (p_, g_) in enumerate(zip(ps, flat_grads(grads))):
+            ms[i], vs[i] = O.adam_step(p_, g_.reshape(p_.shape), ms[i], vs[i], step, 1.5e-4, (0.9, 0.98), 1e-9, 0.0)
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_all > max(seconds, 10.0):
+            break
+    best = min(times)
+    return {"value": round(Bs / best, 3), "unit": "samples/s", "cores": blas_threads(), "kind": "port",
+            "sample": f"{len(times)} FULL steps (forward + backward + Adam over all {sum(p.size for p in ps)} parameters) of the "
+                      f"NumPy-oracle GPT-tiny on {Bs} sequences x {c['seq']} tokens (1/32 of one GPU's batch), min step "
+                      f"{best:.2f} s, OpenBLAS threads={blas_threads()}, host cpus={os.cpu_count()}"}
 
 
 # ------------------------------------------------------------------------------------------------ C5

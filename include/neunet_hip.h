@@ -180,6 +180,14 @@ int nnhipCrossEntropyForwardBackward(float* logits, float* loss, float* lse, con
  * cp.sum(labels != ignore_index).item() of cross_entropy.py:72) */
 int nnhipCountNotEqual(const int32_t* labels, int64_t n, int32_t ignore_index, int32_t* out_count,
                        nnhipStream_t stream);
+/* The 'mean' denominator on its own (labels int16/32/64): count_out[0] = #{labels != ignore_index} (int) and/or
+ * denom_out[0] = that count -- or, with class weights, sum of class_weight[label] over those rows -- as a FLOAT.
+ * Data-parallel use: every rank back-propagates reduction 's', writes its local denominator into the extra slot of the
+ * gradient bucket with this call, and the all-reduced slot becomes the optimizer's gradient divisor
+ * (nnhipFusedOptimizerSetGradDivisor): the global mean without a host read. */
+int nnhipCrossEntropyDenominator(const void* labels, int32_t label_bytes, int64_t n, int64_t ignore_index,
+                                 const float* class_weight_or_null, int64_t n_cols, int32_t* count_out_or_null,
+                                 float* denom_out_or_null, nnhipStream_t stream);
 /* out[0] = sum(loss_rows) ('s'), or sum/count ('m', count from count_dev) -- the device-side
  * reduction cross_entropy.py:98-101 does with cupy. */
 int nnhipReduceLoss(const float* loss_rows, int64_t n_rows, char reduction,

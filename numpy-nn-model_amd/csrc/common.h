@@ -42,7 +42,7 @@ const float* zero_block();
 // Every kernel that uses a slot leaves it zeroed for the next launch.  Slots are per kernel family (the library's
 // workspace already makes it one-stream-at-a-time per process).
 constexpr int kSyncWords = 1024;
-enum SyncSlot { SYNC_CE = 0, SYNC_RMSNORM = 8, SYNC_COLSUM = 16, SYNC_MLP = 24 };
+enum SyncSlot { SYNC_CE = 0, SYNC_MLP = 24 };
 unsigned* sync_words();
 
 // ---- device helpers ----------------------------------------------------------------------------
@@ -99,45 +99,6 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 #pragma unroll
     for (int i = 1; i < NW; ++i) s = fmaxf(s, red[i]);
     return s;
-}
-
-// ---- in-launch hand-off between workgroups (cdna_hip_programming.md Guideline 16) -------------------------------
-// Producer side: every thread of the block has ISSUED its plain stores of the data to publish.  Drains them, one lane
-// does the agent-scope release (L2 write-back) and takes an arrival ticket.  Returns the ticket (0-based arrival index).
-__device__ __forceinline__ int grid_arrive(unsigned* ctr, int* sh) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the compiler may drop the fence's own wait (guide, pitfall 12)
-        *sh = (int)atomicAdd(ctr, 1u);
-    }
-    __syncthreads();
-    return *sh;
-}
-// Consumer side: wait until `n` blocks have arrived (relaxed polling by one lane, bounded), then ONE agent-scope acquire.
-// Only blocks that are among the LAST arrivals may call this (they wait for blocks that are already running, so the
-// wait cannot deadlock whatever the residency).  Returns false on timeout (never observed; a hang would cost the box).
-__device__ __forceinline__ bool grid_wait_all(unsigned* ctr, unsigned n, int* sh) {
-    if (threadIdx.x == 0) {
-        int ok = 0;
-        for (int spin = 0; spin < (1 << 22); ++spin) {
-            if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= n) { ok = 1; break; }
-            __builtin_amdgcn_s_sleep(2);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        *sh = ok;
-    }
-    __syncthreads();
-    return *sh != 0;
-}
-// The finishing blocks (the last `nfin` arrivals) call this when done; the last of them re-zeroes the slot.
-__device__ __forceinline__ void grid_finish_done(unsigned* sync, int nfin) {
-    __syncthreads();
-    if (threadIdx.x == 0 && atomicAdd(&sync[1], 1u) == (unsigned)(nfin - 1)) {
-        __hip_atomic_store(&sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
 }
 
 constexpr float kLog2e = 1.4426950408889634f;

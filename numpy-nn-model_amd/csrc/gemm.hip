@@ -221,7 +221,8 @@ __global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const 
     // priority of every other dispatch round (blocks are dealt out one per CU per round of 256) lets the favoured
     // block take the matrix pipe first and finish early; its epilogue then overlaps the partner's K loop.
     if (p.skew) {
-        if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_setprio(0);
+        const int sel = p.skew == 2 ? ((blockIdx.x >> 3) & 1) : ((blockIdx.x >> 8) & 1);
+        if (sel) __builtin_amdgcn_s_setprio(0);
         else __builtin_amdgcn_s_setprio(2);
     }
 

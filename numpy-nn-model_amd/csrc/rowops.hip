@@ -8,6 +8,7 @@
 // algorithmic traffic of SURVEY 8(d): 8 B/elem forward, 12 B/elem backward, 8 B/elem fused CE.
 // Rows wider than 16384 floats (or with a non-unit stride) take a looped fallback.
 #include <math.h>
+#include <stdlib.h>
 
 #include <mutex>
 #include <unordered_map>
@@ -282,82 +283,126 @@ __global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void rmsnorm_fwd_rows(
     r.store(Y + row * cols, cols, t);
 }
 
-// ---- in-launch column-sum finish ---------------------------------------------------------------------------------
-// part[prow][cols] (dense) -> out[cols], computed by the `nfin` finishing blocks of a launch: finisher f takes the
-// slices f, f+nfin, ...; a slice = 16 float4 columns (VEC) or 16 columns (scalar).  BS threads = 16 column-threads x
-// BS/16 row groups; group g sums partial rows g, g+G, ... (4 loads in flight), the groups meet in LDS in a fixed
-// order, so the result does not depend on which blocks finish.  `part` is read with plain loads AFTER the caller's
-// agent-scope acquire (grid_wait_all).
-constexpr int kFinSW = 16;
-template <int BS, bool VEC>
+// ---- column-sum of per-block partials ------------------------------------------------------------------------
+// part[prow][cols] (dense) -> out[cols].  Work unit = a SLICE of SW float4 columns (VEC) or SW columns (scalar) over ALL
+// partial rows: BS threads = SW column-threads x BS/SW row groups; a thread issues 16 row loads back to back (the
+// partials come out of other XCDs' L2 / HBM: one ~2 us round trip instead of a chain of them), sums them, and the
+// groups meet through wave shuffles + one LDS hop in a fixed order (deterministic).  Used two ways:
+// by colsum_tall_kernel, one block per slice: the one-launch finish of RMSNorm dw/db and of the two-stage column sum.
+template <int BS, int SW, bool VEC>
 __device__ __forceinline__ void colsum_slices(const float* part, int64_t prow, int64_t cols, float* out, int f,
                                               int nfin, float4* lds) {
-    constexpr int G = BS / kFinSW;
-    const int c = threadIdx.x % kFinSW, g = threadIdx.x / kFinSW;
-    const int64_t units = VEC ? (cols >> 2) : cols;           // float4s or floats per partial row
-    const int64_t nsl = (units + kFinSW - 1) / kFinSW;
+    static_assert(SW == 4 || SW == 8 || SW == 16, "slice width");
+    constexpr int G = BS / SW;                       // row groups
+    constexpr int GW = 64 / SW;                      // row groups inside one wave
+    constexpr int NWV = BS / 64;
+    const int c = threadIdx.x % SW, g = threadIdx.x / SW;
+    const int wave = threadIdx.x >> 6;
+    const int64_t units = VEC ? (cols >> 2) : cols;  // float4s or floats per partial row
+    const int64_t nsl = (units + SW - 1) / SW;
     for (int64_t s = f; s < nsl; s += nfin) {
-        const int64_t u = s * kFinSW + c;
+        const int64_t u = s * SW + c;
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
         if (u < units) {
-            if constexpr (VEC) {
-                const float4* p4 = reinterpret_cast<const float4*>(part);
-                int64_t r = g;
-                for (; r + 3 * G < prow; r += 4 * G) {
-                    const float4 v0 = p4[r * units + u], v1 = p4[(r + G) * units + u];
-                    const float4 v2 = p4[(r + 2 * G) * units + u], v3 = p4[(r + 3 * G) * units + u];
-                    a.x += (v0.x + v1.x) + (v2.x + v3.x); a.y += (v0.y + v1.y) + (v2.y + v3.y);
-                    a.z += (v0.z + v1.z) + (v2.z + v3.z); a.w += (v0.w + v1.w) + (v2.w + v3.w);
+            for (int64_t r0 = g; r0 < prow; r0 += 16 * G) {
+                if constexpr (VEC) {
+                    const float4* p4 = reinterpret_cast<const float4*>(part);
+                    float4 v[16];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const int64_t r = r0 + (int64_t)j * G;
+                        v[j] = r < prow ? p4[r * units + u] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) { a.x += v[j].x; a.y += v[j].y; a.z += v[j].z; a.w += v[j].w; }
+                } else {
+                    float v[16];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        const int64_t r = r0 + (int64_t)j * G;
+                        v[j] = r < prow ? part[r * units + u] : 0.f;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) a.x += v[j];
                 }
-                for (; r < prow; r += G) {
-                    const float4 v = p4[r * units + u];
-                    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
-                }
-            } else {
-                for (int64_t r = g; r < prow; r += G) a.x += part[r * units + u];
             }
         }
-        lds[threadIdx.x] = a;
-        __syncthreads();
-        if (g == 0 && u < units) {
-#pragma unroll 4
-            for (int i = 1; i < G; ++i) {
-                const float4 v = lds[i * kFinSW + c];
-                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        // row groups of one wave: lanes c, c+SW, c+2SW, ... hold the same column
+#pragma unroll
+        for (int o = SW; o < 64; o <<= 1) {
+            a.x += __shfl_xor(a.x, o, 64); a.y += __shfl_xor(a.y, o, 64);
+            a.z += __shfl_xor(a.z, o, 64); a.w += __shfl_xor(a.w, o, 64);
+        }
+        (void)GW;
+        if constexpr (NWV > 1) {
+            if ((threadIdx.x & 63) < SW) lds[wave * SW + c] = a;
+            __syncthreads();
+            if (threadIdx.x < SW) {
+                a = lds[c];
+#pragma unroll
+                for (int w = 1; w < NWV; ++w) {
+                    const float4 v = lds[w * SW + c];
+                    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+                }
             }
+        }
+        if (threadIdx.x < SW && u < units) {
             if constexpr (VEC) reinterpret_cast<float4*>(out)[u] = a;
             else out[u] = a.x;
         }
-        __syncthreads();
+        if constexpr (NWV > 1) __syncthreads();
     }
 }
-// how many finishing blocks a [*, cols] column-sum can use
+static inline int fin_sw(int64_t cols, bool vec) { return (vec ? (cols >> 2) : cols) >= 512 ? 8 : 4; }
+// how many slices a [*, cols] column-sum has (= blocks of colsum_tall_kernel; the in-launch variant caps its finishers)
 static inline int fin_slices(int64_t cols, bool vec) {
     const int64_t units = vec ? (cols >> 2) : cols;
-    int64_t n = (units + kFinSW - 1) / kFinSW;
-    if (n > 128) n = 128;   // spinning finishers must stay well below the resident-block capacity (>= 256)
+    const int sw = fin_sw(cols, vec);
+    const int64_t n = (units + sw - 1) / sw;
     return (int)(n < 1 ? 1 : n);
 }
 
-// Backward: block b walks rows b*RPB+rslot + k*gridDim.x*RPB, TWO rows per iteration (both rows' loads
-// are in flight together and their row reductions share one pair of barriers), keeps per-thread column
+// One launch: up to two partial arrays (dw and db) -> their column sums.  grid (slices, narrays), 256 threads.
+template <int SW, bool VEC>
+__global__ __launch_bounds__(256) void colsum_tall_kernel(const float* __restrict__ part_a, float* __restrict__ out_a,
+                                                          const float* __restrict__ part_b, float* __restrict__ out_b,
+                                                          int64_t prow, int64_t cols) {
+    __shared__ float4 lds[4 * SW];
+    const float* part = blockIdx.y ? part_b : part_a;
+    float* out = blockIdx.y ? out_b : out_a;
+    colsum_slices<256, SW, VEC>(part, prow, cols, out, (int)blockIdx.x, (int)gridDim.x, lds);
+}
+static int colsum_tall(const float* part_a, float* out_a, const float* part_b, float* out_b, int64_t prow, int64_t cols,
+                       bool vec, hipStream_t st) {
+    const int sw = fin_sw(cols, vec);
+    dim3 grid((unsigned)fin_slices(cols, vec), part_b ? 2u : 1u);
+#define TALL(SW_, V_) hipLaunchKernelGGL((colsum_tall_kernel<SW_, V_>), grid, dim3(256), 0, st, part_a, out_a, part_b, out_b, prow, cols)
+    if (vec) { if (sw == 8) TALL(8, true); else TALL(4, true); }
+    else { if (sw == 8) TALL(8, false); else TALL(4, false); }
+#undef TALL
+    NNHIP_LAUNCH_CHECK("colsum_tall_kernel");
+    return 0;
+}
+
+// Backward: block b walks rows b*RPB+rslot + k*gridDim.x*RPB, one row per iteration with the next row's loads already
+// in flight, keeps per-thread column
 // partials of dw = sum dy*x/std and db = sum dy in registers (a thread always owns the same columns),
 // and writes them once at the end to part[b][cols] (wave-per-row blocks first add their 4 waves' partials in LDS).
-// dw/db are then finished IN THE SAME LAUNCH: every block takes an arrival ticket after publishing its partials;
-// the last `nfin` arrivals wait until all blocks have arrived and column-sum disjoint slices of the partials
-// (round 1 used two extra column-sum launches here: +10 us on a 77 us kernel at 8192x4096).
+// dw/db are finished by ONE more launch for both (colsum_tall_kernel; round 1 used two two-stage column sums = up to
+// four launches).  Finishing them inside this launch -- arrival ticket after an agent-scope release, the last blocks
+// to arrive column-sum the partials -- was built and measured in round 2: 107 us instead of 81 at 8192x4096, 39
+// instead of 23 at 16384x512 (every block's release fence writes back its XCD's whole L2, which is full of dirty dX
+// lines, and the finishers start from cold caches); a kernel boundary costs ~1.7 us (MI355X_MICROARCH.md).
 // dx needs one row reduction: S = sum(w dy x / std).
 template <int TPR, int NV, bool VEC>
 __global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void rmsnorm_bwd_rows(
     const float* __restrict__ dY, const float* __restrict__ X, const float* __restrict__ w,
-    const float* __restrict__ Xstd, float* __restrict__ dX, float* part_dw, float* part_db, float* dW, float* db,
-    int64_t rows, int64_t cols, const float* __restrict__ dXadd, unsigned* sync, int nfin) {
-    constexpr int BS = (TPR >= 256) ? TPR : 256;
+    const float* __restrict__ Xstd, float* __restrict__ dX, float* __restrict__ part_dw, float* __restrict__ part_db,
+    int64_t rows, int64_t cols, const float* __restrict__ dXadd) {
     constexpr int RPB = (TPR >= 256) ? 1 : 256 / TPR;
     constexpr int NW = TPR / 64;
     __shared__ float red[32];
-    __shared__ int sh_i;
-    __shared__ float4 fin_lds[BS];
+    __shared__ float4 fin_lds[RPB > 1 ? 256 : 1];
     const int t = threadIdx.x % TPR;
     const int rslot = threadIdx.x / TPR;
     RowTile<TPR, NV, VEC> wt, adw, adb;
@@ -367,76 +412,53 @@ __global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void rmsnorm_bwd_rows(
     const float invN = 1.0f / (float)cols;
     const int64_t step = (int64_t)gridDim.x * RPB;
     // when TPR >= 256 every thread of the block runs the same trip count (block barriers inside)
-    constexpr bool TWO = TPR < 1024;  // 1024-thread blocks have 128 VGPRs/lane: one row in flight, no spills
-    if constexpr (TWO) {
-        for (int64_t r0 = (int64_t)blockIdx.x * RPB + rslot; r0 < rows; r0 += 2 * step) {
-            const int64_t r1 = r0 + step;
-            const bool has1 = r1 < rows;
-            RowTile<TPR, NV, VEC> x0, g0, x1, g1;
-            x0.load(X + r0 * cols, cols, t, 0.f);
-            g0.load(dY + r0 * cols, cols, t, 0.f);
-            if (has1) {
-                x1.load(X + r1 * cols, cols, t, 0.f);
-                g1.load(dY + r1 * cols, cols, t, 0.f);
-            } else {
-#pragma unroll
-                for (int e = 0; e < x1.NE; ++e) x1.x[e] = g1.x[e] = 0.f;
-            }
-            const float sd0 = Xstd[r0], sd1 = has1 ? Xstd[r1] : 1.f;
-            const float i0 = 1.0f / sd0, i1 = 1.0f / sd1;
-            float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-            for (int e = 0; e < x0.NE; ++e) {
-                adb.x[e] += g0.x[e] + g1.x[e];
-                adw.x[e] += g0.x[e] * (x0.x[e] * i0) + g1.x[e] * (x1.x[e] * i1);
-                g0.x[e] *= wt.x[e];  // dX_hat = w * dy
-                g1.x[e] *= wt.x[e];
-                s0 += g0.x[e] * x0.x[e] * i0;
-                s1 += g1.x[e] * x1.x[e] * i1;
-            }
-            block_sum2<NW>(s0, s1, red);
-            s0 *= invN;
-            s1 *= invN;
-            const float q0 = i0 * i0, q1 = i1 * i1;
-#pragma unroll
-            for (int e = 0; e < x0.NE; ++e) {
-                g0.x[e] = (g0.x[e] * sd0 - x0.x[e] * s0) * q0;
-                g1.x[e] = (g1.x[e] * sd1 - x1.x[e] * s1) * q1;
-            }
-            if (dXadd) {   // dX = rmsnorm gradient + an already accumulated gradient of X (x0/x1 are dead: reuse them)
-                x0.load(dXadd + r0 * cols, cols, t, 0.f);
-                if (has1) x1.load(dXadd + r1 * cols, cols, t, 0.f);
-#pragma unroll
-                for (int e = 0; e < x0.NE; ++e) { g0.x[e] += x0.x[e]; g1.x[e] += x1.x[e]; }
-            }
-            g0.store(dX + r0 * cols, cols, t);
-            if (has1) g1.store(dX + r1 * cols, cols, t);
+    // PRE: the NEXT row is loaded while the current one is reduced and stored (a second pair of row tiles).  Round 1 kept
+    // two rows in flight per iteration without prefetch: 232 registers -> 2 blocks per CU, and nothing in flight during a
+    // block's reduce / store phase (5.2 TB/s at 8192x4096).  One row + one prefetched row needs half the registers, so
+    // twice the blocks are resident and every one of them always has a row in flight.
+    constexpr bool PRE = TPR < 1024;   // 1024-thread blocks have 128 registers per lane: no room for a second pair
+    RowTile<TPR, NV, VEC> x0, g0, nx, ng;
+    const int64_t first = (int64_t)blockIdx.x * RPB + rslot;
+    if constexpr (PRE) {
+        if (first < rows) {
+            x0.load(X + first * cols, cols, t, 0.f);
+            g0.load(dY + first * cols, cols, t, 0.f);
         }
-    } else {
-        for (int64_t r0 = (int64_t)blockIdx.x * RPB + rslot; r0 < rows; r0 += step) {
-            RowTile<TPR, NV, VEC> x0, g0;
+    }
+    for (int64_t r0 = first; r0 < rows; r0 += step) {
+        if constexpr (PRE) {
+            const int64_t n0 = r0 + step;
+            if (n0 < rows) {
+                nx.load(X + n0 * cols, cols, t, 0.f);
+                ng.load(dY + n0 * cols, cols, t, 0.f);
+            }
+        } else {
             x0.load(X + r0 * cols, cols, t, 0.f);
             g0.load(dY + r0 * cols, cols, t, 0.f);
-            const float sd0 = Xstd[r0];
-            const float i0 = 1.0f / sd0;
-            float s0 = 0.f;
+        }
+        const float sd0 = Xstd[r0];
+        const float i0 = 1.0f / sd0;
+        float s0 = 0.f;
 #pragma unroll
-            for (int e = 0; e < x0.NE; ++e) {
-                adb.x[e] += g0.x[e];
-                adw.x[e] += g0.x[e] * (x0.x[e] * i0);
-                g0.x[e] *= wt.x[e];
-                s0 += g0.x[e] * x0.x[e] * i0;
-            }
-            s0 = block_sum<NW>(s0, red) * invN;
-            const float q0 = i0 * i0;
+        for (int e = 0; e < x0.NE; ++e) {
+            adb.x[e] += g0.x[e];
+            adw.x[e] += g0.x[e] * (x0.x[e] * i0);
+            g0.x[e] *= wt.x[e];  // dX_hat = w * dy
+            s0 += g0.x[e] * x0.x[e] * i0;
+        }
+        s0 = block_sum<NW>(s0, red) * invN;
+        const float q0 = i0 * i0;
 #pragma unroll
-            for (int e = 0; e < x0.NE; ++e) g0.x[e] = (g0.x[e] * sd0 - x0.x[e] * s0) * q0;
-            if (dXadd) {
-                x0.load(dXadd + r0 * cols, cols, t, 0.f);
+        for (int e = 0; e < x0.NE; ++e) g0.x[e] = (g0.x[e] * sd0 - x0.x[e] * s0) * q0;
+        if (dXadd) {   // dX = rmsnorm gradient + an already accumulated gradient of X (x0 is dead: reuse it)
+            x0.load(dXadd + r0 * cols, cols, t, 0.f);
 #pragma unroll
-                for (int e = 0; e < x0.NE; ++e) g0.x[e] += x0.x[e];
-            }
-            g0.store(dX + r0 * cols, cols, t);
+            for (int e = 0; e < x0.NE; ++e) g0.x[e] += x0.x[e];
+        }
+        g0.store(dX + r0 * cols, cols, t);
+        if constexpr (PRE) {
+#pragma unroll
+            for (int e = 0; e < x0.NE; ++e) { x0.x[e] = nx.x[e]; g0.x[e] = ng.x[e]; }
         }
     }
     // ---- this block's column partials -> part[blockIdx.x][cols] ---------------------------------------------------
@@ -472,15 +494,7 @@ __global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void rmsnorm_bwd_rows(
         adw.store(part_dw + (int64_t)blockIdx.x * cols, cols, t);
         if (part_db) adb.store(part_db + (int64_t)blockIdx.x * cols, cols, t);
     }
-    // ---- finish dw/db in this launch ----------------------------------------------------------------------------------
-    const int nblk = (int)gridDim.x;
-    const int ticket = grid_arrive(&sync[0], &sh_i);
-    if (ticket < nblk - nfin) return;
-    grid_wait_all(&sync[0], (unsigned)nblk, &sh_i);
-    const int f = ticket - (nblk - nfin);
-    colsum_slices<BS, VEC>(part_dw, nblk, cols, dW, f, nfin, fin_lds);
-    if (part_db) colsum_slices<BS, VEC>(part_db, nblk, cols, db, f, nfin, fin_lds);
-    grid_finish_done(sync, nfin);
+    // dw/db = column sums of the partials: colsum_tall_kernel, the next launch.
 }
 
 // ---- RMSNorm for rows wider than the register tile (cols > 16384): looped, one block per row -------------------------
@@ -602,6 +616,54 @@ __device__ __forceinline__ int block_sum_int(int v, int* red) {
     return s;
 }
 
+// Block-wide count of labels != ignore (and, with class weights, the sum of w[label] over them) with all loads in
+// flight: a plain `for (i = tid; i < rows; i += BS)` is a chain of dependent L2 round trips (32 of them for 8192 labels
+// and 256 threads ~ 20 us per block -- measured: it doubled the kernel).  T = label type.
+template <int BS, class T>
+__device__ __forceinline__ void count_labels(const T* __restrict__ lab, int64_t rows, int64_t ignore, const float* __restrict__ cw,
+                                             int64_t cols, int& ci, float& ws) {
+    constexpr int U = 8;
+    auto one = [&](int64_t l) {
+        const bool live = l != ignore;
+        ci += live ? 1 : 0;
+        if (cw && live && l >= 0 && l < cols) ws += cw[l];
+    };
+    int64_t done = 0;
+    if constexpr (sizeof(T) == 4) {
+        if ((reinterpret_cast<uintptr_t>(lab) & 15u) == 0) {   // 4 labels per load: 8192 labels = ONE batch of 8 loads for 256 threads
+            const int4* l4 = reinterpret_cast<const int4*>(lab);
+            const int64_t n4 = rows >> 2;
+            for (int64_t base = 0; base < n4; base += (int64_t)BS * U) {
+                int4 v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int64_t i = base + (int64_t)u * BS + threadIdx.x;
+                    v[u] = i < n4 ? l4[i] : make_int4((int)ignore, (int)ignore, (int)ignore, (int)ignore);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int64_t i = base + (int64_t)u * BS + threadIdx.x;
+                    if (i < n4) { one(v[u].x); one(v[u].y); one(v[u].z); one(v[u].w); }
+                }
+            }
+            done = n4 << 2;
+        }
+    }
+    for (int64_t base = done; base < rows; base += (int64_t)BS * U) {
+        T l[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = base + (int64_t)u * BS + threadIdx.x;
+            l[u] = i < rows ? lab[i] : (T)0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = base + (int64_t)u * BS + threadIdx.x;
+            if (i < rows) one((int64_t)l[u]);
+        }
+    }
+}
+
 // 'mean' denominator and gradient scale of this launch; identical in every block.
 template <int BS>
 __device__ __forceinline__ void ce_prologue(const CeArgs& a, float* red, int* ired, float& scale, float& denom) {
@@ -611,12 +673,9 @@ __device__ __forceinline__ void ce_prologue(const CeArgs& a, float* red, int* ir
     if (a.count_in_kernel) {
         int ci = 0;
         float ws = 0.f;
-        for (int64_t i = threadIdx.x; i < a.rows; i += BS) {
-            const int64_t l = load_label(a.labels, i, a.lbytes);
-            const bool live = l != a.ignore;
-            ci += live ? 1 : 0;
-            if (a.cw && live && l >= 0 && l < a.cols) ws += a.cw[l];
-        }
+        if (a.lbytes == 4) count_labels<BS>(reinterpret_cast<const int32_t*>(a.labels), a.rows, a.ignore, a.cw, a.cols, ci, ws);
+        else if (a.lbytes == 8) count_labels<BS>(reinterpret_cast<const int64_t*>(a.labels), a.rows, a.ignore, a.cw, a.cols, ci, ws);
+        else count_labels<BS>(reinterpret_cast<const int16_t*>(a.labels), a.rows, a.ignore, a.cw, a.cols, ci, ws);
         ci = block_sum_int<BS / 64>(ci, ired);
         if (a.cw) ws = block_sum<BS / 64>(ws, red);
         denom = a.cw ? ws : (float)ci;
@@ -647,8 +706,16 @@ __device__ __forceinline__ void ce_epilogue(const CeArgs& a, float lsum, float d
     __syncthreads();
     if (ired[16] != nblk - 1) return;
     float s = 0.f;
-    for (int i = threadIdx.x; i < nblk; i += BS)
-        s += __hip_atomic_load(&a.partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int base = 0; base < nblk; base += BS * 8) {        // all of a batch's loads in flight (nblk <= 8 * BS in practice)
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * BS + (int)threadIdx.x;
+            v[u] = i < nblk ? __hip_atomic_load(&a.partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
     s = block_sum<BS / 64>(s, red);
     if (threadIdx.x == 0) {
         a.loss_out[0] = a.mode == 1 ? s / denom : s;
@@ -664,18 +731,22 @@ __global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void ce_rows_kernel(const
     __shared__ int ired[17];
     const int t = threadIdx.x % TPR;
     const int slot = threadIdx.x / TPR;
+    const int64_t step = (int64_t)gridDim.x * RPB;
+    const int64_t row0 = (int64_t)blockIdx.x * RPB + slot;
+    // the first row's loads are issued BEFORE the denominator is counted: the count's label loads then travel in the
+    // shadow of the row's HBM latency instead of in front of it
+    RowTile<TPR, NV, VEC> r;
+    if (row0 < a.rows) r.load(a.logits + row0 * a.ld, a.cols, t, -INFINITY);
     float scale, denom;
     ce_prologue<BS>(a, red, ired, scale, denom);
     float lsum = 0.f;                                         // meaningful on t == 0 of each row slot
-    const int64_t step = (int64_t)gridDim.x * RPB;
-    for (int64_t row = (int64_t)blockIdx.x * RPB + slot; row < a.rows; row += step) {
+    for (int64_t row = row0; row < a.rows; row += step) {
         const int64_t label = load_label(a.labels, row, a.lbytes);
         const bool valid = label != a.ignore && label >= 0 && label < a.cols;
         const float wy = valid ? (a.cw ? a.cw[label] : 1.f) : 0.f;
         // read the label logit before anything is overwritten (in-place mode)
         const float xl = valid ? a.logits[row * a.ld + label] : 0.f;
-        RowTile<TPR, NV, VEC> r;
-        r.load(a.logits + row * a.ld, a.cols, t, -INFINITY);
+        if (row != row0) r.load(a.logits + row * a.ld, a.cols, t, -INFINITY);
         float m = r.x[0];
 #pragma unroll
         for (int e = 1; e < r.NE; ++e) m = fmaxf(m, r.x[e]);
@@ -768,12 +839,9 @@ __global__ __launch_bounds__(1024) void ce_denominator_kernel(const void* __rest
     __shared__ float red[16];
     int ci = 0;
     float ws = 0.f;
-    for (int64_t i = threadIdx.x; i < n; i += 1024) {
-        const int64_t l = load_label(labels, i, lbytes);
-        const bool live = l != ignore;
-        ci += live ? 1 : 0;
-        if (cw && live && l >= 0 && l < cols) ws += cw[l];
-    }
+    if (lbytes == 4) count_labels<1024>(reinterpret_cast<const int32_t*>(labels), n, ignore, cw, cols, ci, ws);
+    else if (lbytes == 8) count_labels<1024>(reinterpret_cast<const int64_t*>(labels), n, ignore, cw, cols, ci, ws);
+    else count_labels<1024>(reinterpret_cast<const int16_t*>(labels), n, ignore, cw, cols, ci, ws);
     ci = block_sum_int<16>(ci, ired);
     if (cw) ws = block_sum<16>(ws, red);
     if (threadIdx.x == 0) {
@@ -847,15 +915,14 @@ __global__ __launch_bounds__(1024) void ce_small_kernel(const CeArgs a) {
 // Column sums:  out[c] = sum_r X[r*ld + c]     (Linear db: neunet/nn/layers/linear.py:24)
 // Block = 4 waves; lane <-> one float4 column group (256 columns per block) or one column (scalar path,
 // 64 columns per block); wave w sums rows w, w+4, ... of the block's row range (1 KiB coalesced per
-// wave-load); the 4 waves meet in LDS.  grid (col_blocks, row_blocks); with row_blocks > 1 the blocks write
-// partials [row_blocks][cols] and the LAST arrivals finish them in the same launch (round 1: a second launch).
+// wave-load); the 4 waves meet in LDS.  grid (col_blocks, row_blocks); row_blocks > 1 writes partials
+// [row_blocks][cols] that colsum_tall_kernel finishes (one slice of columns per block, all rows in flight).
 // =================================================================================================
 template <bool VEC>
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int64_t rows,
                                                      int64_t cols, int64_t ld, int64_t rows_per_block,
-                                                     float* out, float* part, unsigned* sync, int nfin) {
-    __shared__ float4 red[256];
-    __shared__ int sh_i;
+                                                     float* __restrict__ out) {
+    __shared__ float4 red[3][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t rbeg = (int64_t)blockIdx.y * rows_per_block;
     const int64_t rend = min(rows, rbeg + rows_per_block);
@@ -885,25 +952,18 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
         if (c < cols)
             for (int64_t r = rbeg + w; r < rend; r += 4) a.x += X[r * ld + c];
     }
-    if (w > 0) red[(w - 1) * 64 + lane] = a;
+    if (w > 0) red[w - 1][lane] = a;
     __syncthreads();
-    float* dst = gridDim.y > 1 ? part + (int64_t)blockIdx.y * cols : out;
     if (w == 0 && c < cols) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const float4 v = red[i * 64 + lane];
+            const float4 v = red[i][lane];
             a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
         }
-        if constexpr (VEC) *reinterpret_cast<float4*>(dst + c) = a;
-        else dst[c] = a.x;
+        float* o = out + (int64_t)blockIdx.y * cols + c;
+        if constexpr (VEC) *reinterpret_cast<float4*>(o) = a;
+        else *o = a.x;
     }
-    if (gridDim.y == 1) return;
-    const int nblk = (int)(gridDim.x * gridDim.y);
-    const int ticket = grid_arrive(&sync[0], &sh_i);
-    if (ticket < nblk - nfin) return;
-    grid_wait_all(&sync[0], (unsigned)nblk, &sh_i);
-    colsum_slices<256, VEC>(part, (int64_t)gridDim.y, cols, out, ticket - (nblk - nfin), nfin, red);
-    grid_finish_done(sync, nfin);
 }
 
 // internal API ------------------------------------------------------------------------------------
@@ -920,7 +980,7 @@ static ColsumPlan colsum_plan(const float* X, const float* out, int64_t rows, in
     p.col_blocks = ceil_div(cols, p.vec ? 256 : 64);
     int64_t rb = 2048 / p.col_blocks;             // aim for ~2k blocks
     if (rb > ceil_div(rows, 16)) rb = ceil_div(rows, 16);  // >= 16 rows per block
-    if (rb > 512) rb = 512;
+    if (rb > 512) rb = 512;                        // the tall finish sums <= 512 partial rows per column
     if (rb < 1) rb = 1;
     p.rows_per_block = ceil_div(rows > 0 ? rows : 1, rb);
     p.row_blocks = (int)ceil_div(rows > 0 ? rows : 1, p.rows_per_block);
@@ -931,17 +991,13 @@ static ColsumPlan colsum_plan(const float* X, const float* out, int64_t rows, in
 // `scratch` must hold plan.scratch_floats floats (16-B aligned) when plan.row_blocks > 1.
 static int colsum_run(const ColsumPlan& p, const float* X, int64_t rows, int64_t cols, int64_t ld, float* out,
                       float* scratch, hipStream_t st) {
-    unsigned* sync = sync_words();
-    if (!sync) { set_last_error("sync words allocation failed"); return NNHIP_ENOMEM; }
-    sync += SYNC_COLSUM;
+    float* stage1 = p.row_blocks > 1 ? scratch : out;
     dim3 grid((unsigned)p.col_blocks, (unsigned)p.row_blocks);
-    const bool v = p.vec && (p.row_blocks == 1 || aligned16(scratch));
-    int nfin = fin_slices(cols, v);
-    const int nblk = (int)(p.col_blocks * p.row_blocks);
-    if (nfin > nblk) nfin = nblk;
-    if (v) hipLaunchKernelGGL(colsum_kernel<true>, grid, dim3(256), 0, st, X, rows, cols, ld, p.rows_per_block, out, scratch, sync, nfin);
-    else hipLaunchKernelGGL(colsum_kernel<false>, grid, dim3(256), 0, st, X, rows, cols, ld, p.rows_per_block, out, scratch, sync, nfin);
+    if (p.vec) hipLaunchKernelGGL(colsum_kernel<true>, grid, dim3(256), 0, st, X, rows, cols, ld, p.rows_per_block, stage1);
+    else hipLaunchKernelGGL(colsum_kernel<false>, grid, dim3(256), 0, st, X, rows, cols, ld, p.rows_per_block, stage1);
     NNHIP_LAUNCH_CHECK("colsum_kernel");
+    if (p.row_blocks > 1)
+        return colsum_tall(stage1, out, nullptr, nullptr, (int64_t)p.row_blocks, cols, p.vec && aligned16(stage1), st);
     return 0;
 }
 
@@ -1157,9 +1213,6 @@ extern "C" int nnhipRMSNormBackwardEx(const float* dY, const float* X, const flo
     NNHIP_CHECK_ARG(dY && X && weight && X_std && dX && dW, NNHIP_EINVAL,
                     "nnhipRMSNormBackward: null pointer");
     hipStream_t st = (hipStream_t)s;
-    unsigned* sync = sync_words();
-    NNHIP_CHECK_ARG(sync != nullptr, NNHIP_ENOMEM, "nnhipRMSNormBackward: sync words allocation failed");
-    sync += SYNC_RMSNORM;
     if (cols > kMaxRegRow) {
         // wide rows: looped dX kernel + a column pass for dw/db (partials over row chunks, then the in-launch column sum)
         if (rows > 0) {
@@ -1193,9 +1246,9 @@ extern "C" int nnhipRMSNormBackwardEx(const float* dY, const float* X, const flo
     const bool vec = aligned16(dY) && aligned16(X) && aligned16(weight) && aligned16(dX) && aligned16(dX_addend) &&
                      aligned16(dW) && aligned16(db) && cols % 4 == 0;
     // persistent grid = the blocks that are resident at once (occupancy query), each accumulating dw/db partials over
-    // its rows, two rows in flight per iteration
+    // its rows
     const int rpb = cols <= 1024 ? 4 : 1;
-    int64_t nblk = ceil_div(ceil_div(rows > 0 ? rows : 1, rpb), cols > 8192 ? 1 : 2);
+    int64_t nblk = ceil_div(rows > 0 ? rows : 1, rpb);
     int slots = 1024;
     ROW_DISPATCH_SLOTS(rmsnorm_bwd_rows, cols, vec, slots);
     if (nblk > slots) nblk = slots;
@@ -1204,12 +1257,9 @@ extern "C" int nnhipRMSNormBackwardEx(const float* dY, const float* X, const flo
     NNHIP_CHECK_ARG(part != nullptr, NNHIP_ENOMEM, "nnhipRMSNormBackward: workspace allocation failed");
     float* part_dw = part;
     float* part_db = db ? part + part_floats : nullptr;
-    int nfin = fin_slices(cols, vec);
-    if (nfin > nblk) nfin = (int)nblk;
-    ROW_DISPATCH_GRID(rmsnorm_bwd_rows, cols, vec, nblk, st, dY, X, weight, X_std, dX, part_dw, part_db, dW, db, rows, cols,
-                      dX_addend, sync, nfin);
+    ROW_DISPATCH_GRID(rmsnorm_bwd_rows, cols, vec, nblk, st, dY, X, weight, X_std, dX, part_dw, part_db, rows, cols, dX_addend);
     NNHIP_LAUNCH_CHECK("rmsnorm_backward");
-    return 0;
+    return colsum_tall(part_dw, dW, part_db, db, nblk, cols, vec, st);
 }
 
 // ---- CrossEntropy -------------------------------------------------------------------------------
@@ -1231,12 +1281,12 @@ static int ce_launch(CeArgs a, hipStream_t st) {
     const bool vec = aligned16(a.logits) && aligned16(a.dlogits) && a.cols % 4 == 0 && a.ld % 4 == 0;
     const int rpb = (!looped && a.cols <= 1024) ? 4 : 1;
     int64_t nblk = ceil_div(a.rows, rpb);
-    // two rounds of resident blocks: dynamic enough to absorb stragglers, few enough that the per-block label count
-    // and the final partial reduction stay negligible
+    // persistent grid = the blocks resident at once: the per-block label count and the final partial reduction stay
+    // negligible
     int slots = 512;
     if (looped) slots = resident_slots(ce_looped_kernel, 1024);
     else ROW_DISPATCH_SLOTS(ce_rows_kernel, a.cols, vec, slots);
-    if (nblk > 2 * (int64_t)slots) nblk = 2 * (int64_t)slots;
+    if (nblk > (int64_t)slots) nblk = (int64_t)slots;       // one resident round: equal shares, one prologue per slot
     if (a.loss_out) {
         a.partial = static_cast<float*>(workspace((size_t)nblk * sizeof(float)));
         if (!a.partial) { set_last_error("cross entropy: workspace allocation failed"); return NNHIP_ENOMEM; }
@@ -1330,6 +1380,19 @@ extern "C" int nnhipCountNotEqual(const int32_t* labels, int64_t n, int32_t igno
     NNHIP_CHECK_ARG(n >= 0 && out_count && (labels || n == 0), NNHIP_EINVAL, "nnhipCountNotEqual: bad args");
     hipLaunchKernelGGL(ce_denominator_kernel, dim3(1), dim3(1024), 0, (hipStream_t)s, labels, 4, n, (int64_t)ignore_index,
                        (const float*)nullptr, (int64_t)0, out_count, (float*)nullptr);
+    NNHIP_LAUNCH_CHECK("ce_denominator_kernel");
+    return 0;
+}
+
+extern "C" int nnhipCrossEntropyDenominator(const void* labels, int32_t label_bytes, int64_t n, int64_t ignore_index,
+                                            const float* class_weight_or_null, int64_t n_cols, int32_t* count_out_or_null,
+                                            float* denom_out_or_null, nnhipStream_t s) {
+    NNHIP_CHECK_ARG(n >= 0 && (labels || n == 0), NNHIP_EINVAL, "nnhipCrossEntropyDenominator: bad args");
+    NNHIP_CHECK_ARG(label_bytes == 2 || label_bytes == 4 || label_bytes == 8, NNHIP_EINVAL,
+                    "nnhipCrossEntropyDenominator: labels must be int16, int32 or int64");
+    NNHIP_CHECK_ARG(count_out_or_null || denom_out_or_null, NNHIP_EINVAL, "nnhipCrossEntropyDenominator: no output");
+    hipLaunchKernelGGL(ce_denominator_kernel, dim3(1), dim3(1024), 0, (hipStream_t)s, labels, (int)label_bytes, n, ignore_index,
+                       class_weight_or_null, n_cols, count_out_or_null, denom_out_or_null);
     NNHIP_LAUNCH_CHECK("ce_denominator_kernel");
     return 0;
 }

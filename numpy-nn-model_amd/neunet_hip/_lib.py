@@ -69,6 +69,7 @@ _SIGNATURES = {
     "nnhipSoftmaxBackward": (ctypes.c_int, [P, P, P, c_int64, c_int64, c_int64, c_void_p]),
     "nnhipCrossEntropyForwardBackward": (ctypes.c_int, [P, P, P, P, c_int64, c_int32, c_int64, c_int64, c_char, c_int64, P, P, c_void_p]),
     "nnhipCountNotEqual": (ctypes.c_int, [P, c_int64, c_int32, P, c_void_p]),
+    "nnhipCrossEntropyDenominator": (ctypes.c_int, [P, c_int32, c_int64, c_int64, P, c_int64, P, P, c_void_p]),
     "nnhipReduceLoss": (ctypes.c_int, [P, c_int64, c_char, P, P, c_void_p]),
     "nnhipCrossEntropyLoss": (ctypes.c_int, [P, P, P, P, P, c_int64, ctypes.c_int32, c_int64, c_int64, ctypes.c_char, P, P, c_void_p]),
     "nnhipCrossEntropyLossEx": (ctypes.c_int, [P, P, P, P, P, c_int32, P, c_int64, c_int64, c_int64, c_int64, c_char, P, P, c_void_p]),

@@ -80,6 +80,7 @@ class GradBucket:
         self.segments = []        # (lo, hi, [param indices])  -- flat[lo:hi]
         self._seg_of = {}
         self._pending, self._works, self._launched = [], [], []
+        self._capture_cb = None       # GraphedTrainStep: called instead of launching a segment's all-reduce (graph cut)
         if overlap:
             hi, idxs = self.extra_offset, []
             for n, i in enumerate(reversed(self.layout)):
@@ -107,6 +108,9 @@ class GradBucket:
     def _launch(self, k):
         import torch.distributed as dist
         self._launched[k] = True
+        if self._capture_cb is not None:      # hipGraph capture: the step is cut here; the replay launches the exchange
+            self._capture_cb(k)
+            return
         if self._world() > 1:
             lo, hi, _ = self.segments[k]
             self._works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
@@ -147,10 +151,9 @@ class GradBucket:
             elif g.data_ptr() != v.data_ptr():
                 v.copy_(g.reshape(v.shape))
 
-    def _finish_overlapped(self):
-        """Launch the segments that are still open (parameters without a gradient are zero-filled), exchange the
-        extra scalars, wait for everything (stream-ordered: the host does not block on the GPU)."""
-        import torch.distributed as dist
+    def _close_segments(self):
+        """Make every slot final (parameters without a gradient are zero-filled, gradients written elsewhere are copied
+        in) and launch the segments that are still open."""
         self.has_grad = []
         for p, v in zip(self.params, self.views):
             hg = p.grad is not None
@@ -166,6 +169,19 @@ class GradBucket:
         for k in range(len(self.segments)):
             if not self._launched[k]:
                 self._launch(k)
+
+    def _finish_for_capture(self):
+        """End of a captured backward pass (GraphedTrainStep): like _finish_overlapped without any collective."""
+        self._close_segments()
+        for p, v, hg in zip(self.params, self.views, self.has_grad):
+            p.grad = v if hg else None
+        self._reset_step()
+
+    def _finish_overlapped(self):
+        """Launch the segments that are still open (parameters without a gradient are zero-filled), exchange the
+        extra scalars, wait for everything (stream-ordered: the host does not block on the GPU)."""
+        import torch.distributed as dist
+        self._close_segments()
         if self.extra is not None and self._world() > 1:
             self._works.append(dist.all_reduce(self.flat[self.extra_offset:], op=dist.ReduceOp.SUM, group=self.group,
                                                async_op=True))

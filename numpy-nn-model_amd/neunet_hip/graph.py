@@ -11,21 +11,37 @@ capture one step into a hipGraph and replay it -- the Python tape then runs only
         loss = step()                              # replay
 
 Rules a captured region must obey (all hold for the kernels of libneunet_hip.so): no host synchronisation,
-no hipMalloc (the library workspace is grow-only and was sized during warm-up), static tensor addresses
-(inputs live in fixed buffers; parameter gradients live in the flat GradBucket), and an optimizer step counter
-in device memory (`use_device_step`).  With world_size > 1 the gradient all-reduce stays outside the graphs:
-[forward+backward graph] -> all_reduce (RCCL) -> [optimizer graph]; with one process the whole step is ONE graph
-(one launch per step instead of two: at MNIST-MLP scale the seam between the two graphs was ~8 us of a 100 us step).
+no hipMalloc (the library workspace is grow-only, sized during warm-up and LOCKED after capture so that a later
+eager call of a larger shape fails loudly instead of freeing memory the graph points into), static tensor
+addresses (inputs live in fixed buffers; parameter gradients live in the flat GradBucket; checked on replay), and
+every per-step scalar in device memory: the optimizer's step counter, lr, weight_decay and grad_scale
+(`optimizer.use_device_step`; assigning `optimizer.lr` between replays works -- the new value is written to the
+device before the next replay) and, for a 'sum' loss under data parallelism, the all-reduced target count
+(`optimizer.grad_divisor`).
+
+Shapes of a replayed step:
+  * one process:            [ forward + backward + optimizer ]                      one graph, one launch per step
+  * N ranks, plain bucket:  [ forward + backward ] -> all_reduce(bucket) -> [ optimizer ]
+  * N ranks, GradBucket(overlap=True):
+        [ piece 0 ] -> async all_reduce(segment 0) | [ piece 1 ] -> async all_reduce(segment 1) | ... -> wait -> [ optimizer ]
+    the backward pass is cut into one graph per bucket segment (at the point the segment's last gradient has been
+    written), so RCCL exchanges segment k on its own stream while piece k+1 of the backward pass replays.
 """
 from __future__ import annotations
 
+from ._lib import call_hip_function
+
 
 class GraphedTrainStep:
-    def __init__(self, forward_backward, optimizer, bucket, warmup: int = 3, world: int = 1, pre_optim=None):
+    def __init__(self, forward_backward, optimizer, bucket, warmup: int = 3, world: int = 1, pre_optim=None,
+                 group=None, check_every: int = 256):
         import torch
         self.fb, self.opt, self.bucket, self.world = forward_backward, optimizer, bucket, world
-        self.pre_optim = pre_optim                    # e.g. set optimizer.grad_scale from an all-reduced count
+        self.pre_optim = pre_optim                    # host-side hook between exchange and optimizer (kept for callers)
+        self.group = group if group is not None else getattr(bucket, "group", None)
         self._torch = torch
+        self._calls = 0
+        self._check_every = max(1, int(check_every))
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):                    # warm-up on a side stream, as torch's graph recipe asks
@@ -35,22 +51,67 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         if hasattr(optimizer, "use_device_step"):
             optimizer.use_device_step(True)
-        self.g_fb = torch.cuda.CUDAGraph()
         self.opt.zero_grad()
         self.single = world == 1 and pre_optim is None
-        with torch.cuda.graph(self.g_fb):
-            self.loss = self.fb()
-            self.bucket.collect()
-            if self.single:
-                self._bind_grads()
-                self.opt.step()
+        self.pieces = []                              # [(graph, segment index or None)]
         self.g_opt = None
+        overlap = bool(getattr(bucket, "overlap", False)) and not self.single
+        if overlap:
+            self._capture_overlapped(s)
+        else:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.loss = self.fb()
+                self.bucket.collect()
+                if self.single:
+                    self._bind_grads()
+                    self.opt.step()
+            self.pieces.append((g, None))
         if not self.single:
             self.g_opt = torch.cuda.CUDAGraph()
             self._bind_grads()
-            with torch.cuda.graph(self.g_opt):
+            with torch.cuda.graph(self.g_opt, pool=self.pieces[0][0].pool()):
                 self.opt.step()
         torch.cuda.synchronize()
+        # the captured kernels hold these addresses
+        self._addr = self._addresses()
+        call_hip_function("nnhipWorkspaceLock", 1)
+
+    # ---- capture of the overlapped variant: one graph per bucket segment ------------------------------------------
+    def _capture_overlapped(self, side_stream):
+        torch = self._torch
+        bucket = self.bucket
+        cur = torch.cuda.current_stream()
+        side_stream.wait_stream(cur)
+        pool = torch.cuda.graph_pool_handle()
+        state = {"g": None}
+
+        def begin():
+            g = torch.cuda.CUDAGraph()
+            g.capture_begin(pool=pool)
+            state["g"] = g
+
+        def cut(k):                                   # called by the bucket where it would launch segment k's all-reduce
+            state["g"].capture_end()
+            self.pieces.append((state["g"], k))
+            begin()
+
+        with torch.cuda.stream(side_stream):
+            bucket._capture_cb = cut
+            try:
+                begin()
+                self.loss = self.fb()
+                bucket._finish_for_capture()          # zero-fills, late copies, remaining segments (each a cut)
+                state["g"].capture_end()
+                self.pieces.append((state["g"], None))
+            finally:
+                bucket._capture_cb = None
+        cur.wait_stream(side_stream)
+
+    def _addresses(self):
+        ptrs = [p.data.data_ptr() for p in self.bucket.params]
+        ptrs += [v.data_ptr() for v in self.bucket.views]
+        return ptrs
 
     def _bind_grads(self):
         for p, v, hg in zip(self.bucket.params, self.bucket.views, self.bucket.has_grad):
@@ -59,20 +120,42 @@ class GraphedTrainStep:
     def _eager(self):
         self.opt.zero_grad()
         loss = self.fb()
-        self.bucket.all_reduce()
+        self.bucket.all_reduce(self.group)
         if self.pre_optim is not None:
             self.pre_optim()
         self.opt.step()
         return loss
 
     def __call__(self):
-        self.g_fb.replay()
+        self._calls += 1
+        if self._calls <= 3 or self._calls % self._check_every == 0:
+            if self._addresses() != self._addr:
+                raise RuntimeError("GraphedTrainStep: a parameter or gradient buffer moved since capture (p.data was "
+                                   "re-assigned, or the bucket was rebuilt); the captured kernels would read stale "
+                                   "memory -- capture again")
+        if hasattr(self.opt, "sync_device_hyper"):
+            self.opt.sync_device_hyper()              # lr / weight_decay / grad_scale changed on the host -> device state
         if self.single:
+            self.pieces[0][0].replay()
             return self.loss
-        if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.bucket.flat, op=dist.ReduceOp.SUM)
-            if self.pre_optim is not None:
-                self.pre_optim()
+        import torch.distributed as dist
+        live = self.world > 1 and dist.is_available() and dist.is_initialized()
+        works = []
+        for g, k in self.pieces:
+            g.replay()
+            if k is not None and live:
+                lo, hi, _ = self.bucket.segments[k]
+                works.append(dist.all_reduce(self.bucket.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if live:
+            if getattr(self.bucket, "overlap", False):
+                if self.bucket.extra is not None:
+                    works.append(dist.all_reduce(self.bucket.flat[self.bucket.extra_offset:], op=dist.ReduceOp.SUM,
+                                                 group=self.group, async_op=True))
+            else:
+                dist.all_reduce(self.bucket.flat, op=dist.ReduceOp.SUM, group=self.group)
+        for w in works:
+            w.wait()                                  # stream-ordered: the host does not block on the GPU
+        if self.pre_optim is not None:
+            self.pre_optim()
         self.g_opt.replay()
         return self.loss

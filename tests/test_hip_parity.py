@@ -352,7 +352,9 @@ def test_swish_fast_sigmoid_accuracy_sweep(hip):
     finite range of the sigmoid argument, [-88, 88], densely: the result stays within 1e-6 absolute + 1 ulp of the
     float64 evaluation of the oracle's formula: forward within 1e-6 absolute + 2 ulp (rcp 1 ulp, 1+e and the final
     product half an ulp each; at |x| = 88 one ulp of the output is 7.6e-6, so a pure absolute bound cannot hold there),
-    backward within 1e-6 + 4 ulp."""
+    backward within 1e-6 + 2 ulp of its largest INTERMEDIATE, 1 + |beta f|: the reference's formula
+    beta f + s (1 - beta f) (activations.py:212-216) cancels two terms of size beta*x for large x, so its own float32
+    evaluation is only that accurate."""
     from neunet_hip.nn.experimental import HIPFusedSwishAndMul, HIPSwish
     X = np.linspace(-88.0, 88.0, 1 << 20, dtype=np.float32).reshape(1024, 1024)
     dY = np.ones_like(X)
@@ -366,7 +368,8 @@ def test_swish_fast_sigmoid_accuracy_sweep(hip):
         y.backward(dY)
         refg = O.swish_backward(Xb.astype(np.float64), dY.astype(np.float64), beta)
         errg = np.abs(host(x.grad).astype(np.float64) - refg)
-        assert np.all(errg <= 1e-6 + 4 * np.spacing(np.abs(refg).astype(np.float32))), float(errg.max())
+        mag = 1.0 + np.abs(beta * ref)
+        assert np.all(errg <= 1e-6 + 2 * np.spacing(mag.astype(np.float32))), float((errg / np.spacing(mag.astype(np.float32))).max())
     # the same sigmoid inside the SwiGLU gate: gate = sweep, up = 1
     G = np.concatenate([X[:, :512], np.ones((1024, 512), np.float32)], axis=1)
     g = T(hip, np.ascontiguousarray(G))
@@ -1399,8 +1402,11 @@ def test_error_status_not_exit(hip):
     a = torch.zeros(16, device="cuda")
     with pytest.raises(NeunetHipError, match="multiple of hidden"):
         call_hip_function("nnhipFusedSwishAndMul", a, a, 1.0, 3, 16, get_current_stream_ptr())
-    with pytest.raises(NeunetHipError, match="16384"):
-        call_hip_function("nnhipRMSNormForward", a, a, None, a, a, None, 1, 20000, 1e-6, get_current_stream_ptr())
+    with pytest.raises(NeunetHipError, match="negative size"):
+        call_hip_function("nnhipRMSNormForward", a, a, None, a, a, None, -1, 16, 1e-6, get_current_stream_ptr())
+    with pytest.raises(NeunetHipError, match="int16, int32 or int64"):
+        call_hip_function("nnhipCrossEntropyLossEx", a, None, a, a, a, 3, None, 4, -100, 4, 4, b"n", None, None,
+                          get_current_stream_ptr())
     # the library is still usable afterwards
     call_hip_function("nnhipScale", a, 2.0, 16, get_current_stream_ptr())
 

@@ -112,11 +112,14 @@ def main():
         labels = torch.randint(0, D, (R,), device=dev, dtype=torch.int32)
         loss, lse = torch.empty(R, device=dev), torch.empty(R, device=dev)
         report("ce fwd+bwd 8192x4096", *bench(lambda: call("nnhipCrossEntropyForwardBackward", x, loss, lse, labels, D, -100, R, D, b"m", R, None, dx, st), args.iters), nbytes=8.0 * n)
+        lo, cnt = torch.empty((), device=dev), torch.empty(1, device=dev, dtype=torch.int32)
+        report("ce loss(mean) 1 launch 8192x4096", *bench(lambda: call("nnhipCrossEntropyLossEx", x, dx, loss, lse, labels, 4, None, D, -100, R, D, b"m", lo, cnt, st), args.iters), nbytes=8.0 * n)
         V = 15000
         xl, dxl = randn(16384, V), torch.empty(16384, V, device=dev)
         lab = torch.randint(0, V, (16384,), device=dev, dtype=torch.int32)
         l2, s2 = torch.empty(16384, device=dev), torch.empty(16384, device=dev)
         report("ce fwd+bwd 16384x15000", *bench(lambda: call("nnhipCrossEntropyForwardBackward", xl, l2, s2, lab, V, 0, 16384, V, b"m", 16384, None, dxl, st), args.iters), nbytes=8.0 * xl.numel())
+        report("ce loss(mean) 1 launch 16384x15000", *bench(lambda: call("nnhipCrossEntropyLossEx", xl, dxl, l2, s2, lab, 4, None, V, 0, 16384, V, b"m", lo, cnt, st), args.iters), nbytes=8.0 * xl.numel())
         del xl, dxl
     if want("adamw"):
         p, m, v = randn(R, D), torch.zeros(R, D, device=dev), torch.zeros(R, D, device=dev)
