@@ -270,6 +270,8 @@ def workload_c1(args, rank, world):
                 b.record()
 
     dt = timed_region(step, args.steps, args.warmup, world)
+    if args.graph:
+        gstep.release()
     dev_ms = ev.mean_ms()
     flops = 2.0 * 3 * Bsz * (784 * 128 + 128 * 10)
     return {
@@ -502,6 +504,8 @@ def workload_c4(args, rank, world):
     ach = fl / (dev_ms * 1e-3) / 1e12
     n_grad = sum(int(np.prod(p.shape)) for p in active)
     pieces = len(getattr(gstep, "pieces", [])) if args.graph else 0
+    if args.graph:
+        gstep.release()
     return {
         "samples_per_step": B * world, "dt": dt,
         "config": {"workload": f"C4: GPT-tiny d512 L6 H8 d_ff2048 vocab15000 training step, batch {B} x seq {T} per GPU, "
@@ -619,13 +623,16 @@ def workload_c5(args, rank, world):
                 b.record()
 
     dt = timed_region(step, args.steps, args.warmup, world)
+    if args.graph:
+        gstep.release()
     dev_ms = ev.mean_ms()
     # algorithmic HBM bytes of the two conv layers fwd + bwd: 4*(|X|+|O|+|W|) forward, x2 backward
     conv_bytes = 3 * 4.0 * ((Bsz * 784 + Bsz * 8 * 784 + 72) + (Bsz * 8 * 196 + Bsz * 16 * 196 + 1152))
     return {
         "samples_per_step": Bsz * world, "dt": dt,
         "config": {"workload": "C5: Conv2d MNIST classifier training step (conv-LeakyReLU-MaxPool x2, BatchNorm2d, Linear, "
-                               "Sigmoid, MSE, Adam), 28x28x1, batch 256 per GPU, implicit-GEMM MFMA conv",
+                               "Sigmoid, MSE, Adam), 28x28x1, batch 256 per GPU; at these shapes (Cin, Cout <= 16, 3x3) the DIRECT conv kernels run "
+                               "(conv_direct_fwd/dgrad/wgrad_kernel), not the implicit-GEMM MFMA ones",
                    "global_batch": Bsz * world, "parallelism": f"dp{world}",
                    "launch": "hipGraph replay" if args.graph else "eager"},
         "roofline": {"kernel": "whole step vs the conv layers' algorithmic HBM bytes (K<=72, Cout<=16: HBM/latency bound)",
@@ -665,16 +672,139 @@ def blas_threads():
         return os.cpu_count() or 1
 
 
+# ------------------------------------------------------------------------------------------------ headline
+def c2_forward_roofline(iters=50, sustain_s=2.0):
+    """The metric's "Linear fwd GFLOP/s vs MFMA peak" half: Linear(4096->4096) forward on a 4096-row batch, `iters`
+    launches each bracketed by a HIP-event pair on the launch stream (burst figure = what the roofline object reports),
+    then a >= `sustain_s` seconds back-to-back loop with one event pair around it (sustained clocks)."""
+    import torch
+    from neunet_hip._lib import call_hip_function, get_current_stream_ptr
+    n = 4096
+    g = torch.Generator(device="cuda").manual_seed(1002)
+    X = torch.rand(n, n, device="cuda", generator=g) * 2 - 1
+    W = (torch.rand(n, n, device="cuda", generator=g) * 2 - 1) / 64
+    b = (torch.rand(n, device="cuda", generator=g) * 2 - 1) / 64
+    O_ = torch.empty(n, n, device="cuda")
+    st = get_current_stream_ptr()
+
+    def fwd():
+        call_hip_function("nnhipLinearModuleForward", X, W, b, O_, n, n, n, st)
+
+    for _ in range(10):
+        fwd()
+    torch.cuda.synchronize()
+    t = EventTimer()
+    for _ in range(iters):
+        a, e = t.span()
+        a.record()
+        fwd()
+        e.record()
+    torch.cuda.synchronize()
+    burst_ms = t.mean_ms()
+    # sustained: calibrate the count from the burst time, one event pair around the whole loop
+    reps = max(100, int(sustain_s * 1e3 / burst_ms))
+    a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fwd()
+    e.record()
+    torch.cuda.synchronize()
+    sus_ms = a.elapsed_time(e) / reps
+    flops = 2.0 * n * n * n
+    return {"flops": flops, "burst_ms": burst_ms, "sustained_ms": sus_ms, "sustained_launches": reps,
+            "burst_tflops": flops / (burst_ms * 1e-3) / 1e12, "sustained_tflops": flops / (sus_ms * 1e-3) / 1e12}
+
+
+def workload_headline(args, rank, world):
+    """BASELINE.json's metric in one run: C4 GPT-tiny step (value), C2 Linear forward vs MFMA peak (roofline), C1
+    MNIST-MLP samples/s and the C2 step (also)."""
+    import copy
+    res = workload_c4(args, rank, world)
+    c4_roof = res.pop("roofline")
+    fwd = c2_forward_roofline()
+    res["roofline"] = {
+        "kernel": "gemm_f32_kernel<32,k-major,k-major> -- C2 Linear(4096->4096) forward, batch 4096 (the GEMM family that is "
+                  "~86 % of the C4 step's device time)",
+        "bound": "mfma", "achieved": round(fwd["burst_tflops"], 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(fwd["burst_tflops"] / PEAK_F32_MFMA_TFLOPS, 4), "traffic": read_traffic("gemm_fwd_c2"),
+        "flops_per_launch": fwd["flops"], "avg_launch_ms": round(fwd["burst_ms"], 4),
+        "sustained": {"tflops": round(fwd["sustained_tflops"], 2), "frac": round(fwd["sustained_tflops"] / PEAK_F32_MFMA_TFLOPS, 4),
+                      "avg_launch_ms": round(fwd["sustained_ms"], 4), "launches": fwd["sustained_launches"]},
+    }
+    also = {"c4_gemm": {"what": "whole C4 step, GEMM-equivalent flops (Linear fwd/dX/dW + attention) / device step time",
+                        "tflops": c4_roof["achieved"], "frac_of_mfma_peak": c4_roof["frac"],
+                        "flops_per_step": c4_roof["flops_per_step"], "avg_step_device_ms": c4_roof["avg_step_device_ms"]}}
+    # C1: MNIST-MLP, sustained
+    a1 = copy.copy(args)
+    a1.steps, a1.warmup = args.c1_steps, 20
+    r1 = workload_c1(a1, rank, world)
+    also["c1"] = {"workload": r1["config"]["workload"], "samples_per_s": round(r1["samples_per_step"] * a1.steps / r1["dt"], 1),
+                  "ms_per_step": round(r1["dt"] / a1.steps * 1e3, 5), "steps": a1.steps,
+                  "device_ms_per_step": r1["roofline"].get("avg_step_device_ms"), "launch": r1["config"].get("launch")}
+    # C2: the whole Linear training step
+    a2 = copy.copy(args)
+    a2.steps, a2.warmup = 20, 5
+    r2 = workload_c2(a2, rank, world)
+    also["c2"] = {"workload": r2["config"]["workload"], "samples_per_s": round(r2["samples_per_step"] * a2.steps / r2["dt"], 1),
+                  "ms_per_step": round(r2["dt"] / a2.steps * 1e3, 4), "linear_fwd_tflops_in_step": r2["extra"]["linear_fwd_tflops"],
+                  "linear_bwd_tflops_in_step": r2["extra"]["linear_bwd_tflops"]}
+    res["extra"]["also"] = also
+    return res
+
+
+def cpu_headline(seconds):
+    out = cpu_c4(seconds)
+    c1 = cpu_c1(3.0)
+    out["also_c1"] = {"value": c1["value"], "unit": c1["unit"], "sample": c1["sample"]}
+    return out
+
+
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` without a torchrun environment: start N ranks (one per GPU) of this same script."""
+    import socket
+    import subprocess
+    import torch
+    ngpu = torch.cuda.device_count()
+    if ngpu < args.gpus and os.environ.get("NNHIP_ALLOW_OVERSUBSCRIBE", "0") != "1":
+        print(f"bench.py: --gpus {args.gpus} but only {ngpu} GPU(s) are visible (set NNHIP_ALLOW_OVERSUBSCRIBE=1 to run "
+              f"{args.gpus} ranks on them over gloo for a functional check)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if ngpu < args.gpus:
+        env.setdefault("NNHIP_DIST_BACKEND", "gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(respawn_under_torchrun(args))
     import torch
     from neunet_hip.distributed import init_process_group
     import neunet_hip
     rank, world = init_process_group()
-    if world != args.gpus and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)", file=sys.stderr)
+        sys.exit(2)
     neunet_hip.load_library()
-    wl = {"c1": workload_c1, "c2": workload_c2, "c3": workload_c3, "c4": workload_c4, "c5": workload_c5}[args.workload]
+    rccl_ranks = 1
+    if world > 1:
+        import torch.distributed as dist
+        probe = torch.ones(1, device="cuda")
+        dist.all_reduce(probe)                          # a real collective before anything is reported
+        rccl_ranks = int(round(float(probe.item())))
+        if rank == 0:
+            print(f"[bench] backend={dist.get_backend()} world={dist.get_world_size()} all-reduce(1)={rccl_ranks}",
+                  file=sys.stderr)
+    wl = {"headline": workload_headline, "c1": workload_c1, "c2": workload_c2, "c3": workload_c3, "c4": workload_c4,
+          "c5": workload_c5}[args.workload]
     res = wl(args, rank, world)
     dt = res["dt"]
     value = res["samples_per_step"] * args.steps / dt
@@ -683,12 +813,16 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": res["config"],
-        "roofline": res["roofline"],
+        "roofline": res["roofline"], "rccl_ranks": rccl_ranks,
     }
+    if world > 1:
+        import torch.distributed as dist
+        out["dist_backend"] = dist.get_backend()
     out.update(res.get("extra", {}))
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = {"c1": cpu_c1, "c2": cpu_c2, "c3": cpu_c3, "c4": cpu_c4, "c5": cpu_c5}[args.workload](args.cpu_seconds)
+            out["cpu_baseline"] = {"headline": cpu_headline, "c1": cpu_c1, "c2": cpu_c2, "c3": cpu_c3, "c4": cpu_c4,
+                                   "c5": cpu_c5}[args.workload](args.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -630,18 +630,19 @@ __device__ __forceinline__ void count_labels(const T* __restrict__ lab, int64_t 
     };
     int64_t done = 0;
     if constexpr (sizeof(T) == 4) {
-        if ((reinterpret_cast<uintptr_t>(lab) & 15u) == 0) {   // 4 labels per load: 8192 labels = ONE batch of 8 loads for 256 threads
+        if ((reinterpret_cast<uintptr_t>(lab) & 15u) == 0) {   // 4 labels per load: 8192 labels = 2 batches of 4 loads for 256 threads
             const int4* l4 = reinterpret_cast<const int4*>(lab);
             const int64_t n4 = rows >> 2;
-            for (int64_t base = 0; base < n4; base += (int64_t)BS * U) {
-                int4 v[U];
+            constexpr int U4 = 4;                                // 16 registers: the prologue must not set the kernel's occupancy
+            for (int64_t base = 0; base < n4; base += (int64_t)BS * U4) {
+                int4 v[U4];
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
+                for (int u = 0; u < U4; ++u) {
                     const int64_t i = base + (int64_t)u * BS + threadIdx.x;
                     v[u] = i < n4 ? l4[i] : make_int4((int)ignore, (int)ignore, (int)ignore, (int)ignore);
                 }
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
+                for (int u = 0; u < U4; ++u) {
                     const int64_t i = base + (int64_t)u * BS + threadIdx.x;
                     if (i < n4) { one(v[u].x); one(v[u].y); one(v[u].z); one(v[u].w); }
                 }
@@ -734,8 +735,11 @@ __global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void ce_rows_kernel(const
     const int64_t step = (int64_t)gridDim.x * RPB;
     const int64_t row0 = (int64_t)blockIdx.x * RPB + slot;
     // the first row's loads are issued BEFORE the denominator is counted: the count's label loads then travel in the
-    // shadow of the row's HBM latency instead of in front of it
-    RowTile<TPR, NV, VEC> r;
+    // shadow of the row's HBM latency instead of in front of it.  PRE: while a row is reduced and stored, the block's NEXT
+    // row is already being loaded into a second tile -- a persistent block otherwise has nothing in flight between its
+    // rows (cold HBM: 4 resident blocks per CU x one 16 KB row is not enough to cover ~2 us of latency).
+    constexpr bool PRE = NV <= 4;
+    RowTile<TPR, NV, VEC> r, rn;
     if (row0 < a.rows) r.load(a.logits + row0 * a.ld, a.cols, t, -INFINITY);
     float scale, denom;
     ce_prologue<BS>(a, red, ired, scale, denom);
@@ -746,7 +750,11 @@ __global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void ce_rows_kernel(const
         const float wy = valid ? (a.cw ? a.cw[label] : 1.f) : 0.f;
         // read the label logit before anything is overwritten (in-place mode)
         const float xl = valid ? a.logits[row * a.ld + label] : 0.f;
-        if (row != row0) r.load(a.logits + row * a.ld, a.cols, t, -INFINITY);
+        if constexpr (PRE) {
+            if (row + step < a.rows) rn.load(a.logits + (row + step) * a.ld, a.cols, t, -INFINITY);
+        } else {
+            if (row != row0) r.load(a.logits + row * a.ld, a.cols, t, -INFINITY);
+        }
         float m = r.x[0];
 #pragma unroll
         for (int e = 1; e < r.NE; ++e) m = fmaxf(m, r.x[e]);
@@ -776,6 +784,10 @@ __global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void ce_rows_kernel(const
             for (int e = 0; e < r.NE; ++e) r.x[e] = 0.f;
         }
         r.store(a.dlogits + row * a.ld, a.cols, t);
+        if constexpr (PRE) {
+#pragma unroll
+            for (int e = 0; e < r.NE; ++e) r.x[e] = rn.x[e];
+        }
     }
     if constexpr (RPB > 1) {                                  // row slots -> one block sum, in slot order
         if (a.loss_out) {

@@ -108,6 +108,12 @@ class GraphedTrainStep:
                 bucket._capture_cb = None
         cur.wait_stream(side_stream)
 
+    def release(self):
+        """Drop the captured graphs and unlock the library workspace (call when this step object is retired and other
+        shapes are going to run)."""
+        self.pieces, self.g_opt = [], None
+        call_hip_function("nnhipWorkspaceLock", 0)
+
     def _addresses(self):
         ptrs = [p.data.data_ptr() for p in self.bucket.params]
         ptrs += [v.data_ptr() for v in self.bucket.views]

@@ -95,3 +95,118 @@ def test_dp2_equals_full_batch(overlap):
     for a, b, r in zip(got[0], got[1], ref):
         np.testing.assert_array_equal(a, b)                         # replicas stay bit-identical
         np.testing.assert_allclose(a, r, rtol=1e-4, atol=1e-5)      # and equal the single-process full batch
+
+
+# ---- hipGraph-replayed DP step: 'sum' loss per rank, device-side target count in the bucket, divisor inside Adam ----------
+def _run_graphed(rank, world, port, q, overlap, backend="gloo", graphed=True):
+    """The bench's C4 data-parallel recipe at toy size.  world > 1: every rank back-propagates CrossEntropy(reduction='sum',
+    ignore_index=0) on its shard, a kernel writes the shard's non-ignored count into the bucket's extra slot, the bucket
+    (cut into segments, exchanged asynchronously between the pieces of the captured backward pass when overlap=True) is
+    SUM-all-reduced, and the fused optimizer divides by the all-reduced count -- no host read anywhere.
+    world == 1: plain 'mean' loss, eager or graphed.  Sequence: 1 warm-up step on batch 0, then batches 0, 1, 2."""
+    import neunet_hip as hip
+    import neunet_hip.nn as nn
+    from neunet_hip._lib import call_hip_function, get_current_stream_ptr
+    from neunet_hip.distributed import GradBucket, shard_batch
+    from neunet_hip.graph import GraphedTrainStep
+    from neunet_hip.optim import AdamW
+    dev = rank if backend == "nccl" else 0
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    model = _build(hip)
+    params = model.parameters()
+    bucket = GradBucket(params, extra_scalars=1, overlap=overlap and world > 1, segment_bytes=1 << 12)
+    opt = AdamW(params, lr=1e-2, weight_decay=1e-2)
+    loss_fn = nn.CrossEntropyLoss(ignore_index=0, reduction="sum" if world > 1 else "mean")
+    if world > 1:
+        opt.grad_divisor = bucket.extra
+    X, Y = _data()
+    lo, hi = shard_batch(32, rank, world)
+    xs = hip.Tensor(X[0, lo:hi], device="cuda", requires_grad=True)
+    ys = hip.Tensor(Y[0, lo:hi], dtype=np.int32, requires_grad=False, device="cuda")
+
+    def fb():
+        xs.grad = None
+        loss = loss_fn(model(xs), ys)
+        if world > 1:
+            call_hip_function("nnhipCrossEntropyDenominator", ys.data, 4, ys.data.numel(), 0, None, 10, None, bucket.extra,
+                              get_current_stream_ptr())
+        loss.backward()
+        return loss
+
+    def eager():
+        opt.zero_grad()
+        fb()
+        bucket.all_reduce()
+        opt.step()
+
+    if graphed:
+        step = GraphedTrainStep(fb, opt, bucket, warmup=1, world=world)
+        n_pieces = len(step.pieces)
+    else:
+        eager()
+        step, n_pieces = eager, 0
+    for s in range(3):
+        xs.data.copy_(torch.from_numpy(X[s, lo:hi]))
+        ys.data.copy_(torch.from_numpy(Y[s, lo:hi]))
+        if s == 1 and graphed:
+            opt.lr = 5e-3            # an LR change between replays must take effect (device-side hyper-parameters)
+        elif s == 1:
+            opt.lr = 5e-3
+        step()
+    torch.cuda.synchronize()
+    res = [p.numpy().copy() for p in params]
+    if graphed:
+        step.release()
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+    if q is not None:
+        q.put((rank, res, n_pieces))
+    return res
+
+
+def _spawn2(target, args):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, 2, port, q) + args) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return {g[0]: g[1:] for g in got}
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_dp2_graphed_sum_loss_with_device_count_equals_full_batch_mean(overlap):
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no HIP device is visible")
+    got = _spawn2(_run_graphed, (overlap,))
+    ref = _run_graphed(0, 1, 0, None, False, graphed=False)          # one process, full batch, eager, 'mean' loss
+    ref_g = _run_graphed(0, 1, 0, None, False, graphed=True)         # ... and the same through one captured graph
+    if overlap:
+        assert got[0][1] > 1                                         # the backward pass really was cut into pieces
+    for a, b, r, rg in zip(got[0][0], got[1][0], ref, ref_g):
+        np.testing.assert_array_equal(a, b)                          # replicas stay bit-identical
+        np.testing.assert_allclose(a, r, rtol=1e-4, atol=1e-5)       # and equal the single-process full batch
+        np.testing.assert_allclose(rg, r, rtol=1e-5, atol=1e-6)      # graph replay (incl. the LR change) == eager
+
+
+def test_dp2_nccl_when_two_gpus_are_visible():
+    """The same graphed, overlapped step over RCCL (backend nccl), one GPU per rank.  Skips on a 1-GPU box."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no HIP device is visible")
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL over xGMI); the driver's multi-GPU box runs it")
+    got = _spawn2(_run_graphed, (True, "nccl"))
+    ref = _run_graphed(0, 1, 0, None, False, graphed=False)
+    for a, b, r in zip(got[0][0], got[1][0], ref):
+        np.testing.assert_array_equal(a, b)
+        np.testing.assert_allclose(a, r, rtol=1e-4, atol=1e-5)
