@@ -54,7 +54,9 @@ struct GemmParams {
     const float* addend;  // [M, ldc] or null: C = act(alpha*AB + bias + addend)  (residual / gradient accumulation)
     float* asum;          // CS variants: asum[m] = sum_k A[m,k] (Linear: db = column sums of dO, fused into dW = dO^T X)
     float* asum_slab;     // split-K partials [splitk][M]
-    int skew;             // 1: the first 256 blocks run at raised wave priority (see the kernel)
+    int skew;             // experiments: 1/2 = raised wave priority for every other dispatch round / block octet,
+                          // 3 = the second workgroup slot of a CU starts `skew_sleeps` x ~0.9 us late (see the kernel)
+    int skew_sleeps;
 };
 
 constexpr int BM = 128, BN = 128, NT = 256;
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const 
     // prologue / epilogue of a grid that is a single generation of tiles (all of GPT-tiny's forward GEMMs).  Raising the
     // priority of every other dispatch round (blocks are dealt out one per CU per round of 256) lets the favoured
     // block take the matrix pipe first and finish early; its epilogue then overlaps the partner's K loop.
-    if (p.skew) {
+    if (p.skew == 1 || p.skew == 2) {
         const int sel = p.skew == 2 ? ((blockIdx.x >> 3) & 1) : ((blockIdx.x >> 8) & 1);
         if (sel) __builtin_amdgcn_s_setprio(0);
         else __builtin_amdgcn_s_setprio(2);
@@ -266,6 +268,14 @@ __global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const 
     const float* __restrict__ Z = p.zeros;
     g2r<BK, AKC, VEC>(ra, A, p.lda, p.M, kend, m0, kbeg, tid, nk > 0, Z);
     g2r<BK, BKC, VEC>(rb, B, p.ldb, p.N, kend, n0, kbeg, tid, nk > 0, Z);
+    if (p.skew == 3) {
+        // HW_ID.TG_ID (bits 19:16): the workgroup slot on this CU.  The odd slot waits with its first tile already in
+        // flight, so the two co-resident blocks run phase-shifted: the early one's store-bound epilogue overlaps the late
+        // one's K loop, and the late one's prologue latency is hidden behind the early one's first iterations.
+        const unsigned tg = __builtin_amdgcn_s_getreg(4 | (16 << 6) | (3 << 11));
+        if (tg & 1u)
+            for (int i = 0; i < p.skew_sleeps; ++i) __builtin_amdgcn_s_sleep(32);
+    }
     r2s<BK, AKC>(ra, smem, tid);
     r2s<BK, BKC>(rb, smem + TA::SIZE, tid);
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -537,7 +547,9 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
     p.splitk = 1; p.k_per_split = ceil_div(K > 0 ? K : 1, BK) * BK; p.slab = nullptr;
     p.asum = asum; p.asum_slab = nullptr; p.addend = addend; p.dswish = dswish;
     static const int skew_sel = []() { const char* e = getenv("NNHIP_GEMM_SKEW"); return e ? atoi(e) : 0; }();
+    static const int skew_sleeps = []() { const char* e = getenv("NNHIP_GEMM_SKEW_SLEEPS"); return e ? atoi(e) : 8; }();
     p.skew = skew_sel;
+    p.skew_sleeps = skew_sleeps;
     p.zeros = zero_block();
     if (!p.zeros) { set_last_error("zero block allocation failed"); return NNHIP_ENOMEM; }
 

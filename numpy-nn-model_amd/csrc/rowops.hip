@@ -83,8 +83,8 @@ __device__ __forceinline__ float row_max(float v, float* red) {
 #define ROW_PROLOGUE(TPR)                                                     \
     __shared__ float red[16];                                                 \
     constexpr int RPB = (TPR >= 256) ? 1 : 256 / TPR;                         \
-    const int t = threadIdx.x % TPR;                                          \
-    const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / TPR;        \
+    const int t = RPB > 1 ? threadIdx.x % TPR : threadIdx.x;                  \
+    const int64_t row = (int64_t)blockIdx.x * RPB + (RPB > 1 ? threadIdx.x / TPR : 0); /* uniform when a block owns one row */ \
     if (TPR == 64 && row >= rows) return; /* wave-uniform; no block barriers in the TPR=64 path */ \
     (void)red;
 
@@ -404,7 +404,7 @@ __global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void rmsnorm_bwd_rows(
     __shared__ float red[32];
     __shared__ float4 fin_lds[RPB > 1 ? 256 : 1];
     const int t = threadIdx.x % TPR;
-    const int rslot = threadIdx.x / TPR;
+    const int rslot = RPB > 1 ? threadIdx.x / TPR : 0;   // a compile-time 0 keeps the row pointers in scalar registers
     RowTile<TPR, NV, VEC> wt, adw, adb;
     wt.load(w, cols, t, 0.f);
 #pragma unroll
@@ -731,7 +731,7 @@ __global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void ce_rows_kernel(const
     __shared__ float red[16];
     __shared__ int ired[17];
     const int t = threadIdx.x % TPR;
-    const int slot = threadIdx.x / TPR;
+    const int slot = RPB > 1 ? threadIdx.x / TPR : 0;    // a compile-time 0 keeps the row pointers in scalar registers
     const int64_t step = (int64_t)gridDim.x * RPB;
     const int64_t row0 = (int64_t)blockIdx.x * RPB + slot;
     // the first row's loads are issued BEFORE the denominator is counted: the count's label loads then travel in the

@@ -33,6 +33,8 @@ from ._lib import call_hip_function
 
 
 class GraphedTrainStep:
+    _live = 0          # captured steps alive in this process: the library workspace stays locked while > 0
+
     def __init__(self, forward_backward, optimizer, bucket, warmup: int = 3, world: int = 1, pre_optim=None,
                  group=None, check_every: int = 256):
         import torch
@@ -75,6 +77,8 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         # the captured kernels hold these addresses
         self._addr = self._addresses()
+        self._locked = True
+        GraphedTrainStep._live += 1
         call_hip_function("nnhipWorkspaceLock", 1)
 
     # ---- capture of the overlapped variant: one graph per bucket segment ------------------------------------------
@@ -112,7 +116,18 @@ class GraphedTrainStep:
         """Drop the captured graphs and unlock the library workspace (call when this step object is retired and other
         shapes are going to run)."""
         self.pieces, self.g_opt = [], None
-        call_hip_function("nnhipWorkspaceLock", 0)
+        if getattr(self, "_locked", False):
+            self._locked = False
+            GraphedTrainStep._live -= 1
+            if GraphedTrainStep._live <= 0:
+                GraphedTrainStep._live = 0
+                call_hip_function("nnhipWorkspaceLock", 0)
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
 
     def _addresses(self):
         ptrs = [p.data.data_ptr() for p in self.bucket.params]
