@@ -222,6 +222,13 @@ __global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const 
     // prologue / epilogue of a grid that is a single generation of tiles (all of GPT-tiny's forward GEMMs).  Raising the
     // priority of every other dispatch round (blocks are dealt out one per CU per round of 256) lets the favoured
     // block take the matrix pipe first and finish early; its epilogue then overlaps the partner's K loop.
+    if (p.skew == 3) {
+        // HW_ID.TG_ID (bits 19:16): the workgroup slot on this CU.  The odd slot starts late, so the two co-resident blocks
+        // run phase-shifted: the early one's store-bound epilogue overlaps the late one's K loop.
+        const unsigned tg = __builtin_amdgcn_s_getreg(4 | (16 << 6) | (3 << 11));
+        if (tg & 1u)
+            for (int i = 0; i < p.skew_sleeps; ++i) __builtin_amdgcn_s_sleep(32);
+    }
     if (p.skew == 1 || p.skew == 2) {
         const int sel = p.skew == 2 ? ((blockIdx.x >> 3) & 1) : ((blockIdx.x >> 8) & 1);
         if (sel) __builtin_amdgcn_s_setprio(0);
@@ -268,14 +275,6 @@ __global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const 
     const float* __restrict__ Z = p.zeros;
     g2r<BK, AKC, VEC>(ra, A, p.lda, p.M, kend, m0, kbeg, tid, nk > 0, Z);
     g2r<BK, BKC, VEC>(rb, B, p.ldb, p.N, kend, n0, kbeg, tid, nk > 0, Z);
-    if (p.skew == 3) {
-        // HW_ID.TG_ID (bits 19:16): the workgroup slot on this CU.  The odd slot waits with its first tile already in
-        // flight, so the two co-resident blocks run phase-shifted: the early one's store-bound epilogue overlaps the late
-        // one's K loop, and the late one's prologue latency is hidden behind the early one's first iterations.
-        const unsigned tg = __builtin_amdgcn_s_getreg(4 | (16 << 6) | (3 << 11));
-        if (tg & 1u)
-            for (int i = 0; i < p.skew_sleeps; ++i) __builtin_amdgcn_s_sleep(32);
-    }
     r2s<BK, AKC>(ra, smem, tid);
     r2s<BK, BKC>(rb, smem + TA::SIZE, tid);
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);

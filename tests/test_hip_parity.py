@@ -550,6 +550,19 @@ def test_cross_entropy_class_weights_and_label_dtypes(hip, rows, C, reduction, l
         assert np.all(host(x.grad)[labels == 0] == 0)
 
 
+@pytest.mark.parametrize("reduction", ["mean", "sum", "none"])
+def test_cross_entropy_class_weights_golden(hip, golden, reduction):
+    """neunet.nn.CrossEntropyLoss(weight=w, ignore_index=-100) of the reference, int64 labels (golden ce_weighted)."""
+    import neunet_hip.nn as nn
+    g = golden("ce_weighted")
+    x = T(hip, g["logits"])
+    y = T(hip, g["labels"], dtype=np.int64, requires_grad=False)
+    loss = nn.CrossEntropyLoss(weight=hip.Tensor(g["weight"]), ignore_index=int(g["ignore_index"]), reduction=reduction)(x, y)
+    np.testing.assert_allclose(host(loss.data).reshape(-1), g[f"loss_{reduction}"], rtol=1e-5, atol=1e-5)
+    loss.backward()
+    np.testing.assert_allclose(host(x.grad), g[f"dlogits_{reduction}"], rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("inplace", [False, True])
 @pytest.mark.parametrize("rows,C", [(16, 10), (300, 2000)])      # single-block kernel / persistent kernel
 def test_cross_entropy_out_of_range_label_is_inert(hip, rows, C, inplace):
@@ -1207,6 +1220,34 @@ def test_gpt_tiny_step_golden(hip, golden, fused):
         #     softmax is shift-invariant -- turns rounding noise into a full +-lr step in BOTH implementations)
         sig = np.abs(g[f"g{i}"]) > 1e-5
         np.testing.assert_allclose(got[sig], g[f"p_after{i}"][sig], rtol=1e-4, atol=2e-5, err_msg=f"param {i}")
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_reference_checkpoint_loads_and_reproduces_the_reference_logits(hip, golden, fused, tmp_path):
+    """a checkpoint written BY THE REFERENCE (neunet.save(model.state_dict()) -> pickle of an OrderedDict of
+    NumPy arrays, neunet/__init__.py:26-29, nn/modules.py:76-86; tests/golden/gpt_tiny_state.pkl) loads through
+    neunet_hip.load + Module.load_state_dict and the HIP forward reproduces the reference's logits; our own
+    save(state_dict()) round-trips to the identical dictionary (same keys, same order, same arrays)."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import gpt_tiny
+    from conftest import GOLDEN
+    g = golden("gpt_tiny")
+    V, D, H, F, L = [int(v) for v in g["cfg"]]
+    np.random.seed(99)                                           # a different init: everything must come from the file
+    model = gpt_tiny.build_gpt(V, D, H, F, L, pad_idx=0, max_len=64, fused=fused)
+    sd = hip.load(os.path.join(GOLDEN, "gpt_tiny_state.pkl"))
+    assert list(model.state_dict()) == list(sd)                  # the reference's key names, in its order
+    model.load_state_dict(sd)
+    out, _ = model.forward(g["batch"][:, :-1])
+    np.testing.assert_allclose(host(out.data), g["logits"], rtol=1e-4, atol=1e-4)
+    path = str(tmp_path / "ours.pkl")
+    hip.save(model.state_dict(), path)
+    back = hip.load(path)
+    assert list(back) == list(sd)
+    for k in sd:
+        assert isinstance(back[k], np.ndarray) and back[k].dtype == sd[k].dtype
+        np.testing.assert_array_equal(back[k], sd[k], err_msg=k)
 
 
 @pytest.mark.parametrize("dropout,fused", [(0.0, True), (0.1, True), (0.0, False)])

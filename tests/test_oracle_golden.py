@@ -259,3 +259,59 @@ def test_conv_classifier_step(golden):
     # channel mean one-for-one); step-1 statistics are pinned exactly by test_vision_ops
     np.testing.assert_allclose(model.rm, g["rm"], rtol=1e-3, atol=2e-3)
     np.testing.assert_allclose(model.rv, g["rv"], rtol=1e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("reduction", ["mean", "sum", "none"])
+def test_cross_entropy_class_weights(golden, reduction):
+    """CrossEntropyLoss(weight=w) of the reference (losses.py:93-118), int64 labels, ignored rows."""
+    g = golden("ce_weighted")
+    loss, dl = O.cross_entropy_forward_backward(g["logits"], g["labels"], g["weight"], int(g["ignore_index"]), reduction)
+    np.testing.assert_allclose(np.reshape(loss, -1), g[f"loss_{reduction}"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(dl, g[f"dlogits_{reduction}"], rtol=1e-5, atol=1e-7)
+    assert np.all(dl[g["labels"] == int(g["ignore_index"])] == 0)
+
+
+def test_reference_written_checkpoint_matches_the_gpt_fixture(golden):
+    """tests/golden/gpt_tiny_state.pkl was written by the REFERENCE (neunet.save(model.state_dict()),
+    neunet/__init__.py:26-29, nn/modules.py:76-86).  Its values, walked in key order, are the p{i} arrays of the gpt_tiny
+    fixture in Module.parameters() order -- so the GPU test that loads it through load_state_dict starts from the
+    reference's weights."""
+    import os
+    import pickle
+    from conftest import GOLDEN
+    g = golden("gpt_tiny")
+    with open(os.path.join(GOLDEN, "gpt_tiny_state.pkl"), "rb") as f:
+        sd = pickle.load(f)
+    assert len(sd) == int(g["n_params"])
+    keys = list(sd)
+    assert keys[0] == "decoder.token_embedding.weight" and keys[-1] == "decoder.fc_out.bias"
+    assert "decoder.layers.0.self_attn.wq.weight" in sd and "decoder.layers.1.cross_attn.fc.bias" in sd
+    for i, k in enumerate(keys):
+        np.testing.assert_array_equal(sd[k], g[f"p{i}"], err_msg=k)
+
+
+def test_fixtures_regenerate_bit_for_bit(tmp_path):
+    """Every generator in tools/gen_golden.py seeds the global np.random that the reference layers initialise from, so
+    re-running it against /root/reference reproduces every committed fixture exactly (build container only)."""
+    import os
+    import pickle
+    import subprocess
+    import sys
+    from conftest import GOLDEN, ROOT
+    if not os.path.isdir("/root/reference/neunet"):
+        pytest.skip("/root/reference is only present in the build container")
+    out = str(tmp_path / "golden")
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_golden.py"), "--out", out], check=True,
+                   stdout=subprocess.DEVNULL, timeout=600)
+    names = sorted(f for f in os.listdir(GOLDEN) if f.endswith(".npz"))
+    assert names == sorted(f for f in os.listdir(out) if f.endswith(".npz"))
+    for f in names:
+        a, b = np.load(os.path.join(GOLDEN, f), allow_pickle=False), np.load(os.path.join(out, f), allow_pickle=False)
+        assert sorted(a.files) == sorted(b.files), f
+        for k in a.files:
+            np.testing.assert_array_equal(a[k], b[k], err_msg=f"{f}:{k}")
+    sa = pickle.load(open(os.path.join(GOLDEN, "gpt_tiny_state.pkl"), "rb"))
+    sb = pickle.load(open(os.path.join(out, "gpt_tiny_state.pkl"), "rb"))
+    assert list(sa) == list(sb)
+    for k in sa:
+        np.testing.assert_array_equal(sa[k], sb[k], err_msg=k)

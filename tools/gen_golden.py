@@ -26,14 +26,23 @@ from neunet.autograd import Tensor  # noqa: E402
 from neunet.optim import Adam, AdamW  # noqa: E402
 
 OUT = os.path.join(ROOT, "tests", "golden")
-os.makedirs(OUT, exist_ok=True)
 F32 = np.float32
+QUIET = False
 
 
 def save(name, **arrays):
+    os.makedirs(OUT, exist_ok=True)
     path = os.path.join(OUT, name + ".npz")
     np.savez_compressed(path, **arrays)
-    print(f"{name:28s} {os.path.getsize(path) / 1024:8.1f} KiB")
+    if not QUIET:
+        print(f"{name:28s} {os.path.getsize(path) / 1024:8.1f} KiB")
+
+
+def seed_layers(n):
+    """The reference layers draw their initial weights from the GLOBAL np.random (nn.Linear / Conv2d / Embedding
+    __init__): seed it at the top of every generator so every fixture regenerates bit for bit
+    (tests/test_oracle_golden.py::test_fixtures_regenerate_bit_for_bit)."""
+    np.random.seed(n)
 
 
 def T(a, **kw):
@@ -48,6 +57,7 @@ def set_linear(layer, W, b):
 
 # --------------------------------------------------------------------------- Linear
 def gen_linear():
+    seed_layers(100)
     rng = np.random.default_rng(11)
     for name, xshape, bias in [("linear_2d", (16, 24), True), ("linear_3d", (4, 6, 24), True),
                                ("linear_nobias", (16, 24), False)]:
@@ -68,6 +78,7 @@ def gen_linear():
 
 # --------------------------------------------------------------------------- activations
 def gen_activations():
+    seed_layers(101)
     rng = np.random.default_rng(12)
     X = (rng.standard_normal((8, 64)) * 2).astype(F32)
     dY = rng.standard_normal((8, 64)).astype(F32)
@@ -105,6 +116,7 @@ def gen_activations():
 
 # --------------------------------------------------------------------------- CrossEntropy
 def gen_ce():
+    seed_layers(102)
     rng = np.random.default_rng(13)
     cases = [("ce_mean", (16, 128), -100, "mean", 0), ("ce_sum", (16, 128), -100, "sum", 0),
              ("ce_none", (16, 128), -100, "none", 0),
@@ -128,8 +140,28 @@ def gen_ce():
              ignore_index=np.int64(ign), reduction=np.array(red))
 
 
+def gen_ce_weighted():
+    """CrossEntropyLoss(weight=...) (neunet/nn/losses.py:93-118) with ignored labels, the three reductions, int64 labels."""
+    seed_layers(150)
+    rng = np.random.default_rng(33)
+    rows, C = 24, 130                      # C >= 100 so that weight[-100] indexes (losses.py:115 quirk)
+    logits = (rng.standard_normal((rows, C)) * 2).astype(F32)
+    labels = rng.integers(0, C, rows).astype(np.int64)
+    labels[::5] = -100
+    w = rng.uniform(0.2, 3.0, C).astype(F32)
+    arrs = dict(logits=logits, labels=labels, weight=w, ignore_index=np.int64(-100))
+    for red in ("mean", "sum", "none"):
+        x = T(logits)
+        loss = nn.CrossEntropyLoss(weight=w.copy(), ignore_index=-100, reduction=red)(x, Tensor(labels, dtype=np.int64, requires_grad=False))
+        loss.backward()
+        arrs[f"loss_{red}"] = np.asarray(loss.data, dtype=F32).reshape(-1)
+        arrs[f"dlogits_{red}"] = x.grad
+    save("ce_weighted", **arrs)
+
+
 # --------------------------------------------------------------------------- RMSNorm
 def gen_rmsnorm():
+    seed_layers(103)
     rng = np.random.default_rng(14)
     for tag, shape, bias in [("rmsnorm_2d", (8, 64), False), ("rmsnorm_3d_bias", (2, 4, 64), True)]:
         X = rng.standard_normal(shape).astype(F32)
@@ -151,6 +183,7 @@ def gen_rmsnorm():
 
 # --------------------------------------------------------------------------- Conv2d
 def gen_conv():
+    seed_layers(104)
     rng = np.random.default_rng(15)
     cases = [
         ("conv2d_s2p1d2", (2, 3, 9, 9), 4, 3, (2, 2), (1, 1), (2, 2)),
@@ -179,6 +212,7 @@ def gen_conv():
 
 # --------------------------------------------------------------------------- Adam / AdamW
 def gen_adam():
+    seed_layers(105)
     rng = np.random.default_rng(16)
     shapes = [(8, 16), (1, 16), (5,)]
     for tag, cls, wd in [("adam_wd0", Adam, 0.0), ("adam_wd1e-2", Adam, 1e-2),
@@ -209,6 +243,7 @@ def gen_adam():
 
 # --------------------------------------------------------------------------- Linear->Swish
 def gen_linear_swish():
+    seed_layers(106)
     rng = np.random.default_rng(17)
     X = rng.uniform(-1, 1, (16, 24)).astype(F32)
     W = rng.uniform(-0.4, 0.4, (40, 24)).astype(F32)
@@ -225,6 +260,7 @@ def gen_linear_swish():
 
 # --------------------------------------------------------------------------- C1 MLP trajectory
 def gen_mlp():
+    seed_layers(107)
     """README.md:57-71 quick-start loop: 784->128->10, CE(mean), Adam(lr 1e-3), batch 32, 3 steps."""
     rng = np.random.default_rng(1001)
 
@@ -284,6 +320,7 @@ def _notebook_namespace():
 
 
 def gen_gpt():
+    seed_layers(108)
     ns = _notebook_namespace()
     rng = np.random.default_rng(18)
     # --- embedding with repeated ids (last-write-wins gradient)
@@ -324,6 +361,9 @@ def gen_gpt():
     batch[0, 2] = batch[0, 5]                       # repeated token ids inside one batch
     params = model.parameters()
     p0 = [p.data.copy() for p in params]
+    # a checkpoint written BY THE REFERENCE (neunet.save = pickle of state_dict(), neunet/__init__.py:26-29,
+    # nn/modules.py:76-86): data only (an OrderedDict of NumPy arrays under the reference's key names)
+    neunet.save(model.state_dict(), os.path.join(OUT, "gpt_tiny_state.pkl"))
     opt = Adam(params, lr=1.5e-4, betas=(0.9, 0.98), eps=1e-9)
     loss_fn = nn.CrossEntropyLoss(ignore_index=0)
     output, _ = model.forward(batch[:, :-1])
@@ -346,6 +386,7 @@ def gen_gpt():
 
 # --------------------------------------------------------------------------- conv classifier (config 5)
 def gen_vision():
+    seed_layers(109)
     import json
     rng = np.random.default_rng(19)
     X = (rng.standard_normal((2, 3, 7, 6)) * 2).astype(F32)
@@ -418,14 +459,22 @@ def gen_vision():
     save("conv_classifier", **arrs)
 
 
+GENERATORS = [gen_linear, gen_activations, gen_ce, gen_ce_weighted, gen_rmsnorm, gen_conv, gen_adam, gen_linear_swish, gen_mlp,
+              gen_gpt, gen_vision]
+
+
+def generate_all(out_dir=None, quiet=False):
+    global OUT, QUIET
+    if out_dir is not None:
+        OUT = out_dir
+    QUIET = quiet
+    for g in GENERATORS:
+        g()
+
+
 if __name__ == "__main__":
-    gen_linear()
-    gen_activations()
-    gen_ce()
-    gen_rmsnorm()
-    gen_conv()
-    gen_adam()
-    gen_linear_swish()
-    gen_mlp()
-    gen_gpt()
-    gen_vision()
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=None, help="write the fixtures here instead of tests/golden")
+    a = ap.parse_args()
+    generate_all(a.out)
