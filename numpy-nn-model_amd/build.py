@@ -25,7 +25,9 @@ ARCH = "gfx950"
 
 # MFMA kernels whose inner loops must not touch scratch memory: a harmless-looking edit (an extra branch between the
 # prologue loads and the first LDS store) once made the GEMM spill 144 B/lane and lose 30 % -- the build fails instead.
-NO_SPILL = {"gemm.hip": ("gemm_f32_kernel",), "attention.hip": ("attn_fwd_kernel", "attn_bwd_dkdv_kernel", "attn_bwd_dq_kernel")}
+# (regexes on the mangled names; the GEMM's scalar-load variants -- VEC = false, unaligned operands -- are exempt.)
+NO_SPILL = {"gemm.hip": (r"gemm_f32_kernelILi\d+ELb[01]ELb[01]ELb1E",),
+            "attention.hip": ("attn_fwd_kernel", "attn_bwd_dkdv_kernel", "attn_bwd_dq_kernel")}
 
 
 def check_no_spills(src, remarks):
@@ -36,7 +38,7 @@ def check_no_spills(src, remarks):
         if m:
             name = m.group(1)
         m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
-        if m and name and int(m.group(1)) > 0 and any(k in name for k in NO_SPILL[src]):
+        if m and name and int(m.group(1)) > 0 and any(re.search(k, name) for k in NO_SPILL[src]):
             bad.append((name, int(m.group(1))))
     # pass real diagnostics through (a remark is followed by its source line and a caret line: drop those too)
     lines, out, skip = remarks.splitlines(), [], 0
@@ -99,7 +101,11 @@ def build(force=False, debug=False, verbose=True):
         if r.returncode != 0:
             sys.stderr.write(r.stderr)
             raise subprocess.CalledProcessError(r.returncode, cmd)
-        check_no_spills(os.path.basename(src), r.stderr)
+        try:
+            check_no_spills(os.path.basename(src), r.stderr)
+        except Exception:
+            os.remove(obj)      # so that the next build checks again
+            raise
         return obj
 
     with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
