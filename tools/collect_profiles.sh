@@ -1,23 +1,30 @@
 #!/bin/bash
-# Run on the GPU box (via gpurun): benches + rocprofv3 kernel stats + PMC passes into gpurun_out/.
-# Post-process locally with tools/prof_summary.py into profiles/.
+# Run on the GPU box (via gpurun): benches + rocprofv3 kernel stats + PMC passes into gpurun_out/<tag>/.
+# Post-process locally with tools/make_profiles.sh <tag> into profiles/.
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-/root/repo}
-mkdir -p $R/gpurun_out
+O=$R/gpurun_out/$TAG
+mkdir -p $O
 cd $R
-python tools/kbench.py > gpurun_out/kbench.log 2>&1
-python bench.py --steps 20 --warmup 5 > gpurun_out/bench_c2.json 2> gpurun_out/bench_c2.err
-python bench.py --workload c3 --steps 20 --warmup 5 > gpurun_out/bench_c3.json 2> gpurun_out/bench_c3.err
-python bench.py --workload c1 --steps 500 --warmup 50 > gpurun_out/bench_c1.json 2> gpurun_out/bench_c1.err
-python bench.py --workload c4 --steps 10 --warmup 3 > gpurun_out/bench_c4.json 2> gpurun_out/bench_c4.err
-python bench.py --workload c5 --steps 200 --warmup 20 > gpurun_out/bench_c5.json 2> gpurun_out/bench_c5.err
+python tools/kbench.py > $O/kbench.log 2>&1
+python tools/stream_roof.py > $O/stream_roof.txt 2>&1
+python bench.py --steps 20 --warmup 5 > $O/bench_headline.json 2> $O/bench_headline.err
+python bench.py --workload c2 --steps 20 --warmup 5 > $O/bench_c2.json 2> $O/bench_c2.err
+python bench.py --workload c3 --steps 20 --warmup 5 > $O/bench_c3.json 2> $O/bench_c3.err
+python bench.py --workload c1 --steps 500 --warmup 50 > $O/bench_c1.json 2> $O/bench_c1.err
+python bench.py --workload c4 --steps 10 --warmup 3 > $O/bench_c4.json 2> $O/bench_c4.err
+python bench.py --workload c5 --steps 200 --warmup 20 > $O/bench_c5.json 2> $O/bench_c5.err
 cd /tmp && export TMPDIR=/tmp
-for W in c1 c2 c3 c4 c5; do
-  S=30; [ $W = c4 ] && S=8; [ $W = c1 ] && S=200; [ $W = c5 ] && S=100
-  rocprofv3 --kernel-trace --stats -f csv -d $R/gpurun_out/prof_$W -o $W -- python $R/bench.py --workload $W --steps $S --warmup 5 --no-cpu-baseline > $R/gpurun_out/prof_$W.log 2>&1
+for W in headline c1 c2 c3 c4 c5; do
+  S=30; [ $W = c4 ] && S=8; [ $W = headline ] && S=8; [ $W = c1 ] && S=200; [ $W = c5 ] && S=100
+  rocprofv3 --kernel-trace --stats -f csv -d $O/prof_$W -o $W -- python $R/bench.py --workload $W --steps $S --warmup 5 --no-cpu-baseline > $O/prof_$W.log 2>&1
 done
 for W in c2 c3; do
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $R/gpurun_out/pmc_fetch_$W -o f -- python $R/bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_fetch_$W.log 2>&1
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $R/gpurun_out/pmc_write_$W -o w -- python $R/bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_write_$W.log 2>&1
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $O/pmc_fetch_$W -o f -- python $R/bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_fetch_$W.log 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $O/pmc_write_$W -o w -- python $R/bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_write_$W.log 2>&1
 done
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -f csv -d $R/gpurun_out/pmc_sq_c2 -o sq -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_sq_c2.log 2>&1
-ls $R/gpurun_out
+rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -f csv -d $O/pmc_sq_c2 -o sq -- python $R/bench.py --workload c2 --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_sq_c2.log 2>&1
+# keep the merge under the 64 MiB limit: drop the raw traces, keep stats + counter CSVs
+find $O -name "*_kernel_trace.csv" -size +2M -delete
+find $O -name "*.db" -delete
+du -sh $O

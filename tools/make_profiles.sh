@@ -1,13 +1,20 @@
 #!/bin/bash
-# Local post-processing of gpurun_out/ (rocprofv3 CSVs) into the tracked profiles/ directory.  Usage: tools/make_profiles.sh r01
-TAG=${1:-r01}; G=gpurun_out; P=profiles; mkdir -p $P
-for W in c1 c2 c3 c4 c5; do
-  python tools/prof_summary.py stats $G/prof_$W/${W}_kernel_stats.csv $P/${TAG}_${W}_kernel_stats.md "Round ${TAG#r} -- rocprofv3 --kernel-trace --stats -- python bench.py --workload $W --no-cpu-baseline (MI355X)"
+# Local post-processing of gpurun_out/<tag>/ (rocprofv3 CSVs) into the tracked profiles/ directory.  Usage: tools/make_profiles.sh r02
+TAG=${1:-r02}; G=gpurun_out/$TAG; P=profiles; mkdir -p $P
+for W in headline c1 c2 c3 c4 c5; do
+  F=$(find $G/prof_$W -name "*_kernel_stats.csv" | head -1)
+  [ -n "$F" ] && python tools/prof_summary.py stats $F $P/${TAG}_${W}_kernel_stats.md "Round ${TAG#r} -- rocprofv3 --kernel-trace --stats -- python bench.py --workload $W --no-cpu-baseline (MI355X)"
 done
-python tools/prof_summary.py pmc $G/pmc_sq_c2/sq_counter_collection.csv $P/${TAG}_c2_pmc_sq.md
-for W in c2 c3; do python tools/prof_summary.py pmc $G/pmc_fetch_$W/f_counter_collection.csv $G/pmc_write_$W/w_counter_collection.csv $P/${TAG}_${W}_pmc_hbm.md; done
-python tools/prof_summary.py traffic $G/pmc_fetch_c2/f_counter_collection.csv $G/pmc_write_c2/w_counter_collection.csv /tmp/t_c2.json "gemm_f32_kernel<32, true, true, true, false>=gemm_fwd_c2" "gemm_f32_kernel<32, true, false, true, false>=gemm_dx_c2" "gemm_f32_kernel<32, false, false, true, false>=gemm_dw_c2" "adamw_multi=adamw_c2" > /dev/null
-python tools/prof_summary.py traffic $G/pmc_fetch_c3/f_counter_collection.csv $G/pmc_write_c3/w_counter_collection.csv /tmp/t_c3.json "map1_kernel<SwishF>=swish_fwd_c3" "map2_kernel<SwishB>=swish_bwd_c3" "rmsnorm_fwd_rows=rmsnorm_fwd_c3" "rmsnorm_bwd_rows=rmsnorm_bwd_c3" "softmax_fwd_rows=softmax_fwd_c3" "softmax_bwd_rows=softmax_bwd_c3" "ce_fwd_bwd_rows=ce_c3" "adamw_multi=adamw_c3" > /dev/null
+SQ=$(find $G/pmc_sq_c2 -name "*counter_collection.csv" | head -1)
+[ -n "$SQ" ] && python tools/prof_summary.py pmc $SQ $P/${TAG}_c2_pmc_sq.md
+for W in c2 c3; do
+  FF=$(find $G/pmc_fetch_$W -name "*counter_collection.csv" | head -1); WW=$(find $G/pmc_write_$W -name "*counter_collection.csv" | head -1)
+  python tools/prof_summary.py pmc $FF $WW $P/${TAG}_${W}_pmc_hbm.md
+done
+FF=$(find $G/pmc_fetch_c2 -name "*counter_collection.csv" | head -1); WW=$(find $G/pmc_write_c2 -name "*counter_collection.csv" | head -1)
+python tools/prof_summary.py traffic $FF $WW /tmp/t_c2.json "gemm_f32_kernel<32, true, true, true, false>=gemm_fwd_c2" "gemm_f32_kernel<32, true, false, true, false>=gemm_dx_c2" "gemm_f32_kernel<32, false, false, true, false>=gemm_dw_c2" "adamw_multi=adamw_c2" > /dev/null
+FF=$(find $G/pmc_fetch_c3 -name "*counter_collection.csv" | head -1); WW=$(find $G/pmc_write_c3 -name "*counter_collection.csv" | head -1)
+python tools/prof_summary.py traffic $FF $WW /tmp/t_c3.json "map1_kernel<SwishF>=swish_fwd_c3" "map2_kernel<SwishB>=swish_bwd_c3" "rmsnorm_fwd_rows=rmsnorm_fwd_c3" "rmsnorm_bwd_rows=rmsnorm_bwd_c3" "softmax_fwd_rows=softmax_fwd_c3" "softmax_bwd_rows=softmax_bwd_c3" "ce_rows_kernel=ce_c3" "adamw_multi=adamw_c3" > /dev/null
 python - <<PY
 import json
 t = {}
@@ -22,5 +29,6 @@ json.dump(out, open('$P/pmc_traffic.json', 'w'), indent=1)
 for k, v in out.items():
     if not k.startswith('_'): print(f"{k:18s} {v/1e6:9.1f} MB")
 PY
-for W in c1 c2 c3 c4 c5; do cp $G/bench_$W.json $P/${TAG}_bench_$W.json; done
+for W in headline c1 c2 c3 c4 c5; do cp $G/bench_$W.json $P/${TAG}_bench_$W.json; done
 cp $G/kbench.log $P/${TAG}_kbench.txt
+cp $G/stream_roof.txt $P/${TAG}_stream_roof.txt
