@@ -117,6 +117,17 @@ int nnhipReLUBackward(float* dIn, const float* dOut, const float* out, int64_t s
 int nnhipLinearInputGradSwish(const float* dO, const float* W, const float* Z, float* dZ, int64_t rows,
                               int64_t in_features, int64_t out_features, float swish_beta, nnhipStream_t stream);
 
+/* The same for h = relu(z): dZ = (dO * W) (.) [F > 0] with F = the ReLU's forward output (activations.py:44-45); dZ must
+ * not alias F (F is still the Linear's input for its dW). */
+int nnhipLinearInputGradReLU(const float* dO, const float* W, const float* F, float* dZ, int64_t rows,
+                             int64_t in_features, int64_t out_features, nnhipStream_t stream);
+/* O = act(X*W^T + b), activation in the GEMM epilogue: 1 = swish(beta) without saving z, 2 = relu, 3 = sigmoid.
+ * One launch for what `act(Linear(x))` is on the reference's tape (linear.py:48-58 + activations.py); the host side
+ * uses it when an activation module is applied to a Linear output nobody else has looked at yet. */
+int nnhipLinearActivationForward(const float* X, const float* W, const float* b, float* O, int64_t rows,
+                                 int64_t in_features, int64_t out_features, int32_t activation, float beta,
+                                 nnhipStream_t stream);
+
 /* ---- a5 Swish  (replaces cudaSwishForward/Backward, swish.cu:50,65) ------------------------- */
 int nnhipSwishForward(float* out, const float* in, float beta, int64_t size, nnhipStream_t stream);
 int nnhipSwishBackward(float* dIn, const float* dOut, const float* in, float beta, int64_t size,

@@ -31,7 +31,7 @@ namespace nnhip {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { ACT_NONE = 0, ACT_SWISH = 1, ACT_RELU = 2 };
+enum { ACT_NONE = 0, ACT_SWISH = 1, ACT_RELU = 2, ACT_SIGMOID = 3 };
 
 struct GemmParams {
     const float* A;
@@ -50,7 +50,8 @@ struct GemmParams {
     int cvec;             // 1: C/bias/preact rows are 16-B aligned and N % 4 == 0 -> float4 epilogue
     int act;
     float beta;
-    const float* dswish;  // [M, ldc] or null: C = (alpha*AB + bias + addend) * swish'(dswish[m,n]; beta)  (may alias C)
+    const float* dswish;  // [M, ldc] or null: C = (alpha*AB + bias + addend) * act'(dswish[m,n])  (may alias C); act' per `dact`
+    int dact;             // 1: swish'(z; beta), dswish = z;  2: relu'(f) = [f > 0], dswish = the forward OUTPUT f
     const float* addend;  // [M, ldc] or null: C = act(alpha*AB + bias + addend)  (residual / gradient accumulation)
     float* asum;          // CS variants: asum[m] = sum_k A[m,k] (Linear: db = column sums of dO, fused into dW = dO^T X)
     float* asum_slab;     // split-K partials [splitk][M]
@@ -353,6 +354,9 @@ __global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const 
                         if (extra) {
                             if (is_add) {
                                 v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+                            } else if (p.dact == 2) {   // gradient through h = relu(z): mask by the forward output
+                                v.x = x.x > 0.f ? v.x : 0.f; v.y = x.y > 0.f ? v.y : 0.f;
+                                v.z = x.z > 0.f ? v.z : 0.f; v.w = x.w > 0.f ? v.w : 0.f;
                             } else {   // gradient through h = swish(z): the dX GEMM of the NEXT layer hands back dz
                                 v.x *= swish_grad_(x.x, p.beta); v.y *= swish_grad_(x.y, p.beta);
                                 v.z *= swish_grad_(x.z, p.beta); v.w *= swish_grad_(x.w, p.beta);
@@ -364,6 +368,8 @@ __global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const 
                             v.z *= sigmoid_fast_(p.beta * v.z); v.w *= sigmoid_fast_(p.beta * v.w);
                         } else if (p.act == ACT_RELU) {
                             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                        } else if (p.act == ACT_SIGMOID) {
+                            v.x = sigmoid_fast_(v.x); v.y = sigmoid_fast_(v.y); v.z = sigmoid_fast_(v.z); v.w = sigmoid_fast_(v.w);
                         }
                     }
                     *reinterpret_cast<float4*>(C + row * ldc + col) = v;
@@ -389,12 +395,17 @@ __global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const 
                 float v = to_slab ? acc[i][n][e] : p.alpha * acc[i][n][e] + bv;
                 if (!to_slab) {
                     if (p.addend) v += p.addend[c_off + row * ldc + col];
-                    if (p.dswish) v *= swish_grad_(p.dswish[c_off + row * ldc + col], p.beta);
+                    if (p.dswish) {
+                        const float x = p.dswish[c_off + row * ldc + col];
+                        v = p.dact == 2 ? (x > 0.f ? v : 0.f) : v * swish_grad_(x, p.beta);
+                    }
                     if (p.act == ACT_SWISH) {
                         if (p.preact) p.preact[c_off + row * ldc + col] = v;
                         v = v * sigmoid_fast_(p.beta * v);
                     } else if (p.act == ACT_RELU) {
                         v = fmaxf(v, 0.f);
+                    } else if (p.act == ACT_SIGMOID) {
+                        v = sigmoid_fast_(v);
                     }
                 }
                 C[row * ldc + col] = v;
@@ -412,7 +423,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
                                                             int splitk, int act, float beta, float alpha,
                                                             const float* __restrict__ asum_slab, float* __restrict__ asum,
                                                             const float* __restrict__ addend, int asum_blocks, int vec,
-                                                            const float* __restrict__ dswish) {
+                                                            const float* __restrict__ dswish, int dact) {
     const int64_t total = M * N;
     // the last `asum_blocks` blocks reduce the row-sum partials (their splitk dependent loads must not sit in front of
     // the main loop of the first blocks: that put +5 us on the critical path of every split-K dW)
@@ -431,12 +442,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         s *= alpha;
         if (bias) s += bias[n];
         if (addend) s += addend[m * ldc + n];
-        if (dswish) s *= swish_grad_(dswish[m * ldc + n], beta);
+        if (dswish) {
+            const float x = dswish[m * ldc + n];
+            s = dact == 2 ? (x > 0.f ? s : 0.f) : s * swish_grad_(x, beta);
+        }
         if (act == ACT_SWISH) {
             if (preact) preact[m * ldc + n] = s;
             s = s * sigmoid_fast_(beta * s);
         } else if (act == ACT_RELU) {
             s = fmaxf(s, 0.f);
+        } else if (act == ACT_SIGMOID) {
+            s = sigmoid_fast_(s);
         }
         return s;
     };
@@ -492,7 +508,7 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
                 int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, bool a_kmajor, bool b_kmajor,
                 int64_t batch1, int64_t sA, int64_t sB, int64_t sC, int64_t batch2, int64_t sA2,
                 int64_t sB2, int64_t sC2, float alpha, int act, float beta, hipStream_t st, float* asum = nullptr,
-                const float* addend = nullptr, const float* dswish = nullptr);
+                const float* addend = nullptr, const float* dswish = nullptr, int dact = 1);
 
 int gemm_f32(const float* A, const float* B, float* C, const float* bias, float* preact, int64_t M,
              int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, bool a_kmajor,
@@ -518,6 +534,13 @@ int gemm_f32_dswish(const float* A, const float* B, float* C, const float* Z, fl
                        ACT_NONE, beta, st, nullptr, nullptr, Z);
 }
 
+// C = (A B) * [F > 0]: the input gradient of a Linear whose input was h = relu(z), F = h (C must not alias F).
+int gemm_f32_drelu(const float* A, const float* B, float* C, const float* F, int64_t M, int64_t N, int64_t K,
+                   int64_t lda, int64_t ldb, int64_t ldc, bool a_kmajor, bool b_kmajor, hipStream_t st) {
+    return gemm_f32_ex(A, B, C, nullptr, nullptr, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, 1, 0, 0, 0, 1, 0, 0, 0, 1.0f,
+                       ACT_NONE, 1.f, st, nullptr, nullptr, F, 2);
+}
+
 int gemm_f32_asum(const float* A, const float* B, float* C, float* asum, int64_t M, int64_t N, int64_t K, int64_t lda,
                   int64_t ldb, int64_t ldc, bool b_kmajor, hipStream_t st) {
     return gemm_f32_ex(A, B, C, nullptr, nullptr, M, N, K, lda, ldb, ldc, false, b_kmajor, 1, 0, 0, 0, 1, 0, 0, 0, 1.0f,
@@ -528,7 +551,7 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
                 int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, bool a_kmajor, bool b_kmajor,
                 int64_t batch1, int64_t sA, int64_t sB, int64_t sC, int64_t batch2, int64_t sA2,
                 int64_t sB2, int64_t sC2, float alpha, int act, float beta, hipStream_t st, float* asum,
-                const float* addend, const float* dswish) {
+                const float* addend, const float* dswish, int dact) {
     const int64_t batch = batch1 * batch2;
     if (M <= 0 || N <= 0 || batch <= 0) return 0;
     if (addend && dswish) { set_last_error("gemm: addend and dswish are mutually exclusive"); return NNHIP_EINVAL; }
@@ -544,7 +567,7 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
     p.tiles_n = (int)ceil_div(N, BN);
     p.act = act; p.beta = beta;
     p.splitk = 1; p.k_per_split = ceil_div(K > 0 ? K : 1, BK) * BK; p.slab = nullptr;
-    p.asum = asum; p.asum_slab = nullptr; p.addend = addend; p.dswish = dswish;
+    p.asum = asum; p.asum_slab = nullptr; p.addend = addend; p.dswish = dswish; p.dact = dact;
     static const int skew_sel = []() { const char* e = getenv("NNHIP_GEMM_SKEW"); return e ? atoi(e) : 0; }();
     static const int skew_sleeps = []() { const char* e = getenv("NNHIP_GEMM_SKEW_SLEEPS"); return e ? atoi(e) : 8; }();
     p.skew = skew_sel;
@@ -618,7 +641,7 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
         int blocks = (int)(ceil_div(work, 256) < 2048 ? ceil_div(work, 256) : 2048);
         const int asum_blocks = asum ? (int)ceil_div(M, 256) : 0;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks + asum_blocks), dim3(256), 0, st, p.slab, C, preact,
-                           bias, M, N, ldc, p.splitk, act, beta, alpha, p.asum_slab, asum, addend, asum_blocks, rvec, dswish);
+                           bias, M, N, ldc, p.splitk, act, beta, alpha, p.asum_slab, asum, addend, asum_blocks, rvec, dswish, p.dact);
         NNHIP_LAUNCH_CHECK("splitk_reduce_kernel");
     }
     return 0;

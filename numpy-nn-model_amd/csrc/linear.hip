@@ -12,12 +12,14 @@ int gemm_f32_add(const float* A, const float* B, float* C, const float* bias, co
                  int64_t K, int64_t lda, int64_t ldb, int64_t ldc, bool a_kmajor, bool b_kmajor, hipStream_t st);
 int gemm_f32_dswish(const float* A, const float* B, float* C, const float* Z, float beta, int64_t M, int64_t N, int64_t K,
                     int64_t lda, int64_t ldb, int64_t ldc, bool a_kmajor, bool b_kmajor, hipStream_t st);
+int gemm_f32_drelu(const float* A, const float* B, float* C, const float* F, int64_t M, int64_t N, int64_t K,
+                   int64_t lda, int64_t ldb, int64_t ldc, bool a_kmajor, bool b_kmajor, hipStream_t st);
 int gemm_f32_asum(const float* A, const float* B, float* C, float* asum, int64_t M, int64_t N, int64_t K, int64_t lda,
                   int64_t ldb, int64_t ldc, bool b_kmajor, hipStream_t st);
 int colsum(const float* X, int64_t rows, int64_t cols, int64_t ld, float* out, hipStream_t st);
 int swish_backward_inplace(float* z_inout, const float* dY, float beta, int64_t n, hipStream_t st);
 int fill_f32(float* p, float v, int64_t n, hipStream_t st);
-enum { ACT_NONE = 0, ACT_SWISH = 1, ACT_RELU = 2 };
+enum { ACT_NONE = 0, ACT_SWISH = 1, ACT_RELU = 2, ACT_SIGMOID = 3 };
 
 static int linear_backward(const float* X, const float* W, const float* dO, float* dX, float* dW,
                            float* db, int64_t rows, int64_t in, int64_t out, hipStream_t st, const float* dX_addend = nullptr) {
@@ -125,4 +127,31 @@ extern "C" int nnhipLinearInputGradSwish(const float* dO, const float* W, const 
                     "nnhipLinearInputGradSwish: misaligned pointer");
     return gemm_f32_dswish(dO, W, dZ, Z, swish_beta, rows, in_features, out_features, out_features, in_features,
                            in_features, true, false, (hipStream_t)stream);
+}
+
+// O = act(X W^T + b) with the activation in the GEMM epilogue: activation 1 = swish(beta) (no pre-activation saved; use
+// nnhipLinearSwishForward to keep z), 2 = relu, 3 = sigmoid.  What `act(Linear(x))` computes on the reference's tape
+// (neunet/nn/layers/linear.py:48-58 followed by activations.py:54-56 / 221-233 / 20-25) in one launch.
+extern "C" int nnhipLinearActivationForward(const float* X, const float* W, const float* b, float* O, int64_t rows,
+                                            int64_t in_features, int64_t out_features, int32_t activation, float beta,
+                                            nnhipStream_t stream) {
+    if (int rc = check_linear("nnhipLinearActivationForward", X, W, rows, in_features, out_features)) return rc;
+    NNHIP_CHECK_ARG(activation >= 1 && activation <= 3, NNHIP_EINVAL, "nnhipLinearActivationForward: activation must be 1 (swish), 2 (relu) or 3 (sigmoid)");
+    if (rows == 0) return 0;
+    NNHIP_CHECK_ARG(O != nullptr, NNHIP_EINVAL, "nnhipLinearActivationForward: null output");
+    return gemm_f32(X, W, O, b, nullptr, rows, out_features, in_features, in_features, in_features, out_features, true, true,
+                    1, 0, 0, 0, activation, beta, (hipStream_t)stream);
+}
+
+// dZ[rows,in] = (dO[rows,out] * W[out,in]) (.) [F[rows,in] > 0]: the input gradient of a Linear fed by h = relu(z), F = h,
+// with the ReLU backward (neunet/nn/activations.py:44-45) folded into the dX GEMM's epilogue.  dZ must not alias F.
+extern "C" int nnhipLinearInputGradReLU(const float* dO, const float* W, const float* F, float* dZ, int64_t rows,
+                                        int64_t in_features, int64_t out_features, nnhipStream_t stream) {
+    NNHIP_CHECK_ARG(rows >= 0 && in_features >= 0 && out_features >= 0, NNHIP_EINVAL, "nnhipLinearInputGradReLU: negative size");
+    if (rows == 0 || in_features == 0) return 0;
+    NNHIP_CHECK_ARG(dO && W && F && dZ && F != dZ, NNHIP_EINVAL, "nnhipLinearInputGradReLU: null or aliased pointer");
+    NNHIP_CHECK_ARG(aligned4(dO) && aligned4(W) && aligned4(F) && aligned4(dZ), NNHIP_EALIGN,
+                    "nnhipLinearInputGradReLU: misaligned pointer");
+    return gemm_f32_drelu(dO, W, dZ, F, rows, in_features, out_features, out_features, in_features, in_features, true, false,
+                          (hipStream_t)stream);
 }

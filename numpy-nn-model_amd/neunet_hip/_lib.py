@@ -44,6 +44,8 @@ _SIGNATURES = {
     "nnhipLinearModuleForward": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_void_p]),
     "nnhipLinearModuleBackward": (ctypes.c_int, [P, P, P, P, P, P, c_int64, c_int64, c_int64, c_void_p]),
     "nnhipLinearInputGradSwish": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_float, c_void_p]),
+    "nnhipLinearInputGradReLU": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_void_p]),
+    "nnhipLinearActivationForward": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_int32, c_float, c_void_p]),
     "nnhipLinearModuleForwardEx": (ctypes.c_int, [P, P, P, P, P, c_int64, c_int64, c_int64, c_void_p]),
     "nnhipLinearModuleBackwardEx": (ctypes.c_int, [P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_void_p]),
     "nnhipLinearSwishForward": (ctypes.c_int, [P, P, P, P, P, c_int64, c_int64, c_int64, c_float, ctypes.c_int, c_void_p]),

@@ -223,13 +223,18 @@ class Tensor:
         if not self.requires_grad:
             return
         self._seeded_with_ones = grad is None
-        if grad is None:
+        if grad is None and getattr(self, "_implicit_seed", False):
+            # a loss tensor whose grad_fn already holds d(loss)/d(input) for a unit seed (fused CrossEntropy / MSE):
+            # no ones tensor, no fill launch -- its grad_fn ignores `grad` when `_seeded_with_ones` is set
+            grad = None
+        elif grad is None:
             grad = self.xp.ones_like(self.data, dtype=self.dtype)
         elif self.device == "cpu":
             grad = np.array(grad, dtype=self.dtype)
         else:
             grad = _to_device_array(grad.data if isinstance(grad, Tensor) else grad, self.dtype)
-        self.apply_grad(grad)
+        if grad is not None:
+            self.apply_grad(grad)
 
         tape: list = []
         visited: set = set()

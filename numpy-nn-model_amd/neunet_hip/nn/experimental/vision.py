@@ -184,6 +184,8 @@ class HIPBatchNorm2d(Module):
 
 # ------------------------------------------------------------------------------------------------- MSELoss
 class _HIPMSETensor(Tensor):
+    _implicit_seed = True      # backward() with no argument needs no ones tensor: grad_fn below handles the unit seed
+
     def __init__(self, data, args, op, device):
         super().__init__(data, args, op, device=device, _nocopy=True)
         out_ref = weakref.ref(self)   # no tensor -> grad_fn -> closure -> tensor cycle: activations die by refcount
