@@ -1,10 +1,13 @@
 """HIP activations: drop-ins for CUDASwish (experimental/activations/swish/swish.py:92-120),
 CUDAFusedSwishAndMul (.../fused_swish_and_mul/fused_swish_and_mul.py:154-179), CUDASoftmax
 (.../softmax/softmax.py:139-169), plus HIPReLU (CPU reference: neunet/nn/activations.py:40-59)."""
+import weakref
+
 import numpy as np
 
 from ...autograd import Tensor
 from ..modules import Module
+from .linear import ACT_RELU, ACT_SWISH, _HIPLinearTensor
 from .utils import call_hip_function, contiguous, get_current_stream_ptr, require_device_f32
 
 
@@ -34,9 +37,16 @@ def hip_relu_backward(grad_input, grad_output, f_x):
 class _HIPReLUTensor(Tensor):
     def __init__(self, data, args, op, device):
         super().__init__(data, args, op, device=device, _nocopy=True)
+        self_ref = weakref.ref(self)
 
         def grad_fn(t: Tensor, f_x, grad):
-            grad_input = t.xp.empty_like(t.data)
+            me = self_ref()
+            if getattr(me, "_grad_is_dz", False):
+                # the consumer (a HIPLinear) already applied [f > 0] in its dX epilogue (linear.py:_fold_relu_backward)
+                me._grad_is_dz = False
+                t.apply_grad(grad)
+                return
+            grad_input = t.xp.empty_like(f_x)        # not t.data: t may be a Linear output that was never materialised
             hip_relu_backward(grad_input, grad, f_x)
             t.apply_grad(grad_input)
 
@@ -49,8 +59,11 @@ class HIPReLU(Module):
 
     def forward(self, x: Tensor):
         require_device_f32(x)
-        f_x = x.xp.empty_like(x.data)
-        hip_relu_forward(x.data, f_x)
+        if isinstance(x, _HIPLinearTensor) and x.pending():
+            f_x = x.run_fused(ACT_RELU)              # relu in the Linear's GEMM epilogue: one launch instead of two
+        else:
+            f_x = x.xp.empty_like(x.data)
+            hip_relu_forward(x.data, f_x)
         return _HIPReLUTensor(f_x, [x, f_x], "relu", device=x.device)
 
 
@@ -93,8 +106,12 @@ class HIPSwish(Module):
 
     def forward(self, x: Tensor):
         require_device_f32(x)
-        out = x.xp.empty_like(x.data)
-        hip_swish_forward(x.data, out, self.beta)
+        if isinstance(x, _HIPLinearTensor) and x.pending():
+            # Swish(Linear(x)): one GEMM writes z (the Linear's own output, needed by the Swish backward) and swish(z)
+            out = x.run_fused(ACT_SWISH, self.beta, save_preactivation=True)
+        else:
+            out = x.xp.empty_like(x.data)
+            hip_swish_forward(x.data, out, self.beta)
         return _HIPSwishTensor(out, [x, self.beta], "swish", device=x.device)
 
 

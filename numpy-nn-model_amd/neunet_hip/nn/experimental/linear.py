@@ -5,6 +5,7 @@ N-D inputs are flattened to rows = prod(shape[:-1]) exactly like the reference's
 (linear.py:193), which equals the CPU path's batched-dW-then-reverse-broadcast result
 (neunet/nn/layers/linear.py:17-24 + autograd.py:948-962).
 """
+import os
 from typing import Union
 
 import numpy as np
@@ -62,6 +63,22 @@ def _fold_swish_backward(X, weight, grad, rows, in_features, out_features):
     return True
 
 
+def _fold_relu_backward(X, weight, grad, rows, in_features, out_features):
+    """If this Linear's input is the output of a ReLU that nothing else consumes (README quick-start: l2(relu(l1(x)))),
+    compute d(relu input) = (dO W) * [f > 0] in the dX GEMM's epilogue and hand it to the ReLU node marked as 'already
+    masked' -- the separate ReLU-backward pass (one more launch; at MNIST-MLP scale one more ~6 us graph node) goes away.
+    Returns True when done."""
+    if X.op != "relu" or X.grad is not None or getattr(X, "_consumers", 0) != 1 or not X.requires_grad:
+        return False
+    f_x = X.args[1]
+    dz = X.xp.empty_like(f_x, dtype=np.float32)
+    call_hip_function("nnhipLinearInputGradReLU", grad, weight.data, f_x, dz, rows, in_features, out_features,
+                      get_current_stream_ptr())
+    X.grad = dz
+    X._grad_is_dz = True
+    return True
+
+
 def _finish_param(param, grad):
     """apply_grad + the DP bucket's gradient-ready hook (GradBucket(overlap=True))."""
     param.apply_grad(grad)
@@ -70,15 +87,26 @@ def _finish_param(param, grad):
         hook(param)
 
 
+ACT_SWISH, ACT_RELU, ACT_SIGMOID = 1, 2, 3      # nnhipLinearActivationForward codes
+_LAZY = os.environ.get("NNHIP_LAZY_LINEAR", "1") != "0"
+
+
 class _HIPLinearTensor(Tensor):
-    def __init__(self, data, args, op, device):
+    """Output of HIPLinear.  Its GEMM is DEFERRED until somebody reads `.data`: an activation module applied to it
+    first (ReLU / Sigmoid / Swish: `act(Linear(x))`, the composition the reference's fused CUDALinearSwish is tested
+    against) then launches ONE GEMM with the activation in its epilogue instead of GEMM + elementwise pass; anything
+    else that touches `.data` simply runs the plain GEMM at that point.  Values are identical either way."""
+
+    def __init__(self, data, args, op, device, thunk=None, shape=None):
+        self._data, self._thunk, self._lazy_shape = None, thunk, shape
         super().__init__(data, args, op, device=device, _nocopy=True)
 
         def grad_fn(X: Tensor, weight: Tensor, bias, in_rows_num, in_features, out_features, residual, grad):
             grad = grad if grad.is_contiguous() else grad.contiguous()
             if residual is not None:
                 residual.apply_grad(grad)       # d(x + linear(h))/dx = 1: the same buffer, by reference
-            folded = _fold_swish_backward(X, weight, grad, in_rows_num, in_features, out_features)
+            folded = (_fold_swish_backward(X, weight, grad, in_rows_num, in_features, out_features)
+                      or _fold_relu_backward(X, weight, grad, in_rows_num, in_features, out_features))
             grad_X = X.xp.empty_like(X.data, dtype=np.float32) if X.requires_grad and not folded else None
             # a gradient X already received (e.g. q/k/v projections sharing one input) is folded into the dX GEMM's
             # epilogue instead of a separate accumulation pass (neunet/autograd.py:85-93 allocates and adds)
@@ -109,6 +137,43 @@ class _HIPLinearTensor(Tensor):
                     X.apply_grad(grad_X)
 
         self.grad_fn = grad_fn
+
+    # ---- deferred output --------------------------------------------------------------------------------------------
+    @property
+    def data(self):
+        if self._data is None and self._thunk is not None:
+            thunk, self._thunk = self._thunk, None
+            self._data = thunk(0, 1.0, None)
+        return self._data
+
+    @data.setter
+    def data(self, value):
+        self._data = value
+
+    def pending(self) -> bool:
+        return self._data is None and self._thunk is not None
+
+    def run_fused(self, activation: int, beta: float = 1.0, save_preactivation: bool = False):
+        """Launch the deferred GEMM with `activation` in its epilogue; returns act(XW^T + b).  With save_preactivation the
+        same launch also writes z = XW^T + b, which becomes this tensor's data."""
+        if save_preactivation:
+            z = self.xp.empty(self._lazy_shape, dtype=np.float32)
+            out = self._thunk(activation, beta, z)
+            self._data, self._thunk = z, None
+            return out
+        return self._thunk(activation, beta, None)
+
+    @property
+    def shape(self):
+        return tuple(self._lazy_shape) if self._data is None and self._lazy_shape is not None else tuple(self._data.shape)
+
+    @property
+    def dtype(self):
+        return np.dtype(np.float32)
+
+    @property
+    def ndim(self):
+        return len(self.shape)
 
 
 class HIPLinear(Module):
@@ -142,8 +207,29 @@ class HIPLinear(Module):
         if X.shape[-1] != self.in_features:
             raise ValueError(f"Expected last dim {self.in_features}, got {X.shape[-1]}")
         xdata = X.data if X.data.is_contiguous() else X.data.contiguous()
-        output = X.xp.empty(X.shape[:-1] + (self.out_features,), dtype=np.float32)
         input_rows = int(np.prod(X.shape[:-1]))
+        out_shape = tuple(X.shape[:-1]) + (self.out_features,)
+        if residual is None and _LAZY:
+            weight, bias, in_f, out_f, xp = self.weight, self.bias, self.in_features, self.out_features, X.xp
+            w_ptr, b_ptr = weight.data, bias.data if bias is not None else None   # the arrays as they are NOW
+
+            def launch(activation, beta, preact):
+                out = xp.empty(out_shape, dtype=np.float32)
+                if activation == 0:
+                    hip_linear_module_forward(xdata, w_ptr, b_ptr, out, input_rows, in_f, out_f)
+                elif preact is not None:
+                    call_hip_function("nnhipLinearSwishForward", xdata, w_ptr, b_ptr, out, preact, input_rows, in_f, out_f,
+                                      float(beta), 1, get_current_stream_ptr())
+                else:
+                    call_hip_function("nnhipLinearActivationForward", xdata, w_ptr, b_ptr, out, input_rows, in_f, out_f,
+                                      activation, float(beta), get_current_stream_ptr())
+                return out
+
+            if xdata is not X.data:
+                X = _ContiguousView(X, xdata)
+            args = (X, self.weight, self.bias, input_rows, self.in_features, self.out_features, None)
+            return _HIPLinearTensor(None, args, "linear", device=self.device, thunk=launch, shape=out_shape)
+        output = X.xp.empty(out_shape, dtype=np.float32)
         addend = None
         if residual is not None:
             if not isinstance(residual, Tensor) or tuple(residual.shape) != tuple(output.shape) or residual.dtype != "float32":

@@ -11,7 +11,7 @@ from ..._lib import Pool2dDesc
 from ...autograd import Tensor
 from ..modules import Module
 from ..parameter import Parameter
-from .linear import _finish_param, _grad_out
+from .linear import ACT_SIGMOID, _HIPLinearTensor, _finish_param, _grad_out
 from .utils import call_hip_function, contiguous, get_current_stream_ptr, require_device_f32
 
 
@@ -53,7 +53,7 @@ class _HIPSigmoidTensor(Tensor):
         super().__init__(data, args, op, device=device, _nocopy=True)
 
         def grad_fn(x: Tensor, f_x, grad):
-            g = x.xp.empty_like(x.data)
+            g = x.xp.empty_like(f_x)                 # not x.data: x may be a Linear output that was never materialised
             call_hip_function("nnhipSigmoidBackward", g, contiguous(grad), f_x, f_x.numel(), get_current_stream_ptr())
             x.apply_grad(g)
 
@@ -68,8 +68,11 @@ class HIPSigmoid(Module):
 
     def forward(self, x: Tensor):
         require_device_f32(x)
-        f_x = x.xp.empty_like(x.data)
-        call_hip_function("nnhipSigmoidForward", f_x, contiguous(x.data), f_x.numel(), get_current_stream_ptr())
+        if isinstance(x, _HIPLinearTensor) and x.pending():
+            f_x = x.run_fused(ACT_SIGMOID)           # sigmoid in the Linear's GEMM epilogue (conv classifier's last layer)
+        else:
+            f_x = x.xp.empty_like(x.data)
+            call_hip_function("nnhipSigmoidForward", f_x, contiguous(x.data), f_x.numel(), get_current_stream_ptr())
         return _HIPSigmoidTensor(f_x, [x, f_x], "sigmoid", device=x.device)
 
 

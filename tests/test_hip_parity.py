@@ -220,6 +220,82 @@ def test_rmsnorm_backward_addend(hip, rows, cols):
     np.testing.assert_allclose(host(norm.weight.grad), dw, rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("act_name", ["relu", "sigmoid", "swish"])
+def test_linear_activation_deferred_fusion(hip, act_name):
+    """act(Linear(x)): the Linear's GEMM is deferred until its output is read, so an activation applied first runs as the
+    GEMM's epilogue (one launch).  Same values and gradients as the two-launch path (output read before the activation)
+    and as the oracle; the Linear node's own output stays available (Swish: written by the same launch as z)."""
+    from neunet_hip.nn.experimental import HIPLinear, HIPReLU, HIPSigmoid, HIPSwish
+    rng = np.random.default_rng(4)
+    rows, inf, outf = 96, 70, 52
+    X = rng.uniform(-1, 1, (rows, inf)).astype(np.float32)
+    dY = rng.uniform(-1, 1, (rows, outf)).astype(np.float32)
+    layer = HIPLinear(inf, outf)
+    W, b = host(layer.weight.data), host(layer.bias.data)
+    act = {"relu": HIPReLU(), "sigmoid": HIPSigmoid(), "swish": HIPSwish(1.5)}[act_name]
+    res = []
+    for fused in (True, False):
+        layer.weight.grad = layer.bias.grad = None
+        x = T(hip, X)
+        lin = layer(x)
+        assert lin.pending() and lin.shape == (rows, outf)
+        if not fused:
+            _ = lin.data                                   # reading the output first materialises the plain GEMM
+            assert not lin.pending()
+        y = act(lin)
+        assert lin.pending() == (fused and act_name != "swish")
+        y.backward(dY)
+        res.append((host(y.data), host(x.grad), host(layer.weight.grad), host(layer.bias.grad)))
+    for a, c in zip(*res):
+        np.testing.assert_allclose(a, c, rtol=1e-5, atol=1e-6)
+    z = O.linear_forward(X, W, b)
+    if act_name == "relu":
+        yr, dz = O.relu_forward(z), O.relu_backward(O.relu_forward(z), dY)
+    elif act_name == "sigmoid":
+        yr = O.sigmoid_forward(z)
+        dz = O.sigmoid_backward(yr, dY)
+    else:
+        yr, dz = O.swish_forward(z, 1.5), O.swish_backward(z, dY, 1.5)
+    dX, dW, db = O.linear_backward(X, W, b, dz)
+    np.testing.assert_allclose(res[0][0], yr, **TOL)
+    np.testing.assert_allclose(res[0][1], dX, **TOL)
+    np.testing.assert_allclose(res[0][2], dW, **TOL)
+    np.testing.assert_allclose(res[0][3], db, **TOL)
+
+
+def test_relu_backward_folded_into_next_linear(hip):
+    """l2(relu(l1(x))): the ReLU backward runs in the epilogue of l2's dX GEMM when nothing else consumes the ReLU output;
+    with a second consumer the plain path is taken.  Both == oracle."""
+    from neunet_hip.nn.experimental import HIPLinear, HIPReLU
+    rng = np.random.default_rng(6)
+    X = rng.uniform(-1, 1, (64, 40)).astype(np.float32)
+    dY = rng.uniform(-1, 1, (64, 24)).astype(np.float32)
+    l1, l2, relu = HIPLinear(40, 56), HIPLinear(56, 24), HIPReLU()
+    W1, b1, W2, b2 = [host(t.data) for t in (l1.weight, l1.bias, l2.weight, l2.bias)]
+    z = O.linear_forward(X, W1, b1)
+    h = O.relu_forward(z)
+    dh, dW2, db2 = O.linear_backward(h, W2, b2, dY)
+    dz = O.relu_backward(h, dh)
+    dX, dW1, db1 = O.linear_backward(X, W1, b1, dz)
+    x = T(hip, X)
+    hidden = relu(l1(x))
+    out = l2(hidden)
+    out.backward(dY)
+    assert getattr(hidden, "_consumers", 0) == 1
+    np.testing.assert_allclose(host(x.grad), dX, **TOL)
+    np.testing.assert_allclose(host(l1.weight.grad), dW1, **TOL)
+    np.testing.assert_allclose(host(l2.weight.grad), dW2, **TOL)
+    np.testing.assert_allclose(host(hidden.grad), dz, **TOL)     # what the ReLU node received is already masked
+    # two consumers of the ReLU output: no folding, gradients accumulate on the tape
+    for t in (l1.weight, l1.bias, l2.weight, l2.bias):
+        t.grad = None
+    x = T(hip, X)
+    hidden = relu(l1(x))
+    (l2(hidden) + l2(hidden)).backward(dY)
+    np.testing.assert_allclose(host(x.grad), 2 * dX, rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(host(l2.weight.grad), 2 * dW2, rtol=1e-4, atol=2e-4)
+
+
 def test_linear_transpose_detecting(hip):
     """A = I against an asymmetric B catches a swapped C-write (guide rule 16)."""
     from neunet_hip.nn.experimental import HIPLinear
