@@ -510,6 +510,12 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
                 int64_t sB2, int64_t sC2, float alpha, int act, float beta, hipStream_t st, float* asum = nullptr,
                 const float* addend = nullptr, const float* dswish = nullptr, int dact = 1);
 
+// gemm_small.hip: the latency-optimised kernel for problems of a few 32x32 tiles
+bool gemm_small_wanted(int64_t M, int64_t N, int64_t K, int64_t batch);
+int gemm_small(const float* A, const float* B, float* C, const float* bias, float* preact, int64_t M, int64_t N, int64_t K,
+               int64_t lda, int64_t ldb, int64_t ldc, bool a_kmajor, bool b_kmajor, float alpha, int act, float beta,
+               float* asum, const float* addend, const float* dact_arg, int dact, hipStream_t st);
+
 int gemm_f32(const float* A, const float* B, float* C, const float* bias, float* preact, int64_t M,
              int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, bool a_kmajor,
              bool b_kmajor, int64_t batch, int64_t sA, int64_t sB, int64_t sC, int act, float beta,
@@ -556,6 +562,10 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
     if (M <= 0 || N <= 0 || batch <= 0) return 0;
     if (addend && dswish) { set_last_error("gemm: addend and dswish are mutually exclusive"); return NNHIP_EINVAL; }
     if (asum && (a_kmajor || batch != 1 || K <= 0)) { set_last_error("gemm: asum needs an outer-major, unbatched A"); return NNHIP_EINVAL; }
+    static const int small_on = []() { const char* e = getenv("NNHIP_GEMM_SMALL"); return e ? atoi(e) : 1; }();
+    if (small_on && gemm_small_wanted(M, N, K, batch))
+        return gemm_small(A, B, C, bias, preact, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, alpha, act, beta, asum, addend,
+                          dswish, dact, st);
     static const int bk_sel = []() { const char* e = getenv("NNHIP_GEMM_BK"); return e ? atoi(e) : 32; }();
     const int BK = (bk_sel == 16) ? 16 : 32;
     GemmParams p;

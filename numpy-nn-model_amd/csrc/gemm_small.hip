@@ -1,0 +1,171 @@
+// gemm_small.hip -- latency-optimised fp32 MFMA GEMM for SMALL problems (the README quick-start MLP: 32x784x128,
+// 32x128x10 and their gradients; the conv classifier's 256x784x10 head).
+//
+// The 128x128-tile kernel of gemm.hip is built for throughput: a problem with a handful of output tiles runs as a few
+// blocks that each walk their k-tiles at ~2 us apiece (64 MFMAs of which up to 3/4 multiply padding), plus a split-K
+// reduce launch -- 8-15 us per GEMM, and the MNIST-MLP step is five of them.  Here:
+//   * one block per 32x32 output tile, 4 or 8 waves per block that SPLIT K between them (wave w takes k-groups
+//     w, w+NW, ...; a k-group = 8 consecutive k = 4 MFMAs 32x32x2);
+//   * operands go global -> registers -> MFMA directly (no LDS staging, no barriers in the loop): lane (l31, lh)
+//     holds A[m0 + l31][8g + 4lh .. +3] -- one float4 for a k-major operand, four coalesced dwords for an outer-major
+//     one -- exactly the fragment layout of the big kernel, so the k permutation is the same;
+//   * the waves' 32x32 accumulators meet in LDS (conflict-free: lane <-> column) and are summed in wave order
+//     (deterministic), then the epilogue of gemm.hip: alpha, bias, addend, activation-gradient mask, activation, preact;
+//   * asum (row sums of A = db of a Linear) falls out of the operand registers.
+// Exact fp32 (v_mfma_f32_32x32x2_f32), same results as gemm.hip up to summation order.
+#include "common.h"
+
+namespace nnhip {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+enum { SG_ACT_NONE = 0, SG_ACT_SWISH = 1, SG_ACT_RELU = 2, SG_ACT_SIGMOID = 3 };
+
+struct SmallGemmParams {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;
+    float* preact;
+    const float* addend;
+    const float* dact_arg;   // activation-gradient operand (see gemm.hip: dswish / dact)
+    float* asum;
+    int64_t M, N, K, lda, ldb, ldc;
+    float alpha, beta;
+    int act, dact, a_kmajor, b_kmajor, avec, bvec;
+};
+
+// 4 consecutive k (k0 .. k0+3) of row r of an operand.  k-major: P[r*ld + k]; outer-major: P[k*ld + r].
+template <bool KMAJOR>
+__device__ __forceinline__ float4 sg_load(const float* __restrict__ P, int64_t ld, int64_t r, int64_t R, int64_t k0, int64_t K,
+                                          bool vec) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r >= R) return v;
+    if constexpr (KMAJOR) {
+        const float* p = P + r * ld + k0;
+        if (vec && k0 + 3 < K) return *reinterpret_cast<const float4*>(p);
+        if (k0 < K) v.x = p[0];
+        if (k0 + 1 < K) v.y = p[1];
+        if (k0 + 2 < K) v.z = p[2];
+        if (k0 + 3 < K) v.w = p[3];
+    } else {
+        const float* p = P + k0 * ld + r;
+        if (k0 < K) v.x = p[0];
+        if (k0 + 1 < K) v.y = p[ld];
+        if (k0 + 2 < K) v.z = p[2 * ld];
+        if (k0 + 3 < K) v.w = p[3 * ld];
+    }
+    return v;
+}
+
+template <int NW, bool AKM, bool BKM>
+__global__ __launch_bounds__(NW * 64) void gemm_small_kernel(const SmallGemmParams p) {
+    __shared__ float red[NW][32 * 32];
+    __shared__ float ared[NW][32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int64_t m0 = (int64_t)blockIdx.y * 32, n0 = (int64_t)blockIdx.x * 32;
+    const int64_t groups = (p.K + 7) >> 3;
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    float asum = 0.f;
+    // U k-groups in flight per wave (2 x U float4 of operands): a whole K = 784 / 8 waves is two round trips to L2
+    constexpr int U = 8;
+    for (int64_t gb = wave; gb < groups; gb += (int64_t)NW * U) {
+        float4 a[U], b[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t g = gb + (int64_t)u * NW;
+            a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            b[u] = a[u];
+            if (g < groups) {
+                a[u] = sg_load<AKM>(p.A, p.lda, m0 + l31, p.M, 8 * g + 4 * lh, p.K, p.avec != 0);
+                b[u] = sg_load<BKM>(p.B, p.ldb, n0 + l31, p.N, 8 * g + 4 * lh, p.K, p.bvec != 0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b[u].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, b[u].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].z, b[u].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].w, b[u].w, acc, 0, 0, 0);
+            asum += (a[u].x + a[u].y) + (a[u].z + a[u].w);
+        }
+    }
+    // accumulator register e holds row (e&3) + 8(e>>2) + 4lh, column l31
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[wave][((e & 3) + 8 * (e >> 2) + 4 * lh) * 32 + l31] = acc[e];
+    if (p.asum) {
+        asum += __shfl_xor(asum, 32, 64);
+        if (lh == 0) ared[wave][l31] = asum;
+    }
+    __syncthreads();
+    constexpr int PER = 1024 / (NW * 64);                      // outputs per thread
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int o = tid + i * NW * 64;
+        float v = red[0][o];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) v += red[w][o];
+        const int64_t row = m0 + (o >> 5), col = n0 + (o & 31);
+        if (row < p.M && col < p.N) {
+            v = p.alpha * v + (p.bias ? p.bias[col] : 0.f);
+            if (p.addend) v += p.addend[row * p.ldc + col];
+            if (p.dact_arg) {
+                const float x = p.dact_arg[row * p.ldc + col];
+                v = p.dact == 2 ? (x > 0.f ? v : 0.f) : v * swish_grad_(x, p.beta);
+            }
+            if (p.act == SG_ACT_SWISH) {
+                if (p.preact) p.preact[row * p.ldc + col] = v;
+                v = v * sigmoid_fast_(p.beta * v);
+            } else if (p.act == SG_ACT_RELU) {
+                v = fmaxf(v, 0.f);
+            } else if (p.act == SG_ACT_SIGMOID) {
+                v = sigmoid_fast_(v);
+            }
+            p.C[row * p.ldc + col] = v;
+        }
+    }
+    if (p.asum && blockIdx.x == 0 && tid < 32) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) s += ared[w][tid];
+        if (m0 + tid < p.M) p.asum[m0 + tid] = s;
+    }
+}
+
+// Is this problem one for the small kernel?  (gemm.hip asks before planning its own launch.)
+bool gemm_small_wanted(int64_t M, int64_t N, int64_t K, int64_t batch) {
+    if (batch != 1 || M <= 0 || N <= 0 || K > 2048) return false;
+    const int64_t tiles128 = ceil_div(M, 128) * ceil_div(N, 128);
+    const int64_t tiles32 = ceil_div(M, 32) * ceil_div(N, 32);
+    return tiles128 <= 8 && tiles32 <= 256;
+}
+
+int gemm_small(const float* A, const float* B, float* C, const float* bias, float* preact, int64_t M, int64_t N, int64_t K,
+               int64_t lda, int64_t ldb, int64_t ldc, bool a_kmajor, bool b_kmajor, float alpha, int act, float beta,
+               float* asum, const float* addend, const float* dact_arg, int dact, hipStream_t st) {
+    SmallGemmParams p;
+    p.A = A; p.B = B; p.C = C; p.bias = bias; p.preact = preact; p.addend = addend; p.dact_arg = dact_arg; p.asum = asum;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.alpha = alpha; p.beta = beta; p.act = act; p.dact = dact;
+    p.a_kmajor = a_kmajor; p.b_kmajor = b_kmajor;
+    p.avec = a_kmajor && aligned16(A) && (lda & 3) == 0;
+    p.bvec = b_kmajor && aligned16(B) && (ldb & 3) == 0;
+    const int64_t groups = (K + 7) >> 3;
+    const int nw = groups >= 8 ? 8 : 4;
+    dim3 grid((unsigned)ceil_div(N, 32), (unsigned)ceil_div(M, 32));
+#define SG_LAUNCH(NW)                                                                                             \
+    do {                                                                                                          \
+        if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_small_kernel<NW, true, true>), grid, dim3(NW * 64), 0, st, p);        \
+        else if (a_kmajor) hipLaunchKernelGGL((gemm_small_kernel<NW, true, false>), grid, dim3(NW * 64), 0, st, p);              \
+        else if (b_kmajor) hipLaunchKernelGGL((gemm_small_kernel<NW, false, true>), grid, dim3(NW * 64), 0, st, p);              \
+        else hipLaunchKernelGGL((gemm_small_kernel<NW, false, false>), grid, dim3(NW * 64), 0, st, p);                            \
+    } while (0)
+    if (nw == 8) SG_LAUNCH(8);
+    else SG_LAUNCH(4);
+#undef SG_LAUNCH
+    NNHIP_LAUNCH_CHECK("gemm_small_kernel");
+    return 0;
+}
+
+}  // namespace nnhip

@@ -188,7 +188,7 @@ class Tensor:
     # ---- tape ---------------------------------------------------------------------------------------
     def _reverse_broadcast(self, grad):
         """autograd.py:948-962."""
-        gshape, sshape = tuple(grad.shape), tuple(self.data.shape)
+        gshape, sshape = tuple(grad.shape), tuple(self.shape)    # .shape, not .data.shape: a deferred Linear output stays deferred
         if gshape == sshape:
             return grad
         if len(sshape) == grad.ndim:
@@ -214,7 +214,7 @@ class Tensor:
         """The gradient this tensor already holds, if a kernel can fold it into the next one it produces
         (out = new + held, written to a fresh buffer): same shape, contiguous.  None otherwise."""
         g = self.grad
-        if g is None or isinstance(g, np.ndarray) or tuple(g.shape) != tuple(self.data.shape) or not g.is_contiguous():
+        if g is None or isinstance(g, np.ndarray) or tuple(g.shape) != tuple(self.shape) or not g.is_contiguous():
             return None
         return g
 

@@ -245,6 +245,7 @@ def test_linear_activation_deferred_fusion(hip, act_name):
         y = act(lin)
         assert lin.pending() == (fused and act_name != "swish")
         y.backward(dY)
+        assert lin.pending() == (fused and act_name != "swish")   # the backward pass never needed the un-activated output
         res.append((host(y.data), host(x.grad), host(layer.weight.grad), host(layer.bias.grad)))
     for a, c in zip(*res):
         np.testing.assert_allclose(a, c, rtol=1e-5, atol=1e-6)
