@@ -158,10 +158,10 @@ int nnhipMaskedSoftmaxBackward(float* dX, const float* dY, const float* Y, const
                                int64_t B, int64_t H, int64_t Tq, int64_t Tk, float scale, int causal,
                                nnhipStream_t stream);
 
-/* Fused (flash-style) attention, head_dim 64: same math as  QK^T*scale -> mask(-1e9) -> softmax -> *V  above, but the
- * [B,H,Tq,Tk] score matrix is never written.  O/dO are [B,T,H*64] (the projection layout); Q/K/V/dQ/dK/dV are
- * [B,T,*] with row stride ld_qkv floats (0 = H*64; 3*H*64 when they are the three column blocks of one fused q|k|v
- * projection buffer).  LSE [B,H,Tq,2] = (row max, log2 row sum) of each masked score row in log2 units, saved by the
+/* Fused (flash-style) attention, head_dim 32 / 64 / 128: same math as  QK^T*scale -> mask(-1e9) -> softmax -> dropout -> *V
+ * above, but the [B,H,Tq,Tk] score matrix is never written.  O/dO are [B,T,H*head_dim] (the projection layout); Q/K/V/dQ/dK/dV
+ * are [B,T,*] with row stride ld_qkv floats (0 = H*head_dim; 3*H*head_dim when they are the three column blocks of one fused
+ * q|k|v projection buffer).  LSE [B,H,Tq,2] = (row max, log2 row sum) of each masked score row in log2 units, saved by the
  * forward and consumed by the backward; the pair is kept apart because a fully-masked row has max = -1e9*log2(e),
  * where fp32 cannot hold max + log(sum). */
 int nnhipAttentionForward(const float* Q, const float* K, const float* V, const int32_t* key_valid, float* O,
@@ -173,6 +173,38 @@ int nnhipAttentionBackward(const float* Q, const float* K, const float* V, const
                            const float* dO, const float* LSE, float* dQ, float* dK, float* dV, int64_t B, int64_t H,
                            int64_t Tq, int64_t Tk, int64_t head_dim, int64_t ld_qkv, float scale, int causal,
                            nnhipStream_t stream);
+/* The same with the rest of examples/gpt.ipynb cell 2 inside the kernels (all fields optional; a NULL struct == the calls
+ * above):
+ *   mask_bits / mask_bitsT / row_any: an arbitrary dense [B,Tq,Tk] mask (what the notebook builds with get_pad_mask &
+ *     get_sub_mask and passes down), packed by nnhipAttentionPackMask; when given it REPLACES key_valid and causal;
+ *   attention dropout (the notebook's self.dropout(softmax(scores)), dropout.py:17-37): the multiplier of element
+ *     (b,h,q,k) is dropout_mask[b,h,q,k] (0 or 1/(1-p): an injected mask, for parity tests against the oracle) or, with
+ *     dropout_mask == NULL and dropout_p > 0, (hash(dropout_seed, b, h, q, k) >= p*2^32) / (1-p) -- a counter-based hash
+ *     that the forward and both backward kernels re-evaluate (nothing is stored); nnhipAttentionDropoutMask writes the
+ *     same multipliers out.  Pass the SAME options to the forward and the backward of one step. */
+typedef struct nnhipAttentionOptions {
+    const uint64_t* mask_bits;    /* [B, Tq, ceil(Tk/64)] */
+    const uint64_t* mask_bitsT;   /* [B, Tk, ceil(Tq/64)] */
+    const uint8_t* row_any;       /* [B, Tq] (NULL: no tile skipping under a dense mask) */
+    const float* dropout_mask;    /* [B, H, Tq, Tk] */
+    float dropout_p;
+    uint32_t dropout_seed;
+    const uint32_t* dropout_seed_dev; /* NULL, or a device word added to dropout_seed when the kernel runs: point it at a
+                                       * per-step counter so that a captured hipGraph draws a fresh mask on every replay */
+} nnhipAttentionOptions;
+int nnhipAttentionForwardEx(const float* Q, const float* K, const float* V, const int32_t* key_valid, float* O,
+                            float* LSE, int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t head_dim, int64_t ld_qkv,
+                            float scale, int causal, const nnhipAttentionOptions* opts, nnhipStream_t stream);
+int nnhipAttentionBackwardEx(const float* Q, const float* K, const float* V, const int32_t* key_valid, const float* O,
+                             const float* dO, const float* LSE, float* dQ, float* dK, float* dV, int64_t B, int64_t H,
+                             int64_t Tq, int64_t Tk, int64_t head_dim, int64_t ld_qkv, float scale, int causal,
+                             const nnhipAttentionOptions* opts, nnhipStream_t stream);
+/* mask [B,Tq,Tk] int32 (non-zero = visible) -> mask_bits, mask_bitsT, row_any (one launch). */
+int nnhipAttentionPackMask(const int32_t* mask, uint64_t* mask_bits, uint64_t* mask_bitsT, uint8_t* row_any, int64_t B,
+                           int64_t Tq, int64_t Tk, nnhipStream_t stream);
+/* out [B,H,Tq,Tk] = the hash dropout multipliers the fused kernels use for (dropout_p, seed). */
+int nnhipAttentionDropoutMask(float* out, int64_t B, int64_t H, int64_t Tq, int64_t Tk, float dropout_p, uint32_t seed,
+                              nnhipStream_t stream);
 
 /* ---- a9 fused CrossEntropy forward+backward  (replaces cudaCrossEntropyForwardBackward,
  *      cross_entropy.cu:249-260).

@@ -1,9 +1,13 @@
-// attention.hip -- fused (flash-style) masked multi-head attention for gfx950, fp32 MFMA, head dim 64.
+// attention.hip -- fused (flash-style) masked multi-head attention for gfx950, fp32 MFMA, head dim 32 / 64 / 128.
 // Semantics = examples/gpt.ipynb cell 2:  scores = QK^T / sqrt(d_model); scores = where(mask == 0, -1e9, scores);
-// attn = Softmax(-1)(scores); ctx = attn V -- with mask = key padding (key_valid) AND causal, exactly what
-// nnhipMaskedSoftmaxForward implements unfused.  The [B,H,T,T] score / attention matrices are never written: the
-// forward keeps a running (max, sum) per query row and stores only LSE[B,H,T,2] = (max, log2 sum) in log2 units;
-// the backward recomputes P from it.
+// attn = Softmax(-1)(scores); attn = dropout(attn); ctx = attn V.
+// The mask is either (key padding AND causal) -- what the notebook's get_pad_mask & get_sub_mask always produce, carried
+// as key_valid[B,Tk] + a flag -- or ANY dense [B,Tq,Tk] mask, handed over as packed bits (nnhipAttentionPackMask).
+// The [B,H,T,T] score / attention matrices are never written: the forward keeps a running (max, sum) per query row and
+// stores only LSE[B,H,T,2] = (max, log2 sum) in log2 units; the backward recomputes P from it.  Attention dropout
+// (neunet/nn/layers/dropout.py:17-37 applied to the attention map) happens inside the kernels: the keep/scale multiplier
+// of element (b,h,q,k) is either read from an injected [B,H,Tq,Tk] mask (parity tests against the oracle) or a
+// counter-based hash of (seed, b, h, q, k) that the forward and both backward kernels re-evaluate -- never stored.
 //
 // Register layout trick (all three kernels): every product is arranged so that the softmax axis lands on the
 // LANE index of the 32x32 MFMA accumulator (col = lane & 31) and the other axis on the register index:
@@ -15,7 +19,9 @@
 // The MFMA phases read their A operands from LDS one step ahead of the MFMAs that consume them and pin that issue
 // order with sched_group_barrier (left alone, hipcc re-uses one register pair and waits lgkmcnt(0) before every
 // MFMA pair -- measured 2.3x off the MFMA bound).  K/V (Q/dO) tiles are fetched into registers one tile ahead.
-// Q, K, V, ctx live in the [B, T, H*64] layout of the projections (row stride D = H*64).
+// Q, K, V, ctx live in the [B, T, H*DH] layout of the projections (row stride D = H*DH).
+// Kernels are templates on <DH, GEN>: GEN = false is the (key_valid, causal, no dropout) fast path that round 1 tuned at
+// DH = 64; GEN = true adds the dense-mask bits and the dropout multiplier to the softmax phase.
 #include <math.h>
 
 #include "common.h"
@@ -24,10 +30,8 @@ namespace nnhip {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int AT_DH = 64;    // head dim
 constexpr int AT_BQ = 128;   // queries (keys in the dK/dV kernel) per block: 4 waves x 32
 constexpr int AT_BK = 64;    // keys (queries in the dK/dV kernel) per tile
-constexpr int AT_KLD = 68;   // tile row stride (floats): conflict-free ds_read_b128 of 4 consecutive d
 constexpr float AT_MASKED = -1e9f;
 constexpr float AT_LOG2E = 1.4426950408889634f;
 constexpr float AT_MASKED2 = AT_MASKED * AT_LOG2E;   // the -1e9 fill in log2 units (scores are carried as s*log2(e))
@@ -36,16 +40,28 @@ constexpr float AT_MASKED2 = AT_MASKED * AT_LOG2E;   // the -1e9 fill in log2 un
 #define AT_SCHED_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, (n), 0)
 #define AT_SCHED_DSRD(n) __builtin_amdgcn_sched_group_barrier(0x100, (n), 0)
 
+struct AttnExtra {                                    // GEN = true only
+    const unsigned long long* mask_bits;              // [B, Tq, ceil(Tk/64)]: bit j of word w = key 64w+j visible to this query; or null
+    const unsigned long long* mask_bitsT;             // [B, Tk, ceil(Tq/64)]: the same mask, bits running over queries; or null
+    const unsigned char* row_any;                     // [B, Tq]: 1 iff the query sees at least one key (tile skipping); or null
+    const float* drop_mask;                           // [B, H, Tq, Tk] multipliers (0 or 1/(1-p)); or null
+    const unsigned* seed_dev;                         // or null: a device word ADDED to drop_seed (e.g. a step counter, so that a
+                                                      // captured hipGraph draws a fresh mask on every replay)
+    unsigned drop_seed, drop_threshold;               // hash dropout: keep iff hash >= threshold (0 = no dropout)
+    float drop_scale;                                 // 1/(1-p)
+};
+
 struct AttnParams {
     const float* Q; const float* K; const float* V;   // [B, T, D]
     float* O;                                         // [B, Tq, D]
     float* LSE;                                       // [B, H, Tq, 2] = (max, log2 sum), log2 units
     const int32_t* key_valid;                         // [B, Tk] or null
     int B, H, Tq, Tk;
-    int64_t D;                                        // row stride of O (floats): H * 64
-    int64_t LQ;                                       // row stride of Q, K, V (>= H * 64: 3*H*64 for a fused q|k|v buffer)
+    int64_t D;                                        // row stride of O (floats): H * DH
+    int64_t LQ;                                       // row stride of Q, K, V (>= H * DH: 3*H*DH for a fused q|k|v buffer)
     float scale;                                      // multiplies QK^T (1/sqrt(d_model))
     int causal;
+    AttnExtra x;
 };
 
 struct AttnBwdParams {
@@ -59,32 +75,49 @@ struct AttnBwdParams {
     int64_t LQ;                                                        // row stride of Q, K, V, dQ, dK, dV
     float scale;
     int causal;
+    AttnExtra x;
 };
 
 // row (within a 32-row tile) carried by accumulator register e, for half-wave lh
 __device__ __forceinline__ int acc_row(int e, int lh) { return (e & 3) + 8 * (e >> 2) + 4 * lh; }
 
-// A [64 x 64] tile staged through registers: fetch early (the loads stay in flight during the MFMA phase), commit
-// to LDS (row stride LD) at the top of the next iteration.  Rows past nrows are zero-filled.
+// ---- dropout multiplier of element (row = (b*H + h)*Tq + q, key) ------------------------------------------------------
+// lowbias32-style integer hash of (seed, row, key): cheap enough (~10 VALU) to re-evaluate in all three kernels.
+__device__ __forceinline__ unsigned at_rowkey(unsigned seed, unsigned row) { return (seed * 0x85EBCA6Bu + 0x9E3779B9u) ^ (row * 0xC2B2AE35u); }
+__device__ __forceinline__ unsigned at_hash(unsigned rowkey, unsigned key) {
+    unsigned x = rowkey ^ (key * 0x9E3779B1u);
+    x ^= x >> 16; x *= 0x7FEB352Du;
+    x ^= x >> 15; x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float at_drop_mult(const AttnExtra& x, unsigned rowkey, int64_t row, int Tk, int key) {
+    if (x.drop_mask) return x.drop_mask[row * Tk + key];
+    return at_hash(rowkey, (unsigned)key) >= x.drop_threshold ? x.drop_scale : 0.f;
+}
+
+// A [rows x DH] tile staged through registers: fetch early (the loads stay in flight during the MFMA phase), commit
+// to LDS (row stride DH + 4) at the top of the next iteration.  Rows past nrows are zero-filled.
 template <int NV>
-struct TileRegsN { float4 v[NV]; };          // NV*16 rows x 64 floats over 256 threads
-typedef TileRegsN<4> TileRegs;
-template <int NV>
+struct TileRegsN { float4 v[NV]; };          // NV*1024/DH rows x DH floats over 256 threads
+template <int DH, int NV>
 __device__ __forceinline__ void tile_fetch(TileRegsN<NV>& r, const float* __restrict__ base, int64_t D, int row0, int nrows, int tid) {
+    constexpr int C4 = DH / 4;
 #pragma unroll
     for (int p = 0; p < NV; ++p) {
         const int idx = tid + 256 * p;
-        const int rr = idx >> 4, c4 = (idx & 15) * 4;
+        const int rr = idx / C4, c4 = (idx % C4) * 4;
         r.v[p] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (row0 + rr < nrows) r.v[p] = *reinterpret_cast<const float4*>(base + (int64_t)(row0 + rr) * D + c4);
     }
 }
-template <int LD, int NV>
+template <int DH, int NV>
 __device__ __forceinline__ void tile_commit(float* __restrict__ S, const TileRegsN<NV>& r, int tid) {
+    constexpr int C4 = DH / 4, LD = DH + 4;
 #pragma unroll
     for (int p = 0; p < NV; ++p) {
         const int idx = tid + 256 * p;
-        *reinterpret_cast<float4*>(&S[(idx >> 4) * LD + (idx & 15) * 4]) = r.v[p];
+        *reinterpret_cast<float4*>(&S[(idx / C4) * LD + (idx % C4) * 4]) = r.v[p];
     }
 }
 // padding flag of key kv0 + lane (1 = real token); the wave ballots it into a 64-bit mask per tile
@@ -124,17 +157,18 @@ __device__ __forceinline__ bool map_block(int id, int BH, int nblk, bool heavy_i
 __host__ inline unsigned mapped_grid(int64_t BH, int64_t nblk) { return (unsigned)(ceil_div(BH, 8) * 8 * nblk); }
 
 // ---- MFMA phases -------------------------------------------------------------------------------------------------
-// accA += TA_rows . fA^T and accB += TB_rows . fB^T (64 MFMAs): the A operands are 32 rows of a k-major LDS tile
-// (ta / tb = this lane's row pointer, &T[(r0 + l31) * AT_KLD + 4 * lh]), the B operands per-lane register fragments
+// accA += TA_rows . fA^T and accB += TB_rows . fB^T (8*G MFMAs, G = DH/8): the A operands are 32 rows of a k-major LDS
+// tile (ta / tb = this lane's row pointer, &T[(r0 + l31) * LD + 4 * lh]), the B operands per-lane register fragments
 // f[g][j] = X[lane's row][8g + 4lh + j].  One ds_read_b128 per product per g, issued one g ahead of its 4 MFMAs.
-__device__ __forceinline__ void mma2_rows(f32x16& accA, const float* __restrict__ ta, const float (&fA)[8][4],
-                                          f32x16& accB, const float* __restrict__ tb, const float (&fB)[8][4]) {
+template <int G>
+__device__ __forceinline__ void mma2_rows(f32x16& accA, const float* __restrict__ ta, const float (&fA)[G][4],
+                                          f32x16& accB, const float* __restrict__ tb, const float (&fB)[G][4]) {
     float4 a[2], c[2];
     a[0] = *reinterpret_cast<const float4*>(ta);
     c[0] = *reinterpret_cast<const float4*>(tb);
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
-        if (g + 1 < 8) {
+    for (int g = 0; g < G; ++g) {
+        if (g + 1 < G) {
             a[(g + 1) & 1] = *reinterpret_cast<const float4*>(ta + 8 * (g + 1));
             c[(g + 1) & 1] = *reinterpret_cast<const float4*>(tb + 8 * (g + 1));
         }
@@ -150,7 +184,7 @@ __device__ __forceinline__ void mma2_rows(f32x16& accA, const float* __restrict_
     }
     AT_SCHED_DSRD(2);
 #pragma unroll
-    for (int g = 0; g < 7; ++g) {
+    for (int g = 0; g < G - 1; ++g) {
         AT_SCHED_MFMA(4);
         AT_SCHED_DSRD(1);
         AT_SCHED_MFMA(4);
@@ -159,54 +193,53 @@ __device__ __forceinline__ void mma2_rows(f32x16& accA, const float* __restrict_
     AT_SCHED_MFMA(8);
 }
 
-// acc[dt] += T^T[d = 32dt + l31][row(e)] * P[e] over the 32 rows carried by accumulator P (32 MFMAs): the A operand
-// of step e is T[(r0 + acc_row(e, lh)) * LD + 32dt + l31] (tl = &T[(r0 + 4lh) * LD + l31]), the B operand register e
-// of P.  LDS values are read 4 e-steps ahead.
-template <int LD>
-__device__ __forceinline__ void mma_cols(f32x16 (&acc)[2], const float* __restrict__ tl, const f32x16& P) {
-    float v[2][4][2];
+// acc[dt] += T^T[d = 32dt + l31][row(e)] * P[e] over the 32 rows carried by accumulator P (16*DT MFMAs, DT = DH/32): the
+// A operand of step e is T[(r0 + acc_row(e, lh)) * LD + 32dt + l31] (tl = &T[(r0 + 4lh) * LD + l31]), the B operand
+// register e of P.  LDS values are read 4 e-steps ahead.
+template <int DT, int LD>
+__device__ __forceinline__ void mma_cols(f32x16 (&acc)[DT], const float* __restrict__ tl, const f32x16& P) {
+    float v[2][4][DT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        v[0][i][0] = tl[((i & 3) + 8 * (i >> 2)) * LD];
-        v[0][i][1] = tl[((i & 3) + 8 * (i >> 2)) * LD + 32];
-    }
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) v[0][i][dt] = tl[((i & 3) + 8 * (i >> 2)) * LD + 32 * dt];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         if (c + 1 < 4) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int e = 4 * (c + 1) + i;
-                v[(c + 1) & 1][i][0] = tl[((e & 3) + 8 * (e >> 2)) * LD];
-                v[(c + 1) & 1][i][1] = tl[((e & 3) + 8 * (e >> 2)) * LD + 32];
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) v[(c + 1) & 1][i][dt] = tl[((e & 3) + 8 * (e >> 2)) * LD + 32 * dt];
             }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            acc[0] = AT_MFMA(v[c & 1][i][0], P[4 * c + i], acc[0]);
-            acc[1] = AT_MFMA(v[c & 1][i][1], P[4 * c + i], acc[1]);
-        }
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) acc[dt] = AT_MFMA(v[c & 1][i][dt], P[4 * c + i], acc[dt]);
     }
-    AT_SCHED_DSRD(4);                 // each (d, d+32) pair is one ds_read2_b32
+    if constexpr (DT == 2) {
+        AT_SCHED_DSRD(4);                 // each (d, d+32) pair is one ds_read2_b32
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
+        for (int c = 0; c < 3; ++c)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            AT_SCHED_MFMA(2);
-            AT_SCHED_DSRD(1);
-        }
-    AT_SCHED_MFMA(8);
+            for (int i = 0; i < 4; ++i) {
+                AT_SCHED_MFMA(2);
+                AT_SCHED_DSRD(1);
+            }
+        AT_SCHED_MFMA(8);
+    }
 }
 
-// two such products sharing the pipeline (64 MFMAs): accA += TA^T PA, accB += TB^T PB; LDS read 2 e-steps ahead.
-template <int LD>
-__device__ __forceinline__ void mma2_cols(f32x16 (&accA)[2], const float* __restrict__ ta, const f32x16& PA,
-                                          f32x16 (&accB)[2], const float* __restrict__ tb, const f32x16& PB) {
-    float va[2][2][2], vb[2][2][2];
+// two such products sharing the pipeline: accA += TA^T PA, accB += TB^T PB; LDS read 2 e-steps ahead.
+template <int DT, int LD>
+__device__ __forceinline__ void mma2_cols(f32x16 (&accA)[DT], const float* __restrict__ ta, const f32x16& PA,
+                                          f32x16 (&accB)[DT], const float* __restrict__ tb, const f32x16& PB) {
+    float va[2][2][DT], vb[2][2][DT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        va[0][i][0] = ta[i * LD]; va[0][i][1] = ta[i * LD + 32];
-        vb[0][i][0] = tb[i * LD]; vb[0][i][1] = tb[i * LD + 32];
-    }
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) { va[0][i][dt] = ta[i * LD + 32 * dt]; vb[0][i][dt] = tb[i * LD + 32 * dt]; }
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         if (c + 1 < 8) {
@@ -214,57 +247,71 @@ __device__ __forceinline__ void mma2_cols(f32x16 (&accA)[2], const float* __rest
             for (int i = 0; i < 2; ++i) {
                 const int e = 2 * (c + 1) + i;
                 const int off = ((e & 3) + 8 * (e >> 2)) * LD;
-                va[(c + 1) & 1][i][0] = ta[off]; va[(c + 1) & 1][i][1] = ta[off + 32];
-                vb[(c + 1) & 1][i][0] = tb[off]; vb[(c + 1) & 1][i][1] = tb[off + 32];
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) { va[(c + 1) & 1][i][dt] = ta[off + 32 * dt]; vb[(c + 1) & 1][i][dt] = tb[off + 32 * dt]; }
             }
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            accA[0] = AT_MFMA(va[c & 1][i][0], PA[2 * c + i], accA[0]);
-            accB[0] = AT_MFMA(vb[c & 1][i][0], PB[2 * c + i], accB[0]);
-            accA[1] = AT_MFMA(va[c & 1][i][1], PA[2 * c + i], accA[1]);
-            accB[1] = AT_MFMA(vb[c & 1][i][1], PB[2 * c + i], accB[1]);
-        }
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                accA[dt] = AT_MFMA(va[c & 1][i][dt], PA[2 * c + i], accA[dt]);
+                accB[dt] = AT_MFMA(vb[c & 1][i][dt], PB[2 * c + i], accB[dt]);
+            }
     }
-    AT_SCHED_DSRD(4);
+    if constexpr (DT == 2) {
+        AT_SCHED_DSRD(4);
 #pragma unroll
-    for (int c = 0; c < 7; ++c)
+        for (int c = 0; c < 7; ++c)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            AT_SCHED_MFMA(2);
-            AT_SCHED_DSRD(1);
-        }
-    AT_SCHED_MFMA(8);
+            for (int i = 0; i < 4; ++i) {
+                AT_SCHED_MFMA(2);
+                AT_SCHED_DSRD(1);
+            }
+        AT_SCHED_MFMA(8);
+    }
 }
 
-// per-wave transposed store: acc[dt][e] = X^T[d = 32dt + acc_row(e, lh)][row = l31]  ->  dst rows of 64 contiguous floats
-__device__ __forceinline__ void store_transposed(float* __restrict__ E, const f32x16 (&acc)[2], float mul, float* __restrict__ dst,
+// per-wave transposed store: acc[dt][e] = X^T[d = 32dt + acc_row(e, lh)][row = l31]  ->  dst rows of DH contiguous floats
+template <int DH>
+__device__ __forceinline__ void store_transposed(float* __restrict__ E, const f32x16 (&acc)[DH / 32], float mul, float* __restrict__ dst,
                                                  int64_t D, int row0, int nrows, int lane) {
+    constexpr int LD = DH + 4, C4 = DH / 4;
     const int l31 = lane & 31, lh = lane >> 5;
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < DH / 32; ++dt)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) E[l31 * AT_KLD + dt * 32 + acc_row(e, lh)] = acc[dt][e] * mul;
+        for (int e = 0; e < 16; ++e) E[l31 * LD + dt * 32 + acc_row(e, lh)] = acc[dt][e] * mul;
     __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the staging area is private to the wave
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int r = it * 4 + (lane >> 4), c4 = (lane & 15) * 4;
+    for (int it = 0; it < DH / 8; ++it) {
+        const int idx = it * 64 + lane;
+        const int r = idx / C4, c4 = (idx % C4) * 4;
         if (row0 + r < nrows)
-            *reinterpret_cast<float4*>(dst + (int64_t)(row0 + r) * D + c4) = *reinterpret_cast<const float4*>(&E[r * AT_KLD + c4]);
+            *reinterpret_cast<float4*>(dst + (int64_t)(row0 + r) * D + c4) = *reinterpret_cast<const float4*>(&E[r * LD + c4]);
     }
+}
+
+// visible-key bits of this lane's query for the 64 keys of tile t, already shifted so that bit kl <-> local key kl + 4lh
+__device__ __forceinline__ unsigned long long dense_bits(const AttnExtra& x, int b, int q, int Tq, int Tk, int t, int lh) {
+    const int nw = (Tk + 63) >> 6;
+    const unsigned long long w = q < Tq ? x.mask_bits[((int64_t)b * Tq + q) * nw + t] : 0ull;
+    return w >> (4 * lh);
 }
 
 // =====================================================================================================
 // forward: block = 128 queries (4 waves x 32), loop over 64-key tiles
 // =====================================================================================================
-__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
-    // one LDS block: [K tile 64 x 68 | V tile 64 x 68]; the epilogue re-uses it as [4 waves][32 q][68]
-    constexpr int SM_FLOATS = 2 * AT_BK * AT_KLD > 4 * 32 * AT_KLD ? 2 * AT_BK * AT_KLD : 4 * 32 * AT_KLD;
+template <int DH, bool GEN>
+__global__ __launch_bounds__(256, DH <= 64 ? 2 : 1) void attn_fwd_kernel(const AttnParams p) {
+    constexpr int LD = DH + 4, G = DH / 8, DT = DH / 32, NV = AT_BK * DH / 1024;
+    // one LDS block: [K tile 64 x LD | V tile 64 x LD]; the epilogue re-uses it as [4 waves][32 q][LD]
+    constexpr int SM_FLOATS = 2 * AT_BK * LD > 4 * 32 * LD ? 2 * AT_BK * LD : 4 * 32 * LD;
     __shared__ __attribute__((aligned(16))) float smem[SM_FLOATS];
     __shared__ int sh_fv;
     float* Ks = smem;
-    float* Vs = smem + AT_BK * AT_KLD;
+    float* Vs = smem + AT_BK * LD;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -274,17 +321,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     const int b = bh / p.H, h = bh - b * p.H;
     const int q0 = qb * AT_BQ + wave * 32;           // this wave's first query
     const int q = q0 + l31;                           // this lane's query
-    const float* Qb = p.Q + ((int64_t)b * p.Tq) * p.LQ + (int64_t)h * AT_DH;
-    const float* Kb = p.K + ((int64_t)b * p.Tk) * p.LQ + (int64_t)h * AT_DH;
-    const float* Vb = p.V + ((int64_t)b * p.Tk) * p.LQ + (int64_t)h * AT_DH;
+    const float* Qb = p.Q + ((int64_t)b * p.Tq) * p.LQ + (int64_t)h * DH;
+    const float* Kb = p.K + ((int64_t)b * p.Tk) * p.LQ + (int64_t)h * DH;
+    const float* Vb = p.V + ((int64_t)b * p.Tk) * p.LQ + (int64_t)h * DH;
     const int32_t* kv = p.key_valid ? p.key_valid + (int64_t)b * p.Tk : nullptr;
     const int shift = p.Tk - p.Tq;                    // causal: key j visible to query i iff j <= i + shift
+    const bool dense = GEN && p.x.mask_bits != nullptr;
+    const bool dropping = GEN && (p.x.drop_mask != nullptr || p.x.drop_threshold != 0u);
+    const int64_t drow = ((int64_t)b * p.H + h) * p.Tq + q;             // row of the [B,H,Tq,Tk] dropout mask
+    const unsigned seed = GEN ? p.x.drop_seed + (p.x.seed_dev ? p.x.seed_dev[0] : 0u) : 0u;
+    const unsigned rowkey = GEN ? at_rowkey(seed, (unsigned)drow) : 0u;
 
     // Q fragments, pre-scaled by scale*log2(e) (softmax runs on exp2): lane (q, lh) holds Q[q][8g + 4lh + j]
-    float qf[8][4];
+    float qf[G][4];
     const float qs = p.scale * AT_LOG2E;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
+    for (int g = 0; g < G; ++g) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (q < p.Tq) v = *reinterpret_cast<const float4*>(Qb + (int64_t)q * p.LQ + 8 * g + 4 * lh);
         qf[g][0] = v.x * qs; qf[g][1] = v.y * qs; qf[g][2] = v.z * qs; qf[g][3] = v.w * qs;
@@ -295,47 +347,55 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     // uniform over ALL keys (every score is the same -1e9) and nothing may be skipped.
     const int fv = first_valid_key(kv, p.Tk, tid, &sh_fv);
     int n_tiles = (p.Tk + AT_BK - 1) / AT_BK;
-    const bool skip_ok = p.causal && fv <= qb * AT_BQ + shift;   // every query of the block sees a non-padding key
+    const bool skip_ok = !dense && p.causal && fv <= qb * AT_BQ + shift;   // every query of the block sees a non-padding key
     if (skip_ok) {
         const int last_key = min(p.Tk - 1, qb * AT_BQ + AT_BQ - 1 + shift);
         n_tiles = last_key < 0 ? 0 : last_key / AT_BK + 1;
     }
+    // dense mask: a tile none of this wave's queries can see is skipped when every one of them sees SOME key elsewhere
+    const bool row_sees = dense && p.x.row_any && q < p.Tq ? p.x.row_any[(int64_t)b * p.Tq + q] != 0 : (q >= p.Tq);
 
-    f32x16 o[2];                                        // O^T: o[dt][e] <-> d = 32dt + acc_row(e, lh), query = lane
+    f32x16 o[DT];                                       // O^T: o[dt][e] <-> d = 32dt + acc_row(e, lh), query = lane
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
     float m = -INFINITY, l = 0.f;                       // running max (log2 units, shared by the lane pair), partial sum
 
-    TileRegs kr, vr;
+    TileRegsN<NV> kr, vr;
     int kflag = 1;
     if (n_tiles > 0) {
-        tile_fetch(kr, Kb, p.LQ, 0, p.Tk, tid);
-        tile_fetch(vr, Vb, p.LQ, 0, p.Tk, tid);
+        tile_fetch<DH>(kr, Kb, p.LQ, 0, p.Tk, tid);
+        tile_fetch<DH>(vr, Vb, p.LQ, 0, p.Tk, tid);
         kflag = key_flag(kv, 0, p.Tk, lane);
     }
     for (int t = 0; t < n_tiles; ++t) {
         const int kv0 = t * AT_BK;
         __syncthreads();                                // previous tile fully consumed
-        tile_commit<AT_KLD>(Ks, kr, tid);
-        tile_commit<AT_KLD>(Vs, vr, tid);
-        const unsigned long long valid = __ballot(kflag != 0) >> (4 * lh);   // bit j: key kv0 + j + 4lh is a real token
+        tile_commit<DH>(Ks, kr, tid);
+        tile_commit<DH>(Vs, vr, tid);
+        unsigned long long valid = __ballot(kflag != 0) >> (4 * lh);   // bit j: key kv0 + j + 4lh is a real token
         __syncthreads();
         if (t + 1 < n_tiles) {                          // next tile's loads fly during this tile's MFMAs
-            tile_fetch(kr, Kb, p.LQ, kv0 + AT_BK, p.Tk, tid);
-            tile_fetch(vr, Vb, p.LQ, kv0 + AT_BK, p.Tk, tid);
+            tile_fetch<DH>(kr, Kb, p.LQ, kv0 + AT_BK, p.Tk, tid);
+            tile_fetch<DH>(vr, Vb, p.LQ, kv0 + AT_BK, p.Tk, tid);
             kflag = key_flag(kv, kv0 + AT_BK, p.Tk, lane);
         }
-        // wave-uniform skip: every key of this tile is above the diagonal for all 32 queries of the wave
-        if (!(skip_ok && kv0 > q0 + 31 + shift)) {
+        bool skip = skip_ok && kv0 > q0 + 31 + shift;   // wave-uniform: every key of this tile is above the diagonal
+        if constexpr (GEN) {
+            if (dense) {
+                valid = dense_bits(p.x, b, q, p.Tq, p.Tk, t, lh);
+                skip = __ballot(valid != 0ull || !row_sees) == 0ull;
+            }
+        }
+        if (!skip) {
             // ---- S^T = K Q^T (2 key sub-tiles of 32) -------------------------------------------------------
             f32x16 s[2];
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) s[kt][e] = 0.f;
-            mma2_rows(s[0], &Ks[l31 * AT_KLD + 4 * lh], qf, s[1], &Ks[(32 + l31) * AT_KLD + 4 * lh], qf);
+            mma2_rows<G>(s[0], &Ks[l31 * LD + 4 * lh], qf, s[1], &Ks[(32 + l31) * LD + 4 * lh], qf);
             // ---- mask + online softmax (lane <-> query); local key of register (kt, e) = kt*32 + rc(e) + 4lh ------
             const int lim_causal = p.causal ? q + shift - kv0 - 4 * lh : 1 << 30;   // masked iff local index > lim
             const int lim_range = p.Tk - 1 - kv0 - 4 * lh;                            // not a key at all iff local index > lim
@@ -359,19 +419,25 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    const float pv = __builtin_amdgcn_exp2f(s[kt][e] - m_new);
+                    float pv = __builtin_amdgcn_exp2f(s[kt][e] - m_new);
+                    ps += pv;                                        // the softmax denominator is over the UN-dropped map
+                    if constexpr (GEN) {
+                        if (dropping) {
+                            const int key = kv0 + kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                            pv *= (q < p.Tq && key < p.Tk) ? at_drop_mult(p.x, rowkey, drow, p.Tk, key) : 0.f;
+                        }
+                    }
                     s[kt][e] = pv;
-                    ps += pv;
                 }
             l = l * alpha + ps;
             m = m_new;
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
+            for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;
             // ---- O^T += V^T P^T ------------------------------------------------------------------------------
-            mma_cols<AT_KLD>(o, &Vs[(4 * lh) * AT_KLD + l31], s[0]);
-            mma_cols<AT_KLD>(o, &Vs[(32 + 4 * lh) * AT_KLD + l31], s[1]);
+            mma_cols<DT, LD>(o, &Vs[(4 * lh) * LD + l31], s[0]);
+            mma_cols<DT, LD>(o, &Vs[(32 + 4 * lh) * LD + l31], s[1]);
         }
     }
 
@@ -381,28 +447,32 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     const float inv = lt > 0.f ? 1.0f / lt : 0.f;
     if (lh == 0 && q < p.Tq)
         *reinterpret_cast<float2*>(p.LSE + 2 * (((int64_t)b * p.H + h) * p.Tq + q)) = make_float2(m, log2f(lt));
-    __syncthreads();                                     // K/V tiles are dead: reuse the block as [4 waves][32 q][68]
-    store_transposed(smem + wave * (32 * AT_KLD), o, inv, p.O + ((int64_t)b * p.Tq) * p.D + (int64_t)h * AT_DH, p.D, q0, p.Tq, lane);
+    __syncthreads();                                     // K/V tiles are dead: reuse the block as [4 waves][32 q][LD]
+    store_transposed<DH>(smem + wave * (32 * LD), o, inv, p.O + ((int64_t)b * p.Tq) * p.D + (int64_t)h * DH, p.D, q0, p.Tq, lane);
 }
 
 // =====================================================================================================
 // dK, dV: block = 128 keys (4 waves x 32), loop over 32-query tiles
 // S[q,key] = Q K^T (A = Q tile rows from LDS, B = K fragments in registers; lane <-> key, registers <-> queries),
-// P = exp2(S - m[q] - l[q]), dP = dO V^T (B = V fragments in registers), dS = P (dP - Dsum[q]) * scale (0 where
-// masked), dV^T[d,key] += dO^T P, dK^T[d,key] += Q^T dS -- P and dS feed those MFMAs as B operands straight from
+// P = exp2(S - m[q] - l[q]), dP = dO V^T (B = V fragments in registers), dS = P (dP*drop - Dsum[q]) * scale (0 where
+// masked), dV^T[d,key] += dO^T (P*drop), dK^T[d,key] += Q^T dS -- P and dS feed those MFMAs as B operands straight from
 // their accumulator registers.
 // =====================================================================================================
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdParams p) {
-    constexpr int QT = 32;                                     // queries per tile (keeps the kernel at 2 blocks / CU)
-    constexpr int SM_FLOATS = 4 * 32 * AT_KLD;                 // epilogue staging; the loop uses Q tile, dO tile, max, log2sum, Dsum
-    static_assert(SM_FLOATS >= 2 * QT * AT_KLD + 3 * QT, "tiles must fit");
+template <int DH, bool GEN>
+__global__ __launch_bounds__(256, DH <= 64 ? 2 : 1) void attn_bwd_dkdv_kernel(const AttnBwdParams p) {
+    constexpr int LD = DH + 4, G = DH / 8, DT = DH / 32;
+    constexpr int QT = 32;                                     // queries per tile (keeps the DH = 64 kernel at 2 blocks / CU)
+    constexpr int NV = QT * DH / 1024;
+    constexpr int SM_FLOATS = 4 * 32 * LD;                     // epilogue staging; the loop uses Q tile, dO tile, max, log2sum, Dsum, any
+    static_assert(SM_FLOATS >= 2 * QT * LD + 4 * QT, "tiles must fit");
     __shared__ __attribute__((aligned(16))) float smem[SM_FLOATS];
     __shared__ int sh_fv;
     float* Qs = smem;
-    float* dOs = smem + QT * AT_KLD;
-    float* Ms = smem + 2 * QT * AT_KLD;
+    float* dOs = smem + QT * LD;
+    float* Ms = smem + 2 * QT * LD;
     float* Ls = Ms + QT;
     float* Ds = Ls + QT;
+    float* As = Ds + QT;                                       // GEN: row_any of the tile's queries
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -412,10 +482,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdPara
     const int b = bh / p.H, h = bh - b * p.H;
     const int k0w = kb * 128 + wave * 32;
     const int key = k0w + l31;                                  // this lane's key
-    const float* Qb = p.Q + ((int64_t)b * p.Tq) * p.LQ + (int64_t)h * AT_DH;
-    const float* dOb = p.dO + ((int64_t)b * p.Tq) * p.D + (int64_t)h * AT_DH;
-    const float* Kb = p.K + ((int64_t)b * p.Tk) * p.LQ + (int64_t)h * AT_DH;
-    const float* Vb = p.V + ((int64_t)b * p.Tk) * p.LQ + (int64_t)h * AT_DH;
+    const float* Qb = p.Q + ((int64_t)b * p.Tq) * p.LQ + (int64_t)h * DH;
+    const float* dOb = p.dO + ((int64_t)b * p.Tq) * p.D + (int64_t)h * DH;
+    const float* Kb = p.K + ((int64_t)b * p.Tk) * p.LQ + (int64_t)h * DH;
+    const float* Vb = p.V + ((int64_t)b * p.Tk) * p.LQ + (int64_t)h * DH;
     const float2* LSEb = reinterpret_cast<const float2*>(p.LSE) + ((int64_t)b * p.H + h) * p.Tq;
     const float* Dsb = p.Dsum + ((int64_t)b * p.H + h) * p.Tq;
     const int32_t* kv = p.key_valid ? p.key_valid + (int64_t)b * p.Tk : nullptr;
@@ -423,12 +493,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdPara
     const int fv = first_valid_key(kv, p.Tk, tid, &sh_fv);
     const bool key_in = key < p.Tk;
     const bool key_pad = kv && key_in && kv[key] == 0;
+    const bool dense = GEN && p.x.mask_bitsT != nullptr;
+    const bool dropping = GEN && (p.x.drop_mask != nullptr || p.x.drop_threshold != 0u);
+    const int nwq = (p.Tq + 63) >> 6;
+    const unsigned long long* bitsT = dense && key_in ? p.x.mask_bitsT + ((int64_t)b * p.Tk + key) * nwq : nullptr;
+    const int64_t drow0 = ((int64_t)b * p.H + h) * p.Tq;
+    const unsigned seed = GEN ? p.x.drop_seed + (p.x.seed_dev ? p.x.seed_dev[0] : 0u) : 0u;
 
     // K (pre-scaled by scale*log2e: scores in log2 units, as the forward saved them) and V fragments of this lane's key
-    float kf[8][4], vf[8][4];
+    float kf[G][4], vf[G][4];
     const float sl2 = p.scale * AT_LOG2E;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
+    for (int g = 0; g < G; ++g) {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
         if (key_in) {
             a = *reinterpret_cast<const float4*>(Kb + (int64_t)key * p.LQ + 8 * g + 4 * lh);
@@ -437,9 +513,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdPara
         kf[g][0] = a.x * sl2; kf[g][1] = a.y * sl2; kf[g][2] = a.z * sl2; kf[g][3] = a.w * sl2;
         vf[g][0] = c.x; vf[g][1] = c.y; vf[g][2] = c.z; vf[g][3] = c.w;
     }
-    f32x16 dk[2], dv[2];                                        // dK^T / dV^T: [dt][e] <-> d = 32dt + acc_row(e,lh), key = lane
+    f32x16 dk[DT], dv[DT];                                      // dK^T / dV^T: [dt][e] <-> d = 32dt + acc_row(e,lh), key = lane
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) { dk[dt][e] = 0.f; dv[dt][e] = 0.f; }
 
@@ -447,41 +523,57 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdPara
     // AND the whole key block lies above its diagonal; both conditions are monotone in qt, so the visited tiles are
     // [0, qt_lo) (rows that may be fully masked) and [qt_hi, n_qt) (on / below the diagonal).
     const int n_qt = (p.Tq + QT - 1) / QT;
-    auto tile_skipped = [&](int qt) { return p.causal && fv <= qt * QT + shift && kb * 128 > qt * QT + QT - 1 + shift; };
+    auto tile_skipped = [&](int qt) { return !dense && p.causal && fv <= qt * QT + shift && kb * 128 > qt * QT + QT - 1 + shift; };
     auto next_tile = [&](int qt) { while (qt < n_qt && tile_skipped(qt)) ++qt; return qt; };
 
-    TileRegsN<2> qr, gr;
+    TileRegsN<NV> qr, gr;
     float2 ml = make_float2(0.f, 0.f);
-    float dsv = 0.f;
+    float dsv = 0.f, anyv = 1.f;
+    auto fetch_rows = [&](int qs) {
+        ml = make_float2(0.f, 0.f); dsv = 0.f; anyv = 1.f;
+        if (tid < QT && qs + tid < p.Tq) {
+            ml = LSEb[qs + tid]; dsv = Dsb[qs + tid];
+            if (GEN && dense && p.x.row_any) anyv = p.x.row_any[(int64_t)b * p.Tq + qs + tid] ? 1.f : 0.f;
+        }
+    };
     int qt = next_tile(0);
     if (qt < n_qt) {
-        tile_fetch(qr, Qb, p.LQ, qt * QT, p.Tq, tid);
-        tile_fetch(gr, dOb, p.D, qt * QT, p.Tq, tid);
-        if (tid < QT && qt * QT + tid < p.Tq) { ml = LSEb[qt * QT + tid]; dsv = Dsb[qt * QT + tid]; }
+        tile_fetch<DH>(qr, Qb, p.LQ, qt * QT, p.Tq, tid);
+        tile_fetch<DH>(gr, dOb, p.D, qt * QT, p.Tq, tid);
+        fetch_rows(qt * QT);
     }
     while (qt < n_qt) {
         const int qs = qt * QT;
         __syncthreads();
-        tile_commit<AT_KLD>(Qs, qr, tid);
-        tile_commit<AT_KLD>(dOs, gr, tid);
-        if (tid < QT) { Ms[tid] = ml.x; Ls[tid] = ml.y; Ds[tid] = dsv; }
+        tile_commit<DH>(Qs, qr, tid);
+        tile_commit<DH>(dOs, gr, tid);
+        if (tid < QT) { Ms[tid] = ml.x; Ls[tid] = ml.y; Ds[tid] = dsv; As[tid] = anyv; }
         __syncthreads();
         const int qn = next_tile(qt + 1);
         if (qn < n_qt) {
-            tile_fetch(qr, Qb, p.LQ, qn * QT, p.Tq, tid);
-            tile_fetch(gr, dOb, p.D, qn * QT, p.Tq, tid);
-            ml = make_float2(0.f, 0.f); dsv = 0.f;
-            if (tid < QT && qn * QT + tid < p.Tq) { ml = LSEb[qn * QT + tid]; dsv = Dsb[qn * QT + tid]; }
+            tile_fetch<DH>(qr, Qb, p.LQ, qn * QT, p.Tq, tid);
+            tile_fetch<DH>(gr, dOb, p.D, qn * QT, p.Tq, tid);
+            fetch_rows(qn * QT);
         }
         // wave-uniform skip: this wave's 32 keys are above the diagonal for all queries of the tile (which all see a real key)
-        if (!(p.causal && fv <= qs + shift && k0w > qs + QT - 1 + shift)) {
+        bool skip = !dense && p.causal && fv <= qs + shift && k0w > qs + QT - 1 + shift;
+        unsigned validq = 0xFFFFFFFFu;                           // dense: bit ql <-> query qs + ql + 4lh visible to this key
+        if constexpr (GEN) {
+            if (dense) {
+                const unsigned long long w = bitsT ? bitsT[qs >> 6] : 0ull;
+                const unsigned w32 = (unsigned)(w >> (qs & 63));
+                validq = w32 >> (4 * lh);
+                skip = __ballot(w32 != 0u) == 0ull && __ballot(As[l31] == 0.f) == 0ull;
+            }
+        }
+        if (!skip) {
             const int lim_causal = p.causal ? key - shift - qs - 4 * lh : -(1 << 30);   // masked iff local query < lim
             const int lim_range = p.Tq - qs - 4 * lh;                                     // a query iff local index < lim
             f32x16 s, dp;
 #pragma unroll
             for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
-            mma2_rows(s, &Qs[l31 * AT_KLD + 4 * lh], kf, dp, &dOs[l31 * AT_KLD + 4 * lh], vf);
-            // ---- P = exp2(S_masked - m[q] - l[q]);  dS = P (dP - Dsum[q]) scale, zero where masked -------------------
+            mma2_rows<G>(s, &Qs[l31 * LD + 4 * lh], kf, dp, &dOs[l31 * LD + 4 * lh], vf);
+            // ---- P = exp2(S_masked - m[q] - l[q]);  dS = P (dP*drop - Dsum[q]) scale, zero where masked ---------------
 #pragma unroll
             for (int e4 = 0; e4 < 4; ++e4) {
                 const float4 M4 = *reinterpret_cast<const float4*>(&Ms[8 * e4 + 4 * lh]);
@@ -492,39 +584,48 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnBwdPara
                 for (int r = 0; r < 4; ++r) {
                     const int e = e4 * 4 + r;
                     const int ql = 8 * e4 + r;                          // local query index minus 4lh
-                    const bool masked = ql < lim_causal || key_pad;
+                    const bool masked = ql < lim_causal || key_pad || !((validq >> ql) & 1u);
                     float arg = ((masked ? AT_MASKED2 : s[e]) - Mr[r]) - Lr[r];
                     if (!(key_in && ql < lim_range)) arg = -INFINITY;
                     const float pv = __builtin_amdgcn_exp2f(arg);
-                    s[e] = pv;
-                    dp[e] = (masked ? 0.f : pv) * ((dp[e] - Dr[r]) * p.scale);
+                    float mult = 1.f;
+                    if constexpr (GEN) {
+                        if (dropping && key_in && ql < lim_range) {
+                            const int64_t row = drow0 + qs + ql + 4 * lh;
+                            mult = at_drop_mult(p.x, at_rowkey(seed, (unsigned)row), row, p.Tk, key);
+                        }
+                    }
+                    s[e] = pv * mult;                                   // dV^T += dO^T (P * drop)
+                    dp[e] = (masked ? 0.f : pv) * ((dp[e] * mult - Dr[r]) * p.scale);
                 }
             }
             // ---- dV^T += dO^T P ; dK^T += Q^T dS ----------------------------------------------------------------
-            mma2_cols<AT_KLD>(dv, &dOs[(4 * lh) * AT_KLD + l31], s, dk, &Qs[(4 * lh) * AT_KLD + l31], dp);
+            mma2_cols<DT, LD>(dv, &dOs[(4 * lh) * LD + l31], s, dk, &Qs[(4 * lh) * LD + l31], dp);
         }
         qt = qn;
     }
 
     // ---- store dK, dV rows (transpose through LDS) --------------------------------------------------------------
     __syncthreads();
-    float* E = smem + wave * (32 * AT_KLD);
-    store_transposed(E, dk, 1.0f, p.dK + ((int64_t)b * p.Tk) * p.LQ + (int64_t)h * AT_DH, p.LQ, k0w, p.Tk, lane);
+    float* E = smem + wave * (32 * LD);
+    store_transposed<DH>(E, dk, 1.0f, p.dK + ((int64_t)b * p.Tk) * p.LQ + (int64_t)h * DH, p.LQ, k0w, p.Tk, lane);
     __builtin_amdgcn_wave_barrier();
-    store_transposed(E, dv, 1.0f, p.dV + ((int64_t)b * p.Tk) * p.LQ + (int64_t)h * AT_DH, p.LQ, k0w, p.Tk, lane);
+    store_transposed<DH>(E, dv, 1.0f, p.dV + ((int64_t)b * p.Tk) * p.LQ + (int64_t)h * DH, p.LQ, k0w, p.Tk, lane);
 }
 
 // =====================================================================================================
 // dQ: block = 128 queries (4 waves x 32), loop over 64-key tiles (mirror of the forward)
 // S^T = K Q^T, P^T = exp2(S^T - m[q] - l[q]) (lane <-> query), dP^T = V dO^T (B = dO fragments in registers),
-// dS^T = P^T (dP^T - Dsum[q]) scale, dQ^T[d,q] += K^T dS^T.
+// dS^T = P^T (dP^T*drop - Dsum[q]) scale, dQ^T[d,q] += K^T dS^T.
 // =====================================================================================================
-__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdParams p) {
-    constexpr int SM_FLOATS = 2 * AT_BK * AT_KLD > 4 * 32 * AT_KLD ? 2 * AT_BK * AT_KLD : 4 * 32 * AT_KLD;
+template <int DH, bool GEN>
+__global__ __launch_bounds__(256, DH <= 64 ? 2 : 1) void attn_bwd_dq_kernel(const AttnBwdParams p) {
+    constexpr int LD = DH + 4, G = DH / 8, DT = DH / 32, NV = AT_BK * DH / 1024;
+    constexpr int SM_FLOATS = 2 * AT_BK * LD > 4 * 32 * LD ? 2 * AT_BK * LD : 4 * 32 * LD;
     __shared__ __attribute__((aligned(16))) float smem[SM_FLOATS];
     __shared__ int sh_fv;
     float* Ks = smem;
-    float* Vs = smem + AT_BK * AT_KLD;
+    float* Vs = smem + AT_BK * LD;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -534,22 +635,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdParams
     const int b = bh / p.H, h = bh - b * p.H;
     const int q0 = qb * AT_BQ + wave * 32;
     const int q = q0 + l31;
-    const float* Qb = p.Q + ((int64_t)b * p.Tq) * p.LQ + (int64_t)h * AT_DH;
-    const float* dOb = p.dO + ((int64_t)b * p.Tq) * p.D + (int64_t)h * AT_DH;
-    const float* Kb = p.K + ((int64_t)b * p.Tk) * p.LQ + (int64_t)h * AT_DH;
-    const float* Vb = p.V + ((int64_t)b * p.Tk) * p.LQ + (int64_t)h * AT_DH;
+    const float* Qb = p.Q + ((int64_t)b * p.Tq) * p.LQ + (int64_t)h * DH;
+    const float* dOb = p.dO + ((int64_t)b * p.Tq) * p.D + (int64_t)h * DH;
+    const float* Kb = p.K + ((int64_t)b * p.Tk) * p.LQ + (int64_t)h * DH;
+    const float* Vb = p.V + ((int64_t)b * p.Tk) * p.LQ + (int64_t)h * DH;
     const int32_t* kv = p.key_valid ? p.key_valid + (int64_t)b * p.Tk : nullptr;
     const int shift = p.Tk - p.Tq;
     const int fv = first_valid_key(kv, p.Tk, tid, &sh_fv);
     const bool q_in = q < p.Tq;
     const float2 ml = q_in ? reinterpret_cast<const float2*>(p.LSE)[((int64_t)b * p.H + h) * p.Tq + q] : make_float2(0.f, 0.f);
-    const float* Ob = p.O + ((int64_t)b * p.Tq) * p.D + (int64_t)h * AT_DH;
+    const float* Ob = p.O + ((int64_t)b * p.Tq) * p.D + (int64_t)h * DH;
+    const bool dense = GEN && p.x.mask_bits != nullptr;
+    const bool dropping = GEN && (p.x.drop_mask != nullptr || p.x.drop_threshold != 0u);
+    const int64_t drow = ((int64_t)b * p.H + h) * p.Tq + q;
+    const unsigned seed = GEN ? p.x.drop_seed + (p.x.seed_dev ? p.x.seed_dev[0] : 0u) : 0u;
+    const unsigned rowkey = GEN ? at_rowkey(seed, (unsigned)drow) : 0u;
+    const bool row_sees = dense && p.x.row_any && q_in ? p.x.row_any[(int64_t)b * p.Tq + q] != 0 : !q_in;
 
-    float qf[8][4], gf[8][4];                                   // Q (pre-scaled, log2 units) and dO fragments of this lane's query
+    float qf[G][4], gf[G][4];                                   // Q (pre-scaled, log2 units) and dO fragments of this lane's query
     const float sl2 = p.scale * AT_LOG2E;
     float dpart = 0.f;                                          // this half-wave's part of Dsum[q] = sum_d dO[q,d] O[q,d]
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
+    for (int g = 0; g < G; ++g) {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a, o4 = a;
         if (q_in) {
             a = *reinterpret_cast<const float4*>(Qb + (int64_t)q * p.LQ + 8 * g + 4 * lh);
@@ -560,42 +667,49 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdParams
         gf[g][0] = c.x; gf[g][1] = c.y; gf[g][2] = c.z; gf[g][3] = c.w;
         dpart += c.x * o4.x + c.y * o4.y + c.z * o4.z + c.w * o4.w;
     }
-    // Dsum (= sum_k dP P, the softmax-backward row term) is produced here -- the dO fragments are already in registers --
-    // and saved for the dK/dV kernel, which runs after this one.
+    // Dsum (= sum_k dP P, the softmax-backward row term; with dropout O already holds the dropped map, so dO.O is still it)
+    // is produced here -- the dO fragments are already in registers -- and saved for the dK/dV kernel, which runs after.
     const float dsum = dpart + __shfl_xor(dpart, 32, 64);
     if (lh == 0 && q_in) p.Dsum[((int64_t)b * p.H + h) * p.Tq + q] = dsum;
     int n_tiles = (p.Tk + AT_BK - 1) / AT_BK;
-    const bool skip_ok = p.causal && fv <= qb * AT_BQ + shift;
+    const bool skip_ok = !dense && p.causal && fv <= qb * AT_BQ + shift;
     if (skip_ok) {
         const int last_key = min(p.Tk - 1, qb * AT_BQ + AT_BQ - 1 + shift);
         n_tiles = last_key < 0 ? 0 : last_key / AT_BK + 1;
     }
-    f32x16 dq[2];
+    f32x16 dq[DT];
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int e = 0; e < 16; ++e) dq[dt][e] = 0.f;
 
-    TileRegs kr, vr;
+    TileRegsN<NV> kr, vr;
     int kflag = 1;
     if (n_tiles > 0) {
-        tile_fetch(kr, Kb, p.LQ, 0, p.Tk, tid);
-        tile_fetch(vr, Vb, p.LQ, 0, p.Tk, tid);
+        tile_fetch<DH>(kr, Kb, p.LQ, 0, p.Tk, tid);
+        tile_fetch<DH>(vr, Vb, p.LQ, 0, p.Tk, tid);
         kflag = key_flag(kv, 0, p.Tk, lane);
     }
     for (int t = 0; t < n_tiles; ++t) {
         const int kv0 = t * AT_BK;
         __syncthreads();
-        tile_commit<AT_KLD>(Ks, kr, tid);
-        tile_commit<AT_KLD>(Vs, vr, tid);
-        const unsigned long long valid = __ballot(kflag != 0) >> (4 * lh);
+        tile_commit<DH>(Ks, kr, tid);
+        tile_commit<DH>(Vs, vr, tid);
+        unsigned long long valid = __ballot(kflag != 0) >> (4 * lh);
         __syncthreads();
         if (t + 1 < n_tiles) {
-            tile_fetch(kr, Kb, p.LQ, kv0 + AT_BK, p.Tk, tid);
-            tile_fetch(vr, Vb, p.LQ, kv0 + AT_BK, p.Tk, tid);
+            tile_fetch<DH>(kr, Kb, p.LQ, kv0 + AT_BK, p.Tk, tid);
+            tile_fetch<DH>(vr, Vb, p.LQ, kv0 + AT_BK, p.Tk, tid);
             kflag = key_flag(kv, kv0 + AT_BK, p.Tk, lane);
         }
-        if (!(skip_ok && kv0 > q0 + 31 + shift)) {
+        bool skip = skip_ok && kv0 > q0 + 31 + shift;
+        if constexpr (GEN) {
+            if (dense) {
+                valid = dense_bits(p.x, b, q, p.Tq, p.Tk, t, lh);
+                skip = __ballot(valid != 0ull || !row_sees) == 0ull;
+            }
+        }
+        if (!skip) {
             const int lim_causal = p.causal ? q + shift - kv0 - 4 * lh : 1 << 30;
             const int lim_range = q_in ? p.Tk - 1 - kv0 - 4 * lh : -1;
 #pragma unroll
@@ -603,20 +717,72 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnBwdParams
                 f32x16 s, dp;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
-                mma2_rows(s, &Ks[(kt * 32 + l31) * AT_KLD + 4 * lh], qf, dp, &Vs[(kt * 32 + l31) * AT_KLD + 4 * lh], gf);
+                mma2_rows<G>(s, &Ks[(kt * 32 + l31) * LD + 4 * lh], qf, dp, &Vs[(kt * 32 + l31) * LD + 4 * lh], gf);
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int kl = kt * 32 + (e & 3) + 8 * (e >> 2);
                     const bool live = kl <= lim_range && kl <= lim_causal && ((valid >> kl) & 1ull);
                     const float arg = live ? (s[e] - ml.x) - ml.y : -INFINITY;
-                    dp[e] = __builtin_amdgcn_exp2f(arg) * ((dp[e] - dsum) * p.scale);
+                    float mult = 1.f;
+                    if constexpr (GEN) {
+                        if (dropping && live) mult = at_drop_mult(p.x, rowkey, drow, p.Tk, kv0 + kl + 4 * lh);
+                    }
+                    dp[e] = __builtin_amdgcn_exp2f(arg) * ((dp[e] * mult - dsum) * p.scale);
                 }
-                mma_cols<AT_KLD>(dq, &Ks[(kt * 32 + 4 * lh) * AT_KLD + l31], dp);      // dQ^T += K^T dS^T
+                mma_cols<DT, LD>(dq, &Ks[(kt * 32 + 4 * lh) * LD + l31], dp);      // dQ^T += K^T dS^T
             }
         }
     }
     __syncthreads();
-    store_transposed(smem + wave * (32 * AT_KLD), dq, 1.0f, p.dQ + ((int64_t)b * p.Tq) * p.LQ + (int64_t)h * AT_DH, p.LQ, q0, p.Tq, lane);
+    store_transposed<DH>(smem + wave * (32 * LD), dq, 1.0f, p.dQ + ((int64_t)b * p.Tq) * p.LQ + (int64_t)h * DH, p.LQ, q0, p.Tq, lane);
+}
+
+// ---- dense mask -> packed bits ---------------------------------------------------------------------------------------
+// mask [B, Tq, Tk] int32 (non-zero = key visible; the notebook's get_pad_mask & get_sub_mask) ->
+//   bits  [B, Tq, ceil(Tk/64)]  one wave per word: lanes <-> 64 consecutive keys (coalesced), ballot
+//   bitsT [B, Tk, ceil(Tq/64)]  one wave per word: lanes <-> 64 consecutive queries (stride Tk; the mask is small)
+//   row_any [B, Tq]             1 iff the row has a visible key
+__global__ __launch_bounds__(256) void attn_pack_mask_kernel(const int32_t* __restrict__ mask, unsigned long long* __restrict__ bits,
+                                                             unsigned long long* __restrict__ bitsT, unsigned char* __restrict__ row_any,
+                                                             int B, int Tq, int Tk) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wid = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int nw = (Tk + 63) >> 6, nwq = (Tq + 63) >> 6;
+    const int64_t n1 = (int64_t)B * Tq * nw, n2 = (int64_t)B * Tk * nwq, n3 = (int64_t)B * Tq;
+    if (wid < n1) {
+        const int64_t bq = wid / nw;
+        const int w = (int)(wid - bq * nw);
+        const int k = w * 64 + lane;
+        const int v = k < Tk ? mask[bq * Tk + k] : 0;
+        const unsigned long long word = __ballot(v != 0);
+        if (lane == 0) bits[wid] = word;
+    } else if (wid < n1 + n2) {
+        const int64_t j = wid - n1;
+        const int64_t bk = j / nwq;
+        const int w = (int)(j - bk * nwq);
+        const int64_t b = bk / Tk;
+        const int k = (int)(bk - b * Tk);
+        const int q = w * 64 + lane;
+        const int v = q < Tq ? mask[(b * Tq + q) * Tk + k] : 0;
+        const unsigned long long word = __ballot(v != 0);
+        if (lane == 0) bitsT[j] = word;
+    } else if (wid < n1 + n2 + n3) {
+        const int64_t bq = wid - n1 - n2;
+        int any = 0;
+        for (int k = lane; k < Tk; k += 64) any |= mask[bq * Tk + k] != 0;
+        const unsigned long long word = __ballot(any != 0);
+        if (lane == 0) row_any[bq] = word != 0ull;
+    }
+}
+
+// materialise the hash dropout multipliers (tests: the unfused path / the oracle run with exactly this mask)
+__global__ __launch_bounds__(256) void attn_dropout_mask_kernel(float* __restrict__ out, int64_t rows, int Tk, unsigned seed,
+                                                                unsigned threshold, float scale) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * Tk) return;
+    const int64_t row = i / Tk;
+    const int key = (int)(i - row * Tk);
+    out[i] = at_hash(at_rowkey(seed, (unsigned)row), (unsigned)key) >= threshold ? scale : 0.f;
 }
 
 }  // namespace nnhip
@@ -628,7 +794,7 @@ static int attn_check(const char* fn, const void* Q, const void* K, const void* 
     NNHIP_CHECK_ARG(ld_qkv == 0 || (ld_qkv >= H * dh && ld_qkv % 4 == 0), NNHIP_EINVAL,
                     "%s: ld_qkv must be 0 or a multiple of 4 that is >= H * head_dim", fn);
     NNHIP_CHECK_ARG(B >= 0 && H > 0 && Tq >= 0 && Tk >= 0, NNHIP_EINVAL, "%s: bad sizes", fn);
-    NNHIP_CHECK_ARG(dh == AT_DH, NNHIP_EINVAL, "%s: only head_dim 64 is supported by the fused kernel", fn);
+    NNHIP_CHECK_ARG(dh == 32 || dh == 64 || dh == 128, NNHIP_EINVAL, "%s: the fused kernels support head_dim 32, 64 and 128", fn);
     NNHIP_CHECK_ARG(Tq < (1 << 24) && Tk < (1 << 24) && B * H < (1 << 24), NNHIP_EINVAL, "%s: sizes too large", fn);
     if (B == 0 || Tq == 0) return 0;
     NNHIP_CHECK_ARG(Q && K && V, NNHIP_EINVAL, "%s: null pointer", fn);
@@ -636,26 +802,64 @@ static int attn_check(const char* fn, const void* Q, const void* K, const void* 
     return 0;
 }
 
-extern "C" int nnhipAttentionForward(const float* Q, const float* K, const float* V, const int32_t* key_valid,
-                                     float* O, float* LSE, int64_t B, int64_t H, int64_t Tq, int64_t Tk,
-                                     int64_t head_dim, int64_t ld_qkv, float scale, int causal, nnhipStream_t s) {
+static int fill_extra(const char* fn, AttnExtra& x, const nnhipAttentionOptions* o, const int32_t*& key_valid, int& causal) {
+    x = AttnExtra{};
+    if (!o) return 0;
+    NNHIP_CHECK_ARG((o->mask_bits == nullptr) == (o->mask_bitsT == nullptr), NNHIP_EINVAL,
+                    "%s: mask_bits and mask_bitsT come together (nnhipAttentionPackMask writes both)", fn);
+    NNHIP_CHECK_ARG(o->dropout_p >= 0.f && o->dropout_p < 1.f, NNHIP_EINVAL, "%s: dropout_p must be in [0, 1)", fn);
+    x.mask_bits = reinterpret_cast<const unsigned long long*>(o->mask_bits);
+    x.mask_bitsT = reinterpret_cast<const unsigned long long*>(o->mask_bitsT);
+    x.row_any = o->row_any;
+    x.drop_mask = o->dropout_mask;
+    x.drop_seed = o->dropout_seed;
+    x.seed_dev = o->dropout_seed_dev;
+    x.drop_scale = o->dropout_p > 0.f ? 1.0f / (1.0f - o->dropout_p) : 1.0f;
+    // keep iff hash >= threshold: P(drop) = threshold / 2^32
+    const double th = (double)o->dropout_p * 4294967296.0;
+    x.drop_threshold = o->dropout_mask ? 0u : (unsigned)(th < 4294967295.0 ? th : 4294967295.0);
+    if (x.mask_bits) { key_valid = nullptr; causal = 0; }   // the dense mask is the whole mask
+    return 0;
+}
+static bool extra_active(const AttnExtra& x) { return x.mask_bits || x.drop_mask || x.drop_threshold != 0u; }
+
+#define AT_DISPATCH(KERNEL, dh, gen, grid, st, p)                                                                      \
+    do {                                                                                                               \
+        if ((dh) == 64) { if (gen) hipLaunchKernelGGL((KERNEL<64, true>), grid, dim3(256), 0, st, p); else hipLaunchKernelGGL((KERNEL<64, false>), grid, dim3(256), 0, st, p); }     \
+        else if ((dh) == 32) { if (gen) hipLaunchKernelGGL((KERNEL<32, true>), grid, dim3(256), 0, st, p); else hipLaunchKernelGGL((KERNEL<32, false>), grid, dim3(256), 0, st, p); } \
+        else { if (gen) hipLaunchKernelGGL((KERNEL<128, true>), grid, dim3(256), 0, st, p); else hipLaunchKernelGGL((KERNEL<128, false>), grid, dim3(256), 0, st, p); }             \
+    } while (0)
+
+extern "C" int nnhipAttentionForwardEx(const float* Q, const float* K, const float* V, const int32_t* key_valid,
+                                       float* O, float* LSE, int64_t B, int64_t H, int64_t Tq, int64_t Tk,
+                                       int64_t head_dim, int64_t ld_qkv, float scale, int causal,
+                                       const nnhipAttentionOptions* opts, nnhipStream_t s) {
     if (int rc = attn_check("nnhipAttentionForward", Q, K, V, B, H, Tq, Tk, head_dim, ld_qkv)) return rc;
     if (B == 0 || Tq == 0) return 0;
     NNHIP_CHECK_ARG(Tk > 0, NNHIP_EINVAL, "nnhipAttentionForward: Tk must be > 0");
     NNHIP_CHECK_ARG(O && LSE && aligned16(O), NNHIP_EINVAL, "nnhipAttentionForward: null / misaligned output");
     AttnParams p;
+    if (int rc = fill_extra("nnhipAttentionForward", p.x, opts, key_valid, causal)) return rc;
     p.Q = Q; p.K = K; p.V = V; p.O = O; p.LSE = LSE; p.key_valid = key_valid;
-    p.B = (int)B; p.H = (int)H; p.Tq = (int)Tq; p.Tk = (int)Tk; p.D = H * AT_DH; p.LQ = ld_qkv ? ld_qkv : p.D; p.scale = scale; p.causal = causal;
+    p.B = (int)B; p.H = (int)H; p.Tq = (int)Tq; p.Tk = (int)Tk; p.D = H * head_dim; p.LQ = ld_qkv ? ld_qkv : p.D; p.scale = scale; p.causal = causal;
     const int64_t qblocks = ceil_div(Tq, AT_BQ);
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3(mapped_grid(B * H, qblocks)), dim3(256), 0, (hipStream_t)s, p);
+    const bool gen = extra_active(p.x);
+    AT_DISPATCH(attn_fwd_kernel, head_dim, gen, dim3(mapped_grid(B * H, qblocks)), (hipStream_t)s, p);
     NNHIP_LAUNCH_CHECK("attn_fwd_kernel");
     return 0;
 }
 
-extern "C" int nnhipAttentionBackward(const float* Q, const float* K, const float* V, const int32_t* key_valid,
-                                      const float* O, const float* dO, const float* LSE, float* dQ, float* dK,
-                                      float* dV, int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t head_dim,
-                                      int64_t ld_qkv, float scale, int causal, nnhipStream_t s) {
+extern "C" int nnhipAttentionForward(const float* Q, const float* K, const float* V, const int32_t* key_valid,
+                                     float* O, float* LSE, int64_t B, int64_t H, int64_t Tq, int64_t Tk,
+                                     int64_t head_dim, int64_t ld_qkv, float scale, int causal, nnhipStream_t s) {
+    return nnhipAttentionForwardEx(Q, K, V, key_valid, O, LSE, B, H, Tq, Tk, head_dim, ld_qkv, scale, causal, nullptr, s);
+}
+
+extern "C" int nnhipAttentionBackwardEx(const float* Q, const float* K, const float* V, const int32_t* key_valid,
+                                        const float* O, const float* dO, const float* LSE, float* dQ, float* dK,
+                                        float* dV, int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t head_dim,
+                                        int64_t ld_qkv, float scale, int causal, const nnhipAttentionOptions* opts,
+                                        nnhipStream_t s) {
     if (int rc = attn_check("nnhipAttentionBackward", Q, K, V, B, H, Tq, Tk, head_dim, ld_qkv)) return rc;
     if (B == 0 || Tq == 0 || Tk == 0) return 0;
     NNHIP_CHECK_ARG(O && dO && LSE && dQ && dK && dV, NNHIP_EINVAL, "nnhipAttentionBackward: null pointer");
@@ -665,13 +869,50 @@ extern "C" int nnhipAttentionBackward(const float* Q, const float* K, const floa
     float* dsum = static_cast<float*>(workspace((size_t)B * H * Tq * sizeof(float)));
     NNHIP_CHECK_ARG(dsum != nullptr, NNHIP_ENOMEM, "nnhipAttentionBackward: workspace allocation failed");
     AttnBwdParams p;
+    if (int rc = fill_extra("nnhipAttentionBackward", p.x, opts, key_valid, causal)) return rc;
     p.Q = Q; p.K = K; p.V = V; p.dO = dO; p.LSE = LSE; p.Dsum = dsum; p.O = O; p.dQ = dQ; p.dK = dK; p.dV = dV;
-    p.key_valid = key_valid; p.B = (int)B; p.H = (int)H; p.Tq = (int)Tq; p.Tk = (int)Tk; p.D = H * AT_DH;
+    p.key_valid = key_valid; p.B = (int)B; p.H = (int)H; p.Tq = (int)Tq; p.Tk = (int)Tk; p.D = H * head_dim;
     p.LQ = ld_qkv ? ld_qkv : p.D; p.scale = scale; p.causal = causal;
+    const bool gen = extra_active(p.x);
     // dQ first: it also produces Dsum, which the dK/dV kernel consumes
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(mapped_grid(B * H, ceil_div(Tq, AT_BQ))), dim3(256), 0, st, p);
+    AT_DISPATCH(attn_bwd_dq_kernel, head_dim, gen, dim3(mapped_grid(B * H, ceil_div(Tq, AT_BQ))), st, p);
     NNHIP_LAUNCH_CHECK("attn_bwd_dq_kernel");
-    hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3(mapped_grid(B * H, ceil_div(Tk, 128))), dim3(256), 0, st, p);
+    AT_DISPATCH(attn_bwd_dkdv_kernel, head_dim, gen, dim3(mapped_grid(B * H, ceil_div(Tk, 128))), st, p);
     NNHIP_LAUNCH_CHECK("attn_bwd_dkdv_kernel");
+    return 0;
+}
+
+extern "C" int nnhipAttentionBackward(const float* Q, const float* K, const float* V, const int32_t* key_valid,
+                                      const float* O, const float* dO, const float* LSE, float* dQ, float* dK,
+                                      float* dV, int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t head_dim,
+                                      int64_t ld_qkv, float scale, int causal, nnhipStream_t s) {
+    return nnhipAttentionBackwardEx(Q, K, V, key_valid, O, dO, LSE, dQ, dK, dV, B, H, Tq, Tk, head_dim, ld_qkv, scale,
+                                    causal, nullptr, s);
+}
+
+extern "C" int nnhipAttentionPackMask(const int32_t* mask, uint64_t* mask_bits, uint64_t* mask_bitsT, uint8_t* row_any,
+                                      int64_t B, int64_t Tq, int64_t Tk, nnhipStream_t s) {
+    NNHIP_CHECK_ARG(B >= 0 && Tq >= 0 && Tk >= 0 && Tq < (1 << 24) && Tk < (1 << 24), NNHIP_EINVAL, "nnhipAttentionPackMask: bad sizes");
+    if (B == 0 || Tq == 0 || Tk == 0) return 0;
+    NNHIP_CHECK_ARG(mask && mask_bits && mask_bitsT && row_any, NNHIP_EINVAL, "nnhipAttentionPackMask: null pointer");
+    const int64_t waves = B * Tq * ceil_div(Tk, 64) + B * Tk * ceil_div(Tq, 64) + B * Tq;
+    hipLaunchKernelGGL(attn_pack_mask_kernel, dim3((unsigned)ceil_div(waves, 4)), dim3(256), 0, (hipStream_t)s, mask,
+                       reinterpret_cast<unsigned long long*>(mask_bits), reinterpret_cast<unsigned long long*>(mask_bitsT), row_any,
+                       (int)B, (int)Tq, (int)Tk);
+    NNHIP_LAUNCH_CHECK("attn_pack_mask_kernel");
+    return 0;
+}
+
+extern "C" int nnhipAttentionDropoutMask(float* out, int64_t B, int64_t H, int64_t Tq, int64_t Tk, float dropout_p,
+                                         uint32_t seed, nnhipStream_t s) {
+    NNHIP_CHECK_ARG(B >= 0 && H >= 0 && Tq >= 0 && Tk >= 0 && Tk < (1 << 24), NNHIP_EINVAL, "nnhipAttentionDropoutMask: bad sizes");
+    NNHIP_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, NNHIP_EINVAL, "nnhipAttentionDropoutMask: dropout_p must be in [0, 1)");
+    const int64_t rows = B * H * Tq;
+    if (rows == 0 || Tk == 0) return 0;
+    NNHIP_CHECK_ARG(out != nullptr, NNHIP_EINVAL, "nnhipAttentionDropoutMask: null pointer");
+    const double th = (double)dropout_p * 4294967296.0;
+    hipLaunchKernelGGL(attn_dropout_mask_kernel, dim3((unsigned)ceil_div(rows * Tk, 256)), dim3(256), 0, (hipStream_t)s, out, rows,
+                       (int)Tk, seed, (unsigned)(th < 4294967295.0 ? th : 4294967295.0), dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f);
+    NNHIP_LAUNCH_CHECK("attn_dropout_mask_kernel");
     return 0;
 }

@@ -28,6 +28,12 @@ class Conv2dDesc(ctypes.Structure):
                                        "pu", "pd", "pl", "pr")]
 
 
+class AttentionOptions(ctypes.Structure):
+    """struct nnhipAttentionOptions (include/neunet_hip.h)."""
+    _fields_ = [("mask_bits", c_void_p), ("mask_bitsT", c_void_p), ("row_any", c_void_p), ("dropout_mask", c_void_p),
+                ("dropout_p", c_float), ("dropout_seed", ctypes.c_uint32), ("dropout_seed_dev", c_void_p)]
+
+
 class Pool2dDesc(ctypes.Structure):
     """struct nnhipPool2dDesc (include/neunet_hip.h)."""
     _fields_ = [(n, c_int64) for n in ("B", "C", "H", "W", "kh", "kw", "sh", "sw", "pu", "pd", "pl", "pr")]
@@ -58,6 +64,12 @@ _SIGNATURES = {
     "nnhipMaskedSoftmaxBackward": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, ctypes.c_int, c_void_p]),
     "nnhipAttentionForward": (ctypes.c_int, [P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_float, ctypes.c_int, c_void_p]),
     "nnhipAttentionBackward": (ctypes.c_int, [P, P, P, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_float, ctypes.c_int, c_void_p]),
+    "nnhipAttentionForwardEx": (ctypes.c_int, [P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_float, ctypes.c_int,
+                                               POINTER(AttentionOptions), c_void_p]),
+    "nnhipAttentionBackwardEx": (ctypes.c_int, [P, P, P, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_float,
+                                                ctypes.c_int, POINTER(AttentionOptions), c_void_p]),
+    "nnhipAttentionPackMask": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_void_p]),
+    "nnhipAttentionDropoutMask": (ctypes.c_int, [P, c_int64, c_int64, c_int64, c_int64, c_float, ctypes.c_uint32, c_void_p]),
     "nnhipEmbeddingForward": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, c_void_p]),
     "nnhipEmbeddingBackward": (ctypes.c_int, [P, P, P, c_int64, c_int64, c_int64, c_float, c_void_p]),
     "nnhipMul": (ctypes.c_int, [P, P, P, c_int64, c_void_p]),

@@ -7,6 +7,8 @@ two-level batch stride (T*D, dh) with row stride D, so QK^T, attn*V and all four
 that layout directly -- no transpose or .contiguous() copies; 1/sqrt(d_model) and the pad/causal mask are
 fused into the softmax kernel.  Same parameters, same order (wq, wk, wv, fc) and the same math as the notebook.
 """
+import ctypes
+import itertools
 import math
 
 import numpy as np
@@ -15,7 +17,7 @@ from ...autograd import Tensor
 from ..modules import Module
 from .embedding import HIPDropout
 from .linear import HIPLinear, _finish_param, hip_linear_module_backward, hip_linear_module_forward
-from ..._lib import StridedView
+from ..._lib import AttentionOptions, StridedView
 from .utils import call_hip_function, get_current_stream_ptr
 
 
@@ -56,23 +58,79 @@ def _row_stride(*ts):
     return ld
 
 
-def fused_attention_forward(q, k, v, key_valid, n_heads, scale, causal):
-    """Flash-style forward (nnhipAttentionForward, head_dim 64): returns (ctx [B,Tq,D], lse [B,H,Tq,2]); the score
-    matrix is never materialised.  q, k, v may be column blocks of one fused [B,T,3D] projection buffer."""
+FUSED_HEAD_DIMS = (32, 64, 128)
+_SEEDS = itertools.count(1)
+
+
+class FusedAttentionOptions:
+    """What the fused attention kernels can do beyond (key_valid, causal): a dense mask (packed bits) and attention
+    dropout (injected mask or hash RNG) -- the Python side of struct nnhipAttentionOptions.  One object is shared by the
+    forward and the backward of a step, so both see the same mask and the same dropout multipliers."""
+
+    def __init__(self, mask_bits=None, mask_bitsT=None, row_any=None, dropout_mask=None, dropout_p=0.0, seed=0,
+                 seed_dev=None):
+        self.mask_bits, self.mask_bitsT, self.row_any = mask_bits, mask_bitsT, row_any
+        self.dropout_mask, self.dropout_p, self.seed, self.seed_dev = dropout_mask, float(dropout_p), int(seed), seed_dev
+
+    def cstruct(self):
+        ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
+        return AttentionOptions(ptr(self.mask_bits), ptr(self.mask_bitsT), ptr(self.row_any), ptr(self.dropout_mask),
+                                self.dropout_p if self.dropout_mask is None else 0.0, self.seed & 0xFFFFFFFF, ptr(self.seed_dev))
+
+
+def pack_attention_mask(mask):
+    """Dense mask (device int array [B,Tq,Tk] or [B,1,Tq,Tk], non-zero = visible: the notebook's
+    get_pad_mask(x) & get_sub_mask(x), examples/gpt.ipynb cell 7) -> (mask_bits, mask_bitsT, row_any) for the fused
+    kernels (nnhipAttentionPackMask)."""
+    import torch
+    if mask.dim() == 4:
+        if mask.shape[1] != 1:
+            raise ValueError("a per-head mask is not supported: expected [B,1,Tq,Tk] or [B,Tq,Tk]")
+        mask = mask[:, 0]
+    if mask.dim() != 3:
+        raise ValueError("mask must be [B,Tq,Tk] or [B,1,Tq,Tk]")
+    mask = mask.to(torch.int32).contiguous()
+    B, Tq, Tk = mask.shape
+    bits = torch.empty((B, Tq, (Tk + 63) // 64), dtype=torch.int64, device=mask.device)
+    bitsT = torch.empty((B, Tk, (Tq + 63) // 64), dtype=torch.int64, device=mask.device)
+    row_any = torch.empty((B, Tq), dtype=torch.uint8, device=mask.device)
+    call_hip_function("nnhipAttentionPackMask", mask, bits, bitsT, row_any, B, Tq, Tk, get_current_stream_ptr())
+    return bits, bitsT, row_any
+
+
+def attention_dropout_mask(B, H, Tq, Tk, p, seed, device="cuda"):
+    """The [B,H,Tq,Tk] multipliers (0 or 1/(1-p)) the fused kernels' hash RNG yields for (p, seed)."""
+    import torch
+    out = torch.empty((B, H, Tq, Tk), dtype=torch.float32, device=device)
+    call_hip_function("nnhipAttentionDropoutMask", out, B, H, Tq, Tk, float(p), int(seed) & 0xFFFFFFFF, get_current_stream_ptr())
+    return out
+
+
+def fused_attention_forward(q, k, v, key_valid, n_heads, scale, causal, opts=None):
+    """Flash-style forward (nnhipAttentionForward[Ex], head_dim 32 / 64 / 128): returns (ctx [B,Tq,D], lse [B,H,Tq,2]);
+    the score matrix is never materialised.  q, k, v may be column blocks of one fused [B,T,3D] projection buffer.
+    opts: FusedAttentionOptions (dense mask, attention dropout) or None."""
     import torch
     B, Tq, D = q.shape
     Tk = k.shape[1]
     ctx = torch.empty((B, Tq, D), dtype=torch.float32, device=q.device)
     lse = torch.empty((B, n_heads, Tq, 2), dtype=torch.float32, device=q.device)   # (row max, log2 row sum)
-    call_hip_function("nnhipAttentionForward", StridedView(q), StridedView(k), StridedView(v), key_valid, ctx, lse, B,
-                      n_heads, Tq, Tk, D // n_heads, _row_stride(q, k, v), 1.0 / scale, int(causal),
-                      get_current_stream_ptr())
+    if opts is None:
+        call_hip_function("nnhipAttentionForward", StridedView(q), StridedView(k), StridedView(v), key_valid, ctx, lse, B,
+                          n_heads, Tq, Tk, D // n_heads, _row_stride(q, k, v), 1.0 / scale, int(causal),
+                          get_current_stream_ptr())
+    else:
+        cs = opts.cstruct()
+        call_hip_function("nnhipAttentionForwardEx", StridedView(q), StridedView(k), StridedView(v), key_valid, ctx, lse, B,
+                          n_heads, Tq, Tk, D // n_heads, _row_stride(q, k, v), 1.0 / scale, int(causal), ctypes.byref(cs),
+                          get_current_stream_ptr())
     return ctx, lse
 
 
-def fused_attention_backward(q, k, v, key_valid, ctx, lse, n_heads, scale, causal, dctx, out=None):
-    """Flash-style backward (nnhipAttentionBackward): (dq, dk, dv) from the saved ctx and row statistics.
-    out = (dq, dk, dv) destinations laid out like q, k, v (e.g. column blocks of one [B,T,3D] buffer)."""
+def fused_attention_backward(q, k, v, key_valid, ctx, lse, n_heads, scale, causal, dctx, out=None, opts=None):
+    """Flash-style backward (nnhipAttentionBackward[Ex]): (dq, dk, dv) from the saved ctx and row statistics.
+    out = (dq, dk, dv) destinations laid out like q, k, v (e.g. column blocks of one [B,T,3D] buffer).
+    opts must be the object the forward used."""
     import torch
     B, Tq, D = q.shape
     Tk = k.shape[1]
@@ -80,9 +138,15 @@ def fused_attention_backward(q, k, v, key_valid, ctx, lse, n_heads, scale, causa
     ld = _row_stride(q, k, v)
     if _row_stride(dq, dk, dv) != ld:
         raise ValueError("dq/dk/dv must share the row stride of q/k/v")
-    call_hip_function("nnhipAttentionBackward", StridedView(q), StridedView(k), StridedView(v), key_valid, ctx, dctx,
-                      lse, StridedView(dq), StridedView(dk), StridedView(dv), B, n_heads, Tq, Tk, D // n_heads, ld,
-                      1.0 / scale, int(causal), get_current_stream_ptr())
+    if opts is None:
+        call_hip_function("nnhipAttentionBackward", StridedView(q), StridedView(k), StridedView(v), key_valid, ctx, dctx,
+                          lse, StridedView(dq), StridedView(dk), StridedView(dv), B, n_heads, Tq, Tk, D // n_heads, ld,
+                          1.0 / scale, int(causal), get_current_stream_ptr())
+    else:
+        cs = opts.cstruct()
+        call_hip_function("nnhipAttentionBackwardEx", StridedView(q), StridedView(k), StridedView(v), key_valid, ctx, dctx,
+                          lse, StridedView(dq), StridedView(dk), StridedView(dv), B, n_heads, Tq, Tk, D // n_heads, ld,
+                          1.0 / scale, int(causal), ctypes.byref(cs), get_current_stream_ptr())
     return dq, dk, dv
 
 
@@ -143,10 +207,10 @@ class _HIPFusedAttentionTensor(Tensor):
         super().__init__(data, args, op, device=device, _nocopy=True)
         ctx = data   # the closure owns the output ARRAY, not the Tensor (no tensor -> grad_fn -> tensor cycle)
 
-        def grad_fn(q: Tensor, k: Tensor, v: Tensor, lse, key_valid, n_heads, scale, causal, grad):
+        def grad_fn(q: Tensor, k: Tensor, v: Tensor, lse, key_valid, n_heads, scale, causal, opts, grad):
             grad = grad if grad.is_contiguous() else grad.contiguous()
             dq, dk, dv = fused_attention_backward(q.data, k.data, v.data, key_valid, ctx, lse, n_heads, scale,
-                                                  causal, grad)
+                                                  causal, grad, opts=opts)
             if q.requires_grad:
                 q.apply_grad(dq)
             if k.requires_grad:
@@ -214,20 +278,18 @@ class _HIPFusedSelfAttentionTensor(Tensor):
         super().__init__(data, args, op, device=device, _nocopy=True)
         ctx = data   # the closure owns the output ARRAY, not the Tensor (no tensor -> grad_fn -> tensor cycle)
 
-        def grad_fn(qkv: Tensor, lse, key_valid, n_heads, scale, causal, grad):
+        def grad_fn(qkv: Tensor, lse, key_valid, n_heads, scale, causal, opts, grad):
             import torch
             grad = grad if grad.is_contiguous() else grad.contiguous()
             D = ctx.shape[-1]
             x = qkv.data
             dqkv = torch.empty_like(x)
             fused_attention_backward(x[..., 0:D], x[..., D:2 * D], x[..., 2 * D:], key_valid, ctx, lse, n_heads,
-                                     scale, causal, grad, out=(dqkv[..., 0:D], dqkv[..., D:2 * D], dqkv[..., 2 * D:]))
+                                     scale, causal, grad, out=(dqkv[..., 0:D], dqkv[..., D:2 * D], dqkv[..., 2 * D:]),
+                                     opts=opts)
             qkv.apply_grad(dqkv)
 
         self.grad_fn = grad_fn
-
-
-FUSED_HEAD_DIM = 64
 
 
 class HIPMultiHeadAttention(Module):
@@ -243,8 +305,12 @@ class HIPMultiHeadAttention(Module):
         self.wk = HIPLinear(d_model, d_model, device=device)
         self.wv = HIPLinear(d_model, d_model, device=device)
         self.fc = HIPLinear(d_model, d_model, device=device)
-        self.fuse_qkv = True     # self-attention + need_weights=False + head_dim 64: one GEMM for the q|k|v projections
-        if self.depth == FUSED_HEAD_DIM and device == "cuda":
+        self.fuse_qkv = True     # self-attention + need_weights=False + a fused head dim: one GEMM for the q|k|v projections
+        self.dropout_seed_dev = None     # optional device int32 tensor added to the dropout seed inside the kernels (set it to
+        #                                  a per-step counter when the step is replayed from a hipGraph)
+        self._seed_base = (next(_SEEDS) * 0x9E3779B9) & 0x7FFFFFFF
+        self._calls = 0
+        if self.depth in FUSED_HEAD_DIMS and device == "cuda":
             self._pack_qkv()     # now, so a GradBucket built before the first forward already sees the slot groups
 
     def _pack_qkv(self):
@@ -268,7 +334,7 @@ class HIPMultiHeadAttention(Module):
         ws[0]._bucket_group, bs[0]._bucket_group = ws, bs      # GradBucket keeps their slots back-to-back
         return ws, bs, torch.as_strided(ws[0].data, (3 * D, D), (D, 1)), torch.as_strided(bs[0].data, (1, 3 * D), (3 * D, 1))
 
-    def _forward_fused_qkv(self, x: Tensor, key_valid, causal, residual):
+    def _forward_fused_qkv(self, x: Tensor, key_valid, causal, residual, opts):
         import torch
         D = self.d_model
         ws, bs, Wqkv, bqkv = self._pack_qkv()
@@ -278,32 +344,55 @@ class HIPMultiHeadAttention(Module):
         qkv_t = _HIPQKVProjTensor(qkv, (x, ws, bs, Wqkv, rows, D), "qkv_proj", device="cuda")
         q3 = qkv.reshape(-1, x.shape[-2], 3 * D) if qkv.dim() != 3 else qkv
         ctx, lse = fused_attention_forward(q3[..., 0:D], q3[..., D:2 * D], q3[..., 2 * D:], key_valid, self.n_heads,
-                                           self.scale, causal)
-        ctx_t = _HIPFusedSelfAttentionTensor(ctx, (qkv_t, lse, key_valid, self.n_heads, self.scale, causal),
+                                           self.scale, causal, opts)
+        ctx_t = _HIPFusedSelfAttentionTensor(ctx, (qkv_t, lse, key_valid, self.n_heads, self.scale, causal, opts),
                                              "fused_self_attention", device="cuda")
         return self.fc(ctx_t, residual=residual)
 
+    def _fused_options(self, mask, drop_mask, dropping):
+        """FusedAttentionOptions for this call (None when neither a dense mask nor dropout is involved)."""
+        if mask is None and not dropping:
+            return None
+        opts = FusedAttentionOptions()
+        if mask is not None:
+            m = mask.data if isinstance(mask, Tensor) else mask
+            opts.mask_bits, opts.mask_bitsT, opts.row_any = pack_attention_mask(m)
+        if drop_mask is not None:
+            opts.dropout_mask = drop_mask if drop_mask.is_contiguous() else drop_mask.contiguous()
+        elif dropping:
+            self._calls += 1
+            opts.dropout_p, opts.seed, opts.seed_dev = self.dropout.p, self._seed_base + self._calls, self.dropout_seed_dev
+        return opts
+
     def forward(self, q: Tensor, k: Tensor, v: Tensor, key_valid=None, causal=True, need_weights=True, residual=None,
-                drop_mask=None):
+                drop_mask=None, mask=None):
         """key_valid: int32 device array [B,Tk] (1 = real token, 0 = padding) or None.  The notebook's dense
-        mask get_pad_mask(x) & get_sub_mask(x) (cell 7) is exactly (key_valid, causal=True).
+        mask get_pad_mask(x) & get_sub_mask(x) (cell 7) is exactly (key_valid, causal=True); an arbitrary dense
+        `mask` ([B,Tq,Tk] or [B,1,Tq,Tk], non-zero = visible -- what the notebook's forward takes) is accepted too
+        and then replaces (key_valid, causal).
 
         drop_mask ([B,H,Tq,Tk], entries 0 or 1/(1-p)) injects the attention-dropout mask (parity tests); with
-        dropout p > 0 in training mode one is drawn with the device RNG.  Dropout runs on the GEMM + masked-softmax path.
+        dropout p > 0 in training mode the fused kernels draw it from a hash of (seed, b, h, q, k).
 
         need_weights=False (training steps that never look at the attention map) takes the fused flash-style
-        kernels when head_dim == 64 and returns (out, None): scores/attn/dattn are never written to HBM.
+        kernels when head_dim is 32, 64 or 128 and returns (out, None): scores/attn/dattn are never written to HBM.
         residual (extension): out = residual + fc(ctx), folded into the output projection's epilogue."""
         dropping = drop_mask is not None or (self.dropout.p != 0 and self.dropout.training)
-        if (not dropping and not need_weights and self.depth == FUSED_HEAD_DIM and q is k and k is v and self.fuse_qkv
-                and self.wq.bias is not None and q.dtype == "float32" and q.data.is_contiguous()):
-            return self._forward_fused_qkv(q, key_valid, causal, residual), None
-        qp, kp, vp = self.wq(q), self.wk(k), self.wv(v)
-        if not dropping and not need_weights and self.depth == FUSED_HEAD_DIM:
-            ctx, lse = fused_attention_forward(qp.data, kp.data, vp.data, key_valid, self.n_heads, self.scale, causal)
-            ctx_t = _HIPFusedAttentionTensor(ctx, (qp, kp, vp, lse, key_valid, self.n_heads, self.scale, causal),
+        fusable = not need_weights and self.depth in FUSED_HEAD_DIMS
+        if fusable:
+            opts = self._fused_options(mask, drop_mask, dropping)
+            if (q is k and k is v and self.fuse_qkv and self.wq.bias is not None and q.dtype == "float32"
+                    and q.data.is_contiguous()):
+                return self._forward_fused_qkv(q, key_valid, causal, residual, opts), None
+            qp, kp, vp = self.wq(q), self.wk(k), self.wv(v)
+            ctx, lse = fused_attention_forward(qp.data, kp.data, vp.data, key_valid, self.n_heads, self.scale, causal, opts)
+            ctx_t = _HIPFusedAttentionTensor(ctx, (qp, kp, vp, lse, key_valid, self.n_heads, self.scale, causal, opts),
                                              "fused_attention", device="cuda")
             return self.fc(ctx_t, residual=residual), None
+        if mask is not None:
+            raise NotImplementedError("a dense mask needs the fused path (need_weights=False, head_dim 32/64/128); the "
+                                      "GEMM + masked-softmax path takes (key_valid, causal)")
+        qp, kp, vp = self.wq(q), self.wk(k), self.wv(v)
         if dropping and drop_mask is None:   # attention dropout (cell 2: self.dropout(softmax(scores))), device RNG
             import torch
             shape = (qp.shape[0], self.n_heads, qp.shape[1], kp.shape[1])

@@ -1120,15 +1120,146 @@ def test_mha_attention_dropout(hip, B, Tn, D, H):
         np.testing.assert_allclose(host(lin.bias.grad), db, rtol=1e-4, atol=5e-4)
     # device RNG in training mode; identity in eval mode (fused kernels again when need_weights=False)
     x2 = T(hip, X)
-    y_train, a_train = mha(x2, x2, x2, kv, causal=True, need_weights=False)
+    y_train, a_train = mha(x2, x2, x2, kv, causal=True, need_weights=True)
     assert a_train is not None and np.isfinite(host(y_train.data)).all()
     assert (host(a_train) == 0).mean() > 0.5          # causal zeros + ~25 % dropped
+    y_fused, a_fused = mha(x2, x2, x2, kv, causal=True, need_weights=False)   # dropout inside the fused kernels (hash RNG)
+    assert a_fused is None and np.isfinite(host(y_fused.data)).all()
+    assert not np.allclose(host(y_fused.data), yr, atol=1e-3)
     y_train.backward(dY)
     assert np.isfinite(host(x2.grad)).all()
     mha.dropout.eval()
     y_eval, _ = mha(x2, x2, x2, kv, causal=True)
     ref0 = O.MHA(*ps, n_heads=H)
     np.testing.assert_allclose(host(y_eval.data), ref0.forward(X, O.attention_mask(tok, 0))[0], **TOL)
+
+
+@pytest.mark.parametrize("dh,H,Tq,Tk,causal", [(32, 4, 150, 150, True), (32, 2, 64, 200, False), (128, 2, 200, 200, True),
+                                                (128, 1, 70, 130, False), (64, 3, 257, 257, True)])
+def test_fused_attention_head_dims(hip, dh, H, Tq, Tk, causal):
+    """The fused kernels at head_dim 32 / 64 / 128 (round 1: 64 only) against the GEMM + masked-softmax path, forward and
+    all three gradients, with padded keys and (causal case) leading padding -> fully masked rows."""
+    from neunet_hip.nn.experimental import attention as A
+    rng = np.random.default_rng(dh + Tq)
+    B, D = 2, H * dh
+    q = dev(rng.standard_normal((B, Tq, D)).astype(np.float32) * 1.5)
+    k = dev(rng.standard_normal((B, Tk, D)).astype(np.float32) * 1.5)
+    v = dev(rng.standard_normal((B, Tk, D)).astype(np.float32))
+    do = dev(rng.standard_normal((B, Tq, D)).astype(np.float32))
+    kvh = (rng.random((B, Tk)) > 0.15).astype(np.int32)
+    if causal:
+        kvh[0, :9] = 0
+    kv = dev(kvh)
+    scale = float(np.sqrt(D))
+    ctx_u, attn, _ = A.attention_forward(q, k, v, kv, H, scale, causal)
+    gu = A.attention_backward(q, k, v, attn, kv, H, scale, causal, do)
+    ctx_f, lse = A.fused_attention_forward(q, k, v, kv, H, scale, causal)
+    gf = A.fused_attention_backward(q, k, v, kv, ctx_f, lse, H, scale, causal, do)
+    np.testing.assert_allclose(host(ctx_f), host(ctx_u), rtol=1e-4, atol=2e-5)
+    for a, b, n in zip(gf, gu, "qkv"):
+        np.testing.assert_allclose(host(a), host(b), rtol=1e-4, atol=5e-5, err_msg="d" + n)
+
+
+@pytest.mark.parametrize("dh,H,Tn", [(64, 2, 130), (32, 3, 70), (128, 1, 96)])
+def test_fused_attention_dropout_injected_and_hash(hip, dh, H, Tn):
+    """Attention dropout inside the fused kernels.  (1) an injected [B,H,T,T] mask: output and gradients equal the GEMM +
+    masked-softmax path given the same mask (which test_mha_attention_dropout pins to the oracle).  (2) the hash RNG:
+    identical to injecting the mask nnhipAttentionDropoutMask writes for the same (p, seed); about p of the entries are
+    dropped; another seed -- host side or through the device-side seed offset -- gives another mask."""
+    from neunet_hip.nn.experimental import attention as A
+    rng = np.random.default_rng(dh * 7 + Tn)
+    B, D, p = 2, H * dh, 0.3
+    q, k, v, do = [dev(rng.standard_normal((B, Tn, D)).astype(np.float32)) for _ in range(4)]
+    kvh = np.ones((B, Tn), np.int32)
+    kvh[1, -11:] = 0
+    kv = dev(kvh)
+    scale = float(np.sqrt(D))
+    drop = dev(((rng.random((B, H, Tn, Tn)) >= p) / (1 - p)).astype(np.float32))
+    ctx_u, attn, used = A.attention_forward(q, k, v, kv, H, scale, True, drop)
+    gu = A.attention_backward(q, k, v, attn, kv, H, scale, True, do, drop_mask=drop, attn_used=used)
+    o1 = A.FusedAttentionOptions(dropout_mask=drop)
+    ctx_f, lse = A.fused_attention_forward(q, k, v, kv, H, scale, True, o1)
+    gf = A.fused_attention_backward(q, k, v, kv, ctx_f, lse, H, scale, True, do, opts=o1)
+    np.testing.assert_allclose(host(ctx_f), host(ctx_u), rtol=1e-4, atol=2e-5)
+    for a, b, n in zip(gf, gu, "qkv"):
+        np.testing.assert_allclose(host(a), host(b), rtol=1e-4, atol=5e-5, err_msg="injected d" + n)
+    # hash RNG == its own materialised mask
+    seed = 12345
+    hmask = A.attention_dropout_mask(B, H, Tn, Tn, p, seed)
+    hm = host(hmask)
+    assert set(np.unique(hm)).issubset({0.0, np.float32(1 / (1 - p))})
+    assert abs((hm == 0).mean() - p) < 0.02
+    o2, o3 = A.FusedAttentionOptions(dropout_p=p, seed=seed), A.FusedAttentionOptions(dropout_mask=hmask)
+    c2, l2 = A.fused_attention_forward(q, k, v, kv, H, scale, True, o2)
+    c3, l3 = A.fused_attention_forward(q, k, v, kv, H, scale, True, o3)
+    np.testing.assert_array_equal(host(c2), host(c3))
+    g2 = A.fused_attention_backward(q, k, v, kv, c2, l2, H, scale, True, do, opts=o2)
+    g3 = A.fused_attention_backward(q, k, v, kv, c3, l3, H, scale, True, do, opts=o3)
+    for a, b in zip(g2, g3):
+        np.testing.assert_array_equal(host(a), host(b))
+    # a different seed, and the same seed shifted by a device-side counter
+    c4, _ = A.fused_attention_forward(q, k, v, kv, H, scale, True, A.FusedAttentionOptions(dropout_p=p, seed=seed + 1))
+    assert not np.array_equal(host(c4), host(c2))
+    one = torch.ones(1, dtype=torch.int32, device="cuda")
+    c5, _ = A.fused_attention_forward(q, k, v, kv, H, scale, True, A.FusedAttentionOptions(dropout_p=p, seed=seed, seed_dev=one))
+    np.testing.assert_array_equal(host(c5), host(c4))
+
+
+@pytest.mark.parametrize("D,H,Tn", [(128, 2, 150), (64, 2, 64), (256, 2, 97)])
+def test_fused_attention_dense_mask(hip, D, H, Tn):
+    """The notebook hands MultiHeadAttention a DENSE mask (cell 7: get_pad_mask(x) & get_sub_mask(x)).  (1) that very mask,
+    packed into bits, gives the same output and gradients as its (key_valid, causal) form; (2) an arbitrary random dense
+    mask -- including rows with no visible key, which the reference turns into a uniform distribution over ALL keys --
+    matches the oracle MHA given the same mask; dropout on top still matches the unfused formula."""
+    import neunet_hip.nn as nn
+    rng = np.random.default_rng(D + Tn)
+    B = 2
+    mha = nn.MultiHeadAttention(D, H)
+    ps = []
+    for lin in (mha.wq, mha.wk, mha.wv, mha.fc):
+        lin.weight.data.mul_(2.0)
+        ps += [host(lin.weight.data), host(lin.bias.data)]
+    X = rng.standard_normal((B, Tn, D)).astype(np.float32)
+    dY = rng.standard_normal((B, Tn, D)).astype(np.float32)
+    tok = rng.integers(1, 9, (B, Tn))
+    tok[0, -7:] = 0
+    tok[1, :3] = 0
+    pc = O.attention_mask(tok, 0)                                  # [B,T,T] pad & causal
+    masks = [pc]
+    rnd = (rng.random((B, Tn, Tn)) > 0.4).astype(np.int32)
+    rnd[0, 5, :] = 0                                               # rows that see nothing
+    rnd[1, Tn - 1, :] = 0
+    rnd[1, :, 64:] = 0 if Tn > 64 else rnd[1, :, 64:]              # whole key tiles invisible to a batch (tile skipping)
+    masks.append(rnd)
+    for mi, mask in enumerate(masks):
+        ref = O.MHA(*ps, n_heads=H)
+        yr, _ = ref.forward(X, mask)
+        dxr, gr = ref.backward(dY)
+        for lin in (mha.wq, mha.wk, mha.wv, mha.fc):
+            lin.weight.grad = lin.bias.grad = None
+        x = T(hip, X)
+        y, attn = mha(x, x, x, need_weights=False, mask=T(hip, mask[:, None], dtype=np.int32, requires_grad=False))
+        assert attn is None
+        np.testing.assert_allclose(host(y.data), yr, **TOL)
+        y.backward(dY)
+        np.testing.assert_allclose(host(x.grad), dxr, rtol=1e-4, atol=2e-4, err_msg=f"mask {mi}")
+        for lin, dW, db in zip((mha.wq, mha.wk, mha.wv, mha.fc), gr[0::2], gr[1::2]):
+            np.testing.assert_allclose(host(lin.weight.grad), dW, rtol=1e-4, atol=5e-4)
+            np.testing.assert_allclose(host(lin.bias.grad), db, rtol=1e-4, atol=5e-4)
+        if mi == 0:   # identical to the (key_valid, causal) form of the same mask
+            x2 = T(hip, X)
+            y2, _ = mha(x2, x2, x2, dev((tok != 0).astype(np.int32)), causal=True, need_weights=False)
+            np.testing.assert_allclose(host(y.data), host(y2.data), rtol=1e-5, atol=1e-6)
+    # dense mask + injected dropout mask vs the oracle
+    drop = ((rng.random((B, H, Tn, Tn)) >= 0.2) / 0.8).astype(np.float32)
+    ref = O.MHA(*ps, n_heads=H)
+    yr, _ = ref.forward(X, rnd, drop_mask=drop)
+    dxr, _ = ref.backward(dY)
+    x = T(hip, X)
+    y, _ = mha(x, x, x, need_weights=False, mask=dev(rnd), drop_mask=dev(drop))
+    np.testing.assert_allclose(host(y.data), yr, **TOL)
+    y.backward(dY)
+    np.testing.assert_allclose(host(x.grad), dxr, rtol=1e-4, atol=2e-4)
 
 
 def test_fused_attention_fully_masked_rows(hip):
