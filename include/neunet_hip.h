@@ -158,6 +158,14 @@ int nnhipMaskedSoftmaxBackward(float* dX, const float* dY, const float* Y, const
                                int64_t B, int64_t H, int64_t Tq, int64_t Tk, float scale, int causal,
                                nnhipStream_t stream);
 
+/* The same with an additional dense mask [B,Tq,Tk] int32 (0 = masked; broadcast over heads; NULL = none): what the notebook's
+ * MultiHeadAttention.forward receives (get_pad_mask & get_sub_mask, cell 7), for callers that want the attention map. */
+int nnhipMaskedSoftmaxForwardEx(float* out, const float* in, const int32_t* key_valid, const int32_t* dense_mask, int64_t B,
+                                int64_t H, int64_t Tq, int64_t Tk, float scale, int causal, nnhipStream_t stream);
+int nnhipMaskedSoftmaxBackwardEx(float* dX, const float* dY, const float* Y, const int32_t* key_valid,
+                                 const int32_t* dense_mask, int64_t B, int64_t H, int64_t Tq, int64_t Tk, float scale,
+                                 int causal, nnhipStream_t stream);
+
 /* Fused (flash-style) attention, head_dim 32 / 64 / 128: same math as  QK^T*scale -> mask(-1e9) -> softmax -> dropout -> *V
  * above, but the [B,H,Tq,Tk] score matrix is never written.  O/dO are [B,T,H*head_dim] (the projection layout); Q/K/V/dQ/dK/dV
  * are [B,T,*] with row stride ld_qkv floats (0 = H*head_dim; 3*H*head_dim when they are the three column blocks of one fused

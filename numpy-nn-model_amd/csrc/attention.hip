@@ -91,6 +91,11 @@ __device__ __forceinline__ unsigned at_hash(unsigned rowkey, unsigned key) {
     x ^= x >> 16;
     return x;
 }
+// the device-side seed offset: an agent-scope (L2-served) load, NOT a scalar load -- the word is rewritten between launches
+// by other kernels and a scalar-cache line of it was observed stale on some CUs
+__device__ __forceinline__ unsigned at_seed_offset(const AttnExtra& x) {
+    return x.seed_dev ? __hip_atomic_load(x.seed_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+}
 __device__ __forceinline__ float at_drop_mult(const AttnExtra& x, unsigned rowkey, int64_t row, int Tk, int key) {
     if (x.drop_mask) return x.drop_mask[row * Tk + key];
     return at_hash(rowkey, (unsigned)key) >= x.drop_threshold ? x.drop_scale : 0.f;
@@ -329,7 +334,7 @@ __global__ __launch_bounds__(256, DH <= 64 ? 2 : 1) void attn_fwd_kernel(const A
     const bool dense = GEN && p.x.mask_bits != nullptr;
     const bool dropping = GEN && (p.x.drop_mask != nullptr || p.x.drop_threshold != 0u);
     const int64_t drow = ((int64_t)b * p.H + h) * p.Tq + q;             // row of the [B,H,Tq,Tk] dropout mask
-    const unsigned seed = GEN ? p.x.drop_seed + (p.x.seed_dev ? p.x.seed_dev[0] : 0u) : 0u;
+    const unsigned seed = GEN ? p.x.drop_seed + at_seed_offset(p.x) : 0u;
     const unsigned rowkey = GEN ? at_rowkey(seed, (unsigned)drow) : 0u;
 
     // Q fragments, pre-scaled by scale*log2(e) (softmax runs on exp2): lane (q, lh) holds Q[q][8g + 4lh + j]
@@ -498,7 +503,7 @@ __global__ __launch_bounds__(256, DH <= 64 ? 2 : 1) void attn_bwd_dkdv_kernel(co
     const int nwq = (p.Tq + 63) >> 6;
     const unsigned long long* bitsT = dense && key_in ? p.x.mask_bitsT + ((int64_t)b * p.Tk + key) * nwq : nullptr;
     const int64_t drow0 = ((int64_t)b * p.H + h) * p.Tq;
-    const unsigned seed = GEN ? p.x.drop_seed + (p.x.seed_dev ? p.x.seed_dev[0] : 0u) : 0u;
+    const unsigned seed = GEN ? p.x.drop_seed + at_seed_offset(p.x) : 0u;
 
     // K (pre-scaled by scale*log2e: scores in log2 units, as the forward saved them) and V fragments of this lane's key
     float kf[G][4], vf[G][4];
@@ -648,7 +653,7 @@ __global__ __launch_bounds__(256, DH <= 64 ? 2 : 1) void attn_bwd_dq_kernel(cons
     const bool dense = GEN && p.x.mask_bits != nullptr;
     const bool dropping = GEN && (p.x.drop_mask != nullptr || p.x.drop_threshold != 0u);
     const int64_t drow = ((int64_t)b * p.H + h) * p.Tq + q;
-    const unsigned seed = GEN ? p.x.drop_seed + (p.x.seed_dev ? p.x.seed_dev[0] : 0u) : 0u;
+    const unsigned seed = GEN ? p.x.drop_seed + at_seed_offset(p.x) : 0u;
     const unsigned rowkey = GEN ? at_rowkey(seed, (unsigned)drow) : 0u;
     const bool row_sees = dense && p.x.row_any && q_in ? p.x.row_any[(int64_t)b * p.Tq + q] != 0 : !q_in;
 

@@ -101,6 +101,12 @@ __device__ __forceinline__ float block_max(float v, float* red) {
     return s;
 }
 
+// A device WORD that other kernels rewrite between launches (step counters, counts, scales) and that every thread of a
+// block reads: take it with an agent-scope load.  A plain uniform load becomes a scalar load, and a scalar-cache line of
+// such a word was observed stale across a kernel boundary on some CUs (round 2, the attention dropout seed offset).
+__device__ __forceinline__ float ld_dev_f32(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int ld_dev_i32(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 constexpr float kLog2e = 1.4426950408889634f;
 // exp(x) for x <= ~0 as one v_exp_f32 (1 ulp) after a multiply: softmax / log-sum-exp terms exp(x - max).
 __device__ __forceinline__ float exp_fast_(float x) { return __builtin_amdgcn_exp2f(x * kLog2e); }

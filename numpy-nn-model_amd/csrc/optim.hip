@@ -99,18 +99,18 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const unsigned char* _
     __shared__ float bc[2];
     if (dev_state) {
         if (threadIdx.x == 0) {
-            const int step = reinterpret_cast<const int*>(dev_state)[0] + 1;
+            const int step = ld_dev_i32(reinterpret_cast<const int*>(dev_state)) + 1;
             bc[0] = (float)(1.0 - pow(b1, (double)step));
             bc[1] = (float)(1.0 - pow(b2, (double)step));
         }
         __syncthreads();
         h.bc1 = bc[0];
         h.bc2 = bc[1];
-        h.lr = dev_state[1];
-        h.grad_scale = dev_state[2];
-        h.wd = dev_state[4];
+        h.lr = ld_dev_f32(dev_state + 1);
+        h.grad_scale = ld_dev_f32(dev_state + 2);
+        h.wd = ld_dev_f32(dev_state + 4);
     }
-    if (grad_div) h.grad_scale = h.grad_scale / grad_div[0];
+    if (grad_div) h.grad_scale = h.grad_scale / ld_dev_f32(grad_div);
     float* const* P = reinterpret_cast<float* const*>(blob);
     const float* const* G = reinterpret_cast<const float* const*>(blob + sizeof(void*) * n);
     float* const* M = reinterpret_cast<float* const*>(blob + sizeof(void*) * 2 * n);

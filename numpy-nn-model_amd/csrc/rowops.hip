@@ -138,7 +138,7 @@ __global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void softmax_bwd_rows(
 template <int TPR, int NV, bool VEC>
 __global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void softmax_masked_fwd_rows(
     float* out, const float* in, const int32_t* __restrict__ key_valid,  // out may alias in
-    int64_t rows, int64_t cols, int64_t HTq, int64_t Tq, float scale, int causal) {
+    int64_t rows, int64_t cols, int64_t HTq, int64_t Tq, float scale, int causal, const int32_t* __restrict__ dense) {
     ROW_PROLOGUE(TPR)
     RowTile<TPR, NV, VEC> r;
     r.load(in + row * cols, cols, t, -INFINITY);
@@ -146,12 +146,13 @@ __global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void softmax_masked_fwd_r
     const int64_t i = row % Tq;
     const int64_t lim = causal ? i + (cols - Tq) : cols;  // last visible column
     const int32_t* kv = key_valid ? key_valid + b * cols : nullptr;
+    const int32_t* dm = dense ? dense + (b * Tq + i) * cols : nullptr;   // dense [B,Tq,Tk] mask row (0 = masked)
     float m = -INFINITY;
 #pragma unroll
     for (int e = 0; e < r.NE; ++e) {
         const int64_t c = r.col(t, e);
         if (c < cols) {
-            const bool masked = c > lim || (kv && kv[c] == 0);
+            const bool masked = c > lim || (kv && kv[c] == 0) || (dm && dm[c] == 0);
             r.x[e] = masked ? -1e9f : r.x[e] * scale;
         }
         m = fmaxf(m, r.x[e]);
@@ -175,7 +176,7 @@ template <int TPR, int NV, bool VEC>
 __global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void softmax_masked_bwd_rows(
     float* dx, const float* dy, const float* __restrict__ y,  // dx may alias dy
     const int32_t* __restrict__ key_valid, int64_t rows, int64_t cols, int64_t HTq, int64_t Tq,
-    float scale, int causal) {
+    float scale, int causal, const int32_t* __restrict__ dense) {
     ROW_PROLOGUE(TPR)
     RowTile<TPR, NV, VEC> g, f;
     g.load(dy + row * cols, cols, t, 0.f);
@@ -188,10 +189,11 @@ __global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void softmax_masked_bwd_r
     const int64_t i = row % Tq;
     const int64_t lim = causal ? i + (cols - Tq) : cols;
     const int32_t* kv = key_valid ? key_valid + b * cols : nullptr;
+    const int32_t* dm = dense ? dense + (b * Tq + i) * cols : nullptr;
 #pragma unroll
     for (int e = 0; e < g.NE; ++e) {
         const int64_t c = g.col(t, e);
-        const bool masked = c < cols && (c > lim || (kv && kv[c] == 0));
+        const bool masked = c < cols && (c > lim || (kv && kv[c] == 0) || (dm && dm[c] == 0));
         g.x[e] = masked ? 0.f : (g.x[e] - s) * f.x[e] * scale;
     }
     g.store(dx + row * cols, cols, t);
@@ -683,10 +685,10 @@ __device__ __forceinline__ void ce_prologue(const CeArgs& a, float* red, int* ir
         if (a.count_out && blockIdx.x == 0 && threadIdx.x == 0) a.count_out[0] = ci;
         scale = denom > 0.f ? 1.0f / denom : 0.0f;
     } else if (a.denom_dev) {
-        denom = a.denom_dev[0];
+        denom = ld_dev_f32(a.denom_dev);
         scale = denom > 0.f ? 1.0f / denom : 0.0f;
     } else if (a.count_dev) {
-        denom = (float)a.count_dev[0];
+        denom = (float)ld_dev_i32(a.count_dev);
         scale = 1.0f / denom;
     } else {
         denom = a.scale_host > 0.f ? 1.0f / a.scale_host : 0.f;
@@ -870,7 +872,7 @@ __global__ __launch_bounds__(1024) void reduce_loss_kernel(const float* __restri
     float s = 0.f;
     for (int64_t i = threadIdx.x; i < n; i += 1024) s += loss[i];
     s = block_sum<16>(s, red);
-    if (threadIdx.x == 0) out[0] = mean ? s / (float)count_dev[0] : s;
+    if (threadIdx.x == 0) out[0] = mean ? s / (float)ld_dev_i32(count_dev) : s;
 }
 
 // Whole CrossEntropyLoss of a SMALL problem in one single-block launch (one 1024-thread block, a wave per row): same
@@ -1027,15 +1029,17 @@ int colsum(const float* X, int64_t rows, int64_t cols, int64_t ld, float* out, h
 // ---- attention-score softmax for key counts beyond the register tile (Tk > 16384): looped, one block per row ------
 __global__ __launch_bounds__(1024) void softmax_masked_fwd_looped(float* out, const float* in,
                                                                   const int32_t* __restrict__ key_valid, int64_t cols,
-                                                                  int64_t HTq, int64_t Tq, float scale, int causal) {
+                                                                  int64_t HTq, int64_t Tq, float scale, int causal,
+                                                                  const int32_t* __restrict__ dense) {
     __shared__ float red[16];
     const int64_t row = blockIdx.x;
     const int64_t b = row / HTq, i = row % Tq;
     const int64_t lim = causal ? i + (cols - Tq) : cols;
     const int32_t* kv = key_valid ? key_valid + b * cols : nullptr;
+    const int32_t* dm = dense ? dense + (b * Tq + i) * cols : nullptr;
     const float* x = in + row * cols;
     float* o = out + row * cols;
-    auto val = [&](int64_t c) { return (c > lim || (kv && kv[c] == 0)) ? -1e9f : x[c] * scale; };
+    auto val = [&](int64_t c) { return (c > lim || (kv && kv[c] == 0) || (dm && dm[c] == 0)) ? -1e9f : x[c] * scale; };
     float m = -INFINITY;
     for (int64_t c = threadIdx.x; c < cols; c += 1024) m = fmaxf(m, val(c));
     m = block_max<16>(m, red);
@@ -1048,19 +1052,21 @@ __global__ __launch_bounds__(1024) void softmax_masked_fwd_looped(float* out, co
 }
 __global__ __launch_bounds__(1024) void softmax_masked_bwd_looped(float* dx, const float* dy, const float* __restrict__ y,
                                                                   const int32_t* __restrict__ key_valid, int64_t cols,
-                                                                  int64_t HTq, int64_t Tq, float scale, int causal) {
+                                                                  int64_t HTq, int64_t Tq, float scale, int causal,
+                                                                  const int32_t* __restrict__ dense) {
     __shared__ float red[16];
     const int64_t row = blockIdx.x;
     const int64_t b = row / HTq, i = row % Tq;
     const int64_t lim = causal ? i + (cols - Tq) : cols;
     const int32_t* kv = key_valid ? key_valid + b * cols : nullptr;
+    const int32_t* dm = dense ? dense + (b * Tq + i) * cols : nullptr;
     const float* g = dy + row * cols;
     const float* f = y + row * cols;
     float s = 0.f;
     for (int64_t c = threadIdx.x; c < cols; c += 1024) s += g[c] * f[c];
     s = block_sum<16>(s, red);
     for (int64_t c = threadIdx.x; c < cols; c += 1024) {
-        const bool masked = c > lim || (kv && kv[c] == 0);
+        const bool masked = c > lim || (kv && kv[c] == 0) || (dm && dm[c] == 0);
         dx[row * cols + c] = masked ? 0.f : (g[c] - s) * f[c] * scale;
     }
 }
@@ -1432,38 +1438,50 @@ extern "C" int nnhipCrossEntropyLoss(float* logits, float* dlogits_or_null, floa
 }
 
 // ---- attention-score softmax (scale + pad/causal mask fused) --------------------------------------------
-extern "C" int nnhipMaskedSoftmaxForward(float* out, const float* in, const int32_t* key_valid, int64_t B,
-                                         int64_t H, int64_t Tq, int64_t Tk, float scale, int causal,
-                                         nnhipStream_t s) {
+extern "C" int nnhipMaskedSoftmaxForwardEx(float* out, const float* in, const int32_t* key_valid, const int32_t* dense_mask,
+                                           int64_t B, int64_t H, int64_t Tq, int64_t Tk, float scale, int causal,
+                                           nnhipStream_t s) {
     NNHIP_CHECK_ARG(B >= 0 && H >= 0 && Tq >= 0 && Tk >= 0, NNHIP_EINVAL, "nnhipMaskedSoftmaxForward: negative size");
     const int64_t rows = B * H * Tq;
     if (rows == 0 || Tk == 0) return 0;
     NNHIP_CHECK_ARG(out && in, NNHIP_EINVAL, "nnhipMaskedSoftmaxForward: null pointer");
     hipStream_t st = (hipStream_t)s;
     if (Tk > kMaxRegRow) {
-        hipLaunchKernelGGL(softmax_masked_fwd_looped, dim3((unsigned)rows), dim3(1024), 0, st, out, in, key_valid, Tk, H * Tq, Tq, scale, causal);
+        hipLaunchKernelGGL(softmax_masked_fwd_looped, dim3((unsigned)rows), dim3(1024), 0, st, out, in, key_valid, Tk, H * Tq, Tq, scale, causal, dense_mask);
     } else {
         const bool vec = aligned16(out) && aligned16(in) && Tk % 4 == 0;
-        ROW_DISPATCH(softmax_masked_fwd_rows, Tk, vec, rows, st, out, in, key_valid, rows, Tk, H * Tq, Tq, scale, causal);
+        ROW_DISPATCH(softmax_masked_fwd_rows, Tk, vec, rows, st, out, in, key_valid, rows, Tk, H * Tq, Tq, scale, causal, dense_mask);
     }
     NNHIP_LAUNCH_CHECK("softmax_masked_fwd_rows");
     return 0;
 }
 
-extern "C" int nnhipMaskedSoftmaxBackward(float* dX, const float* dY, const float* Y, const int32_t* key_valid,
-                                          int64_t B, int64_t H, int64_t Tq, int64_t Tk, float scale, int causal,
-                                          nnhipStream_t s) {
+extern "C" int nnhipMaskedSoftmaxForward(float* out, const float* in, const int32_t* key_valid, int64_t B,
+                                         int64_t H, int64_t Tq, int64_t Tk, float scale, int causal,
+                                         nnhipStream_t s) {
+    return nnhipMaskedSoftmaxForwardEx(out, in, key_valid, nullptr, B, H, Tq, Tk, scale, causal, s);
+}
+
+extern "C" int nnhipMaskedSoftmaxBackwardEx(float* dX, const float* dY, const float* Y, const int32_t* key_valid,
+                                            const int32_t* dense_mask, int64_t B, int64_t H, int64_t Tq, int64_t Tk,
+                                            float scale, int causal, nnhipStream_t s) {
     NNHIP_CHECK_ARG(B >= 0 && H >= 0 && Tq >= 0 && Tk >= 0, NNHIP_EINVAL, "nnhipMaskedSoftmaxBackward: negative size");
     const int64_t rows = B * H * Tq;
     if (rows == 0 || Tk == 0) return 0;
     NNHIP_CHECK_ARG(dX && dY && Y, NNHIP_EINVAL, "nnhipMaskedSoftmaxBackward: null pointer");
     hipStream_t st = (hipStream_t)s;
     if (Tk > kMaxRegRow) {
-        hipLaunchKernelGGL(softmax_masked_bwd_looped, dim3((unsigned)rows), dim3(1024), 0, st, dX, dY, Y, key_valid, Tk, H * Tq, Tq, scale, causal);
+        hipLaunchKernelGGL(softmax_masked_bwd_looped, dim3((unsigned)rows), dim3(1024), 0, st, dX, dY, Y, key_valid, Tk, H * Tq, Tq, scale, causal, dense_mask);
     } else {
         const bool vec = aligned16(dX) && aligned16(dY) && aligned16(Y) && Tk % 4 == 0;
-        ROW_DISPATCH(softmax_masked_bwd_rows, Tk, vec, rows, st, dX, dY, Y, key_valid, rows, Tk, H * Tq, Tq, scale, causal);
+        ROW_DISPATCH(softmax_masked_bwd_rows, Tk, vec, rows, st, dX, dY, Y, key_valid, rows, Tk, H * Tq, Tq, scale, causal, dense_mask);
     }
     NNHIP_LAUNCH_CHECK("softmax_masked_bwd_rows");
     return 0;
+}
+
+extern "C" int nnhipMaskedSoftmaxBackward(float* dX, const float* dY, const float* Y, const int32_t* key_valid,
+                                          int64_t B, int64_t H, int64_t Tq, int64_t Tk, float scale, int causal,
+                                          nnhipStream_t s) {
+    return nnhipMaskedSoftmaxBackwardEx(dX, dY, Y, key_valid, nullptr, B, H, Tq, Tk, scale, causal, s);
 }

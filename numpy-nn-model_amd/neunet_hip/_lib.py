@@ -62,6 +62,8 @@ _SIGNATURES = {
                                       c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_float, c_void_p]),
     "nnhipMaskedSoftmaxForward": (ctypes.c_int, [P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, ctypes.c_int, c_void_p]),
     "nnhipMaskedSoftmaxBackward": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, ctypes.c_int, c_void_p]),
+    "nnhipMaskedSoftmaxForwardEx": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, ctypes.c_int, c_void_p]),
+    "nnhipMaskedSoftmaxBackwardEx": (ctypes.c_int, [P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, ctypes.c_int, c_void_p]),
     "nnhipAttentionForward": (ctypes.c_int, [P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_float, ctypes.c_int, c_void_p]),
     "nnhipAttentionBackward": (ctypes.c_int, [P, P, P, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_float, ctypes.c_int, c_void_p]),
     "nnhipAttentionForwardEx": (ctypes.c_int, [P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int64, c_int64, c_float, ctypes.c_int,

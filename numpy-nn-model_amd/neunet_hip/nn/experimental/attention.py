@@ -26,9 +26,10 @@ def _gemm_ex(A, B, C, M, N, K, lda, ldb, ldc, akm, bkm, b1, sA1, sB1, sC1, b2, s
                       b2, sA2, sB2, sC2, float(alpha), get_current_stream_ptr())
 
 
-def attention_forward(q, k, v, key_valid, n_heads, scale, causal, drop_mask=None):
+def attention_forward(q, k, v, key_valid, n_heads, scale, causal, drop_mask=None, dense_mask=None):
     """q,k,v: device arrays [B,T,D] (D = H*dh).  Returns (ctx [B,Tq,D], attn [B,H,Tq,Tk], attn_used) where attn_used is
-    attn * drop_mask (the notebook's `self.dropout(softmax(scores))`, cell 2) or attn itself without dropout."""
+    attn * drop_mask (the notebook's `self.dropout(softmax(scores))`, cell 2) or attn itself without dropout.
+    dense_mask: int32 device array [B,Tq,Tk] (0 = masked), applied on top of (key_valid, causal)."""
     import torch
     B, Tq, D = q.shape
     Tk = k.shape[1]
@@ -37,7 +38,7 @@ def attention_forward(q, k, v, key_valid, n_heads, scale, causal, drop_mask=None
     # scores[b,h] = q[b,:,h,:] (Tq x dh, k-major, lda=D)  x  k[b,:,h,:]^T (B operand k-major, ldb=D)
     _gemm_ex(q, k, scores, Tq, Tk, dh, D, D, Tk, 1, 1, B, Tq * D, Tk * D, H * Tq * Tk, H, dh, dh, Tq * Tk)
     attn = scores  # softmax in place over the scores buffer
-    call_hip_function("nnhipMaskedSoftmaxForward", attn, scores, key_valid, B, H, Tq, Tk, 1.0 / scale,
+    call_hip_function("nnhipMaskedSoftmaxForwardEx", attn, scores, key_valid, dense_mask, B, H, Tq, Tk, 1.0 / scale,
                       int(causal), get_current_stream_ptr())
     used = attn
     if drop_mask is not None:
@@ -151,7 +152,7 @@ def fused_attention_backward(q, k, v, key_valid, ctx, lse, n_heads, scale, causa
 
 
 def attention_backward(q, k, v, attn, key_valid, n_heads, scale, causal, dctx, need=(True, True, True),
-                       drop_mask=None, attn_used=None):
+                       drop_mask=None, attn_used=None, dense_mask=None):
     """Returns (dq, dk, dv) in the [B,T,D] layout of the projections.  With attention dropout: attn_used = attn*mask
     feeds dV, and the gradient of the attention map is multiplied by the same mask before the softmax backward."""
     import torch
@@ -170,7 +171,7 @@ def attention_backward(q, k, v, attn, key_valid, n_heads, scale, causal, dctx, n
     if drop_mask is not None:
         call_hip_function("nnhipMul", dattn, dattn, drop_mask, dattn.numel(), get_current_stream_ptr())
     # dscores (in place over dattn) = where(mask, 0, softmax_bwd(dattn, attn)) / scale
-    call_hip_function("nnhipMaskedSoftmaxBackward", dattn, dattn, attn, key_valid, B, H, Tq, Tk, 1.0 / scale,
+    call_hip_function("nnhipMaskedSoftmaxBackwardEx", dattn, dattn, attn, key_valid, dense_mask, B, H, Tq, Tk, 1.0 / scale,
                       int(causal), get_current_stream_ptr())
     ds = dattn
     dq = dk = None
@@ -188,10 +189,11 @@ class _HIPAttentionTensor(Tensor):
         super().__init__(data, args, op, device=device, _nocopy=True)
 
         def grad_fn(q: Tensor, k: Tensor, v: Tensor, attn, key_valid, n_heads, scale, causal, drop_mask, attn_used,
-                    grad):
+                    dense_mask, grad):
             grad = grad if grad.is_contiguous() else grad.contiguous()
             dq, dk, dv = attention_backward(q.data, k.data, v.data, attn, key_valid, n_heads, scale, causal, grad,
-                                            (q.requires_grad, k.requires_grad, v.requires_grad), drop_mask, attn_used)
+                                            (q.requires_grad, k.requires_grad, v.requires_grad), drop_mask, attn_used,
+                                            dense_mask)
             if dq is not None:
                 q.apply_grad(dq)
             if dk is not None:
@@ -389,15 +391,19 @@ class HIPMultiHeadAttention(Module):
             ctx_t = _HIPFusedAttentionTensor(ctx, (qp, kp, vp, lse, key_valid, self.n_heads, self.scale, causal, opts),
                                              "fused_attention", device="cuda")
             return self.fc(ctx_t, residual=residual), None
-        if mask is not None:
-            raise NotImplementedError("a dense mask needs the fused path (need_weights=False, head_dim 32/64/128); the "
-                                      "GEMM + masked-softmax path takes (key_valid, causal)")
+        dense = None
+        if mask is not None:          # the dense mask replaces (key_valid, causal), as in the fused path
+            import torch
+            dense = mask.data if isinstance(mask, Tensor) else mask
+            dense = (dense[:, 0] if dense.dim() == 4 else dense).to(torch.int32).contiguous()
+            key_valid, causal = None, False
         qp, kp, vp = self.wq(q), self.wk(k), self.wv(v)
         if dropping and drop_mask is None:   # attention dropout (cell 2: self.dropout(softmax(scores))), device RNG
             import torch
             shape = (qp.shape[0], self.n_heads, qp.shape[1], kp.shape[1])
             drop_mask = (torch.rand(shape, device=qp.data.device) >= self.dropout.p).to(torch.float32) * self.dropout.scale
-        ctx, attn, used = attention_forward(qp.data, kp.data, vp.data, key_valid, self.n_heads, self.scale, causal, drop_mask)
+        ctx, attn, used = attention_forward(qp.data, kp.data, vp.data, key_valid, self.n_heads, self.scale, causal, drop_mask,
+                                            dense)
         ctx_t = _HIPAttentionTensor(ctx, (qp, kp, vp, attn, key_valid, self.n_heads, self.scale, causal, drop_mask,
-                                          used if drop_mask is not None else None), "attention", device="cuda")
+                                          used if drop_mask is not None else None, dense), "attention", device="cuda")
         return self.fc(ctx_t, residual=residual), used
