@@ -1,0 +1,177 @@
+// gemm_common.h -- what the GEMM kernels of gemm.hip (exact fp32 MFMA) and gemm_bf3.hip (split-bf16 MFMA) share:
+// the launch parameters and the epilogue (alpha, bias, addend, activation-gradient mask, activation, pre-activation
+// store, row sums of A, split-K slabs) -- both accumulate 128x128 tiles as 2x2 32x32 MFMA accumulators per wave, so
+// everything after the K loop is the same code.
+#pragma once
+#include "common.h"
+
+namespace nnhip {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { ACT_NONE = 0, ACT_SWISH = 1, ACT_RELU = 2, ACT_SIGMOID = 3 };
+
+struct GemmParams {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;   // [N] or null
+    float* preact;       // [M, ldc] or null: pre-activation (z) output for ACT_SWISH
+    int64_t M, N, K, lda, ldb, ldc, sA, sB, sC;
+    int64_t sA2, sB2, sC2;  // inner batch level: batch index z -> (z / batch2, z % batch2)
+    int batch2;
+    float alpha;            // C = alpha * (A B) + bias
+    int tiles_m, tiles_n, splitk;
+    int64_t k_per_split;  // multiple of BK
+    float* slab;          // split-K partials [splitk][M][N] (dense)
+    const float* zeros;   // >= 16 bytes of zeros: the load target of out-of-range lanes
+    int cvec;             // 1: C/bias/preact rows are 16-B aligned and N % 4 == 0 -> float4 epilogue
+    int act;
+    float beta;
+    const float* dswish;  // [M, ldc] or null: C = (alpha*AB + bias + addend) * act'(dswish[m,n])  (may alias C); act' per `dact`
+    int dact;             // 1: swish'(z; beta), dswish = z;  2: relu'(f) = [f > 0], dswish = the forward OUTPUT f
+    const float* addend;  // [M, ldc] or null: C = act(alpha*AB + bias + addend)  (residual / gradient accumulation)
+    float* asum;          // CS variants: asum[m] = sum_k A[m,k] (Linear: db = column sums of dO, fused into dW = dO^T X)
+    float* asum_slab;     // split-K partials [splitk][M]
+    int skew;             // experiments: 1/2 = raised wave priority for every other dispatch round / block octet,
+                          // 3 = the second workgroup slot of a CU starts `skew_sleeps` x ~0.9 us late (see the kernel)
+    int skew_sleeps;
+};
+
+constexpr int BM = 128, BN = 128, NT = 256;
+
+// `cs`: this thread's row sums of the A elements it staged (CS variants only).  The K loop has ended with a barrier, so
+// the whole dynamic LDS block `smem` is free.
+template <bool CS>
+__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[2][2], const GemmParams& p, float* __restrict__ smem, float4 cs,
+                                              int tid, int wave, int lane, int wm, int wn, int l31, int lh, int64_t m0,
+                                              int64_t n0, int tn, int split, int64_t c_off) {
+    // ---- epilogue ------------------------------------------------------------------------------------------
+    // acc register e of a 32x32 MFMA tile holds row (e&3) + 8*(e>>2) + 4*lh, column l31: a lane owns a strided
+    // COLUMN, so direct stores are 64 dword stores per lane (2 rows x 128 B per instruction) and the tail is
+    // store-issue bound (~15 us per generation of tiles, measured by a K sweep).  Instead each wave transposes
+    // its tile through its own LDS region, 32 rows at a time, and stores float4 rows: 4x fewer instructions,
+    // 4 rows x 256 B each.  (Scalar path kept for unaligned / N % 4 != 0 outputs.)
+    const bool to_slab = p.splitk > 1;
+    if constexpr (CS) {
+        if (p.asum && tn == 0) {                             // the K loop ended with a barrier: LDS is free
+            *reinterpret_cast<float4*>(&smem[(tid >> 5) * 128 + (tid & 31) * 4]) = cs;
+            __syncthreads();
+            if (tid < 128) {
+                float t = 0.f;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) t += smem[r * 128 + tid];
+                if (m0 + tid < p.M) (to_slab ? p.asum_slab + (int64_t)split * p.M : p.asum)[m0 + tid] = t;
+            }
+            __syncthreads();
+        }
+    }
+    float* __restrict__ C = to_slab ? p.slab + (int64_t)split * p.M * p.N : p.C + c_off;
+    const int64_t ldc = to_slab ? p.N : p.ldc;
+    if (p.cvec) {
+        constexpr int ELD = 68;                              // 64 + 4 floats: rows stay 16-B aligned
+        float* E = smem + wave * (32 * ELD);                 // the K loop ended with a barrier: LDS is free
+        const int er = lane >> 4, ec = (lane & 15) * 4;      // read side: row-in-group, column of the float4
+        const int64_t col = n0 + wn * 64 + ec;
+        const bool col_ok = col < p.N;                       // N % 4 == 0 on this path
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!to_slab && p.bias && col_ok) bv = *reinterpret_cast<const float4*>(p.bias + col);
+        // the one extra epilogue operand (addend or swish' argument; the dispatcher rejects both at once) is fetched one
+        // 32-row group ahead: issued before the LDS transposition of the group that uses it, so its latency hides under
+        // that and under the previous group's stores (loading it inside the store loop cost ~4 us per tile).
+        const float* __restrict__ extra = to_slab ? nullptr : (p.addend ? p.addend : p.dswish);
+        const bool is_add = p.addend != nullptr;
+        float4 ex[8];
+        auto fetch_extra = [&](int i, int it) {
+            const int64_t row = m0 + wm * 64 + i * 32 + it * 4 + er;
+            ex[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < p.M && col_ok) ex[it] = *reinterpret_cast<const float4*>(extra + c_off + row * ldc + col);
+        };
+        if (extra) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) fetch_extra(0, it);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    E[((e & 3) + 8 * (e >> 2) + 4 * lh) * ELD + n * 32 + l31] = acc[i][n][e];
+            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0); E is private to the wave: no block barrier needed
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int rl = it * 4 + er;
+                const int64_t row = m0 + wm * 64 + i * 32 + rl;
+                float4 v = *reinterpret_cast<const float4*>(&E[rl * ELD + ec]);
+                const float4 x = ex[it];
+                if (extra && i == 0) fetch_extra(1, it);
+                if (row < p.M && col_ok) {
+                    if (!to_slab) {
+                        v.x = p.alpha * v.x + bv.x; v.y = p.alpha * v.y + bv.y;
+                        v.z = p.alpha * v.z + bv.z; v.w = p.alpha * v.w + bv.w;
+                        if (extra) {
+                            if (is_add) {
+                                v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+                            } else if (p.dact == 2) {   // gradient through h = relu(z): mask by the forward output
+                                v.x = x.x > 0.f ? v.x : 0.f; v.y = x.y > 0.f ? v.y : 0.f;
+                                v.z = x.z > 0.f ? v.z : 0.f; v.w = x.w > 0.f ? v.w : 0.f;
+                            } else {   // gradient through h = swish(z): the dX GEMM of the NEXT layer hands back dz
+                                v.x *= swish_grad_(x.x, p.beta); v.y *= swish_grad_(x.y, p.beta);
+                                v.z *= swish_grad_(x.z, p.beta); v.w *= swish_grad_(x.w, p.beta);
+                            }
+                        }
+                        if (p.act == ACT_SWISH) {
+                            if (p.preact) *reinterpret_cast<float4*>(p.preact + c_off + row * ldc + col) = v;
+                            v.x *= sigmoid_fast_(p.beta * v.x); v.y *= sigmoid_fast_(p.beta * v.y);
+                            v.z *= sigmoid_fast_(p.beta * v.z); v.w *= sigmoid_fast_(p.beta * v.w);
+                        } else if (p.act == ACT_RELU) {
+                            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                        } else if (p.act == ACT_SIGMOID) {
+                            v.x = sigmoid_fast_(v.x); v.y = sigmoid_fast_(v.y); v.z = sigmoid_fast_(v.z); v.w = sigmoid_fast_(v.w);
+                        }
+                    }
+                    *reinterpret_cast<float4*>(C + row * ldc + col) = v;
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);   // this group's LDS reads are done before the next group overwrites E
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int64_t col = n0 + wn * 64 + n * 32 + l31;
+        if (col >= p.N) continue;
+        const float bv = (!to_slab && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int64_t rbase = m0 + wm * 64 + i * 32 + 4 * lh;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t row = rbase + (e & 3) + 8 * (e >> 2);
+                if (row >= p.M) continue;
+                float v = to_slab ? acc[i][n][e] : p.alpha * acc[i][n][e] + bv;
+                if (!to_slab) {
+                    if (p.addend) v += p.addend[c_off + row * ldc + col];
+                    if (p.dswish) {
+                        const float x = p.dswish[c_off + row * ldc + col];
+                        v = p.dact == 2 ? (x > 0.f ? v : 0.f) : v * swish_grad_(x, p.beta);
+                    }
+                    if (p.act == ACT_SWISH) {
+                        if (p.preact) p.preact[c_off + row * ldc + col] = v;
+                        v = v * sigmoid_fast_(p.beta * v);
+                    } else if (p.act == ACT_RELU) {
+                        v = fmaxf(v, 0.f);
+                    } else if (p.act == ACT_SIGMOID) {
+                        v = sigmoid_fast_(v);
+                    }
+                }
+                C[row * ldc + col] = v;
+            }
+        }
+    }
+}
+
+}  // namespace nnhip
