@@ -45,6 +45,15 @@ int nnhipWorkspaceReserve(int64_t bytes);
  * of freeing the block a captured hipGraph still points into.  nnhipCleanup() unlocks. */
 int nnhipWorkspaceLock(int locked);
 
+/* GEMM arithmetic of every Linear / attention GEMM that runs on the 128x128-tile kernel:
+ *   0 (default)  exact fp32: v_mfma_f32_32x32x2_f32, a k-ordered fmaf chain;
+ *   1            split-bf16 ("bf16x3"): every fp32 operand is split EXACTLY into three bf16 pieces and six of the nine
+ *                piece products are accumulated in fp32 on the bf16 matrix cores -- relative error <= ~2^-23 per
+ *                product (the order of fp32 rounding itself), up to 2.67x the fp32 MFMA rate.  Opt-in; also
+ *                NNHIP_GEMM_MODE=1 in the environment.  Small problems (gemm_small) stay exact either way. */
+int nnhipSetGemmMode(int mode);
+int nnhipGetGemmMode(void);
+
 /* ---- a1/a2 Linear  (replaces cudaLinearModuleForward/Backward,
  *      linear_cublaslt_no_manual_mem.cu:114,142 and linear_cutlass.cu:40,67) ------------------ */
 /* O[rows,out] = X[rows,in] * W[out,in]^T + b[out]      (b may be NULL) */

@@ -37,44 +37,6 @@ struct Tile {
     static constexpr int NV = BK / 8;                             // float4 per thread per tile
 };
 
-// global -> registers.  R = extent of the operand's outer dim, r0/k0 = tile origin.
-// Branch-free: an out-of-range lane loads from a 16-byte block of zeros (`Z`, library-owned) instead of
-// being masked or zeroed afterwards, so the whole K-loop body is one basic block, the loads can be
-// interleaved with MFMAs, and nothing consumes a loaded value before the LDS store at the end of the tile.
-template <int BK, bool KC, bool VEC>
-__device__ __forceinline__ void g2r(float4 (&r)[BK / 8], const float* __restrict__ P, int64_t ld,
-                                    int64_t R, int64_t Kend, int64_t r0, int64_t k0, int tid, bool live,
-                                    const float* __restrict__ Z) {
-#pragma unroll
-    for (int p = 0; p < BK / 8; ++p) {
-        const int idx = tid + NT * p;
-        int64_t gr, gk;
-        const float* src;
-        if constexpr (KC) {
-            const int rr = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
-            gr = r0 + rr; gk = k0 + k4;
-            src = P + gr * ld + gk;
-        } else {
-            const int kk = idx / 32, r4 = (idx % 32) * 4;
-            gk = k0 + kk; gr = r0 + r4;
-            src = P + gk * ld + gr;
-        }
-        if constexpr (VEC) {
-            const bool ok = live && gr < R && gk < Kend;
-            r[p] = *reinterpret_cast<const float4*>(ok ? src : Z);
-        } else {
-            // scalar path: element e steps along the contiguous dim (k for k-major, outer otherwise)
-            float t[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const bool ok = live && (KC ? (gr < R && gk + e < Kend) : (gk < Kend && gr + e < R));
-                t[e] = *(ok ? src + e : Z);
-            }
-            r[p] = make_float4(t[0], t[1], t[2], t[3]);
-        }
-    }
-}
-
 // registers -> LDS stage
 template <int BK, bool KC>
 __device__ __forceinline__ void r2s(const float4 (&r)[BK / 8], float* __restrict__ S, int tid) {
@@ -353,6 +315,17 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
                 int64_t sB2, int64_t sC2, float alpha, int act, float beta, hipStream_t st, float* asum = nullptr,
                 const float* addend = nullptr, const float* dswish = nullptr, int dact = 1);
 
+// gemm_bf3.hip: the same tiles on the bf16 matrix cores (exact 3-way bf16 split of every fp32 operand, 6 products)
+int gemm_bf3_launch(const GemmParams& p, bool a_kmajor, bool b_kmajor, bool vec, bool cs, int64_t batch, hipStream_t st);
+static int g_gemm_mode = -1;    // -1: not initialised (NNHIP_GEMM_MODE decides), 0: exact fp32 MFMA, 1: split-bf16
+static int gemm_mode() {
+    if (g_gemm_mode < 0) {
+        const char* e = getenv("NNHIP_GEMM_MODE");
+        g_gemm_mode = (e && (atoi(e) == 1 || e[0] == 'b')) ? 1 : 0;
+    }
+    return g_gemm_mode;
+}
+
 // gemm_small.hip: the latency-optimised kernel for problems of a few 32x32 tiles
 bool gemm_small_wanted(int64_t M, int64_t N, int64_t K, int64_t batch);
 int gemm_small(const float* A, const float* B, float* C, const float* bias, float* preact, int64_t M, int64_t N, int64_t K,
@@ -468,6 +441,9 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
     }
 
     int rc;
+    if (gemm_mode() == 1) {
+        rc = gemm_bf3_launch(p, a_kmajor, b_kmajor, vec, asum != nullptr, batch, st);
+    } else {
 #define NNHIP_GEMM_CASE(AK, BKM)                                                                   \
     rc = (BK == 16) ? (vec ? launch_variant<16, AK, BKM, true>(p, batch, st)                      \
                            : launch_variant<16, AK, BKM, false>(p, batch, st))                    \
@@ -484,6 +460,7 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
     else if (!a_kmajor && b_kmajor) { NNHIP_GEMM_CASE(false, true); }
     else { NNHIP_GEMM_CASE(false, false); }
 #undef NNHIP_GEMM_CASE
+    }
     if (rc) return rc;
 
     if (p.splitk > 1) {
@@ -501,6 +478,13 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
 }
 
 }  // namespace nnhip
+
+extern "C" int nnhipSetGemmMode(int mode) {
+    NNHIP_CHECK_ARG(mode == 0 || mode == 1, NNHIP_EINVAL, "nnhipSetGemmMode: 0 = exact fp32 MFMA, 1 = split-bf16 (bf16x3)");
+    nnhip::g_gemm_mode = mode;
+    return 0;
+}
+extern "C" int nnhipGetGemmMode(void) { return nnhip::gemm_mode(); }
 
 extern "C" int nnhipGemmF32Ex(const float* A, const float* B, float* C, const float* bias, int64_t M,
                               int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int a_kmajor,

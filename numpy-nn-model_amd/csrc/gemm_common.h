@@ -40,6 +40,44 @@ struct GemmParams {
 
 constexpr int BM = 128, BN = 128, NT = 256;
 
+// global -> registers.  R = extent of the operand's outer dim, r0/k0 = tile origin.
+// Branch-free: an out-of-range lane loads from a 16-byte block of zeros (`Z`, library-owned) instead of
+// being masked or zeroed afterwards, so the whole K-loop body is one basic block, the loads can be
+// interleaved with MFMAs, and nothing consumes a loaded value before the LDS store at the end of the tile.
+template <int BK, bool KC, bool VEC>
+__device__ __forceinline__ void g2r(float4 (&r)[BK / 8], const float* __restrict__ P, int64_t ld,
+                                    int64_t R, int64_t Kend, int64_t r0, int64_t k0, int tid, bool live,
+                                    const float* __restrict__ Z) {
+#pragma unroll
+    for (int p = 0; p < BK / 8; ++p) {
+        const int idx = tid + NT * p;
+        int64_t gr, gk;
+        const float* src;
+        if constexpr (KC) {
+            const int rr = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
+            gr = r0 + rr; gk = k0 + k4;
+            src = P + gr * ld + gk;
+        } else {
+            const int kk = idx / 32, r4 = (idx % 32) * 4;
+            gk = k0 + kk; gr = r0 + r4;
+            src = P + gk * ld + gr;
+        }
+        if constexpr (VEC) {
+            const bool ok = live && gr < R && gk < Kend;
+            r[p] = *reinterpret_cast<const float4*>(ok ? src : Z);
+        } else {
+            // scalar path: element e steps along the contiguous dim (k for k-major, outer otherwise)
+            float t[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool ok = live && (KC ? (gr < R && gk + e < Kend) : (gk < Kend && gr + e < R));
+                t[e] = *(ok ? src + e : Z);
+            }
+            r[p] = make_float4(t[0], t[1], t[2], t[3]);
+        }
+    }
+}
+
 // `cs`: this thread's row sums of the A elements it staged (CS variants only).  The K loop has ended with a barrier, so
 // the whole dynamic LDS block `smem` is free.
 template <bool CS>

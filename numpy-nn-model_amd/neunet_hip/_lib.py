@@ -45,6 +45,8 @@ _SIGNATURES = {
     "nnhipVersion": (ctypes.c_int, []),
     "nnhipGetLastErrorString": (ctypes.c_char_p, []),
     "nnhipCleanup": (ctypes.c_int, []),
+    "nnhipSetGemmMode": (ctypes.c_int, [ctypes.c_int]),
+    "nnhipGetGemmMode": (ctypes.c_int, []),
     "nnhipWorkspaceReserve": (ctypes.c_int, [c_int64]),
     "nnhipWorkspaceLock": (ctypes.c_int, [ctypes.c_int]),
     "nnhipLinearModuleForward": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_void_p]),
@@ -115,7 +117,7 @@ _SIGNATURES = {
     "nnhipScale": (ctypes.c_int, [P, c_float, c_int64, c_void_p]),
     "nnhipAdd": (ctypes.c_int, [P, P, P, c_int64, c_void_p]),
 }
-_NO_STATUS = {"nnhipVersion", "nnhipGetLastErrorString", "nnhipCreateFusedOptimizer"}
+_NO_STATUS = {"nnhipVersion", "nnhipGetLastErrorString", "nnhipCreateFusedOptimizer", "nnhipGetGemmMode"}
 
 _dll = None
 _funcs: dict = {}

@@ -297,6 +297,79 @@ def test_relu_backward_folded_into_next_linear(hip):
     np.testing.assert_allclose(host(l2.weight.grad), 2 * dW2, rtol=1e-4, atol=2e-4)
 
 
+# ------------------------------------------------------------------------------ split-bf16 GEMM mode (opt-in)
+@pytest.fixture
+def bf16x3(hip):
+    from neunet_hip._lib import call_hip_function
+    call_hip_function("nnhipSetGemmMode", 1)
+    yield
+    call_hip_function("nnhipSetGemmMode", 0)
+
+
+@pytest.mark.parametrize("rows,inf,outf", [(512, 512, 512), (1000, 520, 300), (4096, 1024, 2048), (300, 4096, 515),
+                                           (16384, 512, 512), (2048, 64, 640)])
+def test_bf16x3_gemm_is_fp32_accurate(hip, bf16x3, rows, inf, outf):
+    """nnhipSetGemmMode(1): every fp32 operand split exactly into three bf16 pieces, six piece products on the bf16 matrix
+    cores.  Linear forward / dX / dW / db at shapes that take the 128x128-tile kernel in all three operand layouts (and
+    split-K), against float64: the error is of the order of fp32 rounding -- within 2x of what the exact-fp32 MFMA kernel
+    itself leaves on the same inputs, and inside the 1e-4 parity tolerance by orders of magnitude."""
+    from neunet_hip._lib import call_hip_function
+    from neunet_hip.nn.experimental import HIPLinear
+    rng = np.random.default_rng(rows + inf)
+    X = rng.standard_normal((rows, inf)).astype(np.float32)
+    dO = rng.standard_normal((rows, outf)).astype(np.float32)
+    layer = HIPLinear(inf, outf)
+    W, b = host(layer.weight.data).astype(np.float64), host(layer.bias.data).astype(np.float64)
+    X64, dO64 = X.astype(np.float64), dO.astype(np.float64)
+    refs = (X64 @ W.T + b, dO64 @ W, dO64.T @ X64, dO64.sum(0, keepdims=True))
+    errs = []
+    for mode in (1, 0):
+        call_hip_function("nnhipSetGemmMode", mode)
+        layer.weight.grad = layer.bias.grad = None
+        x = T(hip, X)
+        out = layer(x)
+        o = host(out.data)
+        out.backward(dO)
+        got = (o, host(x.grad), host(layer.weight.grad), host(layer.bias.grad))
+        errs.append([float(np.abs(g - r).max() / np.abs(r).max()) for g, r in zip(got, refs)])
+    call_hip_function("nnhipSetGemmMode", 1)
+    for name, e3, e1 in zip(("O", "dX", "dW", "db"), errs[0], errs[1]):
+        assert e3 < 2e-6, (name, e3)                       # relative to the largest entry: ~fp32 rounding at these K
+        assert e3 <= 2.0 * e1 + 2e-7, (name, e3, e1)       # no worse than twice the exact-fp32 kernel's own error
+
+
+def test_bf16x3_split_is_exact_on_hard_inputs(hip, bf16x3):
+    """Operands that stress the three-way split: huge dynamic range inside a row, values with all 24 significand bits set,
+    exact powers of two, zeros, denormal-adjacent magnitudes.  x * 1 must come back EXACTLY (hi + mid + lo = x, and
+    1 = bf16(1)), and a long all-positive dot product stays within 2^-22 of float64."""
+    from neunet_hip._lib import call_hip_function, get_current_stream_ptr
+    rng = np.random.default_rng(9)
+    M = K = 512                                            # 16 tiles of 128x128: the big kernel, not gemm_small
+    A = rng.standard_normal((M, K)).astype(np.float32) * np.exp2(rng.integers(-60, 60, (M, K))).astype(np.float32)
+    A[0, :8] = [np.float32(1) - np.float32(2) ** -24, np.float32(1.9999999), 2.0 ** -100, -2.0 ** 100, 0.0, 3.0, 1e-30, 16777215.0]
+    I = np.eye(K, dtype=np.float32)
+    a_d, i_d, c_d = dev(A), dev(I), torch.empty((M, K), device="cuda")
+    call_hip_function("nnhipGemmF32", a_d, i_d, c_d, None, M, K, K, K, K, K, 1, 1, 1, 0, 0, 0, get_current_stream_ptr())
+    np.testing.assert_array_equal(host(c_d), A)            # A @ I^T: every product is x*1 and the rest are exact zeros
+    P = rng.uniform(0.5, 1.5, (512, 4096)).astype(np.float32)
+    Q = rng.uniform(0.5, 1.5, (512, 4096)).astype(np.float32)
+    c2 = torch.empty((512, 512), device="cuda")
+    call_hip_function("nnhipGemmF32", dev(P), dev(Q), c2, None, 512, 512, 4096, 4096, 4096, 512, 1, 1, 1, 0, 0, 0,
+                      get_current_stream_ptr())
+    ref = P.astype(np.float64) @ Q.astype(np.float64).T
+    assert float(np.abs(host(c2) - ref).max() / ref.max()) < 2.0 ** -21
+
+
+def test_bf16x3_gpt_tiny_step_golden(hip, golden, bf16x3):
+    """The notebook's GPT step golden (reference logits, loss, every gradient) with all large GEMMs in split-bf16 mode:
+    same tolerances as the exact-fp32 run."""
+    test_gpt_tiny_step_golden(hip, golden, True)
+
+
+def test_bf16x3_gemm_batched_all_layouts(hip, bf16x3):
+    test_gemm_batched_all_layouts(hip)
+
+
 def test_linear_transpose_detecting(hip):
     """A = I against an asymmetric B catches a swapped C-write (guide rule 16)."""
     from neunet_hip.nn.experimental import HIPLinear

@@ -47,7 +47,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
     ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--gemm-mode", type=int, default=0, help="0 = exact fp32 MFMA (default), 1 = split-bf16 (bf16x3)")
     args = ap.parse_args()
+    call("nnhipSetGemmMode", args.gemm_mode)
     only = set(filter(None, args.only.split(",")))
     want = lambda k: not only or k in only  # noqa: E731
     st = _lib.get_current_stream_ptr()
