@@ -749,6 +749,29 @@ def workload_headline(args, rank, world):
     also["c2"] = {"workload": r2["config"]["workload"], "samples_per_s": round(r2["samples_per_step"] * a2.steps / r2["dt"], 1),
                   "ms_per_step": round(r2["dt"] / a2.steps * 1e3, 4), "linear_fwd_tflops_in_step": r2["extra"]["linear_fwd_tflops"],
                   "linear_bwd_tflops_in_step": r2["extra"]["linear_bwd_tflops"]}
+    # opt-in split-bf16 GEMM mode (fp32 operands split exactly into 3 bf16 pieces, 6 products on the bf16 matrix cores):
+    # reported NEXT TO the exact-fp32 numbers above, never instead of them
+    if os.environ.get("NNHIP_BENCH_BF16X3", "1") != "0":
+        from neunet_hip._lib import call_hip_function
+        call_hip_function("nnhipSetGemmMode", 1)
+        try:
+            f3 = c2_forward_roofline(iters=30, sustain_s=1.0)
+            a4 = copy.copy(args)
+            a4.steps, a4.warmup = 10, 3
+            r4 = workload_c4(a4, rank, world)
+            also["bf16x3"] = {
+                "what": "the same C2 forward GEMM and C4 step with nnhipSetGemmMode(1): every fp32 operand split exactly "
+                        "into three bf16 pieces, six piece products accumulated in fp32 by v_mfma_f32_32x32x16_bf16 "
+                        "(relative error ~2^-23 per product; parity tests hold the same 1e-4 tolerance). OPT-IN, not the default",
+                "c2_linear_fwd_tflops_fp32_equiv": round(f3["burst_tflops"], 2),
+                "c2_linear_fwd_sustained_tflops_fp32_equiv": round(f3["sustained_tflops"], 2),
+                "c2_bf16_mfma_tflops": round(6 * f3["burst_tflops"], 1), "bf16_mfma_peak_tflops": 2500.0,
+                "c2_frac_of_bf16_mfma_peak": round(6 * f3["burst_tflops"] / 2500.0, 4),
+                "c4_samples_per_s": round(r4["samples_per_step"] * a4.steps / r4["dt"], 2),
+                "c4_ms_per_step": round(r4["dt"] / a4.steps * 1e3, 4),
+            }
+        finally:
+            call_hip_function("nnhipSetGemmMode", 0)
     res["extra"]["also"] = also
     return res
 

@@ -154,21 +154,28 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf3_kernel(const GemmParams p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int nk = (int)((kend - kbeg + B3_BK - 1) / B3_BK);
-    StageRegs ra, rb;
+    // Two register sets per operand: tile kt+2 is fetched while tile kt is multiplied and tile kt+1 (fetched one
+    // iteration earlier) is split and committed to the other LDS stage -- a global load gets a whole iteration to land.
+    StageRegs ra0, rb0, ra1, rb1;
     float rowsum = 0.f;
-    b3_fetch<AKC, VEC>(ra, A, p.lda, p.M, kend, m0, kbeg, tid, nk > 0, Z);
-    b3_fetch<BKC, VEC>(rb, B, p.ldb, p.N, kend, n0, kbeg, tid, nk > 0, Z);
-    if constexpr (CS) rowsum += (ra.v[0].x + ra.v[0].y) + (ra.v[0].z + ra.v[0].w) + (ra.v[1].x + ra.v[1].y) + (ra.v[1].z + ra.v[1].w);
-    b3_commit<AKC>(ra, smem_b, tid);
-    b3_commit<BKC>(rb, smem_b + B3_OPERAND, tid);
+    auto rsum = [](const StageRegs& r) { return (r.v[0].x + r.v[0].y) + (r.v[0].z + r.v[0].w) + (r.v[1].x + r.v[1].y) + (r.v[1].z + r.v[1].w); };
+    b3_fetch<AKC, VEC>(ra0, A, p.lda, p.M, kend, m0, kbeg, tid, nk > 0, Z);
+    b3_fetch<BKC, VEC>(rb0, B, p.ldb, p.N, kend, n0, kbeg, tid, nk > 0, Z);
+    b3_fetch<AKC, VEC>(ra1, A, p.lda, p.M, kend, m0, kbeg + B3_BK, tid, nk > 1, Z);
+    b3_fetch<BKC, VEC>(rb1, B, p.ldb, p.N, kend, n0, kbeg + B3_BK, tid, nk > 1, Z);
+    if constexpr (CS) rowsum += rsum(ra0);
+    b3_commit<AKC>(ra0, smem_b, tid);
+    b3_commit<BKC>(rb0, smem_b + B3_OPERAND, tid);
     __syncthreads();
 
     int cur = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = kt + 1 < nk;
-        const int64_t k0 = kbeg + (int64_t)(kt + 1) * B3_BK;
-        b3_fetch<AKC, VEC>(ra, A, p.lda, p.M, kend, m0, k0, tid, more, Z);      // next tile: in flight during the MFMAs
-        b3_fetch<BKC, VEC>(rb, B, p.ldb, p.N, kend, n0, k0, tid, more, Z);
+    // one k-tile: fetch tile kt+2 into (fa, fb) [free: its tile was committed an iteration ago], multiply tile kt out of
+    // LDS stage `cur`, commit tile kt+1 from (ca, cb) into the other stage
+    auto step = [&](int kt, StageRegs& fa, StageRegs& fb, const StageRegs& ca, const StageRegs& cb) {
+        const bool more2 = kt + 2 < nk;
+        const int64_t k2 = kbeg + (int64_t)(kt + 2) * B3_BK;
+        b3_fetch<AKC, VEC>(fa, A, p.lda, p.M, kend, m0, k2, tid, more2, Z);
+        b3_fetch<BKC, VEC>(fb, B, p.ldb, p.N, kend, n0, k2, tid, more2, Z);
         const unsigned char* As = smem_b + cur * B3_STAGE;
         const unsigned char* Bs = As + B3_OPERAND;
         bf16x8 a[2][3], b[2][3];
@@ -190,13 +197,19 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf3_kernel(const GemmParams p) {
         B3_TERM(0, 1)
         B3_TERM(0, 0)
 #undef B3_TERM
-        if constexpr (CS) rowsum += (ra.v[0].x + ra.v[0].y) + (ra.v[0].z + ra.v[0].w) + (ra.v[1].x + ra.v[1].y) + (ra.v[1].z + ra.v[1].w);
+        if constexpr (CS) rowsum += rsum(ca);          // tile kt+1 (zeros past the end)
         unsigned char* Sn = smem_b + (cur ^ 1) * B3_STAGE;
-        b3_commit<AKC>(ra, Sn, tid);
-        b3_commit<BKC>(rb, Sn + B3_OPERAND, tid);
+        b3_commit<AKC>(ca, Sn, tid);
+        b3_commit<BKC>(cb, Sn + B3_OPERAND, tid);
         __syncthreads();
         cur ^= 1;
+    };
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        step(kt, ra0, rb0, ra1, rb1);
+        step(kt + 1, ra1, rb1, ra0, rb0);
     }
+    if (kt < nk) step(kt, ra0, rb0, ra1, rb1);
 
     float* smem = reinterpret_cast<float*>(smem_b);
     if constexpr (CS) {
