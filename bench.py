@@ -809,6 +809,12 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(respawn_under_torchrun(args))
+    rccl_log = None
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and "NCCL_DEBUG" not in os.environ:
+        # RCCL's own account of the communicator (ranks, rings/trees, transport) goes to a per-rank file -- its default
+        # sink is stdout, which must carry exactly one JSON line -- and rank 0 echoes the topology lines to stderr below
+        rccl_log = f"/tmp/nnhip_rccl.{os.getpid()}.log"
+        os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,GRAPH", NCCL_DEBUG_FILE=rccl_log)
     import torch
     from neunet_hip.distributed import init_process_group
     import neunet_hip
@@ -827,6 +833,12 @@ def main():
         if rank == 0:
             print(f"[bench] backend={dist.get_backend()} world={dist.get_world_size()} all-reduce(1)={rccl_ranks}",
                   file=sys.stderr)
+            if rccl_log and os.path.exists(rccl_log):
+                keep = ("nranks", "Ring", "Tree", "Channel", "via", "Using", "Connected", "comm ")
+                with open(rccl_log, errors="replace") as f:
+                    lines = [ln.rstrip() for ln in f if any(k in ln for k in keep)]
+                for ln in lines[:60]:
+                    print("[rccl] " + ln, file=sys.stderr)
     wl = {"headline": workload_headline, "c1": workload_c1, "c2": workload_c2, "c3": workload_c3, "c4": workload_c4,
           "c5": workload_c5}[args.workload]
     res = wl(args, rank, world)
