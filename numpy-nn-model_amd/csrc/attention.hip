@@ -23,6 +23,7 @@
 // Kernels are templates on <DH, GEN>: GEN = false is the (key_valid, causal, no dropout) fast path that round 1 tuned at
 // DH = 64; GEN = true adds the dense-mask bits and the dropout multiplier to the softmax phase.
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -35,6 +36,18 @@ constexpr int AT_BK = 64;    // keys (queries in the dK/dV kernel) per tile
 constexpr float AT_MASKED = -1e9f;
 constexpr float AT_LOG2E = 1.4426950408889634f;
 constexpr float AT_MASKED2 = AT_MASKED * AT_LOG2E;   // the -1e9 fill in log2 units (scores are carried as s*log2(e))
+
+// Developer instrumentation (tools/attn_prof.py builds this file a second time with -DAT_PROF): per-wave cycle counts of
+// the kernel's phases, written to p.prof[(block * 4 + wave) * 8 + phase].  Compiled out of the library.
+#ifdef AT_PROF
+#define AT_PROF_DECL long long pacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tlast_ = clock64()
+#define AT_T(i) do { const long long t_ = clock64(); pacc_[i] += t_ - tlast_; tlast_ = t_; } while (0)
+#define AT_PROF_STORE(P) do { if ((P) && (threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 8; ++i_) (P)[((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + i_] = pacc_[i_]; } } while (0)
+#else
+#define AT_PROF_DECL do {} while (0)
+#define AT_T(i) do {} while (0)
+#define AT_PROF_STORE(P) do {} while (0)
+#endif
 
 #define AT_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 #define AT_SCHED_MFMA(n) __builtin_amdgcn_sched_group_barrier(0x008, (n), 0)
@@ -61,7 +74,11 @@ struct AttnParams {
     int64_t LQ;                                       // row stride of Q, K, V (>= H * DH: 3*H*DH for a fused q|k|v buffer)
     float scale;                                      // multiplies QK^T (1/sqrt(d_model))
     int causal;
+    int tune;                                         // AT_TUNE_* bits (attn_tune())
     AttnExtra x;
+#ifdef AT_PROF
+    long long* prof;
+#endif
 };
 
 struct AttnBwdParams {
@@ -75,7 +92,11 @@ struct AttnBwdParams {
     int64_t LQ;                                                        // row stride of Q, K, V, dQ, dK, dV
     float scale;
     int causal;
+    int tune;
     AttnExtra x;
+#ifdef AT_PROF
+    long long* prof;
+#endif
 };
 
 // row (within a 32-row tile) carried by accumulator register e, for half-wave lh
@@ -102,18 +123,47 @@ __device__ __forceinline__ float at_drop_mult(const AttnExtra& x, unsigned rowke
 }
 
 // A [rows x DH] tile staged through registers: fetch early (the loads stay in flight during the MFMA phase), commit
-// to LDS (row stride DH + 4) at the top of the next iteration.  Rows past nrows are zero-filled.
+// to LDS (row stride DH + 4) at the top of the next iteration.  The per-thread element offsets are computed once
+// (tile_offsets); a fetch is then NV loads off a wave-uniform tile pointer -- the per-tile 64-bit address arithmetic and
+// the per-row exec-mask branches of round 1 cost ~1500 cycles per tile of a VALU that the fp32 MFMAs share.
+// Rows past the end of the tensor re-read its last row (finite data whose scores are masked / whose probabilities are
+// zero downstream), so no lane is ever switched off.
 template <int NV>
 struct TileRegsN { float4 v[NV]; };          // NV*1024/DH rows x DH floats over 256 threads
+template <int NV>
+struct TileOffs { unsigned o[NV]; };
 template <int DH, int NV>
-__device__ __forceinline__ void tile_fetch(TileRegsN<NV>& r, const float* __restrict__ base, int64_t D, int row0, int nrows, int tid) {
+__device__ __forceinline__ void tile_offsets(TileOffs<NV>& t, int64_t D, int tid) {
     constexpr int C4 = DH / 4;
 #pragma unroll
     for (int p = 0; p < NV; ++p) {
         const int idx = tid + 256 * p;
-        const int rr = idx / C4, c4 = (idx % C4) * 4;
-        r.v[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row0 + rr < nrows) r.v[p] = *reinterpret_cast<const float4*>(base + (int64_t)(row0 + rr) * D + c4);
+        t.o[p] = (unsigned)(idx / C4) * (unsigned)D + (unsigned)(idx % C4) * 4u;
+    }
+}
+template <int DH, int NV>
+__device__ __forceinline__ void tile_fetch(TileRegsN<NV>& r, const TileOffs<NV>& t, const float* __restrict__ base, int64_t D, int row0,
+                                           int nrows, int tid) {
+    constexpr int C4 = DH / 4, ROWS = NV * 1024 / DH;
+    const float* __restrict__ tb = base + (int64_t)row0 * D;          // wave-uniform
+    unsigned off[NV];
+#pragma unroll
+    for (int p = 0; p < NV; ++p) off[p] = t.o[p];
+    if (row0 + ROWS > nrows) {                                        // last, partial tile (wave-uniform)
+        const int last = nrows - 1 - row0;                            // >= 0: callers only fetch tiles that start inside the tensor
+#pragma unroll
+        for (int p = 0; p < NV; ++p) {
+            const int idx = tid + 256 * p;
+            off[p] = (unsigned)min(idx / C4, last) * (unsigned)D + (unsigned)(idx % C4) * 4u;
+        }
+    }
+    // (the zero default + wave-uniform guard keep the tile in registers: an unconditional load-into-struct /
+    //  store-from-struct pair is turned into memcpys through a stack slot by hipcc -- 144 B/lane of scratch)
+#pragma unroll
+    for (int p = 0; p < NV; ++p) r.v[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row0 < nrows) {
+#pragma unroll
+        for (int p = 0; p < NV; ++p) r.v[p] = *reinterpret_cast<const float4*>(tb + off[p]);
     }
 }
 template <int DH, int NV>
@@ -151,13 +201,39 @@ __device__ __forceinline__ int first_valid_key(const int32_t* __restrict__ kv, i
 // next lighter ones, ...): with 2 resident blocks per CU an alternating heavy/light order left some CUs with three
 // heavy blocks out of four (measured 91 us causal vs 97 us non-causal; balanced would be 73).
 // Grid = ceil(BH/8)*8*nblk; returns false for padding blocks.
-__device__ __forceinline__ bool map_block(int id, int BH, int nblk, bool heavy_is_high, int& bh, int& blk) {
+__device__ __forceinline__ bool map_block(int id, int BH, int nblk, bool heavy_is_high, int& bh, int& blk, int tune = 0) {
     const int x = id & 7, r = id >> 3;
     const int nbx = (BH + 7) >> 3;
-    const int j = r / nbx;
-    bh = (r - j * nbx) * 8 + x;
+    int j, i;
+    if (nblk == 2 && (tune & 4)) {
+        // Two weight levels (T <= 256 under a causal mask).  Heaviest-first starts every resident slot with a heavy block:
+        // all of them load their first tiles at once (an HBM burst with idle matrix pipes), finish together, and the
+        // light generation repeats the burst -- the profile showed ~30 % of the kernel in prologues and epilogues.
+        // Order per XCD: [H L H L ...] for the first half of each kind, then the other heavies, then the other lights:
+        // a slot runs light->heavy or heavy->light (same total), so later prologues / epilogues run under somebody
+        // else's MFMA phase.
+        const int A = nbx >> 1;
+        if (r < 2 * A) { j = r & 1; i = r >> 1; }
+        else if (r < 2 * A + (nbx - A)) { j = 0; i = A + (r - 2 * A); }
+        else { j = 1; i = A + (r - 2 * A - (nbx - A)); }
+    } else {
+        j = r / nbx;
+        i = r - j * nbx;
+    }
+    bh = i * 8 + x;
     blk = heavy_is_high ? nblk - 1 - j : j;
     return bh < BH;
+}
+// Which of the block's four 32-row groups does this wave take?  Under a causal mask group g of a block does g-dependent
+// work (group 3 of a query block sees the most keys, group 0 of a key block the most queries) and wave w of EVERY block
+// lands on SIMD w, so with the identity map SIMD 3 (0) carries 6 (12) tile-units per (batch, head) and SIMD 0 (3) only
+// 4 (6): the matrix pipes could never be more than 75-83 % busy.  Every other block (by the two placements the
+// dispatcher is likely to use for the co-resident pair: consecutive ids, or ids one CU-round apart) mirrors the map, so
+// a SIMD's two resident waves carry complementary groups.
+enum { AT_TUNE_FLIP = 1, AT_TUNE_HALF = 2, AT_TUNE_MIX = 4 };
+__device__ __forceinline__ int wave_group(int wave, int tune) {
+    const int r = blockIdx.x >> 3;
+    return ((tune & AT_TUNE_FLIP) && ((r ^ (r >> 5)) & 1)) ? 3 - wave : wave;
 }
 __host__ inline unsigned mapped_grid(int64_t BH, int64_t nblk) { return (unsigned)(ceil_div(BH, 8) * 8 * nblk); }
 
@@ -187,15 +263,42 @@ __device__ __forceinline__ void mma2_rows(f32x16& accA, const float* __restrict_
         accA = AT_MFMA(x.w, fA[g][3], accA);
         accB = AT_MFMA(y.w, fB[g][3], accB);
     }
+    // both reads of group g+1 go out in the first half of group g (a read issued right before its first use showed up
+    // as an lgkmcnt(0) stall in front of every other MFMA group)
     AT_SCHED_DSRD(2);
 #pragma unroll
     for (int g = 0; g < G - 1; ++g) {
-        AT_SCHED_MFMA(4);
+        AT_SCHED_MFMA(2);
+        AT_SCHED_DSRD(1);
+        AT_SCHED_MFMA(2);
         AT_SCHED_DSRD(1);
         AT_SCHED_MFMA(4);
-        AT_SCHED_DSRD(1);
     }
     AT_SCHED_MFMA(8);
+}
+
+// one product of the pair above (4*G MFMAs)
+template <int G>
+__device__ __forceinline__ void mma1_rows(f32x16& acc, const float* __restrict__ ta, const float (&f)[G][4]) {
+    float4 a[2];
+    a[0] = *reinterpret_cast<const float4*>(ta);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        if (g + 1 < G) a[(g + 1) & 1] = *reinterpret_cast<const float4*>(ta + 8 * (g + 1));
+        const float4 x = a[g & 1];
+        acc = AT_MFMA(x.x, f[g][0], acc);
+        acc = AT_MFMA(x.y, f[g][1], acc);
+        acc = AT_MFMA(x.z, f[g][2], acc);
+        acc = AT_MFMA(x.w, f[g][3], acc);
+    }
+    AT_SCHED_DSRD(1);
+#pragma unroll
+    for (int g = 0; g < G - 1; ++g) {
+        AT_SCHED_MFMA(2);
+        AT_SCHED_DSRD(1);
+        AT_SCHED_MFMA(2);
+    }
+    AT_SCHED_MFMA(4);
 }
 
 // acc[dt] += T^T[d = 32dt + l31][row(e)] * P[e] over the 32 rows carried by accumulator P (16*DT MFMAs, DT = DH/32): the
@@ -322,9 +425,10 @@ __global__ __launch_bounds__(256, DH <= 64 ? 2 : 1) void attn_fwd_kernel(const A
     const int l31 = lane & 31, lh = lane >> 5;
     const int qblocks = (p.Tq + AT_BQ - 1) / AT_BQ;
     int bh, qb;
-    if (!map_block(blockIdx.x, p.B * p.H, qblocks, true, bh, qb)) return;
+    if (!map_block(blockIdx.x, p.B * p.H, qblocks, true, bh, qb, p.tune)) return;
+    AT_PROF_DECL;
     const int b = bh / p.H, h = bh - b * p.H;
-    const int q0 = qb * AT_BQ + wave * 32;           // this wave's first query
+    const int q0 = qb * AT_BQ + wave_group(wave, p.tune) * 32;   // this wave's first query
     const int q = q0 + l31;                           // this lane's query
     const float* Qb = p.Q + ((int64_t)b * p.Tq) * p.LQ + (int64_t)h * DH;
     const float* Kb = p.K + ((int64_t)b * p.Tk) * p.LQ + (int64_t)h * DH;
@@ -337,6 +441,15 @@ __global__ __launch_bounds__(256, DH <= 64 ? 2 : 1) void attn_fwd_kernel(const A
     const unsigned seed = GEN ? p.x.drop_seed + at_seed_offset(p.x) : 0u;
     const unsigned rowkey = GEN ? at_rowkey(seed, (unsigned)drow) : 0u;
 
+    // Every global load of the prologue is issued before the first wait: the first K/V tile (every block visits tile 0
+    // unless it visits none), the Q fragments, the key-padding scan -- one memory round trip instead of three.
+    TileRegsN<NV> kr, vr;
+    TileOffs<NV> toff;
+    tile_offsets<DH>(toff, p.LQ, tid);
+    int kflag = 1;
+    tile_fetch<DH>(kr, toff, Kb, p.LQ, 0, p.Tk, tid);
+    tile_fetch<DH>(vr, toff, Vb, p.LQ, 0, p.Tk, tid);
+    kflag = key_flag(kv, 0, p.Tk, lane);
     // Q fragments, pre-scaled by scale*log2(e) (softmax runs on exp2): lane (q, lh) holds Q[q][8g + 4lh + j]
     float qf[G][4];
     const float qs = p.scale * AT_LOG2E;
@@ -344,7 +457,7 @@ __global__ __launch_bounds__(256, DH <= 64 ? 2 : 1) void attn_fwd_kernel(const A
     for (int g = 0; g < G; ++g) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (q < p.Tq) v = *reinterpret_cast<const float4*>(Qb + (int64_t)q * p.LQ + 8 * g + 4 * lh);
-        qf[g][0] = v.x * qs; qf[g][1] = v.y * qs; qf[g][2] = v.z * qs; qf[g][3] = v.w * qs;
+        qf[g][0] = v.x; qf[g][1] = v.y; qf[g][2] = v.z; qf[g][3] = v.w;
     }
 
     // How many key tiles does this block visit?  Causal tiles above the block's last query contribute exp(-1e9-m)=0
@@ -366,26 +479,28 @@ __global__ __launch_bounds__(256, DH <= 64 ? 2 : 1) void attn_fwd_kernel(const A
 #pragma unroll
         for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
     float m = -INFINITY, l = 0.f;                       // running max (log2 units, shared by the lane pair), partial sum
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) qf[g][j] *= qs;
 
-    TileRegsN<NV> kr, vr;
-    int kflag = 1;
-    if (n_tiles > 0) {
-        tile_fetch<DH>(kr, Kb, p.LQ, 0, p.Tk, tid);
-        tile_fetch<DH>(vr, Vb, p.LQ, 0, p.Tk, tid);
-        kflag = key_flag(kv, 0, p.Tk, lane);
-    }
+    AT_T(0);
     for (int t = 0; t < n_tiles; ++t) {
         const int kv0 = t * AT_BK;
         __syncthreads();                                // previous tile fully consumed
+        AT_T(1);
         tile_commit<DH>(Ks, kr, tid);
         tile_commit<DH>(Vs, vr, tid);
-        unsigned long long valid = __ballot(kflag != 0) >> (4 * lh);   // bit j: key kv0 + j + 4lh is a real token
+        const unsigned long long vball = __ballot(kflag != 0);
+        unsigned long long valid = vball >> (4 * lh);                   // bit j: key kv0 + j + 4lh is a real token
         __syncthreads();
+        AT_T(2);
         if (t + 1 < n_tiles) {                          // next tile's loads fly during this tile's MFMAs
-            tile_fetch<DH>(kr, Kb, p.LQ, kv0 + AT_BK, p.Tk, tid);
-            tile_fetch<DH>(vr, Vb, p.LQ, kv0 + AT_BK, p.Tk, tid);
+            tile_fetch<DH>(kr, toff, Kb, p.LQ, kv0 + AT_BK, p.Tk, tid);
+            tile_fetch<DH>(vr, toff, Vb, p.LQ, kv0 + AT_BK, p.Tk, tid);
             kflag = key_flag(kv, kv0 + AT_BK, p.Tk, lane);
         }
+        AT_T(3);
         bool skip = skip_ok && kv0 > q0 + 31 + shift;   // wave-uniform: every key of this tile is above the diagonal
         if constexpr (GEN) {
             if (dense) {
@@ -393,6 +508,9 @@ __global__ __launch_bounds__(256, DH <= 64 ? 2 : 1) void attn_fwd_kernel(const A
                 skip = __ballot(valid != 0ull || !row_sees) == 0ull;
             }
         }
+        // wave-uniform: the tile's upper 32 keys are above the diagonal for every query of the wave (all of which see a
+        // real key): their probabilities are exactly 0, so that half's S, softmax and PV work is dropped
+        const bool half = (p.tune & AT_TUNE_HALF) && skip_ok && kv0 + 32 > q0 + 31 + shift;
         if (!skip) {
             // ---- S^T = K Q^T (2 key sub-tiles of 32) -------------------------------------------------------
             f32x16 s[2];
@@ -400,28 +518,43 @@ __global__ __launch_bounds__(256, DH <= 64 ? 2 : 1) void attn_fwd_kernel(const A
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) s[kt][e] = 0.f;
-            mma2_rows<G>(s[0], &Ks[l31 * LD + 4 * lh], qf, s[1], &Ks[(32 + l31) * LD + 4 * lh], qf);
+            if (half) mma1_rows<G>(s[0], &Ks[l31 * LD + 4 * lh], qf);
+            else mma2_rows<G>(s[0], &Ks[l31 * LD + 4 * lh], qf, s[1], &Ks[(32 + l31) * LD + 4 * lh], qf);
+            AT_T(4);
             // ---- mask + online softmax (lane <-> query); local key of register (kt, e) = kt*32 + rc(e) + 4lh ------
             const int lim_causal = p.causal ? q + shift - kv0 - 4 * lh : 1 << 30;   // masked iff local index > lim
             const int lim_range = p.Tk - 1 - kv0 - 4 * lh;                            // not a key at all iff local index > lim
             float mx = -INFINITY;
+            // wave-uniform: every key of the tile is a real token that every query of the wave may see -- nothing to mask
+            // (all tiles left of the diagonal: the common case)
+            const bool plain = !(GEN && dense) && vball == ~0ull && kv0 + AT_BK <= p.Tk && (!p.causal || kv0 + AT_BK - 1 <= q0 + shift);
+            if (plain) {
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
+                for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int kl = kt * 32 + (e & 3) + 8 * (e >> 2);
-                    float v = s[kt][e];
-                    if (kl > lim_causal || !((valid >> kl) & 1ull)) v = AT_MASKED2;
-                    if (kl > lim_range) v = -INFINITY;
-                    s[kt][e] = v;
-                    mx = fmaxf(mx, v);
+                    for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[kt][e]);
+            } else {
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    if (kt == 1 && half) break;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int kl = kt * 32 + (e & 3) + 8 * (e >> 2);
+                        float v = s[kt][e];
+                        if (kl > lim_causal || !((valid >> kl) & 1ull)) v = AT_MASKED2;
+                        if (kl > lim_range) v = -INFINITY;
+                        s[kt][e] = v;
+                        mx = fmaxf(mx, v);
+                    }
                 }
+            }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float m_new = fmaxf(m, mx);
             const float alpha = __builtin_amdgcn_exp2f(m - m_new);   // exp2(-inf) = 0 on the first tile
             float ps = 0.f;
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
+            for (int kt = 0; kt < 2; ++kt) {
+                if (kt == 1 && half) break;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     float pv = __builtin_amdgcn_exp2f(s[kt][e] - m_new);
@@ -434,15 +567,18 @@ __global__ __launch_bounds__(256, DH <= 64 ? 2 : 1) void attn_fwd_kernel(const A
                     }
                     s[kt][e] = pv;
                 }
+            }
             l = l * alpha + ps;
             m = m_new;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;
+            AT_T(5);
             // ---- O^T += V^T P^T ------------------------------------------------------------------------------
             mma_cols<DT, LD>(o, &Vs[(4 * lh) * LD + l31], s[0]);
-            mma_cols<DT, LD>(o, &Vs[(32 + 4 * lh) * LD + l31], s[1]);
+            if (!half) mma_cols<DT, LD>(o, &Vs[(32 + 4 * lh) * LD + l31], s[1]);
+            AT_T(6);
         }
     }
 
@@ -454,6 +590,8 @@ __global__ __launch_bounds__(256, DH <= 64 ? 2 : 1) void attn_fwd_kernel(const A
         *reinterpret_cast<float2*>(p.LSE + 2 * (((int64_t)b * p.H + h) * p.Tq + q)) = make_float2(m, log2f(lt));
     __syncthreads();                                     // K/V tiles are dead: reuse the block as [4 waves][32 q][LD]
     store_transposed<DH>(smem + wave * (32 * LD), o, inv, p.O + ((int64_t)b * p.Tq) * p.D + (int64_t)h * DH, p.D, q0, p.Tq, lane);
+    AT_T(7);
+    AT_PROF_STORE(p.prof);
 }
 
 // =====================================================================================================
@@ -483,9 +621,9 @@ __global__ __launch_bounds__(256, DH <= 64 ? 2 : 1) void attn_bwd_dkdv_kernel(co
     const int l31 = lane & 31, lh = lane >> 5;
     const int kblocks = (p.Tk + 127) / 128;
     int bh, kb;
-    if (!map_block(blockIdx.x, p.B * p.H, kblocks, false, bh, kb)) return;
+    if (!map_block(blockIdx.x, p.B * p.H, kblocks, false, bh, kb, p.tune)) return;
     const int b = bh / p.H, h = bh - b * p.H;
-    const int k0w = kb * 128 + wave * 32;
+    const int k0w = kb * 128 + wave_group(wave, p.tune) * 32;
     const int key = k0w + l31;                                  // this lane's key
     const float* Qb = p.Q + ((int64_t)b * p.Tq) * p.LQ + (int64_t)h * DH;
     const float* dOb = p.dO + ((int64_t)b * p.Tq) * p.D + (int64_t)h * DH;
@@ -495,9 +633,7 @@ __global__ __launch_bounds__(256, DH <= 64 ? 2 : 1) void attn_bwd_dkdv_kernel(co
     const float* Dsb = p.Dsum + ((int64_t)b * p.H + h) * p.Tq;
     const int32_t* kv = p.key_valid ? p.key_valid + (int64_t)b * p.Tk : nullptr;
     const int shift = p.Tk - p.Tq;
-    const int fv = first_valid_key(kv, p.Tk, tid, &sh_fv);
     const bool key_in = key < p.Tk;
-    const bool key_pad = kv && key_in && kv[key] == 0;
     const bool dense = GEN && p.x.mask_bitsT != nullptr;
     const bool dropping = GEN && (p.x.drop_mask != nullptr || p.x.drop_threshold != 0u);
     const int nwq = (p.Tq + 63) >> 6;
@@ -515,9 +651,15 @@ __global__ __launch_bounds__(256, DH <= 64 ? 2 : 1) void attn_bwd_dkdv_kernel(co
             a = *reinterpret_cast<const float4*>(Kb + (int64_t)key * p.LQ + 8 * g + 4 * lh);
             c = *reinterpret_cast<const float4*>(Vb + (int64_t)key * p.LQ + 8 * g + 4 * lh);
         }
-        kf[g][0] = a.x * sl2; kf[g][1] = a.y * sl2; kf[g][2] = a.z * sl2; kf[g][3] = a.w * sl2;
+        kf[g][0] = a.x; kf[g][1] = a.y; kf[g][2] = a.z; kf[g][3] = a.w;
         vf[g][0] = c.x; vf[g][1] = c.y; vf[g][2] = c.z; vf[g][3] = c.w;
     }
+    const bool key_pad = kv && key_in && kv[key] == 0;
+    const int fv = first_valid_key(kv, p.Tk, tid, &sh_fv);      // (after the fragment loads were issued: one round trip)
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) kf[g][j] *= sl2;
     f32x16 dk[DT], dv[DT];                                      // dK^T / dV^T: [dt][e] <-> d = 32dt + acc_row(e,lh), key = lane
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
@@ -532,6 +674,9 @@ __global__ __launch_bounds__(256, DH <= 64 ? 2 : 1) void attn_bwd_dkdv_kernel(co
     auto next_tile = [&](int qt) { while (qt < n_qt && tile_skipped(qt)) ++qt; return qt; };
 
     TileRegsN<NV> qr, gr;
+    TileOffs<NV> qoff, goff;
+    tile_offsets<DH>(qoff, p.LQ, tid);
+    tile_offsets<DH>(goff, p.D, tid);
     float2 ml = make_float2(0.f, 0.f);
     float dsv = 0.f, anyv = 1.f;
     auto fetch_rows = [&](int qs) {
@@ -543,8 +688,8 @@ __global__ __launch_bounds__(256, DH <= 64 ? 2 : 1) void attn_bwd_dkdv_kernel(co
     };
     int qt = next_tile(0);
     if (qt < n_qt) {
-        tile_fetch<DH>(qr, Qb, p.LQ, qt * QT, p.Tq, tid);
-        tile_fetch<DH>(gr, dOb, p.D, qt * QT, p.Tq, tid);
+        tile_fetch<DH>(qr, qoff, Qb, p.LQ, qt * QT, p.Tq, tid);
+        tile_fetch<DH>(gr, goff, dOb, p.D, qt * QT, p.Tq, tid);
         fetch_rows(qt * QT);
     }
     while (qt < n_qt) {
@@ -556,8 +701,8 @@ __global__ __launch_bounds__(256, DH <= 64 ? 2 : 1) void attn_bwd_dkdv_kernel(co
         __syncthreads();
         const int qn = next_tile(qt + 1);
         if (qn < n_qt) {
-            tile_fetch<DH>(qr, Qb, p.LQ, qn * QT, p.Tq, tid);
-            tile_fetch<DH>(gr, dOb, p.D, qn * QT, p.Tq, tid);
+            tile_fetch<DH>(qr, qoff, Qb, p.LQ, qn * QT, p.Tq, tid);
+            tile_fetch<DH>(gr, goff, dOb, p.D, qn * QT, p.Tq, tid);
             fetch_rows(qn * QT);
         }
         // wave-uniform skip: this wave's 32 keys are above the diagonal for all queries of the tile (which all see a real key)
@@ -578,6 +723,9 @@ __global__ __launch_bounds__(256, DH <= 64 ? 2 : 1) void attn_bwd_dkdv_kernel(co
 #pragma unroll
             for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
             mma2_rows<G>(s, &Qs[l31 * LD + 4 * lh], kf, dp, &dOs[l31 * LD + 4 * lh], vf);
+            // wave-uniform: the wave's 32 keys are real tokens visible to all 32 queries of the tile -- nothing to mask
+            const bool plain = !(GEN && dense) && __ballot(key_pad || !key_in) == 0ull && qs + QT <= p.Tq &&
+                               (!p.causal || k0w + 31 <= qs + shift);
             // ---- P = exp2(S_masked - m[q] - l[q]);  dS = P (dP*drop - Dsum[q]) scale, zero where masked ---------------
 #pragma unroll
             for (int e4 = 0; e4 < 4; ++e4) {
@@ -585,6 +733,23 @@ __global__ __launch_bounds__(256, DH <= 64 ? 2 : 1) void attn_bwd_dkdv_kernel(co
                 const float4 L4 = *reinterpret_cast<const float4*>(&Ls[8 * e4 + 4 * lh]);
                 const float4 D4 = *reinterpret_cast<const float4*>(&Ds[8 * e4 + 4 * lh]);
                 const float Mr[4] = {M4.x, M4.y, M4.z, M4.w}, Lr[4] = {L4.x, L4.y, L4.z, L4.w}, Dr[4] = {D4.x, D4.y, D4.z, D4.w};
+                if (plain) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int e = e4 * 4 + r;
+                        const float pv = __builtin_amdgcn_exp2f((s[e] - Mr[r]) - Lr[r]);
+                        float mult = 1.f;
+                        if constexpr (GEN) {
+                            if (dropping) {
+                                const int64_t row = drow0 + qs + 8 * e4 + r + 4 * lh;
+                                mult = at_drop_mult(p.x, at_rowkey(seed, (unsigned)row), row, p.Tk, key);
+                            }
+                        }
+                        s[e] = pv * mult;
+                        dp[e] = pv * ((dp[e] * mult - Dr[r]) * p.scale);
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int e = e4 * 4 + r;
@@ -636,9 +801,9 @@ __global__ __launch_bounds__(256, DH <= 64 ? 2 : 1) void attn_bwd_dq_kernel(cons
     const int l31 = lane & 31, lh = lane >> 5;
     const int qblocks = (p.Tq + AT_BQ - 1) / AT_BQ;
     int bh, qb;
-    if (!map_block(blockIdx.x, p.B * p.H, qblocks, true, bh, qb)) return;
+    if (!map_block(blockIdx.x, p.B * p.H, qblocks, true, bh, qb, p.tune)) return;
     const int b = bh / p.H, h = bh - b * p.H;
-    const int q0 = qb * AT_BQ + wave * 32;
+    const int q0 = qb * AT_BQ + wave_group(wave, p.tune) * 32;
     const int q = q0 + l31;
     const float* Qb = p.Q + ((int64_t)b * p.Tq) * p.LQ + (int64_t)h * DH;
     const float* dOb = p.dO + ((int64_t)b * p.Tq) * p.D + (int64_t)h * DH;
@@ -646,8 +811,15 @@ __global__ __launch_bounds__(256, DH <= 64 ? 2 : 1) void attn_bwd_dq_kernel(cons
     const float* Vb = p.V + ((int64_t)b * p.Tk) * p.LQ + (int64_t)h * DH;
     const int32_t* kv = p.key_valid ? p.key_valid + (int64_t)b * p.Tk : nullptr;
     const int shift = p.Tk - p.Tq;
-    const int fv = first_valid_key(kv, p.Tk, tid, &sh_fv);
     const bool q_in = q < p.Tq;
+    // prologue loads all in flight before the first wait: first K/V tile, row statistics, Q / dO / O fragments, padding scan
+    TileRegsN<NV> kr, vr;
+    TileOffs<NV> toff;
+    tile_offsets<DH>(toff, p.LQ, tid);
+    int kflag = 1;
+    tile_fetch<DH>(kr, toff, Kb, p.LQ, 0, p.Tk, tid);
+    tile_fetch<DH>(vr, toff, Vb, p.LQ, 0, p.Tk, tid);
+    kflag = key_flag(kv, 0, p.Tk, lane);
     const float2 ml = q_in ? reinterpret_cast<const float2*>(p.LSE)[((int64_t)b * p.H + h) * p.Tq + q] : make_float2(0.f, 0.f);
     const float* Ob = p.O + ((int64_t)b * p.Tq) * p.D + (int64_t)h * DH;
     const bool dense = GEN && p.x.mask_bits != nullptr;
@@ -660,6 +832,7 @@ __global__ __launch_bounds__(256, DH <= 64 ? 2 : 1) void attn_bwd_dq_kernel(cons
     float qf[G][4], gf[G][4];                                   // Q (pre-scaled, log2 units) and dO fragments of this lane's query
     const float sl2 = p.scale * AT_LOG2E;
     float dpart = 0.f;                                          // this half-wave's part of Dsum[q] = sum_d dO[q,d] O[q,d]
+    float4 og[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a, o4 = a;
@@ -668,9 +841,16 @@ __global__ __launch_bounds__(256, DH <= 64 ? 2 : 1) void attn_bwd_dq_kernel(cons
             c = *reinterpret_cast<const float4*>(dOb + (int64_t)q * p.D + 8 * g + 4 * lh);
             o4 = *reinterpret_cast<const float4*>(Ob + (int64_t)q * p.D + 8 * g + 4 * lh);
         }
-        qf[g][0] = a.x * sl2; qf[g][1] = a.y * sl2; qf[g][2] = a.z * sl2; qf[g][3] = a.w * sl2;
+        qf[g][0] = a.x; qf[g][1] = a.y; qf[g][2] = a.z; qf[g][3] = a.w;
         gf[g][0] = c.x; gf[g][1] = c.y; gf[g][2] = c.z; gf[g][3] = c.w;
-        dpart += c.x * o4.x + c.y * o4.y + c.z * o4.z + c.w * o4.w;
+        og[g] = o4;
+    }
+    const int fv = first_valid_key(kv, p.Tk, tid, &sh_fv);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        dpart += gf[g][0] * og[g].x + gf[g][1] * og[g].y + gf[g][2] * og[g].z + gf[g][3] * og[g].w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) qf[g][j] *= sl2;
     }
     // Dsum (= sum_k dP P, the softmax-backward row term; with dropout O already holds the dropped map, so dO.O is still it)
     // is produced here -- the dO fragments are already in registers -- and saved for the dK/dV kernel, which runs after.
@@ -688,23 +868,17 @@ __global__ __launch_bounds__(256, DH <= 64 ? 2 : 1) void attn_bwd_dq_kernel(cons
 #pragma unroll
         for (int e = 0; e < 16; ++e) dq[dt][e] = 0.f;
 
-    TileRegsN<NV> kr, vr;
-    int kflag = 1;
-    if (n_tiles > 0) {
-        tile_fetch<DH>(kr, Kb, p.LQ, 0, p.Tk, tid);
-        tile_fetch<DH>(vr, Vb, p.LQ, 0, p.Tk, tid);
-        kflag = key_flag(kv, 0, p.Tk, lane);
-    }
     for (int t = 0; t < n_tiles; ++t) {
         const int kv0 = t * AT_BK;
         __syncthreads();
         tile_commit<DH>(Ks, kr, tid);
         tile_commit<DH>(Vs, vr, tid);
-        unsigned long long valid = __ballot(kflag != 0) >> (4 * lh);
+        const unsigned long long vball = __ballot(kflag != 0);
+        unsigned long long valid = vball >> (4 * lh);
         __syncthreads();
         if (t + 1 < n_tiles) {
-            tile_fetch<DH>(kr, Kb, p.LQ, kv0 + AT_BK, p.Tk, tid);
-            tile_fetch<DH>(vr, Vb, p.LQ, kv0 + AT_BK, p.Tk, tid);
+            tile_fetch<DH>(kr, toff, Kb, p.LQ, kv0 + AT_BK, p.Tk, tid);
+            tile_fetch<DH>(vr, toff, Vb, p.LQ, kv0 + AT_BK, p.Tk, tid);
             kflag = key_flag(kv, kv0 + AT_BK, p.Tk, lane);
         }
         bool skip = skip_ok && kv0 > q0 + 31 + shift;
@@ -717,22 +891,37 @@ __global__ __launch_bounds__(256, DH <= 64 ? 2 : 1) void attn_bwd_dq_kernel(cons
         if (!skip) {
             const int lim_causal = p.causal ? q + shift - kv0 - 4 * lh : 1 << 30;
             const int lim_range = q_in ? p.Tk - 1 - kv0 - 4 * lh : -1;
+            const bool half = (p.tune & AT_TUNE_HALF) && skip_ok && kv0 + 32 > q0 + 31 + shift;   // upper 32 keys: P = 0 for the whole wave
+            const bool plain = !(GEN && dense) && vball == ~0ull && kv0 + AT_BK <= p.Tk && q0 + 32 <= p.Tq &&
+                               (!p.causal || kv0 + AT_BK - 1 <= q0 + shift);
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
+                if (kt == 1 && half) break;
                 f32x16 s, dp;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
                 mma2_rows<G>(s, &Ks[(kt * 32 + l31) * LD + 4 * lh], qf, dp, &Vs[(kt * 32 + l31) * LD + 4 * lh], gf);
+                if (plain) {                                            // nothing masked in this tile for this wave
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int kl = kt * 32 + (e & 3) + 8 * (e >> 2);
-                    const bool live = kl <= lim_range && kl <= lim_causal && ((valid >> kl) & 1ull);
-                    const float arg = live ? (s[e] - ml.x) - ml.y : -INFINITY;
-                    float mult = 1.f;
-                    if constexpr (GEN) {
-                        if (dropping && live) mult = at_drop_mult(p.x, rowkey, drow, p.Tk, kv0 + kl + 4 * lh);
+                    for (int e = 0; e < 16; ++e) {
+                        float mult = 1.f;
+                        if constexpr (GEN) {
+                            if (dropping) mult = at_drop_mult(p.x, rowkey, drow, p.Tk, kv0 + kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh);
+                        }
+                        dp[e] = __builtin_amdgcn_exp2f((s[e] - ml.x) - ml.y) * ((dp[e] * mult - dsum) * p.scale);
                     }
-                    dp[e] = __builtin_amdgcn_exp2f(arg) * ((dp[e] * mult - dsum) * p.scale);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int kl = kt * 32 + (e & 3) + 8 * (e >> 2);
+                        const bool live = kl <= lim_range && kl <= lim_causal && ((valid >> kl) & 1ull);
+                        const float arg = live ? (s[e] - ml.x) - ml.y : -INFINITY;
+                        float mult = 1.f;
+                        if constexpr (GEN) {
+                            if (dropping && live) mult = at_drop_mult(p.x, rowkey, drow, p.Tk, kv0 + kl + 4 * lh);
+                        }
+                        dp[e] = __builtin_amdgcn_exp2f(arg) * ((dp[e] * mult - dsum) * p.scale);
+                    }
                 }
                 mma_cols<DT, LD>(dq, &Ks[(kt * 32 + 4 * lh) * LD + l31], dp);      // dQ^T += K^T dS^T
             }
@@ -826,6 +1015,22 @@ static int fill_extra(const char* fn, AttnExtra& x, const nnhipAttentionOptions*
     if (x.mask_bits) { key_valid = nullptr; causal = 0; }   // the dense mask is the whole mask
     return 0;
 }
+#ifdef AT_PROF
+static long long* g_prof = nullptr;
+extern "C" void nnhipAttentionSetProfile(long long* buf) { g_prof = buf; }
+#define AT_SET_PROF(p) (p).prof = g_prof
+#else
+#define AT_SET_PROF(p) do {} while (0)
+#endif
+// NNHIP_ATTN_TUNE: bit 0 = mirrored wave -> row-group map (default on); developer A/B switch
+static int attn_tune() {
+    static int t = -1;
+    if (t < 0) {
+        const char* e = getenv("NNHIP_ATTN_TUNE");
+        t = e ? atoi(e) : (AT_TUNE_FLIP | AT_TUNE_HALF | AT_TUNE_MIX);
+    }
+    return t;
+}
 static bool extra_active(const AttnExtra& x) { return x.mask_bits || x.drop_mask || x.drop_threshold != 0u; }
 
 #define AT_DISPATCH(KERNEL, dh, gen, grid, st, p)                                                                      \
@@ -846,7 +1051,7 @@ extern "C" int nnhipAttentionForwardEx(const float* Q, const float* K, const flo
     AttnParams p;
     if (int rc = fill_extra("nnhipAttentionForward", p.x, opts, key_valid, causal)) return rc;
     p.Q = Q; p.K = K; p.V = V; p.O = O; p.LSE = LSE; p.key_valid = key_valid;
-    p.B = (int)B; p.H = (int)H; p.Tq = (int)Tq; p.Tk = (int)Tk; p.D = H * head_dim; p.LQ = ld_qkv ? ld_qkv : p.D; p.scale = scale; p.causal = causal;
+    p.B = (int)B; p.H = (int)H; p.Tq = (int)Tq; p.Tk = (int)Tk; p.D = H * head_dim; p.LQ = ld_qkv ? ld_qkv : p.D; p.scale = scale; p.causal = causal; p.tune = attn_tune(); AT_SET_PROF(p);
     const int64_t qblocks = ceil_div(Tq, AT_BQ);
     const bool gen = extra_active(p.x);
     AT_DISPATCH(attn_fwd_kernel, head_dim, gen, dim3(mapped_grid(B * H, qblocks)), (hipStream_t)s, p);
@@ -877,7 +1082,7 @@ extern "C" int nnhipAttentionBackwardEx(const float* Q, const float* K, const fl
     if (int rc = fill_extra("nnhipAttentionBackward", p.x, opts, key_valid, causal)) return rc;
     p.Q = Q; p.K = K; p.V = V; p.dO = dO; p.LSE = LSE; p.Dsum = dsum; p.O = O; p.dQ = dQ; p.dK = dK; p.dV = dV;
     p.key_valid = key_valid; p.B = (int)B; p.H = (int)H; p.Tq = (int)Tq; p.Tk = (int)Tk; p.D = H * head_dim;
-    p.LQ = ld_qkv ? ld_qkv : p.D; p.scale = scale; p.causal = causal;
+    p.LQ = ld_qkv ? ld_qkv : p.D; p.scale = scale; p.causal = causal; p.tune = attn_tune(); AT_SET_PROF(p);
     const bool gen = extra_active(p.x);
     // dQ first: it also produces Dsum, which the dK/dV kernel consumes
     AT_DISPATCH(attn_bwd_dq_kernel, head_dim, gen, dim3(mapped_grid(B * H, ceil_div(Tq, AT_BQ))), st, p);

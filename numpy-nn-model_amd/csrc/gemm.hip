@@ -136,6 +136,100 @@ __device__ __forceinline__ void gemm_k_loop(f32x16 (&acc)[2][2], float4 (&ra)[BK
     }
 }
 
+// The same loop for the vectorised variants: operand tiles come through g2r_fast (gemm_common.h).  ka / kb are the scalar
+// byte offsets of the k-tile that is resident in LDS stage 0 when the loop starts; the loop walks `nfull` whole k-tiles
+// and leaves, when there is a partial last tile (fetched as the last BK columns of the k range), that tile in stage `cur`
+// for tail_mma.
+template <int BK, bool AKC, bool BKC, bool SUM>
+__device__ __forceinline__ int gemm_k_loop_fast(f32x16 (&acc)[2][2], float4 (&ra)[BK / 8], float4 (&rb)[BK / 8], float4& cs,
+                                                float* __restrict__ smem, __amdgpu_buffer_rsrc_t rsa, __amdgpu_buffer_rsrc_t rsb,
+                                                unsigned ka, unsigned kb, unsigned astep, unsigned bstep, unsigned katail,
+                                                unsigned kbtail, const unsigned (&offa)[BK / 8], const unsigned (&offb)[BK / 8],
+                                                int nfull, bool has_tail, int tid, int wm, int wn, int l31, int lh) {
+    using TA = Tile<BK, AKC>;
+    using TB = Tile<BK, BKC>;
+    constexpr int STAGE = TA::SIZE + TB::SIZE;
+    constexpr int NLD = 2 * (BK / 8);
+    constexpr int NMF = 16 * (BK / 8);
+    int cur = 0;
+    for (int kt = 0; kt < nfull; ++kt) {
+        // tile kt+1: the next whole tile, else the shifted tail tile, else (nothing left) the current tile once more --
+        // a harmless re-read whose LDS copy is never used.  All three are scalar selects (SALU).
+        const bool more = kt + 1 < nfull;
+        ka = more ? ka + astep : (has_tail ? katail : ka);
+        kb = more ? kb + bstep : (has_tail ? kbtail : kb);
+        if constexpr (SUM) {
+#pragma unroll
+            for (int q = 0; q < BK / 8; ++q) { cs.x += ra[q].x; cs.y += ra[q].y; cs.z += ra[q].z; cs.w += ra[q].w; }
+        }
+        g2r_fast<BK>(ra, rsa, ka, offa);
+        g2r_fast<BK>(rb, rsb, kb, offb);
+        const float* As = smem + cur * STAGE;
+        const float* Bs = As + TA::SIZE;
+#pragma unroll
+        for (int g = 0; g < BK / 8; ++g) {
+            float a[2][4], b[2][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                frag<BK, AKC>(a[i], As, wm * 64 + i * 32 + l31, g, lh);
+                frag<BK, BKC>(b[i], Bs, wn * 64 + i * 32 + l31, g, lh);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[n][j], acc[i][n], 0, 0, 0);
+        }
+        {
+            float* Sn = smem + (cur ^ 1) * STAGE;
+            r2s<BK, AKC>(ra, Sn, tid);
+            r2s<BK, BKC>(rb, Sn + TA::SIZE, tid);
+        }
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NMF - 2 * NLD, 0);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // 1 DS write
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    return cur;
+}
+
+// The partial last k-tile sits in LDS stage `cur` as the LAST BK columns of the k range: k-groups [g0, BK/8) are new.
+template <int BK, bool AKC, bool BKC>
+__device__ __forceinline__ void tail_mma(f32x16 (&acc)[2][2], const float* __restrict__ smem, int cur, int g0, int wm, int wn,
+                                         int l31, int lh) {
+    using TA = Tile<BK, AKC>;
+    using TB = Tile<BK, BKC>;
+    const float* As = smem + cur * (TA::SIZE + TB::SIZE);
+    const float* Bs = As + TA::SIZE;
+#pragma unroll 1
+    for (int g = g0; g < BK / 8; ++g) {
+        float a[2][4], b[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            frag<BK, AKC>(a[i], As, wm * 64 + i * 32 + l31, g, lh);
+            frag<BK, BKC>(b[i], Bs, wn * 64 + i * 32 + l31, g, lh);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[n][j], acc[i][n], 0, 0, 0);
+    }
+}
+
 // CS (outer-major A only): every thread also accumulates the A elements it stages -- with the [BK][128] tile layout a
 // thread owns the same 4 A rows (m) in every k-tile -- and the tile_n == 0 blocks reduce them to asum[m] = sum_k A[m,k].
 template <int BK, bool AKC, bool BKC, bool VEC, bool CS = false>
@@ -201,20 +295,51 @@ __global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const 
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     float4 ra[BK / 8], rb[BK / 8];
-    const int nk = (int)((kend - kbeg + BK - 1) / BK);
-
-    const float* __restrict__ Z = p.zeros;
-    g2r<BK, AKC, VEC>(ra, A, p.lda, p.M, kend, m0, kbeg, tid, nk > 0, Z);
-    g2r<BK, BKC, VEC>(rb, B, p.ldb, p.N, kend, n0, kbeg, tid, nk > 0, Z);
-    r2s<BK, AKC>(ra, smem, tid);
-    r2s<BK, BKC>(rb, smem + TA::SIZE, tid);
     float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
-    __syncthreads();
-
-    // (running a sum-free copy of the loop in the tile_n != 0 blocks was tried: two inlined copies made the CS kernel
-    // 15 % slower; the row sums cost ~4 % of the loop, so linear.hip only asks for them when a separate column-sum
-    // pass over dO would cost more.)
-    gemm_k_loop<BK, AKC, BKC, VEC, CS>(acc, ra, rb, cs, smem, A, B, p, nk, kbeg, kend, m0, n0, tid, wm, wn, l31, lh, Z);
+    if constexpr (VEC) {
+        // host guarantees: K % 8 == 0, K >= BK, 16-B aligned rows, ld < 2^22 (gemm_common.h, "fast operand fetch")
+        unsigned offa[BK / 8], offb[BK / 8];
+        op_offsets<BK, AKC>(offa, p.lda, p.M, m0, tid);
+        op_offsets<BK, BKC>(offb, p.ldb, p.N, n0, tid);
+        const int64_t klen = kend - kbeg;
+        const int nfull = (int)(klen / BK), rem = (int)(klen - (int64_t)nfull * BK);
+        const bool has_tail = rem != 0;
+        // descriptor = the operand's rows of this block at k = 0; k-tile at k: byte offset 4k (k-major) or 4k*ld (outer-major)
+        const __amdgpu_buffer_rsrc_t rsa = operand_rsrc(AKC ? A + m0 * p.lda : A + m0);
+        const __amdgpu_buffer_rsrc_t rsb = operand_rsrc(BKC ? B + n0 * p.ldb : B + n0);
+        const unsigned ua = AKC ? 4u : (unsigned)(4 * p.lda), ub = BKC ? 4u : (unsigned)(4 * p.ldb);   // bytes per unit of k
+        const unsigned katail = (unsigned)(kend - BK) * ua, kbtail = (unsigned)(kend - BK) * ub;
+        const unsigned ka = nfull > 0 ? (unsigned)kbeg * ua : katail;
+        const unsigned kb = nfull > 0 ? (unsigned)kbeg * ub : kbtail;
+        g2r_fast<BK>(ra, rsa, ka, offa);
+        g2r_fast<BK>(rb, rsb, kb, offb);
+        r2s<BK, AKC>(ra, smem, tid);
+        r2s<BK, BKC>(rb, smem + TA::SIZE, tid);
+        __syncthreads();
+        const int cur = gemm_k_loop_fast<BK, AKC, BKC, CS>(acc, ra, rb, cs, smem, rsa, rsb, ka, kb, BK * ua, BK * ub, katail, kbtail,
+                                                           offa, offb, nfull, has_tail, tid, wm, wn, l31, lh);
+        if (has_tail) {
+            if constexpr (CS) {   // ra holds the tail tile: only its new k-rows (kk >= BK - rem) belong to the row sums
+#pragma unroll
+                for (int q = 0; q < BK / 8; ++q)
+                    if ((tid + NT * q) / 32 >= BK - rem) { cs.x += ra[q].x; cs.y += ra[q].y; cs.z += ra[q].z; cs.w += ra[q].w; }
+            }
+            tail_mma<BK, AKC, BKC>(acc, smem, cur, (BK - rem) >> 3, wm, wn, l31, lh);
+            __syncthreads();                                  // the epilogue re-uses the LDS block
+        }
+    } else {
+        const int nk = (int)((kend - kbeg + BK - 1) / BK);
+        const float* __restrict__ Z = p.zeros;
+        g2r<BK, AKC, VEC>(ra, A, p.lda, p.M, kend, m0, kbeg, tid, nk > 0, Z);
+        g2r<BK, BKC, VEC>(rb, B, p.ldb, p.N, kend, n0, kbeg, tid, nk > 0, Z);
+        r2s<BK, AKC>(ra, smem, tid);
+        r2s<BK, BKC>(rb, smem + TA::SIZE, tid);
+        __syncthreads();
+        // (running a sum-free copy of the loop in the tile_n != 0 blocks was tried: two inlined copies made the CS kernel
+        // 15 % slower; the row sums cost ~4 % of the loop, so linear.hip only asks for them when a separate column-sum
+        // pass over dO would cost more.)
+        gemm_k_loop<BK, AKC, BKC, VEC, CS>(acc, ra, rb, cs, smem, A, B, p, nk, kbeg, kend, m0, n0, tid, wm, wn, l31, lh, Z);
+    }
 
     gemm_epilogue<CS>(acc, p, smem, cs, tid, wave, lane, wm, wn, l31, lh, m0, n0, tn, split, c_off);
 }
@@ -430,7 +555,14 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
         if (!aligned16(P) || (ld & 3) || (batch1 > 1 && (s1 & 3)) || (batch2 > 1 && (s2 & 3))) return false;
         return kmajor ? ((K & 3) == 0) : ((outer & 3) == 0);
     };
-    const bool vec = vec_ok(A, lda, sA, sA2, a_kmajor, M) && vec_ok(B, ldb, sB, sB2, b_kmajor, N);
+    // the vectorised kernels fetch with `tile base + 32-bit offset`, clamp rows and shift the partial last k-tile back
+    // (gemm_common.h): that needs whole k-groups, at least one full tile of k and offsets that fit 32 bits
+    auto span_ok = [&](int64_t ld, bool kmajor) {       // every byte offset inside a block's operand window fits 32 bits
+        return (kmajor ? 128 * ld + K : K * ld + 128) < ((int64_t)1 << 30);
+    };
+    const bool fast_ok = (K & 7) == 0 && K >= BK && span_ok(lda, a_kmajor) && span_ok(ldb, b_kmajor);
+    const bool vec_any = vec_ok(A, lda, sA, sA2, a_kmajor, M) && vec_ok(B, ldb, sB, sB2, b_kmajor, N);
+    const bool vec = fast_ok && vec_any;
     {
         const bool slab = p.splitk > 1;
         bool ok = (N & 3) == 0;
@@ -442,7 +574,7 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
 
     int rc;
     if (gemm_mode() == 1) {
-        rc = gemm_bf3_launch(p, a_kmajor, b_kmajor, vec, asum != nullptr, batch, st);
+        rc = gemm_bf3_launch(p, a_kmajor, b_kmajor, vec_any, asum != nullptr, batch, st);
     } else {
 #define NNHIP_GEMM_CASE(AK, BKM)                                                                   \
     rc = (BK == 16) ? (vec ? launch_variant<16, AK, BKM, true>(p, batch, st)                      \

@@ -78,6 +78,49 @@ __device__ __forceinline__ void g2r(float4 (&r)[BK / 8], const float* __restrict
     }
 }
 
+// ---- fast operand fetch (vectorised variants of gemm.hip) ---------------------------------------------------------------
+// The fp32 MFMA of gfx950 runs on the SAME lanes as the vector ALU (peak 157.3 TFLOP/s either way; a probe,
+// tools/probes/mfma_valu_probe.hip, shows VALU instructions add their ~3.3 cycles to the MFMA time instead of hiding under
+// it).  Round 1's g2r formed a 64-bit address and an out-of-range select per load: 43 VALU instructions per k-tile of 64
+// MFMAs.  Here a load is `buffer_load_dwordx4 v, v_off, s[rsrc], s_koff offen`: the buffer descriptor holds the operand's
+// row origin for this block, the k position is a scalar byte offset advanced by scalar adds, and the per-thread 32-bit
+// byte offset is computed ONCE -- no vector instruction in the loop besides the MFMAs and the LDS traffic.
+//   * rows past the operand's extent are CLAMPED to its last rows, not zeroed: row m of A (n of B) only ever reaches
+//     row m (column n) of C, which the epilogue does not store;
+//   * a partial last k-tile is fetched as the LAST BK columns of the k range (offset shifted back, all in bounds) and
+//     only its new k-groups are multiplied (gemm.hip, tail_mma) -- no lane ever needs zeros.
+// Host-side conditions (gemm_f32_ex): 16-B aligned rows, K % 8 == 0, K >= BK, byte offsets within a block < 2^32.
+typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t operand_rsrc(const float* origin) {
+    // raw buffer (stride 0), no bounds clamp wanted (num_records = 2^32 - 1), gfx9 dword 3 (32-bit data format)
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(origin), 0, 0xFFFFFFFF, 0x00020000);
+}
+template <int BK, bool KC>
+__device__ __forceinline__ void op_offsets(unsigned (&off)[BK / 8], int64_t ld, int64_t R, int64_t r0, int tid) {
+#pragma unroll
+    for (int p = 0; p < BK / 8; ++p) {
+        const int idx = tid + NT * p;
+        if constexpr (KC) {
+            const int rr = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
+            const int64_t rc = min((int64_t)rr, R - 1 - r0);
+            off[p] = (unsigned)((rc * ld + k4) * 4);
+        } else {
+            const int kk = idx / 32, r4 = (idx % 32) * 4;
+            const int64_t rc = min((int64_t)r4, R - 4 - r0);
+            off[p] = (unsigned)(((int64_t)kk * ld + rc) * 4);
+        }
+    }
+}
+template <int BK>
+__device__ __forceinline__ void g2r_fast(float4 (&r)[BK / 8], __amdgpu_buffer_rsrc_t rs, unsigned koff, const unsigned (&off)[BK / 8]) {
+#pragma unroll
+    for (int p = 0; p < BK / 8; ++p) {
+        // (component-wise: `r[p] = *(float4*)...` is a struct copy that hipcc turns into memcpys through a stack slot)
+        const u32x4_ t = __builtin_amdgcn_raw_buffer_load_b128(rs, off[p], koff, 0);
+        r[p].x = __uint_as_float(t.x); r[p].y = __uint_as_float(t.y); r[p].z = __uint_as_float(t.z); r[p].w = __uint_as_float(t.w);
+    }
+}
+
 // `cs`: this thread's row sums of the A elements it staged (CS variants only).  The K loop has ended with a barrier, so
 // the whole dynamic LDS block `smem` is free.
 template <bool CS>

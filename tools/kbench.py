@@ -140,6 +140,27 @@ def main():
             "nnhipFusedAdamWMultiTensorStep", opt, nt, cast(cp, ctypes.c_void_p), cast(cg, ctypes.c_void_p),
             cast(cm, ctypes.c_void_p), cast(cv, ctypes.c_void_p), cast(cs, ctypes.c_int64), 1e-3, 0.9, 0.999, 1e-8, 1e-2,
             3, 0, 1.0, st), args.iters), nbytes=28.0 * nt * 512 * 1024)
+    if want("attn"):
+        # fused attention at the C4 shape (B64 T256 H8 dh64, pad+causal): Q/K/V as column blocks of one [B,T,3D] buffer
+        for (B_, T_, H_, dh) in [(64, 256, 8, 64), (16, 1024, 8, 64), (64, 256, 4, 128)]:
+            Dm = H_ * dh
+            qkv = randn(B_, T_, 3 * Dm)
+            dqkv = torch.empty_like(qkv)
+            kvalid = torch.ones(B_, T_, dtype=torch.int32, device=dev)
+            ctx, dctx = torch.empty(B_, T_, Dm, device=dev), randn(B_, T_, Dm)
+            lse = torch.empty(B_, H_, T_, 2, device=dev)
+            q_, k_, v_ = (qkv[..., i * Dm:(i + 1) * Dm] for i in range(3))
+            dq_, dk_, dv_ = (dqkv[..., i * Dm:(i + 1) * Dm] for i in range(3))
+            sc = 1.0 / float(np.sqrt(Dm))
+            fwd_fl = 4.0 * B_ * H_ * T_ * T_ * dh / 2          # causal: half the score matrix
+            f = lambda: call("nnhipAttentionForward", _lib.StridedView(q_), _lib.StridedView(k_), _lib.StridedView(v_), kvalid,  # noqa: E731
+                             ctx, lse, B_, H_, T_, T_, dh, 3 * Dm, sc, 1, st)
+            bw = lambda: call("nnhipAttentionBackward", _lib.StridedView(q_), _lib.StridedView(k_), _lib.StridedView(v_), kvalid,  # noqa: E731
+                              ctx, dctx, lse, _lib.StridedView(dq_), _lib.StridedView(dk_), _lib.StridedView(dv_), B_, H_, T_, T_, dh,
+                              3 * Dm, sc, 1, st)
+            report(f"attn fwd B{B_} T{T_} H{H_} dh{dh} causal", *bench(f, args.iters), flops=fwd_fl)
+            report(f"attn bwd B{B_} T{T_} H{H_} dh{dh} causal", *bench(bw, args.iters), flops=2.5 * fwd_fl)
+
     if want("conv"):
         for (B, Cin, H, Cout) in [(256, 1, 28, 8), (256, 8, 14, 16)]:
             X = rnd(B, Cin, H, H)
