@@ -52,12 +52,32 @@ def parse():
     return ap.parse_args()
 
 
-def timed_region(step_fn, steps, warmup, world):
-    """W untimed steps, then EXACTLY K steps bracketed by barrier + synchronize; max over ranks."""
+def timed_region(step_fn, steps, warmup, world, min_warm_s=0.0):
+    """W untimed steps, then EXACTLY K steps bracketed by barrier + synchronize; max over ranks.
+    min_warm_s: sub-millisecond steps (C1, C5) keep stepping untimed until that much wall time has passed -- a GPU that
+    has idled sits in a low power state and replays the same graph ~2x slower for the first few hundred ms."""
     import torch
     import torch.distributed as dist
+    # the first timing-event pair of a process costs ~45 ms (HIP initialises its event/profiling machinery lazily): pay
+    # that here, not inside the timed region of a workload whose whole timed region is 30 ms (C1)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    e1.record()
+    torch.cuda.synchronize()
+    e0.elapsed_time(e1)
+    tw = time.perf_counter()
     for _ in range(warmup):
         step_fn(False)
+    if min_warm_s > 0.0 and warmup > 0:
+        torch.cuda.synchronize()
+        el = time.perf_counter() - tw
+        extra = max(0, min(20000, int((min_warm_s - el) / max(el / warmup, 1e-6))))
+        if world > 1:                                   # every rank must replay the same number of (collective) steps
+            n = torch.tensor([extra], dtype=torch.int64, device="cuda")
+            dist.all_reduce(n, op=dist.ReduceOp.MAX)
+            extra = int(n.item())
+        for _ in range(extra):
+            step_fn(False)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -270,7 +290,7 @@ def workload_c1(args, rank, world):
             if timed:
                 b.record()
 
-    dt = timed_region(step, args.steps, args.warmup, world)
+    dt = timed_region(step, args.steps, args.warmup, world, min_warm_s=0.5)
     if args.graph:
         gstep.release()
     dev_ms = ev.mean_ms()
@@ -623,7 +643,7 @@ def workload_c5(args, rank, world):
             if timed:
                 b.record()
 
-    dt = timed_region(step, args.steps, args.warmup, world)
+    dt = timed_region(step, args.steps, args.warmup, world, min_warm_s=0.5)
     if args.graph:
         gstep.release()
     dev_ms = ev.mean_ms()

@@ -242,24 +242,6 @@ __global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const 
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, lh = lane >> 5;
-    // Two blocks share a CU (2 waves per SIMD share its matrix pipe).  Started together at equal priority they stay in
-    // lock-step: both in the prologue, both in the K loop, both in the store-bound epilogue -- nothing hides the
-    // prologue / epilogue of a grid that is a single generation of tiles (all of GPT-tiny's forward GEMMs).  Raising the
-    // priority of every other dispatch round (blocks are dealt out one per CU per round of 256) lets the favoured
-    // block take the matrix pipe first and finish early; its epilogue then overlaps the partner's K loop.
-    if (p.skew == 3) {
-        // HW_ID.TG_ID (bits 19:16): the workgroup slot on this CU.  The odd slot starts late, so the two co-resident blocks
-        // run phase-shifted: the early one's store-bound epilogue overlaps the late one's K loop.
-        const unsigned tg = __builtin_amdgcn_s_getreg(4 | (16 << 6) | (3 << 11));
-        if (tg & 1u)
-            for (int i = 0; i < p.skew_sleeps; ++i) __builtin_amdgcn_s_sleep(32);
-    }
-    if (p.skew == 1 || p.skew == 2) {
-        const int sel = p.skew == 2 ? ((blockIdx.x >> 3) & 1) : ((blockIdx.x >> 8) & 1);
-        if (sel) __builtin_amdgcn_s_setprio(0);
-        else __builtin_amdgcn_s_setprio(2);
-    }
-
     // ---- block id -> (split, tile_m, tile_n): XCD-aware grouped order --------------------------
     const int nwg = gridDim.x;
     int L;
@@ -519,10 +501,6 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
     p.act = act; p.beta = beta;
     p.splitk = 1; p.k_per_split = ceil_div(K > 0 ? K : 1, BK) * BK; p.slab = nullptr;
     p.asum = asum; p.asum_slab = nullptr; p.addend = addend; p.dswish = dswish; p.dact = dact;
-    static const int skew_sel = []() { const char* e = getenv("NNHIP_GEMM_SKEW"); return e ? atoi(e) : 0; }();
-    static const int skew_sleeps = []() { const char* e = getenv("NNHIP_GEMM_SKEW_SLEEPS"); return e ? atoi(e) : 8; }();
-    p.skew = skew_sel;
-    p.skew_sleeps = skew_sleeps;
     p.zeros = zero_block();
     if (!p.zeros) { set_last_error("zero block allocation failed"); return NNHIP_ENOMEM; }
 

@@ -33,9 +33,6 @@ struct GemmParams {
     const float* addend;  // [M, ldc] or null: C = act(alpha*AB + bias + addend)  (residual / gradient accumulation)
     float* asum;          // CS variants: asum[m] = sum_k A[m,k] (Linear: db = column sums of dO, fused into dW = dO^T X)
     float* asum_slab;     // split-K partials [splitk][M]
-    int skew;             // experiments: 1/2 = raised wave priority for every other dispatch round / block octet,
-                          // 3 = the second workgroup slot of a CU starts `skew_sleeps` x ~0.9 us late (see the kernel)
-    int skew_sleeps;
 };
 
 constexpr int BM = 128, BN = 128, NT = 256;

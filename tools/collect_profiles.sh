@@ -8,6 +8,9 @@ mkdir -p $O
 cd $R
 python tools/kbench.py > $O/kbench.log 2>&1
 python tools/stream_roof.py > $O/stream_roof.txt 2>&1
+python tools/kbench.py --only gemm --gemm-mode 1 > $O/kbench_bf16x3.log 2>&1
+python tools/gemm_accuracy.py > $O/gemm_accuracy.txt 2>&1
+[ -x tools/probes/mfma_valu_probe ] && tools/probes/mfma_valu_probe > $O/mfma_valu_probe.txt 2>&1
 python bench.py --steps 20 --warmup 5 > $O/bench_headline.json 2> $O/bench_headline.err
 python bench.py --workload c2 --steps 20 --warmup 5 > $O/bench_c2.json 2> $O/bench_c2.err
 python bench.py --workload c3 --steps 20 --warmup 5 > $O/bench_c3.json 2> $O/bench_c3.err

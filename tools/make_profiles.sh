@@ -32,3 +32,4 @@ PY
 for W in headline c1 c2 c3 c4 c5; do cp $G/bench_$W.json $P/${TAG}_bench_$W.json; done
 cp $G/kbench.log $P/${TAG}_kbench.txt
 cp $G/stream_roof.txt $P/${TAG}_stream_roof.txt
+for f in kbench_bf16x3.log gemm_accuracy.txt mfma_valu_probe.txt; do [ -f $G/$f ] && grep -v amdgpu.ids $G/$f > $P/${TAG}_${f%.*}.txt; done
