@@ -58,13 +58,15 @@ def timed_region(step_fn, steps, warmup, world, min_warm_s=0.0):
     has idled sits in a low power state and replays the same graph ~2x slower for the first few hundred ms."""
     import torch
     import torch.distributed as dist
-    # the first timing-event pair of a process costs ~45 ms (HIP initialises its event/profiling machinery lazily): pay
-    # that here, not inside the timed region of a workload whose whole timed region is 30 ms (C1)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    e1.record()
+    # The timed steps record one HIP-event pair each (device time per step).  The first few hundred timing events of a
+    # process are slow to create (the runtime grows its signal pool in chunks: ~35 ms in total, measured) -- a fixed cost
+    # that would double the reported time of a workload whose whole timed region is 30 ms (C1).  Warm the pool here.
+    pool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * min(steps, 4096) + 2)]
+    for e in pool:
+        e.record()
     torch.cuda.synchronize()
-    e0.elapsed_time(e1)
+    pool[0].elapsed_time(pool[-1])
+    del pool
     tw = time.perf_counter()
     for _ in range(warmup):
         step_fn(False)

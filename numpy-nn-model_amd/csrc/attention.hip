@@ -74,7 +74,6 @@ struct AttnParams {
     int64_t LQ;                                       // row stride of Q, K, V (>= H * DH: 3*H*DH for a fused q|k|v buffer)
     float scale;                                      // multiplies QK^T (1/sqrt(d_model))
     int causal;
-    int tune;                                         // AT_TUNE_* bits (attn_tune())
     AttnExtra x;
 #ifdef AT_PROF
     long long* prof;
@@ -92,7 +91,6 @@ struct AttnBwdParams {
     int64_t LQ;                                                        // row stride of Q, K, V, dQ, dK, dV
     float scale;
     int causal;
-    int tune;
     AttnExtra x;
 #ifdef AT_PROF
     long long* prof;
@@ -201,40 +199,17 @@ __device__ __forceinline__ int first_valid_key(const int32_t* __restrict__ kv, i
 // next lighter ones, ...): with 2 resident blocks per CU an alternating heavy/light order left some CUs with three
 // heavy blocks out of four (measured 91 us causal vs 97 us non-causal; balanced would be 73).
 // Grid = ceil(BH/8)*8*nblk; returns false for padding blocks.
-__device__ __forceinline__ bool map_block(int id, int BH, int nblk, bool heavy_is_high, int& bh, int& blk, int tune = 0) {
+__device__ __forceinline__ bool map_block(int id, int BH, int nblk, bool heavy_is_high, int& bh, int& blk) {
     const int x = id & 7, r = id >> 3;
     const int nbx = (BH + 7) >> 3;
-    int j, i;
-    if (nblk == 2 && (tune & 4)) {
-        // Two weight levels (T <= 256 under a causal mask).  Heaviest-first starts every resident slot with a heavy block:
-        // all of them load their first tiles at once (an HBM burst with idle matrix pipes), finish together, and the
-        // light generation repeats the burst -- the profile showed ~30 % of the kernel in prologues and epilogues.
-        // Order per XCD: [H L H L ...] for the first half of each kind, then the other heavies, then the other lights:
-        // a slot runs light->heavy or heavy->light (same total), so later prologues / epilogues run under somebody
-        // else's MFMA phase.
-        const int A = nbx >> 1;
-        if (r < 2 * A) { j = r & 1; i = r >> 1; }
-        else if (r < 2 * A + (nbx - A)) { j = 0; i = A + (r - 2 * A); }
-        else { j = 1; i = A + (r - 2 * A - (nbx - A)); }
-    } else {
-        j = r / nbx;
-        i = r - j * nbx;
-    }
-    bh = i * 8 + x;
+    const int j = r / nbx;
+    bh = (r - j * nbx) * 8 + x;
     blk = heavy_is_high ? nblk - 1 - j : j;
     return bh < BH;
 }
-// Which of the block's four 32-row groups does this wave take?  Under a causal mask group g of a block does g-dependent
-// work (group 3 of a query block sees the most keys, group 0 of a key block the most queries) and wave w of EVERY block
-// lands on SIMD w, so with the identity map SIMD 3 (0) carries 6 (12) tile-units per (batch, head) and SIMD 0 (3) only
-// 4 (6): the matrix pipes could never be more than 75-83 % busy.  Every other block (by the two placements the
-// dispatcher is likely to use for the co-resident pair: consecutive ids, or ids one CU-round apart) mirrors the map, so
-// a SIMD's two resident waves carry complementary groups.
-enum { AT_TUNE_FLIP = 1, AT_TUNE_HALF = 2, AT_TUNE_MIX = 4 };
-__device__ __forceinline__ int wave_group(int wave, int tune) {
-    const int r = blockIdx.x >> 3;
-    return ((tune & AT_TUNE_FLIP) && ((r ^ (r >> 5)) & 1)) ? 3 - wave : wave;
-}
+// (Round 2, measured and dropped: a mirrored wave -> row-group map in every other block, so that a SIMD's two resident waves
+//  carry complementary causal work: +-0; starting every slot with one heavy and one light block so that later prologues run
+//  under somebody else's MFMA phase: 80 -> 84 us.  See DESIGN.md 5.8.)
 __host__ inline unsigned mapped_grid(int64_t BH, int64_t nblk) { return (unsigned)(ceil_div(BH, 8) * 8 * nblk); }
 
 // ---- MFMA phases -------------------------------------------------------------------------------------------------
@@ -425,10 +400,10 @@ __global__ __launch_bounds__(256, DH <= 64 ? 2 : 1) void attn_fwd_kernel(const A
     const int l31 = lane & 31, lh = lane >> 5;
     const int qblocks = (p.Tq + AT_BQ - 1) / AT_BQ;
     int bh, qb;
-    if (!map_block(blockIdx.x, p.B * p.H, qblocks, true, bh, qb, p.tune)) return;
+    if (!map_block(blockIdx.x, p.B * p.H, qblocks, true, bh, qb)) return;
     AT_PROF_DECL;
     const int b = bh / p.H, h = bh - b * p.H;
-    const int q0 = qb * AT_BQ + wave_group(wave, p.tune) * 32;   // this wave's first query
+    const int q0 = qb * AT_BQ + wave * 32;   // this wave's first query
     const int q = q0 + l31;                           // this lane's query
     const float* Qb = p.Q + ((int64_t)b * p.Tq) * p.LQ + (int64_t)h * DH;
     const float* Kb = p.K + ((int64_t)b * p.Tk) * p.LQ + (int64_t)h * DH;
@@ -510,7 +485,7 @@ __global__ __launch_bounds__(256, DH <= 64 ? 2 : 1) void attn_fwd_kernel(const A
         }
         // wave-uniform: the tile's upper 32 keys are above the diagonal for every query of the wave (all of which see a
         // real key): their probabilities are exactly 0, so that half's S, softmax and PV work is dropped
-        const bool half = (p.tune & AT_TUNE_HALF) && skip_ok && kv0 + 32 > q0 + 31 + shift;
+        const bool half = skip_ok && kv0 + 32 > q0 + 31 + shift;
         if (!skip) {
             // ---- S^T = K Q^T (2 key sub-tiles of 32) -------------------------------------------------------
             f32x16 s[2];
@@ -621,9 +596,9 @@ __global__ __launch_bounds__(256, DH <= 64 ? 2 : 1) void attn_bwd_dkdv_kernel(co
     const int l31 = lane & 31, lh = lane >> 5;
     const int kblocks = (p.Tk + 127) / 128;
     int bh, kb;
-    if (!map_block(blockIdx.x, p.B * p.H, kblocks, false, bh, kb, p.tune)) return;
+    if (!map_block(blockIdx.x, p.B * p.H, kblocks, false, bh, kb)) return;
     const int b = bh / p.H, h = bh - b * p.H;
-    const int k0w = kb * 128 + wave_group(wave, p.tune) * 32;
+    const int k0w = kb * 128 + wave * 32;
     const int key = k0w + l31;                                  // this lane's key
     const float* Qb = p.Q + ((int64_t)b * p.Tq) * p.LQ + (int64_t)h * DH;
     const float* dOb = p.dO + ((int64_t)b * p.Tq) * p.D + (int64_t)h * DH;
@@ -801,9 +776,9 @@ __global__ __launch_bounds__(256, DH <= 64 ? 2 : 1) void attn_bwd_dq_kernel(cons
     const int l31 = lane & 31, lh = lane >> 5;
     const int qblocks = (p.Tq + AT_BQ - 1) / AT_BQ;
     int bh, qb;
-    if (!map_block(blockIdx.x, p.B * p.H, qblocks, true, bh, qb, p.tune)) return;
+    if (!map_block(blockIdx.x, p.B * p.H, qblocks, true, bh, qb)) return;
     const int b = bh / p.H, h = bh - b * p.H;
-    const int q0 = qb * AT_BQ + wave_group(wave, p.tune) * 32;
+    const int q0 = qb * AT_BQ + wave * 32;
     const int q = q0 + l31;
     const float* Qb = p.Q + ((int64_t)b * p.Tq) * p.LQ + (int64_t)h * DH;
     const float* dOb = p.dO + ((int64_t)b * p.Tq) * p.D + (int64_t)h * DH;
@@ -891,7 +866,7 @@ __global__ __launch_bounds__(256, DH <= 64 ? 2 : 1) void attn_bwd_dq_kernel(cons
         if (!skip) {
             const int lim_causal = p.causal ? q + shift - kv0 - 4 * lh : 1 << 30;
             const int lim_range = q_in ? p.Tk - 1 - kv0 - 4 * lh : -1;
-            const bool half = (p.tune & AT_TUNE_HALF) && skip_ok && kv0 + 32 > q0 + 31 + shift;   // upper 32 keys: P = 0 for the whole wave
+            const bool half = skip_ok && kv0 + 32 > q0 + 31 + shift;   // upper 32 keys: P = 0 for the whole wave
             const bool plain = !(GEN && dense) && vball == ~0ull && kv0 + AT_BK <= p.Tk && q0 + 32 <= p.Tq &&
                                (!p.causal || kv0 + AT_BK - 1 <= q0 + shift);
 #pragma unroll
@@ -1022,15 +997,6 @@ extern "C" void nnhipAttentionSetProfile(long long* buf) { g_prof = buf; }
 #else
 #define AT_SET_PROF(p) do {} while (0)
 #endif
-// NNHIP_ATTN_TUNE: bit 0 = mirrored wave -> row-group map (default on); developer A/B switch
-static int attn_tune() {
-    static int t = -1;
-    if (t < 0) {
-        const char* e = getenv("NNHIP_ATTN_TUNE");
-        t = e ? atoi(e) : (AT_TUNE_FLIP | AT_TUNE_HALF | AT_TUNE_MIX);
-    }
-    return t;
-}
 static bool extra_active(const AttnExtra& x) { return x.mask_bits || x.drop_mask || x.drop_threshold != 0u; }
 
 #define AT_DISPATCH(KERNEL, dh, gen, grid, st, p)                                                                      \
@@ -1051,7 +1017,7 @@ extern "C" int nnhipAttentionForwardEx(const float* Q, const float* K, const flo
     AttnParams p;
     if (int rc = fill_extra("nnhipAttentionForward", p.x, opts, key_valid, causal)) return rc;
     p.Q = Q; p.K = K; p.V = V; p.O = O; p.LSE = LSE; p.key_valid = key_valid;
-    p.B = (int)B; p.H = (int)H; p.Tq = (int)Tq; p.Tk = (int)Tk; p.D = H * head_dim; p.LQ = ld_qkv ? ld_qkv : p.D; p.scale = scale; p.causal = causal; p.tune = attn_tune(); AT_SET_PROF(p);
+    p.B = (int)B; p.H = (int)H; p.Tq = (int)Tq; p.Tk = (int)Tk; p.D = H * head_dim; p.LQ = ld_qkv ? ld_qkv : p.D; p.scale = scale; p.causal = causal; AT_SET_PROF(p);
     const int64_t qblocks = ceil_div(Tq, AT_BQ);
     const bool gen = extra_active(p.x);
     AT_DISPATCH(attn_fwd_kernel, head_dim, gen, dim3(mapped_grid(B * H, qblocks)), (hipStream_t)s, p);
@@ -1082,7 +1048,7 @@ extern "C" int nnhipAttentionBackwardEx(const float* Q, const float* K, const fl
     if (int rc = fill_extra("nnhipAttentionBackward", p.x, opts, key_valid, causal)) return rc;
     p.Q = Q; p.K = K; p.V = V; p.dO = dO; p.LSE = LSE; p.Dsum = dsum; p.O = O; p.dQ = dQ; p.dK = dK; p.dV = dV;
     p.key_valid = key_valid; p.B = (int)B; p.H = (int)H; p.Tq = (int)Tq; p.Tk = (int)Tk; p.D = H * head_dim;
-    p.LQ = ld_qkv ? ld_qkv : p.D; p.scale = scale; p.causal = causal; p.tune = attn_tune(); AT_SET_PROF(p);
+    p.LQ = ld_qkv ? ld_qkv : p.D; p.scale = scale; p.causal = causal; AT_SET_PROF(p);
     const bool gen = extra_active(p.x);
     // dQ first: it also produces Dsum, which the dK/dV kernel consumes
     AT_DISPATCH(attn_bwd_dq_kernel, head_dim, gen, dim3(mapped_grid(B * H, ceil_div(Tq, AT_BQ))), st, p);

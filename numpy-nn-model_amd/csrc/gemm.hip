@@ -243,6 +243,9 @@ __global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const 
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, lh = lane >> 5;
     // ---- block id -> (split, tile_m, tile_n): XCD-aware grouped order --------------------------
+    // (A persistent variant -- one block per resident slot walking tiles b, b + grid, ... so that a tile's stores drain under
+    //  the same waves' next tile -- was measured in round 2 on top of the buffer-load fetch: no gain on any shape, and the
+    //  outer loop cost the (k-major, outer-major) variant 7 % through register allocation.  One block per tile it stays.)
     const int nwg = gridDim.x;
     int L;
     {
@@ -489,8 +492,7 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
     if (small_on && gemm_small_wanted(M, N, K, batch))
         return gemm_small(A, B, C, bias, preact, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, alpha, act, beta, asum, addend,
                           dswish, dact, st);
-    static const int bk_sel = []() { const char* e = getenv("NNHIP_GEMM_BK"); return e ? atoi(e) : 32; }();
-    const int BK = (bk_sel == 16) ? 16 : 32;
+    constexpr int BK = 32;     // (a BK = 16 / 3-blocks-per-CU variant was measured in rounds 1 and 2: never ahead; dropped)
     GemmParams p;
     p.A = A; p.B = B; p.C = C; p.bias = bias; p.preact = preact;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
@@ -554,16 +556,11 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
     if (gemm_mode() == 1) {
         rc = gemm_bf3_launch(p, a_kmajor, b_kmajor, vec_any, asum != nullptr, batch, st);
     } else {
-#define NNHIP_GEMM_CASE(AK, BKM)                                                                   \
-    rc = (BK == 16) ? (vec ? launch_variant<16, AK, BKM, true>(p, batch, st)                      \
-                           : launch_variant<16, AK, BKM, false>(p, batch, st))                    \
-                    : (vec ? launch_variant<32, AK, BKM, true>(p, batch, st)                      \
-                           : launch_variant<32, AK, BKM, false>(p, batch, st))
+#define NNHIP_GEMM_CASE(AK, BKM) \
+    rc = vec ? launch_variant<32, AK, BKM, true>(p, batch, st) : launch_variant<32, AK, BKM, false>(p, batch, st)
     if (asum) {
-        rc = (BK == 16) ? (b_kmajor ? (vec ? launch_variant<16, false, true, true, true>(p, batch, st) : launch_variant<16, false, true, false, true>(p, batch, st))
-                                    : (vec ? launch_variant<16, false, false, true, true>(p, batch, st) : launch_variant<16, false, false, false, true>(p, batch, st)))
-                        : (b_kmajor ? (vec ? launch_variant<32, false, true, true, true>(p, batch, st) : launch_variant<32, false, true, false, true>(p, batch, st))
-                                    : (vec ? launch_variant<32, false, false, true, true>(p, batch, st) : launch_variant<32, false, false, false, true>(p, batch, st)));
+        rc = b_kmajor ? (vec ? launch_variant<32, false, true, true, true>(p, batch, st) : launch_variant<32, false, true, false, true>(p, batch, st))
+                      : (vec ? launch_variant<32, false, false, true, true>(p, batch, st) : launch_variant<32, false, false, false, true>(p, batch, st));
     } else
     if (a_kmajor && b_kmajor) { NNHIP_GEMM_CASE(true, true); }
     else if (a_kmajor && !b_kmajor) { NNHIP_GEMM_CASE(true, false); }

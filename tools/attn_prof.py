@@ -87,7 +87,7 @@ def main():
     ids = np.arange(nblk)
     r = ids >> 3
     j = r // nbx                               # 0 = heaviest
-    tune = int(os.environ.get("NNHIP_ATTN_TUNE", "7"))
+    tune = 0
     if nb == 2 and (tune & 4):                 # map_block's mixed order
         A = nbx >> 1
         j = np.where(r < 2 * A, r & 1, np.where(r < 2 * A + (nbx - A), 0, 1))
