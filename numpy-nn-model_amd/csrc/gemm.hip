@@ -554,7 +554,8 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
 
     int rc;
     if (gemm_mode() == 1) {
-        rc = gemm_bf3_launch(p, a_kmajor, b_kmajor, vec_any, asum != nullptr, batch, st);
+        rc = gemm_bf3_launch(p, a_kmajor, b_kmajor, vec_any && (K & 7) == 0 && K >= 16 && span_ok(lda, a_kmajor) && span_ok(ldb, b_kmajor),
+                             asum != nullptr, batch, st);
     } else {
 #define NNHIP_GEMM_CASE(AK, BKM) \
     rc = vec ? launch_variant<32, AK, BKM, true>(p, batch, st) : launch_variant<32, AK, BKM, false>(p, batch, st)

@@ -72,6 +72,53 @@ __device__ __forceinline__ void b3_fetch(StageRegs& r, const float* __restrict__
     }
 }
 
+// ---- fast operand fetch (vectorised variants; see gemm_common.h "fast operand fetch") -----------------------------------------
+// Loads go through a buffer descriptor (the operand's rows of this block at k = 0) + a scalar k offset + per-thread byte
+// offsets computed once, rows clamped instead of zero-filled.  A partial last k-tile (K % 16 == 8) is fetched as the last
+// 16 columns of the k range and the half that repeats the previous tile is zeroed on its way into LDS (`zero_lo`).
+struct B3Offs { unsigned o[2]; };
+template <bool KC>
+__device__ __forceinline__ void b3_offsets(B3Offs& t, int64_t ld, int64_t R, int64_t r0, int tid) {
+    if constexpr (KC) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int idx = tid + NT * p;
+            const int64_t rc = min((int64_t)(idx >> 2), R - 1 - r0);
+            t.o[p] = (unsigned)((rc * ld + (idx & 3) * 4) * 4);
+        }
+    } else {
+        const int64_t rc = min((int64_t)(tid & 127), R - 1 - r0);
+        t.o[0] = (unsigned)(((int64_t)(8 * (tid >> 7)) * ld + rc) * 4);
+        t.o[1] = 0u;
+    }
+}
+// koff = byte offset of the tile's first k (4k for a k-major operand, 4k*ld for an outer-major one); ldb4 = 4*ld
+template <bool KC>
+__device__ __forceinline__ void b3_fetch_fast(StageRegs& r, __amdgpu_buffer_rsrc_t rs, unsigned koff, unsigned ldb4, const B3Offs& t) {
+    if constexpr (KC) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const u32x4_ v = __builtin_amdgcn_raw_buffer_load_b128(rs, t.o[p], koff, 0);
+            r.v[p].x = __uint_as_float(v.x); r.v[p].y = __uint_as_float(v.y); r.v[p].z = __uint_as_float(v.z); r.v[p].w = __uint_as_float(v.w);
+        }
+    } else {
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, t.o[0], koff + (unsigned)j * ldb4, 0));
+        r.v[0].x = f[0]; r.v[0].y = f[1]; r.v[0].z = f[2]; r.v[0].w = f[3];
+        r.v[1].x = f[4]; r.v[1].y = f[5]; r.v[1].z = f[6]; r.v[1].w = f[7];
+    }
+}
+// zero the k-half [0, 8) of a staged tile (the shifted partial last tile repeats it from the tile before)
+template <bool KC>
+__device__ __forceinline__ void b3_zero_lo(StageRegs& r, int tid) {
+    if constexpr (KC) {
+        if ((tid & 3) < 2) { r.v[0] = make_float4(0.f, 0.f, 0.f, 0.f); r.v[1] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    } else {
+        if ((tid >> 7) == 0) { r.v[0] = make_float4(0.f, 0.f, 0.f, 0.f); r.v[1] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    }
+}
+
 template <bool KC>
 __device__ __forceinline__ void b3_commit(const StageRegs& r, unsigned char* __restrict__ S, int tid) {
     if constexpr (KC) {
@@ -153,29 +200,64 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf3_kernel(const GemmParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int nk = (int)((kend - kbeg + B3_BK - 1) / B3_BK);
     // Two register sets per operand: tile kt+2 is fetched while tile kt is multiplied and tile kt+1 (fetched one
     // iteration earlier) is split and committed to the other LDS stage -- a global load gets a whole iteration to land.
     StageRegs ra0, rb0, ra1, rb1;
     float rowsum = 0.f;
     auto rsum = [](const StageRegs& r) { return (r.v[0].x + r.v[0].y) + (r.v[0].z + r.v[0].w) + (r.v[1].x + r.v[1].y) + (r.v[1].z + r.v[1].w); };
-    b3_fetch<AKC, VEC>(ra0, A, p.lda, p.M, kend, m0, kbeg, tid, nk > 0, Z);
-    b3_fetch<BKC, VEC>(rb0, B, p.ldb, p.N, kend, n0, kbeg, tid, nk > 0, Z);
-    b3_fetch<AKC, VEC>(ra1, A, p.lda, p.M, kend, m0, kbeg + B3_BK, tid, nk > 1, Z);
-    b3_fetch<BKC, VEC>(rb1, B, p.ldb, p.N, kend, n0, kbeg + B3_BK, tid, nk > 1, Z);
-    if constexpr (CS) rowsum += rsum(ra0);
-    b3_commit<AKC>(ra0, smem_b, tid);
-    b3_commit<BKC>(rb0, smem_b + B3_OPERAND, tid);
+    const int64_t klen = kend - kbeg;
+    int nk;
+    // VEC: tiles 0 .. nfull-1 are whole; tile nfull (if any) is the shifted partial tile.  Host guarantees K % 8 == 0, K >= 16.
+    const int nfull = (int)(klen / B3_BK);
+    const bool has_tail = VEC && (klen - (int64_t)nfull * B3_BK) != 0;
+    [[maybe_unused]] B3Offs offa, offb;
+    [[maybe_unused]] __amdgpu_buffer_rsrc_t rsa, rsb;
+    [[maybe_unused]] unsigned ua = 0, ub = 0, la4 = 0, lb4 = 0;
+    if constexpr (VEC) {
+        nk = nfull + (has_tail ? 1 : 0);
+        b3_offsets<AKC>(offa, p.lda, p.M, m0, tid);
+        b3_offsets<BKC>(offb, p.ldb, p.N, n0, tid);
+        rsa = operand_rsrc(AKC ? A + m0 * p.lda : A + m0);
+        rsb = operand_rsrc(BKC ? B + n0 * p.ldb : B + n0);
+        la4 = (unsigned)(4 * p.lda); lb4 = (unsigned)(4 * p.ldb);
+        ua = AKC ? 4u : la4; ub = BKC ? 4u : lb4;
+    } else {
+        nk = (int)((klen + B3_BK - 1) / B3_BK);
+    }
+    // first k of tile t (VEC): whole tiles in order, then the shifted partial tile; past the end: any valid tile (never used)
+    auto tile_k = [&](int t) -> unsigned { return (unsigned)(t < nfull ? kbeg + (int64_t)t * B3_BK : (has_tail ? kend - B3_BK : kbeg)); };
+    auto fetch = [&](StageRegs& fa, StageRegs& fb, int t) {
+        if constexpr (VEC) {
+            const unsigned k = tile_k(t);
+            b3_fetch_fast<AKC>(fa, rsa, k * ua, la4, offa);
+            b3_fetch_fast<BKC>(fb, rsb, k * ub, lb4, offb);
+        } else {
+            const int64_t k = kbeg + (int64_t)t * B3_BK;
+            b3_fetch<AKC, VEC>(fa, A, p.lda, p.M, kend, m0, k, tid, t < nk, Z);
+            b3_fetch<BKC, VEC>(fb, B, p.ldb, p.N, kend, n0, k, tid, t < nk, Z);
+        }
+    };
+    // tile t goes from registers to LDS stage S: zero the repeated half of the shifted partial tile, add the row sums
+    auto commit = [&](StageRegs& ca, StageRegs& cb, int t, unsigned char* S) {
+        if constexpr (VEC) {
+            if (has_tail && t == nfull) { b3_zero_lo<AKC>(ca, tid); b3_zero_lo<BKC>(cb, tid); }
+            if constexpr (CS) { if (t < nk) rowsum += rsum(ca); }
+        } else {
+            if constexpr (CS) rowsum += rsum(ca);          // zeros past the end
+        }
+        b3_commit<AKC>(ca, S, tid);
+        b3_commit<BKC>(cb, S + B3_OPERAND, tid);
+    };
+    fetch(ra0, rb0, 0);
+    fetch(ra1, rb1, 1);
+    commit(ra0, rb0, 0, smem_b);
     __syncthreads();
 
     int cur = 0;
     // one k-tile: fetch tile kt+2 into (fa, fb) [free: its tile was committed an iteration ago], multiply tile kt out of
     // LDS stage `cur`, commit tile kt+1 from (ca, cb) into the other stage
-    auto step = [&](int kt, StageRegs& fa, StageRegs& fb, const StageRegs& ca, const StageRegs& cb) {
-        const bool more2 = kt + 2 < nk;
-        const int64_t k2 = kbeg + (int64_t)(kt + 2) * B3_BK;
-        b3_fetch<AKC, VEC>(fa, A, p.lda, p.M, kend, m0, k2, tid, more2, Z);
-        b3_fetch<BKC, VEC>(fb, B, p.ldb, p.N, kend, n0, k2, tid, more2, Z);
+    auto step = [&](int kt, StageRegs& fa, StageRegs& fb, StageRegs& ca, StageRegs& cb) {
+        fetch(fa, fb, kt + 2);
         const unsigned char* As = smem_b + cur * B3_STAGE;
         const unsigned char* Bs = As + B3_OPERAND;
         bf16x8 a[2][3], b[2][3];
@@ -197,10 +279,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf3_kernel(const GemmParams p) {
         B3_TERM(0, 1)
         B3_TERM(0, 0)
 #undef B3_TERM
-        if constexpr (CS) rowsum += rsum(ca);          // tile kt+1 (zeros past the end)
-        unsigned char* Sn = smem_b + (cur ^ 1) * B3_STAGE;
-        b3_commit<AKC>(ca, Sn, tid);
-        b3_commit<BKC>(cb, Sn + B3_OPERAND, tid);
+        commit(ca, cb, kt + 1, smem_b + (cur ^ 1) * B3_STAGE);
         __syncthreads();
         cur ^= 1;
     };
@@ -213,7 +292,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf3_kernel(const GemmParams p) {
 
     float* smem = reinterpret_cast<float*>(smem_b);
     if constexpr (CS) {
-        // thread (row = tid & 127, kh = tid >> 7) holds its half of the row sum (the last fetch of the loop added zeros)
+        // thread (row = tid & 127, kh = tid >> 7) holds its half of the row sum
         if (p.asum && tn == 0) {
             smem[tid] = rowsum;
             __syncthreads();
