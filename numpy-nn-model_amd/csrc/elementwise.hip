@@ -4,6 +4,8 @@
 // 1 ulp each, so x*sigmoid(x) stays within ~3 ulp of NumPy's float32 result (tests/test_hip_parity.py sweeps
 // [-88, 88]); the library expf + IEEE divide were ~30 VALU instructions per element and made the *simplest*
 // kernel of the C3 pass (Swish forward) slower than Softmax forward on the same 268 MB (round-1 VERDICT).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace nnhip {
@@ -21,9 +23,28 @@ inline int ew_blocks(int64_t n_items) {
 // (EW_U x 16 B in flight per lane) before any math, then EW_U stores.
 constexpr int EW_U = 4;
 
+typedef float ew_f4 __attribute__((ext_vector_type(4)));
+// Streaming accesses.  Non-temporal LOADS (bit 0, the default for tensors of >= 128 MB) read the inputs without allocating
+// in L2, which leaves L2 to the write-back of the previous kernel's output: cold C3 pass Swish forward 0.58-0.64 -> 0.74-0.78
+// of the HBM spec, backward 0.62 -> 0.69-0.77; back-to-back on hot buffers forward -4 %, backward +22 %.  Non-temporal
+// STORES (bit 1) win back-to-back (backward 6.8 TB/s) but lose cold (forward 0.58 -> 0.51) -- the consumer of an output is
+// usually the next kernel.  NNHIP_EW_NT overrides (developer switch).
+__device__ __forceinline__ float4 ew_load(const float4* p, int nt) {
+    if (nt & 1) { const ew_f4 t = __builtin_nontemporal_load(reinterpret_cast<const ew_f4*>(p)); return make_float4(t.x, t.y, t.z, t.w); }
+    return *p;
+}
+__device__ __forceinline__ void ew_store(float4* p, float4 v, int nt) {
+    if (nt & 2) { ew_f4 t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; __builtin_nontemporal_store(t, reinterpret_cast<ew_f4*>(p)); }
+    else *p = v;
+}
+static int ew_nt(int64_t n) {
+    static const int forced = []() { const char* e = getenv("NNHIP_EW_NT"); return e ? atoi(e) : -1; }();
+    if (forced >= 0) return forced;
+    return n * 4 >= ((int64_t)128 << 20) ? 1 : 0;
+}
 template <class F>
 __global__ __launch_bounds__(EW_THREADS) void map1_kernel(float* out, const float* a, int64_t n,
-                                                          bool vec, F f) {
+                                                          bool vec, F f, int nt) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
     if (vec) {
@@ -35,7 +56,7 @@ __global__ __launch_bounds__(EW_THREADS) void map1_kernel(float* out, const floa
 #pragma unroll
             for (int u = 0; u < EW_U; ++u) {
                 const int64_t i = base + u * EW_THREADS + threadIdx.x;
-                if (i < nv) x[u] = a4[i];
+                if (i < nv) x[u] = ew_load(a4 + i, nt);
             }
 #pragma unroll
             for (int u = 0; u < EW_U; ++u) {
@@ -43,7 +64,7 @@ __global__ __launch_bounds__(EW_THREADS) void map1_kernel(float* out, const floa
                 if (i < nv) {
                     float4 y;
                     y.x = f(x[u].x); y.y = f(x[u].y); y.z = f(x[u].z); y.w = f(x[u].w);
-                    o4[i] = y;
+                    ew_store(o4 + i, y, nt);
                 }
             }
         }
@@ -55,7 +76,7 @@ __global__ __launch_bounds__(EW_THREADS) void map1_kernel(float* out, const floa
 
 template <class F>
 __global__ __launch_bounds__(EW_THREADS) void map2_kernel(float* out, const float* a, const float* b, int64_t n,
-                                                          bool vec, F f) {
+                                                          bool vec, F f, int nt) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t gsz = (int64_t)gridDim.x * blockDim.x;
     if (vec) {
@@ -68,7 +89,7 @@ __global__ __launch_bounds__(EW_THREADS) void map2_kernel(float* out, const floa
 #pragma unroll
             for (int u = 0; u < EW_U; ++u) {
                 const int64_t i = base + u * EW_THREADS + threadIdx.x;
-                if (i < nv) { x[u] = a4[i]; z[u] = b4[i]; }
+                if (i < nv) { x[u] = ew_load(a4 + i, nt); z[u] = ew_load(b4 + i, nt); }
             }
 #pragma unroll
             for (int u = 0; u < EW_U; ++u) {
@@ -76,7 +97,7 @@ __global__ __launch_bounds__(EW_THREADS) void map2_kernel(float* out, const floa
                 if (i < nv) {
                     float4 y;
                     y.x = f(x[u].x, z[u].x); y.y = f(x[u].y, z[u].y); y.z = f(x[u].z, z[u].z); y.w = f(x[u].w, z[u].w);
-                    o4[i] = y;
+                    ew_store(o4 + i, y, nt);
                 }
             }
         }
@@ -115,7 +136,7 @@ static int launch_map1(float* out, const float* a, int64_t n, F f, hipStream_t s
     if (n == 0) return 0;
     const bool vec = aligned16(out) && aligned16(a);
     hipLaunchKernelGGL(map1_kernel<F>, dim3(ew_blocks(vec ? ceil_div(n >> 2, EW_U) : n)), dim3(EW_THREADS), 0, st,
-                       out, a, n, vec, f);
+                       out, a, n, vec, f, ew_nt(n));
     NNHIP_LAUNCH_CHECK(nm);
     return 0;
 }
@@ -125,7 +146,7 @@ static int launch_map2(float* out, const float* a, const float* b, int64_t n, F 
     if (n == 0) return 0;
     const bool vec = aligned16(out) && aligned16(a) && aligned16(b);
     hipLaunchKernelGGL(map2_kernel<F>, dim3(ew_blocks(vec ? ceil_div(n >> 2, EW_U) : n)), dim3(EW_THREADS), 0, st,
-                       out, a, b, n, vec, f);
+                       out, a, b, n, vec, f, ew_nt(n));
     NNHIP_LAUNCH_CHECK(nm);
     return 0;
 }

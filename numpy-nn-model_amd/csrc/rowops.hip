@@ -29,16 +29,38 @@ struct RowTile {
         if constexpr (VEC) return 4 * (int64_t)(t + TPR * (e >> 2)) + (e & 3);
         else return (int64_t)t + (int64_t)TPR * e;
     }
-    __device__ __forceinline__ void load(const float* __restrict__ row, int64_t cols, int t, float fill) {
+    // nt (wave-uniform): streaming (non-temporal) loads.  A tensor that cannot be cache-resident anyway is read without
+    // allocating in L2, which leaves L2 to the write-back of the previous kernel's output: the cold C3 pass gained 10-30 %
+    // per op (RMSNorm backward 0.59 -> 0.72 of the HBM spec, CE 0.46 -> 0.59, softmax backward 0.67 -> 0.80).  It LOSES on
+    // tensors the producer left in L2 / MALL (RMSNorm at 16384x512: -20 %) and on rows whose pitch is not a multiple of the
+    // 128-B line (CE at 16384x15000: the line two rows share is fetched twice, -14 %) -- row_streaming() decides.
+    __device__ __forceinline__ void load(const float* __restrict__ row, int64_t cols, int t, float fill, bool nt = false) {
         if constexpr (VEC) {
+            typedef float rt_f4 __attribute__((ext_vector_type(4)));
+            if (nt) {
+                // (a select between the two kinds of load is folded into ONE plain load: the hint is only metadata.  Two
+                //  copies of the loop under a wave-uniform branch, kept apart by an empty asm)
+                asm volatile("" ::: "memory");
 #pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                const int64_t c = 4 * (int64_t)(t + TPR * v);
-                if (c < cols) {
-                    const float4 q = *reinterpret_cast<const float4*>(row + c);
-                    x[4 * v] = q.x; x[4 * v + 1] = q.y; x[4 * v + 2] = q.z; x[4 * v + 3] = q.w;
-                } else {
-                    x[4 * v] = x[4 * v + 1] = x[4 * v + 2] = x[4 * v + 3] = fill;
+                for (int v = 0; v < NV; ++v) {
+                    const int64_t c = 4 * (int64_t)(t + TPR * v);
+                    if (c < cols) {
+                        const rt_f4 q = __builtin_nontemporal_load(reinterpret_cast<const rt_f4*>(row + c));
+                        x[4 * v] = q.x; x[4 * v + 1] = q.y; x[4 * v + 2] = q.z; x[4 * v + 3] = q.w;
+                    } else {
+                        x[4 * v] = x[4 * v + 1] = x[4 * v + 2] = x[4 * v + 3] = fill;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const int64_t c = 4 * (int64_t)(t + TPR * v);
+                    if (c < cols) {
+                        const rt_f4 q = *reinterpret_cast<const rt_f4*>(row + c);
+                        x[4 * v] = q.x; x[4 * v + 1] = q.y; x[4 * v + 2] = q.z; x[4 * v + 3] = q.w;
+                    } else {
+                        x[4 * v] = x[4 * v + 1] = x[4 * v + 2] = x[4 * v + 3] = fill;
+                    }
                 }
             }
         } else {
@@ -93,10 +115,10 @@ __device__ __forceinline__ float row_max(float v, float* red) {
 // =================================================================================================
 template <int TPR, int NV, bool VEC>
 __global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void softmax_fwd_rows(
-    float* __restrict__ out, const float* __restrict__ in, int64_t rows, int64_t cols) {
+    float* __restrict__ out, const float* __restrict__ in, int64_t rows, int64_t cols, int nt) {
     ROW_PROLOGUE(TPR)
     RowTile<TPR, NV, VEC> r;
-    r.load(in + row * cols, cols, t, -INFINITY);
+    r.load(in + row * cols, cols, t, -INFINITY, nt);
     float m = r.x[0];
 #pragma unroll
     for (int e = 1; e < r.NE; ++e) m = fmaxf(m, r.x[e]);
@@ -117,11 +139,11 @@ __global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void softmax_fwd_rows(
 template <int TPR, int NV, bool VEC>
 __global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void softmax_bwd_rows(
     float* __restrict__ dx, const float* __restrict__ dy, const float* __restrict__ y, int64_t rows,
-    int64_t cols) {
+    int64_t cols, int nt) {
     ROW_PROLOGUE(TPR)
     RowTile<TPR, NV, VEC> g, f;
-    g.load(dy + row * cols, cols, t, 0.f);
-    f.load(y + row * cols, cols, t, 0.f);
+    g.load(dy + row * cols, cols, t, 0.f, nt);
+    f.load(y + row * cols, cols, t, 0.f, nt);
     float s = 0.f;
 #pragma unroll
     for (int e = 0; e < g.NE; ++e) s += g.x[e] * f.x[e];
@@ -260,10 +282,10 @@ template <int TPR, int NV, bool VEC>
 __global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void rmsnorm_fwd_rows(
     const float* __restrict__ X, const float* __restrict__ w, const float* __restrict__ b,
     float* __restrict__ Y, float* __restrict__ Xstd, float* __restrict__ Xnorm, int64_t rows,
-    int64_t cols, float eps) {
+    int64_t cols, float eps, int nt) {
     ROW_PROLOGUE(TPR)
     RowTile<TPR, NV, VEC> r, wt;
-    r.load(X + row * cols, cols, t, 0.f);
+    r.load(X + row * cols, cols, t, 0.f, nt);
     wt.load(w, cols, t, 0.f);
     float ss = 0.f;
 #pragma unroll
@@ -400,7 +422,7 @@ template <int TPR, int NV, bool VEC>
 __global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void rmsnorm_bwd_rows(
     const float* __restrict__ dY, const float* __restrict__ X, const float* __restrict__ w,
     const float* __restrict__ Xstd, float* __restrict__ dX, float* __restrict__ part_dw, float* __restrict__ part_db,
-    int64_t rows, int64_t cols, const float* __restrict__ dXadd) {
+    int64_t rows, int64_t cols, const float* __restrict__ dXadd, int nt) {
     constexpr int RPB = (TPR >= 256) ? 1 : 256 / TPR;
     constexpr int NW = TPR / 64;
     __shared__ float red[32];
@@ -423,20 +445,20 @@ __global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void rmsnorm_bwd_rows(
     const int64_t first = (int64_t)blockIdx.x * RPB + rslot;
     if constexpr (PRE) {
         if (first < rows) {
-            x0.load(X + first * cols, cols, t, 0.f);
-            g0.load(dY + first * cols, cols, t, 0.f);
+            x0.load(X + first * cols, cols, t, 0.f, nt);
+            g0.load(dY + first * cols, cols, t, 0.f, nt);
         }
     }
     for (int64_t r0 = first; r0 < rows; r0 += step) {
         if constexpr (PRE) {
             const int64_t n0 = r0 + step;
             if (n0 < rows) {
-                nx.load(X + n0 * cols, cols, t, 0.f);
-                ng.load(dY + n0 * cols, cols, t, 0.f);
+                nx.load(X + n0 * cols, cols, t, 0.f, nt);
+                ng.load(dY + n0 * cols, cols, t, 0.f, nt);
             }
         } else {
-            x0.load(X + r0 * cols, cols, t, 0.f);
-            g0.load(dY + r0 * cols, cols, t, 0.f);
+            x0.load(X + r0 * cols, cols, t, 0.f, nt);
+            g0.load(dY + r0 * cols, cols, t, 0.f, nt);
         }
         const float sd0 = Xstd[r0];
         const float i0 = 1.0f / sd0;
@@ -595,6 +617,7 @@ struct CeArgs {
     int lbytes;                 // 2 / 4 / 8
     int mode;                   // 0 none, 1 mean, 2 sum
     int count_in_kernel;        // 1: every block derives the 'mean' denominator from the labels
+    int nt;                     // 1: streaming loads of the logits (row_streaming())
 };
 
 __device__ __forceinline__ int64_t load_label(const void* labels, int64_t i, int lbytes) {
@@ -742,7 +765,7 @@ __global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void ce_rows_kernel(const
     // rows (cold HBM: 4 resident blocks per CU x one 16 KB row is not enough to cover ~2 us of latency).
     constexpr bool PRE = NV <= 4;
     RowTile<TPR, NV, VEC> r, rn;
-    if (row0 < a.rows) r.load(a.logits + row0 * a.ld, a.cols, t, -INFINITY);
+    if (row0 < a.rows) r.load(a.logits + row0 * a.ld, a.cols, t, -INFINITY, a.nt != 0);
     float scale, denom;
     ce_prologue<BS>(a, red, ired, scale, denom);
     float lsum = 0.f;                                         // meaningful on t == 0 of each row slot
@@ -753,9 +776,9 @@ __global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void ce_rows_kernel(const
         // read the label logit before anything is overwritten (in-place mode)
         const float xl = valid ? a.logits[row * a.ld + label] : 0.f;
         if constexpr (PRE) {
-            if (row + step < a.rows) rn.load(a.logits + (row + step) * a.ld, a.cols, t, -INFINITY);
+            if (row + step < a.rows) rn.load(a.logits + (row + step) * a.ld, a.cols, t, -INFINITY, a.nt != 0);
         } else {
-            if (row != row0) r.load(a.logits + row * a.ld, a.cols, t, -INFINITY);
+            if (row != row0) r.load(a.logits + row * a.ld, a.cols, t, -INFINITY, a.nt != 0);
         }
         float m = r.x[0];
 #pragma unroll
@@ -1071,6 +1094,15 @@ __global__ __launch_bounds__(1024) void softmax_masked_bwd_looped(float* dx, con
     }
 }
 
+// Streaming loads for a [rows, cols] operand with row pitch ld?  Only when the tensor cannot be cache-resident anyway
+// (>= 128 MB: the producer's output is long gone from the 32 MB of L2 and mostly from the 256 MB MALL) and its rows are
+// whole 128-B lines (see RowTile::load).  NNHIP_ROW_NT=0/1 forces it off/on (developer switch).
+static int row_streaming(int64_t rows, int64_t cols, int64_t ld) {
+    static const int forced = []() { const char* e = getenv("NNHIP_ROW_NT"); return e ? atoi(e) : -1; }();
+    if (forced >= 0) return forced;
+    return (rows * cols * 4 >= ((int64_t)128 << 20) && ((ld * 4) & 127) == 0) ? 1 : 0;
+}
+
 // Row-kernel dispatch: pick (TPR, NV) from the row width.
 #define ROW_DISPATCH(KERNEL, cols, vec, rows, st, ...)                                              \
     do {                                                                                            \
@@ -1169,7 +1201,7 @@ extern "C" int nnhipSoftmaxForward(float* out, const float* in, int64_t num_slic
         hipLaunchKernelGGL(softmax_fwd_looped, dim3((unsigned)num_slices), dim3(256), 0, st, out, in, slice_size);
     } else {
         const bool vec = aligned16(out) && aligned16(in) && slice_size % 4 == 0;
-        ROW_DISPATCH(softmax_fwd_rows, slice_size, vec, num_slices, st, out, in, num_slices, slice_size);
+        ROW_DISPATCH(softmax_fwd_rows, slice_size, vec, num_slices, st, out, in, num_slices, slice_size, row_streaming(num_slices, slice_size, slice_size));
     }
     NNHIP_LAUNCH_CHECK("softmax_forward");
     return 0;
@@ -1189,7 +1221,7 @@ extern "C" int nnhipSoftmaxBackward(float* dX, const float* dY, const float* Y, 
         hipLaunchKernelGGL(softmax_bwd_looped, dim3((unsigned)num_slices), dim3(256), 0, st, dX, dY, Y, slice_size);
     } else {
         const bool vec = aligned16(dX) && aligned16(dY) && aligned16(Y) && slice_size % 4 == 0;
-        ROW_DISPATCH(softmax_bwd_rows, slice_size, vec, num_slices, st, dX, dY, Y, num_slices, slice_size);
+        ROW_DISPATCH(softmax_bwd_rows, slice_size, vec, num_slices, st, dX, dY, Y, num_slices, slice_size, row_streaming(num_slices, slice_size, slice_size));
     }
     NNHIP_LAUNCH_CHECK("softmax_backward");
     return 0;
@@ -1208,7 +1240,7 @@ extern "C" int nnhipRMSNormForward(const float* X, const float* weight, const fl
     } else {
         const bool vec = aligned16(X) && aligned16(Y) && aligned16(weight) && (!bias || aligned16(bias)) &&
                          (!X_norm || aligned16(X_norm)) && cols % 4 == 0;
-        ROW_DISPATCH(rmsnorm_fwd_rows, cols, vec, rows, st, X, weight, bias, Y, X_std, X_norm, rows, cols, eps);
+        ROW_DISPATCH(rmsnorm_fwd_rows, cols, vec, rows, st, X, weight, bias, Y, X_std, X_norm, rows, cols, eps, row_streaming(rows, cols, cols));
     }
     NNHIP_LAUNCH_CHECK("rmsnorm_forward");
     return 0;
@@ -1275,7 +1307,7 @@ extern "C" int nnhipRMSNormBackwardEx(const float* dY, const float* X, const flo
     NNHIP_CHECK_ARG(part != nullptr, NNHIP_ENOMEM, "nnhipRMSNormBackward: workspace allocation failed");
     float* part_dw = part;
     float* part_db = db ? part + part_floats : nullptr;
-    ROW_DISPATCH_GRID(rmsnorm_bwd_rows, cols, vec, nblk, st, dY, X, weight, X_std, dX, part_dw, part_db, rows, cols, dX_addend);
+    ROW_DISPATCH_GRID(rmsnorm_bwd_rows, cols, vec, nblk, st, dY, X, weight, X_std, dX, part_dw, part_db, rows, cols, dX_addend, row_streaming(rows, cols, cols));
     NNHIP_LAUNCH_CHECK("rmsnorm_backward");
     return colsum_tall(part_dw, dW, part_db, db, nblk, cols, vec, st);
 }
@@ -1287,6 +1319,7 @@ static int ce_launch(CeArgs a, hipStream_t st) {
     unsigned* sync = sync_words();
     if (!sync) { set_last_error("cross entropy: sync words allocation failed"); return NNHIP_ENOMEM; }
     a.sync = sync + SYNC_CE;
+    a.nt = row_streaming(a.rows, a.cols, a.ld);
     float* denom_scratch = reinterpret_cast<float*>(sync + SYNC_CE + 4);
     const bool need_denom = a.mode == 1 && !a.count_dev && a.scale_host < 0.f;   // scale_host < 0: "derive it from the labels"
     if (a.rows * a.cols <= 65536 && a.cols <= 4096) {
