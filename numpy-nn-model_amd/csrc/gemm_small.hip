@@ -139,7 +139,9 @@ bool gemm_small_wanted(int64_t M, int64_t N, int64_t K, int64_t batch) {
     if (batch != 1 || M <= 0 || N <= 0 || K > 2048) return false;
     const int64_t tiles128 = ceil_div(M, 128) * ceil_div(N, 128);
     const int64_t tiles32 = ceil_div(M, 32) * ceil_div(N, 32);
-    return tiles128 <= 8 && tiles32 <= 256;
+    // a very short reduction (the conv classifier's 256x10 -> 784 input gradient) is all launch + epilogue: 32x32 blocks
+    // cover it faster than the 128x128 scalar-load kernel even when there are a few hundred of them
+    return (tiles128 <= 8 && tiles32 <= 256) || (K <= 64 && tiles32 <= 512);
 }
 
 int gemm_small(const float* A, const float* B, float* C, const float* bias, float* preact, int64_t M, int64_t N, int64_t K,

@@ -209,6 +209,118 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(float* __restrict__ d
     dx[i] = wc * g[i] * iv + dstd * 2.0f * xc * invN + sums[4 * c + 1] * iv * (-1.0f) * invN;
 }
 
+// ---- one launch per direction when a channel fits the registers of one block ------------------------------------------
+// A 1024-thread block holds up to NE = 16 elements per thread: ceil(B/16) * ceil(HW/64) <= 16 (the conv classifier's
+// 256 x 16 x 7 x 7 is exactly 16 x 1).  Same element -> thread map and the same reduction order as bn_stats_kernel /
+// bn_bwd_stats_kernel, so the statistics are bit-identical to the two-launch path; the point is the launch it saves
+// (C5 is bound by its ~30 graph nodes, not by bytes).
+constexpr int BN_NE = 16;
+// element e of this thread: image wave + 16 (e / nh), position lane + 64 (e % nh); off[e] = its offset from the channel's
+// first element, or -1.  Computed once (the runtime division by nh is not something to repeat in three loops: the first
+// version of the backward kernel spilled 1.4 KB per lane and took 316 us).
+// loads through a buffer descriptor (channel base in SGPRs + a 32-bit offset per element): 32 plain global loads in flight
+// would hold 32 64-bit address pairs -- that alone spilled the backward kernel
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t bn_rsrc(const float* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0xFFFFFFFF, 0x00020000);
+}
+__device__ __forceinline__ float bn_ld(__amdgpu_buffer_rsrc_t rs, int off) {     // off < 0: no element -> 0
+    const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (off >= 0 ? off : 0) * 4, 0, 0));
+    return off >= 0 ? v : 0.f;
+}
+__device__ __forceinline__ void bn_offsets(int (&off)[BN_NE], int B, int C, int HW) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nh = (HW + 63) >> 6;
+    int eb = 0, eh = 0;                                     // e / nh, e % nh carried incrementally
+#pragma unroll
+    for (int e = 0; e < BN_NE; ++e) {
+        const int b = wave + 16 * eb, i = lane + 64 * eh;
+        off[e] = (b < B && i < HW) ? b * C * HW + i : -1;
+        if (++eh == nh) { eh = 0; ++eb; }
+    }
+}
+__global__ __launch_bounds__(1024) void bn_fwd_fused_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                            const float* __restrict__ w, const float* __restrict__ bias,
+                                                            float* __restrict__ mean_out, float* __restrict__ inv_out,
+                                                            float* __restrict__ run_mean, float* __restrict__ run_var, int B,
+                                                            int C, int HW, float eps, float momentum) {
+    __shared__ float red[16];
+    const int c = blockIdx.x;
+    const float n = (float)((int64_t)B * HW);
+    const __amdgpu_buffer_rsrc_t rx = bn_rsrc(x + (int64_t)c * HW);
+    float* __restrict__ yc_ = y + (int64_t)c * HW;
+    int off[BN_NE];
+    bn_offsets(off, B, C, HW);
+    float v[BN_NE];
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < BN_NE; ++e) {
+        v[e] = bn_ld(rx, off[e]);
+        s += v[e];
+    }
+    const float mean = block_sum<16>(s, red) / n;
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < BN_NE; ++e)
+        if (off[e] >= 0) { const float d = v[e] - mean; q += d * d; }
+    const float var = block_sum<16>(q, red) / n;
+    const float inv = 1.0f / sqrtf(var + eps);
+    if (threadIdx.x == 0) {
+        mean_out[c] = mean;
+        inv_out[c] = inv;
+        if (run_mean) {
+            run_mean[c] = momentum * run_mean[c] + (1.0f - momentum) * mean;
+            run_var[c] = momentum * run_var[c] + (1.0f - momentum) * var;
+        }
+    }
+    const float wc = w ? w[c] : 1.f, bc = w ? bias[c] : 0.f;
+#pragma unroll
+    for (int e = 0; e < BN_NE; ++e)
+        if (off[e] >= 0) {
+            float t = (v[e] - mean) * inv;
+            if (w) t = wc * t + bc;
+            yc_[off[e]] = t;
+        }
+}
+__global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const float* __restrict__ g, const float* __restrict__ x,
+                                                            const float* __restrict__ mean, const float* __restrict__ inv,
+                                                            const float* __restrict__ w, float* __restrict__ dx,
+                                                            float* __restrict__ dw, float* __restrict__ db, int B, int C, int HW,
+                                                            float invN) {
+    __shared__ float red[32];
+    __shared__ float tot[2];
+    const int c = blockIdx.x;
+    const float m = mean[c], iv = inv[c], wc = w ? w[c] : 1.f;
+    const __amdgpu_buffer_rsrc_t rg = bn_rsrc(g + (int64_t)c * HW), rx = bn_rsrc(x + (int64_t)c * HW);
+    float* __restrict__ dc_ = dx + (int64_t)c * HW;
+    int off[BN_NE];
+    bn_offsets(off, B, C, HW);
+    float gv[BN_NE], xc[BN_NE];
+    float s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
+#pragma unroll
+    for (int e = 0; e < BN_NE; ++e) {
+        gv[e] = bn_ld(rg, off[e]);                            // 0 for a slot without an element: all four sums take 0
+        xc[e] = off[e] >= 0 ? bn_ld(rx, off[e]) - m : 0.f;
+        s1 += wc * gv[e] * xc[e];
+        s2 += wc * gv[e];
+        s3 += gv[e] * (xc[e] * iv);
+        s4 += gv[e];
+    }
+    block_sum2<16>(s1, s2, red);
+    block_sum2<16>(s3, s4, red);
+    if (threadIdx.x == 0) {
+        tot[0] = s1; tot[1] = s2;
+        if (dw) { dw[c] = s3; db[c] = s4; }
+    }
+    __syncthreads();
+    const float dstd = -0.5f * (iv * iv * iv) * tot[0];
+    const float t2 = tot[1];
+#pragma unroll
+    for (int e = 0; e < BN_NE; ++e)
+        if (off[e] >= 0) dc_[off[e]] = wc * gv[e] * iv + dstd * 2.0f * xc[e] * invN + t2 * iv * (-1.0f) * invN;
+}
+// (also guarantees that every offset fits an int: B * HW <= 16384 elements per channel, C * that < 2^31 for C < 131072)
+static inline bool bn_fits_fused(int64_t B, int64_t C, int64_t HW) { return ceil_div(B, 16) * ceil_div(HW, 64) <= BN_NE && C < 131072; }
+
 // ---- MSELoss (neunet/nn/losses.py:9-22): loss = sum((p - t)^2) / N ; dp = 2 (p - t) / N -------------------------
 __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ p, const float* __restrict__ t,
                                                   float* __restrict__ dp, float* __restrict__ part, int64_t n,
@@ -229,6 +341,20 @@ __global__ __launch_bounds__(256) void mse_final_kernel(const float* __restrict_
     float s = 0.f;
     for (int i = threadIdx.x; i < nparts; i += 256) s += part[i];
     s = block_sum<4>(s, red);
+    if (threadIdx.x == 0) loss[0] = s * invN;
+}
+
+// small problems (the conv classifier's 256 x 10): one block, one launch
+__global__ __launch_bounds__(1024) void mse_small_kernel(const float* __restrict__ p, const float* __restrict__ t,
+                                                         float* __restrict__ dp, int64_t n, float invN, float* __restrict__ loss) {
+    __shared__ float red[16];
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const float d = p[i] - t[i];
+        s += d * d;
+        if (dp) dp[i] = 2.0f * d * invN;
+    }
+    s = block_sum<16>(s, red);
     if (threadIdx.x == 0) loss[0] = s * invN;
 }
 
@@ -326,6 +452,12 @@ extern "C" int nnhipBatchNorm2dForward(const float* X, const float* weight, cons
     NNHIP_CHECK_ARG((weight == nullptr) == (bias == nullptr), NNHIP_EINVAL, "nnhipBatchNorm2dForward: weight and bias go together");
     NNHIP_CHECK_ARG(training || (running_mean && running_var), NNHIP_EINVAL, "nnhipBatchNorm2dForward: eval needs running stats");
     hipStream_t st = (hipStream_t)s;
+    if (training && bn_fits_fused(B, C, HW)) {
+        hipLaunchKernelGGL(bn_fwd_fused_kernel, dim3((unsigned)C), dim3(1024), 0, st, X, Y, weight, bias, save_mean, save_inv,
+                           running_mean, running_var, (int)B, (int)C, (int)HW, eps, momentum);
+        NNHIP_LAUNCH_CHECK("bn_fwd_fused_kernel");
+        return 0;
+    }
     if (training)
         hipLaunchKernelGGL(bn_stats_kernel, dim3((unsigned)C), dim3(1024), 0, st, X, save_mean, save_inv, running_mean, running_var,
                            (int)B, (int)C, (int)HW, eps, momentum);
@@ -347,6 +479,12 @@ extern "C" int nnhipBatchNorm2dBackward(const float* dY, const float* X, const f
     NNHIP_CHECK_ARG(dY && X && save_mean && save_inv && dX, NNHIP_EINVAL, "nnhipBatchNorm2dBackward: null pointer");
     NNHIP_CHECK_ARG((dW == nullptr) == (db == nullptr), NNHIP_EINVAL, "nnhipBatchNorm2dBackward: dW and db go together");
     hipStream_t st = (hipStream_t)s;
+    if (bn_fits_fused(B, C, HW)) {
+        hipLaunchKernelGGL(bn_bwd_fused_kernel, dim3((unsigned)C), dim3(1024), 0, st, dY, X, save_mean, save_inv, weight, dX, dW, db,
+                           (int)B, (int)C, (int)HW, 1.0f / (float)(B * HW));
+        NNHIP_LAUNCH_CHECK("bn_bwd_fused_kernel");
+        return 0;
+    }
     float* sums = static_cast<float*>(workspace((size_t)C * 4 * sizeof(float)));
     NNHIP_CHECK_ARG(sums != nullptr, NNHIP_ENOMEM, "nnhipBatchNorm2dBackward: workspace allocation failed");
     hipLaunchKernelGGL(bn_bwd_stats_kernel, dim3((unsigned)C), dim3(1024), 0, st, dY, X, save_mean, save_inv, weight, sums, (int)B,
@@ -364,6 +502,11 @@ extern "C" int nnhipMSELossForwardBackward(const float* pred, const float* targe
     NNHIP_CHECK_ARG(n > 0, NNHIP_EINVAL, "nnhipMSELossForwardBackward: n must be > 0");
     NNHIP_CHECK_ARG(pred && target && loss, NNHIP_EINVAL, "nnhipMSELossForwardBackward: null pointer");
     hipStream_t st = (hipStream_t)s;
+    if (n <= 16384) {
+        hipLaunchKernelGGL(mse_small_kernel, dim3(1), dim3(1024), 0, st, pred, target, dpred, n, 1.0f / (float)n, loss);
+        NNHIP_LAUNCH_CHECK("mse_small_kernel");
+        return 0;
+    }
     int64_t blocks = ceil_div(n, 1024);
     if (blocks > 1024) blocks = 1024;
     float* part = static_cast<float*>(workspace((size_t)blocks * sizeof(float)));
