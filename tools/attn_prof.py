@@ -44,7 +44,8 @@ def main():
     kvalid = torch.ones(B, T, dtype=torch.int32, device=dev)
     ctx, dctx = torch.empty(B, T, D, device=dev), torch.randn(B, T, D, device=dev)
     lse = torch.empty(B, H, T, 2, device=dev)
-    nblk = ((B * H + 7) // 8) * 8 * ((T + 127) // 128)
+    NW = 4 if os.environ.get("NNHIP_ATTN_WAVES", "2") == "4" or dh != 64 else 2     # waves (32-row groups) per block
+    nblk = ((B * H + 7) // 8) * 8 * ((T + 32 * NW - 1) // (32 * NW))
     prof = torch.zeros(nblk * 4 * 8, dtype=torch.int64, device=dev)
     P = ctypes.c_void_p
     i64, i32, f32 = ctypes.c_int64, ctypes.c_int32, ctypes.c_float
@@ -82,7 +83,7 @@ def main():
     torch.cuda.synchronize()
     lib.nnhipAttentionSetProfile(None)
     pr = prof.cpu().numpy().reshape(nblk, 4, 8).astype(np.float64)
-    nb = (T + 127) // 128
+    nb = (T + 32 * NW - 1) // (32 * NW)
     nbx = (B * H + 7) // 8
     ids = np.arange(nblk)
     r = ids >> 3
@@ -94,9 +95,9 @@ def main():
     names = ["prologue", "barrier wait", "commit+barrier", "fetch issue", "MFMA phase 1", "VALU phase", "MFMA phase 2", "epilogue"]
     for lvl in range(nb):
         sel = pr[j == lvl]
-        tot = sel.sum(axis=2)
+        tot = sel[:, :NW].sum(axis=2)
         print(f"-- blocks of weight level {lvl} ({sel.shape[0]} blocks): mean total cycles per wave {tot.mean():.0f}")
-        for w in range(4):
+        for w in range(NW):
             row = "  wave %d: " % w + "  ".join(f"{names[i]} {sel[:, w, i].mean():7.0f}" for i in range(8))
             print(row)
 
