@@ -369,6 +369,13 @@ int nnhipMaxPool2dForward(float* out, int32_t* argmax, const float* X, const nnh
                           nnhipStream_t stream);
 int nnhipMaxPool2dBackward(float* dX, const float* dY, const int32_t* argmax, const nnhipPool2dDesc* d,
                            nnhipStream_t stream);
+/* MaxPool2d(LeakyReLU(X; alpha)) forward / backward as ONE launch each (alpha > 0): the composition
+ * neunet/nn/activations.py:72-84 -> neunet/nn/layers/maxpool2d.py:85-249 of the conv classifier.  `out`/`argmax` as above;
+ * the backward takes the pooled forward output and returns the gradient of the LeakyReLU's INPUT. */
+int nnhipMaxPool2dLeakyForward(float* out, int32_t* argmax, const float* X, float alpha, const nnhipPool2dDesc* d,
+                               nnhipStream_t stream);
+int nnhipMaxPool2dLeakyBackward(float* dX, const float* dY, const int32_t* argmax, const float* pooled, float alpha,
+                                const nnhipPool2dDesc* d, nnhipStream_t stream);
 /* BatchNorm2d (neunet/nn/layers/batchnorm2d.py:57-115, 11-54), X [B,C,HW].  training != 0: batch mean / biased
  * variance per channel, running = momentum*running + (1-momentum)*stat (the reference's convention; running_*
  * may be NULL); else the running statistics are used.  save_mean / save_inv [C] feed the backward.
@@ -382,6 +389,10 @@ int nnhipBatchNorm2dBackward(const float* dY, const float* X, const float* weigh
 /* MSELoss (neunet/nn/losses.py:9-22): loss[0] = sum((pred-target)^2)/n ; dpred = 2 (pred-target)/n (may be NULL). */
 int nnhipMSELossForwardBackward(const float* pred, const float* target, float* loss, float* dpred, int64_t n,
                                 nnhipStream_t stream);
+/* MSELoss(Sigmoid(z), target) with the Sigmoid backward folded in: `pred` = the sigmoid output, dz_out = d(loss)/dz
+ * (neunet/nn/losses.py:9-22 composed with neunet/nn/activations.py:12-13; the conv classifier's last two modules). */
+int nnhipMSELossSigmoidForwardBackward(const float* pred, const float* target, float* loss, float* dz_out, int64_t n,
+                                       nnhipStream_t stream);
 
 /* ---- gradient-bucket helpers for data-parallel training (net-new) ---------------- */
 /* x[i] *= alpha */

@@ -57,7 +57,7 @@ __device__ __forceinline__ float4 sg_load(const float* __restrict__ P, int64_t l
     return v;
 }
 
-template <int NW, bool AKM, bool BKM>
+template <int NW, bool AKM, bool BKM, int U = 8>
 __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(const SmallGemmParams p) {
     __shared__ float red[NW][32 * 32];
     __shared__ float ared[NW][32];
@@ -69,8 +69,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(const SmallGemmPara
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
     float asum = 0.f;
-    // U k-groups in flight per wave (2 x U float4 of operands): a whole K = 784 / 8 waves is two round trips to L2
-    constexpr int U = 8;
+    // U k-groups in flight per wave (2 x U float4 of operands).  U = 8: a K = 784 over 8 waves is two round trips to L2;
+    // the U = 16 instantiation (k-major operands, 64 < K/8 <= 128 groups per block) makes it one.
     for (int64_t gb = wave; gb < groups; gb += (int64_t)NW * U) {
         float4 a[U], b[U];
 #pragma unroll
@@ -163,7 +163,9 @@ int gemm_small(const float* A, const float* B, float* C, const float* bias, floa
         else if (b_kmajor) hipLaunchKernelGGL((gemm_small_kernel<NW, false, true>), grid, dim3(NW * 64), 0, st, p);              \
         else hipLaunchKernelGGL((gemm_small_kernel<NW, false, false>), grid, dim3(NW * 64), 0, st, p);                            \
     } while (0)
-    if (nw == 8) SG_LAUNCH(8);
+    if (nw == 8 && a_kmajor && b_kmajor && groups > 64 && groups <= 128)
+        hipLaunchKernelGGL((gemm_small_kernel<8, true, true, 16>), grid, dim3(512), 0, st, p);
+    else if (nw == 8) SG_LAUNCH(8);
     else SG_LAUNCH(4);
 #undef SG_LAUNCH
     NNHIP_LAUNCH_CHECK("gemm_small_kernel");

@@ -57,7 +57,8 @@ struct SigmoidB { __device__ float operator()(float dy, float f) const { return 
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(float* __restrict__ out, int32_t* __restrict__ arg,
                                                           const float* __restrict__ x, int64_t BC, int H, int W,
                                                           int Ho, int Wo, int kh, int kw, int sh, int sw, int pu,
-                                                          int pl) {
+                                                          int pl, float pre_alpha) {
+    // pre_alpha != 1: the window is taken over LeakyReLU(x; pre_alpha), evaluated on the fly (nnhipMaxPool2dLeakyForward)
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t total = BC * Ho * Wo;
     if (i >= total) return;
@@ -75,7 +76,11 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(float* __restrict__ ou
     for (int r = 0; r < kh; ++r)
         for (int s = 0; s < kw; ++s) {
             const int y = ho * sh - pu + r, xx = wo * sw - pl + s;
-            const float v = (y >= 0 && y < H && xx >= 0 && xx < W) ? p[(int64_t)y * W + xx] : -INFINITY;
+            float v = -INFINITY;
+            if (y >= 0 && y < H && xx >= 0 && xx < W) {
+                v = p[(int64_t)y * W + xx];
+                if (pre_alpha != 1.0f) v = v <= 0.f ? pre_alpha * v : v;       // LeakyF
+            }
             if (v > best) { best = v; bi = r * kw + s; }
         }
     out[i] = best;
@@ -85,7 +90,9 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(float* __restrict__ ou
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(float* __restrict__ dx, const float* __restrict__ dy,
                                                           const int32_t* __restrict__ arg, int64_t BC, int H, int W,
                                                           int Ho, int Wo, int kh, int kw, int sh, int sw, int pu,
-                                                          int pl) {
+                                                          int pl, const float* __restrict__ pooled, float alpha) {
+    // pooled != null: dx is the gradient of the LeakyReLU's INPUT -- the routed gradient times LeakyB's factor, read off
+    // the pooled output (= the LeakyReLU output at the arg-max: f <= 0 ? alpha : 1)
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t total = BC * H * W;
     if (i >= total) return;
@@ -109,10 +116,36 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(float* __restrict__ dx
             const int wo = tx / sw;
             if (wo >= Wo) continue;
             const int64_t o = (bc * Ho + ho) * Wo + wo;
-            if (arg[o] == r * kw + s) g += dy[o];
+            if (arg[o] == r * kw + s) g += (pooled && pooled[o] <= 0.f) ? dy[o] * alpha : dy[o];
         }
     }
     dx[i] = g;
+}
+
+// Non-overlapping windows that tile the input exactly (kernel == stride, no padding, H = Ho*kh, W = Wo*kw: the conv
+// classifier's 2x2/2 pools): one thread per WINDOW writes its kh x kw input gradients -- the routed one and zeros -- with
+// no per-pixel division / modulo (the gather kernel above spends 15 us on 1.6 M pixels, this one ~4).
+template <int KW>
+__global__ __launch_bounds__(256) void maxpool_bwd_tiles_kernel(float* __restrict__ dx, const float* __restrict__ dy,
+                                                                const int32_t* __restrict__ arg, int64_t total_out, int W,
+                                                                int Ho, int Wo, int kh, int kw_rt,
+                                                                const float* __restrict__ pooled, float alpha) {
+    const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (o >= total_out) return;
+    const int kw = KW ? KW : kw_rt;
+    const int64_t row_o = o / Wo;                       // bc * Ho + ho
+    const int wo = (int)(o - row_o * Wo);
+    float g = dy[o];
+    if (pooled && pooled[o] <= 0.f) g *= alpha;
+    const int a = arg[o];
+    float* __restrict__ base = dx + row_o * kh * (int64_t)W + (int64_t)wo * kw;     // H = Ho * kh: row (bc*Ho + ho)*kh of [BC*H, W]
+    for (int r = 0; r < kh; ++r) {
+        if constexpr (KW == 2) {
+            *reinterpret_cast<float2*>(base + (int64_t)r * W) = make_float2(a == 2 * r ? g : 0.f, a == 2 * r + 1 ? g : 0.f);
+        } else {
+            for (int s = 0; s < kw; ++s) base[(int64_t)r * W + s] = (a == r * kw + s) ? g : 0.f;
+        }
+    }
 }
 
 // ---- BatchNorm2d (neunet/nn/layers/batchnorm2d.py:57-115 fwd, 11-54 bwd) --------------------------------------
@@ -324,13 +357,13 @@ static inline bool bn_fits_fused(int64_t B, int64_t C, int64_t HW) { return ceil
 // ---- MSELoss (neunet/nn/losses.py:9-22): loss = sum((p - t)^2) / N ; dp = 2 (p - t) / N -------------------------
 __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ p, const float* __restrict__ t,
                                                   float* __restrict__ dp, float* __restrict__ part, int64_t n,
-                                                  float invN) {
+                                                  float invN, int sig) {
     __shared__ float red[4];
     float s = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const float d = p[i] - t[i];
         s += d * d;
-        if (dp) dp[i] = 2.0f * d * invN;
+        if (dp) dp[i] = sig ? (2.0f * d * invN) * p[i] * (1.0f - p[i]) : 2.0f * d * invN;   // sig: SigmoidB folded in
     }
     s = block_sum<4>(s, red);
     if (threadIdx.x == 0) part[blockIdx.x] = s;
@@ -346,13 +379,14 @@ __global__ __launch_bounds__(256) void mse_final_kernel(const float* __restrict_
 
 // small problems (the conv classifier's 256 x 10): one block, one launch
 __global__ __launch_bounds__(1024) void mse_small_kernel(const float* __restrict__ p, const float* __restrict__ t,
-                                                         float* __restrict__ dp, int64_t n, float invN, float* __restrict__ loss) {
+                                                         float* __restrict__ dp, int64_t n, float invN, float* __restrict__ loss,
+                                                         int sig) {
     __shared__ float red[16];
     float s = 0.f;
     for (int64_t i = threadIdx.x; i < n; i += 1024) {
         const float d = p[i] - t[i];
         s += d * d;
-        if (dp) dp[i] = 2.0f * d * invN;
+        if (dp) dp[i] = sig ? (2.0f * d * invN) * p[i] * (1.0f - p[i]) : 2.0f * d * invN;
     }
     s = block_sum<16>(s, red);
     if (threadIdx.x == 0) loss[0] = s * invN;
@@ -415,31 +449,66 @@ static int pool_check(const nnhipPool2dDesc* d, int& Ho, int& Wo) {
     return 0;
 }
 
-extern "C" int nnhipMaxPool2dForward(float* out, int32_t* argmax, const float* X, const nnhipPool2dDesc* d,
-                                     nnhipStream_t s) {
+static int maxpool_forward(const char* fn, float* out, int32_t* argmax, const float* X, const nnhipPool2dDesc* d, float pre_alpha,
+                           nnhipStream_t s) {
     int Ho, Wo;
     if (int rc = pool_check(d, Ho, Wo)) return rc;
     const int64_t total = d->B * d->C * Ho * Wo;
     if (total == 0) return 0;
-    NNHIP_CHECK_ARG(out && argmax && X, NNHIP_EINVAL, "nnhipMaxPool2dForward: null pointer");
+    NNHIP_CHECK_ARG(out && argmax && X, NNHIP_EINVAL, "%s: null pointer", fn);
     hipLaunchKernelGGL(maxpool_fwd_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)s, out, argmax, X,
                        d->B * d->C, (int)d->H, (int)d->W, Ho, Wo, (int)d->kh, (int)d->kw, (int)d->sh, (int)d->sw,
-                       (int)d->pu, (int)d->pl);
+                       (int)d->pu, (int)d->pl, pre_alpha);
     NNHIP_LAUNCH_CHECK("maxpool_fwd_kernel");
     return 0;
 }
-extern "C" int nnhipMaxPool2dBackward(float* dX, const float* dY, const int32_t* argmax, const nnhipPool2dDesc* d,
-                                      nnhipStream_t s) {
+static int maxpool_backward(const char* fn, float* dX, const float* dY, const int32_t* argmax, const float* pooled, float alpha,
+                            const nnhipPool2dDesc* d, nnhipStream_t s) {
     int Ho, Wo;
     if (int rc = pool_check(d, Ho, Wo)) return rc;
     const int64_t total = d->B * d->C * d->H * d->W;
     if (total == 0) return 0;
-    NNHIP_CHECK_ARG(dX && dY && argmax, NNHIP_EINVAL, "nnhipMaxPool2dBackward: null pointer");
+    NNHIP_CHECK_ARG(dX && dY && argmax, NNHIP_EINVAL, "%s: null pointer", fn);
+    if (d->kh == d->sh && d->kw == d->sw && d->pu + d->pd + d->pl + d->pr == 0 && d->H == (int64_t)Ho * d->kh &&
+        d->W == (int64_t)Wo * d->kw) {
+        const int64_t nout = d->B * d->C * Ho * Wo;
+        const bool two = d->kw == 2 && (d->W & 1) == 0 && (reinterpret_cast<uintptr_t>(dX) & 7u) == 0;
+        if (two)
+            hipLaunchKernelGGL(maxpool_bwd_tiles_kernel<2>, dim3((unsigned)ceil_div(nout, 256)), dim3(256), 0, (hipStream_t)s, dX, dY,
+                               argmax, nout, (int)d->W, Ho, Wo, (int)d->kh, (int)d->kw, pooled, alpha);
+        else
+            hipLaunchKernelGGL(maxpool_bwd_tiles_kernel<0>, dim3((unsigned)ceil_div(nout, 256)), dim3(256), 0, (hipStream_t)s, dX, dY,
+                               argmax, nout, (int)d->W, Ho, Wo, (int)d->kh, (int)d->kw, pooled, alpha);
+        NNHIP_LAUNCH_CHECK("maxpool_bwd_tiles_kernel");
+        return 0;
+    }
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)s, dX, dY, argmax,
                        d->B * d->C, (int)d->H, (int)d->W, Ho, Wo, (int)d->kh, (int)d->kw, (int)d->sh, (int)d->sw,
-                       (int)d->pu, (int)d->pl);
+                       (int)d->pu, (int)d->pl, pooled, alpha);
     NNHIP_LAUNCH_CHECK("maxpool_bwd_kernel");
     return 0;
+}
+extern "C" int nnhipMaxPool2dForward(float* out, int32_t* argmax, const float* X, const nnhipPool2dDesc* d,
+                                     nnhipStream_t s) {
+    return maxpool_forward("nnhipMaxPool2dForward", out, argmax, X, d, 1.0f, s);
+}
+extern "C" int nnhipMaxPool2dBackward(float* dX, const float* dY, const int32_t* argmax, const nnhipPool2dDesc* d,
+                                      nnhipStream_t s) {
+    return maxpool_backward("nnhipMaxPool2dBackward", dX, dY, argmax, nullptr, 1.0f, d, s);
+}
+// MaxPool2d(LeakyReLU(X; alpha)) and its backward as one launch each (alpha > 0; the conv classifier's
+// conv -> LeakyReLU -> MaxPool chain, examples/convolutional_digits_classifier.ipynb): the activation is evaluated inside the
+// pooling window, its full-resolution output is never written; the backward routes dY through the arg-max and applies the
+// LeakyReLU gradient factor of that element (read off the pooled output) -- dX is the gradient of the LeakyReLU's input.
+extern "C" int nnhipMaxPool2dLeakyForward(float* out, int32_t* argmax, const float* X, float alpha, const nnhipPool2dDesc* d,
+                                          nnhipStream_t s) {
+    NNHIP_CHECK_ARG(alpha > 0.f, NNHIP_EINVAL, "nnhipMaxPool2dLeakyForward: alpha must be > 0 (a strictly increasing activation)");
+    return maxpool_forward("nnhipMaxPool2dLeakyForward", out, argmax, X, d, alpha, s);
+}
+extern "C" int nnhipMaxPool2dLeakyBackward(float* dX, const float* dY, const int32_t* argmax, const float* pooled, float alpha,
+                                           const nnhipPool2dDesc* d, nnhipStream_t s) {
+    NNHIP_CHECK_ARG(pooled != nullptr, NNHIP_EINVAL, "nnhipMaxPool2dLeakyBackward: null pointer");
+    return maxpool_backward("nnhipMaxPool2dLeakyBackward", dX, dY, argmax, pooled, alpha, d, s);
 }
 
 extern "C" int nnhipBatchNorm2dForward(const float* X, const float* weight, const float* bias, float* Y,
@@ -497,24 +566,34 @@ extern "C" int nnhipBatchNorm2dBackward(const float* dY, const float* X, const f
     return 0;
 }
 
-extern "C" int nnhipMSELossForwardBackward(const float* pred, const float* target, float* loss, float* dpred,
-                                           int64_t n, nnhipStream_t s) {
-    NNHIP_CHECK_ARG(n > 0, NNHIP_EINVAL, "nnhipMSELossForwardBackward: n must be > 0");
-    NNHIP_CHECK_ARG(pred && target && loss, NNHIP_EINVAL, "nnhipMSELossForwardBackward: null pointer");
+static int mse_launch(const char* fn, const float* pred, const float* target, float* loss, float* dpred, int64_t n, int sig,
+                      nnhipStream_t s) {
+    NNHIP_CHECK_ARG(n > 0, NNHIP_EINVAL, "%s: n must be > 0", fn);
+    NNHIP_CHECK_ARG(pred && target && loss, NNHIP_EINVAL, "%s: null pointer", fn);
     hipStream_t st = (hipStream_t)s;
     if (n <= 16384) {
-        hipLaunchKernelGGL(mse_small_kernel, dim3(1), dim3(1024), 0, st, pred, target, dpred, n, 1.0f / (float)n, loss);
+        hipLaunchKernelGGL(mse_small_kernel, dim3(1), dim3(1024), 0, st, pred, target, dpred, n, 1.0f / (float)n, loss, sig);
         NNHIP_LAUNCH_CHECK("mse_small_kernel");
         return 0;
     }
     int64_t blocks = ceil_div(n, 1024);
     if (blocks > 1024) blocks = 1024;
     float* part = static_cast<float*>(workspace((size_t)blocks * sizeof(float)));
-    NNHIP_CHECK_ARG(part != nullptr, NNHIP_ENOMEM, "nnhipMSELossForwardBackward: workspace allocation failed");
+    NNHIP_CHECK_ARG(part != nullptr, NNHIP_ENOMEM, "%s: workspace allocation failed", fn);
     const float invN = 1.0f / (float)n;
-    hipLaunchKernelGGL(mse_kernel, dim3((unsigned)blocks), dim3(256), 0, st, pred, target, dpred, part, n, invN);
+    hipLaunchKernelGGL(mse_kernel, dim3((unsigned)blocks), dim3(256), 0, st, pred, target, dpred, part, n, invN, sig);
     NNHIP_LAUNCH_CHECK("mse_kernel");
     hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(256), 0, st, part, (int)blocks, invN, loss);
     NNHIP_LAUNCH_CHECK("mse_final_kernel");
     return 0;
+}
+extern "C" int nnhipMSELossForwardBackward(const float* pred, const float* target, float* loss, float* dpred,
+                                           int64_t n, nnhipStream_t s) {
+    return mse_launch("nnhipMSELossForwardBackward", pred, target, loss, dpred, n, 0, s);
+}
+// MSELoss(Sigmoid(z), target): `pred` is the sigmoid OUTPUT; dz_out = d(loss)/dz = 2 (pred - target) / n * pred (1 - pred)
+// -- the Sigmoid backward (neunet/nn/activations.py:12-13) folded into the loss kernel.
+extern "C" int nnhipMSELossSigmoidForwardBackward(const float* pred, const float* target, float* loss, float* dz_out,
+                                                  int64_t n, nnhipStream_t s) {
+    return mse_launch("nnhipMSELossSigmoidForwardBackward", pred, target, loss, dz_out, n, 1, s);
 }

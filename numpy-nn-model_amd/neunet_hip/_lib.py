@@ -111,9 +111,12 @@ _SIGNATURES = {
     "nnhipSigmoidBackward": (ctypes.c_int, [P, P, P, c_int64, c_void_p]),
     "nnhipMaxPool2dForward": (ctypes.c_int, [P, P, P, POINTER(Pool2dDesc), c_void_p]),
     "nnhipMaxPool2dBackward": (ctypes.c_int, [P, P, P, POINTER(Pool2dDesc), c_void_p]),
+    "nnhipMaxPool2dLeakyForward": (ctypes.c_int, [P, P, P, c_float, POINTER(Pool2dDesc), c_void_p]),
+    "nnhipMaxPool2dLeakyBackward": (ctypes.c_int, [P, P, P, P, c_float, POINTER(Pool2dDesc), c_void_p]),
     "nnhipBatchNorm2dForward": (ctypes.c_int, [P, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_float, c_float, ctypes.c_int, c_void_p]),
     "nnhipBatchNorm2dBackward": (ctypes.c_int, [P, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_void_p]),
     "nnhipMSELossForwardBackward": (ctypes.c_int, [P, P, P, P, c_int64, c_void_p]),
+    "nnhipMSELossSigmoidForwardBackward": (ctypes.c_int, [P, P, P, P, c_int64, c_void_p]),
     "nnhipScale": (ctypes.c_int, [P, c_float, c_int64, c_void_p]),
     "nnhipAdd": (ctypes.c_int, [P, P, P, c_int64, c_void_p]),
 }

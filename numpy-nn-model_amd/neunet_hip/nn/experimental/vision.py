@@ -1,8 +1,9 @@
 """The remaining modules of the conv-classifier step (examples/convolutional_digits_classifier.ipynb
 cell 2): HIPLeakyReLU, HIPSigmoid, HIPMaxPool2d, HIPBatchNorm2d, HIPMSELoss -- same constructor arguments,
 `args` layout and gradient formulas as the reference classes they stand in for."""
-import weakref
 import ctypes
+import os
+import weakref
 from typing import Union
 
 import numpy as np
@@ -21,16 +22,52 @@ def _pair(v):
 
 # ------------------------------------------------------------------------------------------ LeakyReLU / Sigmoid
 class _HIPLeakyReLUTensor(Tensor):
-    def __init__(self, data, args, op, device):
+    """Output of HIPLeakyReLU.  The elementwise pass is DEFERRED until somebody reads `.data`: a MaxPool2d applied to it
+    first (the conv classifier's conv -> LeakyReLU -> MaxPool chain) evaluates the activation inside its pooling window
+    and takes over the backward as well (nnhipMaxPool2dLeakyForward / Backward: two launches instead of four per chain);
+    anything else that touches `.data` runs the plain kernel at that point.  Values are identical either way."""
+
+    def __init__(self, data, args, op, device, thunk=None, shape=None):
+        self._data, self._thunk, self._lazy_shape = None, thunk, shape
         super().__init__(data, args, op, device=device, _nocopy=True)
 
-        def grad_fn(t: Tensor, f_x, alpha, grad):
-            g = t.xp.empty_like(t.data)
+        def grad_fn(t: Tensor, out_ref, alpha, grad):
+            f_x = out_ref().data                      # materialised by now (a consumer read it) -- or materialise it
+            g = t.xp.empty_like(f_x)
             call_hip_function("nnhipLeakyReLUBackward", g, contiguous(grad), f_x, float(alpha), f_x.numel(),
                               get_current_stream_ptr())
             t.apply_grad(g)
 
         self.grad_fn = grad_fn
+
+    @property
+    def data(self):
+        if self._data is None and self._thunk is not None:
+            thunk, self._thunk = self._thunk, None
+            self._data = thunk()
+        return self._data
+
+    @data.setter
+    def data(self, value):
+        self._data = value
+
+    def pending(self) -> bool:
+        return self._data is None and self._thunk is not None
+
+    @property
+    def shape(self):
+        return tuple(self._lazy_shape) if self._data is None and self._lazy_shape is not None else tuple(self._data.shape)
+
+    @property
+    def dtype(self):
+        return np.dtype(np.float32)
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+
+_LAZY_LEAKY = os.environ.get("NNHIP_LAZY_LEAKY", "1") != "0"
 
 
 class HIPLeakyReLU(Module):
@@ -42,10 +79,19 @@ class HIPLeakyReLU(Module):
 
     def forward(self, x: Tensor):
         require_device_f32(x)
-        f_x = x.xp.empty_like(x.data)
-        call_hip_function("nnhipLeakyReLUForward", f_x, contiguous(x.data), float(self.alpha), f_x.numel(),
-                          get_current_stream_ptr())
-        return _HIPLeakyReLUTensor(f_x, [x, f_x, self.alpha], "leakyrelu", device=x.device)
+        alpha = float(self.alpha)
+
+        def thunk():
+            f_x = x.xp.empty_like(x.data)
+            call_hip_function("nnhipLeakyReLUForward", f_x, contiguous(x.data), alpha, f_x.numel(), get_current_stream_ptr())
+            return f_x
+
+        if _LAZY_LEAKY and alpha > 0.0:
+            out = _HIPLeakyReLUTensor(None, None, "leakyrelu", device=x.device, thunk=thunk, shape=tuple(x.shape))
+        else:
+            out = _HIPLeakyReLUTensor(thunk(), None, "leakyrelu", device=x.device)
+        out.args = [x, weakref.ref(out), self.alpha]
+        return out
 
 
 class _HIPSigmoidTensor(Tensor):
@@ -81,10 +127,14 @@ class _HIPMaxPool2dTensor(Tensor):
     def __init__(self, data, args, op, device):
         super().__init__(data, args, op, device=device, _nocopy=True)
 
-        def grad_fn(X: Tensor, argmax, desc, grad):
-            grad_X = X.xp.empty_like(X.data)
-            call_hip_function("nnhipMaxPool2dBackward", grad_X, contiguous(grad), argmax, ctypes.byref(desc),
-                              get_current_stream_ptr())
+        def grad_fn(X: Tensor, argmax, desc, pooled, alpha, grad):
+            grad_X = X.xp.empty(tuple(X.shape), dtype=np.float32)
+            if pooled is None:
+                call_hip_function("nnhipMaxPool2dBackward", grad_X, contiguous(grad), argmax, ctypes.byref(desc),
+                                  get_current_stream_ptr())
+            else:   # X is the INPUT of the LeakyReLU this pool absorbed: route + activation gradient in one launch
+                call_hip_function("nnhipMaxPool2dLeakyBackward", grad_X, contiguous(grad), argmax, pooled, float(alpha),
+                                  ctypes.byref(desc), get_current_stream_ptr())
             X.apply_grad(grad_X)
 
         self.grad_fn = grad_fn
@@ -118,9 +168,14 @@ class HIPMaxPool2d(Module):
         desc = Pool2dDesc(B, C, H, W, kh, kw, sh, sw, pu, pd, pl, pr)
         O = X.xp.empty((B, C, Ho, Wo), dtype=np.float32)
         argmax = torch.empty((B, C, Ho, Wo), dtype=torch.int32, device=O.device)
+        if isinstance(X, _HIPLeakyReLUTensor) and X.pending():
+            src, alpha = X.args[0], float(X.args[2])       # pool over LeakyReLU(src) without materialising it
+            call_hip_function("nnhipMaxPool2dLeakyForward", O, argmax, contiguous(src.data), alpha, ctypes.byref(desc),
+                              get_current_stream_ptr())
+            return _HIPMaxPool2dTensor(O, (src, argmax, desc, O, alpha), "maxpool2d", device=X.device)
         call_hip_function("nnhipMaxPool2dForward", O, argmax, contiguous(X.data), ctypes.byref(desc),
                           get_current_stream_ptr())
-        return _HIPMaxPool2dTensor(O, (X, argmax, desc), "maxpool2d", device=X.device)
+        return _HIPMaxPool2dTensor(O, (X, argmax, desc, None, 1.0), "maxpool2d", device=X.device)
 
 
 # --------------------------------------------------------------------------------------------- BatchNorm2d
@@ -220,5 +275,11 @@ class HIPMSELoss(Module):
         p, t = contiguous(y_pred.data), contiguous(y_true.data)
         loss = torch.empty((), dtype=torch.float32, device=p.device)
         dpred = torch.empty_like(p)
+        if isinstance(y_pred, _HIPSigmoidTensor) and _LAZY_LEAKY:
+            # MSE(Sigmoid(z)): the loss kernel also applies the Sigmoid backward and hands d(loss)/dz straight to z -- the
+            # Sigmoid node drops out of this loss's backward (one launch less; other consumers of the Sigmoid output, if
+            # any, still go through it and the gradients add up in z)
+            call_hip_function("nnhipMSELossSigmoidForwardBackward", p, t, loss, dpred, p.numel(), get_current_stream_ptr())
+            return _HIPMSETensor(loss, (y_pred.args[0], dpred), "mse", device="cuda")
         call_hip_function("nnhipMSELossForwardBackward", p, t, loss, dpred, p.numel(), get_current_stream_ptr())
         return _HIPMSETensor(loss, (y_pred, dpred), "mse", device="cuda")

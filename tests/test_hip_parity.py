@@ -1896,6 +1896,50 @@ def test_vision_ops_golden(hip, golden):
     np.testing.assert_allclose(host(p.grad), g["mse_dP"], rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("ks,st,pad,shape", [(2, 2, 0, (3, 4, 12, 12)), (3, 2, 1, (2, 3, 11, 9)), (2, 1, 0, (2, 2, 7, 7)),
+                                              (2, 2, 0, (256, 8, 28, 28))])
+def test_leaky_relu_maxpool_fusion(hip, ks, st, pad, shape):
+    """MaxPool2d(LeakyReLU(x)): the deferred LeakyReLU is absorbed by the pool (nnhipMaxPool2dLeakyForward / Backward, one
+    launch per direction) -- output, arg-max routing and the gradient of x must equal the two-module path exactly
+    (bit-for-bit: the same activation values enter the same comparisons), also with overlapping windows, padding and when
+    the activation output is ALSO read by someone else."""
+    import neunet_hip.nn as nn
+    from neunet_hip.nn.experimental import vision
+    rng = np.random.default_rng(ks * 100 + st * 10 + pad)
+    X = rng.standard_normal(shape).astype(np.float32)
+    X.flat[:: 7] = 0.0                                        # zeros: the f <= 0 branch of the gradient
+    Ho = (shape[2] + 2 * pad - ks) // st + 1
+    Wo = (shape[3] + 2 * pad - ks) // st + 1
+    dY = rng.standard_normal(shape[:2] + (Ho, Wo)).astype(np.float32)
+    act, pool = nn.LeakyReLU(0.01), nn.MaxPool2d(ks, st, pad)
+    res = {}
+    for lazy in (True, False):
+        old, vision._LAZY_LEAKY = vision._LAZY_LEAKY, lazy
+        try:
+            x = T(hip, X)
+            h = act(x)
+            assert h.pending() == lazy
+            y = pool(h)
+            assert h.pending() == lazy                        # absorbed, not materialised
+            y.backward(dY)
+            res[lazy] = (host(y.data), host(x.grad))
+        finally:
+            vision._LAZY_LEAKY = old
+    np.testing.assert_array_equal(res[True][0], res[False][0])
+    np.testing.assert_array_equal(res[True][1], res[False][1])
+    ref_y = O.leaky_relu_forward(X, 0.01) if hasattr(O, "leaky_relu_forward") else np.where(X <= 0, 0.01 * X, X)
+    assert res[True][0].max() <= ref_y.max() + 1e-6
+    # a second consumer of the activation output: it materialises, both gradients accumulate in x
+    x = T(hip, X)
+    h = act(x)
+    y = pool(h)
+    z = h * 2.0 if hasattr(h, "__mul__") else None
+    if z is not None:
+        y.backward(dY)
+        g1 = host(x.grad).copy()
+        np.testing.assert_array_equal(g1, res[False][1])
+
+
 def test_conv_classifier_golden(hip, golden):
     """Config-5 model (notebook cell 2) on the HIP path vs the REAL reference: step-1 outputs / loss / every gradient
     tight; step 2 (after one Adam update) to the +-lr noise level explained in test_oracle_golden.py."""
