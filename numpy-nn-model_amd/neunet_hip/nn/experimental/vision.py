@@ -67,7 +67,8 @@ class _HIPLeakyReLUTensor(Tensor):
         return len(self.shape)
 
 
-_LAZY_LEAKY = os.environ.get("NNHIP_LAZY_LEAKY", "1") != "0"
+# NNHIP_VISION_FUSION=0: no deferred LeakyReLU / MaxPool absorption, no Sigmoid fold into MSE (developer A/B switch)
+_FUSE = os.environ.get("NNHIP_VISION_FUSION", "1") != "0"
 
 
 class HIPLeakyReLU(Module):
@@ -86,7 +87,7 @@ class HIPLeakyReLU(Module):
             call_hip_function("nnhipLeakyReLUForward", f_x, contiguous(x.data), alpha, f_x.numel(), get_current_stream_ptr())
             return f_x
 
-        if _LAZY_LEAKY and alpha > 0.0:
+        if _FUSE and alpha > 0.0:
             out = _HIPLeakyReLUTensor(None, None, "leakyrelu", device=x.device, thunk=thunk, shape=tuple(x.shape))
         else:
             out = _HIPLeakyReLUTensor(thunk(), None, "leakyrelu", device=x.device)
@@ -275,7 +276,7 @@ class HIPMSELoss(Module):
         p, t = contiguous(y_pred.data), contiguous(y_true.data)
         loss = torch.empty((), dtype=torch.float32, device=p.device)
         dpred = torch.empty_like(p)
-        if isinstance(y_pred, _HIPSigmoidTensor) and _LAZY_LEAKY:
+        if isinstance(y_pred, _HIPSigmoidTensor) and _FUSE:
             # MSE(Sigmoid(z)): the loss kernel also applies the Sigmoid backward and hands d(loss)/dz straight to z -- the
             # Sigmoid node drops out of this loss's backward (one launch less; other consumers of the Sigmoid output, if
             # any, still go through it and the gradients add up in z)

@@ -1914,7 +1914,7 @@ def test_leaky_relu_maxpool_fusion(hip, ks, st, pad, shape):
     act, pool = nn.LeakyReLU(0.01), nn.MaxPool2d(ks, st, pad)
     res = {}
     for lazy in (True, False):
-        old, vision._LAZY_LEAKY = vision._LAZY_LEAKY, lazy
+        old, vision._FUSE = vision._FUSE, lazy
         try:
             x = T(hip, X)
             h = act(x)
@@ -1924,20 +1924,24 @@ def test_leaky_relu_maxpool_fusion(hip, ks, st, pad, shape):
             y.backward(dY)
             res[lazy] = (host(y.data), host(x.grad))
         finally:
-            vision._LAZY_LEAKY = old
+            vision._FUSE = old
     np.testing.assert_array_equal(res[True][0], res[False][0])
     np.testing.assert_array_equal(res[True][1], res[False][1])
-    ref_y = O.leaky_relu_forward(X, 0.01) if hasattr(O, "leaky_relu_forward") else np.where(X <= 0, 0.01 * X, X)
-    assert res[True][0].max() <= ref_y.max() + 1e-6
-    # a second consumer of the activation output: it materialises, both gradients accumulate in x
-    x = T(hip, X)
-    h = act(x)
-    y = pool(h)
-    z = h * 2.0 if hasattr(h, "__mul__") else None
-    if z is not None:
+    ref = np.where(X <= 0, np.float32(0.01) * X, X)
+    # the activation output read by someone else: AFTER the pool absorbed it (it materialises then, the pool's result and
+    # backward are unaffected) and BEFORE (the pool then sees a plain tensor and takes the two-launch path)
+    for read_first in (False, True):
+        x = T(hip, X)
+        h = act(x)
+        if read_first:
+            np.testing.assert_array_equal(host(h.data), ref)
+        y = pool(h)
+        if not read_first:
+            np.testing.assert_array_equal(host(h.data), ref)
+        assert not h.pending()
         y.backward(dY)
-        g1 = host(x.grad).copy()
-        np.testing.assert_array_equal(g1, res[False][1])
+        np.testing.assert_array_equal(host(y.data), res[False][0])
+        np.testing.assert_array_equal(host(x.grad), res[False][1])
 
 
 def test_conv_classifier_golden(hip, golden):
