@@ -136,72 +136,70 @@ __device__ __forceinline__ void gemm_k_loop(f32x16 (&acc)[2][2], float4 (&ra)[BK
     }
 }
 
-// The same loop for the vectorised variants: operand tiles come through g2r_fast (gemm_common.h).  ka / kb are the scalar
-// byte offsets of the k-tile that is resident in LDS stage 0 when the loop starts; the loop walks `nfull` whole k-tiles
-// and leaves, when there is a partial last tile (fetched as the last BK columns of the k range), that tile in stage `cur`
-// for tail_mma.
+// One k-tile of the vectorised variants (operand tiles through g2r_fast, gemm_common.h): fetch a tile into (fa, fb), multiply
+// the tile in LDS stage `cur`, commit the tile held in (ca, cb) to the other stage.  The fetched tile is TWO ahead of the one
+// being multiplied (the committed one is one ahead): a load has two iterations (~7 us with two blocks per CU) to land, so
+// the loop rides through the latency spike of a generation of blocks storing their C tiles together -- with a one-deep
+// prefetch that store burst (33.5 MB per 512 tiles = 6.7 us at 5 TB/s) was fully exposed in grids of a few generations
+// (a build without stores ran exactly that much faster).
+// SUM: cs += csf[q] * (the committed A tile) -- csf = 1 for a whole tile, the new-rows mask for the shifted partial tile,
+// 0 for the never-used tiles fetched past the end.
 template <int BK, bool AKC, bool BKC, bool SUM>
-__device__ __forceinline__ int gemm_k_loop_fast(f32x16 (&acc)[2][2], float4 (&ra)[BK / 8], float4 (&rb)[BK / 8], float4& cs,
-                                                float* __restrict__ smem, __amdgpu_buffer_rsrc_t rsa, __amdgpu_buffer_rsrc_t rsb,
-                                                unsigned ka, unsigned kb, unsigned astep, unsigned bstep, unsigned katail,
-                                                unsigned kbtail, const unsigned (&offa)[BK / 8], const unsigned (&offb)[BK / 8],
-                                                int nfull, bool has_tail, int tid, int wm, int wn, int l31, int lh) {
+__device__ __forceinline__ void gemm_k_step(f32x16 (&acc)[2][2], float4 (&fa)[BK / 8], float4 (&fb)[BK / 8],
+                                            const float4 (&ca)[BK / 8], const float4 (&cb)[BK / 8], float4& cs,
+                                            const float (&csf)[BK / 8], float* __restrict__ smem, int cur,
+                                            __amdgpu_buffer_rsrc_t rsa, __amdgpu_buffer_rsrc_t rsb, unsigned kfa, unsigned kfb,
+                                            const unsigned (&offa)[BK / 8], const unsigned (&offb)[BK / 8], int tid, int wm,
+                                            int wn, int l31, int lh) {
     using TA = Tile<BK, AKC>;
     using TB = Tile<BK, BKC>;
     constexpr int STAGE = TA::SIZE + TB::SIZE;
     constexpr int NLD = 2 * (BK / 8);
     constexpr int NMF = 16 * (BK / 8);
-    int cur = 0;
-    for (int kt = 0; kt < nfull; ++kt) {
-        // tile kt+1: the next whole tile, else the shifted tail tile, else (nothing left) the current tile once more --
-        // a harmless re-read whose LDS copy is never used.  All three are scalar selects (SALU).
-        const bool more = kt + 1 < nfull;
-        ka = more ? ka + astep : (has_tail ? katail : ka);
-        kb = more ? kb + bstep : (has_tail ? kbtail : kb);
-        if constexpr (SUM) {
+    g2r_fast<BK>(fa, rsa, kfa, offa);
+    g2r_fast<BK>(fb, rsb, kfb, offb);
+    const float* As = smem + cur * STAGE;
+    const float* Bs = As + TA::SIZE;
 #pragma unroll
-            for (int q = 0; q < BK / 8; ++q) { cs.x += ra[q].x; cs.y += ra[q].y; cs.z += ra[q].z; cs.w += ra[q].w; }
-        }
-        g2r_fast<BK>(ra, rsa, ka, offa);
-        g2r_fast<BK>(rb, rsb, kb, offb);
-        const float* As = smem + cur * STAGE;
-        const float* Bs = As + TA::SIZE;
+    for (int g = 0; g < BK / 8; ++g) {
+        float a[2][4], b[2][4];
 #pragma unroll
-        for (int g = 0; g < BK / 8; ++g) {
-            float a[2][4], b[2][4];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                frag<BK, AKC>(a[i], As, wm * 64 + i * 32 + l31, g, lh);
-                frag<BK, BKC>(b[i], Bs, wn * 64 + i * 32 + l31, g, lh);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n)
-                        acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[n][j], acc[i][n], 0, 0, 0);
-        }
-        {
-            float* Sn = smem + (cur ^ 1) * STAGE;
-            r2s<BK, AKC>(ra, Sn, tid);
-            r2s<BK, BKC>(rb, Sn + TA::SIZE, tid);
+        for (int i = 0; i < 2; ++i) {
+            frag<BK, AKC>(a[i], As, wm * 64 + i * 32 + l31, g, lh);
+            frag<BK, BKC>(b[i], Bs, wn * 64 + i * 32 + l31, g, lh);
         }
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, NMF - 2 * NLD, 0);
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // 1 DS write
-        }
-        __syncthreads();
-        cur ^= 1;
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[n][j], acc[i][n], 0, 0, 0);
     }
-    return cur;
+    if constexpr (SUM) {
+#pragma unroll
+        for (int q = 0; q < BK / 8; ++q) {
+            cs.x = fmaf(csf[q], ca[q].x, cs.x); cs.y = fmaf(csf[q], ca[q].y, cs.y);
+            cs.z = fmaf(csf[q], ca[q].z, cs.z); cs.w = fmaf(csf[q], ca[q].w, cs.w);
+        }
+    }
+    {
+        float* Sn = smem + (cur ^ 1) * STAGE;
+        r2s<BK, AKC>(ca, Sn, tid);
+        r2s<BK, BKC>(cb, Sn + TA::SIZE, tid);
+    }
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, NMF - 2 * NLD, 0);
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);   // 1 DS write
+    }
+    __syncthreads();
 }
 
 // The partial last k-tile sits in LDS stage `cur` as the LAST BK columns of the k range: k-groups [g0, BK/8) are new.
@@ -296,19 +294,54 @@ __global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const 
         const unsigned katail = (unsigned)(kend - BK) * ua, kbtail = (unsigned)(kend - BK) * ub;
         const unsigned ka = nfull > 0 ? (unsigned)kbeg * ua : katail;
         const unsigned kb = nfull > 0 ? (unsigned)kbeg * ub : kbtail;
-        g2r_fast<BK>(ra, rsa, ka, offa);
-        g2r_fast<BK>(rb, rsb, kb, offb);
+        // tile t of this block's k range: whole tiles in order, then the shifted partial tile; tiles past the end are
+        // fetched too (any valid address: the first tile) and never used.  All scalar.
+        const unsigned astep = BK * ua, bstep = BK * ub;
+        auto ka_of = [&](int t) -> unsigned { return t < nfull ? ka + (unsigned)t * astep : ((t == nfull && has_tail) ? katail : ka); };
+        auto kb_of = [&](int t) -> unsigned { return t < nfull ? kb + (unsigned)t * bstep : ((t == nfull && has_tail) ? kbtail : kb); };
+        [[maybe_unused]] float tailmask[BK / 8], csf[BK / 8];
+        auto set_csf = [&](int t) {                       // weights of tile t in the row sums (CS variants)
+            if constexpr (CS) {
+#pragma unroll
+                for (int q = 0; q < BK / 8; ++q) csf[q] = t < nfull ? 1.f : ((t == nfull && has_tail) ? tailmask[q] : 0.f);
+            }
+        };
+        if constexpr (CS) {
+#pragma unroll
+            for (int q = 0; q < BK / 8; ++q) tailmask[q] = (tid + NT * q) / 32 >= BK - rem ? 1.f : 0.f;
+        }
+        float4 ra2[BK / 8], rb2[BK / 8];
+        g2r_fast<BK>(ra, rsa, ka_of(0), offa);
+        g2r_fast<BK>(rb, rsb, kb_of(0), offb);
+        if constexpr (CS) {
+            set_csf(0);
+#pragma unroll
+            for (int q = 0; q < BK / 8; ++q) {
+                cs.x = fmaf(csf[q], ra[q].x, cs.x); cs.y = fmaf(csf[q], ra[q].y, cs.y);
+                cs.z = fmaf(csf[q], ra[q].z, cs.z); cs.w = fmaf(csf[q], ra[q].w, cs.w);
+            }
+        }
         r2s<BK, AKC>(ra, smem, tid);
         r2s<BK, BKC>(rb, smem + TA::SIZE, tid);
+        g2r_fast<BK>(ra, rsa, ka_of(1), offa);            // tile 1: in flight until the first step commits it
+        g2r_fast<BK>(rb, rsb, kb_of(1), offb);
         __syncthreads();
-        const int cur = gemm_k_loop_fast<BK, AKC, BKC, CS>(acc, ra, rb, cs, smem, rsa, rsb, ka, kb, BK * ua, BK * ub, katail, kbtail,
-                                                           offa, offb, nfull, has_tail, tid, wm, wn, l31, lh);
+        int cur = 0, kt = 0;
+        for (; kt + 1 < nfull; kt += 2) {
+            set_csf(kt + 1);
+            gemm_k_step<BK, AKC, BKC, CS>(acc, ra2, rb2, ra, rb, cs, csf, smem, cur, rsa, rsb, ka_of(kt + 2), kb_of(kt + 2), offa, offb,
+                                          tid, wm, wn, l31, lh);
+            set_csf(kt + 2);
+            gemm_k_step<BK, AKC, BKC, CS>(acc, ra, rb, ra2, rb2, cs, csf, smem, cur ^ 1, rsa, rsb, ka_of(kt + 3), kb_of(kt + 3), offa, offb,
+                                          tid, wm, wn, l31, lh);
+        }
+        if (kt < nfull) {
+            set_csf(kt + 1);
+            gemm_k_step<BK, AKC, BKC, CS>(acc, ra2, rb2, ra, rb, cs, csf, smem, cur, rsa, rsb, ka_of(kt + 2), kb_of(kt + 2), offa, offb,
+                                          tid, wm, wn, l31, lh);
+            cur ^= 1;
+        }
         if (has_tail) {
-            if constexpr (CS) {   // ra holds the tail tile: only its new k-rows (kk >= BK - rem) belong to the row sums
-#pragma unroll
-                for (int q = 0; q < BK / 8; ++q)
-                    if ((tid + NT * q) / 32 >= BK - rem) { cs.x += ra[q].x; cs.y += ra[q].y; cs.z += ra[q].z; cs.w += ra[q].w; }
-            }
             tail_mma<BK, AKC, BKC>(acc, smem, cur, (BK - rem) >> 3, wm, wn, l31, lh);
             __syncthreads();                                  // the epilogue re-uses the LDS block
         }
