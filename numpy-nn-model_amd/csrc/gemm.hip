@@ -7,10 +7,11 @@
 // Structure (MI355X-first, not a CUTLASS translation):
 //   * block = 256 threads = 4 wave64 in a 2x2 grid; block tile 128x128; wave tile 64x64 =
 //     2x2 MFMA 32x32 tiles -> 4 x f32x16 accumulators (64 acc registers / lane);
-//   * K is walked in BK-deep tiles, global -> registers -> LDS with a 2-stage LDS ring:
-//     the global loads of tile t+1 are issued before the MFMAs of tile t and written to the
-//     other LDS stage after them -> one __syncthreads per tile, HBM/L2 latency hidden under
-//     64-cycle MFMAs; 2 blocks/CU (2 waves/SIMD) cover each other's barrier/LDS phases;
+//   * K is walked in BK-deep tiles, global -> registers -> LDS with a 2-stage LDS ring and two register staging sets:
+//     tile t+2 is fetched while tile t is multiplied and tile t+1 goes to the other LDS stage -> one __syncthreads per
+//     tile, two iterations of 64-cycle MFMAs to hide a load; 2 blocks/CU (2 waves/SIMD) cover each other's barrier/LDS
+//     phases.  The fp32 MFMA runs on the vector ALU's lanes, so the loop carries NO vector instruction
+//     besides the MFMAs: operands come through buffer descriptors with scalar k offsets (gemm_common.h);
 //   * each operand is either "k-major" (reduction dim contiguous in memory) or "outer-major";
 //     k-major tiles live in LDS as [128][BK+4] (row stride 36 floats = conflict-free
 //     ds_read_b128 of 4 consecutive k per lane), outer-major tiles as [BK][128] (ds_read_b32, the
