@@ -8,6 +8,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 template <int MODE, int K>
 __global__ __launch_bounds__(512) void probe(float* out, int iters, long long* cyc) {
@@ -17,7 +18,7 @@ __global__ __launch_bounds__(512) void probe(float* out, int iters, long long* c
     float x = threadIdx.x * 1e-3f, y = 1.0f;
     float v[8];
     for (int i = 0; i < 8; ++i) v[i] = x + i;
-    const bool do_mfma = MODE == 0 || MODE == 3 || (MODE == 2 && (wave >> 2) == 0);   // waves 0-3 -> SIMDs 0-3, waves 4-7 -> SIMDs 0-3 again
+    const bool do_mfma = MODE == 0 || MODE == 3 || MODE == 4 || (MODE == 2 && (wave >> 2) == 0);   // waves 0-3 -> SIMDs 0-3, waves 4-7 -> SIMDs 0-3 again
     const bool do_valu = MODE == 1 || (MODE == 2 && (wave >> 2) == 1);
     const long long t0 = clock64();
     if (MODE == 3) {
@@ -30,6 +31,24 @@ __global__ __launch_bounds__(512) void probe(float* out, int iters, long long* c
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, K, 0);
                 a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, x, a1, 0, 0, 0);
+#pragma unroll
+                for (int k = 0; k < K; ++k) v[(k + 4) & 7] = __builtin_fmaf(v[(k + 4) & 7], 1.0001f, 0.5f);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, K, 0);
+            }
+        }
+    } else if (MODE == 4) {       // bf16 (XDL) MFMA 32x32x16 + K independent VALU per MFMA, same wave
+        bf16x8 ba, bb;
+        for (int i = 0; i < 8; ++i) { ba[i] = (__bf16)(x + i); bb[i] = (__bf16)(y - i); }
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ba, bb, a0, 0, 0, 0);
+#pragma unroll
+                for (int k = 0; k < K; ++k) v[k & 7] = __builtin_fmaf(v[k & 7], 1.0001f, 0.5f);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, K, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bb, ba, a1, 0, 0, 0);
 #pragma unroll
                 for (int k = 0; k < K; ++k) v[(k + 4) & 7] = __builtin_fmaf(v[(k + 4) & 7], 1.0001f, 0.5f);
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -89,5 +108,11 @@ int main() {
     run<3, 8>("3: each MFMA + 8 VALU (same wave)", iters);
     run<3, 12>("3: each MFMA + 12 VALU (same wave)", iters);
     run<3, 14>("3: each MFMA + 14 VALU (same wave)", iters);
+    // bf16 32x32x16 MFMA: 8 passes = 32 cycles each; 16 per iteration per wave, 2 waves per SIMD -> 1024 cycles / iter
+    run<4, 0>("4: bf16 MFMA 32x32x16 only (16/iter)", iters);
+    run<4, 2>("4: each bf16 MFMA + 2 VALU (same wave)", iters);
+    run<4, 4>("4: each bf16 MFMA + 4 VALU (same wave)", iters);
+    run<4, 6>("4: each bf16 MFMA + 6 VALU (same wave)", iters);
+    run<4, 8>("4: each bf16 MFMA + 8 VALU (same wave)", iters);
     return 0;
 }
