@@ -494,46 +494,76 @@ def workload_c4(args, rank, world):
     active = [p for p in params if p.grad is not None]
     opt.zero_grad()
     overlap = world > 1 and bool(args.overlap) and os.environ.get("NNHIP_DP_OVERLAP", "1") != "0"
-    bucket = GradBucket(active, extra_scalars=1, overlap=overlap)
-    state["bucket"] = bucket
+
+    def make(overlap, use_graph):
+        """Bucket + step function for one exchange / launch mode, exercised once."""
+        opt.zero_grad()
+        bucket = GradBucket(active, extra_scalars=1, overlap=overlap)
+        state["bucket"] = bucket
+        if world > 1:
+            opt.grad_divisor = bucket.extra              # g / (all-reduced non-PAD count), inside the Adam kernel
+        gstep = None
+        if use_graph:
+            gstep = GraphedTrainStep(fwd_bwd, opt, bucket, warmup=2, world=world)
+
+            def step(timed):
+                if timed:
+                    a, b = ev.span()
+                    a.record()
+                gstep()
+                if timed:
+                    b.record()
+        else:
+            def step(timed):
+                if timed:
+                    a, b = ev.span()
+                    a.record()
+                opt.zero_grad()
+                fwd_bwd()
+                bucket.all_reduce()
+                opt.step()
+                if timed:
+                    b.record()
+        try:
+            step(False)
+            torch.cuda.synchronize()
+        except Exception:
+            if gstep is not None:
+                gstep.release()
+            raise
+        return step, gstep, bucket
+
+    # N > 1 has only ever run on gloo here (one GPU per box): if RCCL refuses the overlapped / captured exchange, fall back
+    # to the plainer modes instead of losing the measurement (every rank takes the same path: the failure modes are
+    # structural, not data-dependent).  N = 1 takes the first mode.
+    modes = [(overlap, bool(args.graph))]
     if world > 1:
-        opt.grad_divisor = bucket.extra              # g / (all-reduced non-PAD count), inside the Adam kernel
-
-    if args.graph:
-        gstep = GraphedTrainStep(fwd_bwd, opt, bucket, warmup=2, world=world)
-
-        def step(timed):
-            if timed:
-                a, b = ev.span()
-                a.record()
-            gstep()
-            if timed:
-                b.record()
-    else:
-        def step(timed):
-            if timed:
-                a, b = ev.span()
-                a.record()
-            opt.zero_grad()
-            fwd_bwd()
-            bucket.all_reduce()
-            opt.step()
-            if timed:
-                b.record()
+        modes += [(False, bool(args.graph)), (False, False)]
+    step = gstep = bucket = None
+    for i, (ov, gr) in enumerate(modes):
+        try:
+            step, gstep, bucket = make(ov, gr)
+            overlap, args_graph = ov, gr
+            break
+        except Exception as exc:  # noqa: BLE001
+            if i + 1 == len(modes):
+                raise
+            print(f"[bench] C4 step with overlap={ov} graph={gr} failed ({exc!r}); trying the next mode", file=sys.stderr)
+    use_graph = args_graph
 
     dt = timed_region(step, args.steps, args.warmup, world)
     dev_ms = ev.mean_ms()
     fl = c4_flops(B, T)
     ach = fl / (dev_ms * 1e-3) / 1e12
     n_grad = sum(int(np.prod(p.shape)) for p in active)
-    pieces = len(getattr(gstep, "pieces", [])) if args.graph else 0
-    if args.graph:
+    pieces = len(getattr(gstep, "pieces", [])) if use_graph else 0
+    if use_graph:
         gstep.release()
     return {
         "samples_per_step": B * world, "dt": dt,
         "config": {"workload": f"C4: GPT-tiny d512 L6 H8 d_ff2048 vocab15000 training step, batch {B} x seq {T} per GPU, "
                                "Adam(1.5e-4), dropout 0", "global_batch": B * world, "seq_len": T,
-                   "parallelism": f"dp{world}", "launch": "hipGraph replay" if args.graph else "eager"},
+                   "parallelism": f"dp{world}", "launch": "hipGraph replay" if use_graph else "eager"},
         "roofline": {"kernel": "whole step, GEMM flops only (fp32 MFMA gemm_f32_kernel family: Linear fwd/dX/dW + attention)",
                      "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "flops_per_step": fl,
@@ -541,7 +571,7 @@ def workload_c4(args, rank, world):
         "extra": {"tokens_per_s": round(B * world * T * args.steps / dt, 1), "grad_floats": n_grad,
                   "dp_exchange": ("none" if world == 1 else
                                   (f"{len(bucket.segments)} bucket segments, async all-reduce overlapped with backward"
-                                   + (f" ({pieces} graph pieces)" if args.graph else "") if overlap
+                                   + (f" ({pieces} graph pieces)" if use_graph else "") if overlap
                                    else "one blocking all-reduce of the flat bucket"))},
     }
 
@@ -760,23 +790,38 @@ def workload_headline(args, rank, world):
     # C1: MNIST-MLP, sustained
     a1 = copy.copy(args)
     a1.steps, a1.warmup = args.c1_steps, 20
-    r1 = workload_c1(a1, rank, world)
-    also["c1"] = {"workload": r1["config"]["workload"], "samples_per_s": round(r1["samples_per_step"] * a1.steps / r1["dt"], 1),
-                  "ms_per_step": round(r1["dt"] / a1.steps * 1e3, 5), "steps": a1.steps,
-                  "device_ms_per_step": r1["roofline"].get("avg_step_device_ms"), "launch": r1["config"].get("launch")}
+    def guarded(name, fn):
+        # the headline value (C4) is already measured: a side workload that fails (N > 1 has only run on gloo here) is
+        # reported as such instead of taking the JSON line down with it
+        try:
+            fn()
+        except Exception as exc:  # noqa: BLE001
+            also[name] = {"error": repr(exc)[:300]}
+            print(f"[bench] also.{name} failed: {exc!r}", file=sys.stderr)
+
+    def run_c1():
+        r1 = workload_c1(a1, rank, world)
+        also["c1"] = {"workload": r1["config"]["workload"], "samples_per_s": round(r1["samples_per_step"] * a1.steps / r1["dt"], 1),
+                      "ms_per_step": round(r1["dt"] / a1.steps * 1e3, 5), "steps": a1.steps,
+                      "device_ms_per_step": r1["roofline"].get("avg_step_device_ms"), "launch": r1["config"].get("launch")}
+    guarded("c1", run_c1)
     # C2: the whole Linear training step
     a2 = copy.copy(args)
     a2.steps, a2.warmup = 20, 5
-    r2 = workload_c2(a2, rank, world)
-    also["c2"] = {"workload": r2["config"]["workload"], "samples_per_s": round(r2["samples_per_step"] * a2.steps / r2["dt"], 1),
-                  "ms_per_step": round(r2["dt"] / a2.steps * 1e3, 4), "linear_fwd_tflops_in_step": r2["extra"]["linear_fwd_tflops"],
-                  "linear_bwd_tflops_in_step": r2["extra"]["linear_bwd_tflops"]}
+
+    def run_c2():
+        r2 = workload_c2(a2, rank, world)
+        also["c2"] = {"workload": r2["config"]["workload"], "samples_per_s": round(r2["samples_per_step"] * a2.steps / r2["dt"], 1),
+                      "ms_per_step": round(r2["dt"] / a2.steps * 1e3, 4), "linear_fwd_tflops_in_step": r2["extra"]["linear_fwd_tflops"],
+                      "linear_bwd_tflops_in_step": r2["extra"]["linear_bwd_tflops"]}
+    guarded("c2", run_c2)
     # opt-in split-bf16 GEMM mode (fp32 operands split exactly into 3 bf16 pieces, 6 products on the bf16 matrix cores):
     # reported NEXT TO the exact-fp32 numbers above, never instead of them
     if os.environ.get("NNHIP_BENCH_BF16X3", "1") != "0":
         from neunet_hip._lib import call_hip_function
         call_hip_function("nnhipSetGemmMode", 1)
-        try:
+
+        def run_bf3():
             f3 = c2_forward_roofline(iters=30, sustain_s=1.0)
             a4 = copy.copy(args)
             a4.steps, a4.warmup = 10, 3
@@ -792,6 +837,8 @@ def workload_headline(args, rank, world):
                 "c4_samples_per_s": round(r4["samples_per_step"] * a4.steps / r4["dt"], 2),
                 "c4_ms_per_step": round(r4["dt"] / a4.steps * 1e3, 4),
             }
+        try:
+            guarded("bf16x3", run_bf3)
         finally:
             call_hip_function("nnhipSetGemmMode", 0)
     res["extra"]["also"] = also
