@@ -241,6 +241,13 @@ __global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const 
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, lh = lane >> 5;
+#ifdef GEMM_PROF
+    long long ts_[5];
+    ts_[0] = clock64();
+#define GP_STAMP(i) ts_[i] = clock64()
+#else
+#define GP_STAMP(i) do {} while (0)
+#endif
     // ---- block id -> (split, tile_m, tile_n): XCD-aware grouped order --------------------------
     // (A persistent variant -- one block per resident slot walking tiles b, b + grid, ... so that a tile's stores drain under
     //  the same waves' next tile -- was measured in round 2 on top of the buffer-load fetch: no gain on any shape, and the
@@ -327,6 +334,7 @@ __global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const 
         g2r_fast<BK>(ra, rsa, ka_of(1), offa);            // tile 1: in flight until the first step commits it
         g2r_fast<BK>(rb, rsb, kb_of(1), offb);
         __syncthreads();
+        GP_STAMP(1);
         int cur = 0, kt = 0;
         for (; kt + 1 < nfull; kt += 2) {
             set_csf(kt + 1);
@@ -346,6 +354,7 @@ __global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const 
             tail_mma<BK, AKC, BKC>(acc, smem, cur, (BK - rem) >> 3, wm, wn, l31, lh);
             __syncthreads();                                  // the epilogue re-uses the LDS block
         }
+        GP_STAMP(2);
     } else {
         const int nk = (int)((kend - kbeg + BK - 1) / BK);
         const float* __restrict__ Z = p.zeros;
@@ -360,7 +369,24 @@ __global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const 
         gemm_k_loop<BK, AKC, BKC, VEC, CS>(acc, ra, rb, cs, smem, A, B, p, nk, kbeg, kend, m0, n0, tid, wm, wn, l31, lh, Z);
     }
 
+#ifdef GEMM_PROF
+    long long ets_[5] = {0, 0, 0, 0, 0};
+    gemm_epilogue<CS>(acc, p, smem, cs, tid, wave, lane, wm, wn, l31, lh, m0, n0, tn, split, c_off, ets_);
+#else
     gemm_epilogue<CS>(acc, p, smem, cs, tid, wave, lane, wm, wn, l31, lh, m0, n0, tn, split, c_off);
+#endif
+#ifdef GEMM_PROF
+    if constexpr (VEC) {
+        GP_STAMP(3);                                          // epilogue issued
+        __builtin_amdgcn_s_waitcnt(0);                        // ... and its stores acknowledged
+        GP_STAMP(4);
+        if (p.prof && lane == 0) {
+            long long* o = p.prof + ((int64_t)blockIdx.x * 4 + wave) * 10;
+            o[0] = ts_[0]; o[1] = ts_[1]; o[2] = ts_[2]; o[3] = ts_[3]; o[4] = ts_[4];
+            for (int q_ = 0; q_ < 5; ++q_) o[5 + q_] = ets_[q_];
+        }
+    }
+#endif
 }
 
 // C[m,n] = sum_s slab[s][m][n] (+bias)(act).  One thread per float4 of a row (N%4 handled).
@@ -476,6 +502,10 @@ int gemm_small(const float* A, const float* B, float* C, const float* bias, floa
                int64_t lda, int64_t ldb, int64_t ldc, bool a_kmajor, bool b_kmajor, float alpha, int act, float beta,
                float* asum, const float* addend, const float* dact_arg, int dact, hipStream_t st);
 
+#ifdef GEMM_PROF
+static long long* g_gemm_prof = nullptr;
+extern "C" void nnhipGemmSetProfile(long long* buf) { g_gemm_prof = buf; }
+#endif
 int gemm_f32(const float* A, const float* B, float* C, const float* bias, float* preact, int64_t M,
              int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, bool a_kmajor,
              bool b_kmajor, int64_t batch, int64_t sA, int64_t sB, int64_t sC, int act, float beta,
@@ -537,6 +567,9 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
     p.act = act; p.beta = beta;
     p.splitk = 1; p.k_per_split = ceil_div(K > 0 ? K : 1, BK) * BK; p.slab = nullptr;
     p.asum = asum; p.asum_slab = nullptr; p.addend = addend; p.dswish = dswish; p.dact = dact;
+#ifdef GEMM_PROF
+    p.prof = g_gemm_prof;
+#endif
     p.zeros = zero_block();
     if (!p.zeros) { set_last_error("zero block allocation failed"); return NNHIP_ENOMEM; }
 

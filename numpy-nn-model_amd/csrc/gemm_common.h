@@ -22,6 +22,9 @@ struct GemmParams {
     int batch2;
     float alpha;            // C = alpha * (A B) + bias
     int tiles_m, tiles_n, splitk;
+#ifdef GEMM_PROF
+    long long* prof;      // developer instrumentation (tools/gemm_prof.py): per-block cycle stamps
+#endif
     int64_t k_per_split;  // multiple of BK
     float* slab;          // split-K partials [splitk][M][N] (dense)
     const float* zeros;   // >= 16 bytes of zeros: the load target of out-of-range lanes
@@ -123,7 +126,7 @@ __device__ __forceinline__ void g2r_fast(float4 (&r)[BK / 8], __amdgpu_buffer_rs
 template <bool CS>
 __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[2][2], const GemmParams& p, float* __restrict__ smem, float4 cs,
                                               int tid, int wave, int lane, int wm, int wn, int l31, int lh, int64_t m0,
-                                              int64_t n0, int tn, int split, int64_t c_off) {
+                                              int64_t n0, int tn, int split, int64_t c_off, long long* ets = nullptr) {
     // ---- epilogue ------------------------------------------------------------------------------------------
     // acc register e of a 32x32 MFMA tile holds row (e&3) + 8*(e>>2) + 4*lh, column l31: a lane owns a strided
     // COLUMN, so direct stores are 64 dword stores per lane (2 rows x 128 B per instruction) and the tail is
@@ -169,6 +172,9 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[2][2], const GemmPar
 #pragma unroll
             for (int it = 0; it < 8; ++it) fetch_extra(0, it);
         }
+#ifdef GEMM_PROF
+        if (ets) ets[0] = clock64();
+#endif
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -178,6 +184,9 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[2][2], const GemmPar
                     E[((e & 3) + 8 * (e >> 2) + 4 * lh) * ELD + n * 32 + l31] = acc[i][n][e];
             __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0); E is private to the wave: no block barrier needed
             __builtin_amdgcn_wave_barrier();
+#ifdef GEMM_PROF
+            if (ets) ets[1 + 2 * i] = clock64();
+#endif
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int rl = it * 4 + er;
@@ -215,6 +224,9 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[2][2], const GemmPar
             }
             __builtin_amdgcn_s_waitcnt(0xc07f);   // this group's LDS reads are done before the next group overwrites E
             __builtin_amdgcn_wave_barrier();
+#ifdef GEMM_PROF
+            if (ets) ets[2 + 2 * i] = clock64();
+#endif
         }
         return;
     }
