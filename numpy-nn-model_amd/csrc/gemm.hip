@@ -31,42 +31,6 @@
 namespace nnhip {
 
 
-template <int BK, bool KC>
-struct Tile {
-    static constexpr int LD = KC ? (BK + 4) : 128;
-    static constexpr int SIZE = KC ? 128 * (BK + 4) : BK * 128;  // floats
-    static constexpr int NV = BK / 8;                             // float4 per thread per tile
-};
-
-// registers -> LDS stage
-template <int BK, bool KC>
-__device__ __forceinline__ void r2s(const float4 (&r)[BK / 8], float* __restrict__ S, int tid) {
-#pragma unroll
-    for (int p = 0; p < BK / 8; ++p) {
-        const int idx = tid + NT * p;
-        if constexpr (KC) {
-            const int rr = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
-            *reinterpret_cast<float4*>(&S[rr * (BK + 4) + k4]) = r[p];
-        } else {
-            const int kk = idx / 32, r4 = (idx % 32) * 4;
-            *reinterpret_cast<float4*>(&S[kk * 128 + r4]) = r[p];
-        }
-    }
-}
-
-// Read the 4 MFMA operands (k = 8g+j [+4 for the upper half-wave], j = 0..3) of one 32-row subtile.
-template <int BK, bool KC>
-__device__ __forceinline__ void frag(float (&f)[4], const float* __restrict__ S, int row, int g,
-                                     int lh) {
-    if constexpr (KC) {
-        const float4 v = *reinterpret_cast<const float4*>(&S[row * (BK + 4) + g * 8 + lh * 4]);
-        f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) f[j] = S[(g * 8 + j + 4 * lh) * 128 + row];
-    }
-}
-
 // K loop.  One basic block per iteration; the issue order is pinned with sched_group_barrier so that the
 // 2*BK/8 global loads of tile t+1 ride in the shadow of the first MFMAs of tile t (one load per 64-cycle
 // MFMA) and the 2*BK/8 LDS stores in the shadow of the last ones -- the ablation (profiles/) showed the
@@ -496,6 +460,11 @@ static int gemm_mode() {
     return g_gemm_mode;
 }
 
+// gemm_pst.hip: the persistent variant for multi-generation forward GEMMs (stores and first-tile loads hidden in the k-step stream)
+bool gemm_pst_wanted(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, const float* A, const float* B,
+                     const float* C, const float* bias);
+int gemm_pst(const float* A, const float* B, float* C, const float* bias, int64_t M, int64_t N, int64_t K, int64_t lda,
+             int64_t ldb, int64_t ldc, float alpha, hipStream_t st);
 // gemm_small.hip: the latency-optimised kernel for problems of a few 32x32 tiles
 bool gemm_small_wanted(int64_t M, int64_t N, int64_t K, int64_t batch);
 int gemm_small(const float* A, const float* B, float* C, const float* bias, float* preact, int64_t M, int64_t N, int64_t K,
@@ -552,6 +521,9 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
     if (M <= 0 || N <= 0 || batch <= 0) return 0;
     if (addend && dswish) { set_last_error("gemm: addend and dswish are mutually exclusive"); return NNHIP_EINVAL; }
     if (asum && (a_kmajor || batch != 1 || K <= 0)) { set_last_error("gemm: asum needs an outer-major, unbatched A"); return NNHIP_EINVAL; }
+    if (a_kmajor && b_kmajor && batch == 1 && !asum && !addend && !dswish && !preact && act == ACT_NONE && gemm_mode() == 0 &&
+        gemm_pst_wanted(M, N, K, lda, ldb, ldc, A, B, C, bias))
+        return gemm_pst(A, B, C, bias, M, N, K, lda, ldb, ldc, alpha, st);
     static const int small_on = []() { const char* e = getenv("NNHIP_GEMM_SMALL"); return e ? atoi(e) : 1; }();
     if (small_on && gemm_small_wanted(M, N, K, batch))
         return gemm_small(A, B, C, bias, preact, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, alpha, act, beta, asum, addend,

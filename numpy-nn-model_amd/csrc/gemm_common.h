@@ -78,6 +78,43 @@ __device__ __forceinline__ void g2r(float4 (&r)[BK / 8], const float* __restrict
     }
 }
 
+// ---- LDS staging shared by gemm.hip and gemm_pst.hip ---------------------------------------------------------------------
+template <int BK, bool KC>
+struct Tile {
+    static constexpr int LD = KC ? (BK + 4) : 128;
+    static constexpr int SIZE = KC ? 128 * (BK + 4) : BK * 128;  // floats
+    static constexpr int NV = BK / 8;                             // float4 per thread per tile
+};
+
+// registers -> LDS stage
+template <int BK, bool KC>
+__device__ __forceinline__ void r2s(const float4 (&r)[BK / 8], float* __restrict__ S, int tid) {
+#pragma unroll
+    for (int p = 0; p < BK / 8; ++p) {
+        const int idx = tid + NT * p;
+        if constexpr (KC) {
+            const int rr = idx / (BK / 4), k4 = (idx % (BK / 4)) * 4;
+            *reinterpret_cast<float4*>(&S[rr * (BK + 4) + k4]) = r[p];
+        } else {
+            const int kk = idx / 32, r4 = (idx % 32) * 4;
+            *reinterpret_cast<float4*>(&S[kk * 128 + r4]) = r[p];
+        }
+    }
+}
+
+// Read the 4 MFMA operands (k = 8g+j [+4 for the upper half-wave], j = 0..3) of one 32-row subtile.
+template <int BK, bool KC>
+__device__ __forceinline__ void frag(float (&f)[4], const float* __restrict__ S, int row, int g,
+                                     int lh) {
+    if constexpr (KC) {
+        const float4 v = *reinterpret_cast<const float4*>(&S[row * (BK + 4) + g * 8 + lh * 4]);
+        f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[j] = S[(g * 8 + j + 4 * lh) * 128 + row];
+    }
+}
+
 // ---- fast operand fetch (vectorised variants of gemm.hip) ---------------------------------------------------------------
 // The fp32 MFMA of gfx950 runs on the SAME lanes as the vector ALU (peak 157.3 TFLOP/s either way; a probe,
 // tools/probes/mfma_valu_probe.hip, shows VALU instructions add their ~3.3 cycles to the MFMA time instead of hiding under
