@@ -122,6 +122,34 @@ def test_gemm_fast_fetch_edges(hip, rows, inf, outf):
     np.testing.assert_allclose(host(db), dO64.sum(0, keepdims=True), rtol=1e-4, atol=1e-4 * np.sqrt(rows))
 
 
+@pytest.mark.parametrize("rows,inf,outf", [(8192, 64, 1100), (8192, 512, 1100), (16384, 96, 520), (4096, 992, 2200)])
+def test_gemm_persistent_forward(hip, rows, inf, outf):
+    """csrc/gemm_pst.hip: a forward Linear whose grid has more 128x128 tiles than resident slots (and K <= 1024, K % 32 == 0,
+    rows % 128 == 0) runs the persistent kernel -- one k-step stream across a block's tiles, the finished tile's stores inside the
+    next tile's first step.  Against float64, and BIT-IDENTICAL to the classic kernel, which the same rows take when they
+    are computed in chunks small enough to stay under the slot count (same k order, same fmaf chain; K < 1024 so that no
+    chunk takes the classic kernel's split-K, which sums in a different order)."""
+    from neunet_hip._lib import call_hip_function as call, get_current_stream_ptr
+    import torch
+    rng = np.random.default_rng(rows + inf + outf)
+    st = get_current_stream_ptr()
+    X = rng.standard_normal((rows, inf)).astype(np.float32)
+    W = (rng.standard_normal((outf, inf)) / np.sqrt(inf)).astype(np.float32)
+    b = rng.standard_normal((1, outf)).astype(np.float32)
+    x, w, bb = dev(X), dev(W), dev(b)
+    o = torch.full((rows, outf), float("nan"), device="cuda")
+    call("nnhipLinearModuleForward", x, w, bb, o, rows, inf, outf, st)
+    got = host(o)
+    np.testing.assert_allclose(got, X.astype(np.float64) @ W.astype(np.float64).T + b, rtol=1e-4, atol=1e-4 * np.sqrt(inf))
+    tiles_n = -(-outf // 128)
+    chunk = max(128, (400 // tiles_n) * 128)                   # <= 400 tiles per call: the classic kernel
+    o2 = torch.full((rows, outf), float("nan"), device="cuda")
+    for r0 in range(0, rows, chunk):
+        n = min(chunk, rows - r0)
+        call("nnhipLinearModuleForward", x[r0:r0 + n], w, bb, o2[r0:r0 + n], n, inf, outf, st)
+    np.testing.assert_array_equal(got, host(o2))
+
+
 @pytest.mark.parametrize("rows,inf,outf", [(300, 96, 200), (128, 512, 512), (37, 50, 33), (4096, 1024, 128)])
 def test_linear_addend_extensions(hip, rows, inf, outf):
     """nnhipLinearModuleForwardEx / BackwardEx: O = XW^T + b + R and dX = dO W + G from the GEMM epilogue (also through
