@@ -264,7 +264,8 @@ bool gemm_pst_wanted(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, 
     if (on < 2 && K > 1024) return false;
     if ((K % PBK) != 0 || K < 2 * PBK || (M % 128) != 0 || N <= 0) return false;
     if (!aligned16(A) || !aligned16(B) || (lda & 3) || (ldb & 3) || ((reinterpret_cast<uintptr_t>(C) | (bias ? reinterpret_cast<uintptr_t>(bias) : 0)) & 3)) return false;
-    if (M * ldc * 4 >= ((int64_t)1 << 32) || 128 * lda * 4 + K * 4 >= ((int64_t)1 << 32) || 128 * ldb * 4 + K * 4 >= ((int64_t)1 << 32)) return false;
+    // (C's byte size is the store descriptor's num_records and must stay below the 0xFFFFFFF0 offset that drops a lane)
+    if (M * ldc * 4 >= (int64_t)0xFFFF0000 || 128 * lda * 4 + K * 4 >= ((int64_t)1 << 32) || 128 * ldb * 4 + K * 4 >= ((int64_t)1 << 32)) return false;
     const int slots = pst_slots();
     if (slots <= 0) return false;
     const int64_t tiles = (M / 128) * ceil_div(N, 128);
