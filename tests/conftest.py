@@ -16,6 +16,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(autouse=True)
+def _seed_global_rng(request):
+    """The layers draw their initial weights from NumPy's GLOBAL generator (as the reference's do); seed it per test
+    (from the test id), so that a test which builds a layer sees the same weights in every run."""
+    import zlib
+
+    import numpy as np
+    np.random.seed(zlib.crc32(request.node.nodeid.encode()) & 0x7FFFFFFF)
+    yield
+
+
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np
