@@ -12,10 +12,17 @@
 //     FIRST k-step of the next tile (buffer_store_dword with scalar row offsets: the only vector instructions added to that
 //     step are the 64 alpha/bias FMAs), so there is no store phase either.
 // Same arithmetic as gemm_f32_kernel (same k order, same fmaf chain, alpha/bias applied the same way): bit-identical C.
-// Conditions (gemm_pst_wanted): both operands k-major and 16-B aligned rows, K % 32 == 0, K >= 64, M % 128 == 0,
-// bias-only epilogue, no split-K / batch, C and the operand windows addressable with 32-bit byte offsets, more tiles than
-// resident slots.  Everything else takes gemm.hip.
+// EPI = 1 is the fused Linear->Swish epilogue (neunet/nn/experimental/linear_swish/linear_swish_cutlass.cu: D = swish(z),
+// z = alpha A B^T + bias optionally stored as well): its two outputs double the store traffic, which gemm_f32_kernel pays as
+// an exposed burst per generation; here the pending tile goes out one row half under each of the next tile's first TWO k-steps
+// (all 128 stores per lane under one step saturate the CU's store path when both resident blocks flush together: measured no
+// gain; one per MFMA over two steps: 16384x512->2048 with z, 0.278 -> 0.255 ms).
+// Conditions (gemm_pst_wanted): both operands k-major and 16-B aligned rows, K % 32 == 0, K >= 64 (96 with Swish),
+// M % 128 == 0, bias-only or Swish epilogue, no split-K / batch, C and the operand windows addressable with 32-bit byte
+// offsets, more tiles than resident slots.  Everything else takes gemm.hip.
 #include <stdlib.h>
+
+#include <type_traits>
 
 #include "gemm_common.h"
 
@@ -27,8 +34,9 @@ constexpr int PSTAGE = 2 * PTile::SIZE;                        // A tile + B til
 
 struct PstParams {
     const float* A; const float* B; float* C; const float* bias;
+    float* preact;                                             // EPI 1: z output [M, ldc] or null
     int64_t M, N, K, lda, ldb, ldc;
-    float alpha;
+    float alpha, beta;
     int tiles_m, tiles_n, total;
 };
 
@@ -58,16 +66,38 @@ __device__ __forceinline__ void pst_tile(int vb, int total, int tiles_m, int til
     tn = (L % in_group) / gsz;
 }
 
-// one k-step: fetch the next k-tile (whatever tile it belongs to) into (ra, rb), multiply LDS stage `cur`, [flush the
-// pending tile's stores, one per MFMA,] commit (ra, rb) to the other stage.
-template <bool FLUSH>
-__device__ __forceinline__ void pst_step(f32x16 (&acc)[2][2], float4 (&ra)[4], float4 (&rb)[4], float* __restrict__ smem, int cur,
-                                         __amdgpu_buffer_rsrc_t fa, __amdgpu_buffer_rsrc_t fb, unsigned koff,
-                                         const unsigned (&offa)[4], const unsigned (&offb)[4], int tid, int wm, int wn, int l31,
-                                         int lh, const f32x16 (&pend)[2][2], const PstStore& ps, __amdgpu_buffer_rsrc_t rc,
-                                         unsigned vo, unsigned ldc4, float alpha) {
-    g2r_fast<PBK>(ra, fa, koff, offa);
-    g2r_fast<PBK>(rb, fb, koff, offb);
+// the stores of row half i (32 rows per wave) of the pending tile.  accumulator register e of tile (i, n): row
+// i*32 + (e&3) + 8(e>>2) (+ 4 lh + 64 wm: in vo), column n*32 + l31 (+ 64 wn: in vo)
+template <int EPI>
+__device__ __forceinline__ void pst_flush_half(int i, const f32x16 (&pend)[2][2], const PstStore& ps, __amdgpu_buffer_rsrc_t rc,
+                                               __amdgpu_buffer_rsrc_t rz, unsigned ldc4, float alpha, float beta) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const unsigned so = ps.soff + (unsigned)(i * 32 + (e & 3) + 8 * (e >> 2)) * ldc4;
+        float v0 = fmaf(alpha, pend[i][0][e], ps.b0), v1 = fmaf(alpha, pend[i][1][e], ps.b1);
+        if constexpr (EPI == 1) {
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), rz, ps.vo0, so, 0);   // rz has 0 records without a z output
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), rz, ps.vo1, so, 0);
+            v0 *= sigmoid_fast_(beta * v0);
+            v1 *= sigmoid_fast_(beta * v1);
+        }
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), rc, ps.vo0, so, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), rc, ps.vo1, so, 0);
+    }
+}
+
+// one k-step: fetch the next k-tile (whatever tile it belongs to) into (fa, fb), multiply LDS stage `cur`, [flush stores of
+// the pending tile, one per MFMA,] commit (fa, fb) to the other stage.  FLUSH: bit i = row half i of the pending tile goes out
+// in this step.  (A two-deep variant -- a second register set, the k-tile after next in flight -- was measured: no change at
+// K = 512, level with gemm_f32_kernel at K = 4096; not kept.)
+template <int EPI, int FLUSH>
+__device__ __forceinline__ void pst_step(f32x16 (&acc)[2][2], float4 (&fa)[4], float4 (&fb)[4],
+                                         float* __restrict__ smem, int cur, __amdgpu_buffer_rsrc_t rsa, __amdgpu_buffer_rsrc_t rsb,
+                                         unsigned koff, const unsigned (&offa)[4], const unsigned (&offb)[4], int tid, int wm, int wn,
+                                         int l31, int lh, const f32x16 (&pend)[2][2], const PstStore& ps, __amdgpu_buffer_rsrc_t rc,
+                                         __amdgpu_buffer_rsrc_t rz, unsigned ldc4, float alpha, float beta) {
+    g2r_fast<PBK>(fa, rsa, koff, offa);
+    g2r_fast<PBK>(fb, rsb, koff, offb);
     const float* As = smem + cur * PSTAGE;
     const float* Bs = As + PTile::SIZE;
 #pragma unroll
@@ -86,24 +116,16 @@ __device__ __forceinline__ void pst_step(f32x16 (&acc)[2][2], float4 (&ra)[4], f
                 for (int n = 0; n < 2; ++n)
                     acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[n][j], acc[i][n], 0, 0, 0);
     }
-    if constexpr (FLUSH) {
-        // accumulator register e of tile (i, n): row i*32 + (e&3) + 8(e>>2) (+ 4 lh + 64 wm: in vo), column n*32 + l31 (+ 64 wn: in vo)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const unsigned so = ps.soff + (unsigned)(i * 32 + (e & 3) + 8 * (e >> 2)) * ldc4;
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(fmaf(alpha, pend[i][0][e], ps.b0)), rc, ps.vo0, so, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(fmaf(alpha, pend[i][1][e], ps.b1)), rc, ps.vo1, so, 0);
-            }
-    }
+    if constexpr ((FLUSH & 1) != 0) pst_flush_half<EPI>(0, pend, ps, rc, rz, ldc4, alpha, beta);
+    if constexpr ((FLUSH & 2) != 0) pst_flush_half<EPI>(1, pend, ps, rc, rz, ldc4, alpha, beta);
     {
         float* Sn = smem + (cur ^ 1) * PSTAGE;
-        r2s<PBK, true>(ra, Sn, tid);
-        r2s<PBK, true>(rb, Sn + PTile::SIZE, tid);
+        r2s<PBK, true>(fa, Sn, tid);
+        r2s<PBK, true>(fb, Sn + PTile::SIZE, tid);
     }
-    // issue order: 8 loads under the first MFMAs, 8 LDS stores under the last ones; FLUSH: a store after every MFMA
-    if constexpr (FLUSH) {
+    // issue order: 8 loads under the first MFMAs, 8 LDS stores under the last ones; FLUSH: a store after every MFMA (the Swish
+    // epilogue's arithmetic goes wherever the scheduler likes: fp32 MFMAs and VALU share the lanes, it overlaps with nothing)
+    if constexpr (FLUSH != 0) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -137,6 +159,7 @@ __device__ __forceinline__ void pst_step(f32x16 (&acc)[2][2], float4 (&ra)[4], f
     __syncthreads();
 }
 
+template <int EPI>
 __global__ __launch_bounds__(NT, 2) void gemm_pst_kernel(const PstParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -158,6 +181,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_pst_kernel(const PstParams p) {
         return pst_rsrc(P + r0 * ld, (unsigned)(rows * ld * 4));
     };
     const __amdgpu_buffer_rsrc_t rc = pst_rsrc(p.C, (unsigned)(p.M * p.ldc * 4));
+    const __amdgpu_buffer_rsrc_t rz = pst_rsrc(p.preact ? p.preact : p.C, p.preact ? (unsigned)(p.M * p.ldc * 4) : 0u);
     const unsigned vo = (unsigned)(wm * 64 + 4 * lh) * ldc4 + (unsigned)(wn * 64 + l31) * 4u;
     auto store_of = [&](int tm, int tn) {
         PstStore s;
@@ -191,27 +215,33 @@ __global__ __launch_bounds__(NT, 2) void gemm_pst_kernel(const PstParams p) {
     __syncthreads();
 
     int cur = 0;
-    bool have_pend = false;
     PstStore ps = store_of(tm, tn);                               // placeholder until a tile is pending
-    for (;;) {
+    // one tile of the block's k-step stream.  PEND: a finished tile is waiting in `pend`; its stores go out under the first
+    // k-step (EPI 1, twice the stores: one row half under each of the first two).  Returns false after the block's last tile.
+    // (The first tile is peeled instead of testing a `have_pend` flag inside one loop: with the flag the kernel took 236 VGPRs --
+    // and spilled with the two-step flush; peeled it takes 152 / 208.)
+    auto run_tile = [&](auto pend_tag) -> bool {
+        constexpr bool PEND = decltype(pend_tag)::value;
+        constexpr int F0 = PEND ? (EPI == 1 ? 1 : 3) : 0, F1 = (PEND && EPI == 1) ? 2 : 0;
         const int vbn = vb + (int)gridDim.x;
         const bool has_next = vbn < p.total;
         int tmn = tm, tnn = tn;
         if (has_next) pst_tile(vbn, p.total, p.tiles_m, p.tiles_n, tmn, tnn);
         const __amdgpu_buffer_rsrc_t rsan = rs_of(p.A, p.lda, p.M, (int64_t)tmn * 128), rsbn = rs_of(p.B, p.ldb, p.N, (int64_t)tnn * 128);
         const PstStore mine = store_of(tm, tn);
-        // first k-step: flushes the pending tile (if any)
-        if (have_pend) pst_step<true>(acc, ra, rb, smem, cur, rsa, rsb, 128u, offa, offb, tid, wm, wn, l31, lh, pend, ps, rc, vo, ldc4, p.alpha);
-        else pst_step<false>(acc, ra, rb, smem, cur, rsa, rsb, 128u, offa, offb, tid, wm, wn, l31, lh, pend, ps, rc, vo, ldc4, p.alpha);
-        cur ^= 1;
-        for (int kt = 1; kt + 1 < nk; ++kt) {
-            pst_step<false>(acc, ra, rb, smem, cur, rsa, rsb, (unsigned)(kt + 1) * 128u, offa, offb, tid, wm, wn, l31, lh, pend, ps, rc, vo, ldc4,
-                            p.alpha);
-            cur ^= 1;
+#define PST_STEP(F, RA, RB, KOFF) \
+    pst_step<EPI, F>(acc, ra, rb, smem, cur, RA, RB, KOFF, offa, offb, tid, wm, wn, l31, lh, pend, ps, rc, rz, ldc4, p.alpha, p.beta); \
+    cur ^= 1
+        int kt = 1;
+        PST_STEP(F0, rsa, rsb, 128u);
+        if constexpr (EPI == 1) {
+            PST_STEP(F1, rsa, rsb, 256u);
+            kt = 2;
         }
+        for (; kt + 1 < nk; ++kt) { PST_STEP(0, rsa, rsb, (unsigned)(kt + 1) * 128u); }
         // last k-step: fetches the first k-tile of the next tile (or, with nothing left, re-reads this one's: never used)
-        pst_step<false>(acc, ra, rb, smem, cur, rsan, rsbn, 0u, offa, offb, tid, wm, wn, l31, lh, pend, ps, rc, vo, ldc4, p.alpha);
-        cur ^= 1;
+        PST_STEP(0, rsan, rsbn, 0u);
+#undef PST_STEP
         // the finished tile becomes the pending one
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -222,48 +252,53 @@ __global__ __launch_bounds__(NT, 2) void gemm_pst_kernel(const PstParams p) {
                 for (int e = 0; e < 16; ++e) acc[i][n][e] = 0.f;
             }
         ps = mine;
-        have_pend = true;
-        if (!has_next) break;
         vb = vbn; tm = tmn; tn = tnn; rsa = rsan; rsb = rsbn;
-    }
+        return has_next;
+    };
+    if (run_tile(std::false_type{}))
+        while (run_tile(std::true_type{})) {}
     // the block's last tile: nothing left to hide its stores under
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const unsigned so = ps.soff + (unsigned)(i * 32 + (e & 3) + 8 * (e >> 2)) * ldc4;
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(fmaf(p.alpha, pend[i][0][e], ps.b0)), rc, ps.vo0, so, 0);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(fmaf(p.alpha, pend[i][1][e], ps.b1)), rc, ps.vo1, so, 0);
-        }
+    pst_flush_half<EPI>(0, pend, ps, rc, rz, ldc4, p.alpha, p.beta);
+    pst_flush_half<EPI>(1, pend, ps, rc, rz, ldc4, p.alpha, p.beta);
 }
 
 // ---- host ---------------------------------------------------------------------------------------------------------
+template <int EPI>
+static int pst_slots_of() {
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    const size_t lds = 2 * PSTAGE * sizeof(float);
+    const void* k = reinterpret_cast<const void*>(gemm_pst_kernel<EPI>);
+    if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
+        hipGetDeviceProperties(&prop, dev) != hipSuccess || hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, NT, lds) != hipSuccess)
+        return -1;
+    return per_cu > 0 ? prop.multiProcessorCount * per_cu : -1;
+}
+
+// resident blocks of the whole chip (LDS admits two per CU for both variants), a multiple of the 8 XCDs
 static int pst_slots() {
-    static int slots = 0;
-    if (!slots) {
-        int per_cu = 0, dev = 0;
-        hipDeviceProp_t prop;
-        const size_t lds = 2 * PSTAGE * sizeof(float);
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pst_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
-            hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(gemm_pst_kernel), NT, lds) == hipSuccess && per_cu > 0)
-            slots = (prop.multiProcessorCount * per_cu) & ~7;
-        if (slots <= 0) slots = -1;
-    }
+    static const int slots = []() {
+        const int s = min(pst_slots_of<0>(), pst_slots_of<1>());
+        return s > 0 ? (s & ~7) : -1;
+    }();
     return slots;
 }
 
 // NNHIP_GEMM_PST: 0 = never, 1 (default) = when the conditions hold, 2 = also for long reductions
 bool gemm_pst_wanted(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, const float* A, const float* B,
-                     const float* C, const float* bias) {
+                     const float* C, const float* bias, int act, const float* preact) {
     static const int on = []() { const char* e = getenv("NNHIP_GEMM_PST"); return e ? atoi(e) : 1; }();
     if (!on) return false;
+    if (act != ACT_NONE && act != ACT_SWISH) return false;
+    if (act == ACT_NONE && preact) return false;
     // short reductions only (on = 2 lifts that: developer switch): measured on MI355X, 16384x512->15000 135 -> 141 TFLOP/s and
     // 16384x512->2048 129 -> 133, but K = 4096 shapes -2 % -- there the fixed cost is 1.5 % of a tile and gemm.hip's two-deep
-    // prefetch (for which this kernel has no registers left: 236 VGPRs) is worth more
+    // prefetch is worth more (with a two-deep prefetch of its own this kernel draws level there, no better: not kept)
     if (on < 2 && K > 1024) return false;
-    if ((K % PBK) != 0 || K < 2 * PBK || (M % 128) != 0 || N <= 0) return false;
-    if (!aligned16(A) || !aligned16(B) || (lda & 3) || (ldb & 3) || ((reinterpret_cast<uintptr_t>(C) | (bias ? reinterpret_cast<uintptr_t>(bias) : 0)) & 3)) return false;
+    // (the Swish epilogue's second flush step needs a third k-tile)
+    if ((K % PBK) != 0 || K < (act == ACT_SWISH ? 3 : 2) * PBK || (M % 128) != 0 || N <= 0) return false;
+    if (!aligned16(A) || !aligned16(B) || (lda & 3) || (ldb & 3) ||
+        ((reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(preact) | reinterpret_cast<uintptr_t>(bias)) & 3)) return false;
     // (C's byte size is the store descriptor's num_records and must stay below the 0xFFFFFFF0 offset that drops a lane)
     if (M * ldc * 4 >= (int64_t)0xFFFF0000 || 128 * lda * 4 + K * 4 >= ((int64_t)1 << 32) || 128 * ldb * 4 + K * 4 >= ((int64_t)1 << 32)) return false;
     const int slots = pst_slots();
@@ -272,13 +307,16 @@ bool gemm_pst_wanted(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, 
     return tiles > slots;
 }
 
-int gemm_pst(const float* A, const float* B, float* C, const float* bias, int64_t M, int64_t N, int64_t K, int64_t lda,
-             int64_t ldb, int64_t ldc, float alpha, hipStream_t st) {
+int gemm_pst(const float* A, const float* B, float* C, const float* bias, float* preact, int64_t M, int64_t N, int64_t K,
+             int64_t lda, int64_t ldb, int64_t ldc, float alpha, int act, float beta, hipStream_t st) {
     PstParams p;
-    p.A = A; p.B = B; p.C = C; p.bias = bias; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.alpha = alpha;
+    p.A = A; p.B = B; p.C = C; p.bias = bias; p.preact = preact; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.alpha = alpha; p.beta = beta;
     p.tiles_m = (int)(M / 128); p.tiles_n = (int)ceil_div(N, 128); p.total = p.tiles_m * p.tiles_n;
     const size_t lds = 2 * PSTAGE * sizeof(float);
-    hipLaunchKernelGGL(gemm_pst_kernel, dim3((unsigned)pst_slots()), dim3(NT), lds, st, p);
+    const dim3 grid((unsigned)pst_slots()), block(NT);
+    if (act == ACT_SWISH) hipLaunchKernelGGL(gemm_pst_kernel<1>, grid, block, lds, st, p);
+    else hipLaunchKernelGGL(gemm_pst_kernel<0>, grid, block, lds, st, p);
     NNHIP_LAUNCH_CHECK("gemm_pst_kernel");
     return 0;
 }

@@ -150,6 +150,41 @@ def test_gemm_persistent_forward(hip, rows, inf, outf):
     np.testing.assert_array_equal(got, host(o2))
 
 
+@pytest.mark.parametrize("rows,inf,outf,beta,save", [(8192, 96, 1100, 1.0, 1), (16384, 512, 2048, 1.0, 1), (8192, 128, 1100, 1.5, 0),
+                                                     (4096, 992, 2200, 0.7, 1)])
+def test_gemm_persistent_swish(hip, rows, inf, outf, beta, save):
+    """The fused Linear->Swish forward (nnhipLinearSwishForward, with and without the saved pre-activation) on the persistent
+    kernel's Swish epilogue: against the float64 oracle formula, and BIT-IDENTICAL (both outputs) to the classic kernel's
+    epilogue, which row chunks under the slot count take."""
+    from neunet_hip._lib import call_hip_function as call, get_current_stream_ptr
+    import torch
+    rng = np.random.default_rng(rows + inf + outf)
+    st = get_current_stream_ptr()
+    X = rng.standard_normal((rows, inf)).astype(np.float32)
+    W = (rng.standard_normal((outf, inf)) / np.sqrt(inf)).astype(np.float32)
+    b = rng.standard_normal((1, outf)).astype(np.float32)
+    x, w, bb = dev(X), dev(W), dev(b)
+    o = torch.full((rows, outf), float("nan"), device="cuda")
+    z = torch.full((rows, outf), float("nan"), device="cuda")
+    call("nnhipLinearSwishForward", x, w, bb, o, z if save else None, rows, inf, outf, beta, save, st)
+    z64 = X.astype(np.float64) @ W.astype(np.float64).T + b
+    np.testing.assert_allclose(host(o), z64 / (1.0 + np.exp(-beta * z64)), rtol=1e-4, atol=1e-4 * np.sqrt(inf))
+    if save:
+        np.testing.assert_allclose(host(z), z64, rtol=1e-4, atol=1e-4 * np.sqrt(inf))
+    else:
+        assert bool(torch.isnan(z).all())                      # nothing may be written without save_preactivation
+    tiles_n = -(-outf // 128)
+    chunk = max(128, (400 // tiles_n) * 128)
+    o2, z2 = torch.empty_like(o), torch.empty_like(z)
+    for r0 in range(0, rows, chunk):
+        n = min(chunk, rows - r0)
+        call("nnhipLinearSwishForward", x[r0:r0 + n], w, bb, o2[r0:r0 + n], z2[r0:r0 + n] if save else None, n, inf, outf, beta,
+             save, st)
+    assert torch.equal(o, o2)
+    if save:
+        assert torch.equal(z, z2)
+
+
 @pytest.mark.parametrize("rows,inf,outf", [(300, 96, 200), (128, 512, 512), (37, 50, 33), (4096, 1024, 128)])
 def test_linear_addend_extensions(hip, rows, inf, outf):
     """nnhipLinearModuleForwardEx / BackwardEx: O = XW^T + b + R and dX = dO W + G from the GEMM epilogue (also through
