@@ -462,9 +462,10 @@ static int gemm_mode() {
 
 // gemm_pst.hip: the persistent variant for multi-generation forward GEMMs (stores and first-tile loads hidden in the k-step stream)
 bool gemm_pst_wanted(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, const float* A, const float* B,
-                     const float* C, const float* bias, int act, const float* preact);
+                     const float* C, const float* bias, bool b_kmajor, int act, const float* preact, const float* dswish, int dact);
 int gemm_pst(const float* A, const float* B, float* C, const float* bias, float* preact, int64_t M, int64_t N, int64_t K,
-             int64_t lda, int64_t ldb, int64_t ldc, float alpha, int act, float beta, hipStream_t st);
+             int64_t lda, int64_t ldb, int64_t ldc, bool b_kmajor, float alpha, int act, float beta, const float* dswish, int dact,
+             hipStream_t st);
 // gemm_small.hip: the latency-optimised kernel for problems of a few 32x32 tiles
 bool gemm_small_wanted(int64_t M, int64_t N, int64_t K, int64_t batch);
 int gemm_small(const float* A, const float* B, float* C, const float* bias, float* preact, int64_t M, int64_t N, int64_t K,
@@ -521,9 +522,9 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
     if (M <= 0 || N <= 0 || batch <= 0) return 0;
     if (addend && dswish) { set_last_error("gemm: addend and dswish are mutually exclusive"); return NNHIP_EINVAL; }
     if (asum && (a_kmajor || batch != 1 || K <= 0)) { set_last_error("gemm: asum needs an outer-major, unbatched A"); return NNHIP_EINVAL; }
-    if (a_kmajor && b_kmajor && batch == 1 && !asum && !addend && !dswish && gemm_mode() == 0 &&
-        gemm_pst_wanted(M, N, K, lda, ldb, ldc, A, B, C, bias, act, preact))
-        return gemm_pst(A, B, C, bias, preact, M, N, K, lda, ldb, ldc, alpha, act, beta, st);
+    if (a_kmajor && batch == 1 && !asum && !addend && gemm_mode() == 0 &&
+        gemm_pst_wanted(M, N, K, lda, ldb, ldc, A, B, C, bias, b_kmajor, act, preact, dswish, dact))
+        return gemm_pst(A, B, C, bias, preact, M, N, K, lda, ldb, ldc, b_kmajor, alpha, act, beta, dswish, dact, st);
     static const int small_on = []() { const char* e = getenv("NNHIP_GEMM_SMALL"); return e ? atoi(e) : 1; }();
     if (small_on && gemm_small_wanted(M, N, K, batch))
         return gemm_small(A, B, C, bias, preact, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, alpha, act, beta, asum, addend,

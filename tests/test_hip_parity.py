@@ -185,6 +185,49 @@ def test_gemm_persistent_swish(hip, rows, inf, outf, beta, save):
         assert torch.equal(z, z2)
 
 
+@pytest.mark.parametrize("rows,inf,outf,inplace", [(8192, 1100, 160, True), (16384, 2048, 512, True), (8192, 1100, 192, False),
+                                                   (4096, 2200, 992, True)])
+def test_gemm_persistent_input_grad(hip, rows, inf, outf, inplace):
+    """The input-gradient layout (B = W outer-major) on the persistent kernel: plain dX = dO W, and
+    nnhipLinearInputGradSwish's dZ = (dO W) * swish'(z) -- in place over z, as the fused Linear->Swish backward uses it, and
+    out of place -- whose z values are fetched a k-step ahead of the quarter of the tile they scale.  Against float64, and
+    BIT-IDENTICAL to the classic kernel (row chunks under the slot count)."""
+    from neunet_hip._lib import call_hip_function as call, get_current_stream_ptr
+    import torch
+    rng = np.random.default_rng(rows + inf + outf)
+    st = get_current_stream_ptr()
+    beta = 1.25
+    dO = rng.standard_normal((rows, outf)).astype(np.float32)
+    W = (rng.standard_normal((outf, inf)) / np.sqrt(outf)).astype(np.float32)
+    Z = rng.standard_normal((rows, inf)).astype(np.float32) * 2
+    X = rng.standard_normal((rows, inf)).astype(np.float32)
+    g, w, x = dev(dO), dev(W), dev(X)
+    tiles_n = -(-inf // 128)
+    chunk = max(128, (400 // tiles_n) * 128)
+    dx64 = dO.astype(np.float64) @ W.astype(np.float64)
+    # plain dX
+    dx = torch.full((rows, inf), float("nan"), device="cuda")
+    call("nnhipLinearModuleBackward", x, w, g, dx, None, None, rows, inf, outf, st)
+    np.testing.assert_allclose(host(dx), dx64, rtol=1e-4, atol=1e-4 * np.sqrt(outf))
+    dx2 = torch.empty_like(dx)
+    for r0 in range(0, rows, chunk):
+        n = min(chunk, rows - r0)
+        call("nnhipLinearModuleBackward", x[r0:r0 + n], w, g[r0:r0 + n], dx2[r0:r0 + n], None, None, n, inf, outf, st)
+    assert torch.equal(dx, dx2)
+    # dZ = dX * swish'(z)
+    z = dev(Z)
+    dz = z.clone() if inplace else torch.full((rows, inf), float("nan"), device="cuda")
+    call("nnhipLinearInputGradSwish", g, w, dz if inplace else z, dz, rows, inf, outf, beta, st)
+    s64 = 1.0 / (1.0 + np.exp(-beta * Z.astype(np.float64)))
+    f64 = Z * s64
+    np.testing.assert_allclose(host(dz), dx64 * (beta * f64 + s64 * (1 - beta * f64)), rtol=1e-4, atol=2e-4 * np.sqrt(outf))
+    dz2 = z.clone()
+    for r0 in range(0, rows, chunk):
+        n = min(chunk, rows - r0)
+        call("nnhipLinearInputGradSwish", g[r0:r0 + n], w, dz2[r0:r0 + n], dz2[r0:r0 + n], n, inf, outf, beta, st)
+    assert torch.equal(dz, dz2)
+
+
 @pytest.mark.parametrize("rows,inf,outf", [(300, 96, 200), (128, 512, 512), (37, 50, 33), (4096, 1024, 128)])
 def test_linear_addend_extensions(hip, rows, inf, outf):
     """nnhipLinearModuleForwardEx / BackwardEx: O = XW^T + b + R and dX = dO W + G from the GEMM epilogue (also through

@@ -83,6 +83,10 @@ def main():
         O5, Z5 = torch.empty(16384, 2048, device=dev), torch.empty(16384, 2048, device=dev)
         report("linear_swish fwd 16384x512->2048 (save z)", *bench(lambda: call("nnhipLinearSwishForward", X5, W5, b5, O5, Z5, 16384, 512, 2048, 1.0, 1, st), args.iters), flops=2.0 * 16384 * 512 * 2048)
         report("linear fwd 16384x512->2048", *bench(lambda: call("nnhipLinearModuleForward", X5, W5, b5, O5, 16384, 512, 2048, st), args.iters), flops=2.0 * 16384 * 512 * 2048)
+        dO5, W6 = rnd(16384, 512), rnd(512, 2048) / 16
+        report("dZ = (dO W) swish'(z) 16384x512->2048 (in place)", *bench(lambda: call("nnhipLinearInputGradSwish", dO5, W6, Z5, Z5, 16384, 2048, 512, 1.0, st), args.iters), flops=2.0 * 16384 * 512 * 2048)
+        dX5 = torch.empty(16384, 2048, device=dev)
+        report("linear dX 16384x2048<-512 (plain)", *bench(lambda: call("nnhipLinearModuleBackward", Z5, W6, dO5, dX5, None, None, 16384, 2048, 512, st), args.iters), flops=2.0 * 16384 * 512 * 2048)
         report("linear_swish fwd (no z)", *bench(lambda: call("nnhipLinearSwishForward", X, W, b, O_, None, R, D, D, 1.0, 0, st), args.iters), flops=2.0 * R * D * D)
         del X, W, O_, Z
     x, dy, y, dx = randn(R, D), randn(R, D), torch.empty(R, D, device=dev), torch.empty(R, D, device=dev)
