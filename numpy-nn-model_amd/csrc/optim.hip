@@ -96,21 +96,36 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const unsigned char* _
                                                           int nblk, AdamHyper h, float* __restrict__ dev_state,
                                                           double b1, double b2, int chunk,
                                                           const float* __restrict__ grad_div) {
-    __shared__ float bc[2];
-    if (dev_state) {
+    // Device-driven stepping: thread 0 reads the optimizer's device state with PLAIN (L1-cached) loads and hands it to the
+    // block through LDS.  Every thread used to read it with agent-scope atomic loads: L1-bypassing requests of 2100 blocks x
+    // 4 waves x 5 values that all land on ONE L2 channel the moment the grid starts, and the last wave to be served sets the
+    // kernel's length -- the C4 step's launch took 237-270 us in graph replay against 152-169 us with host-side stepping.
+    // Plain loads are safe: the state only changes in the last block's epilogue below, after every block has read it, and the
+    // next launch starts with clean caches.  The bias corrections of this step were left in dev_state by the previous step's
+    // last block; only the first step after SetStep, or a change of the betas, computes the two double-precision pow()s here.
+    __shared__ float sh[5];
+    if (dev_state || grad_div) {
         if (threadIdx.x == 0) {
-            const int step = ld_dev_i32(reinterpret_cast<const int*>(dev_state)) + 1;
-            bc[0] = (float)(1.0 - pow(b1, (double)step));
-            bc[1] = (float)(1.0 - pow(b2, (double)step));
+            float gs = h.grad_scale;
+            if (dev_state) {
+                const float4 s0 = *reinterpret_cast<const float4*>(dev_state);        // step, lr, grad_scale, ticket
+                const float4 s1 = *reinterpret_cast<const float4*>(dev_state + 4);    // wd, bc_step, bc1, bc2
+                const float2 s2 = *reinterpret_cast<const float2*>(dev_state + 8);    // the betas bc1 / bc2 were computed for
+                const int step = __float_as_int(s0.x) + 1;
+                const bool cached = __float_as_int(s1.y) == step && s2.x == (float)b1 && s2.y == (float)b2;
+                sh[0] = cached ? s1.z : (float)(1.0 - pow(b1, (double)step));
+                sh[1] = cached ? s1.w : (float)(1.0 - pow(b2, (double)step));
+                sh[2] = s0.y;
+                sh[4] = s1.x;
+                gs = s0.z;
+            }
+            if (grad_div) gs = gs / grad_div[0];
+            sh[3] = gs;
         }
         __syncthreads();
-        h.bc1 = bc[0];
-        h.bc2 = bc[1];
-        h.lr = ld_dev_f32(dev_state + 1);
-        h.grad_scale = ld_dev_f32(dev_state + 2);
-        h.wd = ld_dev_f32(dev_state + 4);
+        if (dev_state) { h.bc1 = sh[0]; h.bc2 = sh[1]; h.lr = sh[2]; h.wd = sh[4]; }
+        h.grad_scale = sh[3];
     }
-    if (grad_div) h.grad_scale = h.grad_scale / ld_dev_f32(grad_div);
     float* const* P = reinterpret_cast<float* const*>(blob);
     const float* const* G = reinterpret_cast<const float* const*>(blob + sizeof(void*) * n);
     float* const* M = reinterpret_cast<float* const*>(blob + sizeof(void*) * 2 * n);
@@ -135,8 +150,14 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const unsigned char* _
         if (threadIdx.x == 0) {
             int* si = reinterpret_cast<int*>(dev_state);
             if (atomicAdd(&si[3], 1) == nblk - 1) {        // last block to finish
+                const int next = si[0] + 2;                // the step after the one that now ends
                 si[3] = 0;
-                si[0] = si[0] + 1;
+                si[0] = next - 1;
+                dev_state[6] = (float)(1.0 - pow(b1, (double)next));
+                dev_state[7] = (float)(1.0 - pow(b2, (double)next));
+                dev_state[8] = (float)b1;
+                dev_state[9] = (float)b2;
+                si[5] = next;
             }
         }
     }
@@ -158,7 +179,8 @@ struct FusedOptimizer {
     bool ev_pending[kRing] = {false, false, false, false};
     int ring = 0;
     int nblk = 0;
-    float* dev_state = nullptr;  // {step, lr, grad_scale, ticket, weight_decay} for device-driven stepping (graph replay)
+    float* dev_state = nullptr;  // {step, lr, grad_scale, ticket, weight_decay, bc_step, bc1, bc2, beta1, beta2} for device-driven
+                                 // stepping (graph replay); bc*: the bias corrections of step bc_step, left by the previous step
     bool hyper_set = false;
     const float* grad_div = nullptr;  // device float: divide gradients by it (all-reduced target count), or null
 
@@ -296,9 +318,9 @@ __global__ void set_hyper_kernel(float* st, float lr, float grad_scale, float wd
 }
 static int ensure_dev_state(FusedOptimizer* fo) {
     if (fo->dev_state) return 0;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&fo->dev_state), 8 * sizeof(float));
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&fo->dev_state), 16 * sizeof(float));
     if (e != hipSuccess) { fo->dev_state = nullptr; return hip_status(e, "hipMalloc(optimizer device state)"); }
-    e = hipMemset(fo->dev_state, 0, 8 * sizeof(float));
+    e = hipMemset(fo->dev_state, 0, 16 * sizeof(float));
     return hip_status(e, "hipMemset(optimizer device state)");
 }
 }  // namespace nnhip

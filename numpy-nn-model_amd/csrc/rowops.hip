@@ -707,12 +707,14 @@ __device__ __forceinline__ void ce_prologue(const CeArgs& a, float* red, int* ir
         denom = a.cw ? ws : (float)ci;
         if (a.count_out && blockIdx.x == 0 && threadIdx.x == 0) a.count_out[0] = ci;
         scale = denom > 0.f ? 1.0f / denom : 0.0f;
-    } else if (a.denom_dev) {
-        denom = ld_dev_f32(a.denom_dev);
-        scale = denom > 0.f ? 1.0f / denom : 0.0f;
-    } else if (a.count_dev) {
-        denom = (float)ld_dev_i32(a.count_dev);
-        scale = 1.0f / denom;
+    } else if (a.denom_dev || a.count_dev) {
+        // one plain (L1-cached) load per block, broadcast through LDS: the value was produced by an earlier launch or collective.
+        // (An agent-scope load by every wave of every block is thousands of requests to one L2 channel at grid start.)
+        if (threadIdx.x == 0) red[0] = a.denom_dev ? a.denom_dev[0] : (float)a.count_dev[0];
+        __syncthreads();
+        denom = red[0];
+        __syncthreads();                                      // `red` is reused by the reductions that follow
+        scale = a.denom_dev ? (denom > 0.f ? 1.0f / denom : 0.0f) : 1.0f / denom;
     } else {
         denom = a.scale_host > 0.f ? 1.0f / a.scale_host : 0.f;
     }
