@@ -19,10 +19,10 @@
 // (all 128 stores per lane under one step saturate the CU's store path when both resident blocks flush together: measured no
 // gain; one per MFMA over two steps: 16384x512->2048 with z, 0.278 -> 0.255 ms).
 // EPI = 2 is the Swish-backward epilogue of the input gradient that feeds a fused Linear->Swish (C = (A B) * swish'(z), z read
-// from a [M, ldc] tensor that C may alias -- linear_swish's in-place dZ contract): the z values of the pending tile are
-// fetched one k-step before the flush step that uses them (row half 0 under the tile's own last k-step, half 1 under the next
-// tile's first), so neither their latency nor the stores are exposed.
-// Conditions (gemm_pst_wanted): A k-major, 16-B aligned rows, K % 32 == 0, K >= 64 (96 with an EPI 1 / 2 epilogue),
+// from a [M, ldc] tensor that C may alias -- linear_swish's in-place dZ contract): the pending tile goes out in quarters under
+// the next tile's first FOUR k-steps, and the z values of a quarter are fetched one k-step before the step that stores it
+// (quarter 0 under the tile's own last k-step), so neither their latency nor the stores are exposed.
+// Conditions (gemm_pst_wanted): A k-major, 16-B aligned rows, K % 32 == 0, K >= 64 (96 with EPI 1, 160 with EPI 2),
 // M % 128 == 0, no split-K / batch / addend, C and the operand windows addressable with 32-bit byte offsets, more tiles than
 // resident slots.  Everything else takes gemm.hip.
 #include <stdlib.h>
