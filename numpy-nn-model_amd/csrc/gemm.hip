@@ -467,7 +467,7 @@ int gemm_pst(const float* A, const float* B, float* C, const float* bias, float*
              int64_t lda, int64_t ldb, int64_t ldc, bool b_kmajor, float alpha, int act, float beta, const float* dswish, int dact,
              hipStream_t st);
 // gemm_small.hip: the latency-optimised kernel for problems of a few 32x32 tiles
-bool gemm_small_wanted(int64_t M, int64_t N, int64_t K, int64_t batch);
+bool gemm_small_wanted(int64_t M, int64_t N, int64_t K, int64_t batch, int64_t lda, int64_t ldb, bool a_kmajor, bool b_kmajor);
 int gemm_small(const float* A, const float* B, float* C, const float* bias, float* preact, int64_t M, int64_t N, int64_t K,
                int64_t lda, int64_t ldb, int64_t ldc, bool a_kmajor, bool b_kmajor, float alpha, int act, float beta,
                float* asum, const float* addend, const float* dact_arg, int dact, hipStream_t st);
@@ -526,7 +526,7 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
         gemm_pst_wanted(M, N, K, lda, ldb, ldc, A, B, C, bias, b_kmajor, act, preact, dswish, dact))
         return gemm_pst(A, B, C, bias, preact, M, N, K, lda, ldb, ldc, b_kmajor, alpha, act, beta, dswish, dact, st);
     static const int small_on = []() { const char* e = getenv("NNHIP_GEMM_SMALL"); return e ? atoi(e) : 1; }();
-    if (small_on && gemm_small_wanted(M, N, K, batch))
+    if (small_on && gemm_small_wanted(M, N, K, batch, lda, ldb, a_kmajor, b_kmajor))
         return gemm_small(A, B, C, bias, preact, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, alpha, act, beta, asum, addend,
                           dswish, dact, st);
     constexpr int BK = 32;     // (a BK = 16 / 3-blocks-per-CU variant was measured in rounds 1 and 2: never ahead; dropped)

@@ -31,58 +31,72 @@ struct SmallGemmParams {
     float* asum;
     int64_t M, N, K, lda, ldb, ldc;
     float alpha, beta;
-    int act, dact, a_kmajor, b_kmajor, avec, bvec;
+    int act, dact, a_kmajor, b_kmajor;
 };
 
 // 4 consecutive k (k0 .. k0+3) of row r of an operand.  k-major: P[r*ld + k]; outer-major: P[k*ld + r].
-template <bool KMAJOR>
-__device__ __forceinline__ float4 sg_load(const float* __restrict__ P, int64_t ld, int64_t r, int64_t R, int64_t k0, int64_t K,
-                                          bool vec) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r >= R) return v;
-    if constexpr (KMAJOR) {
-        const float* p = P + r * ld + k0;
-        if (vec && k0 + 3 < K) return *reinterpret_cast<const float4*>(p);
-        if (k0 < K) v.x = p[0];
-        if (k0 + 1 < K) v.y = p[1];
-        if (k0 + 2 < K) v.z = p[2];
-        if (k0 + 3 < K) v.w = p[3];
+// Buffer loads with a per-lane byte offset; a lane with nothing to fetch (row past the operand, k past K, k-group past the
+// last) gets an offset beyond the descriptor's num_records and reads 0 -- no branch, no select on the loaded value.  (With
+// `if (in range) v = *p` every load sat in its own control-flow region that ended in `s_waitcnt vmcnt(0)`: the 32 loads of a
+// wave of the 32x784x128 forward were 32 memory round trips, 12 us for 6 MFLOP.)
+typedef unsigned sg_u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned SG_OOB = 0xFFFFFFF0u;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sg_rsrc(const float* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
+}
+
+// row_off: byte offset of the lane's row (k-major: r*ld*4; outer-major: r*4), SG_OOB-safe only through `ok`
+template <bool KMAJOR, bool VEC>
+__device__ __forceinline__ float4 sg_fetch(__amdgpu_buffer_rsrc_t rs, unsigned ld4, unsigned row_off, bool ok, unsigned k0, unsigned K) {
+    float4 v;
+    if constexpr (KMAJOR && VEC) {                             // K % 4 == 0 here: a float4 never straddles K
+        const unsigned off = (ok && k0 < K) ? row_off + k0 * 4u : SG_OOB;
+        const sg_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+        v.x = __uint_as_float(t.x); v.y = __uint_as_float(t.y); v.z = __uint_as_float(t.z); v.w = __uint_as_float(t.w);
     } else {
-        const float* p = P + k0 * ld + r;
-        if (k0 < K) v.x = p[0];
-        if (k0 + 1 < K) v.y = p[ld];
-        if (k0 + 2 < K) v.z = p[2 * ld];
-        if (k0 + 3 < K) v.w = p[3 * ld];
+        const unsigned step = KMAJOR ? 4u : ld4;
+        const unsigned base = KMAJOR ? row_off + k0 * 4u : k0 * ld4 + row_off;
+        v.x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (ok && k0 < K) ? base : SG_OOB, 0, 0));
+        v.y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (ok && k0 + 1 < K) ? base + step : SG_OOB, 0, 0));
+        v.z = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (ok && k0 + 2 < K) ? base + 2 * step : SG_OOB, 0, 0));
+        v.w = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (ok && k0 + 3 < K) ? base + 3 * step : SG_OOB, 0, 0));
     }
     return v;
 }
 
-template <int NW, bool AKM, bool BKM, int U = 8>
+template <int NW, bool AKM, bool BKM, bool VEC, int U = 8>
 __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(const SmallGemmParams p) {
     __shared__ float red[NW][32 * 32];
     __shared__ float ared[NW][32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     const int64_t m0 = (int64_t)blockIdx.y * 32, n0 = (int64_t)blockIdx.x * 32;
-    const int64_t groups = (p.K + 7) >> 3;
+    const unsigned groups = (unsigned)((p.K + 7) >> 3), K = (unsigned)p.K;
+    // operand windows: everything from the operand's origin to the end of its last row / k-line (gemm_small() checked that this
+    // fits 31 bits); the per-lane row offset is loop-invariant
+    const unsigned la4 = (unsigned)p.lda * 4u, lb4 = (unsigned)p.ldb * 4u;
+    const __amdgpu_buffer_rsrc_t rsa = sg_rsrc(p.A, (unsigned)((AKM ? (p.M - 1) * p.lda + p.K : (p.K - 1) * p.lda + p.M) * 4));
+    const __amdgpu_buffer_rsrc_t rsb = sg_rsrc(p.B, (unsigned)((BKM ? (p.N - 1) * p.ldb + p.K : (p.K - 1) * p.ldb + p.N) * 4));
+    const bool a_ok = m0 + l31 < p.M, b_ok = n0 + l31 < p.N;
+    const unsigned a_row = (unsigned)(m0 + l31) * (AKM ? la4 : 4u), b_row = (unsigned)(n0 + l31) * (BKM ? lb4 : 4u);
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
     float asum = 0.f;
     // U k-groups in flight per wave (2 x U float4 of operands).  U = 8: a K = 784 over 8 waves is two round trips to L2;
     // the U = 16 instantiation (k-major operands, 64 < K/8 <= 128 groups per block) makes it one.
-    for (int64_t gb = wave; gb < groups; gb += (int64_t)NW * U) {
+    for (unsigned gb = wave; gb < groups; gb += (unsigned)NW * U) {
         float4 a[U], b[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int64_t g = gb + (int64_t)u * NW;
-            a[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            b[u] = a[u];
-            if (g < groups) {
-                a[u] = sg_load<AKM>(p.A, p.lda, m0 + l31, p.M, 8 * g + 4 * lh, p.K, p.avec != 0);
-                b[u] = sg_load<BKM>(p.B, p.ldb, n0 + l31, p.N, 8 * g + 4 * lh, p.K, p.bvec != 0);
-            }
+            const unsigned k0 = 8u * (gb + (unsigned)u * NW) + 4u * lh;      // a k-group past the last has k0 >= K: reads 0
+            a[u] = sg_fetch<AKM, VEC>(rsa, la4, a_row, a_ok, k0, K);
+            b[u] = sg_fetch<BKM, VEC>(rsb, lb4, b_row, b_ok, k0, K);
         }
+        // all 2U loads are in flight before the first MFMA waits for its operands (left alone, the scheduler sinks each load
+        // to just above its use -- `load, s_waitcnt vmcnt(0), mfma` U times: U memory round trips instead of one)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b[u].x, acc, 0, 0, 0);
@@ -135,8 +149,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(const SmallGemmPara
 }
 
 // Is this problem one for the small kernel?  (gemm.hip asks before planning its own launch.)
-bool gemm_small_wanted(int64_t M, int64_t N, int64_t K, int64_t batch) {
-    if (batch != 1 || M <= 0 || N <= 0 || K > 2048) return false;
+bool gemm_small_wanted(int64_t M, int64_t N, int64_t K, int64_t batch, int64_t lda, int64_t ldb, bool a_kmajor, bool b_kmajor) {
+    if (batch != 1 || M <= 0 || N <= 0 || K <= 0 || K > 2048) return false;
+    // the operand windows are addressed with 32-bit byte offsets below an out-of-range sentinel
+    const int64_t ea = a_kmajor ? (M - 1) * lda + K : (K - 1) * lda + M, eb = b_kmajor ? (N - 1) * ldb + K : (K - 1) * ldb + N;
+    if (ea * 4 >= ((int64_t)1 << 31) || eb * 4 >= ((int64_t)1 << 31)) return false;
     const int64_t tiles128 = ceil_div(M, 128) * ceil_div(N, 128);
     const int64_t tiles32 = ceil_div(M, 32) * ceil_div(N, 32);
     // a very short reduction (the conv classifier's 256x10 -> 784 input gradient) is all launch + epilogue: 32x32 blocks
@@ -151,23 +168,30 @@ int gemm_small(const float* A, const float* B, float* C, const float* bias, floa
     p.A = A; p.B = B; p.C = C; p.bias = bias; p.preact = preact; p.addend = addend; p.dact_arg = dact_arg; p.asum = asum;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.alpha = alpha; p.beta = beta; p.act = act; p.dact = dact;
     p.a_kmajor = a_kmajor; p.b_kmajor = b_kmajor;
-    p.avec = a_kmajor && aligned16(A) && (lda & 3) == 0;
-    p.bvec = b_kmajor && aligned16(B) && (ldb & 3) == 0;
+    // float4 loads for the k-major operands: 16-B aligned rows and K % 4 == 0 (a float4 then never straddles the end of a row)
+    const bool vec = (a_kmajor || b_kmajor) && (K & 3) == 0 && (!a_kmajor || (aligned16(A) && (lda & 3) == 0)) &&
+                     (!b_kmajor || (aligned16(B) && (ldb & 3) == 0));
     const int64_t groups = (K + 7) >> 3;
     const int nw = groups >= 8 ? 8 : 4;
     dim3 grid((unsigned)ceil_div(N, 32), (unsigned)ceil_div(M, 32));
-#define SG_LAUNCH(NW)                                                                                             \
-    do {                                                                                                          \
-        if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_small_kernel<NW, true, true>), grid, dim3(NW * 64), 0, st, p);        \
-        else if (a_kmajor) hipLaunchKernelGGL((gemm_small_kernel<NW, true, false>), grid, dim3(NW * 64), 0, st, p);              \
-        else if (b_kmajor) hipLaunchKernelGGL((gemm_small_kernel<NW, false, true>), grid, dim3(NW * 64), 0, st, p);              \
-        else hipLaunchKernelGGL((gemm_small_kernel<NW, false, false>), grid, dim3(NW * 64), 0, st, p);                            \
+#define SG_LAUNCH2(NW, V)                                                                                                     \
+    do {                                                                                                                      \
+        if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_small_kernel<NW, true, true, V>), grid, dim3(NW * 64), 0, st, p);  \
+        else if (a_kmajor) hipLaunchKernelGGL((gemm_small_kernel<NW, true, false, V>), grid, dim3(NW * 64), 0, st, p);        \
+        else if (b_kmajor) hipLaunchKernelGGL((gemm_small_kernel<NW, false, true, V>), grid, dim3(NW * 64), 0, st, p);        \
+        else hipLaunchKernelGGL((gemm_small_kernel<NW, false, false, false>), grid, dim3(NW * 64), 0, st, p);                 \
     } while (0)
-    if (nw == 8 && a_kmajor && b_kmajor && groups > 64 && groups <= 128)
-        hipLaunchKernelGGL((gemm_small_kernel<8, true, true, 16>), grid, dim3(512), 0, st, p);
+#define SG_LAUNCH(NW)                                                                                                         \
+    do {                                                                                                                      \
+        if (vec) SG_LAUNCH2(NW, true);                                                                                        \
+        else SG_LAUNCH2(NW, false);                                                                                           \
+    } while (0)
+    if (nw == 8 && vec && a_kmajor && b_kmajor && groups > 64 && groups <= 128)
+        hipLaunchKernelGGL((gemm_small_kernel<8, true, true, true, 16>), grid, dim3(512), 0, st, p);
     else if (nw == 8) SG_LAUNCH(8);
     else SG_LAUNCH(4);
 #undef SG_LAUNCH
+#undef SG_LAUNCH2
     NNHIP_LAUNCH_CHECK("gemm_small_kernel");
     return 0;
 }
