@@ -329,10 +329,17 @@ __global__ __launch_bounds__(1024) void bn_bwd_fused_kernel(const float* __restr
     bn_offsets(off, B, C, HW);
     float gv[BN_NE], xc[BN_NE];
     float s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f;
+    // every load is issued before the first value is used (with `off >= 0 ? bn_ld(..) - m : 0` the x load sat under a branch
+    // that ended in s_waitcnt vmcnt(0): 16 memory round trips per thread)
 #pragma unroll
     for (int e = 0; e < BN_NE; ++e) {
         gv[e] = bn_ld(rg, off[e]);                            // 0 for a slot without an element: all four sums take 0
-        xc[e] = off[e] >= 0 ? bn_ld(rx, off[e]) - m : 0.f;
+        xc[e] = bn_ld(rx, off[e]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < BN_NE; ++e) {
+        xc[e] = off[e] >= 0 ? xc[e] - m : 0.f;
         s1 += wc * gv[e] * xc[e];
         s2 += wc * gv[e];
         s3 += gv[e] * (xc[e] * iv);
