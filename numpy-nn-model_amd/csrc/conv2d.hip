@@ -296,6 +296,34 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __r
 // weights sit in LDS laid out so that one ds_read_b128 hands a thread 4 channels' weights for the tap it is on (all
 // threads read the same address: broadcast).  Same formulas, same summation order over (ci, r, s).
 // =================================================================================================
+// global -> LDS staging by a 256-thread block with the loads BATCHED: 8 loads per thread are in flight before the first LDS
+// store (`for (i = tid; i < n; i += 256) S[i] = f(i)` is one memory round trip per iteration).  `src_index(i)` maps a staged
+// element to its source index or -1 (zero fill).
+template <typename F>
+__device__ __forceinline__ void stage_to_lds(float* __restrict__ dst, const float* __restrict__ src, int n, int tid, F src_index) {
+    constexpr int D = 8;
+    for (int base = 0; base < n; base += 256 * D) {
+        float t[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const int i = base + tid + 256 * j;
+            const int64_t si = i < n ? src_index(i) : -1;
+            const float v = src[si >= 0 ? si : 0];
+            t[j] = si >= 0 ? v : 0.f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const int i = base + tid + 256 * j;
+            if (i < n) dst[i] = t[j];
+        }
+    }
+}
+
+constexpr unsigned CD_OOB = 0xFFFFFFF0u;                   // a byte offset no descriptor below covers
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t cd_rsrc(const float* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
+}
 constexpr int CD_MAXC = 16;
 constexpr int CD_MAXTAPS = 25;
 
@@ -306,10 +334,10 @@ __global__ __launch_bounds__(256) void conv_direct_fwd_kernel(const float* __res
                                                               const ConvGeom g) {
     __shared__ __attribute__((aligned(16))) float Wl[CD_MAXC * CD_MAXTAPS * CO];
     const int khkw = g.kh * g.kw, K = g.Cin * khkw;
-    for (int i = threadIdx.x; i < K * CO; i += 256) {
+    stage_to_lds(Wl, Wt, K * CO, threadIdx.x, [&](int i) -> int64_t {
         const int co = i % CO, k = i / CO;
-        Wl[i] = co < g.Cout ? Wt[(int64_t)co * K + k] : 0.f;
-    }
+        return co < g.Cout ? (int64_t)co * K + k : -1;
+    });
     __syncthreads();
     const int64_t HWo = (int64_t)g.Ho * g.Wo, N = (int64_t)g.B * HWo;
     const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -331,18 +359,40 @@ __global__ __launch_bounds__(256) void conv_direct_fwd_kernel(const float* __res
                 const int hi = ho * g.sh - g.pu + r * g.dh, wi = wo * g.sw - g.pl + q * g.dw;
                 off[r * 3 + q] = (hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) ? hi * g.W + wi : -1;
             }
+        // The loads go through ONE buffer descriptor of the whole tensor: the tap's byte offset sits in a VGPR (computed once; a
+        // tap outside the image gets an offset past num_records and reads 0), the channel's plane is the scalar offset -- no
+        // vector instruction per load (with 64-bit pointers and `off >= 0 ? x[..] : 0` the addressing and selects were 3/4 of
+        // the kernel's vector instructions: SQ counters, 2300 VALU per wave for 576 packed FMAs).  The descriptor must be
+        // wave-uniform: with a per-image descriptor a wave that straddles two images turns every load into a readfirstlane loop
+        // (measured: 16 -> 22 us).  Channels go in groups of CG with the 9*CG loads of a group in flight before its first FMA.
+        // (Measured and dropped: ALL taps up front, before the weights are staged -- 144 live values cost the occupancy that hides
+        // the rest: conv1's forward 5.8 -> 10.9 us.)
         const int HWi = g.H * g.W;
-        for (int ci = 0; ci < g.Cin; ++ci) {
-            float x[9];
+        const __amdgpu_buffer_rsrc_t rx = cd_rsrc(X, (unsigned)((int64_t)g.B * g.Cin * HWi) * 4u);
+        unsigned vo[9];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) x[t] = off[t] >= 0 ? xb[(int64_t)ci * HWi + off[t]] : 0.f;
+        for (int t = 0; t < 9; ++t) vo[t] = off[t] >= 0 ? (unsigned)(b * g.Cin * HWi + off[t]) * 4u : CD_OOB;
+        constexpr int CG = 8;
+        for (int c0 = 0; c0 < g.Cin; c0 += CG) {
+            float x[CG][9];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const float4* w4 = reinterpret_cast<const float4*>(&Wl[(ci * 9 + t) * CO]);
+            for (int j = 0; j < CG; ++j) {
+                const unsigned so = (unsigned)((c0 + j) * HWi) * 4u;        // a channel past Cin: past num_records, reads 0
 #pragma unroll
-                for (int c4 = 0; c4 < CO / 4; ++c4) {
-                    const float4 w = w4[c4];
-                    acc[4 * c4] += x[t] * w.x; acc[4 * c4 + 1] += x[t] * w.y; acc[4 * c4 + 2] += x[t] * w.z; acc[4 * c4 + 3] += x[t] * w.w;
+                for (int t = 0; t < 9; ++t) x[j][t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vo[t], so, 0));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < CG; ++j) {
+                if (c0 + j >= g.Cin) break;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const float4* w4 = reinterpret_cast<const float4*>(&Wl[((c0 + j) * 9 + t) * CO]);
+#pragma unroll
+                    for (int c4 = 0; c4 < CO / 4; ++c4) {
+                        const float4 w = w4[c4];
+                        acc[4 * c4] += x[j][t] * w.x; acc[4 * c4 + 1] += x[j][t] * w.y; acc[4 * c4 + 2] += x[j][t] * w.z; acc[4 * c4 + 3] += x[j][t] * w.w;
+                    }
                 }
             }
         }
@@ -374,10 +424,10 @@ __global__ __launch_bounds__(256) void conv_direct_dgrad_kernel(const float* __r
                                                                 float* __restrict__ dX, const ConvGeom g) {
     __shared__ __attribute__((aligned(16))) float Wl[CD_MAXC * CD_MAXTAPS * CI];
     const int khkw = g.kh * g.kw;
-    for (int i = threadIdx.x; i < g.Cout * khkw * CI; i += 256) {
+    stage_to_lds(Wl, Wt, g.Cout * khkw * CI, threadIdx.x, [&](int i) -> int64_t {
         const int ci = i % CI, k = i / CI, co = k / khkw, rs = k - co * khkw;
-        Wl[i] = ci < g.Cin ? Wt[((int64_t)co * g.Cin + ci) * khkw + rs] : 0.f;
-    }
+        return ci < g.Cin ? ((int64_t)co * g.Cin + ci) * khkw + rs : -1;
+    });
     __syncthreads();
     const int64_t HW = (int64_t)g.H * g.W, HWo = (int64_t)g.Ho * g.Wo, N = (int64_t)g.B * HW;
     const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -398,17 +448,31 @@ __global__ __launch_bounds__(256) void conv_direct_dgrad_kernel(const float* __r
                 const bool ok = th >= 0 && tw >= 0 && th % g.sh == 0 && tw % g.sw == 0 && th / g.sh < g.Ho && tw / g.sw < g.Wo;
                 off[r * 3 + q] = ok ? (th / g.sh) * g.Wo + tw / g.sw : -1;
             }
-        for (int co = 0; co < g.Cout; ++co) {
-            float v[9];
+        const __amdgpu_buffer_rsrc_t rg = cd_rsrc(dO, (unsigned)((int64_t)g.B * g.Cout * HWo) * 4u);      // as in the forward kernel
+        unsigned vo[9];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) v[t] = off[t] >= 0 ? gb[(int64_t)co * HWo + off[t]] : 0.f;
+        for (int t = 0; t < 9; ++t) vo[t] = off[t] >= 0 ? (unsigned)(b * g.Cout * (int)HWo + off[t]) * 4u : CD_OOB;
+        constexpr int CG = 8;
+        for (int c0 = 0; c0 < g.Cout; c0 += CG) {
+            float v[CG][9];
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const float4* w4 = reinterpret_cast<const float4*>(&Wl[(co * 9 + t) * CI]);
+            for (int j = 0; j < CG; ++j) {
+                const unsigned so = (unsigned)((c0 + j) * (int)HWo) * 4u;
 #pragma unroll
-                for (int c4 = 0; c4 < CI / 4; ++c4) {
-                    const float4 ww = w4[c4];
-                    acc[4 * c4] += v[t] * ww.x; acc[4 * c4 + 1] += v[t] * ww.y; acc[4 * c4 + 2] += v[t] * ww.z; acc[4 * c4 + 3] += v[t] * ww.w;
+                for (int t = 0; t < 9; ++t) v[j][t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, vo[t], so, 0));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < CG; ++j) {
+                if (c0 + j >= g.Cout) break;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const float4* w4 = reinterpret_cast<const float4*>(&Wl[((c0 + j) * 9 + t) * CI]);
+#pragma unroll
+                    for (int c4 = 0; c4 < CI / 4; ++c4) {
+                        const float4 ww = w4[c4];
+                        acc[4 * c4] += v[j][t] * ww.x; acc[4 * c4 + 1] += v[j][t] * ww.y; acc[4 * c4 + 2] += v[j][t] * ww.z; acc[4 * c4 + 3] += v[j][t] * ww.w;
+                    }
                 }
             }
         }
@@ -466,8 +530,8 @@ __global__ __launch_bounds__(256) void conv_direct_wgrad_kernel(const float* __r
     }
     for (int b = blockIdx.x; b < g.B; b += gridDim.x) {
         __syncthreads();
-        for (int i = tid; i < g.Cin * HW; i += 256) Xs[i] = X[(int64_t)b * g.Cin * HW + i];
-        for (int i = tid; i < g.Cout * HWo; i += 256) Gs[i] = dO[(int64_t)b * g.Cout * HWo + i];
+        stage_to_lds(Xs, X + (int64_t)b * g.Cin * HW, g.Cin * HW, tid, [](int i) -> int64_t { return i; });
+        stage_to_lds(Gs, dO + (int64_t)b * g.Cout * HWo, g.Cout * HWo, tid, [](int i) -> int64_t { return i; });
         __syncthreads();
         for (int p = slice; p < HWo; p += S) {
             const int ho = p / g.Wo, wo = p - ho * g.Wo;
@@ -539,7 +603,10 @@ static int launch_direct_wgrad(const float* X, const float* dO, float* part, con
 
 static bool conv_direct_ok(const ConvGeom& g) {
     static const bool off = []() { const char* e = getenv("NNHIP_CONV_DIRECT"); return e && atoi(e) == 0; }();
-    return !off && g.Cin <= CD_MAXC && g.Cout <= CD_MAXC && g.kh * g.kw <= CD_MAXTAPS;
+    // (both activation tensors are addressed with 32-bit byte offsets below CD_OOB)
+    const int64_t lim = (int64_t)1 << 29;
+    return !off && g.Cin <= CD_MAXC && g.Cout <= CD_MAXC && g.kh * g.kw <= CD_MAXTAPS && (int64_t)g.B * g.Cin * g.H * g.W < lim &&
+           (int64_t)g.B * g.Cout * g.Ho * g.Wo < lim;
 }
 
 static int make_geom(const nnhipConv2dDesc* d, ConvGeom& g) {
