@@ -130,6 +130,13 @@ int nnhipLinearInputGradSwish(const float* dO, const float* W, const float* Z, f
  * not alias F (F is still the Linear's input for its dW). */
 int nnhipLinearInputGradReLU(const float* dO, const float* W, const float* F, float* dZ, int64_t rows,
                              int64_t in_features, int64_t out_features, nnhipStream_t stream);
+/* Both of the above plus the parameter gradients in one call: dZ = (dO * W) (.) act'(act_arg) -- act_grad 1: swish'(act_arg = Z;
+ * beta), dZ may alias Z; 2: [act_arg = F > 0], dZ must not alias F -- and dW = dO^T X, db = column sums of dO (either may be NULL),
+ * i.e. _LinearTensor.grad_fn (linear.py:17-24) followed by the activation's backward.  A small layer (the README MLP's
+ * 128 -> 10 head) gets dZ, dW and db from ONE launch. */
+int nnhipLinearModuleBackwardAct(const float* X, const float* W, const float* dO, const float* act_arg, int32_t act_grad,
+                                 float beta, float* dZ, float* dW, float* db, int64_t rows, int64_t in_features,
+                                 int64_t out_features, nnhipStream_t stream);
 /* O = act(X*W^T + b), activation in the GEMM epilogue: 1 = swish(beta) without saving z, 2 = relu, 3 = sigmoid.
  * One launch for what `act(Linear(x))` is on the reference's tape (linear.py:48-58 + activations.py); the host side
  * uses it when an activation module is applied to a Linear output nobody else has looked at yet. */

@@ -466,6 +466,9 @@ bool gemm_pst_wanted(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, 
 int gemm_pst(const float* A, const float* B, float* C, const float* bias, float* preact, int64_t M, int64_t N, int64_t K,
              int64_t lda, int64_t ldb, int64_t ldc, bool b_kmajor, float alpha, int act, float beta, const float* dswish, int dact,
              hipStream_t st);
+int gemm_small_linear_backward(const float* X, const float* W, const float* dO, float* dX, float* dW, float* db, int64_t rows,
+                               int64_t in, int64_t out, const float* addend, const float* dact_arg, int dact, float beta,
+                               hipStream_t st);
 // gemm_small.hip: the latency-optimised kernel for problems of a few 32x32 tiles
 bool gemm_small_wanted(int64_t M, int64_t N, int64_t K, int64_t batch, int64_t lda, int64_t ldb, bool a_kmajor, bool b_kmajor);
 int gemm_small(const float* A, const float* B, float* C, const float* bias, float* preact, int64_t M, int64_t N, int64_t K,
@@ -494,6 +497,19 @@ int gemm_f32_add(const float* A, const float* B, float* C, const float* bias, co
 }
 
 // C = (A B) * swish'(Z; beta): the input gradient of a Linear whose input is h = swish(z) comes back as dz (C may alias Z).
+// Both gradients of a small Linear in one launch (gemm_small.hip: gemm_small_pair_kernel) when each of the two GEMMs would take
+// the small kernel anyway.  Returns 1 when it did the work, 0 when the caller should run the two GEMMs, < 0 on error.
+int gemm_f32_linear_backward_small(const float* X, const float* W, const float* dO, float* dX, float* dW, float* db, int64_t rows,
+                                   int64_t in, int64_t out, const float* addend, const float* dact_arg, int dact, float beta,
+                                   hipStream_t st) {
+    static const int small_on = []() { const char* e = getenv("NNHIP_GEMM_SMALL"); return e ? atoi(e) : 1; }();
+    static const int pair_on = []() { const char* e = getenv("NNHIP_GEMM_PAIR"); return e ? atoi(e) : 1; }();
+    if (!small_on || !pair_on || gemm_mode() != 0 || !dX || !dW || rows <= 0 || in <= 0 || out <= 0) return 0;
+    if (!gemm_small_wanted(rows, in, out, 1, out, in, true, false) || !gemm_small_wanted(out, in, rows, 1, out, in, false, false)) return 0;
+    const int rc = gemm_small_linear_backward(X, W, dO, dX, dW, db, rows, in, out, addend, dact_arg, dact, beta, st);
+    return rc ? rc : 1;
+}
+
 int gemm_f32_dswish(const float* A, const float* B, float* C, const float* Z, float beta, int64_t M, int64_t N, int64_t K,
                     int64_t lda, int64_t ldb, int64_t ldc, bool a_kmajor, bool b_kmajor, hipStream_t st) {
     return gemm_f32_ex(A, B, C, nullptr, nullptr, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, 1, 0, 0, 0, 1, 0, 0, 0, 1.0f,

@@ -65,13 +65,12 @@ __device__ __forceinline__ float4 sg_fetch(__amdgpu_buffer_rsrc_t rs, unsigned l
     return v;
 }
 
-template <int NW, bool AKM, bool BKM, bool VEC, int U = 8>
-__global__ __launch_bounds__(NW * 64) void gemm_small_kernel(const SmallGemmParams p) {
-    __shared__ float red[NW][32 * 32];
-    __shared__ float ared[NW][32];
+// one 32x32 output tile (bx, by) of problem p; `red` / `ared`: NW x 1024 and NW x 32 floats of LDS
+template <int NW, bool AKM, bool BKM, bool VEC, int U>
+__device__ __forceinline__ void sg_tile(const SmallGemmParams& p, int bx, int by, float (*red)[32 * 32], float (*ared)[32]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
-    const int64_t m0 = (int64_t)blockIdx.y * 32, n0 = (int64_t)blockIdx.x * 32;
+    const int64_t m0 = (int64_t)by * 32, n0 = (int64_t)bx * 32;
     const unsigned groups = (unsigned)((p.K + 7) >> 3), K = (unsigned)p.K;
     // operand windows: everything from the operand's origin to the end of its last row / k-line (gemm_small() checked that this
     // fits 31 bits); the per-lane row offset is loop-invariant
@@ -140,11 +139,48 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(const SmallGemmPara
             p.C[row * p.ldc + col] = v;
         }
     }
-    if (p.asum && blockIdx.x == 0 && tid < 32) {
+    if (p.asum && bx == 0 && tid < 32) {
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) s += ared[w][tid];
         if (m0 + tid < p.M) p.asum[m0 + tid] = s;
+    }
+}
+
+template <int NW, bool AKM, bool BKM, bool VEC, int U = 8>
+__global__ __launch_bounds__(NW * 64) void gemm_small_kernel(const SmallGemmParams p) {
+    __shared__ float red[NW][32 * 32];
+    __shared__ float ared[NW][32];
+    sg_tile<NW, AKM, BKM, VEC, U>(p, (int)blockIdx.x, (int)blockIdx.y, red, ared);
+}
+
+// Two independent small problems in ONE launch (blockIdx.z picks): the input gradient dX = dO W (A k-major, B outer-major,
+// any epilogue) and the weight gradient dW = dO^T X (+ db; both outer-major) of a small Linear.  At MNIST-MLP scale a launch is
+// ~4.7 us of a 45 us step whatever it computes, so two tiles' worth of work should not cost two launches.  The grid is the
+// larger of the two tile grids; a block outside its problem's grid exits.
+struct SmallLinearBwd {                                    // compact kernel argument of the pair kernel (84 bytes)
+    const float* dO; const float* W; const float* X;
+    float* dX; float* dW; float* db;
+    const float* addend; const float* dact_arg;
+    int rows, in, out, dact;
+    float beta;
+};
+
+template <int NW, bool VEC0>
+__global__ __launch_bounds__(NW * 64) void gemm_small_pair_kernel(const SmallLinearBwd q) {
+    __shared__ float red[NW][32 * 32];
+    __shared__ float ared[NW][32];
+    const int bx = (int)blockIdx.x, by = (int)blockIdx.y;
+    SmallGemmParams p{};
+    p.A = q.dO; p.lda = q.out; p.ldb = q.in; p.ldc = q.in; p.N = q.in; p.alpha = 1.f;
+    if (blockIdx.z == 0) {                                 // dX[rows, in] = dO[rows, out] W[out, in]   (+ addend, (.) act')
+        p.B = q.W; p.C = q.dX; p.addend = q.addend; p.dact_arg = q.dact_arg; p.dact = q.dact; p.beta = q.beta;
+        p.M = q.rows; p.K = q.out; p.a_kmajor = 1;
+        if ((int64_t)bx * 32 < p.N && (int64_t)by * 32 < p.M) sg_tile<NW, true, false, VEC0, 8>(p, bx, by, red, ared);
+    } else {                                               // dW[out, in] = dO^T[out, rows] X[rows, in],  db = row sums of dO^T
+        p.B = q.X; p.C = q.dW; p.asum = q.db; p.beta = 1.f;
+        p.M = q.out; p.K = q.rows;
+        if ((int64_t)bx * 32 < p.N && (int64_t)by * 32 < p.M) sg_tile<NW, false, false, false, 8>(p, bx, by, red, ared);
     }
 }
 
@@ -193,6 +229,28 @@ int gemm_small(const float* A, const float* B, float* C, const float* bias, floa
 #undef SG_LAUNCH
 #undef SG_LAUNCH2
     NNHIP_LAUNCH_CHECK("gemm_small_kernel");
+    return 0;
+}
+
+// dX = (dO W) [(.) act'] and dW = dO^T X (+ db) of one Linear in one launch; the caller checked gemm_small_wanted() for both.
+int gemm_small_linear_backward(const float* X, const float* W, const float* dO, float* dX, float* dW, float* db, int64_t rows,
+                               int64_t in, int64_t out, const float* addend, const float* dact_arg, int dact, float beta,
+                               hipStream_t st) {
+    SmallLinearBwd q;
+    q.dO = dO; q.W = W; q.X = X; q.dX = dX; q.dW = dW; q.db = db; q.addend = addend; q.dact_arg = dact_arg;
+    q.rows = (int)rows; q.in = (int)in; q.out = (int)out; q.dact = dact; q.beta = beta;
+    const bool vec0 = (out & 3) == 0 && aligned16(dO);
+    const int64_t g0 = (out + 7) >> 3, g1 = (rows + 7) >> 3;
+    const int nw = (g0 >= 8 || g1 >= 8) ? 8 : 4;
+    dim3 grid((unsigned)ceil_div(in, 32), (unsigned)max(ceil_div(rows, 32), ceil_div(out, 32)), 2);
+    if (nw == 8) {
+        if (vec0) hipLaunchKernelGGL((gemm_small_pair_kernel<8, true>), grid, dim3(512), 0, st, q);
+        else hipLaunchKernelGGL((gemm_small_pair_kernel<8, false>), grid, dim3(512), 0, st, q);
+    } else {
+        if (vec0) hipLaunchKernelGGL((gemm_small_pair_kernel<4, true>), grid, dim3(256), 0, st, q);
+        else hipLaunchKernelGGL((gemm_small_pair_kernel<4, false>), grid, dim3(256), 0, st, q);
+    }
+    NNHIP_LAUNCH_CHECK("gemm_small_pair_kernel");
     return 0;
 }
 

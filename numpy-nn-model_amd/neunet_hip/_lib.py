@@ -53,6 +53,7 @@ _SIGNATURES = {
     "nnhipLinearModuleBackward": (ctypes.c_int, [P, P, P, P, P, P, c_int64, c_int64, c_int64, c_void_p]),
     "nnhipLinearInputGradSwish": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_float, c_void_p]),
     "nnhipLinearInputGradReLU": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_void_p]),
+    "nnhipLinearModuleBackwardAct": (ctypes.c_int, [P, P, P, P, c_int32, c_float, P, P, P, c_int64, c_int64, c_int64, c_void_p]),
     "nnhipLinearActivationForward": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_int32, c_float, c_void_p]),
     "nnhipLinearModuleForwardEx": (ctypes.c_int, [P, P, P, P, P, c_int64, c_int64, c_int64, c_void_p]),
     "nnhipLinearModuleBackwardEx": (ctypes.c_int, [P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_void_p]),

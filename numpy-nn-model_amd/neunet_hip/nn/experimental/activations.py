@@ -42,7 +42,7 @@ class _HIPReLUTensor(Tensor):
         def grad_fn(t: Tensor, f_x, grad):
             me = self_ref()
             if getattr(me, "_grad_is_dz", False):
-                # the consumer (a HIPLinear) already applied [f > 0] in its dX epilogue (linear.py:_fold_relu_backward)
+                # the consumer (a HIPLinear) already applied [f > 0] in its dX epilogue (linear.py:_plan_fold)
                 me._grad_is_dz = False
                 t.apply_grad(grad)
                 return

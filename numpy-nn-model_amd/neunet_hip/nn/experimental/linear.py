@@ -46,37 +46,32 @@ def _grad_out(param, shape_like):
     return param.xp.empty_like(shape_like, dtype=np.float32)
 
 
-def _fold_swish_backward(X, weight, grad, rows, in_features, out_features):
-    """If this Linear's input is the output of a fused Linear->Swish that saved its pre-activation z and nothing else
-    consumes it (the FFN of examples/gpt.ipynb: fc_2(swish(fc_1(x)))), compute dz = (dO W) * swish'(z) in the dX
-    GEMM's epilogue, in place over z, and hand it to that node marked as 'already dz' -- no separate Swish-backward
-    pass over the [rows, d_ff] tensor.  Returns True when done."""
-    if X.op != "linear_swish" or X.grad is not None or getattr(X, "_consumers", 0) != 1 or not X.requires_grad:
-        return False
-    z, saved = X.args[7], X.args[8]
-    if not saved or z is None:
-        return False
-    call_hip_function("nnhipLinearInputGradSwish", grad, weight.data, z, z, rows, in_features, out_features,
-                      float(X.args[6]), get_current_stream_ptr())
-    X.grad = z.reshape(X.data.shape)
-    X._grad_is_dz = True
-    return True
+def _plan_fold(X):
+    """Can the backward of the activation that produced this Linear's input ride in the dX GEMM's epilogue?
+    Returns (act_grad, act_arg, dz, beta) for nnhipLinearModuleBackwardAct / nnhipLinearInputGrad*, or None.
+      * act_grad 1 -- X is the output of a fused Linear->Swish that saved its pre-activation z and nothing else consumes it
+        (the FFN of examples/gpt.ipynb: fc_2(swish(fc_1(x)))): dz = (dO W) * swish'(z), in place over z -- no separate
+        Swish-backward pass over the [rows, d_ff] tensor;
+      * act_grad 2 -- X is the output of a ReLU that nothing else consumes (README quick-start: l2(relu(l1(x)))):
+        d(relu input) = (dO W) * [f > 0] -- the separate ReLU-backward launch (at MNIST-MLP scale one more ~5 us graph node)
+        goes away."""
+    if X.grad is not None or getattr(X, "_consumers", 0) != 1 or not X.requires_grad:
+        return None
+    if X.op == "linear_swish":
+        z, saved = X.args[7], X.args[8]
+        if not saved or z is None:
+            return None
+        return 1, z, z, float(X.args[6])
+    if X.op == "relu":
+        f_x = X.args[1]
+        return 2, f_x, X.xp.empty_like(f_x, dtype=np.float32), 1.0
+    return None
 
 
-def _fold_relu_backward(X, weight, grad, rows, in_features, out_features):
-    """If this Linear's input is the output of a ReLU that nothing else consumes (README quick-start: l2(relu(l1(x)))),
-    compute d(relu input) = (dO W) * [f > 0] in the dX GEMM's epilogue and hand it to the ReLU node marked as 'already
-    masked' -- the separate ReLU-backward pass (one more launch; at MNIST-MLP scale one more ~6 us graph node) goes away.
-    Returns True when done."""
-    if X.op != "relu" or X.grad is not None or getattr(X, "_consumers", 0) != 1 or not X.requires_grad:
-        return False
-    f_x = X.args[1]
-    dz = X.xp.empty_like(f_x, dtype=np.float32)
-    call_hip_function("nnhipLinearInputGradReLU", grad, weight.data, f_x, dz, rows, in_features, out_features,
-                      get_current_stream_ptr())
-    X.grad = dz
+def _commit_fold(X, dz):
+    """Hand dz to the activation's node marked as 'already the gradient of its input'."""
+    X.grad = dz.reshape(X.data.shape)
     X._grad_is_dz = True
-    return True
 
 
 def _finish_param(param, grad):
@@ -105,8 +100,8 @@ class _HIPLinearTensor(Tensor):
             grad = grad if grad.is_contiguous() else grad.contiguous()
             if residual is not None:
                 residual.apply_grad(grad)       # d(x + linear(h))/dx = 1: the same buffer, by reference
-            folded = (_fold_swish_backward(X, weight, grad, in_rows_num, in_features, out_features)
-                      or _fold_relu_backward(X, weight, grad, in_rows_num, in_features, out_features))
+            plan = _plan_fold(X)
+            folded = plan is not None
             grad_X = X.xp.empty_like(X.data, dtype=np.float32) if X.requires_grad and not folded else None
             # a gradient X already received (e.g. q/k/v projections sharing one input) is folded into the dX GEMM's
             # epilogue instead of a separate accumulation pass (neunet/autograd.py:85-93 allocates and adds)
@@ -114,7 +109,16 @@ class _HIPLinearTensor(Tensor):
             grad_weight = _grad_out(weight, weight.data)
             grad_bias = _grad_out(bias, bias.data) if bias is not None else None
             hook = getattr(weight, "_grad_hook", None)
-            if hook is not None and grad_X is not None:
+            if folded and hook is None:
+                # dz, dW and db from one C call (one LAUNCH for a small layer)
+                kind, arg, dz, beta = plan
+                call_hip_function("nnhipLinearModuleBackwardAct", X.data, weight.data, grad, arg, kind, beta, dz, grad_weight,
+                                  grad_bias, in_rows_num, in_features, out_features, get_current_stream_ptr())
+                _commit_fold(X, dz)
+                _finish_param(weight, grad_weight)
+                if bias is not None:
+                    _finish_param(bias, grad_bias)
+            elif folded or (hook is not None and grad_X is not None):
                 # DP overlap: parameter gradients first, hand them to the bucket (async all-reduce of a finished
                 # segment), THEN the input gradient -- the exchange rides under the dX GEMM
                 hip_linear_module_backward(X.data, weight.data, grad, None, grad_weight, grad_bias,
@@ -122,8 +126,18 @@ class _HIPLinearTensor(Tensor):
                 _finish_param(weight, grad_weight)
                 if bias is not None:
                     _finish_param(bias, grad_bias)
-                hip_linear_module_backward(X.data, weight.data, grad, grad_X, None, None,
-                                           in_rows_num, in_features, out_features, grad_X_addend=held)
+                if folded:
+                    kind, arg, dz, beta = plan
+                    if kind == 1:
+                        call_hip_function("nnhipLinearInputGradSwish", grad, weight.data, arg, dz, in_rows_num, in_features,
+                                          out_features, beta, get_current_stream_ptr())
+                    else:
+                        call_hip_function("nnhipLinearInputGradReLU", grad, weight.data, arg, dz, in_rows_num, in_features,
+                                          out_features, get_current_stream_ptr())
+                    _commit_fold(X, dz)
+                else:
+                    hip_linear_module_backward(X.data, weight.data, grad, grad_X, None, None,
+                                               in_rows_num, in_features, out_features, grad_X_addend=held)
             else:
                 hip_linear_module_backward(X.data, weight.data, grad, grad_X, grad_weight, grad_bias,
                                            in_rows_num, in_features, out_features, grad_X_addend=held)

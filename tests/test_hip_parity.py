@@ -228,6 +228,48 @@ def test_gemm_persistent_input_grad(hip, rows, inf, outf, inplace):
     assert torch.equal(dz, dz2)
 
 
+@pytest.mark.parametrize("rows,inf,outf", [(32, 128, 10), (256, 784, 10), (37, 50, 33), (100, 40, 260), (2048, 1024, 384)])
+@pytest.mark.parametrize("kind", [1, 2])
+def test_linear_backward_act(hip, rows, inf, outf, kind):
+    """nnhipLinearModuleBackwardAct: dZ = (dO W) * act'(arg), dW = dO^T X, db from one call -- for small layers from ONE launch
+    (gemm_small_pair_kernel).  Against float64, and bit-identical to nnhipLinearInputGradSwish / ReLU followed by
+    nnhipLinearModuleBackward(dX = NULL), which run the same tiles in separate launches."""
+    from neunet_hip._lib import call_hip_function as call, get_current_stream_ptr
+    import torch
+    rng = np.random.default_rng(rows + inf + outf + kind)
+    st = get_current_stream_ptr()
+    beta = 1.3
+    X = rng.standard_normal((rows, inf)).astype(np.float32)
+    W = (rng.standard_normal((outf, inf)) / np.sqrt(inf)).astype(np.float32)
+    dO = rng.standard_normal((rows, outf)).astype(np.float32)
+    A = rng.standard_normal((rows, inf)).astype(np.float32)              # z (swish) or the ReLU output f
+    if kind == 2:
+        A = np.maximum(A, 0)
+    x, w, g, a = dev(X), dev(W), dev(dO), dev(A)
+    dz = a.clone() if kind == 1 else torch.full((rows, inf), float("nan"), device="cuda")
+    dw = torch.full((outf, inf), float("nan"), device="cuda")
+    db = torch.full((outf,), float("nan"), device="cuda")
+    call("nnhipLinearModuleBackwardAct", x, w, g, dz if kind == 1 else a, kind, beta, dz, dw, db, rows, inf, outf, st)
+    dx64 = dO.astype(np.float64) @ W.astype(np.float64)
+    if kind == 1:
+        s64 = 1.0 / (1.0 + np.exp(-beta * A.astype(np.float64)))
+        f64 = A * s64
+        want = dx64 * (beta * f64 + s64 * (1 - beta * f64))
+    else:
+        want = dx64 * (A > 0)
+    np.testing.assert_allclose(host(dz), want, rtol=1e-4, atol=2e-4 * np.sqrt(outf))
+    np.testing.assert_allclose(host(dw), dO.astype(np.float64).T @ X.astype(np.float64), rtol=1e-4, atol=2e-4 * np.sqrt(rows))
+    np.testing.assert_allclose(host(db), dO.astype(np.float64).sum(0), rtol=1e-4, atol=2e-4 * np.sqrt(rows))
+    dz2 = a.clone() if kind == 1 else torch.empty_like(dz)
+    dw2, db2 = torch.empty_like(dw), torch.empty_like(db)
+    if kind == 1:
+        call("nnhipLinearInputGradSwish", g, w, dz2, dz2, rows, inf, outf, beta, st)
+    else:
+        call("nnhipLinearInputGradReLU", g, w, a, dz2, rows, inf, outf, st)
+    call("nnhipLinearModuleBackward", x, w, g, None, dw2, db2, rows, inf, outf, st)
+    assert torch.equal(dz, dz2) and torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
 @pytest.mark.parametrize("rows,inf,outf", [(300, 96, 200), (128, 512, 512), (37, 50, 33), (4096, 1024, 128)])
 def test_linear_addend_extensions(hip, rows, inf, outf):
     """nnhipLinearModuleForwardEx / BackwardEx: O = XW^T + b + R and dX = dO W + G from the GEMM epilogue (also through
