@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--overlap", type=int, default=1, help="N>1: overlap the gradient exchange with the backward pass")
     ap.add_argument("--c4-batch", type=int, default=64, help="sequences per GPU for the GPT-tiny workload")
     ap.add_argument("--graph", type=int, default=1, help="c1/c4: replay the step as a captured hipGraph (1) or launch eagerly (0)")
+    ap.add_argument("--unroll", type=int, default=4, help="c1/c5, one process: training steps captured per hipGraph (1 = one step per replay)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -97,6 +98,15 @@ def timed_region(step_fn, steps, warmup, world, min_warm_s=0.0):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt
+
+
+def graph_unroll(args, world):
+    """Steps captured per hipGraph for the sub-0.1 ms workloads (C1, C5): U > 1 only for one process replaying graphs, and only
+    when the requested step counts are whole numbers of replays (EXACTLY --steps steps are timed either way)."""
+    U = max(1, int(args.unroll))
+    if world != 1 or not args.graph or args.steps % U != 0 or args.steps < U:
+        return 1
+    return U
 
 
 class EventTimer:
@@ -260,18 +270,20 @@ def workload_c1(args, rank, world):
     opt.grad_scale = 1.0 / world
     loss_fn = nn.CrossEntropyLoss()
     drng = np.random.default_rng(3000 + rank)
-    X = neunet_hip.Tensor(drng.uniform(-1, 1, (Bsz, 784)).astype(np.float32), device="cuda", requires_grad=False)
-    Y = neunet_hip.Tensor(drng.integers(0, 10, Bsz).astype(np.int32), dtype=np.int32, requires_grad=False, device="cuda")
+    U = graph_unroll(args, world)                        # steps per captured graph, each reading its own static batch slot
+    Xs = [neunet_hip.Tensor(drng.uniform(-1, 1, (Bsz, 784)).astype(np.float32), device="cuda", requires_grad=False) for _ in range(U)]
+    Ys = [neunet_hip.Tensor(drng.integers(0, 10, Bsz).astype(np.int32), dtype=np.int32, requires_grad=False, device="cuda")
+          for _ in range(U)]
     ev = EventTimer()
     from neunet_hip.graph import GraphedTrainStep
 
-    def fwd_bwd():
-        loss = loss_fn(model(X), Y)
+    def fwd_bwd(k=0):
+        loss = loss_fn(model(Xs[k]), Ys[k])
         loss.backward()
         return loss
 
     if args.graph:
-        gstep = GraphedTrainStep(fwd_bwd, opt, bucket, warmup=3, world=world)
+        gstep = GraphedTrainStep(fwd_bwd, opt, bucket, warmup=3, world=world, unroll=U)
         tick = [0]
 
         def step(timed):
@@ -297,17 +309,17 @@ def workload_c1(args, rank, world):
             if timed:
                 b.record()
 
-    dt = timed_region(step, args.steps, args.warmup, world, min_warm_s=0.5)
+    dt = timed_region(step, args.steps // U, max(1, args.warmup // U), world, min_warm_s=0.5)      # one call = U steps
     if args.graph:
         gstep.release()
-    dev_ms = ev.mean_ms()
+    dev_ms = ev.mean_ms() / U
     flops = 2.0 * 3 * Bsz * (784 * 128 + 128 * 10)
     return {
         "samples_per_step": Bsz * world, "dt": dt,
         "config": {"workload": "C1: MNIST-MLP 784->128->10 training step (Linear+ReLU+CrossEntropy+Adam), batch 32 per GPU",
                    "global_batch": Bsz * world, "parallelism": f"dp{world}",
-                   "launch": "hipGraph replay" if args.graph else "eager"},
-        "roofline": {"kernel": "whole step (13 launches, launch-latency bound)", "bound": "mfma",
+                   "launch": (f"hipGraph replay, {U} steps per graph" if U > 1 else "hipGraph replay") if args.graph else "eager"},
+        "roofline": {"kernel": "whole step (7 launches, launch-latency bound)", "bound": "mfma",
                      "achieved": round(flops / (dev_ms * 1e-3) / 1e12, 5), "peak": PEAK_F32_MFMA_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(flops / (dev_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 6),
                      "traffic": None, "avg_step_device_ms": round(dev_ms, 4)},
@@ -648,18 +660,20 @@ def workload_c5(args, rank, world):
     opt = Adam(params, lr=1e-3)
     opt.grad_scale = 1.0 / world
     rng = np.random.default_rng(5000 + rank)
-    X = neunet_hip.Tensor(rng.uniform(-1, 1, (Bsz, 1, 28, 28)).astype(np.float32), device="cuda", requires_grad=False)
-    Tt = neunet_hip.Tensor(np.eye(10, dtype=np.float32)[rng.integers(0, 10, Bsz)], device="cuda", requires_grad=False)
+    U = graph_unroll(args, world)                        # steps per captured graph, each reading its own static batch slot
+    Xs = [neunet_hip.Tensor(rng.uniform(-1, 1, (Bsz, 1, 28, 28)).astype(np.float32), device="cuda", requires_grad=False) for _ in range(U)]
+    Ts = [neunet_hip.Tensor(np.eye(10, dtype=np.float32)[rng.integers(0, 10, Bsz)], device="cuda", requires_grad=False)
+          for _ in range(U)]
     loss_fn = nn.MSELoss()
     ev = EventTimer()
 
-    def fwd_bwd():
-        loss = loss_fn(model(X), Tt)
+    def fwd_bwd(k=0):
+        loss = loss_fn(model(Xs[k]), Ts[k])
         loss.backward()
         return loss
 
     if args.graph:
-        gstep = GraphedTrainStep(fwd_bwd, opt, bucket, warmup=3, world=world)
+        gstep = GraphedTrainStep(fwd_bwd, opt, bucket, warmup=3, world=world, unroll=U)
         tick = [0]
 
         def step(timed):
@@ -685,10 +699,10 @@ def workload_c5(args, rank, world):
             if timed:
                 b.record()
 
-    dt = timed_region(step, args.steps, args.warmup, world, min_warm_s=0.5)
+    dt = timed_region(step, args.steps // U, max(1, args.warmup // U), world, min_warm_s=0.5)      # one call = U steps
     if args.graph:
         gstep.release()
-    dev_ms = ev.mean_ms()
+    dev_ms = ev.mean_ms() / U
     # algorithmic HBM bytes of the two conv layers fwd + bwd: 4*(|X|+|O|+|W|) forward, x2 backward
     conv_bytes = 3 * 4.0 * ((Bsz * 784 + Bsz * 8 * 784 + 72) + (Bsz * 8 * 196 + Bsz * 16 * 196 + 1152))
     return {
@@ -697,7 +711,7 @@ def workload_c5(args, rank, world):
                                "Sigmoid, MSE, Adam), 28x28x1, batch 256 per GPU; at these shapes (Cin, Cout <= 16, 3x3) the DIRECT conv kernels run "
                                "(conv_direct_fwd/dgrad/wgrad_kernel), not the implicit-GEMM MFMA ones",
                    "global_batch": Bsz * world, "parallelism": f"dp{world}",
-                   "launch": "hipGraph replay" if args.graph else "eager"},
+                   "launch": (f"hipGraph replay, {U} steps per graph" if U > 1 else "hipGraph replay") if args.graph else "eager"},
         "roofline": {"kernel": "whole step vs the conv layers' algorithmic HBM bytes (K<=72, Cout<=16: HBM/latency bound)",
                      "bound": "hbm", "achieved": round(conv_bytes / (dev_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
                      "unit": "GB/s", "frac": round(conv_bytes / (dev_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 5), "traffic": None,

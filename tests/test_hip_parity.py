@@ -1743,6 +1743,76 @@ def test_gpt_tiny_learns(hip, dropout, fused):
     assert np.mean(losses[-10:]) < 0.3 * losses[0], (losses[0], losses[-10:])
 
 
+def test_graphed_step_unrolled(hip):
+    """GraphedTrainStep(unroll=U): U consecutive training steps captured into one graph (each reading its own static batch
+    slot) leave exactly the parameters of U single-step replays and of the eager loop -- README quick-start MLP, Adam with
+    its device-side step counter and cached bias corrections, 3 replays of 4 steps."""
+    import neunet_hip.nn as nn
+    from neunet_hip.distributed import GradBucket
+    from neunet_hip.graph import GraphedTrainStep
+    from neunet_hip.optim import Adam
+    U, R, B = 4, 3, 32
+    rng = np.random.default_rng(11)
+    data = [(rng.uniform(-1, 1, (B, 784)).astype(np.float32), rng.integers(0, 10, B).astype(np.int32)) for _ in range(2 + U * R)]
+
+    class MLP(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.l1, self.relu, self.l2 = nn.Linear(784, 128), nn.ReLU(), nn.Linear(128, 10)
+
+        def forward(self, x):
+            return self.l2(self.relu(self.l1(x)))
+
+    def make(unroll):
+        np.random.seed(42)
+        model = MLP()
+        xs = [hip.Tensor(data[0][0], device="cuda", requires_grad=False) for _ in range(unroll)]
+        ys = [hip.Tensor(data[0][1], dtype=np.int32, device="cuda", requires_grad=False) for _ in range(unroll)]
+        loss_fn = nn.CrossEntropyLoss()
+
+        def fb(k=0):
+            loss = loss_fn(model(xs[k]), ys[k])
+            loss.backward()
+            return loss
+
+        opt = Adam(model.parameters(), lr=1e-3)
+        return model, xs, ys, fb, opt, GradBucket(model.parameters())
+
+    def feed(xs, ys, k, item):
+        xs[k].data.copy_(dev(item[0]))
+        ys[k].data.copy_(dev(item[1]))
+
+    # eager reference: 2 warm-up steps on item 0 / 1 (what the graphed objects run before capture), then U*R steps
+    m0, xs0, ys0, fb0, opt0, bk0 = make(1)
+    for item in data:
+        feed(xs0, ys0, 0, item)
+        opt0.zero_grad()
+        fb0()
+        opt0.step()
+    want = [host(p.data) for p in m0.parameters()]
+
+    for unroll in (1, U):
+        m, xs, ys, fb, opt, bk = make(unroll)
+        warm = iter(data[:2])
+
+        def fb_warm(k=0, fb=fb, xs=xs, ys=ys, warm=warm):
+            item = next(warm, None)
+            if item is not None:                         # the two eager warm-up steps read items 0 and 1 through slot 0
+                feed(xs, ys, 0, item)
+            return fb(k)
+
+        g = GraphedTrainStep(fb_warm, opt, bk, warmup=2, unroll=unroll)
+        rest = data[2:]
+        for r in range(len(rest) // unroll):
+            for k in range(unroll):
+                feed(xs, ys, k, rest[r * unroll + k])
+            g()
+        got = [host(p.data) for p in m.parameters()]
+        g.release()
+        for a, b in zip(got, want):
+            np.testing.assert_array_equal(a, b)
+
+
 def test_graphed_step_equals_eager(hip):
     """A hipGraph-replayed GPT step (neunet_hip.graph.GraphedTrainStep, device-side Adam step counter) produces
     the same parameters as the eager step, step after step, with fresh data copied into the static buffers."""
