@@ -280,6 +280,16 @@ int nnhipCrossEntropyLossEx(float* logits, float* dlogits_or_null, float* loss_r
                             int64_t ignore_index, int64_t n_rows, int64_t n_cols, char reduction,
                             float* loss_out_or_null, int32_t* count_out_or_null, nnhipStream_t stream);
 
+/* A small classifier head and its loss in one launch: logits[rows, classes] = X * W^T + b (Linear.forward, linear.py:48-58), then
+ * exactly nnhipCrossEntropyLossEx on them (out of place: dlogits != logits).  1 <= rows <= 256, 1 <= classes <= 32,
+ * 1 <= in_features <= 2048, else NNHIP_EINVAL -- the two entries called separately give the same results.  At README-MLP scale
+ * (32 x 128 -> 10) a launch is ~1/8 of the training step whatever it computes. */
+int nnhipLinearCrossEntropyLoss(const float* X, const float* W, const float* b, float* logits, float* dlogits,
+                                float* loss_rows, float* lse, const void* labels, int32_t label_bytes,
+                                const float* class_weight_or_null, int64_t ignore_index, int64_t rows, int64_t in_features,
+                                int64_t classes, char reduction, float* loss_out_or_null, int32_t* count_out_or_null,
+                                nnhipStream_t stream);
+
 /* ---- a10 RMSNorm  (replaces RMSNormForward/Backward, rmsnorm.cu:116-140, 282-308) ---------- */
 /* X_std[rows] = sqrt(mean(x^2)+eps) always written.  X_norm[rows,cols] may be NULL (not stored;
  * the backward recomputes it) -- the reference always stores it. */

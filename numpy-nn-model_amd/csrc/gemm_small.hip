@@ -13,139 +13,9 @@
 //     (deterministic), then the epilogue of gemm.hip: alpha, bias, addend, activation-gradient mask, activation, preact;
 //   * asum (row sums of A = db of a Linear) falls out of the operand registers.
 // Exact fp32 (v_mfma_f32_32x32x2_f32), same results as gemm.hip up to summation order.
-#include "common.h"
+#include "gemm_small.h"
 
 namespace nnhip {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-enum { SG_ACT_NONE = 0, SG_ACT_SWISH = 1, SG_ACT_RELU = 2, SG_ACT_SIGMOID = 3 };
-
-struct SmallGemmParams {
-    const float* A;
-    const float* B;
-    float* C;
-    const float* bias;
-    float* preact;
-    const float* addend;
-    const float* dact_arg;   // activation-gradient operand (see gemm.hip: dswish / dact)
-    float* asum;
-    int64_t M, N, K, lda, ldb, ldc;
-    float alpha, beta;
-    int act, dact, a_kmajor, b_kmajor;
-};
-
-// 4 consecutive k (k0 .. k0+3) of row r of an operand.  k-major: P[r*ld + k]; outer-major: P[k*ld + r].
-// Buffer loads with a per-lane byte offset; a lane with nothing to fetch (row past the operand, k past K, k-group past the
-// last) gets an offset beyond the descriptor's num_records and reads 0 -- no branch, no select on the loaded value.  (With
-// `if (in range) v = *p` every load sat in its own control-flow region that ended in `s_waitcnt vmcnt(0)`: the 32 loads of a
-// wave of the 32x784x128 forward were 32 memory round trips, 12 us for 6 MFLOP.)
-typedef unsigned sg_u32x4 __attribute__((ext_vector_type(4)));
-constexpr unsigned SG_OOB = 0xFFFFFFF0u;
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t sg_rsrc(const float* base, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
-}
-
-// row_off: byte offset of the lane's row (k-major: r*ld*4; outer-major: r*4), SG_OOB-safe only through `ok`
-template <bool KMAJOR, bool VEC>
-__device__ __forceinline__ float4 sg_fetch(__amdgpu_buffer_rsrc_t rs, unsigned ld4, unsigned row_off, bool ok, unsigned k0, unsigned K) {
-    float4 v;
-    if constexpr (KMAJOR && VEC) {                             // K % 4 == 0 here: a float4 never straddles K
-        const unsigned off = (ok && k0 < K) ? row_off + k0 * 4u : SG_OOB;
-        const sg_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
-        v.x = __uint_as_float(t.x); v.y = __uint_as_float(t.y); v.z = __uint_as_float(t.z); v.w = __uint_as_float(t.w);
-    } else {
-        const unsigned step = KMAJOR ? 4u : ld4;
-        const unsigned base = KMAJOR ? row_off + k0 * 4u : k0 * ld4 + row_off;
-        v.x = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (ok && k0 < K) ? base : SG_OOB, 0, 0));
-        v.y = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (ok && k0 + 1 < K) ? base + step : SG_OOB, 0, 0));
-        v.z = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (ok && k0 + 2 < K) ? base + 2 * step : SG_OOB, 0, 0));
-        v.w = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (ok && k0 + 3 < K) ? base + 3 * step : SG_OOB, 0, 0));
-    }
-    return v;
-}
-
-// one 32x32 output tile (bx, by) of problem p; `red` / `ared`: NW x 1024 and NW x 32 floats of LDS
-template <int NW, bool AKM, bool BKM, bool VEC, int U>
-__device__ __forceinline__ void sg_tile(const SmallGemmParams& p, int bx, int by, float (*red)[32 * 32], float (*ared)[32]) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, lh = lane >> 5;
-    const int64_t m0 = (int64_t)by * 32, n0 = (int64_t)bx * 32;
-    const unsigned groups = (unsigned)((p.K + 7) >> 3), K = (unsigned)p.K;
-    // operand windows: everything from the operand's origin to the end of its last row / k-line (gemm_small() checked that this
-    // fits 31 bits); the per-lane row offset is loop-invariant
-    const unsigned la4 = (unsigned)p.lda * 4u, lb4 = (unsigned)p.ldb * 4u;
-    const __amdgpu_buffer_rsrc_t rsa = sg_rsrc(p.A, (unsigned)((AKM ? (p.M - 1) * p.lda + p.K : (p.K - 1) * p.lda + p.M) * 4));
-    const __amdgpu_buffer_rsrc_t rsb = sg_rsrc(p.B, (unsigned)((BKM ? (p.N - 1) * p.ldb + p.K : (p.K - 1) * p.ldb + p.N) * 4));
-    const bool a_ok = m0 + l31 < p.M, b_ok = n0 + l31 < p.N;
-    const unsigned a_row = (unsigned)(m0 + l31) * (AKM ? la4 : 4u), b_row = (unsigned)(n0 + l31) * (BKM ? lb4 : 4u);
-    f32x16 acc;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-    float asum = 0.f;
-    // U k-groups in flight per wave (2 x U float4 of operands).  U = 8: a K = 784 over 8 waves is two round trips to L2;
-    // the U = 16 instantiation (k-major operands, 64 < K/8 <= 128 groups per block) makes it one.
-    for (unsigned gb = wave; gb < groups; gb += (unsigned)NW * U) {
-        float4 a[U], b[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const unsigned k0 = 8u * (gb + (unsigned)u * NW) + 4u * lh;      // a k-group past the last has k0 >= K: reads 0
-            a[u] = sg_fetch<AKM, VEC>(rsa, la4, a_row, a_ok, k0, K);
-            b[u] = sg_fetch<BKM, VEC>(rsb, lb4, b_row, b_ok, k0, K);
-        }
-        // all 2U loads are in flight before the first MFMA waits for its operands (left alone, the scheduler sinks each load
-        // to just above its use -- `load, s_waitcnt vmcnt(0), mfma` U times: U memory round trips instead of one)
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b[u].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, b[u].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].z, b[u].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].w, b[u].w, acc, 0, 0, 0);
-            asum += (a[u].x + a[u].y) + (a[u].z + a[u].w);
-        }
-    }
-    // accumulator register e holds row (e&3) + 8(e>>2) + 4lh, column l31
-#pragma unroll
-    for (int e = 0; e < 16; ++e) red[wave][((e & 3) + 8 * (e >> 2) + 4 * lh) * 32 + l31] = acc[e];
-    if (p.asum) {
-        asum += __shfl_xor(asum, 32, 64);
-        if (lh == 0) ared[wave][l31] = asum;
-    }
-    __syncthreads();
-    constexpr int PER = 1024 / (NW * 64);                      // outputs per thread
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int o = tid + i * NW * 64;
-        float v = red[0][o];
-#pragma unroll
-        for (int w = 1; w < NW; ++w) v += red[w][o];
-        const int64_t row = m0 + (o >> 5), col = n0 + (o & 31);
-        if (row < p.M && col < p.N) {
-            v = p.alpha * v + (p.bias ? p.bias[col] : 0.f);
-            if (p.addend) v += p.addend[row * p.ldc + col];
-            if (p.dact_arg) {
-                const float x = p.dact_arg[row * p.ldc + col];
-                v = p.dact == 2 ? (x > 0.f ? v : 0.f) : v * swish_grad_(x, p.beta);
-            }
-            if (p.act == SG_ACT_SWISH) {
-                if (p.preact) p.preact[row * p.ldc + col] = v;
-                v = v * sigmoid_fast_(p.beta * v);
-            } else if (p.act == SG_ACT_RELU) {
-                v = fmaxf(v, 0.f);
-            } else if (p.act == SG_ACT_SIGMOID) {
-                v = sigmoid_fast_(v);
-            }
-            p.C[row * p.ldc + col] = v;
-        }
-    }
-    if (p.asum && bx == 0 && tid < 32) {
-        float s = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) s += ared[w][tid];
-        if (m0 + tid < p.M) p.asum[m0 + tid] = s;
-    }
-}
 
 template <int NW, bool AKM, bool BKM, bool VEC, int U = 8>
 __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(const SmallGemmParams p) {

@@ -14,6 +14,7 @@
 #include <unordered_map>
 
 #include "common.h"
+#include "gemm_small.h"
 
 namespace nnhip {
 
@@ -903,15 +904,15 @@ __global__ __launch_bounds__(1024) void reduce_loss_kernel(const float* __restri
 // Whole CrossEntropyLoss of a SMALL problem in one single-block launch (one 1024-thread block, a wave per row): same
 // arithmetic as the persistent kernel (the row sums run over a wave instead of a block, so the last bits of lse can
 // differ by rounding); at MNIST-MLP scale (32 x 10) a 2048-block grid would be all launch overhead.
-__global__ __launch_bounds__(1024) void ce_small_kernel(const CeArgs a) {
-    __shared__ int ired[17];
-    __shared__ float red[16];
+// The whole problem in one block of BS threads (one wave per row, waves striding the rows).
+// xs / xld: where the rows are READ (the logits themselves, or a copy of them in LDS); scale / denom from ce_prologue.
+template <int BS>
+__device__ __forceinline__ void ce_small_body(const CeArgs& a, float* red, float scale, float denom, const float* xs, int64_t xld) {
+    constexpr int NWV = BS / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float scale, denom;
-    ce_prologue<1024>(a, red, ired, scale, denom);
     float lsum = 0.f;
-    for (int64_t r = wave; r < a.rows; r += 16) {
-        const float* x = a.logits + r * a.ld;
+    for (int64_t r = wave; r < a.rows; r += NWV) {
+        const float* x = xs + r * xld;
         float* dx = a.dlogits + r * a.ld;
         const int64_t y = load_label(a.labels, r, a.lbytes);
         const bool live = y != a.ignore && y >= 0 && y < a.cols;   // same guard as the large kernels (cross_entropy.cu:176)
@@ -945,9 +946,44 @@ __global__ __launch_bounds__(1024) void ce_small_kernel(const CeArgs a) {
     __syncthreads();
     if (threadIdx.x == 0) {
         float t = 0.f;
-        for (int i = 0; i < 16; ++i) t += red[i];
+        for (int i = 0; i < NWV; ++i) t += red[i];
         a.loss_out[0] = a.mode == 1 ? t / denom : t;
     }
+}
+
+__global__ __launch_bounds__(1024) void ce_small_kernel(const CeArgs a) {
+    __shared__ int ired[17];
+    __shared__ float red[16];
+    float scale, denom;
+    ce_prologue<1024>(a, red, ired, scale, denom);
+    ce_small_body<1024>(a, red, scale, denom, a.logits, a.ld);
+}
+
+// A small classifier head and its loss in ONE launch: logits = X W^T + b (gemm_small.hip's tile body, 32 rows at a time, the
+// block's 8 waves splitting K), then the block runs ce_small_body on the logits it has just written.  At MNIST-MLP scale a
+// launch is ~4.7 us of a 36 us step whatever it computes.  rows <= 256, classes <= 32 (nnhipLinearCrossEntropyLoss).
+// NW waves, as gemm_small() picks them (4 for K < 64, else 8): the logits are bit-identical to nnhipLinearModuleForward's.
+// The label count (the 'mean' denominator) is taken first -- its loads fly while the GEMM's do -- and for <= 128 rows the loss
+// part reads the logits from a copy the GEMM epilogue leaves in LDS instead of waiting for its own global stores.
+template <bool VEC, int NW>
+__global__ __launch_bounds__(NW * 64) void linear_ce_small_kernel(const SmallGemmParams p, const CeArgs a) {
+    __shared__ float gred[NW][32 * 32];
+    __shared__ float ared[NW][32];
+    __shared__ float tile[128 * 32];
+    __shared__ int ired[17];
+    __shared__ float red[16];
+    float scale, denom;
+    ce_prologue<NW * 64>(a, red, ired, scale, denom);
+    const bool in_lds = p.M <= 128;
+    for (int by = 0; (int64_t)by * 32 < p.M; ++by) {
+        sg_tile<NW, true, true, VEC, 8>(p, 0, by, gred, ared, in_lds ? tile : nullptr);
+        __syncthreads();                                   // gred is reused by the next tile
+    }
+    if (!in_lds) {
+        __threadfence_block();                             // the logits were written by other threads of this block
+        __syncthreads();
+    }
+    ce_small_body<NW * 64>(a, red, scale, denom, in_lds ? tile : a.logits, in_lds ? 32 : a.ld);
 }
 
 // =================================================================================================
@@ -1398,6 +1434,51 @@ extern "C" int nnhipCrossEntropyLossEx(float* logits, float* dlogits_or_null, fl
     a.loss_out = a.mode ? loss_out_or_null : nullptr;
     a.count_out = count_out_or_null;
     return ce_launch(a, (hipStream_t)s);
+}
+
+// logits = X W^T + b (written to `logits`, [rows, classes] dense) followed by nnhipCrossEntropyLossEx on them, in ONE launch:
+// Linear.forward (neunet/nn/layers/linear.py:48-58) + CrossEntropyLoss (losses.py:59-126) for a small classifier head.
+// Limits: rows <= 256, 1 <= classes <= 32, in_features <= 2048; NNHIP_EINVAL outside them (the caller then runs the two
+// entries separately -- same results).
+extern "C" int nnhipLinearCrossEntropyLoss(const float* X, const float* W, const float* b, float* logits, float* dlogits,
+                                           float* loss_rows, float* lse, const void* labels, int32_t label_bytes,
+                                           const float* class_weight_or_null, int64_t ignore_index, int64_t rows,
+                                           int64_t in_features, int64_t classes, char reduction, float* loss_out_or_null,
+                                           int32_t* count_out_or_null, nnhipStream_t s) {
+    NNHIP_CHECK_ARG(rows >= 1 && rows <= 256 && classes >= 1 && classes <= 32 && in_features >= 1 && in_features <= 2048, NNHIP_EINVAL,
+                    "nnhipLinearCrossEntropyLoss: needs 1 <= rows <= 256, 1 <= classes <= 32, 1 <= in_features <= 2048");
+    NNHIP_CHECK_ARG(reduction == 'n' || reduction == 'm' || reduction == 's', NNHIP_EINVAL,
+                    "nnhipLinearCrossEntropyLoss: reduction must be 'n', 'm' or 's'");
+    NNHIP_CHECK_ARG(label_bytes == 2 || label_bytes == 4 || label_bytes == 8, NNHIP_EINVAL,
+                    "nnhipLinearCrossEntropyLoss: labels must be int16, int32 or int64");
+    NNHIP_CHECK_ARG(reduction == 'n' || loss_out_or_null, NNHIP_EINVAL, "nnhipLinearCrossEntropyLoss: 'm'/'s' need loss_out");
+    NNHIP_CHECK_ARG(X && W && logits && dlogits && logits != dlogits && loss_rows && lse && labels, NNHIP_EINVAL,
+                    "nnhipLinearCrossEntropyLoss: null or aliased pointer");
+    NNHIP_CHECK_ARG(aligned4(X) && aligned4(W) && aligned4(b) && aligned4(logits) && aligned4(dlogits), NNHIP_EALIGN,
+                    "nnhipLinearCrossEntropyLoss: misaligned pointer");
+    SmallGemmParams p{};
+    p.A = X; p.B = W; p.C = logits; p.bias = b; p.M = rows; p.N = classes; p.K = in_features;
+    p.lda = in_features; p.ldb = in_features; p.ldc = classes; p.alpha = 1.f; p.beta = 1.f; p.a_kmajor = 1; p.b_kmajor = 1;
+    CeArgs a{};
+    a.logits = logits; a.dlogits = dlogits; a.loss_rows = loss_rows; a.lse = lse; a.labels = labels; a.cw = class_weight_or_null;
+    a.ld = classes; a.ignore = ignore_index; a.rows = rows; a.cols = classes; a.lbytes = label_bytes;
+    a.mode = reduction == 'm' ? 1 : (reduction == 's' ? 2 : 0);
+    a.scale_host = a.mode == 1 ? -1.f : 1.f;
+    a.loss_out = a.mode ? loss_out_or_null : nullptr;
+    a.count_out = count_out_or_null;
+    a.count_in_kernel = a.mode == 1 ? 1 : 0;
+    const bool vec = (in_features & 3) == 0 && aligned16(X) && aligned16(W);
+    const bool nw8 = ((in_features + 7) >> 3) >= 8;        // gemm_small()'s choice
+    hipStream_t st = (hipStream_t)s;
+    if (nw8) {
+        if (vec) hipLaunchKernelGGL((linear_ce_small_kernel<true, 8>), dim3(1), dim3(512), 0, st, p, a);
+        else hipLaunchKernelGGL((linear_ce_small_kernel<false, 8>), dim3(1), dim3(512), 0, st, p, a);
+    } else {
+        if (vec) hipLaunchKernelGGL((linear_ce_small_kernel<true, 4>), dim3(1), dim3(256), 0, st, p, a);
+        else hipLaunchKernelGGL((linear_ce_small_kernel<false, 4>), dim3(1), dim3(256), 0, st, p, a);
+    }
+    NNHIP_LAUNCH_CHECK("linear_ce_small_kernel");
+    return 0;
 }
 
 extern "C" int nnhipCrossEntropyForwardBackward(float* logits, float* loss, float* lse,

@@ -91,6 +91,8 @@ _SIGNATURES = {
     "nnhipCrossEntropyDenominator": (ctypes.c_int, [P, c_int32, c_int64, c_int64, P, c_int64, P, P, c_void_p]),
     "nnhipReduceLoss": (ctypes.c_int, [P, c_int64, c_char, P, P, c_void_p]),
     "nnhipCrossEntropyLoss": (ctypes.c_int, [P, P, P, P, P, c_int64, ctypes.c_int32, c_int64, c_int64, ctypes.c_char, P, P, c_void_p]),
+    "nnhipLinearCrossEntropyLoss": (ctypes.c_int, [P, P, P, P, P, P, P, P, c_int32, P, c_int64, c_int64, c_int64, c_int64, c_char, P, P,
+                                                   c_void_p]),
     "nnhipCrossEntropyLossEx": (ctypes.c_int, [P, P, P, P, P, c_int32, P, c_int64, c_int64, c_int64, c_int64, c_char, P, P, c_void_p]),
     "nnhipRMSNormForward": (ctypes.c_int, [P, P, P, P, P, P, c_int64, c_int64, c_float, c_void_p]),
     "nnhipRMSNormBackward": (ctypes.c_int, [P, P, P, P, P, P, P, P, c_int64, c_int64, c_void_p]),

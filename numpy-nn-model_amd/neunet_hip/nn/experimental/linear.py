@@ -167,6 +167,11 @@ class _HIPLinearTensor(Tensor):
     def pending(self) -> bool:
         return self._data is None and self._thunk is not None
 
+    def adopt(self, data):
+        """A consumer launched the deferred GEMM inside its own kernel (losses.py: Linear -> CrossEntropy): `data` is its
+        output."""
+        self._data, self._thunk, self._operands = data, None, None
+
     def run_fused(self, activation: int, beta: float = 1.0, save_preactivation: bool = False):
         """Launch the deferred GEMM with `activation` in its epilogue; returns act(XW^T + b).  With save_preactivation the
         same launch also writes z = XW^T + b, which becomes this tensor's data."""
@@ -242,7 +247,9 @@ class HIPLinear(Module):
             if xdata is not X.data:
                 X = _ContiguousView(X, xdata)
             args = (X, self.weight, self.bias, input_rows, self.in_features, self.out_features, None)
-            return _HIPLinearTensor(None, args, "linear", device=self.device, thunk=launch, shape=out_shape)
+            out = _HIPLinearTensor(None, args, "linear", device=self.device, thunk=launch, shape=out_shape)
+            out._operands = (xdata, w_ptr, b_ptr)     # for a consumer that fuses the pending GEMM into its own launch
+            return out
         output = X.xp.empty(out_shape, dtype=np.float32)
         addend = None
         if residual is not None:

@@ -63,6 +63,40 @@ def _LABEL_BYTES():
     return {torch.int16: 2, torch.int32: 4, torch.int64: 8}
 
 
+def _fused_linear_cross_entropy(y_pred, labels, reduction, ignore_index, weight):
+    """If y_pred is the still-pending output of a small HIPLinear (a classifier head: <= 256 rows, <= 32 classes), run the
+    GEMM and the loss as ONE launch (nnhipLinearCrossEntropyLoss) and hand the logits to the Linear's tensor.  Returns
+    (loss, grad_logits) or None when the ordinary two-launch path has to run."""
+    import torch
+    ops = getattr(y_pred, "_operands", None)
+    if ops is None or not getattr(y_pred, "pending", lambda: False)() or len(y_pred.shape) != 2:
+        return None
+    rows, classes = y_pred.shape
+    xdata, w, b = ops
+    in_features = w.shape[1]
+    if not (1 <= rows <= 256 and 1 <= classes <= 32 and 1 <= in_features <= 2048):
+        return None
+    if labels.ndim != 1 or labels.shape[0] != rows or labels.dtype not in _LABEL_BYTES() or reduction not in _RED:
+        return None                                    # let the ordinary path raise its errors
+    if weight is not None and (tuple(weight.shape) != (classes,) or weight.dtype != torch.float32):
+        return None
+    labels = contiguous(labels)
+    dev = xdata.device
+    logits = torch.empty((rows, classes), dtype=torch.float32, device=dev)
+    grad_logits = torch.empty_like(logits)
+    loss_rows = torch.empty(rows, dtype=torch.float32, device=dev)
+    lse = torch.empty(rows, dtype=torch.float32, device=dev)
+    loss = count = None
+    if reduction != "none":
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        count = torch.empty(1, dtype=torch.int32, device=dev) if reduction == "mean" else None
+    call_hip_function("nnhipLinearCrossEntropyLoss", xdata, w, b, logits, grad_logits, loss_rows, lse, labels,
+                      _LABEL_BYTES()[labels.dtype], None if weight is None else contiguous(weight), int(ignore_index), rows,
+                      in_features, classes, _RED[reduction], loss, count, get_current_stream_ptr())
+    y_pred.adopt(logits)
+    return (loss_rows if reduction == "none" else loss), grad_logits
+
+
 class _HIPCrossEntropyTensor(Tensor):
     _implicit_seed = True      # backward() with no argument needs no ones tensor: grad_fn below handles the unit seed
 
@@ -106,9 +140,14 @@ class HIPCrossEntropyLoss(Module):
             raise TypeError("Predictions must be of float32 dtype")
         if y_true.dtype not in ("int16", "int32", "int64"):
             raise TypeError("Target must be of int dtype")
-        loss, grad_y_pred = cross_entropy_forward_backward(y_pred.data, y_true.data, reduction=self.reduction,
-                                                           ignore_index=self.ignore_index, inplace=self.inplace,
-                                                           weight=self.weight)
+        fused = None if self.inplace else _fused_linear_cross_entropy(y_pred, y_true.data, self.reduction, self.ignore_index,
+                                                                     self.weight)
+        if fused is not None:
+            loss, grad_y_pred = fused
+        else:
+            loss, grad_y_pred = cross_entropy_forward_backward(y_pred.data, y_true.data, reduction=self.reduction,
+                                                               ignore_index=self.ignore_index, inplace=self.inplace,
+                                                               weight=self.weight)
         return _HIPCrossEntropyTensor(loss, (y_pred, grad_y_pred), "cross_entropy", device="cuda")
 
 

@@ -1743,6 +1743,79 @@ def test_gpt_tiny_learns(hip, dropout, fused):
     assert np.mean(losses[-10:]) < 0.3 * losses[0], (losses[0], losses[-10:])
 
 
+@pytest.mark.parametrize("rows,inf,classes,reduction", [(32, 128, 10, "mean"), (200, 784, 10, "sum"), (256, 2048, 32, "none"),
+                                                         (7, 50, 3, "mean"), (64, 33, 1, "mean")])
+def test_linear_cross_entropy_fused(hip, rows, inf, classes, reduction):
+    """nnhipLinearCrossEntropyLoss (a small classifier head and its loss in one launch): logits, loss, d(logits) against the
+    oracle, and bit-identical to nnhipLinearModuleForward followed by nnhipCrossEntropyLossEx; ignored and out-of-range labels,
+    class weights.  Module level: CrossEntropyLoss applied to a pending Linear output takes the fused entry and the backward pass
+    gives the gradients of the unfused tape."""
+    from neunet_hip._lib import call_hip_function as call, get_current_stream_ptr
+    import neunet_hip.nn as nn
+    import torch
+    rng = np.random.default_rng(rows + inf + classes)
+    st = get_current_stream_ptr()
+    X = rng.standard_normal((rows, inf)).astype(np.float32)
+    W = (rng.standard_normal((classes, inf)) / np.sqrt(inf)).astype(np.float32)
+    b = rng.standard_normal((1, classes)).astype(np.float32)
+    IGN = 0                                                    # an in-range ignore_index: the oracle gathers weight[label] first
+    Y = rng.integers(0, classes, rows).astype(np.int32)
+    Y[::5] = IGN
+    cw = rng.uniform(0.5, 2.0, classes).astype(np.float32)
+    red = {"mean": b"m", "sum": b"s", "none": b"n"}[reduction]
+    x, w, bb, y, cwd = dev(X), dev(W), dev(b), dev(Y), dev(cw)
+
+    def run(fused, weight):
+        logits = torch.full((rows, classes), float("nan"), device="cuda")
+        dl = torch.full((rows, classes), float("nan"), device="cuda")
+        lr, lse = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+        loss = torch.full((), float("nan"), device="cuda")
+        cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+        if fused:
+            call("nnhipLinearCrossEntropyLoss", x, w, bb, logits, dl, lr, lse, y, 4, weight, IGN, rows, inf, classes, red,
+                 None if reduction == "none" else loss, cnt if reduction == "mean" else None, st)
+        else:
+            call("nnhipLinearModuleForward", x, w, bb, logits, rows, inf, classes, st)
+            call("nnhipCrossEntropyLossEx", logits, dl, lr, lse, y, 4, weight, classes, IGN, rows, classes, red,
+                 None if reduction == "none" else loss, cnt if reduction == "mean" else None, st)
+        return logits, dl, lr, lse, loss, cnt
+
+    for weight in (None, cwd):
+        f, u = run(True, weight), run(False, weight)
+        assert torch.equal(f[0], u[0])                         # the logits: same tile code, same wave split
+        for name, a, c in zip(("dlogits", "loss_rows", "lse"), f[1:4], u[1:4]):   # same formulas, a 512- vs 1024-thread block
+            np.testing.assert_allclose(host(a), host(c), rtol=2e-6, atol=1e-7, err_msg=name)
+        if reduction != "none":
+            np.testing.assert_allclose(host(f[4]), host(u[4]), rtol=2e-6, atol=1e-7)
+        if reduction == "mean":
+            assert int(f[5].item()) == int(u[5].item())
+        z = O.linear_forward(X, W, b)
+        np.testing.assert_allclose(host(f[0]), z, **TOL)
+        if classes > 1:                                        # (one class, every label ignored: 0/0 in the oracle's mean)
+            want_loss, want_grad = O.cross_entropy_forward_backward(z, Y, None if weight is None else cw, IGN, reduction)
+            got_loss = host(f[2]) if reduction == "none" else host(f[4])
+            np.testing.assert_allclose(got_loss, want_loss, rtol=1e-4, atol=1e-5)
+            np.testing.assert_allclose(host(f[1]), want_grad, rtol=1e-4, atol=1e-6)
+
+    # module level: the tape with and without the fusion
+    def tape(fuse):
+        np.random.seed(9)
+        lin = nn.Linear(inf, classes)
+        xt = T(hip, X)
+        out = lin(xt)
+        if not fuse:
+            out.data                                           # materialise the Linear first: the two-launch path
+        loss = nn.CrossEntropyLoss(reduction=reduction, ignore_index=IGN)(out, hip.Tensor(Y, dtype=np.int32, device="cuda", requires_grad=False))
+        if reduction == "none":
+            loss.backward(dev(np.ones(rows, np.float32)))
+        else:
+            loss.backward()
+        return host(loss.data), host(out.data), host(xt.grad), host(lin.weight.grad), host(lin.bias.grad)
+
+    for a, c in zip(tape(True), tape(False)):
+        np.testing.assert_allclose(a, c, rtol=1e-5, atol=1e-6)
+
+
 def test_graphed_step_unrolled(hip):
     """GraphedTrainStep(unroll=U): U consecutive training steps captured into one graph (each reading its own static batch
     slot) leave exactly the parameters of U single-step replays and of the eager loop -- README quick-start MLP, Adam with
