@@ -601,6 +601,119 @@ static int launch_direct_wgrad(const float* X, const float* dO, float* part, con
     return 0;
 }
 
+// wgrad for small channel counts on the 16x16x4 MFMA: per image a [Cout <= 16] x [Cin*9 + 1] x [Ho*Wo] GEMM
+//   dW[co][ci,r,q] = sum_p dO[co][p] * X[ci][ho(p)*sh - pu + r*dh][wo(p)*sw - pl + q*dw],   db[co] = sum_p dO[co][p] * 1
+// with the image zero-padded in LDS (no bounds logic in the loop) and dO[b] next to it.  Lane (l16, kq): A operand = dO[co = l16]
+// [pixel 4s + kq], B operand of column tile t = the padded image at (column n = l16 + 16t: its (ci, r, q) offset, fixed per
+// lane) + the pixel's offset; the db column reads a cell that holds 1.0.  The four waves interleave the 4-pixel steps and keep
+// their 16 x 16NT accumulators across the images a block walks; they meet once, in LDS, in wave order (deterministic), and the
+// per-block partials go to conv_wgrad_reduce_kernel as before.  The direct kernel this replaces (thread <-> (ci, pixel slice),
+// CO*9 accumulators per thread, a 3-stage shuffle tree over 160 values) spent its time in LDS latency and that tree: C5 conv2
+// 18.5 us, conv1 13.1.
+typedef float cw_f32x4 __attribute__((ext_vector_type(4)));
+template <int NT>
+__global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(const float* __restrict__ X, const float* __restrict__ dO,
+                                                              float* __restrict__ part, const ConvGeom g, int ncols) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    const int HW = g.H * g.W, HWo = g.Ho * g.Wo;
+    const int Hp = (g.Ho - 1) * g.sh + 2 * g.dh + 1, Wp = (g.Wo - 1) * g.sw + 2 * g.dw + 1;   // padded extent the taps reach
+    const int S = (HWo + 3) >> 2, Lg = 4 * S;             // 4-pixel steps; dO rows padded with zeros to whole steps
+    const int nXp = g.Cin * Hp * Wp;
+    float* Xp = wsm;                                       // [Cin][Hp][Wp], then Xp[nXp] = 1.0 (the db column)
+    float* Gs = wsm + nXp + 4;                             // [Cout][Lg]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, kq = lane >> 4;
+    const int Nw = g.Cin * 9;
+    int nbase[NT], nmul[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int n = l16 + 16 * t;
+        if (n < Nw) {
+            const int ci = n / 9, rq = n - ci * 9, r = rq / 3, q = rq - r * 3;
+            nbase[t] = (ci * Hp + r * g.dh) * Wp + q * g.dw;
+            nmul[t] = 1;
+        } else {
+            nbase[t] = nXp;                                // 1.0: the db column (columns past it are never stored)
+            nmul[t] = 0;
+        }
+    }
+    const bool co_ok = l16 < g.Cout;
+    const int abase = (co_ok ? l16 : 0) * Lg;
+    const float inv_wo = 1.0f / (float)g.Wo;
+    cw_f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = cw_f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = blockIdx.x; b < g.B; b += gridDim.x) {
+        __syncthreads();                                   // the previous image's readers are done
+        const float* xb = X + (int64_t)b * g.Cin * HW;
+        stage_to_lds(Xp, xb, nXp, tid, [&](int i) -> int64_t {
+            const int c = i / (Hp * Wp), rem = i - c * (Hp * Wp), hp = rem / Wp, wp = rem - hp * Wp;
+            const int h = hp - g.pu, w = wp - g.pl;
+            return (h >= 0 && h < g.H && w >= 0 && w < g.W) ? (int64_t)c * HW + h * g.W + w : -1;
+        });
+        if (tid == 0) Xp[nXp] = 1.0f;
+        const float* gb = dO + (int64_t)b * g.Cout * HWo;
+        stage_to_lds(Gs, gb, g.Cout * Lg, tid, [&](int i) -> int64_t {
+            const int c = i / Lg, pz = i - c * Lg;
+            return pz < HWo ? (int64_t)c * HWo + pz : -1;
+        });
+        __syncthreads();
+        // four steps per iteration, all their LDS reads issued before the first MFMA (one step at a time is address -> LDS
+        // latency -> MFMA, 49 times over for a 28x28 image); a step past the last one multiplies a = 0
+        for (int s0 = wave; s0 < S; s0 += 16) {
+            float av[4], bv[4][NT];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int sx = s0 + 4 * u;
+                const bool live = sx < S;
+                const int p = 4 * (live ? sx : S - 1) + kq, pc = min(p, HWo - 1);   // a pixel past the image multiplies dO = 0
+                // p / Wo through the reciprocal: exact for the pixel counts that fit LDS (|error| << 0.5 / Wo)
+                const int ho = (int)(((float)pc + 0.5f) * inv_wo), wo = pc - ho * g.Wo;
+                const int poff = ho * g.sh * Wp + wo * g.sw;
+                const float gv = Gs[abase + p];
+                av[u] = (co_ok && live) ? gv : 0.f;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) bv[u][t] = Xp[nbase[t] + nmul[t] * poff];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u][t], acc[t], 0, 0, 0);
+        }
+    }
+    // ---- the four waves meet: accumulator v of tile t is D[co = 4 kq + v][n = l16 + 16 t] -------------------------------------
+    __syncthreads();
+    constexpr int RW = 16 * NT;
+    float* R = wsm;                                        // [4 waves][16][RW]
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) R[(wave * 16 + 4 * kq + v) * RW + 16 * t + l16] = acc[t][v];
+    __syncthreads();
+    const int total = g.Cout * ncols;
+    for (int idx = tid; idx < total; idx += 256) {
+        const int co = idx / ncols, n = idx - co * ncols;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) v += R[(w * 16 + co) * RW + n];
+        part[(int64_t)blockIdx.x * total + idx] = v;
+    }
+}
+
+template <int NT>
+static int launch_mfma_wgrad(const float* X, const float* dO, float* part, const ConvGeom& g, int ncols, int blocks, size_t lds,
+                             hipStream_t st) {
+    auto kern = conv_mfma_wgrad_kernel<NT>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        if (e != hipSuccess) return hip_status(e, "hipFuncSetAttribute(conv_mfma_wgrad_kernel)");
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, X, dO, part, g, ncols);
+    NNHIP_LAUNCH_CHECK("conv_mfma_wgrad_kernel");
+    return 0;
+}
+
 static bool conv_direct_ok(const ConvGeom& g) {
     static const bool off = []() { const char* e = getenv("NNHIP_CONV_DIRECT"); return e && atoi(e) == 0; }();
     // (both activation tensors are addressed with 32-bit byte offsets below CD_OOB)
@@ -679,10 +792,30 @@ extern "C" int nnhipConv2dBackward(const float* X, const float* W, const float* 
         const int blocks = g.B < 512 ? g.B : 512;
         float* part = static_cast<float*>(workspace((size_t)blocks * total * sizeof(float)));
         NNHIP_CHECK_ARG(part != nullptr, NNHIP_ENOMEM, "nnhipConv2dBackward: workspace allocation failed");
+        // the 16x16x4-MFMA kernel when its padded image + zero-padded dO fit LDS (NNHIP_CONV_WGRAD_MFMA=0: the direct kernel)
+        static const bool mfma_on = []() { const char* e = getenv("NNHIP_CONV_WGRAD_MFMA"); return !e || atoi(e) != 0; }();
+        const int Hp = (g.Ho - 1) * g.sh + 2 * g.dh + 1, Wp = (g.Wo - 1) * g.sw + 2 * g.dw + 1;
+        const int Lg = 4 * ((g.Ho * g.Wo + 3) / 4), nt = (ncols + 15) / 16;
+        const int nt_inst = nt <= 3 ? nt : nt <= 5 ? 5 : 10;   // the instantiation that will run (its LDS meeting area is 16*NT wide)
+        size_t m_lds = ((size_t)g.Cin * Hp * Wp + 4 + (size_t)g.Cout * Lg) * sizeof(float);
+        const size_t m_red = (size_t)4 * 16 * 16 * nt_inst * sizeof(float);
+        if (m_lds < m_red) m_lds = m_red;
+        int rc;
+        if (mfma_on && nt <= 10 && m_lds <= 60 * 1024) {
+            rc = nt <= 1 ? launch_mfma_wgrad<1>(X, dO, part, g, ncols, blocks, m_lds, st)
+               : nt <= 2 ? launch_mfma_wgrad<2>(X, dO, part, g, ncols, blocks, m_lds, st)
+               : nt <= 3 ? launch_mfma_wgrad<3>(X, dO, part, g, ncols, blocks, m_lds, st)
+               : nt <= 5 ? launch_mfma_wgrad<5>(X, dO, part, g, ncols, blocks, m_lds, st)
+                         : launch_mfma_wgrad<10>(X, dO, part, g, ncols, blocks, m_lds, st);
+            if (rc) return rc;
+            hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)ceil_div(total, 4)), dim3(256), 0, st, part, dW, db, blocks,
+                               g.Cout, Nw, ncols);
+            NNHIP_LAUNCH_CHECK("conv_wgrad_reduce_kernel");
+            return 0;
+        }
         const int cip = g.Cin <= 1 ? 1 : g.Cin <= 2 ? 2 : g.Cin <= 4 ? 4 : g.Cin <= 8 ? 8 : 16;
         const size_t red = (size_t)4 * (g.Cout <= 8 ? 8 : 16) * (cip * 9 + 1) * sizeof(float);
         if (wg_lds < red) wg_lds = red;
-        int rc;
 #define NNHIP_WG(CO_)                                                                                                        \
         (cip == 1 ? launch_direct_wgrad<CO_, 1>(X, dO, part, g, ncols, blocks, wg_lds, st)                                      \
          : cip == 2 ? launch_direct_wgrad<CO_, 2>(X, dO, part, g, ncols, blocks, wg_lds, st)                                    \

@@ -1002,6 +1002,10 @@ def test_conv2d_golden(hip, golden, name):
     ((3, 4, 17, 13), 3, (3, 2), (2, 1), (2, 0), (1, 2)),   # Cout <= 4 variant, strides, asymmetric everything
     ((2, 16, 9, 9), 16, 5, (1, 1), (2, 2), (1, 1)),        # 25 taps, 16 x 16 channels (the direct kernels' limits)
     ((2, 3, 12, 12), 12, 3, (2, 2), (1, 1), (2, 2)),       # stride 2 + dilation 2: inexact divisions in dgrad
+    # 3x3, small channels: the 16x16x4-MFMA wgrad (padded image in LDS) with 4 / 10 column tiles, odd pixel counts, wide padding
+    ((4, 7, 10, 15), 9, 3, (1, 1), (0, 2), (1, 1)),
+    ((2, 16, 8, 8), 16, 3, (1, 1), (1, 1), (1, 1)),
+    ((5, 2, 7, 5), 3, 3, (1, 2), (2, 2), (2, 1)),
 ])
 def test_conv2d_vs_oracle(hip, xshape, cout, ks, stride, pad, dil):
     from neunet_hip.nn.experimental import HIPConv2d
