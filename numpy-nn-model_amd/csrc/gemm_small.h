@@ -53,63 +53,62 @@ __device__ __forceinline__ float4 sg_fetch(__amdgpu_buffer_rsrc_t rs, unsigned l
     return v;
 }
 
-// one 32x32 output tile (bx, by) of problem p; `red` / `ared`: NW x 1024 and NW x 32 floats of LDS
+// One 16x16 output tile (bx, by) of problem p on the 16x16x4 MFMA; `red` / `ared`: NW x 256 and NW x 16 floats of LDS.
+// The block's NW waves split K (wave w takes k-groups w, w + NW, ...; a k-group = 16 consecutive k = 4 MFMAs); lane (l16, kq)
+// holds A[m0 + l16][16g + 4kq .. +3] and the same of B, and step j of a group multiplies component j of both: k = 16g + 4kq + j
+// on both sides (any permutation of k will do).  The four kq lanes of a row read 64 CONTIGUOUS bytes, so a wave-load touches 16
+// cache lines.  (Round 2 first had 32x32 tiles on the 32x32x2 MFMA with lane <-> row, 16 B per lane: 64 lines per wave-load,
+// and the vector L1 looks lines up one per clock -- the 32x784x128 forward spent ~16 k of its 17 k cycles there, 8.4 us
+// against 4.5 now: tools/probes/small_gemm_phases.hip keeps both layouts side by side.)
+// U k-groups (2U float4 of operands) are in flight per wave before the first MFMA.
+typedef float sg_f32x4 __attribute__((ext_vector_type(4)));
 template <int NW, bool AKM, bool BKM, bool VEC, int U>
-__device__ __forceinline__ void sg_tile(const SmallGemmParams& p, int bx, int by, float (*red)[32 * 32], float (*ared)[32],
-                                        float* lds_copy = nullptr) {     // lds_copy: also keep C[row][0..32) at lds_copy[row * 32 + col]
+__device__ __forceinline__ void sg_tile16(const SmallGemmParams& p, int bx, int by, float (*red)[16 * 16], float (*ared)[16],
+                                          float* lds_copy = nullptr) {   // lds_copy: also keep C[row][col] at lds_copy[row * 32 + col]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, lh = lane >> 5;
-    const int64_t m0 = (int64_t)by * 32, n0 = (int64_t)bx * 32;
-    const unsigned groups = (unsigned)((p.K + 7) >> 3), K = (unsigned)p.K;
-    // operand windows: everything from the operand's origin to the end of its last row / k-line (gemm_small() checked that this
-    // fits 31 bits); the per-lane row offset is loop-invariant
+    const int l16 = lane & 15, kq = lane >> 4;
+    const int64_t m0 = (int64_t)by * 16, n0 = (int64_t)bx * 16;
+    const unsigned groups = (unsigned)((p.K + 15) >> 4), K = (unsigned)p.K;
     const unsigned la4 = (unsigned)p.lda * 4u, lb4 = (unsigned)p.ldb * 4u;
     const __amdgpu_buffer_rsrc_t rsa = sg_rsrc(p.A, (unsigned)((AKM ? (p.M - 1) * p.lda + p.K : (p.K - 1) * p.lda + p.M) * 4));
     const __amdgpu_buffer_rsrc_t rsb = sg_rsrc(p.B, (unsigned)((BKM ? (p.N - 1) * p.ldb + p.K : (p.K - 1) * p.ldb + p.N) * 4));
-    const bool a_ok = m0 + l31 < p.M, b_ok = n0 + l31 < p.N;
-    const unsigned a_row = (unsigned)(m0 + l31) * (AKM ? la4 : 4u), b_row = (unsigned)(n0 + l31) * (BKM ? lb4 : 4u);
-    f32x16 acc;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const bool a_ok = m0 + l16 < p.M, b_ok = n0 + l16 < p.N;
+    const unsigned a_row = (unsigned)(m0 + l16) * (AKM ? la4 : 4u), b_row = (unsigned)(n0 + l16) * (BKM ? lb4 : 4u);
+    sg_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     float asum = 0.f;
-    // U k-groups in flight per wave (2 x U float4 of operands).  U = 8: a K = 784 over 8 waves is two round trips to L2;
-    // the U = 16 instantiation (k-major operands, 64 < K/8 <= 128 groups per block) makes it one.
     for (unsigned gb = wave; gb < groups; gb += (unsigned)NW * U) {
         float4 a[U], b[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const unsigned k0 = 8u * (gb + (unsigned)u * NW) + 4u * lh;      // a k-group past the last has k0 >= K: reads 0
+            const unsigned k0 = 16u * (gb + (unsigned)u * NW) + 4u * kq;     // a k-group past the last has k0 >= K: reads 0
             a[u] = sg_fetch<AKM, VEC>(rsa, la4, a_row, a_ok, k0, K);
             b[u] = sg_fetch<BKM, VEC>(rsb, lb4, b_row, b_ok, k0, K);
         }
-        // all 2U loads are in flight before the first MFMA waits for its operands (left alone, the scheduler sinks each load
-        // to just above its use -- `load, s_waitcnt vmcnt(0), mfma` U times: U memory round trips instead of one)
-        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0);                 // all 2U loads in flight before the first MFMA (see sg_tile)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b[u].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, b[u].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].z, b[u].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].w, b[u].w, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, b[u].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, b[u].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, b[u].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, b[u].w, acc, 0, 0, 0);
             asum += (a[u].x + a[u].y) + (a[u].z + a[u].w);
         }
     }
-    // accumulator register e holds row (e&3) + 8(e>>2) + 4lh, column l31
+    // accumulator register v holds row 4 kq + v, column l16
 #pragma unroll
-    for (int e = 0; e < 16; ++e) red[wave][((e & 3) + 8 * (e >> 2) + 4 * lh) * 32 + l31] = acc[e];
+    for (int v = 0; v < 4; ++v) red[wave][(4 * kq + v) * 16 + l16] = acc[v];
     if (p.asum) {
+        asum += __shfl_xor(asum, 16, 64);
         asum += __shfl_xor(asum, 32, 64);
-        if (lh == 0) ared[wave][l31] = asum;
+        if (kq == 0) ared[wave][l16] = asum;
     }
     __syncthreads();
-    constexpr int PER = 1024 / (NW * 64);                      // outputs per thread
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int o = tid + i * NW * 64;
+    if (tid < 256) {
+        const int o = tid;
         float v = red[0][o];
 #pragma unroll
         for (int w = 1; w < NW; ++w) v += red[w][o];
-        const int64_t row = m0 + (o >> 5), col = n0 + (o & 31);
+        const int64_t row = m0 + (o >> 4), col = n0 + (o & 15);
         if (row < p.M && col < p.N) {
             v = p.alpha * v + (p.bias ? p.bias[col] : 0.f);
             if (p.addend) v += p.addend[row * p.ldc + col];
@@ -129,7 +128,7 @@ __device__ __forceinline__ void sg_tile(const SmallGemmParams& p, int bx, int by
             if (lds_copy) lds_copy[row * 32 + col] = v;
         }
     }
-    if (p.asum && bx == 0 && tid < 32) {
+    if (p.asum && bx == 0 && tid < 16) {
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) s += ared[w][tid];

@@ -3,25 +3,24 @@
 //
 // The 128x128-tile kernel of gemm.hip is built for throughput: a problem with a handful of output tiles runs as a few
 // blocks that each walk their k-tiles at ~2 us apiece (64 MFMAs of which up to 3/4 multiply padding), plus a split-K
-// reduce launch -- 8-15 us per GEMM, and the MNIST-MLP step is five of them.  Here:
-//   * one block per 32x32 output tile, 4 or 8 waves per block that SPLIT K between them (wave w takes k-groups
-//     w, w+NW, ...; a k-group = 8 consecutive k = 4 MFMAs 32x32x2);
-//   * operands go global -> registers -> MFMA directly (no LDS staging, no barriers in the loop): lane (l31, lh)
-//     holds A[m0 + l31][8g + 4lh .. +3] -- one float4 for a k-major operand, four coalesced dwords for an outer-major
-//     one -- exactly the fragment layout of the big kernel, so the k permutation is the same;
-//   * the waves' 32x32 accumulators meet in LDS (conflict-free: lane <-> column) and are summed in wave order
-//     (deterministic), then the epilogue of gemm.hip: alpha, bias, addend, activation-gradient mask, activation, preact;
+// reduce launch -- 8-15 us per GEMM, and the MNIST-MLP step is five of them.  Here (tile body: gemm_small.h):
+//   * one block per 16x16 output tile, 4 or 8 waves per block that SPLIT K between them (wave w takes k-groups
+//     w, w+NW, ...; a k-group = 16 consecutive k = 4 MFMAs 16x16x4);
+//   * operands go global -> registers -> MFMA directly (no LDS staging, no barriers in the loop): lane (l16, kq) holds
+//     A[m0 + l16][16g + 4kq .. +3] -- one float4 for a k-major operand, four coalesced dwords for an outer-major one;
+//   * the waves' 16x16 accumulators meet in LDS and are summed in wave order (deterministic), then the epilogue of
+//     gemm.hip: alpha, bias, addend, activation-gradient mask, activation, preact;
 //   * asum (row sums of A = db of a Linear) falls out of the operand registers.
-// Exact fp32 (v_mfma_f32_32x32x2_f32), same results as gemm.hip up to summation order.
+// Exact fp32 (v_mfma_f32_16x16x4_f32), same results as gemm.hip up to summation order.
 #include "gemm_small.h"
 
 namespace nnhip {
 
 template <int NW, bool AKM, bool BKM, bool VEC, int U = 8>
 __global__ __launch_bounds__(NW * 64) void gemm_small_kernel(const SmallGemmParams p) {
-    __shared__ float red[NW][32 * 32];
-    __shared__ float ared[NW][32];
-    sg_tile<NW, AKM, BKM, VEC, U>(p, (int)blockIdx.x, (int)blockIdx.y, red, ared);
+    __shared__ float red[NW][16 * 16];
+    __shared__ float ared[NW][16];
+    sg_tile16<NW, AKM, BKM, VEC, U>(p, (int)blockIdx.x, (int)blockIdx.y, red, ared);
 }
 
 // Two independent small problems in ONE launch (blockIdx.z picks): the input gradient dX = dO W (A k-major, B outer-major,
@@ -38,19 +37,19 @@ struct SmallLinearBwd {                                    // compact kernel arg
 
 template <int NW, bool VEC0>
 __global__ __launch_bounds__(NW * 64) void gemm_small_pair_kernel(const SmallLinearBwd q) {
-    __shared__ float red[NW][32 * 32];
-    __shared__ float ared[NW][32];
+    __shared__ float red[NW][16 * 16];
+    __shared__ float ared[NW][16];
     const int bx = (int)blockIdx.x, by = (int)blockIdx.y;
     SmallGemmParams p{};
     p.A = q.dO; p.lda = q.out; p.ldb = q.in; p.ldc = q.in; p.N = q.in; p.alpha = 1.f;
     if (blockIdx.z == 0) {                                 // dX[rows, in] = dO[rows, out] W[out, in]   (+ addend, (.) act')
         p.B = q.W; p.C = q.dX; p.addend = q.addend; p.dact_arg = q.dact_arg; p.dact = q.dact; p.beta = q.beta;
         p.M = q.rows; p.K = q.out; p.a_kmajor = 1;
-        if ((int64_t)bx * 32 < p.N && (int64_t)by * 32 < p.M) sg_tile<NW, true, false, VEC0, 8>(p, bx, by, red, ared);
+        if ((int64_t)bx * 16 < p.N && (int64_t)by * 16 < p.M) sg_tile16<NW, true, false, VEC0, 8>(p, bx, by, red, ared);
     } else {                                               // dW[out, in] = dO^T[out, rows] X[rows, in],  db = row sums of dO^T
         p.B = q.X; p.C = q.dW; p.asum = q.db; p.beta = 1.f;
         p.M = q.out; p.K = q.rows;
-        if ((int64_t)bx * 32 < p.N && (int64_t)by * 32 < p.M) sg_tile<NW, false, false, false, 8>(p, bx, by, red, ared);
+        if ((int64_t)bx * 16 < p.N && (int64_t)by * 16 < p.M) sg_tile16<NW, false, false, false, 8>(p, bx, by, red, ared);
     }
 }
 
@@ -77,9 +76,9 @@ int gemm_small(const float* A, const float* B, float* C, const float* bias, floa
     // float4 loads for the k-major operands: 16-B aligned rows and K % 4 == 0 (a float4 then never straddles the end of a row)
     const bool vec = (a_kmajor || b_kmajor) && (K & 3) == 0 && (!a_kmajor || (aligned16(A) && (lda & 3) == 0)) &&
                      (!b_kmajor || (aligned16(B) && (ldb & 3) == 0));
-    const int64_t groups = (K + 7) >> 3;
+    const int64_t groups = (K + 15) >> 4;                   // k-groups of 16
     const int nw = groups >= 8 ? 8 : 4;
-    dim3 grid((unsigned)ceil_div(N, 32), (unsigned)ceil_div(M, 32));
+    dim3 grid((unsigned)ceil_div(N, 16), (unsigned)ceil_div(M, 16));
 #define SG_LAUNCH2(NW, V)                                                                                                     \
     do {                                                                                                                      \
         if (a_kmajor && b_kmajor) hipLaunchKernelGGL((gemm_small_kernel<NW, true, true, V>), grid, dim3(NW * 64), 0, st, p);  \
@@ -110,9 +109,9 @@ int gemm_small_linear_backward(const float* X, const float* W, const float* dO, 
     q.dO = dO; q.W = W; q.X = X; q.dX = dX; q.dW = dW; q.db = db; q.addend = addend; q.dact_arg = dact_arg;
     q.rows = (int)rows; q.in = (int)in; q.out = (int)out; q.dact = dact; q.beta = beta;
     const bool vec0 = (out & 3) == 0 && aligned16(dO);
-    const int64_t g0 = (out + 7) >> 3, g1 = (rows + 7) >> 3;
+    const int64_t g0 = (out + 15) >> 4, g1 = (rows + 15) >> 4;
     const int nw = (g0 >= 8 || g1 >= 8) ? 8 : 4;
-    dim3 grid((unsigned)ceil_div(in, 32), (unsigned)max(ceil_div(rows, 32), ceil_div(out, 32)), 2);
+    dim3 grid((unsigned)ceil_div(in, 16), (unsigned)max(ceil_div(rows, 16), ceil_div(out, 16)), 2);
     if (nw == 8) {
         if (vec0) hipLaunchKernelGGL((gemm_small_pair_kernel<8, true>), grid, dim3(512), 0, st, q);
         else hipLaunchKernelGGL((gemm_small_pair_kernel<8, false>), grid, dim3(512), 0, st, q);

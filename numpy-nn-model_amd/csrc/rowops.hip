@@ -962,23 +962,24 @@ __global__ __launch_bounds__(1024) void ce_small_kernel(const CeArgs a) {
 // A small classifier head and its loss in ONE launch: logits = X W^T + b (gemm_small.hip's tile body, 32 rows at a time, the
 // block's 8 waves splitting K), then the block runs ce_small_body on the logits it has just written.  At MNIST-MLP scale a
 // launch is ~4.7 us of a 36 us step whatever it computes.  rows <= 256, classes <= 32 (nnhipLinearCrossEntropyLoss).
-// NW waves, as gemm_small() picks them (4 for K < 64, else 8): the logits are bit-identical to nnhipLinearModuleForward's.
+// NW waves, as gemm_small() picks them (4 for K < 113, else 8): the logits are bit-identical to nnhipLinearModuleForward's.
 // The label count (the 'mean' denominator) is taken first -- its loads fly while the GEMM's do -- and for <= 128 rows the loss
 // part reads the logits from a copy the GEMM epilogue leaves in LDS instead of waiting for its own global stores.
 template <bool VEC, int NW>
 __global__ __launch_bounds__(NW * 64) void linear_ce_small_kernel(const SmallGemmParams p, const CeArgs a) {
-    __shared__ float gred[NW][32 * 32];
-    __shared__ float ared[NW][32];
+    __shared__ float gred[NW][16 * 16];
+    __shared__ float ared[NW][16];
     __shared__ float tile[128 * 32];
     __shared__ int ired[17];
     __shared__ float red[16];
     float scale, denom;
     ce_prologue<NW * 64>(a, red, ired, scale, denom);
     const bool in_lds = p.M <= 128;
-    for (int by = 0; (int64_t)by * 32 < p.M; ++by) {
-        sg_tile<NW, true, true, VEC, 8>(p, 0, by, gred, ared, in_lds ? tile : nullptr);
-        __syncthreads();                                   // gred is reused by the next tile
-    }
+    for (int by = 0; (int64_t)by * 16 < p.M; ++by)
+        for (int bx = 0; (int64_t)bx * 16 < p.N; ++bx) {
+            sg_tile16<NW, true, true, VEC, 8>(p, bx, by, gred, ared, in_lds ? tile : nullptr);
+            __syncthreads();                               // gred is reused by the next tile
+        }
     if (!in_lds) {
         __threadfence_block();                             // the logits were written by other threads of this block
         __syncthreads();
@@ -1468,7 +1469,7 @@ extern "C" int nnhipLinearCrossEntropyLoss(const float* X, const float* W, const
     a.count_out = count_out_or_null;
     a.count_in_kernel = a.mode == 1 ? 1 : 0;
     const bool vec = (in_features & 3) == 0 && aligned16(X) && aligned16(W);
-    const bool nw8 = ((in_features + 7) >> 3) >= 8;        // gemm_small()'s choice
+    const bool nw8 = ((in_features + 15) >> 4) >= 8;       // gemm_small()'s choice
     hipStream_t st = (hipStream_t)s;
     if (nw8) {
         if (vec) hipLaunchKernelGGL((linear_ce_small_kernel<true, 8>), dim3(1), dim3(512), 0, st, p, a);

@@ -232,8 +232,8 @@ def test_gemm_persistent_input_grad(hip, rows, inf, outf, inplace):
 @pytest.mark.parametrize("kind", [1, 2])
 def test_linear_backward_act(hip, rows, inf, outf, kind):
     """nnhipLinearModuleBackwardAct: dZ = (dO W) * act'(arg), dW = dO^T X, db from one call -- for small layers from ONE launch
-    (gemm_small_pair_kernel).  Against float64, and bit-identical to nnhipLinearInputGradSwish / ReLU followed by
-    nnhipLinearModuleBackward(dX = NULL), which run the same tiles in separate launches."""
+    (gemm_small_pair_kernel).  Against float64, and dZ bit-identical to nnhipLinearInputGradSwish / ReLU (the same tiles in a
+    separate launch); dW / db equal to nnhipLinearModuleBackward(dX = NULL)'s up to the summation order."""
     from neunet_hip._lib import call_hip_function as call, get_current_stream_ptr
     import torch
     rng = np.random.default_rng(rows + inf + outf + kind)
@@ -267,7 +267,11 @@ def test_linear_backward_act(hip, rows, inf, outf, kind):
     else:
         call("nnhipLinearInputGradReLU", g, w, a, dz2, rows, inf, outf, st)
     call("nnhipLinearModuleBackward", x, w, g, None, dw2, db2, rows, inf, outf, st)
-    assert torch.equal(dz, dz2) and torch.equal(dw, dw2) and torch.equal(db, db2)
+    assert torch.equal(dz, dz2)
+    # (the pair launch gives both problems the larger of their two wave counts: dW / db can differ from the separate launch in
+    # the order their K partial sums meet)
+    np.testing.assert_allclose(host(dw), host(dw2), rtol=1e-5, atol=1e-6 * np.sqrt(rows))
+    np.testing.assert_allclose(host(db), host(db2), rtol=1e-5, atol=1e-6 * np.sqrt(rows))
 
 
 @pytest.mark.parametrize("rows,inf,outf", [(300, 96, 200), (128, 512, 512), (37, 50, 33), (4096, 1024, 128)])
