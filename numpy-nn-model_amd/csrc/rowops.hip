@@ -905,14 +905,15 @@ __global__ __launch_bounds__(1024) void reduce_loss_kernel(const float* __restri
 // arithmetic as the persistent kernel (the row sums run over a wave instead of a block, so the last bits of lse can
 // differ by rounding); at MNIST-MLP scale (32 x 10) a 2048-block grid would be all launch overhead.
 // The whole problem in one block of BS threads (one wave per row, waves striding the rows).
-// xs / xld: where the rows are READ (the logits themselves, or a copy of them in LDS); scale / denom from ce_prologue.
+// Rows [r0, r1) of a small problem, one wave per row (waves striding the rows); xs / xld: where row r0 is READ and the pitch
+// there (the logits themselves, or a copy of them in LDS).  Returns the wave's loss sum (meaningful on lane 0).
 template <int BS>
-__device__ __forceinline__ void ce_small_body(const CeArgs& a, float* red, float scale, float denom, const float* xs, int64_t xld) {
+__device__ __forceinline__ float ce_rows_range(const CeArgs& a, float scale, const float* xs, int64_t xld, int64_t r0, int64_t r1) {
     constexpr int NWV = BS / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float lsum = 0.f;
-    for (int64_t r = wave; r < a.rows; r += NWV) {
-        const float* x = xs + r * xld;
+    for (int64_t r = r0 + wave; r < r1; r += NWV) {
+        const float* x = xs + (r - r0) * xld;
         float* dx = a.dlogits + r * a.ld;
         const int64_t y = load_label(a.labels, r, a.lbytes);
         const bool live = y != a.ignore && y >= 0 && y < a.cols;   // same guard as the large kernels (cross_entropy.cu:176)
@@ -940,51 +941,61 @@ __device__ __forceinline__ void ce_small_body(const CeArgs& a, float* red, float
             lsum += l;
         }
     }
+    return lsum;
+}
+
+// The whole problem in one block.
+__global__ __launch_bounds__(1024) void ce_small_kernel(const CeArgs a) {
+    __shared__ int ired[17];
+    __shared__ float red[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float scale, denom;
+    ce_prologue<1024>(a, red, ired, scale, denom);
+    const float lsum = ce_rows_range<1024>(a, scale, a.logits, a.ld, 0, a.rows);
     if (!a.loss_out) return;
     __syncthreads();
     if (lane == 0) red[wave] = lsum;
     __syncthreads();
     if (threadIdx.x == 0) {
         float t = 0.f;
-        for (int i = 0; i < NWV; ++i) t += red[i];
+        for (int i = 0; i < 16; ++i) t += red[i];
         a.loss_out[0] = a.mode == 1 ? t / denom : t;
     }
 }
 
-__global__ __launch_bounds__(1024) void ce_small_kernel(const CeArgs a) {
-    __shared__ int ired[17];
-    __shared__ float red[16];
-    float scale, denom;
-    ce_prologue<1024>(a, red, ired, scale, denom);
-    ce_small_body<1024>(a, red, scale, denom, a.logits, a.ld);
-}
-
-// A small classifier head and its loss in ONE launch: logits = X W^T + b (gemm_small.hip's tile body, 32 rows at a time, the
-// block's 8 waves splitting K), then the block runs ce_small_body on the logits it has just written.  At MNIST-MLP scale a
-// launch is ~4.7 us of a 36 us step whatever it computes.  rows <= 256, classes <= 32 (nnhipLinearCrossEntropyLoss).
-// NW waves, as gemm_small() picks them (4 for K < 113, else 8): the logits are bit-identical to nnhipLinearModuleForward's.
-// The label count (the 'mean' denominator) is taken first -- its loads fly while the GEMM's do -- and for <= 128 rows the loss
-// part reads the logits from a copy the GEMM epilogue leaves in LDS instead of waiting for its own global stores.
+// A small classifier head and its loss in ONE launch: block b computes rows [16b, 16b + 16) of logits = X W^T + b with
+// gemm_small's tile body (NW waves, as gemm_small() picks them -- 4 for K < 113, else 8: bit-identical to
+// nnhipLinearModuleForward's), keeps them in LDS and runs the loss rows on that copy; the label count (the 'mean' denominator)
+// is taken first by every block -- its loads fly while the GEMM's do -- and the blocks' loss sums meet in ce_epilogue (ticket,
+// fixed order).  At MNIST-MLP scale a launch is ~4.7 us of a 35 us step whatever it computes.  rows <= 256, classes <= 32
+// (nnhipLinearCrossEntropyLoss).
 template <bool VEC, int NW>
 __global__ __launch_bounds__(NW * 64) void linear_ce_small_kernel(const SmallGemmParams p, const CeArgs a) {
+    constexpr int BS = NW * 64;
     __shared__ float gred[NW][16 * 16];
     __shared__ float ared[NW][16];
-    __shared__ float tile[128 * 32];
+    __shared__ float tile[16 * 32];
     __shared__ int ired[17];
     __shared__ float red[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float scale, denom;
-    ce_prologue<NW * 64>(a, red, ired, scale, denom);
-    const bool in_lds = p.M <= 128;
-    for (int by = 0; (int64_t)by * 16 < p.M; ++by)
-        for (int bx = 0; (int64_t)bx * 16 < p.N; ++bx) {
-            sg_tile16<NW, true, true, VEC, 8>(p, bx, by, gred, ared, in_lds ? tile : nullptr);
-            __syncthreads();                               // gred is reused by the next tile
-        }
-    if (!in_lds) {
-        __threadfence_block();                             // the logits were written by other threads of this block
-        __syncthreads();
+    ce_prologue<BS>(a, red, ired, scale, denom);
+    const int by = (int)blockIdx.x;
+    const int64_t r0 = (int64_t)by * 16, r1 = min(r0 + 16, a.rows);
+    for (int bx = 0; (int64_t)bx * 16 < p.N; ++bx) {
+        sg_tile16<NW, true, true, VEC, 8>(p, bx, by, gred, ared, tile - r0 * 32);   // row r of C also lands at tile[(r - r0) * 32 + col]
+        __syncthreads();                                   // gred is reused by the next tile; after the last one: tile is complete
     }
-    ce_small_body<NW * 64>(a, red, scale, denom, in_lds ? tile : a.logits, in_lds ? 32 : a.ld);
+    const float lsum = ce_rows_range<BS>(a, scale, tile, 32, r0, r1);
+    if (!a.loss_out) return;
+    __syncthreads();
+    if (lane == 0) red[wave] = lsum;
+    __syncthreads();
+    float t = 0.f;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < NW; ++i) t += red[i];
+    __syncthreads();                                       // ce_epilogue reuses red / ired
+    ce_epilogue<BS>(a, t, denom, red, ired);
 }
 
 // =================================================================================================
@@ -1468,15 +1479,22 @@ extern "C" int nnhipLinearCrossEntropyLoss(const float* X, const float* W, const
     a.loss_out = a.mode ? loss_out_or_null : nullptr;
     a.count_out = count_out_or_null;
     a.count_in_kernel = a.mode == 1 ? 1 : 0;
+    const unsigned nblk = (unsigned)ceil_div(rows, 16);    // one block per 16 rows
+    if (a.loss_out) {
+        unsigned* sync = sync_words();
+        a.partial = static_cast<float*>(workspace((size_t)nblk * sizeof(float)));
+        if (!sync || !a.partial) { set_last_error("nnhipLinearCrossEntropyLoss: workspace allocation failed"); return NNHIP_ENOMEM; }
+        a.sync = sync + SYNC_CE;
+    }
     const bool vec = (in_features & 3) == 0 && aligned16(X) && aligned16(W);
     const bool nw8 = ((in_features + 15) >> 4) >= 8;       // gemm_small()'s choice
     hipStream_t st = (hipStream_t)s;
     if (nw8) {
-        if (vec) hipLaunchKernelGGL((linear_ce_small_kernel<true, 8>), dim3(1), dim3(512), 0, st, p, a);
-        else hipLaunchKernelGGL((linear_ce_small_kernel<false, 8>), dim3(1), dim3(512), 0, st, p, a);
+        if (vec) hipLaunchKernelGGL((linear_ce_small_kernel<true, 8>), dim3(nblk), dim3(512), 0, st, p, a);
+        else hipLaunchKernelGGL((linear_ce_small_kernel<false, 8>), dim3(nblk), dim3(512), 0, st, p, a);
     } else {
-        if (vec) hipLaunchKernelGGL((linear_ce_small_kernel<true, 4>), dim3(1), dim3(256), 0, st, p, a);
-        else hipLaunchKernelGGL((linear_ce_small_kernel<false, 4>), dim3(1), dim3(256), 0, st, p, a);
+        if (vec) hipLaunchKernelGGL((linear_ce_small_kernel<true, 4>), dim3(nblk), dim3(256), 0, st, p, a);
+        else hipLaunchKernelGGL((linear_ce_small_kernel<false, 4>), dim3(nblk), dim3(256), 0, st, p, a);
     }
     NNHIP_LAUNCH_CHECK("linear_ce_small_kernel");
     return 0;
