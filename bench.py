@@ -48,6 +48,14 @@ def parse():
     ap.add_argument("--c4-batch", type=int, default=64, help="sequences per GPU for the GPT-tiny workload")
     ap.add_argument("--graph", type=int, default=1, help="c1/c4: replay the step as a captured hipGraph (1) or launch eagerly (0)")
     ap.add_argument("--unroll", type=int, default=4, help="c1/c5, one process: training steps captured per hipGraph (1 = one step per replay)")
+    ap.add_argument("--force-dp", action="store_true",
+                    help="one rank: run the data-parallel machinery anyway (1-rank nccl = RCCL process group, bucket segments, "
+                         "graph cuts, async all-reduce, 'sum' loss + device-side divisor)")
+    ap.add_argument("--dp-ingraph", type=int, default=int(os.environ.get("NNHIP_DP_INGRAPH", "0")),
+                    help="DP + hipGraph: capture the all-reduces INTO the step graph (falls back to graph pieces if refused)")
+    ap.add_argument("--dp-op", default="sum", choices=["sum", "avg"],
+                    help="reduction of the gradient all-reduce (avg: RCCL pre-scales by 1/world; on a forced 1-rank group it is "
+                         "what makes RCCL launch a device kernel -- a 1-rank in-place SUM is elided by the library)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     return ap.parse_args()
@@ -103,8 +111,9 @@ def timed_region(step_fn, steps, warmup, world, min_warm_s=0.0):
 def graph_unroll(args, world):
     """Steps captured per hipGraph for the sub-0.1 ms workloads (C1, C5): U > 1 only for one process replaying graphs, and only
     when the requested step counts are whole numbers of replays (EXACTLY --steps steps are timed either way)."""
+    from neunet_hip.distributed import collectives_live
     U = max(1, int(args.unroll))
-    if world != 1 or not args.graph or args.steps % U != 0 or args.steps < U:
+    if world != 1 or collectives_live() or not args.graph or args.steps % U != 0 or args.steps < U:
         return 1
     return U
 
@@ -481,7 +490,9 @@ def workload_c4(args, rank, world):
     from neunet_hip.distributed import GradBucket
     from neunet_hip.graph import GraphedTrainStep
     from neunet_hip.optim import Adam
+    from neunet_hip.distributed import collectives_live
     B, T = args.c4_batch, C4["seq"]
+    dp = world > 1 or collectives_live()                          # a gradient exchange is part of the step
     np.random.seed(1004)                                          # identical init on every rank
     model = gpt_tiny.build_gpt(C4["vocab"], C4["d_model"], C4["n_heads"], C4["d_ff"], C4["n_layers"], pad_idx=0,
                                max_len=1024, fused=True)
@@ -491,7 +502,7 @@ def workload_c4(args, rank, world):
     ids = neunet_hip.Tensor(np.ascontiguousarray(batch[:, :-1]), dtype=np.int32, requires_grad=False, device="cuda")
     tgt_host = np.ascontiguousarray(batch[:, 1:]).reshape(-1)
     tgt = neunet_hip.Tensor(tgt_host, dtype=np.int32, requires_grad=False, device="cuda")
-    loss_fn = nn.CrossEntropyLoss(ignore_index=0, reduction="mean" if world == 1 else "sum")
+    loss_fn = nn.CrossEntropyLoss(ignore_index=0, reduction="sum" if dp else "mean")
     ev = EventTimer()
     state = {"bucket": None}
 
@@ -500,7 +511,7 @@ def workload_c4(args, rank, world):
         out = out.reshape(out.shape[0] * out.shape[1], out.shape[2])
         loss = loss_fn(out, tgt)
         bk = state["bucket"]
-        if world > 1 and bk is not None:    # this rank's non-PAD count -> the bucket's extra slot (device side)
+        if dp and bk is not None:           # this rank's non-PAD count -> the bucket's extra slot (device side)
             call_hip_function("nnhipCrossEntropyDenominator", tgt.data, 4, tgt.data.numel(), 0, None, C4["vocab"], None,
                               bk.extra, get_current_stream_ptr())
         loss.backward()
@@ -510,18 +521,18 @@ def workload_c4(args, rank, world):
     fwd_bwd()
     active = [p for p in params if p.grad is not None]
     opt.zero_grad()
-    overlap = world > 1 and bool(args.overlap) and os.environ.get("NNHIP_DP_OVERLAP", "1") != "0"
+    overlap = dp and bool(args.overlap) and os.environ.get("NNHIP_DP_OVERLAP", "1") != "0"
 
-    def make(overlap, use_graph):
+    def make(overlap, use_graph, ingraph=False):
         """Bucket + step function for one exchange / launch mode, exercised once."""
         opt.zero_grad()
-        bucket = GradBucket(active, extra_scalars=1, overlap=overlap)
+        bucket = GradBucket(active, extra_scalars=1, overlap=overlap, reduce_op=args.dp_op)
         state["bucket"] = bucket
-        if world > 1:
+        if dp:
             opt.grad_divisor = bucket.extra              # g / (all-reduced non-PAD count), inside the Adam kernel
         gstep = None
         if use_graph:
-            gstep = GraphedTrainStep(fwd_bwd, opt, bucket, warmup=2, world=world)
+            gstep = GraphedTrainStep(fwd_bwd, opt, bucket, warmup=2, world=world, capture_collectives=ingraph)
 
             def step(timed):
                 if timed:
@@ -553,20 +564,27 @@ def workload_c4(args, rank, world):
     # N > 1 has only ever run on gloo here (one GPU per box): if RCCL refuses the overlapped / captured exchange, fall back
     # to the plainer modes instead of losing the measurement (every rank takes the same path: the failure modes are
     # structural, not data-dependent).  N = 1 takes the first mode.
-    modes = [(overlap, bool(args.graph))]
-    if world > 1:
-        modes += [(False, bool(args.graph)), (False, False)]
+    modes = [(overlap, bool(args.graph), False)]
+    if dp:
+        if args.dp_ingraph and args.graph:
+            modes.insert(0, (overlap, True, True))
+        modes += [(False, bool(args.graph), False), (False, False, False)]
     step = gstep = bucket = None
-    for i, (ov, gr) in enumerate(modes):
+    tried = []
+    for i, (ov, gr, ig) in enumerate(modes):
         try:
-            step, gstep, bucket = make(ov, gr)
+            step, gstep, bucket = make(ov, gr, ig)
             overlap, args_graph = ov, gr
             break
         except Exception as exc:  # noqa: BLE001
             if i + 1 == len(modes):
                 raise
-            print(f"[bench] C4 step with overlap={ov} graph={gr} failed ({exc!r}); trying the next mode", file=sys.stderr)
+            tried.append(f"overlap={ov} graph={gr} ingraph={ig}: {exc!r}"[:200])
+            print(f"[bench] C4 step with overlap={ov} graph={gr} ingraph={ig} failed ({exc!r}); trying the next mode",
+                  file=sys.stderr)
     use_graph = args_graph
+    graph_mode = getattr(gstep, "mode", None) if use_graph else None
+    ingraph_error = getattr(gstep, "ingraph_error", None) if use_graph else None
 
     dt = timed_region(step, args.steps, args.warmup, world)
     dev_ms = ev.mean_ms()
@@ -586,10 +604,12 @@ def workload_c4(args, rank, world):
                      "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "flops_per_step": fl,
                      "avg_step_device_ms": round(dev_ms, 4)},
         "extra": {"tokens_per_s": round(B * world * T * args.steps / dt, 1), "grad_floats": n_grad,
-                  "dp_exchange": ("none" if world == 1 else
+                  "dp_exchange": ("none" if not dp else
                                   (f"{len(bucket.segments)} bucket segments, async all-reduce overlapped with backward"
                                    + (f" ({pieces} graph pieces)" if use_graph else "") if overlap
-                                   else "one blocking all-reduce of the flat bucket"))},
+                                   else "one blocking all-reduce of the flat bucket")),
+                  "dp_mode": ({"forced_one_rank": world == 1, "overlap": bool(overlap), "launch": graph_mode or "eager",
+                               "ingraph_error": ingraph_error, "modes_that_failed": tried, "reduce_op": args.dp_op} if dp else None)},
     }
 
 
@@ -898,10 +918,21 @@ def respawn_under_torchrun(args):
     return subprocess.call(cmd, env=env)
 
 
+def claim_stdout():
+    """stdout must carry exactly ONE JSON line, but libraries write there too (RCCL prints a five-line version banner to
+    stdout when its communicator comes up).  Point file descriptor 1 at stderr for the life of the process and hand
+    back a handle on the real stdout for the JSON line."""
+    sys.stdout.flush()
+    real = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    return real
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(respawn_under_torchrun(args))
+    json_out = claim_stdout()
     rccl_log = None
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 and "NCCL_DEBUG" not in os.environ:
         # RCCL's own account of the communicator (ranks, rings/trees, transport) goes to a per-rank file -- its default
@@ -911,14 +942,14 @@ def main():
     import torch
     from neunet_hip.distributed import init_process_group
     import neunet_hip
-    rank, world = init_process_group()
+    rank, world = init_process_group(force=args.force_dp)
     if world != args.gpus:
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)", file=sys.stderr)
         sys.exit(2)
     neunet_hip.load_library()
     rccl_ranks = 1
-    if world > 1:
+    if world > 1 or args.force_dp:
         import torch.distributed as dist
         probe = torch.ones(1, device="cuda")
         dist.all_reduce(probe)                          # a real collective before anything is reported
@@ -944,16 +975,16 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": res["config"],
         "roofline": res["roofline"], "rccl_ranks": rccl_ranks,
     }
-    if world > 1:
+    if world > 1 or args.force_dp:
         import torch.distributed as dist
         out["dist_backend"] = dist.get_backend()
     out.update(res.get("extra", {}))
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:        # N > 1 too: timed on rank 0's host cores while the other ranks wait at the barrier
             out["cpu_baseline"] = {"headline": cpu_headline, "c1": cpu_c1, "c2": cpu_c2, "c3": cpu_c3, "c4": cpu_c4,
                                    "c5": cpu_c5}[args.workload](args.cpu_seconds)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        print(json.dumps(out), file=json_out, flush=True)
+    if world > 1 or args.force_dp:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

@@ -19,14 +19,33 @@ from __future__ import annotations
 
 import os
 
+# A ONE-rank process group normally skips every collective (nothing to exchange).  With this switch on (NNHIP_FORCE_DP=1,
+# `bench.py --force-dp`, tests) the data-parallel machinery runs all the same: bucket segments, graph cuts, asynchronous
+# all-reduces on the backend's own stream, 'sum' loss + device-side divisor.  It is how the RCCL path is driven on a
+# one-GPU box: `init_process_group("nccl", force=True)` makes a 1-rank RCCL communicator.
+force_collectives = os.environ.get("NNHIP_FORCE_DP", "0") == "1"
 
-def init_process_group(backend: str | None = None):
-    """Initialise torch.distributed from the torchrun env (RANK / WORLD_SIZE / MASTER_*). Returns (rank, world)."""
+
+def collectives_live(group=None) -> bool:
+    """True when a gradient exchange has to be issued: an initialised process group with more than one rank, or with
+    one rank and `force_collectives` set."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or force_collectives
+
+
+def init_process_group(backend: str | None = None, force: bool = False):
+    """Initialise torch.distributed from the torchrun env (RANK / WORLD_SIZE / MASTER_*). Returns (rank, world).
+    force=True: create the group even for one rank and switch `force_collectives` on."""
     import torch
     import torch.distributed as dist
+    global force_collectives
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if force:
+        force_collectives = True
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = os.environ.get("NNHIP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():
@@ -44,8 +63,15 @@ class GradBucket:
     """Flat gradient bucket over `params` (any objects with .data (torch tensor) and .grad)."""
 
     def __init__(self, params, extra_scalars: int = 0, overlap: bool = False, segment_bytes: int = 32 << 20,
-                 group=None):
+                 group=None, reduce_op: str = "sum"):
         import torch
+        # "sum" (default; the optimizer folds 1/world or 1/global_count into its gradient load) or "avg" (RCCL pre-scales
+        # by 1/world inside the collective: numerator and extra-slot count shrink together, so g/count is unchanged and
+        # plain mean losses need no grad_scale).  On a forced 1-rank group "avg" is also what makes RCCL launch a device
+        # kernel at all -- a 1-rank in-place SUM is elided inside the library.
+        if reduce_op not in ("sum", "avg"):
+            raise ValueError(f"reduce_op must be 'sum' or 'avg', got {reduce_op!r}")
+        self.reduce_op = reduce_op
         self.params = list(params)
         self.overlap = overlap
         self.group = group
@@ -101,9 +127,12 @@ class GradBucket:
         self._seen = set()
         self._works = []
 
-    def _world(self):
+    def _live(self):
+        return collectives_live(self.group)
+
+    def op(self):
         import torch.distributed as dist
-        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+        return dist.ReduceOp.AVG if self.reduce_op == "avg" else dist.ReduceOp.SUM
 
     def _launch(self, k):
         import torch.distributed as dist
@@ -111,9 +140,9 @@ class GradBucket:
         if self._capture_cb is not None:      # hipGraph capture: the step is cut here; the replay launches the exchange
             self._capture_cb(k)
             return
-        if self._world() > 1:
+        if self._live():
             lo, hi, _ = self.segments[k]
-            self._works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._works.append(dist.all_reduce(self.flat[lo:hi], op=self.op(), group=self.group, async_op=True))
 
     def _on_grad(self, param):
         """Called by a layer right after it wrote `param`'s gradient (into the slot, or elsewhere -> copied in)."""
@@ -182,8 +211,8 @@ class GradBucket:
         extra scalars, wait for everything (stream-ordered: the host does not block on the GPU)."""
         import torch.distributed as dist
         self._close_segments()
-        if self.extra is not None and self._world() > 1:
-            self._works.append(dist.all_reduce(self.flat[self.extra_offset:], op=dist.ReduceOp.SUM, group=self.group,
+        if self.extra is not None and self._live():
+            self._works.append(dist.all_reduce(self.flat[self.extra_offset:], op=self.op(), group=self.group,
                                                async_op=True))
         for w in self._works:
             w.wait()
@@ -199,8 +228,8 @@ class GradBucket:
             return self._finish_overlapped()
         group = group if group is not None else self.group     # a bucket built for a sub-group reduces over THAT group
         self.collect()
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+        if collectives_live(group):
+            dist.all_reduce(self.flat, op=self.op(), group=group)
         for p, v, hg in zip(self.params, self.views, self.has_grad):
             p.grad = v if hg else None
 

@@ -26,17 +26,28 @@ Shapes of a replayed step:
         [ piece 0 ] -> async all_reduce(segment 0) | [ piece 1 ] -> async all_reduce(segment 1) | ... -> wait -> [ optimizer ]
     the backward pass is cut into one graph per bucket segment (at the point the segment's last gradient has been
     written), so RCCL exchanges segment k on its own stream while piece k+1 of the backward pass replays.
+  * N ranks, capture_collectives=True:
+        [ forward + backward + the segments' all-reduces on RCCL's stream (fork/join inside the capture) + optimizer ]
+    one graph again: torch's ProcessGroupNCCL records its collectives into an ongoing stream capture, so the exchange
+    becomes graph nodes on a parallel branch.  If the capture (or the first replay) fails, the constructor falls back
+    to the cut-into-pieces form above; `self.mode` says which one runs ("single" / "pieces" / "ingraph").
 """
 from __future__ import annotations
 
 from ._lib import call_hip_function
+from .distributed import collectives_live
 
 
 class GraphedTrainStep:
     _live = 0          # captured steps alive in this process: the library workspace stays locked while > 0
+    # Every capture is thread-local.  torch's default ("global") makes ANY thread's capture-unsafe HIP call fail while this
+    # thread captures -- and ProcessGroupNCCL's watchdog thread polls hipEventQuery on the warm-up steps' all-reduce works
+    # all the time: the first run of the cut-into-pieces step on a real nccl group died with
+    # hipErrorStreamCaptureUnsupported in the watchdog (round 3; gloo has no such thread, which is why it went unseen).
+    _CAPTURE_MODE = "thread_local"
 
     def __init__(self, forward_backward, optimizer, bucket, warmup: int = 3, world: int = 1, pre_optim=None,
-                 group=None, check_every: int = 256, unroll: int = 1):
+                 group=None, check_every: int = 256, unroll: int = 1, capture_collectives: bool = False):
         import torch
         self.fb, self.opt, self.bucket, self.world = forward_backward, optimizer, bucket, world
         self.pre_optim = pre_optim                    # host-side hook between exchange and optimizer (kept for callers)
@@ -44,8 +55,11 @@ class GraphedTrainStep:
         # launch per U steps.  A sub-0.1 ms step (MNIST-MLP: 7 kernels, 44 us) is otherwise at the mercy of the host's graph
         # launch time.  forward_backward is then called as forward_backward(k), k = 0..U-1, and should read its batch from
         # static input slot k (the caller refills the U slots before every replay); __call__ runs U steps.
-        self.unroll = max(1, int(unroll)) if (world == 1 and pre_optim is None) else 1
         self.group = group if group is not None else getattr(bucket, "group", None)
+        # "one process" = nothing to exchange: world 1 and no forced collectives (distributed.force_collectives drives the
+        # whole DP machinery through a 1-rank group -- the RCCL check on a one-GPU box)
+        self.single = world == 1 and pre_optim is None and not collectives_live(self.group)
+        self.unroll = max(1, int(unroll)) if self.single else 1
         self._torch = torch
         self._calls = 0
         self._check_every = max(1, int(check_every))
@@ -59,15 +73,29 @@ class GraphedTrainStep:
         if hasattr(optimizer, "use_device_step"):
             optimizer.use_device_step(True)
         self.opt.zero_grad()
-        self.single = world == 1 and pre_optim is None
         self.pieces = []                              # [(graph, segment index or None)]
         self.g_opt = None
+        self.mode = "single" if self.single else "pieces"
+        self.ingraph_error = None
         overlap = bool(getattr(bucket, "overlap", False)) and not self.single
-        if overlap:
+        if capture_collectives and not self.single and pre_optim is None:
+            try:
+                self._capture_with_collectives(s)
+                self.mode = "ingraph"
+            except Exception as exc:  # noqa: BLE001 -- the backend refused: keep the collectives between the pieces
+                self.ingraph_error = repr(exc)[:300]
+                self.pieces = []
+                torch.cuda.synchronize()
+                if overlap:
+                    bucket._reset_step()
+                self.opt.zero_grad()
+        if self.mode == "ingraph":
+            pass
+        elif overlap:
             self._capture_overlapped(s)
         else:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode=self._CAPTURE_MODE):
                 for k in range(self.unroll):
                     if k:
                         self.opt.zero_grad()          # host bookkeeping only: the next step's kernels overwrite the gradients
@@ -76,11 +104,13 @@ class GraphedTrainStep:
                     if self.single:
                         self._bind_grads()
                         self.opt.step()
+                    if getattr(self.bucket, "overlap", False) and self.bucket.segments:
+                        self.bucket._reset_step()     # an overlap bucket on the one-process path: per-step hook state
             self.pieces.append((g, None))
-        if not self.single:
+        if self.mode == "pieces":
             self.g_opt = torch.cuda.CUDAGraph()
             self._bind_grads()
-            with torch.cuda.graph(self.g_opt, pool=self.pieces[0][0].pool()):
+            with torch.cuda.graph(self.g_opt, pool=self.pieces[0][0].pool(), capture_error_mode=self._CAPTURE_MODE):
                 self.opt.step()
         torch.cuda.synchronize()
         # the captured kernels hold these addresses
@@ -100,7 +130,7 @@ class GraphedTrainStep:
 
         def begin():
             g = torch.cuda.CUDAGraph()
-            g.capture_begin(pool=pool)
+            g.capture_begin(pool=pool, capture_error_mode=self._CAPTURE_MODE)
             state["g"] = g
 
         def cut(k):                                   # called by the bucket where it would launch segment k's all-reduce
@@ -119,6 +149,18 @@ class GraphedTrainStep:
             finally:
                 bucket._capture_cb = None
         cur.wait_stream(side_stream)
+
+    # ---- capture WITH the collectives: the whole DP step is one graph ------------------------------------------------
+    def _capture_with_collectives(self, side_stream):
+        torch = self._torch
+        g = torch.cuda.CUDAGraph()
+        # thread_local: the process group's watchdog thread may touch the runtime while this thread captures
+        with torch.cuda.graph(g, stream=side_stream, capture_error_mode=self._CAPTURE_MODE):
+            self.loss = self.fb()
+            self.bucket.all_reduce(self.group)        # overlap: segments were launched by the hooks; this launches the rest + joins
+            self.opt.step()
+        torch.cuda.synchronize()
+        self.pieces.append((g, None))
 
     def release(self):
         """Drop the captured graphs and unlock the library workspace (call when this step object is retired and other
@@ -164,24 +206,25 @@ class GraphedTrainStep:
                                    "memory -- capture again")
         if hasattr(self.opt, "sync_device_hyper"):
             self.opt.sync_device_hyper()              # lr / weight_decay / grad_scale changed on the host -> device state
-        if self.single:
+        if self.single or self.mode == "ingraph":
             self.pieces[0][0].replay()
             return self.loss
         import torch.distributed as dist
-        live = self.world > 1 and dist.is_available() and dist.is_initialized()
+        live = collectives_live(self.group)
         works = []
+        op = self.bucket.op() if hasattr(self.bucket, "op") else dist.ReduceOp.SUM
         for g, k in self.pieces:
             g.replay()
             if k is not None and live:
                 lo, hi, _ = self.bucket.segments[k]
-                works.append(dist.all_reduce(self.bucket.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                works.append(dist.all_reduce(self.bucket.flat[lo:hi], op=op, group=self.group, async_op=True))
         if live:
             if getattr(self.bucket, "overlap", False):
                 if self.bucket.extra is not None:
-                    works.append(dist.all_reduce(self.bucket.flat[self.bucket.extra_offset:], op=dist.ReduceOp.SUM,
+                    works.append(dist.all_reduce(self.bucket.flat[self.bucket.extra_offset:], op=op,
                                                  group=self.group, async_op=True))
             else:
-                dist.all_reduce(self.bucket.flat, op=dist.ReduceOp.SUM, group=self.group)
+                dist.all_reduce(self.bucket.flat, op=op, group=self.group)
         for w in works:
             w.wait()                                  # stream-ordered: the host does not block on the GPU
         if self.pre_optim is not None:

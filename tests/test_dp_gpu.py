@@ -98,7 +98,7 @@ def test_dp2_equals_full_batch(overlap):
 
 
 # ---- hipGraph-replayed DP step: 'sum' loss per rank, device-side target count in the bucket, divisor inside Adam ----------
-def _run_graphed(rank, world, port, q, overlap, backend="gloo", graphed=True):
+def _run_graphed(rank, world, port, q, overlap, backend="gloo", graphed=True, force=False, ingraph=False, recipe=None):
     """The bench's C4 data-parallel recipe at toy size.  world > 1: every rank back-propagates CrossEntropy(reduction='sum',
     ignore_index=0) on its shard, a kernel writes the shard's non-ignored count into the bucket's extra slot, the bucket
     (cut into segments, exchanged asynchronously between the pieces of the captured backward pass when overlap=True) is
@@ -110,18 +110,25 @@ def _run_graphed(rank, world, port, q, overlap, backend="gloo", graphed=True):
     from neunet_hip.distributed import GradBucket, shard_batch
     from neunet_hip.graph import GraphedTrainStep
     from neunet_hip.optim import AdamW
-    dev = rank if backend == "nccl" else 0
+    from neunet_hip import distributed as D
+    dev = rank if (backend == "nccl" and world > 1) else 0
     torch.cuda.set_device(dev)
-    if world > 1:
+    info = {}
+    if world > 1 or force:
         import torch.distributed as dist
         os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        os.environ["RANK"], os.environ["WORLD_SIZE"] = str(rank), str(world)
+        D.init_process_group(backend, force=force)      # force: a ONE-rank group whose collectives are issued all the same
+        info["backend"] = dist.get_backend()
+        info["live"] = D.collectives_live()
+    # recipe "dp": 'sum' loss + device-side count + divisor inside Adam (what every DP rank runs); "plain": 'mean' loss
+    dp = (world > 1 or force) if recipe is None else recipe == "dp"
     model = _build(hip)
     params = model.parameters()
-    bucket = GradBucket(params, extra_scalars=1, overlap=overlap and world > 1, segment_bytes=1 << 12)
+    bucket = GradBucket(params, extra_scalars=1, overlap=overlap and (world > 1 or force), segment_bytes=1 << 12)
     opt = AdamW(params, lr=1e-2, weight_decay=1e-2)
-    loss_fn = nn.CrossEntropyLoss(ignore_index=0, reduction="sum" if world > 1 else "mean")
-    if world > 1:
+    loss_fn = nn.CrossEntropyLoss(ignore_index=0, reduction="sum" if dp else "mean")
+    if dp:
         opt.grad_divisor = bucket.extra
     X, Y = _data()
     lo, hi = shard_batch(32, rank, world)
@@ -131,7 +138,7 @@ def _run_graphed(rank, world, port, q, overlap, backend="gloo", graphed=True):
     def fb():
         xs.grad = None
         loss = loss_fn(model(xs), ys)
-        if world > 1:
+        if dp:
             call_hip_function("nnhipCrossEntropyDenominator", ys.data, 4, ys.data.numel(), 0, None, 10, None, bucket.extra,
                               get_current_stream_ptr())
         loss.backward()
@@ -144,8 +151,9 @@ def _run_graphed(rank, world, port, q, overlap, backend="gloo", graphed=True):
         opt.step()
 
     if graphed:
-        step = GraphedTrainStep(fb, opt, bucket, warmup=1, world=world)
+        step = GraphedTrainStep(fb, opt, bucket, warmup=1, world=world, capture_collectives=ingraph)
         n_pieces = len(step.pieces)
+        info["mode"], info["ingraph_error"] = step.mode, step.ingraph_error
     else:
         eager()
         step, n_pieces = eager, 0
@@ -161,11 +169,12 @@ def _run_graphed(rank, world, port, q, overlap, backend="gloo", graphed=True):
     res = [p.numpy().copy() for p in params]
     if graphed:
         step.release()
-    if world > 1:
+    if world > 1 or force:
         import torch.distributed as dist
         dist.destroy_process_group()
+        D.force_collectives = False
     if q is not None:
-        q.put((rank, res, n_pieces))
+        q.put((rank, res, n_pieces, info))
     return res
 
 
@@ -210,3 +219,142 @@ def test_dp2_nccl_when_two_gpus_are_visible():
     for a, b, r in zip(got[0][0], got[1][0], ref):
         np.testing.assert_array_equal(a, b)
         np.testing.assert_allclose(a, r, rtol=1e-4, atol=1e-5)
+
+
+# ---- the RCCL leg on a ONE-GPU box: a 1-rank `nccl` process group with the collectives forced on ---------------------------
+def _spawn1(target, args):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=target, args=(0, 1, _free_port(), q) + args)
+    p.start()
+    got = q.get(timeout=300)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    return got[1:]
+
+
+@pytest.mark.parametrize("launch", ["eager", "pieces", "ingraph"])
+def test_dp1_forced_nccl_runs_the_dp_machinery_on_rccl(launch):
+    """Every DP test above exchanges over gloo; the production backend is nccl (= RCCL).  Here ONE rank makes an `nccl`
+    process group and `force_collectives` makes the bucket issue its per-segment asynchronous all-reduces on RCCL's
+    stream anyway: eager, between the pieces of the captured backward pass, and captured INTO the step graph.
+    Claims: the backend really is nccl; the overlapped step is cut into > 1 pieces; parameters after 3 steps are
+    BIT-IDENTICAL to the same 'sum'-loss + device-divisor recipe run with no process group at all (a 1-rank SUM
+    all-reduce is the identity, so any difference is a stream-ordering bug), and within 1e-4 of the plain 'mean' step."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no HIP device is visible")
+    res, n_pieces, info = _spawn1(_run_graphed, (True, "nccl", launch != "eager", True, launch == "ingraph"))
+    assert info["backend"] == "nccl" and info["live"] is True
+    if launch == "pieces":
+        assert info["mode"] == "pieces" and n_pieces > 1
+    if launch == "ingraph":
+        assert info["mode"] in ("ingraph", "pieces"), info      # a refused capture must have fallen back, and said why
+        assert info["mode"] == "ingraph" or info["ingraph_error"]
+    same = _run_graphed(0, 1, 0, None, False, graphed=False, recipe="dp")       # same recipe, no process group
+    plain = _run_graphed(0, 1, 0, None, False, graphed=False)                   # 'mean' loss, the non-DP step
+    for a, b, c in zip(res, same, plain):
+        np.testing.assert_array_equal(a, b)
+        np.testing.assert_allclose(a, c, rtol=1e-4, atol=1e-5)
+
+
+def _run_gpt_dp(rank, world, port, q, launch, force):
+    """GPT-tiny (the C4 graph: embedding, fused q|k|v attention blocks with grouped bucket slots, RMSNorm, FFN, vocab
+    head, CE with PAD ignored) at d128 L2 through bench.py's DP recipe.  launch: eager / pieces / ingraph."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import gpt_tiny
+    import neunet_hip as hip
+    import neunet_hip.nn as nn
+    from neunet_hip import distributed as D
+    from neunet_hip._lib import call_hip_function, get_current_stream_ptr
+    from neunet_hip.graph import GraphedTrainStep
+    from neunet_hip.optim import Adam
+    torch.cuda.set_device(0)
+    info = {}
+    if force:
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+        D.init_process_group("nccl", force=True)
+        info["backend"] = dist.get_backend()
+    V, Dm, H, F, L, B, T = 1000, 128, 4, 512, 2, 8, 64
+    rng = np.random.default_rng(77)
+    batches = []
+    for _ in range(3):
+        b = rng.integers(3, V, (B, T + 1)).astype(np.int32)
+        b[1, -9:] = 0
+        batches.append(b)
+    np.random.seed(1004)
+    model = gpt_tiny.build_gpt(V, Dm, H, F, L, pad_idx=0, max_len=256, fused=True)
+    ids = hip.Tensor(np.ascontiguousarray(batches[0][:, :-1]), dtype=np.int32, requires_grad=False, device="cuda")
+    tgt = hip.Tensor(np.ascontiguousarray(batches[0][:, 1:]).reshape(-1), dtype=np.int32, requires_grad=False, device="cuda")
+    loss_fn = nn.CrossEntropyLoss(ignore_index=0, reduction="sum")
+    state = {"bucket": None}
+
+    def fb():
+        out, _ = model.forward(ids)
+        loss = loss_fn(out.reshape(B * T, V), tgt)
+        if state["bucket"] is not None:
+            call_hip_function("nnhipCrossEntropyDenominator", tgt.data, 4, tgt.data.numel(), 0, None, V, None,
+                              state["bucket"].extra, get_current_stream_ptr())
+        loss.backward()
+        return loss
+
+    fb()
+    active = [p for p in model.parameters() if p.grad is not None]
+    opt = Adam(model.parameters(), lr=1.5e-4, betas=(0.9, 0.98), eps=1e-9)
+    opt.zero_grad()
+    bucket = D.GradBucket(active, extra_scalars=1, overlap=force, segment_bytes=1 << 18)
+    state["bucket"] = bucket
+    opt.grad_divisor = bucket.extra
+
+    def feed(b):
+        ids.data.copy_(torch.from_numpy(np.ascontiguousarray(b[:, :-1])))
+        tgt.data.copy_(torch.from_numpy(np.ascontiguousarray(b[:, 1:]).reshape(-1)))
+
+    def eager():
+        opt.zero_grad()
+        fb()
+        bucket.all_reduce()
+        opt.step()
+
+    if launch == "eager":
+        eager()                                            # the graphed runs warm up once on batch 0
+        step = eager
+    else:
+        step = GraphedTrainStep(fb, opt, bucket, warmup=1, world=1, capture_collectives=launch == "ingraph")
+        info.update(mode=step.mode, pieces=len(step.pieces), ingraph_error=step.ingraph_error,
+                    segments=len(bucket.segments))
+    for b in batches:
+        feed(b)
+        step()
+    torch.cuda.synchronize()
+    res = [p.numpy().copy() for p in model.parameters()]
+    if launch != "eager":
+        step.release()
+    if force:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+        D.force_collectives = False
+    if q is not None:
+        q.put((rank, res, info))
+    return res
+
+
+@pytest.mark.parametrize("launch", ["eager", "pieces", "ingraph"])
+def test_gpt_forced_nccl_dp_step_is_bit_identical_to_the_local_step(launch):
+    """The GPT step through GradBucket(overlap) + per-segment graph cuts + async all_reduce on RCCL's stream (1-rank nccl,
+    collectives forced) leaves every parameter BIT-IDENTICAL to the same recipe with no process group: a 1-rank SUM
+    all-reduce is the identity, so this pins the stream ordering between our kernels and the backend's stream, the
+    graph cuts, and the device-side divisor -- on the production backend."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no HIP device is visible")
+    res, info = _spawn1(_run_gpt_dp, (launch, True))
+    assert info["backend"] == "nccl"
+    if launch == "pieces":
+        assert info["mode"] == "pieces" and info["segments"] > 1 and info["pieces"] == info["segments"] + 1, info
+    if launch == "ingraph":
+        assert info["mode"] == "ingraph" or info["ingraph_error"], info
+    local = _run_gpt_dp(0, 1, 0, None, "eager", False)
+    for a, b in zip(res, local):
+        np.testing.assert_array_equal(a, b)

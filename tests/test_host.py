@@ -228,3 +228,66 @@ def test_grad_bucket_keeps_bucket_groups_adjacent():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert sorted(i for _, _, idxs in bucket.segments for i in idxs) == list(range(len(params)))
         bucket.detach()
+
+
+def _forced_one_rank_worker(port, q):
+    import torch
+    import torch.distributed as dist
+    from neunet_hip import distributed as D
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    try:
+        assert D.collectives_live() is False
+        D.init_process_group("gloo", force=True)
+        issued = []
+        real = dist.all_reduce
+
+        def counting(t, *a, **k):
+            issued.append(int(t.numel()))
+            return real(t, *a, **k)
+
+        dist.all_reduce = counting
+
+        class P:
+            def __init__(self, n):
+                self.data = torch.zeros(n)
+                self.grad = None
+
+        params = [P(8), P(4), P(12)]
+        bucket = D.GradBucket(params, extra_scalars=1, overlap=True, segment_bytes=4)
+        for p in reversed(params):                             # gradients arrive back to front, written in place
+            p._grad_slot.fill_(float(p.data.numel()))
+            p.grad = p._grad_slot
+            p._grad_hook(p)
+        bucket.extra[0] = 5.0
+        bucket.all_reduce()
+        ok = (D.collectives_live() and dist.get_world_size() == 1 and sorted(issued) == [4, 4, 8, 12]
+              and float(bucket.extra[0]) == 5.0 and all(float(p.grad[0]) == p.data.numel() for p in params))
+        plain = D.GradBucket(params, overlap=False)
+        issued.clear()
+        for p in params:
+            p.grad = torch.ones_like(p.data)
+        plain.all_reduce()
+        ok = ok and issued == [plain.numel]
+        dist.all_reduce = real
+        q.put(bool(ok) or repr(issued))
+    except Exception as exc:
+        q.put(repr(exc))
+        raise
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_forced_one_rank_group_issues_every_collective():
+    """`init_process_group(force=True)` on ONE rank: the bucket launches its per-segment and extra-slot all-reduces as it
+    would on N ranks (this is how the RCCL path is driven on a one-GPU box, tests/test_dp_gpu.py); without the switch a
+    1-rank group issues none."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_forced_one_rank_worker, args=(_free_port(), q))
+    p.start()
+    got = q.get(timeout=120)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert got is True, got
