@@ -76,11 +76,17 @@ def newer(a, b):
     return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
 
 
-def build(force=False, debug=False, verbose=True):
+def build(force=False, debug=False, verbose=True, variant=None, defines=(), csrc=None):
+    """variant / defines: an A/B build -- the same sources with extra -D flags into lib/libneunet_hip.<variant>.so (objects
+    under csrc/build_<variant>/); select it at run time with NEUNET_HIP_LIB=<path>.  The default build is untouched."""
+    CSRC = csrc or globals()["CSRC"]      # --csrc: another checkout's sources (A/B against an older commit)
+    OBJ = os.path.join(globals()["CSRC"], "build" if not variant else f"build_{variant}")
+    LIB = os.path.join(LIBDIR, "libneunet_hip.so" if not variant else f"libneunet_hip.{variant}.so")
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
     cc = hipcc()
     flags = [f"--offload-arch={ARCH}", "-std=c++17", "-fPIC", "-O3", "-Wall", "-Wno-unused-function"]
+    flags += [f"-D{d}" for d in defines]
     if debug:
         flags += ["-g", "-save-temps=obj"]
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
@@ -129,5 +135,8 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--debug", action="store_true")
+    ap.add_argument("--variant", default=None, help="A/B build name: lib/libneunet_hip.<variant>.so")
+    ap.add_argument("-D", dest="defines", action="append", default=[], help="extra preprocessor define (with --variant)")
+    ap.add_argument("--csrc", default=None, help="with --variant: compile the sources of this directory instead of csrc/")
     a = ap.parse_args()
-    print(build(a.force, a.debug))
+    print(build(a.force, a.debug, variant=a.variant, defines=a.defines, csrc=a.csrc))

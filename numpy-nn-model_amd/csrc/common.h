@@ -46,15 +46,44 @@ enum SyncSlot { SYNC_CE = 0, SYNC_MLP = 24 };
 unsigned* sync_words();
 
 // ---- device helpers ----------------------------------------------------------------------------
+// Wave64 all-reduce on the DPP lanes, no LDS traffic and no address registers: four row-local steps (quad_perm xor 1,
+// xor 2, row_half_mirror, row_mirror -- each one VALU instruction with the lane permutation folded into its operand
+// fetch) leave every lane of a 16-lane row with the row's total; v_readlane of lanes 0/16/32/48 then combines the four
+// rows into a wave-uniform (scalar-register) result.  The __shfl_xor form this replaces is six ds_bpermute_b32 round
+// trips through the LDS pipe plus six VGPRs of lane addresses the compiler kept alive across a persistent row loop
+// (round 3: ce_rows_kernel 100 -> 6x VGPRs together with the constant one-hot test).  Must be called wave-converged.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140;
+__device__ __forceinline__ float readlane_f32(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_f32<kDppXor1>(v);
+    v += dpp_f32<kDppXor2>(v);
+    v += dpp_f32<kDppHalfMirror>(v);
+    v += dpp_f32<kDppMirror>(v);
+    return (readlane_f32(v, 0) + readlane_f32(v, 16)) + (readlane_f32(v, 32) + readlane_f32(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_f32<kDppXor1>(v));
+    v = fmaxf(v, dpp_f32<kDppXor2>(v));
+    v = fmaxf(v, dpp_f32<kDppHalfMirror>(v));
+    v = fmaxf(v, dpp_f32<kDppMirror>(v));
+    return fmaxf(fmaxf(readlane_f32(v, 0), readlane_f32(v, 16)), fmaxf(readlane_f32(v, 32), readlane_f32(v, 48)));
+}
+__device__ __forceinline__ int wave_sum_int(int v) {
+    v += dpp_i32<kDppXor1>(v);
+    v += dpp_i32<kDppXor2>(v);
+    v += dpp_i32<kDppHalfMirror>(v);
+    v += dpp_i32<kDppMirror>(v);
+    return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) +
+           (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
 }
 
 // Block-wide sum for blockDim.x = NW*64 threads.  `red` is NW floats of LDS.  All threads get the sum.

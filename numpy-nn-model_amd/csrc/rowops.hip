@@ -629,8 +629,7 @@ __device__ __forceinline__ int64_t load_label(const void* labels, int64_t i, int
 
 template <int NW>
 __device__ __forceinline__ int block_sum_int(int v, int* red) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    v = wave_sum_int(v);
     if constexpr (NW == 1) return v;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     __syncthreads();
@@ -659,7 +658,7 @@ __device__ __forceinline__ void count_labels(const T* __restrict__ lab, int64_t 
         if ((reinterpret_cast<uintptr_t>(lab) & 15u) == 0) {   // 4 labels per load: 8192 labels = 2 batches of 4 loads for 256 threads
             const int4* l4 = reinterpret_cast<const int4*>(lab);
             const int64_t n4 = rows >> 2;
-            constexpr int U4 = 4;                                // 16 registers: the prologue must not set the kernel's occupancy
+            constexpr int U4 = 8;                                // 8192 labels = ONE batch of 8 loads for 256 threads (one L2 round trip)
             for (int64_t base = 0; base < n4; base += (int64_t)BS * U4) {
                 int4 v[U4];
 #pragma unroll
@@ -752,11 +751,15 @@ __device__ __forceinline__ void ce_epilogue(const CeArgs& a, float lsum, float d
     }
 }
 
+#ifndef NNHIP_CE_WAVES
+#define NNHIP_CE_WAVES 4
+#endif
 template <int TPR, int NV, bool VEC>
-__global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void ce_rows_kernel(const CeArgs a) {
+__global__ __launch_bounds__((TPR >= 256) ? TPR : 256) __attribute__((amdgpu_waves_per_eu(NV <= 4 && VEC ? NNHIP_CE_WAVES : 4)))
+void ce_rows_kernel(const CeArgs a) {
     constexpr int BS = (TPR >= 256) ? TPR : 256;
     constexpr int RPB = BS / TPR;
-    __shared__ float red[16];
+    __shared__ float red[32];
     __shared__ int ired[17];
     const int t = threadIdx.x % TPR;
     const int slot = RPB > 1 ? threadIdx.x / TPR : 0;    // a compile-time 0 keeps the row pointers in scalar registers
@@ -769,23 +772,39 @@ __global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void ce_rows_kernel(const
     constexpr bool PRE = NV <= 4;
     RowTile<TPR, NV, VEC> r, rn;
     if (row0 < a.rows) r.load(a.logits + row0 * a.ld, a.cols, t, -INFINITY, a.nt != 0);
+    int64_t label = row0 < a.rows ? load_label(a.labels, row0, a.lbytes) : a.ignore;
+    int64_t label_n = a.ignore;
+    if constexpr (PRE) {                                      // ... and the second row too: two rows per block cross HBM while
+        if (row0 + step < a.rows) {                           // the denominator is being counted out of L2
+            label_n = load_label(a.labels, row0 + step, a.lbytes);
+            rn.load(a.logits + (row0 + step) * a.ld, a.cols, t, -INFINITY, a.nt != 0);
+        }
+    }
     float scale, denom;
     ce_prologue<BS>(a, red, ired, scale, denom);
     float lsum = 0.f;                                         // meaningful on t == 0 of each row slot
     for (int64_t row = row0; row < a.rows; row += step) {
-        const int64_t label = load_label(a.labels, row, a.lbytes);
+        // Nothing in an iteration waits on a load issued IN that iteration: the label arrived with the row's prefetch (an
+        // iteration earlier), the label's logit is picked out of the register tile (no dependent gather), and the
+        // optional class weight is requested before anything else.  Round 2's loop began with label load -> wait ->
+        // gather -> prefetch: one L2 round trip per row in front of every prefetch.
         const bool valid = label != a.ignore && label >= 0 && label < a.cols;
         const float wy = valid ? (a.cw ? a.cw[label] : 1.f) : 0.f;
-        // read the label logit before anything is overwritten (in-place mode)
-        const float xl = valid ? a.logits[row * a.ld + label] : 0.f;
-        if constexpr (PRE) {
-            if (row + step < a.rows) rn.load(a.logits + (row + step) * a.ld, a.cols, t, -INFINITY, a.nt != 0);
-        } else {
+        const int lrel = valid ? (int)label - (VEC ? 4 * t : t) : -1;
+        if constexpr (!PRE) {
             if (row != row0) r.load(a.logits + row * a.ld, a.cols, t, -INFINITY, a.nt != 0);
+            label_n = row + step < a.rows ? load_label(a.labels, row + step, a.lbytes) : a.ignore;
         }
         float m = r.x[0];
 #pragma unroll
         for (int e = 1; e < r.NE; ++e) m = fmaxf(m, r.x[e]);
+        // the label's logit: exactly one thread of the row holds it (read before anything is overwritten: in-place mode)
+        float xl = 0.f;
+#pragma unroll
+        for (int e = 0; e < r.NE; ++e) {
+            const int off = VEC ? 4 * TPR * (e >> 2) + (e & 3) : TPR * e;
+            xl = lrel == off ? r.x[e] : xl;
+        }
         m = row_max<TPR>(m, red);
         float d = 0.f;
 #pragma unroll
@@ -793,7 +812,12 @@ __global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void ce_rows_kernel(const
             r.x[e] = exp_fast_(r.x[e] - m);   // keep exp(x - m): softmax = e / d, no second exp pass
             d += r.x[e];
         }
-        d = row_sum<TPR>(d, red);
+        if constexpr (TPR == 64) {
+            d = wave_sum(d);
+            xl = wave_sum(xl);
+        } else {
+            block_sum2<TPR / 64>(d, xl, red);                 // one pair of barriers for both
+        }
         const float lse = m + logf(d);
         if (t == 0) {
             const float l = valid ? (lse - xl) * wy : 0.f;
@@ -804,17 +828,27 @@ __global__ __launch_bounds__((TPR >= 256) ? TPR : 256) void ce_rows_kernel(const
         if (valid) {
             const float invd = 1.0f / d;
             const float gs = (a.mode == 1 ? scale : 1.f) * wy;
+            // one-hot test against compile-time constants: label - (this thread's first column) is compared with the
+            // element's fixed offset.  `label == r.col(t, e)` made the compiler keep NE 64-bit column indices alive
+            // across the persistent loop (32 VGPRs at NV = 4 -- a quarter of the kernel's registers).
 #pragma unroll
-            for (int e = 0; e < r.NE; ++e)
-                r.x[e] = (r.x[e] * invd - (label == r.col(t, e) ? 1.f : 0.f)) * gs;
+            for (int e = 0; e < r.NE; ++e) {
+                const int off = VEC ? 4 * TPR * (e >> 2) + (e & 3) : TPR * e;
+                r.x[e] = (r.x[e] * invd - (lrel == off ? 1.f : 0.f)) * gs;
+            }
         } else {
 #pragma unroll
             for (int e = 0; e < r.NE; ++e) r.x[e] = 0.f;
         }
         r.store(a.dlogits + row * a.ld, a.cols, t);
+        label = label_n;
         if constexpr (PRE) {
 #pragma unroll
             for (int e = 0; e < r.NE; ++e) r.x[e] = rn.x[e];
+            if (row + 2 * step < a.rows) {                    // the row after next, into the tile just vacated
+                label_n = load_label(a.labels, row + 2 * step, a.lbytes);
+                rn.load(a.logits + (row + 2 * step) * a.ld, a.cols, t, -INFINITY, a.nt != 0);
+            }
         }
     }
     if constexpr (RPB > 1) {                                  // row slots -> one block sum, in slot order
@@ -1394,9 +1428,15 @@ static int ce_launch(CeArgs a, hipStream_t st) {
     }
     a.count_in_kernel = 0;
     if (need_denom) {
-        // every block re-reads the label vector (out of L2): free while that stays ~tens of MB in total
-        if ((double)nblk * (double)a.rows * a.lbytes <= 64.0 * 1024 * 1024) {
+        // every block re-reads the label vector out of L2: grid x rows x 4 B, ~7 us for 32 MB at 8192 rows x 1024 blocks.
+        // (Tried in round 3, both slower: blocks counting one slice each and meeting in a device-wide counter -- one
+        //  arrival word: 200 us for 1792 blocks, read-modify-writes on one address retire at ~25 M/s; 64 sharded 64-bit
+        //  words polled by one lane each: +20 us, a grid barrier costs the launch ramp of the last block.)  The cost grows
+        //  with the grid, so a counting launch caps its grid at four blocks per compute unit.
+        const int64_t capped = nblk > 1024 ? 1024 : nblk;
+        if ((double)capped * (double)a.rows * a.lbytes <= 64.0 * 1024 * 1024) {
             a.count_in_kernel = 1;
+            nblk = capped;
         } else {
             hipLaunchKernelGGL(ce_denominator_kernel, dim3(1), dim3(1024), 0, st, a.labels, a.lbytes, a.rows, a.ignore, a.cw,
                                a.cols, a.count_out, denom_scratch);

@@ -88,6 +88,20 @@ def _to_device_array(data, dtype):
     return torch.from_numpy(arr).to("cuda")
 
 
+# Parameter epoch: advanced by every in-place parameter update (optimizer.step(), a graph replay).  A deferred kernel output
+# (experimental/linear.py: the lazily launched Linear GEMM) remembers the epoch it was created in; materialising it in a
+# LATER epoch would silently compute with the updated weights, so that read raises instead.
+_param_epoch = [0]
+
+
+def param_epoch() -> int:
+    return _param_epoch[0]
+
+
+def bump_param_epoch() -> None:
+    _param_epoch[0] += 1
+
+
 def add_arrays(a, b):
     """apply_grad's `self.grad + grad` (autograd.py:93).  On device: one nnhipAdd launch."""
     if isinstance(a, np.ndarray):

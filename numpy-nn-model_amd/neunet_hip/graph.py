@@ -35,6 +35,7 @@ Shapes of a replayed step:
 from __future__ import annotations
 
 from ._lib import call_hip_function
+from .autograd import bump_param_epoch
 from .distributed import collectives_live
 
 
@@ -199,6 +200,7 @@ class GraphedTrainStep:
 
     def __call__(self):
         self._calls += 1
+        bump_param_epoch()
         if self._calls <= 3 or self._calls % self._check_every == 0:
             if self._addresses() != self._addr:
                 raise RuntimeError("GraphedTrainStep: a parameter or gradient buffer moved since capture (p.data was "

@@ -10,7 +10,7 @@ from typing import Union
 
 import numpy as np
 
-from ...autograd import Tensor
+from ...autograd import Tensor, param_epoch
 from ..modules import Module
 from ..parameter import Parameter
 from .utils import call_hip_function, get_current_stream_ptr
@@ -94,6 +94,7 @@ class _HIPLinearTensor(Tensor):
 
     def __init__(self, data, args, op, device, thunk=None, shape=None):
         self._data, self._thunk, self._lazy_shape = None, thunk, shape
+        self._epoch = param_epoch()
         super().__init__(data, args, op, device=device, _nocopy=True)
 
         def grad_fn(X: Tensor, weight: Tensor, bias, in_rows_num, in_features, out_features, residual, grad):
@@ -156,6 +157,12 @@ class _HIPLinearTensor(Tensor):
     @property
     def data(self):
         if self._data is None and self._thunk is not None:
+            if self._epoch != param_epoch():
+                # the GEMM would run NOW, on weights an optimizer step has since updated in place (and possibly on a
+                # refilled input buffer): not the forward-time value the reference's eager Linear would hold
+                raise RuntimeError("this Linear output was never materialised during its forward pass (its GEMM was fused into "
+                                   "the activation / loss that consumed it) and the parameters have been updated since; read "
+                                   "`.data` before optimizer.step(), or set NNHIP_LAZY_LINEAR=0 for eager Linear outputs")
             thunk, self._thunk = self._thunk, None
             self._data = thunk(0, 1.0, None)
         return self._data
@@ -180,6 +187,8 @@ class _HIPLinearTensor(Tensor):
             out = self._thunk(activation, beta, z)
             self._data, self._thunk = z, None
             return out
+        # the pre-activation is not written: the thunk stays so that a second consumer reading `.data` within the same step
+        # still gets z = XW^T + b from the forward-time operands (one more GEMM); after a parameter update that read raises
         return self._thunk(activation, beta, None)
 
     @property

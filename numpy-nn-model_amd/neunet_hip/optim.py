@@ -6,6 +6,7 @@ import ctypes
 from ctypes import c_int64, c_void_p
 
 from ._lib import call_hip_function, get_current_stream_ptr, load_hip_function
+from .autograd import bump_param_epoch
 
 DECOUPLED, L2_ON_GRAD = 0, 1
 
@@ -35,6 +36,7 @@ class HIPFusedAdamW:
 
     def step(self):
         self.t += 1
+        bump_param_epoch()        # parameters change in place: deferred Linear outputs of this step are now stale
         stream = get_current_stream_ptr()
         for i, p in enumerate(self.params):
             if p.grad is None:
@@ -90,6 +92,7 @@ class HIPFusedMultiTensorAdamW:
 
     def step(self):
         self.t += 1
+        bump_param_epoch()        # parameters change in place: deferred Linear outputs of this step are now stale
         idx = 0
         keep = []        # contiguous copies of strided gradients must outlive the single launch below: a freed block
         #                  could be handed to the next .contiguous() and two table entries would alias one buffer

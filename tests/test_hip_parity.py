@@ -404,6 +404,34 @@ def test_rmsnorm_backward_addend(hip, rows, cols):
     np.testing.assert_allclose(host(norm.weight.grad), dw, rtol=1e-4, atol=1e-3)
 
 
+def test_deferred_linear_output_read_late(hip):
+    """A Linear output whose GEMM rode in its activation's launch is still pending.  Read within the same step it is
+    z = XW^T + b of the forward-time operands (the reference's eager Linear holds exactly that,
+    neunet/nn/layers/linear.py:48-58); read after optimizer.step() updated W in place it would silently be something else,
+    so it raises (round-2 advisor finding)."""
+    from neunet_hip.nn.experimental import HIPLinear, HIPReLU
+    from neunet_hip.optim import Adam
+    rng = np.random.default_rng(41)
+    X = rng.uniform(-1, 1, (40, 24)).astype(np.float32)
+    layer = HIPLinear(24, 16)
+    W, b = host(layer.weight.data), host(layer.bias.data)
+    opt = Adam(layer.parameters(), lr=1e-1)
+    lin = layer(T(hip, X))
+    y = HIPReLU()(lin)
+    assert lin.pending()
+    y.backward(dev(np.ones((40, 16), np.float32)))
+    lin2 = layer(T(hip, X))
+    y2 = HIPReLU()(lin2)
+    np.testing.assert_allclose(host(lin.data), O.linear_forward(X, W, b), **TOL)     # same step: forward-time value
+    assert not lin.pending()
+    opt.step()
+    assert lin2.pending()
+    with pytest.raises(RuntimeError, match="never materialised"):
+        lin2.data
+    np.testing.assert_allclose(host(lin.data), O.linear_forward(X, W, b), **TOL)     # materialised before the step: unchanged
+    del y2
+
+
 @pytest.mark.parametrize("act_name", ["relu", "sigmoid", "swish"])
 def test_linear_activation_deferred_fusion(hip, act_name):
     """act(Linear(x)): the Linear's GEMM is deferred until its output is read, so an activation applied first runs as the

@@ -18,6 +18,9 @@ from neunet_hip._lib import Conv2dDesc, call_hip_function as call  # noqa: E402
 import ctypes  # noqa: E402
 
 
+COLD = {"on": False, "scrub": None}
+
+
 def bench(fn, iters, warmup=5):
     for _ in range(warmup):
         fn()
@@ -25,6 +28,8 @@ def bench(fn, iters, warmup=5):
     ts = []
     for _ in range(iters):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if COLD["on"]:            # --cold: 1.5 GiB of unrelated traffic between launches (L2 / MALL hold none of the operands,
+            COLD["scrub"].add_(1.0)   # and carry a dirty tail to write back, like the previous kernel of a real step)
         a.record()
         fn()
         b.record()
@@ -48,7 +53,10 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--gemm-mode", type=int, default=0, help="0 = exact fp32 MFMA (default), 1 = split-bf16 (bf16x3)")
+    ap.add_argument("--cold", action="store_true", help="scrub the caches between timed launches")
     args = ap.parse_args()
+    if args.cold:
+        COLD["on"], COLD["scrub"] = True, torch.zeros(3 * (1 << 27), device="cuda")
     call("nnhipSetGemmMode", args.gemm_mode)
     only = set(filter(None, args.only.split(",")))
     want = lambda k: not only or k in only  # noqa: E731
