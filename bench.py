@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="headline", choices=["headline", "c1", "c2", "c3", "c4", "c5"])
+    ap.add_argument("--workload", default="headline", choices=["headline", "c1", "c2", "c3", "c4", "c5", "nb"])
     ap.add_argument("--c1-steps", type=int, default=500, help="headline: sustained MNIST-MLP steps")
     ap.add_argument("--overlap", type=int, default=1, help="N>1: overlap the gradient exchange with the backward pass")
     ap.add_argument("--c4-batch", type=int, default=64, help="sequences per GPU for the GPT-tiny workload")
@@ -58,6 +58,8 @@ def parse():
                          "what makes RCCL launch a device kernel -- a 1-rank in-place SUM is elided by the library)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-full-batch", action="store_true",
+                    help="time ONE full-batch (64 x 256) NumPy-oracle GPT-tiny step, print it as JSON and exit (no GPU work)")
     return ap.parse_args()
 
 
@@ -135,7 +137,9 @@ class EventTimer:
 
 
 def read_traffic(tag):
-    """HBM bytes per launch from the committed PMC pass (profiles/r01_pmc.json), or None."""
+    """HBM bytes per launch from the committed PMC pass (profiles/pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE passes over this same bench.py, tools/collect_profiles.sh + tools/make_profiles.sh), or None.  A static
+    number the current run did not measure: traffic_source() says which collection it is from."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(path):
         try:
@@ -143,6 +147,16 @@ def read_traffic(tag):
         except Exception:
             return None
     return None
+
+
+def traffic_source():
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        d = json.load(open(path))
+        tag = d.get("_collected") or (d.get("_note", "").rsplit("round ", 1)[-1].rstrip(". ") or "?")
+        return f"profiles/pmc_traffic.json (rocprofv3 --pmc passes, collection {tag}; not measured by this run)"
+    except Exception:
+        return None
 
 
 # ------------------------------------------------------------------------------------------------ C2
@@ -361,15 +375,18 @@ def cpu_c1(seconds):
 
 # ------------------------------------------------------------------------------------------------ C3
 def workload_c3(args, rank, world):
-    """Fused micro-bench, rows 8192 x d 4096 per GPU: Swish, RMSNorm, Softmax fwd+bwd, fused CE fwd+bwd,
-    multi-tensor AdamW on one 8192x4096 tensor -- each called through the functional C-ABI wrappers on
-    pre-allocated buffers (the shape of the reference's scripts/benchmark_swish_cuda.py).  A 'step' is one
-    pass over all of them; the roofline entry is the Swish forward kernel (HBM bound), per-op GB/s in `ops`."""
+    """Fused micro-bench, rows 8192 x d 4096 per GPU (BASELINE config 3: "Fused Linear-Swish + RMSNorm + Softmax +
+    MultiTensorAdamW"): the fused Linear(4096->4096)->Swish forward and backward (MFMA bound), Swish, RMSNorm, Softmax
+    fwd+bwd, fused CE fwd+bwd, multi-tensor AdamW on one 8192x4096 tensor -- each called through the functional C-ABI
+    wrappers on pre-allocated buffers (the shape of the reference's scripts/benchmark_swish_cuda.py).  A 'step' is one
+    pass over all of them; the roofline entry is the Swish forward kernel (HBM bound), per-op GB/s (TFLOP/s for the
+    two GEMM ops) in `ops`."""
     import torch
     import neunet_hip
     from neunet_hip.nn import Parameter
     from neunet_hip.nn.experimental.activations import (hip_softmax_backward, hip_softmax_forward,
                                                         hip_swish_backward, hip_swish_forward)
+    from neunet_hip.nn.experimental.linear_swish import hip_linear_swish_backward, hip_linear_swish_forward
     from neunet_hip.nn.experimental.losses import cross_entropy_forward_backward
     from neunet_hip.nn.experimental.rmsnorm import rmsnorm_backward, rmsnorm_forward
     from neunet_hip.optim import HIPFusedMultiTensorAdamW
@@ -385,10 +402,16 @@ def workload_c3(args, rank, world):
     p = Parameter(neunet_hip.Tensor(Xn, device="cuda"))
     p.grad = dY
     opt = HIPFusedMultiTensorAdamW([p], lr=1e-3, weight_decay=1e-2)
+    Wl = torch.from_numpy((rng.uniform(-1, 1, (D, D)) / 64).astype(np.float32)).cuda()
+    bl = torch.from_numpy((rng.uniform(-1, 1, (1, D)) / 64).astype(np.float32)).cuda()
+    z, ls_out, dXl, dWl, dbl = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x), torch.empty_like(Wl), torch.empty_like(bl)
     # Order matters for cold-cache timing: a kernel that follows AdamW also pays for the write-back of AdamW's
     # 402 MB of dirty lines (+12 us measured on ANY streaming kernel placed there, tools/order_check.py), so
-    # AdamW goes last and the fused CE -- whose predecessor in a real step is the vocabulary GEMM -- first.
+    # AdamW goes last, the two MFMA-bound Linear->Swish ops first, and the fused CE follows a GEMM -- as it does in a
+    # real step, where its predecessor is the vocabulary projection.
     ops = [
+        ("linear_swish_fwd", lambda: hip_linear_swish_forward(x, Wl, bl, ls_out, z, R, D, D, 1.0, True)),
+        ("linear_swish_bwd", lambda: hip_linear_swish_backward(x, Wl, bl, dY, z, dXl, dWl, dbl, R, D, D, 1.0, False)),
         ("ce_fwd_bwd", lambda: cross_entropy_forward_backward(logits, labels, "mean", -100, inplace=False)),
         ("swish_fwd", lambda: hip_swish_forward(x, y, 1.0)),
         ("swish_bwd", lambda: hip_swish_backward(dx, dY, x, 1.0)),
@@ -403,6 +426,7 @@ def workload_c3(args, rank, world):
     bytes_per = {"swish_fwd": 8 * n, "swish_bwd": 12 * n, "rmsnorm_fwd": 8 * n + 4 * R + 4 * D,
                  "rmsnorm_bwd": 12 * n + 4 * R + 8 * D, "softmax_fwd": 8 * n, "softmax_bwd": 12 * n,
                  "ce_fwd_bwd": 8 * n + 12 * R, "adamw": 28 * n}
+    flops_per = {"linear_swish_fwd": 2.0 * R * D * D, "linear_swish_bwd": 4.0 * R * D * D}
 
     def step(timed):
         for k, fn in ops:
@@ -418,16 +442,21 @@ def workload_c3(args, rank, world):
     res_ops = {k: {"ms": round(t.mean_ms(), 4), "GBps": round(bytes_per[k] / (t.mean_ms() * 1e-3) / 1e9, 1),
                    "frac_of_8TBps": round(bytes_per[k] / (t.mean_ms() * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                    "hbm_traffic_pmc": read_traffic(k.replace("_fwd_bwd", "") + "_c3")}
-               for k, t in timers.items()}
+               for k, t in timers.items() if k in bytes_per}
+    for k, fl in flops_per.items():
+        ms = timers[k].mean_ms()
+        res_ops[k] = {"ms": round(ms, 4), "TFLOPs": round(fl / (ms * 1e-3) / 1e12, 2),
+                      "frac_of_mfma_peak": round(fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
     sw = res_ops["swish_fwd"]
     return {
         "samples_per_step": R * world, "dt": dt,
-        "config": {"workload": "C3: fused micro-bench rows 8192 x d 4096 per GPU (Swish, RMSNorm, Softmax fwd+bwd, "
-                               "fused CrossEntropy, multi-tensor AdamW)", "global_batch": R * world,
+        "config": {"workload": "C3: fused micro-bench rows 8192 x d 4096 per GPU (fused Linear(4096->4096)->Swish fwd+bwd, Swish, "
+                               "RMSNorm, Softmax fwd+bwd, fused CrossEntropy, multi-tensor AdamW)", "global_batch": R * world,
                    "parallelism": f"dp{world}"},
         "roofline": {"kernel": "map1_kernel<SwishF> (Swish forward)", "bound": "hbm", "achieved": sw["GBps"],
                      "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": sw["frac_of_8TBps"],
-                     "traffic": read_traffic("swish_fwd_c3"), "bytes_per_launch": bytes_per["swish_fwd"],
+                     "traffic": read_traffic("swish_fwd_c3"), "traffic_source": traffic_source(),
+                     "bytes_per_launch": bytes_per["swish_fwd"],
                      "avg_launch_ms": sw["ms"]},
         "extra": {"ops": res_ops},
     }
@@ -613,9 +642,11 @@ def workload_c4(args, rank, world):
     }
 
 
-def cpu_c4(seconds):
+def cpu_c4(seconds, Bs=2, max_steps=3):
     """FULL GPT-tiny training step (forward, backward, Adam on every parameter that has a gradient) of the NumPy oracle on
-    a bounded sample of the workload: 2 sequences x 256 tokens = 1/32 of one GPU's batch."""
+    a bounded sample of the workload: 2 sequences x 256 tokens = 1/32 of one GPU's batch.  `--cpu-full-batch` times ONE
+    step on all 64 sequences instead (about a minute; its result is committed as profiles/cpu_c4_full_batch.json and
+    quoted next to every later bounded sample, so the bounded sample's scaling can be read off)."""
     from oracle import neunet_oracle as O
     c = C4
     rng = np.random.default_rng(1004)
@@ -625,7 +656,6 @@ def cpu_c4(seconds):
                "ffn": [u(F, D), u(1, F), u(D, F), u(1, D)], "norm1": np.ones(D, np.float32), "norm2": np.ones(D, np.float32)}
               for _ in range(L)]
     model = O.GPTTiny(rng.standard_normal((V, D)).astype(np.float32), layers, u(V, D), u(1, V), c["n_heads"], 0, 1024)
-    Bs = 2
     batch = c4_batch(rng, Bs, c["seq"], V)
 
     def flat_params(m):
@@ -644,7 +674,7 @@ def cpu_c4(seconds):
     ms, vs = [np.zeros_like(p) for p in ps], [np.zeros_like(p) for p in ps]
     times = []
     t_all = time.perf_counter()
-    for step in range(1, 4):
+    for step in range(1, max_steps + 1):
         t0 = time.perf_counter()
         _, _, grads = model.forward_backward(batch[:, :-1], batch[:, 1:])
         for i, (p_, g_) in enumerate(zip(ps, flat_grads(grads))):
@@ -653,10 +683,88 @@ def cpu_c4(seconds):
         if time.perf_counter() - t_all > max(seconds, 10.0):
             break
     best = min(times)
-    return {"value": round(Bs / best, 3), "unit": "samples/s", "cores": blas_threads(), "kind": "port",
-            "sample": f"{len(times)} FULL steps (forward + backward + Adam over all {sum(p.size for p in ps)} parameters) of the "
-                      f"NumPy-oracle GPT-tiny on {Bs} sequences x {c['seq']} tokens (1/32 of one GPU's batch), min step "
-                      f"{best:.2f} s, OpenBLAS threads={blas_threads()}, host cpus={os.cpu_count()}"}
+    out = {"value": round(Bs / best, 3), "unit": "samples/s", "cores": blas_threads(), "kind": "port",
+           "sample": f"{len(times)} FULL steps (forward + backward + Adam over all {sum(p.size for p in ps)} parameters) of the "
+                     f"NumPy-oracle GPT-tiny on {Bs} sequences x {c['seq']} tokens ({Bs}/64 of one GPU's batch), min step "
+                     f"{best:.2f} s, OpenBLAS threads={blas_threads()}, host cpus={os.cpu_count()}"}
+    full = os.path.join(ROOT, "profiles", "cpu_c4_full_batch.json")
+    if Bs != 64 and os.path.exists(full):
+        try:
+            fb = json.load(open(full))
+            out["full_batch_reference"] = {k: fb[k] for k in ("value", "step_seconds", "cores", "collected") if k in fb}
+            out["sample"] += (f"; ONE full-batch step (64 x 256) timed once on a box of this pool: {fb['step_seconds']:.1f} s = "
+                              f"{fb['value']:.2f} samples/s ({fb.get('collected', '?')})")
+        except Exception:
+            pass
+    else:
+        out["step_seconds"] = round(best, 2)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ notebook GPT
+NB = dict(vocab=15000, d_model=512, n_heads=8, d_ff=2048, n_layers=8, batch=4, dropout=0.1)
+NB_REFERENCE_IT_PER_S = (6.44, 6.67)     # examples/gpt.ipynb cell 16 output (tqdm, epochs 12-14), hardware unstated
+
+
+def nb_batches(rng, n, B, vocab):
+    """Batches shaped like the notebook's (cell 10): B prompts tokenised to <sos> ... <eos>, padded to the longest of the
+    batch with PAD = 0 -- a different length every step."""
+    out = []
+    for _ in range(n):
+        lens = rng.integers(24, 128, B)
+        T = int(lens.max())
+        ids = np.zeros((B, T), np.int32)
+        for r, L in enumerate(lens):
+            ids[r, :L] = rng.integers(3, vocab, L)
+            ids[r, 0], ids[r, L - 1] = 1, 2
+        out.append(ids)
+    return out
+
+
+def workload_nb(args, rank, world):
+    """The reference's ONLY published training throughput: examples/gpt.ipynb's GPT (d512, 8 layers, 8 heads, d_ff 2048,
+    vocab 15000, dropout 0.1, Adam 1.5e-4) on batches of 4 variable-length prompts, 6.44-6.67 it/s in the notebook's own
+    tqdm output (cell 16; CuPy on an unnamed NVIDIA GPU).  Same model and loop body (cell 12) on the HIP path: eager
+    launches -- every batch has its own length, so there is no graph to replay -- device-side dropout masks."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import gpt_tiny
+    import neunet_hip.nn as nn
+    from neunet_hip.optim import Adam
+    c = NB
+    np.random.seed(1006)
+    model = gpt_tiny.build_gpt(c["vocab"], c["d_model"], c["n_heads"], c["d_ff"], c["n_layers"], pad_idx=0, max_len=1024,
+                               fused=True, dropout=c["dropout"])
+    opt = Adam(model.parameters(), lr=1.5e-4, betas=(0.9, 0.98), eps=1e-9)
+    loss_fn = nn.CrossEntropyLoss(ignore_index=0)
+    steps = max(args.steps, 100)
+    batches = nb_batches(np.random.default_rng(6000 + rank), 64, c["batch"], c["vocab"])
+    it = [0]
+
+    def step(timed):
+        gpt_tiny.train_step(model, opt, loss_fn, batches[it[0] % len(batches)])
+        it[0] += 1
+
+    dt = timed_region(step, steps, max(args.warmup, 10), world)
+    ips = steps / dt
+    tokens = float(np.mean([b.shape[0] * (b.shape[1] - 1) for b in batches]))
+    return {
+        "samples_per_step": c["batch"] * world, "dt": dt * args.steps / steps,     # main() divides by args.steps
+        "config": {"workload": "examples/gpt.ipynb GPT (d512 L8 H8 d_ff2048 vocab15000, dropout 0.1, Adam 1.5e-4), batch 4 "
+                               "variable-length prompts (24-127 tokens, padded to the batch maximum), eager launches",
+                   "global_batch": c["batch"] * world, "parallelism": f"dp{world}", "launch": "eager"},
+        "roofline": {"kernel": "whole step (launch bound: ~" + str(int(tokens)) + " tokens per step)", "bound": "mfma",
+                     "achieved": None, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None},
+        "extra": {"it_per_s": round(ips, 2), "timed_steps": steps, "mean_tokens_per_step": round(tokens, 1),
+                  "reference_it_per_s": list(NB_REFERENCE_IT_PER_S),
+                  "vs_reference_notebook": round(ips / NB_REFERENCE_IT_PER_S[1], 1),
+                  "reference_note": "examples/gpt.ipynb cell 16 (tqdm it/s of the CuPy path on an unnamed NVIDIA GPU, real "
+                                    "prompts): different hardware and data, same model / batch size / optimizer"},
+    }
+
+
+def cpu_nb(seconds):
+    return cpu_c4(seconds)
 
 
 # ------------------------------------------------------------------------------------------------ C5
@@ -812,6 +920,66 @@ def c2_forward_roofline(iters=50, sustain_s=2.0):
             "burst_tflops": flops / (burst_ms * 1e-3) / 1e12, "sustained_tflops": flops / (sus_ms * 1e-3) / 1e12}
 
 
+def c4_family_rooflines(iters=20):
+    """The three kernel families that make up ~97 % of the C4 step, each launched on its own at its C4 shape and timed
+    with HIP events (median of `iters`): what the whole-step figure in also.c4_gemm averages over."""
+    import torch
+    from neunet_hip._lib import StridedView, call_hip_function as call, get_current_stream_ptr
+    st = get_current_stream_ptr()
+    g = torch.Generator(device="cuda").manual_seed(7)
+    rnd = lambda *sh: torch.rand(*sh, device="cuda", generator=g) * 2 - 1  # noqa: E731
+
+    def med(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        ev = []
+        for _ in range(iters):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn()
+            b.record()
+            ev.append((a, b))
+        torch.cuda.synchronize()
+        return float(np.median([a.elapsed_time(b) for a, b in ev]))
+
+    M, D, F, V, Bq, T, H = 64 * C4["seq"], C4["d_model"], C4["d_ff"], C4["vocab"], 64, C4["seq"], C4["n_heads"]
+    fams = []
+
+    def linear_family(name, K, N, per_step):
+        X, W, b = rnd(M, K), rnd(N, K) / 16, rnd(1, N)
+        O_, dO, dX, dW, db = torch.empty(M, N, device="cuda"), rnd(M, N), torch.empty(M, K, device="cuda"), \
+            torch.empty(N, K, device="cuda"), torch.empty(1, N, device="cuda")
+        t = (med(lambda: call("nnhipLinearModuleForward", X, W, b, O_, M, K, N, st))
+             + med(lambda: call("nnhipLinearModuleBackward", X, W, dO, dX, None, None, M, K, N, st))
+             + med(lambda: call("nnhipLinearModuleBackward", X, W, dO, None, dW, db, M, K, N, st)))
+        fl = 6.0 * M * K * N
+        fams.append({"family": name, "kernels": "gemm_f32 / gemm_pst forward, dX, dW+db", "launches_per_step": per_step,
+                     "flops": fl, "ms": round(t, 4), "tflops": round(fl / (t * 1e-3) / 1e12, 2),
+                     "frac_of_mfma_peak": round(fl / (t * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)})
+
+    linear_family(f"Linear {D}->{D} (attention projections), rows {M}", D, D, "4 x 6 layers")
+    linear_family(f"Linear {D}->{F} / {F}->{D} (FFN), rows {M}", D, F, "2 x 6 layers")
+    linear_family(f"Linear {D}->{V} (vocabulary head), rows {M}", D, V, "1")
+    qkv = rnd(Bq, T, 3 * D)
+    dqkv = torch.empty_like(qkv)
+    kval = torch.ones(Bq, T, dtype=torch.int32, device="cuda")
+    ctx, dctx, lse = torch.empty(Bq, T, D, device="cuda"), rnd(Bq, T, D), torch.empty(Bq, H, T, 2, device="cuda")
+    q_, k_, v_ = (qkv[..., i * D:(i + 1) * D] for i in range(3))
+    dq_, dk_, dv_ = (dqkv[..., i * D:(i + 1) * D] for i in range(3))
+    sc, dh = 1.0 / float(np.sqrt(D)), D // H
+    tf = med(lambda: call("nnhipAttentionForward", StridedView(q_), StridedView(k_), StridedView(v_), kval, ctx, lse, Bq, H, T, T, dh,
+                          3 * D, sc, 1, st))
+    tb = med(lambda: call("nnhipAttentionBackward", StridedView(q_), StridedView(k_), StridedView(v_), kval, ctx, dctx, lse,
+                          StridedView(dq_), StridedView(dk_), StridedView(dv_), Bq, H, T, T, dh, 3 * D, sc, 1, st))
+    fl = 3.5 * (4.0 * Bq * H * T * T * dh / 2)          # causal: half the score matrix; backward = 2.5 x forward
+    fams.append({"family": f"fused attention B{Bq} T{T} H{H} dh{dh} (causal)", "kernels": "attn_fwd / attn_bwd_dkdv / attn_bwd_dq",
+                 "launches_per_step": "3 x 6 layers", "flops": fl, "ms": round(tf + tb, 4),
+                 "tflops": round(fl / ((tf + tb) * 1e-3) / 1e12, 2),
+                 "frac_of_mfma_peak": round(fl / ((tf + tb) * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)})
+    return fams
+
+
 def workload_headline(args, rank, world):
     """BASELINE.json's metric in one run: C4 GPT-tiny step (value), C2 Linear forward vs MFMA peak (roofline), C1
     MNIST-MLP samples/s and the C2 step (also)."""
@@ -824,6 +992,7 @@ def workload_headline(args, rank, world):
                   "~86 % of the C4 step's device time)",
         "bound": "mfma", "achieved": round(fwd["burst_tflops"], 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
         "frac": round(fwd["burst_tflops"] / PEAK_F32_MFMA_TFLOPS, 4), "traffic": read_traffic("gemm_fwd_c2"),
+        "traffic_source": traffic_source(),
         "flops_per_launch": fwd["flops"], "avg_launch_ms": round(fwd["burst_ms"], 4),
         "sustained": {"tflops": round(fwd["sustained_tflops"], 2), "frac": round(fwd["sustained_tflops"] / PEAK_F32_MFMA_TFLOPS, 4),
                       "avg_launch_ms": round(fwd["sustained_ms"], 4), "launches": fwd["sustained_launches"]},
@@ -831,6 +1000,11 @@ def workload_headline(args, rank, world):
     also = {"c4_gemm": {"what": "whole C4 step, GEMM-equivalent flops (Linear fwd/dX/dW + attention) / device step time",
                         "tflops": c4_roof["achieved"], "frac_of_mfma_peak": c4_roof["frac"],
                         "flops_per_step": c4_roof["flops_per_step"], "avg_step_device_ms": c4_roof["avg_step_device_ms"]}}
+    if rank == 0 or world == 1:
+        try:
+            also["c4_families"] = c4_family_rooflines()
+        except Exception as exc:  # noqa: BLE001
+            also["c4_families"] = {"error": repr(exc)[:300]}
     # C1: MNIST-MLP, sustained
     a1 = copy.copy(args)
     a1.steps, a1.warmup = args.c1_steps, 20
@@ -859,6 +1033,14 @@ def workload_headline(args, rank, world):
                       "ms_per_step": round(r2["dt"] / a2.steps * 1e3, 4), "linear_fwd_tflops_in_step": r2["extra"]["linear_fwd_tflops"],
                       "linear_bwd_tflops_in_step": r2["extra"]["linear_bwd_tflops"]}
     guarded("c2", run_c2)
+
+    def run_nb():
+        an = copy.copy(args)
+        an.steps, an.warmup = 100, 10
+        rn = workload_nb(an, rank, world)
+        also["nb"] = {"workload": rn["config"]["workload"], **rn["extra"]}
+    if os.environ.get("NNHIP_BENCH_NB", "1") != "0":
+        guarded("nb", run_nb)
     # opt-in split-bf16 GEMM mode (fp32 operands split exactly into 3 bf16 pieces, 6 products on the bf16 matrix cores):
     # reported NEXT TO the exact-fp32 numbers above, never instead of them
     if os.environ.get("NNHIP_BENCH_BF16X3", "1") != "0":
@@ -930,6 +1112,11 @@ def claim_stdout():
 
 def main():
     args = parse()
+    if args.cpu_full_batch:
+        r = cpu_c4(1e9, Bs=64, max_steps=1)
+        r["collected"] = time.strftime("%Y-%m-%d") + " (round 3)"
+        print(json.dumps(r), flush=True)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(respawn_under_torchrun(args))
     json_out = claim_stdout()
@@ -964,7 +1151,7 @@ def main():
                 for ln in lines[:60]:
                     print("[rccl] " + ln, file=sys.stderr)
     wl = {"headline": workload_headline, "c1": workload_c1, "c2": workload_c2, "c3": workload_c3, "c4": workload_c4,
-          "c5": workload_c5}[args.workload]
+          "c5": workload_c5, "nb": workload_nb}[args.workload]
     res = wl(args, rank, world)
     dt = res["dt"]
     value = res["samples_per_step"] * args.steps / dt
@@ -982,7 +1169,7 @@ def main():
     if rank == 0:
         if not args.no_cpu_baseline:        # N > 1 too: timed on rank 0's host cores while the other ranks wait at the barrier
             out["cpu_baseline"] = {"headline": cpu_headline, "c1": cpu_c1, "c2": cpu_c2, "c3": cpu_c3, "c4": cpu_c4,
-                                   "c5": cpu_c5}[args.workload](args.cpu_seconds)
+                                   "c5": cpu_c5, "nb": cpu_nb}[args.workload](args.cpu_seconds)
         print(json.dumps(out), file=json_out, flush=True)
     if world > 1 or args.force_dp:
         import torch.distributed as dist

@@ -99,7 +99,12 @@ class GPT(nn.Module):
         get_pad_mask(x) & get_sub_mask(x) is carried as (key_valid = x != pad, causal=True)."""
         import torch
         ids = x if isinstance(x, Tensor) else Tensor(np.asarray(x), dtype=np.int32, requires_grad=False, device="cuda")
-        key_valid = (ids.data != self.pad_idx).to(torch.int32)
+        if ids.data.dtype == torch.int32 and ids.data.is_contiguous():
+            from neunet_hip._lib import call_hip_function, get_current_stream_ptr
+            key_valid = torch.empty_like(ids.data)
+            call_hip_function("nnhipNotEqualInt32", key_valid, ids.data, ids.data.numel(), int(self.pad_idx), get_current_stream_ptr())
+        else:
+            key_valid = (ids.data != self.pad_idx).to(torch.int32)
         return self.decoder(ids, key_valid)
 
 

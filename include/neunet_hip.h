@@ -53,6 +53,10 @@ int nnhipWorkspaceLock(int locked);
  *                NNHIP_GEMM_MODE=1 in the environment.  Small problems (gemm_small) stay exact either way. */
 int nnhipSetGemmMode(int mode);
 int nnhipGetGemmMode(void);
+/* Launches since the library was loaded, per GEMM kernel family: 0 = classic fp32 128x128 tiles (gemm_f32_kernel),
+ * 1 = persistent fp32 (gemm_pst_kernel), 2 = small-problem kernel (gemm_small*), 3 = split-bf16 (gemm_bf3_kernel);
+ * -1 for any other argument.  Host-side bookkeeping for tests that must know which kernel produced a result.  ABI 203 */
+int64_t nnhipGemmLaunchCount(int family);
 
 /* ---- a1/a2 Linear  (replaces cudaLinearModuleForward/Backward,
  *      linear_cublaslt_no_manual_mem.cu:114,142 and linear_cutlass.cu:40,67) ------------------ */
@@ -367,6 +371,9 @@ int nnhipEmbeddingForward(float* out, const float* weight, const int32_t* ids, c
                           nnhipStream_t stream);
 int nnhipEmbeddingBackward(float* dW, const float* grad_out, const int32_t* ids, int64_t n_ids,
                            int64_t dim, int64_t vocab, float scale, nnhipStream_t stream);
+/* out[i] = (ids[i] != value) as int32: the key-padding mask of examples/gpt.ipynb cell 7 (get_pad_mask:
+ * (x != pad_idx).astype(int)) without leaving the library (torch would run a compare and a cast kernel).  ABI 203 */
+int nnhipNotEqualInt32(int32_t* out, const int32_t* ids, int64_t n, int32_t value, nnhipStream_t stream);
 
 /* ---- the rest of the conv-classifier step (examples/convolutional_digits_classifier.ipynb) ----
  * LeakyReLU (neunet/nn/activations.py:60-84): f = x <= 0 ? alpha*x : x ; dx = dy * (f <= 0 ? alpha : 1). */
@@ -381,6 +388,7 @@ int nnhipSigmoidBackward(float* dIn, const float* dOut, const float* out, int64_
  * overlapping windows accumulate deterministically. */
 typedef struct nnhipPool2dDesc {
     int64_t B, C, H, W, kh, kw, sh, sw, pu, pd, pl, pr;
+    int64_t dh, dw;   /* dilation (maxpool2d.py:170-186: taps at r*dh, s*dw; 0 is read as 1).  ABI 203 */
 } nnhipPool2dDesc;
 int nnhipMaxPool2dForward(float* out, int32_t* argmax, const float* X, const nnhipPool2dDesc* d,
                           nnhipStream_t stream);

@@ -50,6 +50,13 @@ __global__ __launch_bounds__(256) void fill_i32_kernel(int32_t* __restrict__ p, 
     if (i < n) p[i] = v;
 }
 
+// out[i] = ids[i] != value  (the notebook's get_pad_mask, examples/gpt.ipynb cell 7: (x != pad_idx).astype(int))
+__global__ __launch_bounds__(256) void not_equal_i32_kernel(int32_t* __restrict__ out, const int32_t* __restrict__ ids,
+                                                            int64_t n, int32_t value) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = ids[i] != value ? 1 : 0;
+}
+
 __global__ __launch_bounds__(256) void embedding_last_kernel(const int32_t* __restrict__ ids, int64_t n,
                                                              int64_t vocab, int32_t* __restrict__ last) {
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -122,5 +129,14 @@ extern "C" int nnhipEmbeddingBackward(float* dW, const float* grad_out, const in
     if (vec) hipLaunchKernelGGL(embedding_bwd_kernel<true>, dim3(grid), dim3(256), 0, st, dW, grad_out, last, vocab, dim, scale);
     else hipLaunchKernelGGL(embedding_bwd_kernel<false>, dim3(grid), dim3(256), 0, st, dW, grad_out, last, vocab, dim, scale);
     NNHIP_LAUNCH_CHECK("embedding_bwd_kernel");
+    return 0;
+}
+
+extern "C" int nnhipNotEqualInt32(int32_t* out, const int32_t* ids, int64_t n, int32_t value, nnhipStream_t s) {
+    NNHIP_CHECK_ARG(n >= 0, NNHIP_EINVAL, "nnhipNotEqualInt32: negative size");
+    if (n == 0) return 0;
+    NNHIP_CHECK_ARG(out && ids, NNHIP_EINVAL, "nnhipNotEqualInt32: null pointer");
+    hipLaunchKernelGGL(not_equal_i32_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)s, out, ids, n, value);
+    NNHIP_LAUNCH_CHECK("not_equal_i32_kernel");
     return 0;
 }

@@ -451,6 +451,10 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
 
 // gemm_bf3.hip: the same tiles on the bf16 matrix cores (exact 3-way bf16 split of every fp32 operand, 6 products)
 int gemm_bf3_launch(const GemmParams& p, bool a_kmajor, bool b_kmajor, bool vec, bool cs, int64_t batch, hipStream_t st);
+// launches per kernel family since load (nnhipGemmLaunchCount): 0 classic fp32 128x128, 1 persistent fp32, 2 small, 3 split-bf16.
+// Host-side counters for tests that must know WHICH kernel produced a result (a "bf16x3" test that only ever reaches the
+// small kernel proves nothing about gemm_bf3_kernel).
+static long long g_gemm_launches[4] = {0, 0, 0, 0};
 static int g_gemm_mode = -1;    // -1: not initialised (NNHIP_GEMM_MODE decides), 0: exact fp32 MFMA, 1: split-bf16
 static int gemm_mode() {
     if (g_gemm_mode < 0) {
@@ -539,12 +543,16 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
     if (addend && dswish) { set_last_error("gemm: addend and dswish are mutually exclusive"); return NNHIP_EINVAL; }
     if (asum && (a_kmajor || batch != 1 || K <= 0)) { set_last_error("gemm: asum needs an outer-major, unbatched A"); return NNHIP_EINVAL; }
     if (a_kmajor && batch == 1 && !asum && !addend && gemm_mode() == 0 &&
-        gemm_pst_wanted(M, N, K, lda, ldb, ldc, A, B, C, bias, b_kmajor, act, preact, dswish, dact))
+        gemm_pst_wanted(M, N, K, lda, ldb, ldc, A, B, C, bias, b_kmajor, act, preact, dswish, dact)) {
+        ++g_gemm_launches[1];
         return gemm_pst(A, B, C, bias, preact, M, N, K, lda, ldb, ldc, b_kmajor, alpha, act, beta, dswish, dact, st);
+    }
     static const int small_on = []() { const char* e = getenv("NNHIP_GEMM_SMALL"); return e ? atoi(e) : 1; }();
-    if (small_on && gemm_small_wanted(M, N, K, batch, lda, ldb, a_kmajor, b_kmajor))
+    if (small_on && gemm_small_wanted(M, N, K, batch, lda, ldb, a_kmajor, b_kmajor)) {
+        ++g_gemm_launches[2];
         return gemm_small(A, B, C, bias, preact, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, alpha, act, beta, asum, addend,
                           dswish, dact, st);
+    }
     constexpr int BK = 32;     // (a BK = 16 / 3-blocks-per-CU variant was measured in rounds 1 and 2: never ahead; dropped)
     GemmParams p;
     p.A = A; p.B = B; p.C = C; p.bias = bias; p.preact = preact;
@@ -609,6 +617,7 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
     }
 
     int rc;
+    ++g_gemm_launches[gemm_mode() == 1 ? 3 : 0];
     if (gemm_mode() == 1) {
         rc = gemm_bf3_launch(p, a_kmajor, b_kmajor, vec_any && (K & 7) == 0 && K >= 16 && span_ok(lda, a_kmajor) && span_ok(ldb, b_kmajor),
                              asum != nullptr, batch, st);
@@ -649,6 +658,9 @@ extern "C" int nnhipSetGemmMode(int mode) {
     return 0;
 }
 extern "C" int nnhipGetGemmMode(void) { return nnhip::gemm_mode(); }
+extern "C" int64_t nnhipGemmLaunchCount(int family) {
+    return family >= 0 && family < 4 ? (int64_t)nnhip::g_gemm_launches[family] : -1;
+}
 
 extern "C" int nnhipGemmF32Ex(const float* A, const float* B, float* C, const float* bias, int64_t M,
                               int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, int a_kmajor,

@@ -50,14 +50,15 @@ struct SigmoidF { __device__ float operator()(float x) const { return 1.0f / (1.
 // dx = dy * f * (1 - f)                          (activations.py:12-13)
 struct SigmoidB { __device__ float operator()(float dy, float f) const { return dy * f * (1.0f - f); } };
 
-// ---- MaxPool2d (neunet/nn/layers/maxpool2d.py:85-249; dilation 1) ----------------------------------------------
+// ---- MaxPool2d (neunet/nn/layers/maxpool2d.py:85-249; dilation: taps at r*dh, s*dw -- the reference multiplies the
+// dilated window by a kernel that is NaN between the taps and takes nanmax / nanargmax, :187-220) ----------------------------------------------
 // Forward: one thread per output; windows read -inf outside the padded input; the FIRST maximum in (r, s)
 // row-major order is remembered (np.nanargmax, maxpool2d.py:37).  Backward is a gather over the windows that
 // cover an input pixel (deterministic, also correct for overlapping windows).
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(float* __restrict__ out, int32_t* __restrict__ arg,
                                                           const float* __restrict__ x, int64_t BC, int H, int W,
                                                           int Ho, int Wo, int kh, int kw, int sh, int sw, int pu,
-                                                          int pl, float pre_alpha) {
+                                                          int pl, int dh, int dw, float pre_alpha) {
     // pre_alpha != 1: the window is taken over LeakyReLU(x; pre_alpha), evaluated on the fly (nnhipMaxPool2dLeakyForward)
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t total = BC * Ho * Wo;
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(float* __restrict__ ou
     int bi = 0;
     for (int r = 0; r < kh; ++r)
         for (int s = 0; s < kw; ++s) {
-            const int y = ho * sh - pu + r, xx = wo * sw - pl + s;
+            const int y = ho * sh - pu + r * dh, xx = wo * sw - pl + s * dw;
             float v = -INFINITY;
             if (y >= 0 && y < H && xx >= 0 && xx < W) {
                 v = p[(int64_t)y * W + xx];
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(float* __restrict__ ou
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(float* __restrict__ dx, const float* __restrict__ dy,
                                                           const int32_t* __restrict__ arg, int64_t BC, int H, int W,
                                                           int Ho, int Wo, int kh, int kw, int sh, int sw, int pu,
-                                                          int pl, const float* __restrict__ pooled, float alpha) {
+                                                          int pl, int dh, int dw, const float* __restrict__ pooled, float alpha) {
     // pooled != null: dx is the gradient of the LeakyReLU's INPUT -- the routed gradient times LeakyB's factor, read off
     // the pooled output (= the LeakyReLU output at the arg-max: f <= 0 ? alpha : 1)
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -106,12 +107,12 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(float* __restrict__ dx
     }
     float g = 0.f;
     for (int r = 0; r < kh; ++r) {
-        const int ty = y + pu - r;
+        const int ty = y + pu - r * dh;
         if (ty < 0 || ty % sh) continue;
         const int ho = ty / sh;
         if (ho >= Ho) continue;
         for (int s = 0; s < kw; ++s) {
-            const int tx = xx + pl - s;
+            const int tx = xx + pl - s * dw;
             if (tx < 0 || tx % sw) continue;
             const int wo = tx / sw;
             if (wo >= Wo) continue;
@@ -444,13 +445,17 @@ extern "C" int nnhipSigmoidBackward(float* dIn, const float* dOut, const float* 
     return 0;
 }
 
+static inline int64_t pool_dil(int64_t v) { return v > 0 ? v : 1; }
 static int pool_check(const nnhipPool2dDesc* d, int& Ho, int& Wo) {
     NNHIP_CHECK_ARG(d != nullptr, NNHIP_EINVAL, "maxpool2d: null descriptor");
+    NNHIP_CHECK_ARG(d->dh >= 0 && d->dw >= 0, NNHIP_EINVAL, "maxpool2d: negative dilation");
     NNHIP_CHECK_ARG(d->B >= 0 && d->C > 0 && d->H > 0 && d->W > 0 && d->kh > 0 && d->kw > 0 && d->sh > 0 && d->sw > 0 &&
                         d->pu >= 0 && d->pd >= 0 && d->pl >= 0 && d->pr >= 0,
                     NNHIP_EINVAL, "maxpool2d: bad descriptor");
-    const int64_t ho = (d->H + d->pu + d->pd - (d->kh - 1) - 1) / d->sh + 1;   // maxpool2d.py:170-183 (dilation 1)
-    const int64_t wo = (d->W + d->pl + d->pr - (d->kw - 1) - 1) / d->sw + 1;
+    const int64_t ho = (d->H + d->pu + d->pd - pool_dil(d->dh) * (d->kh - 1) - 1) / d->sh + 1;   // maxpool2d.py:170-183
+    const int64_t wo = (d->W + d->pl + d->pr - pool_dil(d->dw) * (d->kw - 1) - 1) / d->sw + 1;
+    NNHIP_CHECK_ARG(d->H + d->pu + d->pd >= pool_dil(d->dh) * (d->kh - 1) + 1 && d->W + d->pl + d->pr >= pool_dil(d->dw) * (d->kw - 1) + 1,
+                    NNHIP_EINVAL, "maxpool2d: the (dilated) window is larger than the padded input");
     NNHIP_CHECK_ARG(ho > 0 && wo > 0 && d->H * d->W < ((int64_t)1 << 31), NNHIP_EINVAL, "maxpool2d: bad geometry");
     Ho = (int)ho; Wo = (int)wo;
     return 0;
@@ -465,7 +470,7 @@ static int maxpool_forward(const char* fn, float* out, int32_t* argmax, const fl
     NNHIP_CHECK_ARG(out && argmax && X, NNHIP_EINVAL, "%s: null pointer", fn);
     hipLaunchKernelGGL(maxpool_fwd_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)s, out, argmax, X,
                        d->B * d->C, (int)d->H, (int)d->W, Ho, Wo, (int)d->kh, (int)d->kw, (int)d->sh, (int)d->sw,
-                       (int)d->pu, (int)d->pl, pre_alpha);
+                       (int)d->pu, (int)d->pl, (int)pool_dil(d->dh), (int)pool_dil(d->dw), pre_alpha);
     NNHIP_LAUNCH_CHECK("maxpool_fwd_kernel");
     return 0;
 }
@@ -477,7 +482,7 @@ static int maxpool_backward(const char* fn, float* dX, const float* dY, const in
     if (total == 0) return 0;
     NNHIP_CHECK_ARG(dX && dY && argmax, NNHIP_EINVAL, "%s: null pointer", fn);
     if (d->kh == d->sh && d->kw == d->sw && d->pu + d->pd + d->pl + d->pr == 0 && d->H == (int64_t)Ho * d->kh &&
-        d->W == (int64_t)Wo * d->kw) {
+        d->W == (int64_t)Wo * d->kw && pool_dil(d->dh) == 1 && pool_dil(d->dw) == 1) {
         const int64_t nout = d->B * d->C * Ho * Wo;
         const bool two = d->kw == 2 && (d->W & 1) == 0 && (reinterpret_cast<uintptr_t>(dX) & 7u) == 0;
         if (two)
@@ -491,7 +496,7 @@ static int maxpool_backward(const char* fn, float* dX, const float* dY, const in
     }
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, (hipStream_t)s, dX, dY, argmax,
                        d->B * d->C, (int)d->H, (int)d->W, Ho, Wo, (int)d->kh, (int)d->kw, (int)d->sh, (int)d->sw,
-                       (int)d->pu, (int)d->pl, pooled, alpha);
+                       (int)d->pu, (int)d->pl, (int)pool_dil(d->dh), (int)pool_dil(d->dw), pooled, alpha);
     NNHIP_LAUNCH_CHECK("maxpool_bwd_kernel");
     return 0;
 }

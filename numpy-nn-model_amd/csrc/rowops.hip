@@ -18,6 +18,8 @@
 
 namespace nnhip {
 
+int fill_f32(float* p, float v, int64_t n, hipStream_t st);   // elementwise.hip
+
 // ---- row register tile -------------------------------------------------------------------------
 // Thread t of a row (0 <= t < TPR) owns elements  c = 4*(t + TPR*v) + {0..3}, v < NV   (VEC), or
 // c = t + TPR*e, e < 4*NV (scalar path for rows that are not 16-B aligned / cols % 4 != 0).
@@ -1468,9 +1470,11 @@ extern "C" int nnhipCrossEntropyLossEx(float* logits, float* dlogits_or_null, fl
     if (n_rows == 0 || n_cols == 0) {
         // sum over nothing = 0; mean over nothing = 0/0 (NumPy gives nan): fill without reading anything
         if (loss_out_or_null) {
+            // a fill kernel, not hipMemcpyAsync from this stack frame: the latter is not capturable into a hipGraph (the
+            // node would keep a dangling host pointer)
             const float v = reduction == 'm' ? __builtin_nanf("") : 0.f;
-            hipError_t e = hipMemcpyAsync(loss_out_or_null, &v, sizeof(float), hipMemcpyHostToDevice, (hipStream_t)s);
-            if (e != hipSuccess) return hip_status(e, "nnhipCrossEntropyLossEx(empty)");
+            const int rc = fill_f32(loss_out_or_null, v, 1, (hipStream_t)s);
+            if (rc) return rc;
         }
         return 0;
     }

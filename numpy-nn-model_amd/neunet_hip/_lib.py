@@ -36,7 +36,7 @@ class AttentionOptions(ctypes.Structure):
 
 class Pool2dDesc(ctypes.Structure):
     """struct nnhipPool2dDesc (include/neunet_hip.h)."""
-    _fields_ = [(n, c_int64) for n in ("B", "C", "H", "W", "kh", "kw", "sh", "sw", "pu", "pd", "pl", "pr")]
+    _fields_ = [(n, c_int64) for n in ("B", "C", "H", "W", "kh", "kw", "sh", "sw", "pu", "pd", "pl", "pr", "dh", "dw")]
 
 
 P = c_void_p  # device pointers travel as void*
@@ -47,6 +47,7 @@ _SIGNATURES = {
     "nnhipCleanup": (ctypes.c_int, []),
     "nnhipSetGemmMode": (ctypes.c_int, [ctypes.c_int]),
     "nnhipGetGemmMode": (ctypes.c_int, []),
+    "nnhipGemmLaunchCount": (c_int64, [ctypes.c_int]),
     "nnhipWorkspaceReserve": (ctypes.c_int, [c_int64]),
     "nnhipWorkspaceLock": (ctypes.c_int, [ctypes.c_int]),
     "nnhipLinearModuleForward": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_void_p]),
@@ -77,6 +78,7 @@ _SIGNATURES = {
     "nnhipAttentionDropoutMask": (ctypes.c_int, [P, c_int64, c_int64, c_int64, c_int64, c_float, ctypes.c_uint32, c_void_p]),
     "nnhipEmbeddingForward": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, c_void_p]),
     "nnhipEmbeddingBackward": (ctypes.c_int, [P, P, P, c_int64, c_int64, c_int64, c_float, c_void_p]),
+    "nnhipNotEqualInt32": (ctypes.c_int, [P, P, c_int64, ctypes.c_int32, c_void_p]),
     "nnhipMul": (ctypes.c_int, [P, P, P, c_int64, c_void_p]),
     "nnhipReLUForward": (ctypes.c_int, [P, P, c_int64, c_void_p]),
     "nnhipReLUBackward": (ctypes.c_int, [P, P, P, c_int64, c_void_p]),
@@ -123,7 +125,7 @@ _SIGNATURES = {
     "nnhipScale": (ctypes.c_int, [P, c_float, c_int64, c_void_p]),
     "nnhipAdd": (ctypes.c_int, [P, P, P, c_int64, c_void_p]),
 }
-_NO_STATUS = {"nnhipVersion", "nnhipGetLastErrorString", "nnhipCreateFusedOptimizer", "nnhipGetGemmMode"}
+_NO_STATUS = {"nnhipVersion", "nnhipGetLastErrorString", "nnhipCreateFusedOptimizer", "nnhipGetGemmMode", "nnhipGemmLaunchCount"}
 
 _dll = None
 _funcs: dict = {}

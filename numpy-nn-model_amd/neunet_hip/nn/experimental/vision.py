@@ -142,7 +142,7 @@ class _HIPMaxPool2dTensor(Tensor):
 
 
 class HIPMaxPool2d(Module):
-    """neunet/nn/layers/maxpool2d.py:85-249 (dilation 1 only)."""
+    """neunet/nn/layers/maxpool2d.py:85-249, dilation included (taps at r*dh, s*dw; :170-186)."""
 
     def __init__(self, kernel_size, stride=None, padding=0, dilation=1):
         super().__init__()
@@ -150,8 +150,9 @@ class HIPMaxPool2d(Module):
         self.stride = _pair(stride) if stride else self.kernel_size
         p = _pair(padding)
         self.padding = (p[0], p[0], p[1], p[1]) if len(p) == 2 else tuple(p)
-        if _pair(dilation) != (1, 1):
-            raise NotImplementedError("HIPMaxPool2d supports dilation 1 only")
+        self.dilation = _pair(dilation)
+        if min(self.dilation) < 1:
+            raise ValueError("dilation must be >= 1")
 
     def forward(self, X: Tensor) -> Tensor:
         import torch
@@ -164,9 +165,10 @@ class HIPMaxPool2d(Module):
         kh, kw = self.kernel_size
         sh, sw = self.stride
         pu, pd, pl, pr = self.padding
-        Ho = (H + pu + pd - (kh - 1) - 1) // sh + 1      # maxpool2d.py:170-183
-        Wo = (W + pl + pr - (kw - 1) - 1) // sw + 1
-        desc = Pool2dDesc(B, C, H, W, kh, kw, sh, sw, pu, pd, pl, pr)
+        dh, dw = self.dilation
+        Ho = (H + pu + pd - dh * (kh - 1) - 1) // sh + 1      # maxpool2d.py:170-183
+        Wo = (W + pl + pr - dw * (kw - 1) - 1) // sw + 1
+        desc = Pool2dDesc(B, C, H, W, kh, kw, sh, sw, pu, pd, pl, pr, dh, dw)
         O = X.xp.empty((B, C, Ho, Wo), dtype=np.float32)
         argmax = torch.empty((B, C, Ho, Wo), dtype=torch.int32, device=O.device)
         if isinstance(X, _HIPLeakyReLUTensor) and X.pending():

@@ -38,6 +38,61 @@ def T(hip, a, **kw):
 
 TOL = dict(rtol=1e-4, atol=1e-4)
 
+# ---- error bounds that mean something ------------------------------------------------------------------------------
+# north_star: "within 1e-4 fp32".  rtol = atol = 1e-4 (TOL) is that statement for tensors whose entries are O(1).  Two
+# kinds of tensor need it restated rather than loosened (round-2 review: every atol above 1e-4 was unexplained):
+#   * a dot product of K terms carries an fp32 rounding error proportional to sum_k |a_k||b_k| whatever its own value is
+#     (cancellation): assert_dot_close() bounds |got - float64| by c * 2^-24 * sum|a||b| per element.  Measured on this
+#     kernel (tools/gemm_accuracy.py, profiles/r02c_gemm_accuracy.txt): max 6.3 units for K up to 4096, uniform / normal
+#     operands, in either GEMM mode; c = 32 leaves 5x head-room and is ~K/100 times tighter than the worst-case K * 2^-24;
+#   * a gradient tensor whose entries span orders of magnitude (dW = sum over thousands of rows): assert_close_scaled()
+#     holds every entry to 1e-4 of max(|its reference value|, the tensor's rms) -- pure 1e-4 relative for the entries that
+#     matter, 1e-4 of the typical magnitude for the near-zero ones.
+U24 = 2.0 ** -24
+
+
+def dot_bound(A, B, c=32.0):
+    """c * 2^-24 * (|A| @ |B|), elementwise; A (m, k), B (k, n)."""
+    return c * U24 * (np.abs(np.asarray(A, np.float64)) @ np.abs(np.asarray(B, np.float64)))
+
+
+def assert_within(got, ref, bound, err_msg=""):
+    err = np.abs(np.asarray(got, np.float64) - np.asarray(ref, np.float64))
+    bound = np.broadcast_to(np.asarray(bound, np.float64), err.shape)
+    if np.any(err > bound) or not np.all(np.isfinite(err)):
+        ratio = err / np.maximum(bound, 1e-300)
+        i = np.unravel_index(np.nanargmax(ratio), ratio.shape)
+        raise AssertionError(f"{err_msg}: error {err[i]:.3e} is {ratio[i]:.2f} x the bound {bound[i]:.3e} at {i} "
+                             f"({int(np.sum(err > bound))} of {err.size} entries over)")
+
+
+def assert_dot_close(got, A, B, c=32.0, plus=None, err_msg=""):
+    """got ~= A @ B (+ plus), against float64, within c * 2^-24 * sum|a||b| per element."""
+    ref = np.asarray(A, np.float64) @ np.asarray(B, np.float64)
+    if plus is not None:
+        ref = ref + plus
+    assert_within(got, ref, dot_bound(A, B, c) + 4 * U24 * np.abs(ref), err_msg)
+
+
+def rms_of(a):
+    a = np.asarray(a, np.float64)
+    return float(np.sqrt(np.mean(a ** 2))) if a.size else 0.0
+
+
+def assert_close_scaled(got, ref, tol=1e-4, err_msg="", scale=0.0):
+    """|got - ref| <= tol * max(|ref|, rms(ref), scale) per element.  `scale`: the magnitude the tensor WOULD have if its
+    terms did not cancel, for tensors that are mathematically zero -- e.g. the bias gradient of attention's key projection
+    (softmax is shift-invariant, so d/db_k is exactly 0 and both sides hold rounding noise of a sum over all rows); callers
+    pass the natural scale of that sum (for a Linear fed unit-variance inputs: the rms of its weight gradient)."""
+    ref = np.asarray(ref, np.float64)
+    assert_within(got, ref, tol * np.maximum(np.maximum(np.abs(ref), rms_of(ref)), scale) + 1e-30, err_msg)
+
+
+def grad_list_scale(refs):
+    """Median rms of a model's gradient tensors: the `scale` for the mathematically-zero ones among them."""
+    r = [rms_of(a) for a in refs if a is not None and np.size(a)]
+    return float(np.median(r)) if r else 0.0
+
 
 # ------------------------------------------------------------------------------------------- Linear
 @pytest.mark.parametrize("name", ["linear_2d", "linear_3d", "linear_nobias"])
@@ -85,9 +140,9 @@ def test_linear_vs_oracle(hip, rows, inf, outf, bias):
     out.backward(dO)
     dX, dW, db = O.linear_backward(X, W, b, dO)
     np.testing.assert_allclose(host(x.grad), dX, **TOL)
-    np.testing.assert_allclose(host(layer.weight.grad), dW, rtol=1e-4, atol=2e-4)
+    assert_close_scaled(host(layer.weight.grad), dW)
     if bias:
-        np.testing.assert_allclose(host(layer.bias.grad), db, rtol=1e-4, atol=2e-4)
+        assert_close_scaled(host(layer.bias.grad), db)
 
 
 @pytest.mark.parametrize("rows,inf,outf", [
@@ -114,12 +169,12 @@ def test_gemm_fast_fetch_edges(hip, rows, inf, outf):
     X64, W64, dO64 = X.astype(np.float64), W.astype(np.float64), dO.astype(np.float64)
     o = torch.empty((rows, outf), device="cuda")
     call("nnhipLinearModuleForward", x, w, bb, o, rows, inf, outf, st)
-    np.testing.assert_allclose(host(o), X64 @ W64.T + b, rtol=1e-4, atol=1e-4 * np.sqrt(inf))
+    assert_dot_close(host(o), X64, W64.T, plus=b, err_msg="forward")
     dx, dw, db = torch.empty((rows, inf), device="cuda"), torch.empty((outf, inf), device="cuda"), torch.empty((1, outf), device="cuda")
     call("nnhipLinearModuleBackward", x, w, do, dx, dw, db, rows, inf, outf, st)
-    np.testing.assert_allclose(host(dx), dO64 @ W64, rtol=1e-4, atol=1e-4 * np.sqrt(outf))
-    np.testing.assert_allclose(host(dw), dO64.T @ X64, rtol=1e-4, atol=1e-4 * np.sqrt(rows))
-    np.testing.assert_allclose(host(db), dO64.sum(0, keepdims=True), rtol=1e-4, atol=1e-4 * np.sqrt(rows))
+    assert_dot_close(host(dx), dO64, W64, err_msg="dX")
+    assert_dot_close(host(dw), dO64.T, X64, err_msg="dW")
+    assert_dot_close(host(db), np.ones((1, rows)), dO64, err_msg="db")
 
 
 @pytest.mark.parametrize("rows,inf,outf", [(8192, 64, 1100), (8192, 512, 1100), (16384, 96, 520), (4096, 992, 2200)])
@@ -140,7 +195,7 @@ def test_gemm_persistent_forward(hip, rows, inf, outf):
     o = torch.full((rows, outf), float("nan"), device="cuda")
     call("nnhipLinearModuleForward", x, w, bb, o, rows, inf, outf, st)
     got = host(o)
-    np.testing.assert_allclose(got, X.astype(np.float64) @ W.astype(np.float64).T + b, rtol=1e-4, atol=1e-4 * np.sqrt(inf))
+    assert_dot_close(got, X, W.T, plus=b)
     tiles_n = -(-outf // 128)
     chunk = max(128, (400 // tiles_n) * 128)                   # <= 400 tiles per call: the classic kernel
     o2 = torch.full((rows, outf), float("nan"), device="cuda")
@@ -168,9 +223,11 @@ def test_gemm_persistent_swish(hip, rows, inf, outf, beta, save):
     z = torch.full((rows, outf), float("nan"), device="cuda")
     call("nnhipLinearSwishForward", x, w, bb, o, z if save else None, rows, inf, outf, beta, save, st)
     z64 = X.astype(np.float64) @ W.astype(np.float64).T + b
-    np.testing.assert_allclose(host(o), z64 / (1.0 + np.exp(-beta * z64)), rtol=1e-4, atol=1e-4 * np.sqrt(inf))
+    sig = 1.0 / (1.0 + np.exp(-beta * z64))
+    zb = dot_bound(X, W.T) + 4 * U24 * np.abs(z64)             # bound on z; swish'(z) carries it into the output
+    assert_within(host(o), z64 * sig, zb * (np.abs(sig) + np.abs(beta * z64 * sig * (1 - sig))) + 16 * U24 * np.abs(z64 * sig), "swish(z)")
     if save:
-        np.testing.assert_allclose(host(z), z64, rtol=1e-4, atol=1e-4 * np.sqrt(inf))
+        assert_within(host(z), z64, zb, "z")
     else:
         assert bool(torch.isnan(z).all())                      # nothing may be written without save_preactivation
     tiles_n = -(-outf // 128)
@@ -208,7 +265,7 @@ def test_gemm_persistent_input_grad(hip, rows, inf, outf, inplace):
     # plain dX
     dx = torch.full((rows, inf), float("nan"), device="cuda")
     call("nnhipLinearModuleBackward", x, w, g, dx, None, None, rows, inf, outf, st)
-    np.testing.assert_allclose(host(dx), dx64, rtol=1e-4, atol=1e-4 * np.sqrt(outf))
+    assert_dot_close(host(dx), dO, W, err_msg="dX")
     dx2 = torch.empty_like(dx)
     for r0 in range(0, rows, chunk):
         n = min(chunk, rows - r0)
@@ -220,7 +277,9 @@ def test_gemm_persistent_input_grad(hip, rows, inf, outf, inplace):
     call("nnhipLinearInputGradSwish", g, w, dz if inplace else z, dz, rows, inf, outf, beta, st)
     s64 = 1.0 / (1.0 + np.exp(-beta * Z.astype(np.float64)))
     f64 = Z * s64
-    np.testing.assert_allclose(host(dz), dx64 * (beta * f64 + s64 * (1 - beta * f64)), rtol=1e-4, atol=2e-4 * np.sqrt(outf))
+    sp64 = beta * f64 + s64 * (1 - beta * f64)          # swish'(z): v_exp / v_rcp in the epilogue, a few ulp of its own
+    spmag = np.abs(beta * f64) + s64 * (1 + np.abs(beta * f64))   # magnitude of swish's terms: they cancel where swish' ~ 0
+    assert_within(host(dz), dx64 * sp64, dot_bound(dO, W) * np.abs(sp64) + 16 * U24 * np.abs(dx64) * spmag, "dX * swish'")
     dz2 = z.clone()
     for r0 in range(0, rows, chunk):
         n = min(chunk, rows - r0)
@@ -257,9 +316,13 @@ def test_linear_backward_act(hip, rows, inf, outf, kind):
         want = dx64 * (beta * f64 + s64 * (1 - beta * f64))
     else:
         want = dx64 * (A > 0)
-    np.testing.assert_allclose(host(dz), want, rtol=1e-4, atol=2e-4 * np.sqrt(outf))
-    np.testing.assert_allclose(host(dw), dO.astype(np.float64).T @ X.astype(np.float64), rtol=1e-4, atol=2e-4 * np.sqrt(rows))
-    np.testing.assert_allclose(host(db), dO.astype(np.float64).sum(0), rtol=1e-4, atol=2e-4 * np.sqrt(rows))
+    if kind == 1:
+        fac, facmag = np.abs(beta * f64 + s64 * (1 - beta * f64)), np.abs(beta * f64) + s64 * (1 + np.abs(beta * f64))
+    else:
+        fac = facmag = (A > 0).astype(np.float64)
+    assert_within(host(dz), want, dot_bound(dO, W) * fac + 16 * U24 * np.abs(dx64) * facmag, "dZ")
+    assert_dot_close(host(dw), dO.T, X, err_msg="dW")
+    assert_dot_close(host(db).reshape(1, -1), np.ones((1, rows)), dO, err_msg="db")
     dz2 = a.clone() if kind == 1 else torch.empty_like(dz)
     dw2, db2 = torch.empty_like(dw), torch.empty_like(db)
     if kind == 1:
@@ -293,10 +356,10 @@ def test_linear_addend_extensions(hip, rows, inf, outf):
     np.testing.assert_allclose(host(y.data), O.linear_forward(X, W, b) + R, **TOL)
     y.backward(dY)
     dX, dW, db = O.linear_backward(X, W, b, dY)
-    np.testing.assert_allclose(host(x.grad), dX + G, rtol=1e-4, atol=2e-4)
+    assert_close_scaled(host(x.grad), dX + G)
     np.testing.assert_allclose(host(r.grad), dY, rtol=0, atol=0)
-    np.testing.assert_allclose(host(lin.weight.grad), dW, rtol=1e-4, atol=1e-3)
-    np.testing.assert_allclose(host(lin.bias.grad), db.reshape(1, -1), rtol=1e-4, atol=1e-3)
+    assert_close_scaled(host(lin.weight.grad), dW)
+    assert_close_scaled(host(lin.bias.grad), db.reshape(1, -1))
 
 
 def test_linear_entry_points_fuzz(hip):
@@ -327,28 +390,30 @@ def test_linear_entry_points_fuzz(hip):
         o = torch.empty((rows, outf), device="cuda")
         call("nnhipLinearModuleForward", x, w, bb, o, rows, inf, outf, st)
         ref = X64 @ W64.T + b
-        np.testing.assert_allclose(host(o), ref, rtol=1e-4, atol=1e-4 * np.sqrt(inf), err_msg=tag + " fwd")
+        assert_within(host(o), ref, dot_bound(X, W.T) + 4 * U24 * np.abs(ref), tag + " fwd")
         call("nnhipLinearModuleForwardEx", x, w, None, r, o, rows, inf, outf, st)
-        np.testing.assert_allclose(host(o), ref - b + R, rtol=1e-4, atol=1e-4 * np.sqrt(inf), err_msg=tag + " fwd+addend")
+        assert_within(host(o), ref - b + R, dot_bound(X, W.T) + 4 * U24 * (np.abs(ref) + np.abs(R)), tag + " fwd+addend")
         # backward: everything, then dX with an addend, then db alone (column-sum pass)
         dx, dw, db = torch.empty((rows, inf), device="cuda"), torch.empty((outf, inf), device="cuda"), torch.empty((1, outf), device="cuda")
         call("nnhipLinearModuleBackward", x, w, do, dx, dw, db, rows, inf, outf, st)
         dXr, dWr, dbr = dO64 @ W64, dO64.T @ X64, dO64.sum(0, keepdims=True)
-        np.testing.assert_allclose(host(dx), dXr, rtol=1e-4, atol=1e-4 * np.sqrt(outf), err_msg=tag + " dX")
-        np.testing.assert_allclose(host(dw), dWr, rtol=1e-4, atol=2e-5 * rows ** 0.5 * 4, err_msg=tag + " dW")
-        np.testing.assert_allclose(host(db), dbr, rtol=1e-4, atol=2e-5 * rows ** 0.5 * 4, err_msg=tag + " db")
+        assert_within(host(dx), dXr, dot_bound(dO, W) + 4 * U24 * np.abs(dXr), tag + " dX")
+        assert_dot_close(host(dw), dO.T, X, err_msg=tag + " dW")
+        assert_dot_close(host(db), np.ones((1, rows)), dO, err_msg=tag + " db")
         call("nnhipLinearModuleBackwardEx", x, w, do, gg, dx, None, None, rows, inf, outf, st)
-        np.testing.assert_allclose(host(dx), dXr + G, rtol=1e-4, atol=1e-4 * np.sqrt(outf), err_msg=tag + " dX+addend")
+        assert_within(host(dx), dXr + G, dot_bound(dO, W) + 4 * U24 * (np.abs(dXr) + np.abs(G)), tag + " dX+addend")
         db.zero_()
         call("nnhipLinearModuleBackward", x, w, do, None, None, db, rows, inf, outf, st)
-        np.testing.assert_allclose(host(db), dbr, rtol=1e-4, atol=2e-5 * rows ** 0.5 * 4, err_msg=tag + " db alone")
+        assert_dot_close(host(db), np.ones((1, rows)), dO, err_msg=tag + " db alone")
         # Swish backward folded into dX, in place over z
         beta = 1.3
         sg = 1.0 / (1.0 + np.exp(-beta * Z.astype(np.float64)))
         f = Z * sg
         dzr = dXr * (beta * f + sg * (1 - beta * f))
         call("nnhipLinearInputGradSwish", do, w, zz, zz, rows, inf, outf, beta, st)
-        np.testing.assert_allclose(host(zz), dzr, rtol=2e-4, atol=2e-4 * np.sqrt(outf), err_msg=tag + " dX*swish'")
+        sp = beta * f + sg * (1 - beta * f)
+        spmag = np.abs(beta * f) + sg * (1 + np.abs(beta * f))
+        assert_within(host(zz), dzr, dot_bound(dO, W) * np.abs(sp) + 16 * U24 * np.abs(dXr) * spmag, tag + " dX*swish'")
 
 
 @pytest.mark.parametrize("rows,dm,dff,beta", [(200, 64, 256, 1.0), (16384, 128, 128, 1.0), (50, 30, 70, 1.7)])
@@ -378,11 +443,11 @@ def test_ffn_swish_backward_folded_into_dx(hip, rows, dm, dff, beta):
             (y + y2).backward(dY * 0.5)
         else:
             y.backward(dY)
-        np.testing.assert_allclose(host(x.grad), dX, rtol=1e-4, atol=2e-4)
-        np.testing.assert_allclose(host(fc1.weight.grad), dW1, rtol=1e-4, atol=2e-3)
-        np.testing.assert_allclose(host(fc1.bias.grad), db1.reshape(1, -1), rtol=1e-4, atol=2e-3)
-        np.testing.assert_allclose(host(fc2.weight.grad), dW2, rtol=1e-4, atol=2e-3)
-        np.testing.assert_allclose(host(fc2.bias.grad), db2.reshape(1, -1), rtol=1e-4, atol=2e-3)
+        assert_close_scaled(host(x.grad), dX)
+        assert_close_scaled(host(fc1.weight.grad), dW1)
+        assert_close_scaled(host(fc1.bias.grad), db1.reshape(1, -1))
+        assert_close_scaled(host(fc2.weight.grad), dW2)
+        assert_close_scaled(host(fc2.bias.grad), db2.reshape(1, -1))
 
 
 @pytest.mark.parametrize("rows,cols", [(64, 512), (33, 100), (16, 4096), (8, 12000)])
@@ -401,7 +466,7 @@ def test_rmsnorm_backward_addend(hip, rows, cols):
     y.backward(dY)
     dX, dw, _ = O.rmsnorm_backward(X, w, False, dY, 1e-6)
     np.testing.assert_allclose(host(x.grad), dX + G, rtol=1e-4, atol=1e-4)
-    np.testing.assert_allclose(host(norm.weight.grad), dw, rtol=1e-4, atol=1e-3)
+    assert_close_scaled(host(norm.weight.grad), dw)
 
 
 def test_deferred_linear_output_read_late(hip):
@@ -505,8 +570,8 @@ def test_relu_backward_folded_into_next_linear(hip):
     x = T(hip, X)
     hidden = relu(l1(x))
     (l2(hidden) + l2(hidden)).backward(dY)
-    np.testing.assert_allclose(host(x.grad), 2 * dX, rtol=1e-4, atol=2e-4)
-    np.testing.assert_allclose(host(l2.weight.grad), 2 * dW2, rtol=1e-4, atol=2e-4)
+    assert_close_scaled(host(x.grad), 2 * dX)
+    assert_close_scaled(host(l2.weight.grad), 2 * dW2)
 
 
 # ------------------------------------------------------------------------------ split-bf16 GEMM mode (opt-in)
@@ -574,10 +639,36 @@ def test_bf16x3_split_is_exact_on_hard_inputs(hip, bf16x3):
     assert float(np.abs(host(c2) - ref).max() / ref.max()) < 2.0 ** -21
 
 
+def _bf3_launches():
+    from neunet_hip._lib import call_hip_function
+    return int(call_hip_function("nnhipGemmLaunchCount", 3))
+
+
 def test_bf16x3_gpt_tiny_step_golden(hip, golden, bf16x3):
-    """The notebook's GPT step golden (reference logits, loss, every gradient) with all large GEMMs in split-bf16 mode:
-    same tolerances as the exact-fp32 run."""
+    """The notebook's GPT step golden (reference logits, loss, every gradient) in split-bf16 mode, same tolerances as the
+    exact-fp32 run.  NOTE what this does and does not exercise: the golden model is d32 / vocab 50, so most of its GEMMs are
+    routed to gemm_small (exact in either mode); the launch counter says how many reached gemm_bf3_kernel -- the
+    full-size evidence for that kernel is test_bf16x3_linear_c2_full_size / test_bf16x3_gpt_c4_full_size below."""
+    n0 = _bf3_launches()
     test_gpt_tiny_step_golden(hip, golden, True)
+    print(f"gemm_bf3_kernel launches during the d32 golden step: {_bf3_launches() - n0}")
+
+
+def test_bf16x3_linear_c2_full_size(hip, bf16x3):
+    """BASELINE C2 (4096^3) forward / dX / dW / db and linearity with every GEMM on gemm_bf3_kernel (asserted through the
+    launch counter): the same float64 row samples and tolerances as the exact-fp32 run."""
+    n0 = _bf3_launches()
+    test_linear_c2_full_size_properties(hip)
+    assert _bf3_launches() - n0 >= 5, "the C2 GEMMs did not run on gemm_bf3_kernel"
+
+
+def test_bf16x3_gpt_c4_full_size(hip, bf16x3):
+    """BASELINE C4 at full size (16384 x 15000 logits) in split-bf16 mode: every check of the exact-fp32 run (sampled rows
+    against float64 dot products, losses, gradient rows, fused == unfused attention, Adam) at the same tolerances, with
+    the Linear GEMMs on gemm_bf3_kernel (>= 6 layers x 6 + the head's 3 launches, asserted)."""
+    n0 = _bf3_launches()
+    test_gpt_c4_full_size_properties(hip)
+    assert _bf3_launches() - n0 >= 6 * 6 + 3, "the C4 Linear GEMMs did not run on gemm_bf3_kernel"
 
 
 def test_bf16x3_gemm_batched_all_layouts(hip, bf16x3):
@@ -612,8 +703,8 @@ def test_linear_3d_input_flattens(hip):
     out.backward(dO)
     dX, dW, db = O.linear_backward(X, W, b, dO)
     np.testing.assert_allclose(host(x.grad), dX, **TOL)
-    np.testing.assert_allclose(host(layer.weight.grad), dW, rtol=1e-4, atol=2e-4)
-    np.testing.assert_allclose(host(layer.bias.grad), db, rtol=1e-4, atol=2e-4)
+    assert_close_scaled(host(layer.weight.grad), dW)
+    assert_close_scaled(host(layer.bias.grad), db)
 
 
 def test_gemm_batched_all_layouts(hip):
@@ -657,8 +748,8 @@ def test_linear_swish_vs_oracle(hip, rows, inf, outf, beta, save):
     y.backward(dY)
     dX, dW, db = O.linear_swish_backward(X, W, b, dY, beta)
     np.testing.assert_allclose(host(x.grad), dX, **TOL)
-    np.testing.assert_allclose(host(layer.weight.grad), dW, rtol=1e-4, atol=2e-4)
-    np.testing.assert_allclose(host(layer.bias.grad), db, rtol=1e-4, atol=2e-4)
+    assert_close_scaled(host(layer.weight.grad), dW)
+    assert_close_scaled(host(layer.bias.grad), db)
 
 
 def test_linear_swish_golden(hip, golden):
@@ -803,7 +894,7 @@ def test_softmax_vs_oracle(hip, shape, axis):
     yr = O.softmax_forward(X, axis)
     np.testing.assert_allclose(host(y.data), yr, rtol=1e-5, atol=1e-6)
     y.backward(dY)
-    np.testing.assert_allclose(host(x.grad), O.softmax_backward(yr, dY, axis), rtol=1e-4, atol=1e-6)
+    assert_close_scaled(host(x.grad), O.softmax_backward(yr, dY, axis))
 
 
 # ---------------------------------------------------------------------------------------- RMSNorm
@@ -849,9 +940,9 @@ def test_rmsnorm_vs_oracle(hip, shape, bias):
     dX, dw, db = O.rmsnorm_backward(X, w, bias, dY, 1e-6)
     np.testing.assert_allclose(host(x.grad), dX, **TOL)
     rows = int(np.prod(shape[:-1]))
-    np.testing.assert_allclose(host(layer.weight.grad), dw, rtol=1e-4, atol=1e-4 * max(1.0, np.sqrt(rows)))
+    assert_close_scaled(host(layer.weight.grad), dw)           # column sums over `rows` terms of either sign
     if bias:
-        np.testing.assert_allclose(host(layer.bias.grad), db, rtol=1e-4, atol=1e-4 * max(1.0, np.sqrt(rows)))
+        assert_close_scaled(host(layer.bias.grad), db)
 
 
 # ------------------------------------------------------------------------------------ CrossEntropy
@@ -885,7 +976,7 @@ def test_cross_entropy_vs_oracle(hip, rows, C, reduction):
     lr, dl = O.cross_entropy_forward_backward(logits, labels, None, 0, reduction)
     np.testing.assert_allclose(host(loss.data), lr, rtol=1e-5, atol=1e-5)
     loss.backward()
-    np.testing.assert_allclose(host(x.grad), dl, rtol=1e-4, atol=1e-6)
+    assert_close_scaled(host(x.grad), dl)
     assert np.all(host(x.grad)[labels == 0] == 0)
 
 
@@ -910,7 +1001,7 @@ def test_cross_entropy_class_weights_and_label_dtypes(hip, rows, C, reduction, l
         lr, dl = O.cross_entropy_forward_backward(logits, labels, weight, 0, reduction)
         np.testing.assert_allclose(host(loss.data), lr, rtol=1e-5, atol=1e-5)
         loss.backward()
-        np.testing.assert_allclose(host(x.grad), dl, rtol=1e-4, atol=1e-6)
+        assert_close_scaled(host(x.grad), dl)
         assert np.all(host(x.grad)[labels == 0] == 0)
 
 
@@ -953,7 +1044,7 @@ def test_cross_entropy_out_of_range_label_is_inert(hip, rows, C, inplace):
         lr, dl = O.cross_entropy_forward_backward(logits[good], labels[good], None, -100, "sum")
         denom = (rows - 1) if reduction == "mean" else 1       # out-of-range labels still count in the 'mean' denominator
         np.testing.assert_allclose(loss.item(), float(lr) / denom, rtol=1e-5, atol=1e-5)
-        np.testing.assert_allclose(g[good], dl / denom, rtol=1e-4, atol=1e-6)
+        assert_close_scaled(g[good], dl / denom)
 
 
 def test_cross_entropy_tall_narrow_takes_the_two_launch_path(hip):
@@ -1111,7 +1202,7 @@ def test_fused_adamw_vs_oracle(hip, shapes, wd):
                                                       (0.9, 0.999), 1e-8, wd)
             opt.step()
             for i, p in enumerate(params):
-                np.testing.assert_allclose(host(p.data), ref_p[i], rtol=1e-4, atol=1e-6)
+                assert_close_scaled(host(p.data), ref_p[i])
 
 
 # ---------------------------------------------------------------------------- C1 end-to-end trajectory
@@ -1146,10 +1237,10 @@ def test_mlp_c1_trajectory_golden(hip, golden):
         loss.backward()
         if s == 0:
             ps = model.parameters()
-            np.testing.assert_allclose(host(ps[0].grad)[::8], g["dW1_step0_rows"], rtol=1e-4, atol=1e-6)
-            np.testing.assert_allclose(host(ps[1].grad), g["db1_step0"], rtol=1e-4, atol=1e-6)
-            np.testing.assert_allclose(host(ps[2].grad), g["dW2_step0"], rtol=1e-4, atol=1e-6)
-            np.testing.assert_allclose(host(ps[3].grad), g["db2_step0"], rtol=1e-4, atol=1e-6)
+            assert_close_scaled(host(ps[0].grad)[::8], g["dW1_step0_rows"])
+            assert_close_scaled(host(ps[1].grad), g["db1_step0"])
+            assert_close_scaled(host(ps[2].grad), g["dW2_step0"])
+            assert_close_scaled(host(ps[3].grad), g["db2_step0"])
         opt.step()
         assert abs(loss.item() - g["losses"][s]) < 1e-4
         np.testing.assert_array_equal(host(hip.argmax(out, axis=1).data), g["argmax"][s])
@@ -1179,12 +1270,12 @@ def test_linear_c2_full_size_properties(hip):
     out.backward(dO)
     dX, dW, db = host(x.grad), host(layer.weight.grad), host(layer.bias.grad)
     np.testing.assert_allclose(dX[rows], dO[rows].astype(np.float64) @ W.astype(np.float64), rtol=1e-4, atol=1e-4)
-    np.testing.assert_allclose(dW[rows], dO[:, rows].T.astype(np.float64) @ X.astype(np.float64), rtol=1e-4, atol=2e-3)
-    np.testing.assert_allclose(db[0], dO.astype(np.float64).sum(0), rtol=1e-4, atol=1e-3)
+    assert_close_scaled(dW[rows], dO[:, rows].T.astype(np.float64) @ X.astype(np.float64))
+    assert_close_scaled(db[0], dO.astype(np.float64).sum(0))
     X2 = rng.uniform(-1, 1, (n, n)).astype(np.float32)
     o2 = host(layer(T(hip, X2)).data)
     o12 = host(layer(T(hip, X + X2)).data)
-    np.testing.assert_allclose(o12 - b, (o - b) + (o2 - b), rtol=1e-3, atol=2e-3)
+    assert_close_scaled(o12 - b, (o - b) + (o2 - b))
 
 
 def test_fused_c3_full_size_properties(hip):
@@ -1236,7 +1327,7 @@ def test_fused_c3_full_size_properties(hip):
     yl.backward(dYl)
     sg = 1 / (1 + np.exp(-z64))
     dz64 = dYl[rows].astype(np.float64) * (sg + z64 * sg * (1 - sg))
-    np.testing.assert_allclose(host(x.grad)[rows], dz64 @ W, rtol=1e-3, atol=2e-3)
+    assert_close_scaled(host(x.grad)[rows], dz64 @ W)
     assert bool(torch.isfinite(ls.weight.grad).all())
     del ls, yl, x
 
@@ -1337,15 +1428,15 @@ def test_mha_vs_oracle(hip, B, Tn, D, H):
     yr, ar = ref.forward(X, mask)
     x = T(hip, X)
     y, attn = mha(x, x, x, dev((tok != 0).astype(np.int32)), causal=True)
-    np.testing.assert_allclose(host(attn), ar, rtol=1e-4, atol=1e-6)
+    assert_close_scaled(host(attn), ar)
     np.testing.assert_allclose(host(y.data), yr, **TOL)
     dY = rng.standard_normal(yr.shape).astype(np.float32)
     y.backward(dY)
     dxr, gr = ref.backward(dY)
-    np.testing.assert_allclose(host(x.grad), dxr, rtol=1e-4, atol=2e-4)
+    assert_close_scaled(host(x.grad), dxr)
     for lin, dW, db in zip((mha.wq, mha.wk, mha.wv, mha.fc), gr[0::2], gr[1::2]):
-        np.testing.assert_allclose(host(lin.weight.grad), dW, rtol=1e-4, atol=5e-4)
-        np.testing.assert_allclose(host(lin.bias.grad), db, rtol=1e-4, atol=5e-4)
+        assert_close_scaled(host(lin.weight.grad), dW)
+        assert_close_scaled(host(lin.bias.grad), db, scale=rms_of(dW))
 
 
 @pytest.mark.parametrize("B,Tn,D,H,causal", [(2, 256, 512, 8, True), (3, 100, 256, 4, True), (1, 7, 64, 1, True),
@@ -1374,10 +1465,10 @@ def test_fused_attention_vs_oracle(hip, B, Tn, D, H, causal):
     dY = rng.standard_normal(yr.shape).astype(np.float32)
     y.backward(dY)
     dxr, gr = ref.backward(dY)
-    np.testing.assert_allclose(host(x.grad), dxr, rtol=1e-4, atol=2e-4)
+    assert_close_scaled(host(x.grad), dxr)
     for lin, dW, db in zip((mha.wq, mha.wk, mha.wv, mha.fc), gr[0::2], gr[1::2]):
-        np.testing.assert_allclose(host(lin.weight.grad), dW, rtol=1e-4, atol=5e-4)
-        np.testing.assert_allclose(host(lin.bias.grad), db, rtol=1e-4, atol=5e-4)
+        assert_close_scaled(host(lin.weight.grad), dW)
+        assert_close_scaled(host(lin.bias.grad), db, scale=rms_of(dW))
 
 
 @pytest.mark.parametrize("B,Tn,D,H", [(2, 50, 64, 4), (2, 128, 128, 2)])
@@ -1400,15 +1491,15 @@ def test_mha_attention_dropout(hip, B, Tn, D, H):
     kv = dev((tok != 0).astype(np.int32))
     x = T(hip, X)
     y, attn = mha(x, x, x, kv, causal=True, drop_mask=dev(drop))
-    np.testing.assert_allclose(host(attn), ar, rtol=1e-4, atol=1e-6)
+    assert_close_scaled(host(attn), ar)
     np.testing.assert_allclose(host(y.data), yr, **TOL)
     dY = rng.standard_normal(yr.shape).astype(np.float32)
     y.backward(dY)
     dxr, gr = ref.backward(dY)
-    np.testing.assert_allclose(host(x.grad), dxr, rtol=1e-4, atol=2e-4)
+    assert_close_scaled(host(x.grad), dxr)
     for lin, dW, db in zip((mha.wq, mha.wk, mha.wv, mha.fc), gr[0::2], gr[1::2]):
-        np.testing.assert_allclose(host(lin.weight.grad), dW, rtol=1e-4, atol=5e-4)
-        np.testing.assert_allclose(host(lin.bias.grad), db, rtol=1e-4, atol=5e-4)
+        assert_close_scaled(host(lin.weight.grad), dW)
+        assert_close_scaled(host(lin.bias.grad), db, scale=rms_of(dW))
     # device RNG in training mode; identity in eval mode (fused kernels again when need_weights=False)
     x2 = T(hip, X)
     y_train, a_train = mha(x2, x2, x2, kv, causal=True, need_weights=True)
@@ -1533,19 +1624,19 @@ def test_fused_attention_dense_mask(hip, D, H, Tn):
         assert attn is None
         np.testing.assert_allclose(host(y.data), yr, **TOL)
         y.backward(dY)
-        np.testing.assert_allclose(host(x.grad), dxr, rtol=1e-4, atol=2e-4, err_msg=f"mask {mi}")
+        assert_close_scaled(host(x.grad), dxr, err_msg=f"mask {mi}")
         for lin, dW, db in zip((mha.wq, mha.wk, mha.wv, mha.fc), gr[0::2], gr[1::2]):
-            np.testing.assert_allclose(host(lin.weight.grad), dW, rtol=1e-4, atol=5e-4)
-            np.testing.assert_allclose(host(lin.bias.grad), db, rtol=1e-4, atol=5e-4)
+            assert_close_scaled(host(lin.weight.grad), dW)
+            assert_close_scaled(host(lin.bias.grad), db, scale=rms_of(dW))
         # the GEMM + masked-softmax path (returns the attention map) takes the dense mask too
         for lin in (mha.wq, mha.wk, mha.wv, mha.fc):
             lin.weight.grad = lin.bias.grad = None
         xu = T(hip, X)
         yu, au = mha(xu, xu, xu, need_weights=True, mask=dev(mask))
         np.testing.assert_allclose(host(yu.data), yr, **TOL)
-        np.testing.assert_allclose(host(au), ref.attn, rtol=1e-4, atol=1e-6)
+        assert_close_scaled(host(au), ref.attn)
         yu.backward(dY)
-        np.testing.assert_allclose(host(xu.grad), dxr, rtol=1e-4, atol=2e-4)
+        assert_close_scaled(host(xu.grad), dxr)
         if mi == 0:   # identical to the (key_valid, causal) form of the same mask
             x2 = T(hip, X)
             y2, _ = mha(x2, x2, x2, dev((tok != 0).astype(np.int32)), causal=True, need_weights=False)
@@ -1559,7 +1650,7 @@ def test_fused_attention_dense_mask(hip, D, H, Tn):
     y, _ = mha(x, x, x, need_weights=False, mask=dev(rnd), drop_mask=dev(drop))
     np.testing.assert_allclose(host(y.data), yr, **TOL)
     y.backward(dY)
-    np.testing.assert_allclose(host(x.grad), dxr, rtol=1e-4, atol=2e-4)
+    assert_close_scaled(host(x.grad), dxr)
 
 
 def test_fused_attention_fully_masked_rows(hip):
@@ -1678,7 +1769,7 @@ def test_gpt_step_fused_attention_equals_unfused(hip):
     for i, (a, b) in enumerate(zip(*grads)):
         assert (a is None) == (b is None)
         if a is not None:
-            np.testing.assert_allclose(b, a, rtol=1e-3, atol=2e-6, err_msg=f"grad {i}")
+            assert_close_scaled(b, a, err_msg=f"grad {i}", scale=grad_list_scale(grads[0]))
 
 
 @pytest.mark.parametrize("fused", [False, True])
@@ -1707,9 +1798,10 @@ def test_gpt_tiny_step_golden(hip, golden, fused):
     loss = loss_fn(out2, T(hip, np.ascontiguousarray(batch[:, 1:]).reshape(-1), dtype=np.int32, requires_grad=False))
     assert abs(loss.item() - float(g["loss"])) < 1e-4
     loss.backward()
+    gscale = grad_list_scale([g[f"g{i}"] for i in range(len(params)) if bool(g[f"has_grad{i}"])])
     for i, p in enumerate(params):
         if bool(g[f"has_grad{i}"]):
-            np.testing.assert_allclose(host(p.grad), g[f"g{i}"], rtol=1e-3, atol=2e-6, err_msg=f"grad {i}")
+            assert_close_scaled(host(p.grad), g[f"g{i}"], err_msg=f"grad {i}", scale=gscale)
         else:
             assert p.grad is None, i
     our_grads = [None if p.grad is None else host(p.grad) for p in params]
@@ -1831,7 +1923,7 @@ def test_linear_cross_entropy_fused(hip, rows, inf, classes, reduction):
             want_loss, want_grad = O.cross_entropy_forward_backward(z, Y, None if weight is None else cw, IGN, reduction)
             got_loss = host(f[2]) if reduction == "none" else host(f[4])
             np.testing.assert_allclose(got_loss, want_loss, rtol=1e-4, atol=1e-5)
-            np.testing.assert_allclose(host(f[1]), want_grad, rtol=1e-4, atol=1e-6)
+            assert_close_scaled(host(f[1]), want_grad)
 
     # module level: the tape with and without the fusion
     def tape(fuse):
@@ -2110,7 +2202,7 @@ def test_gpt_c4_full_size_properties(hip):
     m3.load_state_dict(sd)
     out3, _ = m3.forward(ids_np)
     lg3 = host(out3.data.reshape(rows, V)[sel_d])
-    np.testing.assert_allclose(lg3, lg2, rtol=1e-3, atol=1e-3)
+    assert_close_scaled(lg3, lg2)
     assert np.abs(lg3 - first_logits).max() > 0                   # the Adam step did change the weights
     assert np.isfinite(first_loss)
 
@@ -2223,6 +2315,33 @@ def test_vision_ops_golden(hip, golden):
     np.testing.assert_allclose(host(p.grad), g["mse_dP"], rtol=1e-5, atol=1e-7)
 
 
+def test_maxpool_dilated_golden(hip, golden):
+    """MaxPool2d with dilation (the in-row gap of round 2): reference fixtures + an oracle case the reference's own backward
+    cannot run (non-square dilated window, asymmetric padding)."""
+    import neunet_hip.nn as nn
+    g = golden("maxpool_dilated")
+    X = g["X"]
+    for tag in ("k2s1p0d2", "k3s2p2d2", "k2s2p1d3"):
+        ks, st, pad, dil = [int(v) for v in g[f"{tag}_cfg"]]
+        x = T(hip, X)
+        y = nn.MaxPool2d(ks, st, pad, dil)(x)
+        np.testing.assert_array_equal(host(y.data), g[f"{tag}_Y"])
+        y.backward(g[f"{tag}_dY"])
+        np.testing.assert_allclose(host(x.grad), g[f"{tag}_dX"], rtol=1e-6, atol=1e-6)
+    rng = np.random.default_rng(3)
+    X2 = rng.standard_normal((3, 2, 13, 10)).astype(np.float32)
+    x = T(hip, X2)
+    y = nn.MaxPool2d((3, 2), (2, 1), (2, 1), (2, 3))(x)
+    yr, arg = O.maxpool2d_forward(X2, (3, 2), (2, 1), (2, 1), (2, 3))
+    np.testing.assert_array_equal(host(y.data), yr)
+    dY = rng.standard_normal(yr.shape).astype(np.float32)
+    y.backward(dY)
+    np.testing.assert_allclose(host(x.grad), O.maxpool2d_backward(X2.shape, arg, dY, (3, 2), (2, 1), (2, 1), (2, 3)),
+                               rtol=1e-6, atol=1e-6)
+    with pytest.raises(ValueError):
+        nn.MaxPool2d(2, 2, 0, 0)
+
+
 @pytest.mark.parametrize("ks,st,pad,shape", [(2, 2, 0, (3, 4, 12, 12)), (3, 2, 1, (2, 3, 11, 9)), (2, 1, 0, (2, 2, 7, 7)),
                                               (2, 2, 0, (256, 8, 28, 28))])
 def test_leaky_relu_maxpool_fusion(hip, ks, st, pad, shape):
@@ -2295,9 +2414,14 @@ def test_conv_classifier_golden(hip, golden):
         assert abs(loss.item() - g["losses"][s]) < (1e-6 if s == 0 else 2e-4)
         np.testing.assert_allclose(host(out.data), g["outs"][s], rtol=1e-4, atol=1e-5 if s == 0 else 1e-3)
         if s == 0:
+            gscale = grad_list_scale([g[f"g{i}"] for i in range(len(params))])
             for i, p in enumerate(params):
-                np.testing.assert_allclose(host(p.grad), g[f"g{i}"], rtol=1e-3, atol=1e-6, err_msg=f"grad {i}")
+                # conv biases in front of a BatchNorm have a mathematically zero gradient (the norm removes the mean)
+                assert_close_scaled(host(p.grad), g[f"g{i}"], err_msg=f"grad {i}", scale=gscale)
         opt.step()
+    # After Adam steps two correct fp32 implementations may differ by up to lr per step in any parameter whose gradient
+    # is rounding noise (the update is lr * m / (sqrt(v) + eps): the noise's SIGN decides it) -- here lr = 1e-3, 2 steps;
+    # the running mean is an average of activations of those parameters.
     np.testing.assert_allclose(host(model.bnorm.running_mean.data), g["rm"], rtol=1e-3, atol=2e-3)
 
 
@@ -2325,8 +2449,9 @@ def test_conv_classifier_c5_batch_vs_oracle(hip):
     # is only good to ~1e-5 absolute there (measured: 0.6 % relative on the smallest elements for BOTH conv paths
     # against the oracle's pairwise NumPy sums), hence a floor relative to the largest element
     for i, p in enumerate(params):
-        np.testing.assert_allclose(host(p.grad), rg[i], rtol=2e-3, atol=2e-3 * float(np.abs(rg[i]).max()),
-                                   err_msg=f"grad {i}")
+        # fp32 accumulation in a different order than the oracle's pairwise NumPy sums: both are ~1e-5 absolute from the
+        # float64 value there, so they are compared at 1e-3 of the tensor's rms (10x the scaled 1e-4 everything else holds)
+        assert_close_scaled(host(p.grad), rg[i], tol=1e-3, err_msg=f"grad {i}")
 
 
 # =============================================================================================================

@@ -202,6 +202,18 @@ def test_gpt_tiny_step(golden):
 
 
 # ---- the remaining conv-classifier ops and the full config-5 step -----------------------------------
+def test_maxpool_dilated(golden):
+    """MaxPool2d with dilation > 1 (maxpool2d.py:170-220): the oracle's tap formulation == the reference's NaN-kernel one."""
+    g = golden("maxpool_dilated")
+    X = g["X"]
+    for tag in ("k2s1p0d2", "k3s2p2d2", "k2s2p1d3"):
+        ks, st, pad, dil = [int(v) for v in g[f"{tag}_cfg"]]
+        y, arg = O.maxpool2d_forward(X, (ks, ks), (st, st), (pad, pad), (dil, dil))
+        np.testing.assert_array_equal(y, g[f"{tag}_Y"])
+        dX = O.maxpool2d_backward(X.shape, arg, g[f"{tag}_dY"], (ks, ks), (st, st), (pad, pad), (dil, dil))
+        np.testing.assert_allclose(dX, g[f"{tag}_dX"], rtol=1e-6, atol=1e-6)
+
+
 def test_vision_ops(golden):
     g = golden("vision_ops")
     X = g["X"]

@@ -1,2 +1,3 @@
-python tools/ce_parts.py 2>&1 | grep -v amdgpu.ids
-NEUNET_HIP_LIB=$PWD/numpy-nn-model_amd/neunet_hip/lib/libneunet_hip.base.so python tools/ce_parts.py 2>&1 | grep -v amdgpu.ids
+O=gpurun_out/r03h; mkdir -p $O
+timeout 1500 python -m pytest tests -q -m gpu > $O/gpu_tests.log 2>&1; echo "gpu tests rc=$?"
+grep -E "^FAILED|^ERROR|passed|failed|AssertionError:"  $O/gpu_tests.log

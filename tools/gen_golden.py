@@ -384,6 +384,24 @@ def gen_gpt():
     save("gpt_tiny", **arrs)
 
 
+# --------------------------------------------------------------------------- MaxPool2d with dilation
+def gen_maxpool_dilated():
+    """MaxPool2d(kernel, stride, padding, dilation > 1) through the reference class (maxpool2d.py:85-249): square dilated
+    windows and symmetric padding only -- the reference's backward cannot run otherwise (:50-57, :63-64)."""
+    seed_layers(131)
+    rng = np.random.default_rng(31)
+    X = (rng.standard_normal((2, 3, 11, 11)) * 2).astype(F32)
+    X[1, 2, 4, 4] = X[1, 2, 4, 6] = 9.5             # a tie between two taps of one dilated window -> first tap wins
+    arrs = {"X": X}
+    for tag, ks, st, pad, dil in [("k2s1p0d2", 2, 1, 0, 2), ("k3s2p2d2", 3, 2, 2, 2), ("k2s2p1d3", 2, 2, 1, 3)]:
+        x = T(X)
+        y = nn.MaxPool2d(ks, st, pad, dil)(x)
+        dY = rng.standard_normal(y.shape).astype(F32)
+        y.backward(dY)
+        arrs.update({f"{tag}_Y": y.data, f"{tag}_dY": dY, f"{tag}_dX": x.grad, f"{tag}_cfg": np.array([ks, st, pad, dil])})
+    save("maxpool_dilated", **arrs)
+
+
 # --------------------------------------------------------------------------- conv classifier (config 5)
 def gen_vision():
     seed_layers(109)
@@ -460,7 +478,7 @@ def gen_vision():
 
 
 GENERATORS = [gen_linear, gen_activations, gen_ce, gen_ce_weighted, gen_rmsnorm, gen_conv, gen_adam, gen_linear_swish, gen_mlp,
-              gen_gpt, gen_vision]
+              gen_gpt, gen_vision, gen_maxpool_dilated]
 
 
 def generate_all(out_dir=None, quiet=False):

@@ -173,6 +173,63 @@ def main():
             report(f"attn fwd B{B_} T{T_} H{H_} dh{dh} causal", *bench(f, args.iters), flops=fwd_fl)
             report(f"attn bwd B{B_} T{T_} H{H_} dh{dh} causal", *bench(bw, args.iters), flops=2.5 * fwd_fl)
 
+    if want("lssweep"):
+        # The reference's own Linear->Swish sweep (scripts/benchmark_linear_swish_cuda.py:127-138) with its methodology
+        # (:16-56, :59-118): 50 warm-up + 200 timed iterations between two events, and INSIDE the timed loop a device copy
+        # of x, a fresh Tensor, the module call (forward) or call + fresh random upstream gradient + backward.
+        import neunet_hip
+        import neunet_hip.nn as nn
+        print("Linear->Swish sweep, reference methodology (module API, per-iteration device copy + Tensor + launch; "
+              "ms per iteration):")
+        print(f"{'B x In x Out':>20s} {'fwd fused':>10s} {'fwd 2-op':>10s} {'f+b fused':>10s} {'f+b 2-op':>10s} {'fwd kernel':>11s} {'TFLOP/s':>8s}")
+
+        def timed(fn, warm=50, iters=200):
+            for _ in range(warm):
+                fn()
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(iters):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+            return a.elapsed_time(b) / iters
+
+        for (Bn, I, Od) in [(32, 256, 512), (64, 256, 512), (128, 256, 512), (256, 512, 1024), (512, 512, 1024), (1024, 512, 1024),
+                            (1024, 1024, 2048), (2048, 1024, 2048), (4096, 1024, 4096)]:
+            fused = nn.LinearSwish(I, Od, swish_beta=1.0)
+            lin, act = nn.Linear(I, Od), nn.Swish(1.0)
+            lin.weight.data.copy_(fused.weight.data)
+            lin.bias.data.copy_(fused.bias.data)
+            xd = rnd(Bn, I)
+
+            def f_fused():
+                return fused(neunet_hip.Tensor(xd.clone(), device="cuda", requires_grad=False))
+
+            def f_two():
+                h = lin(neunet_hip.Tensor(xd.clone(), device="cuda", requires_grad=False))
+                _ = h.data                                 # the plain GEMM, then the Swish pass: two launches
+                return act(h)
+
+            def fb(mod_call, params):
+                X = neunet_hip.Tensor(xd.clone(), device="cuda", requires_grad=True)
+                out = mod_call(X)
+                out.backward(rnd(Bn, Od))
+                for p_ in params:
+                    p_.grad = None
+
+            def two(X):
+                h = lin(X)
+                _ = h.data
+                return act(h)
+
+            t_ff, t_f2 = timed(f_fused), timed(f_two)
+            t_bf = timed(lambda: fb(fused, (fused.weight, fused.bias)))
+            t_b2 = timed(lambda: fb(two, (lin.weight, lin.bias)))
+            O_ = torch.empty(Bn, Od, device=dev)
+            tk, _ = bench(lambda: call("nnhipLinearSwishForward", xd, fused.weight.data, fused.bias.data, O_, None, Bn, I, Od, 1.0, 0, st), 50)
+            print(f"{f'{Bn} x {I} x {Od}':>20s} {t_ff:10.4f} {t_f2:10.4f} {t_bf:10.4f} {t_b2:10.4f} {tk:11.4f} {2.0 * Bn * I * Od / (tk * 1e-3) / 1e12:8.2f}", flush=True)
+
     if want("conv"):
         for (B, Cin, H, Cout) in [(256, 1, 28, 8), (256, 8, 14, 16)]:
             X = rnd(B, Cin, H, H)
