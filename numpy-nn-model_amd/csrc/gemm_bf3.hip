@@ -30,6 +30,9 @@ namespace nnhip {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int B3_BK = 16;
+#ifndef B3_DEPTH
+#define B3_DEPTH 2
+#endif
 constexpr int B3_RS = 48;                               // bytes per LDS row: 16 bf16 + 16 bytes of padding
 constexpr int B3_PLANE = 128 * B3_RS;                   // one plane of one operand
 constexpr int B3_OPERAND = 3 * B3_PLANE;
@@ -44,6 +47,18 @@ __device__ __forceinline__ void split3(float x, unsigned& hi, unsigned& mid, uns
 }
 // {a.high16, b.high16} -> one dword (a in the low half)
 __device__ __forceinline__ unsigned pack_hi16(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+// Two elements at once, straight to the packed dwords of the three planes: 4 v_and + 2 v_pk_add_f32 + 3 v_perm = 9 VALU per
+// pair (split3 + packing: 11).  The split is issue-bound work next to the MFMAs (see the step schedule), so it counts.
+typedef float f32x2_ __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
+    const unsigned h0 = __float_as_uint(x0) & 0xFFFF0000u, h1 = __float_as_uint(x1) & 0xFFFF0000u;
+    const f32x2_ r1 = f32x2_{x0, x1} - f32x2_{__uint_as_float(h0), __uint_as_float(h1)};
+    const unsigned m0 = __float_as_uint(r1.x) & 0xFFFF0000u, m1 = __float_as_uint(r1.y) & 0xFFFF0000u;
+    const f32x2_ r2 = r1 - f32x2_{__uint_as_float(m0), __uint_as_float(m1)};
+    hi = pack_hi16(h0, h1);
+    mid = pack_hi16(m0, m1);
+    lo = pack_hi16(__float_as_uint(r2.x), __float_as_uint(r2.y));
+}
 
 // ---- operand staging ---------------------------------------------------------------------------------------------
 // k-major operand: 2 float4 per thread (rows idx/4, k = 4 (idx%4) .. +3) -- g2r<16, true, VEC> of gemm_common.h.
@@ -126,25 +141,24 @@ __device__ __forceinline__ void b3_commit(const StageRegs& r, unsigned char* __r
         for (int p = 0; p < 2; ++p) {
             const int idx = tid + NT * p;
             const int rr = idx >> 2, k4 = (idx & 3) * 4;
-            unsigned h[4], m[4], l[4];
-            split3(r.v[p].x, h[0], m[0], l[0]);
-            split3(r.v[p].y, h[1], m[1], l[1]);
-            split3(r.v[p].z, h[2], m[2], l[2]);
-            split3(r.v[p].w, h[3], m[3], l[3]);
+            unsigned h[2], m[2], l[2];
+            split3_pair(r.v[p].x, r.v[p].y, h[0], m[0], l[0]);
+            split3_pair(r.v[p].z, r.v[p].w, h[1], m[1], l[1]);
             unsigned char* dst = S + rr * B3_RS + k4 * 2;
-            *reinterpret_cast<uint2*>(dst) = make_uint2(pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]));
-            *reinterpret_cast<uint2*>(dst + B3_PLANE) = make_uint2(pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]));
-            *reinterpret_cast<uint2*>(dst + 2 * B3_PLANE) = make_uint2(pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]));
+            *reinterpret_cast<uint2*>(dst) = make_uint2(h[0], h[1]);
+            *reinterpret_cast<uint2*>(dst + B3_PLANE) = make_uint2(m[0], m[1]);
+            *reinterpret_cast<uint2*>(dst + 2 * B3_PLANE) = make_uint2(l[0], l[1]);
         }
     } else {
-        const float t[8] = {r.v[0].x, r.v[0].y, r.v[0].z, r.v[0].w, r.v[1].x, r.v[1].y, r.v[1].z, r.v[1].w};
-        unsigned h[8], m[8], l[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) split3(t[j], h[j], m[j], l[j]);
+        unsigned h[4], m[4], l[4];
+        split3_pair(r.v[0].x, r.v[0].y, h[0], m[0], l[0]);
+        split3_pair(r.v[0].z, r.v[0].w, h[1], m[1], l[1]);
+        split3_pair(r.v[1].x, r.v[1].y, h[2], m[2], l[2]);
+        split3_pair(r.v[1].z, r.v[1].w, h[3], m[3], l[3]);
         unsigned char* dst = S + (tid & 127) * B3_RS + (tid >> 7) * 16;
-        *reinterpret_cast<uint4*>(dst) = make_uint4(pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3]), pack_hi16(h[4], h[5]), pack_hi16(h[6], h[7]));
-        *reinterpret_cast<uint4*>(dst + B3_PLANE) = make_uint4(pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3]), pack_hi16(m[4], m[5]), pack_hi16(m[6], m[7]));
-        *reinterpret_cast<uint4*>(dst + 2 * B3_PLANE) = make_uint4(pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3]), pack_hi16(l[4], l[5]), pack_hi16(l[6], l[7]));
+        *reinterpret_cast<uint4*>(dst) = make_uint4(h[0], h[1], h[2], h[3]);
+        *reinterpret_cast<uint4*>(dst + B3_PLANE) = make_uint4(m[0], m[1], m[2], m[3]);
+        *reinterpret_cast<uint4*>(dst + 2 * B3_PLANE) = make_uint4(l[0], l[1], l[2], l[3]);
     }
 }
 
@@ -154,6 +168,124 @@ __device__ __forceinline__ bf16x8 b3_frag(const unsigned char* __restrict__ S, i
 }
 
 #define B3_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
+// ---- pieces of the hand-ordered step (b3_step_fast) -----------------------------------------------------------------------
+// element e (0..7) of a staged tile, as a reference
+__device__ __forceinline__ float& sr_elem(StageRegs& r, int e) {
+    float4& v = r.v[e >> 2];
+    return (e & 3) == 0 ? v.x : (e & 3) == 1 ? v.y : (e & 3) == 2 ? v.z : v.w;
+}
+__device__ __forceinline__ float sr_get(const StageRegs& r, int e) {
+    const float4& v = r.v[e >> 2];
+    return (e & 3) == 0 ? v.x : (e & 3) == 1 ? v.y : (e & 3) == 2 ? v.z : v.w;
+}
+// the idx-th global load of one operand's tile: k-major 2 x b128 (idx 0, 1), outer-major 8 x b32 (idx 0..7)
+template <bool KC>
+__device__ __forceinline__ void b3_load_one(StageRegs& r, __amdgpu_buffer_rsrc_t rs, unsigned koff, unsigned ldb4, const B3Offs& t, int idx) {
+    if constexpr (KC) {
+        const u32x4_ v = __builtin_amdgcn_raw_buffer_load_b128(rs, t.o[idx], koff, 0);
+        r.v[idx].x = __uint_as_float(v.x); r.v[idx].y = __uint_as_float(v.y); r.v[idx].z = __uint_as_float(v.z); r.v[idx].w = __uint_as_float(v.w);
+    } else {
+        sr_elem(r, idx) = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, t.o[0], koff + (unsigned)idx * ldb4, 0));
+    }
+}
+// split of one pair in two halves (issue slots): A = hi / first remainder / mid, B = second remainder and the three packs
+struct PairSplit { f32x2_ r1; unsigned h0, h1, m0, m1; };
+__device__ __forceinline__ void split_pair_a(PairSplit& s, float x0, float x1) {
+    s.h0 = __float_as_uint(x0) & 0xFFFF0000u; s.h1 = __float_as_uint(x1) & 0xFFFF0000u;
+    s.r1 = f32x2_{x0, x1} - f32x2_{__uint_as_float(s.h0), __uint_as_float(s.h1)};
+    s.m0 = __float_as_uint(s.r1.x) & 0xFFFF0000u; s.m1 = __float_as_uint(s.r1.y) & 0xFFFF0000u;
+}
+__device__ __forceinline__ void split_pair_b(const PairSplit& s, unsigned& hi, unsigned& mid, unsigned& lo) {
+    const f32x2_ r2 = s.r1 - f32x2_{__uint_as_float(s.m0), __uint_as_float(s.m1)};
+    hi = pack_hi16(s.h0, s.h1);
+    mid = pack_hi16(s.m0, s.m1);
+    lo = pack_hi16(__float_as_uint(r2.x), __float_as_uint(r2.y));
+}
+// LDS store `w` (0..2 = plane) of group `g` of one operand: k-major groups are (p = g: pairs 2g, 2g+1 -> 8 bytes per plane),
+// an outer-major operand is one group (pairs 0..3 -> 16 bytes per plane)
+template <bool KC>
+__device__ __forceinline__ void b3_store_one(unsigned char* __restrict__ S, int tid, int g, int w, const unsigned (&H)[4], const unsigned (&M)[4],
+                                             const unsigned (&L)[4]) {
+    const unsigned (&P)[4] = w == 0 ? H : (w == 1 ? M : L);
+    if constexpr (KC) {
+        const int idx = tid + NT * g;
+        unsigned char* dst = S + (idx >> 2) * B3_RS + (idx & 3) * 8 + w * B3_PLANE;
+        *reinterpret_cast<uint2*>(dst) = make_uint2(P[2 * g], P[2 * g + 1]);
+    } else {
+        unsigned char* dst = S + (tid & 127) * B3_RS + (tid >> 7) * 16 + w * B3_PLANE;
+        *reinterpret_cast<uint4*>(dst) = make_uint4(P[0], P[1], P[2], P[3]);
+    }
+}
+
+// One whole k-tile of the vectorised variants, hand-ordered: 24 issue slots, each = one MFMA + a few other instructions,
+// separated by scheduling barriers so the compiler keeps them there.
+//   slot q:  product q  |  q < 8: fragment read 4+q  |  q < NVM: global load q of tile kt+D
+//            |  2 <= q < 18: half a pair of the split of tile kt+1  |  LDS stores of a finished group
+// A 32x32x16 bf16 MFMA holds the matrix pipe for 32 cycles (~8 issue slots of which ~5 can carry other work,
+// MI355X_MICROARCH.md): the step's ~100 non-MFMA instructions fit under its 24 MFMAs only if they are PLACED between them.
+// Left to the compiler (round 2, and a sched_group_barrier pipeline tried first in round 3) the order was: reads, 24 MFMAs
+// back to back, THEN the whole split with the matrix pipe idle -> 0.47 of the bf16 MFMA peak.
+template <bool AKC, bool BKC, bool CS>
+__device__ __forceinline__ void b3_step_fast(f32x16 (&acc)[2][2], StageRegs& fa, StageRegs& fb, const StageRegs& ca, const StageRegs& cb,
+                                             unsigned char* __restrict__ smem_b, int cur, __amdgpu_buffer_rsrc_t rsa,
+                                             __amdgpu_buffer_rsrc_t rsb, unsigned koa, unsigned kob, unsigned la4, unsigned lb4,
+                                             const B3Offs& offa, const B3Offs& offb, int tid, int wm, int wn, int l31, int lh,
+                                             float& rowsum) {
+    const unsigned char* As = smem_b + cur * B3_STAGE;
+    const unsigned char* Bs = As + B3_OPERAND;
+    unsigned char* Sa = smem_b + (cur ^ 1) * B3_STAGE;
+    unsigned char* Sb = Sa + B3_OPERAND;
+    constexpr int NLA = AKC ? 2 : 8, NLB = BKC ? 2 : 8;            // global loads per operand
+    // fragments in consumption order: products 0-3 need (a lo, b hi), 4-7 (a hi, b lo), 8-11 (a mid, b mid)
+    bf16x8 a[2][3], b[2][3];
+    auto read_frag = [&](int f) {
+        constexpr int pa[3] = {2, 0, 1}, pb[3] = {0, 2, 1};
+        const int q = f >> 2, j = f & 3;
+        if (j < 2) a[j][pa[q]] = b3_frag(As + pa[q] * B3_PLANE, wm * 64 + j * 32 + l31, lh);
+        else b[j - 2][pb[q]] = b3_frag(Bs + pb[q] * B3_PLANE, wn * 64 + (j - 2) * 32 + l31, lh);
+    };
+#pragma unroll
+    for (int f = 0; f < 4; ++f) read_frag(f);
+    PairSplit ps[8];
+    unsigned HA[4], MA[4], LA[4], HB[4], MB[4], LB[4];
+    constexpr int ta[6] = {2, 0, 1, 1, 0, 0}, tb[6] = {0, 2, 1, 0, 1, 0};   // (piece of a, piece of b) per term, smallest first
+#pragma unroll
+    for (int q = 0; q < 24; ++q) {
+        const int term = q >> 2, i = (q >> 1) & 1, n = q & 1;
+        acc[i][n] = B3_MFMA(a[i][ta[term]], b[n][tb[term]], acc[i][n]);
+        if (q < 8) read_frag(4 + q);
+        if (q < NLA) b3_load_one<AKC>(fa, rsa, koa, la4, offa, q);
+        else if (q < NLA + NLB) b3_load_one<BKC>(fb, rsb, kob, lb4, offb, q - NLA);
+        if (q >= 2 && q < 18) {                                   // pair j of 8 (0-3: A, 4-7: B): half A at even, half B at odd slots
+            const int j = (q - 2) >> 1;
+            const StageRegs& src = j < 4 ? ca : cb;
+            const int e = (j & 3) * 2;
+            if (((q - 2) & 1) == 0) split_pair_a(ps[j], sr_get(src, e), sr_get(src, e + 1));
+            else if (j < 4) split_pair_b(ps[j], HA[j], MA[j], LA[j]);
+            else split_pair_b(ps[j], HB[j - 4], MB[j - 4], LB[j - 4]);
+        }
+        // LDS stores, one per slot: a k-major operand's group g (pairs 2g, 2g+1) is complete after slot 5 + 4g (+8 for B),
+        // an outer-major operand (one group of four pairs) after slot 9 (17 for B)
+        if constexpr (AKC) {
+            if (q >= 6 && q < 9) b3_store_one<true>(Sa, tid, 0, q - 6, HA, MA, LA);
+            if (q >= 10 && q < 13) b3_store_one<true>(Sa, tid, 1, q - 10, HA, MA, LA);
+        } else {
+            if (q >= 10 && q < 13) b3_store_one<false>(Sa, tid, 0, q - 10, HA, MA, LA);
+        }
+        if constexpr (BKC) {
+            if (q >= 14 && q < 17) b3_store_one<true>(Sb, tid, 0, q - 14, HB, MB, LB);
+            if (q >= 18 && q < 21) b3_store_one<true>(Sb, tid, 1, q - 18, HB, MB, LB);
+        } else {
+            if (q >= 18 && q < 21) b3_store_one<false>(Sb, tid, 0, q - 18, HB, MB, LB);
+        }
+        if constexpr (CS) {
+            if (q == 21) rowsum += (ca.v[0].x + ca.v[0].y) + (ca.v[0].z + ca.v[0].w);
+            if (q == 22) rowsum += (ca.v[1].x + ca.v[1].y) + (ca.v[1].z + ca.v[1].w);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
 
 // CS (outer-major A only): every thread also sums the A elements it stages (8 k of ONE row) -> asum[m] = sum_k A[m,k].
 template <bool AKC, bool BKC, bool VEC, bool CS>
@@ -200,9 +332,13 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf3_kernel(const GemmParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    // Two register sets per operand: tile kt+2 is fetched while tile kt is multiplied and tile kt+1 (fetched one
-    // iteration earlier) is split and committed to the other LDS stage -- a global load gets a whole iteration to land.
-    StageRegs ra0, rb0, ra1, rb1;
+    // D register sets per operand (tile t lives in set t % D): tile kt+D is fetched while tile kt is multiplied and tile
+    // kt+1 (fetched D-1 iterations earlier) is split and committed to the other LDS stage.  An iteration of this kernel is
+    // only 24 MFMAs = 768 matrix-pipe cycles (0.32 us), far less than an L2 round trip: with round 2's two sets (a load
+    // had ONE iteration to land) both resident blocks of a CU sat in s_waitcnt vmcnt for half of the time -- the kernel
+    // ran at 0.47 of the bf16 MFMA peak whatever the tile order.  B3_DEPTH sets give a load D-1 iterations.
+    constexpr int D = VEC ? B3_DEPTH : 2;          // (the scalar-load variants have no registers to spare)
+    StageRegs ra[D], rb[D];
     float rowsum = 0.f;
     auto rsum = [](const StageRegs& r) { return (r.v[0].x + r.v[0].y) + (r.v[0].z + r.v[0].w) + (r.v[1].x + r.v[1].y) + (r.v[1].z + r.v[1].w); };
     const int64_t klen = kend - kbeg;
@@ -248,26 +384,21 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf3_kernel(const GemmParams p) {
         b3_commit<AKC>(ca, S, tid);
         b3_commit<BKC>(cb, S + B3_OPERAND, tid);
     };
-    fetch(ra0, rb0, 0);
-    fetch(ra1, rb1, 1);
-    commit(ra0, rb0, 0, smem_b);
+#pragma unroll
+    for (int j = 0; j < D; ++j) fetch(ra[j], rb[j], j);
+    commit(ra[0], rb[0], 0, smem_b);
     __syncthreads();
 
     int cur = 0;
-    // one k-tile: fetch tile kt+2 into (fa, fb) [free: its tile was committed an iteration ago], multiply tile kt out of
-    // LDS stage `cur`, commit tile kt+1 from (ca, cb) into the other stage
-    auto step = [&](int kt, StageRegs& fa, StageRegs& fb, StageRegs& ca, StageRegs& cb) {
-        fetch(fa, fb, kt + 2);
-        const unsigned char* As = smem_b + cur * B3_STAGE;
-        const unsigned char* Bs = As + B3_OPERAND;
-        bf16x8 a[2][3], b[2][3];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-                a[i][pl] = b3_frag(As + pl * B3_PLANE, wm * 64 + i * 32 + l31, lh);
-                b[i][pl] = b3_frag(Bs + pl * B3_PLANE, wn * 64 + i * 32 + l31, lh);
-            }
+    // one k-tile: fetch tile kt+D into (fa, fb) [free: its tile kt was committed an iteration ago], multiply tile kt out of
+    // LDS stage `cur`, commit tile kt+1 from (ca, cb) into the other stage.
+    // FAST (vectorised variants, whole tiles): the body is ONE basic block whose issue order is pinned.  Round 2's step left
+    // the order to the compiler: 12 LDS reads, 24 MFMAs back to back (the last four chained on one accumulator), THEN the
+    // ~110 split / pack / LDS-store instructions of the next tile with the matrix pipe idle, then the barrier -- 0.47 of the
+    // bf16 MFMA peak, and unmoved by prefetch depth (measured, depth 2..8): the wave was issue-bound, not latency-bound.  A
+    // 32x32x16 bf16 MFMA occupies its pipe for 32 cycles = ~8 issue slots, of which ~5 can carry other instructions
+    // (MI355X_MICROARCH.md): the ~100 non-MFMA instructions of a step fit between its 24 MFMAs if they are PUT there.
+    auto mma = [&](const bf16x8 (&a)[2][3], const bf16x8 (&b)[2][3]) {
         // six products per accumulator, smallest first; the four accumulators alternate so that dependent MFMAs are 4 apart
 #define B3_TERM(PA, PB)                                                       \
         _Pragma("unroll") for (int i = 0; i < 2; ++i)                          \
@@ -279,16 +410,55 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf3_kernel(const GemmParams p) {
         B3_TERM(0, 1)
         B3_TERM(0, 0)
 #undef B3_TERM
+    };
+    auto frags = [&](bf16x8 (&a)[2][3], bf16x8 (&b)[2][3]) {
+        const unsigned char* As = smem_b + cur * B3_STAGE;
+        const unsigned char* Bs = As + B3_OPERAND;
+        // in the order the products above consume them: (a lo, b hi), (a hi, b lo), (a mid, b mid)
+        constexpr int pa[3] = {2, 0, 1}, pb[3] = {0, 2, 1};
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i][pa[q]] = b3_frag(As + pa[q] * B3_PLANE, wm * 64 + i * 32 + l31, lh);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) b[i][pb[q]] = b3_frag(Bs + pb[q] * B3_PLANE, wn * 64 + i * 32 + l31, lh);
+        }
+    };
+    auto step_fast = [&](int kt, StageRegs& fa, StageRegs& fb, StageRegs& ca, StageRegs& cb) {
+        if constexpr (VEC) {
+            const int64_t kn = kbeg + (int64_t)(kt + D) * B3_BK;
+            const unsigned k = (unsigned)(kn + B3_BK <= kend ? kn : kbeg);     // scalar; past the end: any whole tile (never used)
+            b3_step_fast<AKC, BKC, CS>(acc, fa, fb, ca, cb, smem_b, cur, rsa, rsb, k * ua, k * ub, la4, lb4, offa, offb, tid, wm, wn,
+                                       l31, lh, rowsum);
+            __syncthreads();
+            cur ^= 1;
+        }
+    };
+    auto step = [&](int kt, StageRegs& fa, StageRegs& fb, StageRegs& ca, StageRegs& cb) {
+        fetch(fa, fb, kt + D);
+        bf16x8 a[2][3], b[2][3];
+        frags(a, b);
+        mma(a, b);
         commit(ca, cb, kt + 1, smem_b + (cur ^ 1) * B3_STAGE);
         __syncthreads();
         cur ^= 1;
     };
+    // steps kt < nfast commit a WHOLE tile (kt + 1 < nfull) and take the hand-ordered body -- in a loop of their OWN: with
+    // the two kinds of step as alternatives inside one loop body the accumulators got different registers on the two paths
+    // and every step ended in 32 v_mov_b64 copies behind an s_nop for the last MFMA's result.
+    const int nfast = VEC ? (nfull > 0 ? nfull - 1 : 0) : 0;
     int kt = 0;
-    for (; kt + 1 < nk; kt += 2) {
-        step(kt, ra0, rb0, ra1, rb1);
-        step(kt + 1, ra1, rb1, ra0, rb0);
+    if constexpr (VEC) {
+        for (; kt + D <= nfast; kt += D) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) step_fast(kt + j, ra[j], rb[j], ra[(j + 1) % D], rb[(j + 1) % D]);
+        }
     }
-    if (kt < nk) step(kt, ra0, rb0, ra1, rb1);
+    for (; kt < nk; kt += D) {                      // the last steps (the shifted partial tile, nothing left to fetch) and every
+#pragma unroll                                      // step of the scalar-load variants
+        for (int j = 0; j < D; ++j)
+            if (kt + j < nk) step(kt + j, ra[j], rb[j], ra[(j + 1) % D], rb[(j + 1) % D]);
+    }
 
     float* smem = reinterpret_cast<float*>(smem_b);
     if constexpr (CS) {

@@ -1,3 +1,3 @@
-O=gpurun_out/r03h; mkdir -p $O
-timeout 1500 python -m pytest tests -q -m gpu > $O/gpu_tests.log 2>&1; echo "gpu tests rc=$?"
-grep -E "^FAILED|^ERROR|passed|failed|AssertionError:"  $O/gpu_tests.log
+bash tools/gemm_pmc.sh bf3 1 8192 4096 4096 2>&1 | tail -40
+echo ======= fp32
+bash tools/gemm_pmc.sh f32 0 8192 4096 4096 2>&1 | tail -40

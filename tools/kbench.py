@@ -78,6 +78,7 @@ def main():
             report(f"linear dX  {tag}", *bench(lambda: call("nnhipLinearModuleBackward", X, W, dO, dX, None, None, M, K, N, st), args.iters), flops=fl)
             report(f"linear dW  {tag}", *bench(lambda: call("nnhipLinearModuleBackward", X, W, dO, None, dW, None, M, K, N, st), args.iters), flops=fl)
             report(f"linear dW+db {tag}", *bench(lambda: call("nnhipLinearModuleBackward", X, W, dO, None, dW, db, M, K, N, st), args.iters), flops=fl)
+            report(f"linear dX+dW+db {tag}", *bench(lambda: call("nnhipLinearModuleBackward", X, W, dO, dX, dW, db, M, K, N, st), args.iters), flops=2 * fl)
             report(f"linear db  {tag}", *bench(lambda: call("nnhipLinearModuleBackward", X, W, dO, None, None, db, M, K, N, st), args.iters), nbytes=4.0 * M * N)
             del X, W, O_, dO, dX, dW
 
