@@ -740,9 +740,17 @@ def workload_nb(args, rank, world):
     steps = max(args.steps, 100)
     batches = nb_batches(np.random.default_rng(6000 + rank), 64, c["batch"], c["vocab"])
     it = [0]
+    bucket = None
+    from neunet_hip.distributed import GradBucket, collectives_live
+    if world > 1 or collectives_live():
+        # data parallel: every rank its own 4 prompts, one all-reduce of the flat gradient bucket per step, mean over ranks
+        # folded into the optimizer's gradient load (each rank's 'mean' loss is over its own tokens, as in the notebook)
+        gpt_tiny.train_step(model, opt, loss_fn, batches[0])          # discovers which parameters receive gradients
+        bucket = GradBucket([p for p in model.parameters()])
+        opt.grad_scale = 1.0 / world
 
     def step(timed):
-        gpt_tiny.train_step(model, opt, loss_fn, batches[it[0] % len(batches)])
+        gpt_tiny.train_step(model, opt, loss_fn, batches[it[0] % len(batches)], bucket=bucket)
         it[0] += 1
 
     dt = timed_region(step, steps, max(args.warmup, 10), world)

@@ -29,18 +29,32 @@ struct ConvGeom {
 };
 
 // =================================================================================================
-// forward / dgrad
+// forward / dgrad: implicit GEMM, block tile (32 MT) x 256, BK = 16, two LDS stages, one barrier per k-step
 // =================================================================================================
+// MT = 32-row tiles per block (1 / 2 / 4 by the number of output channels of the GEMM: Cout forward, Cin dgrad).  Wave w
+// owns columns [64 w, 64 w + 64) of the block's 256 pixels and ALL MT row tiles: every gathered source element feeds MT
+// MFMAs, so at MT = 4 a k-step is 64 fp32 MFMAs per wave (4096 matrix-pipe cycles) against 16 gathered elements and 8
+// weights per thread.  (Round 2's kernel had MT = 1 with per-element integer divisions in the gather and both barriers
+// exposed: the vector work of the gather -- on gfx950 paid in matrix-pipe time, DESIGN 5 -- was larger than the MFMAs.)
+//   * the reduction index k = (source channel, r, s) is block-uniform: (cs, r, s) are carried as SCALAR counters and
+//     stepped, no division anywhere in the loop (dgrad with stride > 1 keeps one per element: the output pixel exists
+//     only where (y + pu - r dh) is a multiple of the stride);
+//   * a thread gathers ONE pixel column (consecutive lanes = consecutive pixels: coalesced rows of the source image)
+//     for the 16 k of a tile, next tile's loads are issued before this tile's MFMAs and written to the other LDS stage
+//     after them.
 constexpr int CF_BK = 16;
 constexpr int CF_BN = 256;
 
-template <bool DGRAD>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict__ Wt,
-                                                         const float* __restrict__ Src,
-                                                         const float* __restrict__ bias,
-                                                         float* __restrict__ Dst, const ConvGeom g) {
-    __shared__ __attribute__((aligned(16))) float As[32 * (CF_BK + 4)];
-    __shared__ __attribute__((aligned(16))) float Bs[CF_BK * CF_BN];
+template <bool DGRAD, int MT>
+__global__ __launch_bounds__(256, MT == 4 ? 2 : 3) void conv_igemm_kernel(const float* __restrict__ Wt,
+                                                                          const float* __restrict__ Src,
+                                                                          const float* __restrict__ bias,
+                                                                          float* __restrict__ Dst, const ConvGeom g) {
+    constexpr int BMT = 32 * MT;
+    constexpr int ALD = CF_BK + 4;
+    constexpr int APT = BMT * CF_BK / 256;           // weights per thread per tile: 2 / 4 / 8
+    __shared__ __attribute__((aligned(16))) float As[2][BMT * ALD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][CF_BK * CF_BN];
 
     const int khkw = g.kh * g.kw;
     const int M = DGRAD ? g.Cin : g.Cout;
@@ -53,9 +67,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
-    const int m0 = blockIdx.y * 32;
+    const int m0 = blockIdx.y * BMT;
 
-    // this thread gathers column n = blockIdx.x*256 + tid for every k of the tile
+    // this thread gathers column n = blockIdx.x*256 + tid for every k of a tile
     const int64_t n = (int64_t)blockIdx.x * CF_BN + tid;
     const bool n_ok = n < N;
     int b = 0, yd = 0, xd = 0;
@@ -65,92 +79,145 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float* __restrict
         yd = rem / Wd;
         xd = rem - yd * Wd;
     }
-    const float* src_b = Src + (int64_t)b * Cs * HWs;
+    // forward: source pixel of tap (r, s) = (y0 + r dh, x0 + s dw);  dgrad: output pixel = ((y0 - r dh) / sh, (x0 - s dw) / sw)
+    const int y0 = DGRAD ? yd + g.pu : yd * g.sh - g.pu;
+    const int x0 = DGRAD ? xd + g.pl : xd * g.sw - g.pl;
+    const bool unit = g.sh == 1 && g.sw == 1;
+    // Branch-free gather: both operands are read through buffer descriptors whose num_records is the tensor's size, and an
+    // element that does not exist (padding, a k or m past the end, a pixel past N) is given the offset 0xFFFFFFFF -- the
+    // hardware returns 0 for it.  Byte offset of tap (cs, r, s) for this thread's pixel = pbase + koff, koff block-uniform.
+    const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Src), 0, (int)((int64_t)g.B * Cs * HWs * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wt), 0, (int)((int64_t)g.Cout * g.Cin * khkw * 4), 0x00020000);
+    const unsigned pbase = n_ok ? (unsigned)(((int64_t)b * Cs * HWs + (int64_t)y0 * Ws + x0) * 4) : 0u;   // wraps for negative y0 / x0: only used when in range
+    const int sgn = DGRAD ? -1 : 1;
 
-    f32x16 acc[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    // A-tile slots of this thread: element a (0..APT-1) is weight (m = am, kk = ak + a) with APT consecutive k of one row
+    const int am = tid / (CF_BK / APT), ak = (tid % (CF_BK / APT)) * APT;
+    const bool m_ok = m0 + am < M;
 
-    for (int k0 = 0; k0 < K; k0 += CF_BK) {
-        // ---- A tile: 32 x 16 weights (2 per thread) ----------------------------------------------
+    f32x16 acc[MT][2];
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int idx = tid + 256 * p;
-            const int m = idx / CF_BK, kk = idx % CF_BK;
-            const int k = k0 + kk;
-            float v = 0.f;
-            if (m0 + m < M && k < K) {
-                if constexpr (DGRAD) {
-                    const int co = k / khkw, rs = k - co * khkw;
-                    v = Wt[((int64_t)co * g.Cin + (m0 + m)) * khkw + rs];
-                } else {
-                    v = Wt[(int64_t)(m0 + m) * K + k];
-                }
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][t][e] = 0.f;
+
+    float ra[APT], rb[CF_BK];
+    // scalar reduction counters of the NEXT tile to fetch: k = (cs, r, s)
+    int fk = 0, fcs = 0, fr = 0, fs = 0;
+    auto fetch = [&]() {
+        // ---- weights ------------------------------------------------------------------------------
+#pragma unroll
+        for (int a = 0; a < APT; ++a) {
+            const int k = fk + ak + a;
+            unsigned off;
+            if constexpr (DGRAD) {
+                const int co = k / khkw, rs = k - co * khkw;              // (per thread, APT per tile: not the hot part)
+                off = (unsigned)((((int64_t)co * g.Cin + (m0 + am)) * khkw + rs) * 4);
+            } else {
+                off = (unsigned)(((int64_t)(m0 + am) * K + k) * 4);
             }
-            As[m * (CF_BK + 4) + kk] = v;
+            off = (m_ok && k < K) ? off : 0xFFFFFFFFu;
+            ra[a] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_w, off, 0, 0));
         }
-        // ---- B tile: 16 x 256 gathered source pixels (16 per thread, k uniform per step) ----------
+        // ---- gathered source pixels: k steps through (cs, r, s) with scalar counters, no branches ---------------
+        int cs = fcs, r = fr, sx = fs;
 #pragma unroll
         for (int kk = 0; kk < CF_BK; ++kk) {
-            const int k = k0 + kk;
-            float v = 0.f;
-            if (n_ok && k < K) {
-                const int cs = k / khkw, rs = k - cs * khkw;
-                const int r = rs / g.kw, s = rs - r * g.kw;
-                int ys, xs;
-                bool ok;
-                if constexpr (DGRAD) {
-                    const int ty = yd + g.pu - r * g.dh, tx = xd + g.pl - s * g.dw;
-                    ys = ty / g.sh;
-                    xs = tx / g.sw;
-                    ok = ty >= 0 && tx >= 0 && ys * g.sh == ty && xs * g.sw == tx && ys < Hs && xs < Ws;
-                } else {
-                    ys = yd * g.sh - g.pu + r * g.dh;
-                    xs = xd * g.sw - g.pl + s * g.dw;
-                    ok = ys >= 0 && ys < Hs && xs >= 0 && xs < Ws;
-                }
-                if (ok) v = src_b[(int64_t)cs * HWs + (int64_t)ys * Ws + xs];
+            const int dy = r * g.dh * sgn, dx = sx * g.dw * sgn;          // scalar
+            unsigned off;
+            bool ok;
+            if (unit || !DGRAD) {
+                const int ys = y0 + dy, xs = x0 + dx;
+                ok = (unsigned)ys < (unsigned)Hs && (unsigned)xs < (unsigned)Ws;
+                off = pbase + (unsigned)((cs * (int)HWs + dy * Ws + dx) * 4);
+            } else {
+                const int ty = y0 + dy, tx = x0 + dx;
+                const int ys = ty / g.sh, xs = tx / g.sw;
+                ok = ty >= 0 && tx >= 0 && ys * g.sh == ty && xs * g.sw == tx && ys < Hs && xs < Ws;
+                off = (unsigned)((((int64_t)b * Cs + cs) * HWs + (int64_t)ys * Ws + xs) * 4);
             }
-            Bs[kk * CF_BN + tid] = v;
+            off = (ok && n_ok && cs < Cs) ? off : 0xFFFFFFFFu;
+            rb[kk] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_src, off, 0, 0));
+            const int w1 = sx + 1 == g.kw;
+            sx = w1 ? 0 : sx + 1;
+            const int w2 = w1 && (r + 1 == g.kh);
+            r = w2 ? 0 : r + w1;
+            cs += w2;
         }
-        __syncthreads();
-        // ---- MFMA: wave w owns columns [w*64, w*64+64) = 2 n-tiles ----------------------------------
+        fcs = cs; fr = r; fs = sx; fk += CF_BK;
+    };
+    auto commit = [&](int st) {
+#pragma unroll
+        for (int a = 0; a < APT; ++a) As[st][am * ALD + ak + a] = ra[a];
+#pragma unroll
+        for (int kk = 0; kk < CF_BK; ++kk) Bs[st][kk * CF_BN + tid] = rb[kk];
+    };
+
+    const int nk = (K + CF_BK - 1) / CF_BK;
+    fetch();
+    commit(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        fetch();                                           // next tile's loads travel under this tile's MFMAs (past the end: zeros)
 #pragma unroll
         for (int gq = 0; gq < CF_BK / 8; ++gq) {
-            const float4 av = *reinterpret_cast<const float4*>(&As[l31 * (CF_BK + 4) + gq * 8 + lh * 4]);
-            const float a[4] = {av.x, av.y, av.z, av.w};
+            float a[MT][4];
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float bv = Bs[(gq * 8 + j + 4 * lh) * CF_BN + wave * 64 + nt * 32 + l31];
-                    acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], bv, acc[nt], 0, 0, 0);
-                }
+            for (int i = 0; i < MT; ++i) {
+                const float4 av = *reinterpret_cast<const float4*>(&As[cur][(i * 32 + l31) * ALD + gq * 8 + lh * 4]);
+                a[i][0] = av.x; a[i][1] = av.y; a[i][2] = av.z; a[i][3] = av.w;
             }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const float bv = Bs[cur][(gq * 8 + j + 4 * lh) * CF_BN + wave * 64 + t * 32 + l31];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], bv, acc[i][t], 0, 0, 0);
+                }
         }
+        commit(cur ^ 1);
         __syncthreads();
     }
 
-    // ---- epilogue: acc[nt][e] -> row m = (e&3)+8*(e>>2)+4*lh, column l31 of n-tile nt ------------------
+    // ---- epilogue: acc[i][t][e] -> row m = 32 i + (e&3)+8*(e>>2)+4*lh, column l31 of n-tile t ------------------
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int64_t nn = (int64_t)blockIdx.x * CF_BN + wave * 64 + nt * 32 + l31;
+    for (int t = 0; t < 2; ++t) {
+        const int64_t nn = (int64_t)blockIdx.x * CF_BN + wave * 64 + t * 32 + l31;
         if (nn >= N) continue;
         const int bb = (int)(nn / HWd);
         const int64_t sp = nn - (int64_t)bb * HWd;
         float* dst = Dst + (int64_t)bb * M * HWd + sp;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int m = m0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-            if (m < M) {
-                float v = acc[nt][e];
-                if (!DGRAD && bias) v += bias[m];
-                dst[(int64_t)m * HWd] = v;
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
+                if (m < M) {
+                    float v = acc[i][t][e];
+                    if (!DGRAD && bias) v += bias[m];
+                    dst[(int64_t)m * HWd] = v;
+                }
             }
-        }
     }
+}
+template <bool DGRAD>
+static int launch_conv_igemm(const float* Wt, const float* Src, const float* bias, float* Dst, const ConvGeom& g, hipStream_t st) {
+    const int M = DGRAD ? g.Cin : g.Cout;
+    const int64_t N = DGRAD ? (int64_t)g.B * g.H * g.W : (int64_t)g.B * g.Ho * g.Wo;
+    const unsigned gx = (unsigned)ceil_div(N, CF_BN);
+    // 32-bit byte offsets into both operands (buffer loads): each tensor below 2 GiB
+    const int64_t src_elems = DGRAD ? (int64_t)g.B * g.Cout * g.Ho * g.Wo : (int64_t)g.B * g.Cin * g.H * g.W;
+    NNHIP_CHECK_ARG(src_elems < ((int64_t)1 << 29) && (int64_t)g.Cout * g.Cin * g.kh * g.kw < ((int64_t)1 << 29), NNHIP_EINVAL,
+                    "conv2d: the implicit-GEMM kernel addresses each operand with 32-bit byte offsets (tensor >= 2 GiB)");
+    if (M <= 32) hipLaunchKernelGGL((conv_igemm_kernel<DGRAD, 1>), dim3(gx, (unsigned)ceil_div(M, 32)), dim3(256), 0, st, Wt, Src, bias, Dst, g);
+    else if (M <= 64) hipLaunchKernelGGL((conv_igemm_kernel<DGRAD, 2>), dim3(gx, (unsigned)ceil_div(M, 64)), dim3(256), 0, st, Wt, Src, bias, Dst, g);
+    else hipLaunchKernelGGL((conv_igemm_kernel<DGRAD, 4>), dim3(gx, (unsigned)ceil_div(M, 128)), dim3(256), 0, st, Wt, Src, bias, Dst, g);
+    NNHIP_LAUNCH_CHECK(DGRAD ? "conv_igemm_kernel<dgrad>" : "conv_igemm_kernel<fwd>");
+    return 0;
 }
 
 // =================================================================================================
@@ -760,10 +827,7 @@ extern "C" int nnhipConv2dForward(const float* X, const float* W, const float* b
         NNHIP_LAUNCH_CHECK("conv_direct_fwd_kernel");
         return 0;
     }
-    dim3 grid((unsigned)ceil_div(N, CF_BN), (unsigned)ceil_div(g.Cout, 32));
-    hipLaunchKernelGGL(conv_igemm_kernel<false>, grid, dim3(256), 0, (hipStream_t)s, W, X, bias, O, g);
-    NNHIP_LAUNCH_CHECK("conv_igemm_kernel<fwd>");
-    return 0;
+    return launch_conv_igemm<false>(W, X, bias, O, g, (hipStream_t)s);
 }
 
 extern "C" int nnhipConv2dBackward(const float* X, const float* W, const float* dO, float* dX, float* dW,
@@ -781,10 +845,7 @@ extern "C" int nnhipConv2dBackward(const float* X, const float* W, const float* 
         else hipLaunchKernelGGL(conv_direct_dgrad_kernel<16>, dgrid, dim3(256), 0, st, W, dO, dX, g);
         NNHIP_LAUNCH_CHECK("conv_direct_dgrad_kernel");
     } else if (dX) {
-        const int64_t N = (int64_t)g.B * g.H * g.W;
-        dim3 grid((unsigned)ceil_div(N, CF_BN), (unsigned)ceil_div(g.Cin, 32));
-        hipLaunchKernelGGL(conv_igemm_kernel<true>, grid, dim3(256), 0, st, W, dO, nullptr, dX, g);
-        NNHIP_LAUNCH_CHECK("conv_igemm_kernel<dgrad>");
+        if (int rc = launch_conv_igemm<true>(W, dO, nullptr, dX, g, st)) return rc;
     }
     size_t wg_lds = ((size_t)g.Cin * g.H * g.W + (size_t)g.Cout * g.Ho * g.Wo) * sizeof(float);
     if ((dW || db) && direct && g.kh == 3 && g.kw == 3 && wg_lds <= 60 * 1024) {

@@ -231,6 +231,22 @@ def main():
             tk, _ = bench(lambda: call("nnhipLinearSwishForward", xd, fused.weight.data, fused.bias.data, O_, None, Bn, I, Od, 1.0, 0, st), 50)
             print(f"{f'{Bn} x {I} x {Od}':>20s} {t_ff:10.4f} {t_f2:10.4f} {t_bf:10.4f} {t_b2:10.4f} {tk:11.4f} {2.0 * Bn * I * Od / (tk * 1e-3) / 1e12:8.2f}", flush=True)
 
+    if want("convg"):
+        # the implicit-GEMM conv kernels at MFMA-bound shapes (channels > 16: conv_igemm_kernel<fwd|dgrad, MT>)
+        for (B, Cin, H, Cout) in [(64, 64, 56, 128), (128, 128, 28, 128), (64, 32, 56, 64)]:
+            X = rnd(B, Cin, H, H)
+            W = rnd(Cout, Cin, 3, 3) / 24
+            bb = rnd(Cout)
+            O_ = torch.empty(B, Cout, H, H, device=dev)
+            dO = rnd(B, Cout, H, H)
+            dX = torch.empty_like(X)
+            d = Conv2dDesc(B, Cin, H, H, Cout, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1)
+            fl = 2.0 * B * H * H * Cout * Cin * 9
+            report(f"conv igemm fwd   {B}x{Cin}x{H}x{H}->{Cout}", *bench(lambda: call("nnhipConv2dForward", X, W, bb, O_, ctypes.byref(d), st), args.iters), flops=fl)
+            report(f"conv igemm dgrad {B}x{Cin}x{H}x{H}->{Cout}", *bench(lambda: call("nnhipConv2dBackward", X, W, dO, dX, None, None, ctypes.byref(d), st), args.iters), flops=fl)
+            dW, db = torch.empty_like(W), torch.empty_like(bb)
+            report(f"conv wgrad+db    {B}x{Cin}x{H}x{H}->{Cout}", *bench(lambda: call("nnhipConv2dBackward", X, W, dO, None, dW, db, ctypes.byref(d), st), args.iters), flops=fl)
+
     if want("conv"):
         for (B, Cin, H, Cout) in [(256, 1, 28, 8), (256, 8, 14, 16)]:
             X = rnd(B, Cin, H, H)
