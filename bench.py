@@ -642,11 +642,13 @@ def workload_c4(args, rank, world):
     }
 
 
-def cpu_c4(seconds, Bs=2, max_steps=3):
-    """FULL GPT-tiny training step (forward, backward, Adam on every parameter that has a gradient) of the NumPy oracle on
-    a bounded sample of the workload: 2 sequences x 256 tokens = 1/32 of one GPU's batch.  `--cpu-full-batch` times ONE
-    step on all 64 sequences instead (about a minute; its result is committed as profiles/cpu_c4_full_batch.json and
-    quoted next to every later bounded sample, so the bounded sample's scaling can be read off)."""
+def cpu_c4(seconds, Bs=64, max_steps=1):
+    """ONE FULL GPT-tiny training step (forward, backward, Adam on every parameter that has a gradient) of the NumPy oracle
+    on the WHOLE per-GPU batch, 64 sequences x 256 tokens: ~18 s on the GPU box's host (profiles/cpu_c4_full_batch.json;
+    rounds 1-2 timed 2 sequences, which understated OpenBLAS by 1.7x -- 2.0 vs 3.5 samples/s).  `--cpu-seconds` below 12
+    falls back to that 2-sequence sample (3 steps)."""
+    if seconds < 12.0 and Bs == 64:
+        Bs, max_steps = 2, 3
     from oracle import neunet_oracle as O
     c = C4
     rng = np.random.default_rng(1004)
