@@ -17,6 +17,10 @@ python bench.py --workload c3 --steps 20 --warmup 5 > $O/bench_c3.json 2> $O/ben
 python bench.py --workload c1 --steps 500 --warmup 50 > $O/bench_c1.json 2> $O/bench_c1.err
 python bench.py --workload c4 --steps 10 --warmup 3 > $O/bench_c4.json 2> $O/bench_c4.err
 python bench.py --workload c5 --steps 200 --warmup 20 > $O/bench_c5.json 2> $O/bench_c5.err
+python bench.py --workload nb --no-cpu-baseline > $O/bench_nb.json 2> $O/bench_nb.err
+# the data-parallel step on the production backend with ONE rank: nccl (= RCCL) group, collectives forced
+python bench.py --workload c4 --force-dp --no-cpu-baseline > $O/bench_c4_forced_nccl.json 2> $O/bench_c4_forced_nccl.err
+python bench.py --workload c4 --force-dp --dp-ingraph 1 --no-cpu-baseline > $O/bench_c4_forced_nccl_ingraph.json 2> $O/bench_c4_forced_nccl_ingraph.err
 cd /tmp && export TMPDIR=/tmp
 for W in headline c1 c2 c3 c4 c5; do
   S=30; [ $W = c4 ] && S=8; [ $W = headline ] && S=8; [ $W = c1 ] && S=200; [ $W = c5 ] && S=100
@@ -27,7 +31,14 @@ for W in c2 c3; do
   rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $O/pmc_write_$W -o w -- python $R/bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_write_$W.log 2>&1
 done
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -f csv -d $O/pmc_sq_c2 -o sq -- python $R/bench.py --workload c2 --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_sq_c2.log 2>&1
+# RCCL's kernels next to ours: kernel trace of the forced one-rank nccl step (--dp-op avg: a 1-rank in-place SUM is elided inside RCCL)
+rocprofv3 --kernel-trace --stats -f csv -d $O/prof_dp -o dp -- python $R/bench.py --workload c4 --force-dp --dp-op avg --steps 5 --warmup 2 --no-cpu-baseline > $O/prof_dp.log 2>&1
+cd $R
+bash tools/gemm_pmc.sh ${TAG}_bf3 1 8192 4096 4096 > $O/gemm_pmc_bf3.txt 2>&1
+bash tools/gemm_pmc.sh ${TAG}_f32 0 8192 4096 4096 > $O/gemm_pmc_f32.txt 2>&1
+cd /tmp
 # keep the merge under the 64 MiB limit: drop the raw traces, keep stats + counter CSVs
+python $R/tools/dp_timeline.py $(find $O/prof_dp -name "*_kernel_trace.csv" | head -1) $O/dp_timeline.md "C4 step, 1-rank nccl (RCCL) process group, collectives forced, --dp-op avg: RCCL kernels vs ours (rocprofv3 --kernel-trace)" > /dev/null 2>&1
 find $O -name "*_kernel_trace.csv" -size +2M -delete
 find $O -name "*.db" -delete
 du -sh $O

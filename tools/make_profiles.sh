@@ -30,7 +30,11 @@ json.dump(out, open('$P/pmc_traffic.json', 'w'), indent=1)
 for k, v in out.items():
     if not k.startswith('_'): print(f"{k:18s} {v/1e6:9.1f} MB")
 PY
-for W in headline c1 c2 c3 c4 c5; do cp $G/bench_$W.json $P/${TAG}_bench_$W.json; done
+for W in headline c1 c2 c3 c4 c5 nb c4_forced_nccl c4_forced_nccl_ingraph; do [ -f $G/bench_$W.json ] && cp $G/bench_$W.json $P/${TAG}_bench_$W.json; done
+[ -f $G/dp_timeline.md ] && cp $G/dp_timeline.md $P/${TAG}_dp_forced_nccl_timeline.md
+F=$(find $G/prof_dp -name "*_kernel_stats.csv" 2>/dev/null | head -1)
+[ -n "$F" ] && python tools/prof_summary.py stats $F $P/${TAG}_c4_forced_nccl_kernel_stats.md "Round ${TAG#r} -- rocprofv3 --kernel-trace --stats -- python bench.py --workload c4 --force-dp --dp-op avg (1-rank nccl group; MI355X)"
+for f in gemm_pmc_bf3.txt gemm_pmc_f32.txt; do [ -f $G/$f ] && cp $G/$f $P/${TAG}_$f; done
 cp $G/kbench.log $P/${TAG}_kbench.txt
 cp $G/stream_roof.txt $P/${TAG}_stream_roof.txt
 for f in kbench_bf16x3.log gemm_accuracy.txt mfma_valu_probe.txt; do [ -f $G/$f ] && grep -v amdgpu.ids $G/$f > $P/${TAG}_${f%.*}.txt; done
