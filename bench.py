@@ -726,8 +726,8 @@ def nb_batches(rng, n, B, vocab):
 def workload_nb(args, rank, world):
     """The reference's ONLY published training throughput: examples/gpt.ipynb's GPT (d512, 8 layers, 8 heads, d_ff 2048,
     vocab 15000, dropout 0.1, Adam 1.5e-4) on batches of 4 variable-length prompts, 6.44-6.67 it/s in the notebook's own
-    tqdm output (cell 16; CuPy on an unnamed NVIDIA GPU).  Same model and loop body (cell 12) on the HIP path: eager
-    launches -- every batch has its own length, so there is no graph to replay -- device-side dropout masks."""
+    tqdm output (cell 16; CuPy on an unnamed NVIDIA GPU).  Same model and loop body (cell 12) on the HIP path, device-side
+    dropout masks; every batch has its own length, so the step is captured once per padded length (`--graph 0`: eager)."""
     import torch
     sys.path.insert(0, os.path.join(ROOT, "examples"))
     import gpt_tiny
@@ -744,28 +744,95 @@ def workload_nb(args, rank, world):
     it = [0]
     bucket = None
     from neunet_hip.distributed import GradBucket, collectives_live
-    if world > 1 or collectives_live():
+    from neunet_hip.graph import GraphedTrainStep, attach_step_seed
+    dp = world > 1 or collectives_live()
+    use_graph = bool(args.graph) and not dp
+    if dp:
         # data parallel: every rank its own 4 prompts, one all-reduce of the flat gradient bucket per step, mean over ranks
         # folded into the optimizer's gradient load (each rank's 'mean' loss is over its own tokens, as in the notebook)
-        gpt_tiny.train_step(model, opt, loss_fn, batches[0])          # discovers which parameters receive gradients
         bucket = GradBucket([p for p in model.parameters()])
         opt.grad_scale = 1.0 / world
 
-    def step(timed):
+    def step_eager(timed):
         gpt_tiny.train_step(model, opt, loss_fn, batches[it[0] % len(batches)], bucket=bucket)
         it[0] += 1
 
+    graphs = {}
+    if use_graph:
+        # One captured step per padded length.  A batch is padded to the next multiple of 8 columns with PAD = 0: padded keys
+        # are masked in the attention, padded targets ignored by the loss, so every real token sees the same arithmetic as in
+        # the notebook's pad-to-the-longest batch; the static id / target buffers are refilled before each replay (the host
+        # batch crosses PCIe every step, as in the notebook's loop), dropout masks come from the device step seed.
+        import neunet_hip
+        step_seed = attach_step_seed(model)
+        B = c["batch"]
+        active = None
+
+        def build(Tp):
+            nonlocal active
+            ids = neunet_hip.Tensor(np.zeros((B, Tp), np.int32), dtype=np.int32, requires_grad=False, device="cuda")
+            tgt = neunet_hip.Tensor(np.zeros(B * Tp, np.int32), dtype=np.int32, requires_grad=False, device="cuda")
+            ids.data[:, 0] = 1
+            ids.data[:, 1] = 5
+            tgt.data[0] = 5                                          # a valid token so that the warm-up loss is finite
+
+            def fb():
+                out, _ = model.forward(ids)
+                loss = loss_fn(out.reshape(B * Tp, c["vocab"]), tgt)
+                loss.backward()
+                return loss
+
+            if active is None:
+                fb()
+                active = [p for p in model.parameters() if p.grad is not None]
+                opt.zero_grad()
+                graphs["bucket"] = GradBucket(active)
+            g = GraphedTrainStep(fb, opt, graphs["bucket"], warmup=1, step_seed=step_seed)
+            return g, ids, tgt
+
+        def padded(b):
+            T = b.shape[1] - 1
+            Tp = (T + 7) // 8 * 8
+            x = np.zeros((b.shape[0], Tp), np.int32)
+            y = np.zeros((b.shape[0], Tp), np.int32)
+            x[:, :T], y[:, :T] = b[:, :-1], b[:, 1:]
+            return Tp, x, y.reshape(-1)
+
+        for b in batches:                                             # capture every length in the data before the clock starts
+            Tp = padded(b)[0]
+            if Tp not in graphs:
+                graphs[Tp] = build(Tp)
+
+    def step_graph(timed):
+        Tp, x, y = padded(batches[it[0] % len(batches)])
+        g, ids, tgt = graphs[Tp]
+        ids.data.copy_(torch.from_numpy(x), non_blocking=True)
+        tgt.data.copy_(torch.from_numpy(y), non_blocking=True)
+        g()
+        it[0] += 1
+
+    eager_ips = None
+    if use_graph:
+        dte = timed_region(step_eager, 40, 5, world)
+        eager_ips = 40 / dte
+    step = step_graph if use_graph else step_eager
     dt = timed_region(step, steps, max(args.warmup, 10), world)
+    for k, v in graphs.items():
+        if isinstance(k, int):
+            v[0].release()
     ips = steps / dt
     tokens = float(np.mean([b.shape[0] * (b.shape[1] - 1) for b in batches]))
     return {
         "samples_per_step": c["batch"] * world, "dt": dt * args.steps / steps,     # main() divides by args.steps
         "config": {"workload": "examples/gpt.ipynb GPT (d512 L8 H8 d_ff2048 vocab15000, dropout 0.1, Adam 1.5e-4), batch 4 "
-                               "variable-length prompts (24-127 tokens, padded to the batch maximum), eager launches",
-                   "global_batch": c["batch"] * world, "parallelism": f"dp{world}", "launch": "eager"},
+                               "variable-length prompts (24-127 tokens, padded to the batch maximum)"
+                               + (", one captured hipGraph per padded length (multiples of 8)" if use_graph else ", eager launches"),
+                   "global_batch": c["batch"] * world, "parallelism": f"dp{world}",
+                   "launch": f"hipGraph replay, {len([k for k in graphs if isinstance(k, int)])} length buckets" if use_graph else "eager"},
         "roofline": {"kernel": "whole step (launch bound: ~" + str(int(tokens)) + " tokens per step)", "bound": "mfma",
                      "achieved": None, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None},
-        "extra": {"it_per_s": round(ips, 2), "timed_steps": steps, "mean_tokens_per_step": round(tokens, 1),
+        "extra": {"it_per_s": round(ips, 2), "it_per_s_eager": None if eager_ips is None else round(eager_ips, 2),
+                  "timed_steps": steps, "mean_tokens_per_step": round(tokens, 1),
                   "reference_it_per_s": list(NB_REFERENCE_IT_PER_S),
                   "vs_reference_notebook": round(ips / NB_REFERENCE_IT_PER_S[1], 1),
                   "reference_note": "examples/gpt.ipynb cell 16 (tqdm it/s of the CuPy path on an unnamed NVIDIA GPU, real "

@@ -374,6 +374,15 @@ int nnhipEmbeddingBackward(float* dW, const float* grad_out, const int32_t* ids,
 /* out[i] = (ids[i] != value) as int32: the key-padding mask of examples/gpt.ipynb cell 7 (get_pad_mask:
  * (x != pad_idx).astype(int)) without leaving the library (torch would run a compare and a cast kernel).  ABI 203 */
 int nnhipNotEqualInt32(int32_t* out, const int32_t* ids, int64_t n, int32_t value, nnhipStream_t stream);
+/* Dropout (neunet/nn/layers/dropout.py:17-37): out[i] = in[i] * m(i), m(i) = 1/(1-p) with probability 1-p, else 0, from a
+ * counter-based hash of (seed + *seed_dev, i) -- never stored: the backward pass calls the same entry with the upstream
+ * gradient as `in` (same seed) and gets dX = dY * m.  seed_dev (optional device uint32, e.g. a step counter) makes a
+ * captured hipGraph draw a fresh mask on every replay.  out may alias in.  ABI 203 */
+int nnhipDropout(float* out, const float* in, int64_t n, float p, uint32_t seed, const uint32_t* seed_dev,
+                 nnhipStream_t stream);
+/* *word += by (one thread): the per-step device counter that nnhipDropout / the attention kernels add to their dropout
+ * seed, advanced on the stream in front of a graph replay.  ABI 203 */
+int nnhipIncrementU32(uint32_t* word, uint32_t by, nnhipStream_t stream);
 
 /* ---- the rest of the conv-classifier step (examples/convolutional_digits_classifier.ipynb) ----
  * LeakyReLU (neunet/nn/activations.py:60-84): f = x <= 0 ? alpha*x : x ; dx = dy * (f <= 0 ? alpha : 1). */

@@ -310,6 +310,57 @@ extern "C" int nnhipFusedSwishAndMulBackward(float* dIn, const float* dOut, cons
     NNHIP_LAUNCH_CHECK("swiglu_bwd_kernel");
     return 0;
 }
+// ---- Dropout (neunet/nn/layers/dropout.py:17-37): out = in * mask, mask = Bernoulli(1 - p) / (1 - p) -------------------------
+// The mask is a counter-based hash of (seed [+ a device word], element index) -- the same construction as the fused
+// attention's dropout (attention.hip: at_hash) -- so it is never stored: the backward pass calls the same entry with the
+// upstream gradient as `in` and gets dX = dY * mask.  `seed_dev` (optional device uint32, e.g. the optimizer's step
+// counter) is added to the seed inside the kernel: a captured hipGraph then draws a fresh mask on every replay.
+// The reference draws its mask with the host NumPy RNG: streams cannot match, parity is tested with injected masks
+// (nnhipMul) and statistically (keep rate, scale, forward/backward consistency).
+__global__ __launch_bounds__(256) void dropout_hash_kernel(float* __restrict__ out, const float* __restrict__ in, int64_t n,
+                                                           unsigned seed, const unsigned* __restrict__ seed_dev, unsigned threshold,
+                                                           float scale, bool vec) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x, gsz = (int64_t)gridDim.x * 256;
+    const unsigned sd = (seed + (seed_dev ? __hip_atomic_load(seed_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u)) * 0x85EBCA6Bu + 0x9E3779B9u;
+    auto keep = [&](int64_t i) {
+        unsigned x = sd ^ ((unsigned)i * 0x9E3779B1u) ^ ((unsigned)(i >> 32) * 0xC2B2AE35u);
+        x ^= x >> 16; x *= 0x7FEB352Du;
+        x ^= x >> 15; x *= 0x846CA68Bu;
+        x ^= x >> 16;
+        return x >= threshold ? scale : 0.f;
+    };
+    if (vec) {
+        const int64_t nv = n >> 2;
+        for (int64_t i = gid; i < nv; i += gsz) {
+            const float4 x = reinterpret_cast<const float4*>(in)[i];
+            reinterpret_cast<float4*>(out)[i] = make_float4(x.x * keep(4 * i), x.y * keep(4 * i + 1), x.z * keep(4 * i + 2), x.w * keep(4 * i + 3));
+        }
+        for (int64_t i = (nv << 2) + gid; i < n; i += gsz) out[i] = in[i] * keep(i);
+    } else {
+        for (int64_t i = gid; i < n; i += gsz) out[i] = in[i] * keep(i);
+    }
+}
+extern "C" int nnhipDropout(float* out, const float* in, int64_t n, float p, uint32_t seed, const uint32_t* seed_dev,
+                            nnhipStream_t s) {
+    NNHIP_CHECK_ARG(n >= 0 && p >= 0.f && p <= 1.f, NNHIP_EINVAL, "nnhipDropout: need n >= 0 and 0 <= p <= 1");
+    if (n == 0) return 0;
+    NNHIP_PTRS("nnhipDropout", out, in);
+    const double th = (double)p * 4294967296.0;
+    const unsigned threshold = (unsigned)(th < 4294967295.0 ? th : 4294967295.0);
+    const float scale = p < 1.f ? 1.0f / (1.0f - p) : 0.f;
+    const bool vec = aligned16(out) && aligned16(in);
+    hipLaunchKernelGGL(dropout_hash_kernel, dim3(ew_blocks(vec ? (n >> 2) + 1 : n)), dim3(EW_THREADS), 0, (hipStream_t)s, out, in, n,
+                       (unsigned)seed, reinterpret_cast<const unsigned*>(seed_dev), threshold, scale, vec);
+    NNHIP_LAUNCH_CHECK("dropout_hash_kernel");
+    return 0;
+}
+__global__ void increment_u32_kernel(unsigned* p, unsigned by) { *p += by; }
+extern "C" int nnhipIncrementU32(uint32_t* word, uint32_t by, nnhipStream_t s) {
+    NNHIP_CHECK_ARG(word != nullptr, NNHIP_EINVAL, "nnhipIncrementU32: null pointer");
+    hipLaunchKernelGGL(increment_u32_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, reinterpret_cast<unsigned*>(word), (unsigned)by);
+    NNHIP_LAUNCH_CHECK("increment_u32_kernel");
+    return 0;
+}
 extern "C" int nnhipScale(float* x, float alpha, int64_t n, nnhipStream_t s) {
     NNHIP_CHECK_ARG(n >= 0, NNHIP_EINVAL, "nnhipScale: negative size");
     if (n == 0) return 0;

@@ -1387,6 +1387,11 @@ extern "C" int nnhipRMSNormBackwardEx(const float* dY, const float* X, const flo
     int64_t nblk = ceil_div(rows > 0 ? rows : 1, rpb);
     int slots = 1024;
     ROW_DISPATCH_SLOTS(rmsnorm_bwd_rows, cols, vec, slots);
+    {
+        static const double mult = []() { const char* e = getenv("NNHIP_RMS_GRID_MULT"); return e ? atof(e) : 1.0; }();
+        slots = (int)(slots * mult);
+        if (slots < 1) slots = 1;
+    }
     if (nblk > slots) nblk = slots;
     const size_t part_floats = ((size_t)nblk * cols + 3) / 4 * 4;
     float* part = static_cast<float*>(workspace(part_floats * (db ? 2 : 1) * sizeof(float)));

@@ -79,6 +79,8 @@ _SIGNATURES = {
     "nnhipEmbeddingForward": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, c_void_p]),
     "nnhipEmbeddingBackward": (ctypes.c_int, [P, P, P, c_int64, c_int64, c_int64, c_float, c_void_p]),
     "nnhipNotEqualInt32": (ctypes.c_int, [P, P, c_int64, ctypes.c_int32, c_void_p]),
+    "nnhipDropout": (ctypes.c_int, [P, P, c_int64, c_float, ctypes.c_uint32, P, c_void_p]),
+    "nnhipIncrementU32": (ctypes.c_int, [P, ctypes.c_uint32, c_void_p]),
     "nnhipMul": (ctypes.c_int, [P, P, P, c_int64, c_void_p]),
     "nnhipReLUForward": (ctypes.c_int, [P, P, c_int64, c_void_p]),
     "nnhipReLUBackward": (ctypes.c_int, [P, P, P, c_int64, c_void_p]),

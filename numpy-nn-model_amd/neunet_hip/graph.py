@@ -39,6 +39,32 @@ from .autograd import bump_param_epoch
 from .distributed import collectives_live
 
 
+def attach_step_seed(model):
+    """Give every dropout site of `model` (HIPDropout, the fused attention's in-kernel dropout) one shared device uint32 that
+    the kernels add to their seed; GraphedTrainStep(step_seed=...) advances it before every replay, so a captured step draws
+    fresh masks each time it runs.  Returns the tensor (int32 storage, read as uint32 by the kernels)."""
+    import torch
+    seed = torch.zeros(1, dtype=torch.int32, device="cuda")
+    seen, stack = set(), [model]
+    while stack:
+        m = stack.pop()
+        if id(m) in seen:
+            continue
+        seen.add(id(m))
+        if hasattr(m, "dropout_seed_dev"):
+            m.dropout_seed_dev = seed
+        if type(m).__name__ == "HIPDropout":
+            m.seed_dev = seed
+        for v in list(getattr(m, "__dict__", {}).values()):
+            if hasattr(v, "__dict__") and not isinstance(v, type) and hasattr(v, "forward"):
+                stack.append(v)
+            elif isinstance(v, (list, tuple)):
+                stack.extend(x for x in v if hasattr(x, "forward"))
+            elif hasattr(v, "modules") and isinstance(getattr(v, "modules"), (list, tuple)):
+                stack.extend(v.modules)
+    return seed
+
+
 class GraphedTrainStep:
     _live = 0          # captured steps alive in this process: the library workspace stays locked while > 0
     # Every capture is thread-local.  torch's default ("global") makes ANY thread's capture-unsafe HIP call fail while this
@@ -48,7 +74,7 @@ class GraphedTrainStep:
     _CAPTURE_MODE = "thread_local"
 
     def __init__(self, forward_backward, optimizer, bucket, warmup: int = 3, world: int = 1, pre_optim=None,
-                 group=None, check_every: int = 256, unroll: int = 1, capture_collectives: bool = False):
+                 group=None, check_every: int = 256, unroll: int = 1, capture_collectives: bool = False, step_seed=None):
         import torch
         self.fb, self.opt, self.bucket, self.world = forward_backward, optimizer, bucket, world
         self.pre_optim = pre_optim                    # host-side hook between exchange and optimizer (kept for callers)
@@ -62,6 +88,7 @@ class GraphedTrainStep:
         self.single = world == 1 and pre_optim is None and not collectives_live(self.group)
         self.unroll = max(1, int(unroll)) if self.single else 1
         self._torch = torch
+        self.step_seed = step_seed                    # attach_step_seed(model): advanced before every replay
         self._calls = 0
         self._check_every = max(1, int(check_every))
         s = torch.cuda.Stream()
@@ -201,6 +228,9 @@ class GraphedTrainStep:
     def __call__(self):
         self._calls += 1
         bump_param_epoch()
+        if self.step_seed is not None:
+            from ._lib import get_current_stream_ptr
+            call_hip_function("nnhipIncrementU32", self.step_seed, 1, get_current_stream_ptr())
         if self._calls <= 3 or self._calls % self._check_every == 0:
             if self._addresses() != self._addr:
                 raise RuntimeError("GraphedTrainStep: a parameter or gradient buffer moved since capture (p.data was "

@@ -4,6 +4,7 @@ the GPT step, examples/gpt.ipynb cells 5-6).
 Embedding: forward = weight[ids] (neunet/nn/layers/embedding.py:61-75); the gradient reproduces the
 reference's assignment semantics -- for repeated ids the LAST occurrence wins (neunet/autograd.py:905-912).
 `scale` and a positional-encoding table can be fused into the gather (cell 6: emb * sqrt(d) + pe[:, :T])."""
+import itertools
 import math
 
 import numpy as np
@@ -92,32 +93,47 @@ class _HIPDropoutTensor(Tensor):
                 X.apply_grad(grad)
                 return
             g = X.xp.empty_like(X.data)
-            call_hip_function("nnhipMul", g, grad if grad.is_contiguous() else grad.contiguous(), mask, g.numel(),
-                              get_current_stream_ptr())
+            grad = grad if grad.is_contiguous() else grad.contiguous()
+            if isinstance(mask, tuple):          # (p, seed, seed_dev): the hash mask is regenerated, never stored
+                p_, seed, seed_dev = mask
+                call_hip_function("nnhipDropout", g, grad, g.numel(), float(p_), int(seed), seed_dev, get_current_stream_ptr())
+            else:
+                call_hip_function("nnhipMul", g, grad, mask, g.numel(), get_current_stream_ptr())
             X.apply_grad(g)
 
         self.grad_fn = grad_fn
 
 
+_DROPOUT_SEEDS = itertools.count(1)
+
+
 class HIPDropout(Module):
     """neunet/nn/layers/dropout.py:17-37.  p == 0 or eval: identity (no kernel, no mask tensor).  p > 0 in
-    training: mask = Bernoulli(1-p)/(1-p) drawn with the device RNG (the reference draws it with the host
-    NumPy RNG, so streams cannot match; `forward(X, mask=...)` injects a mask for parity tests)."""
+    training: out = X * mask, mask = Bernoulli(1-p)/(1-p) from nnhipDropout's counter hash of (seed, element index) --
+    regenerated by the backward pass, never stored (the reference draws it with the host NumPy RNG, so streams cannot
+    match; `forward(X, mask=...)` injects a mask for parity tests).  Every call draws a new seed; `seed_dev` (an optional
+    device uint32 tensor, e.g. a per-step counter) is added to it inside the kernel, so a step replayed from a hipGraph
+    gets a fresh mask per replay."""
 
     def __init__(self, p: float = 0.5):
         super().__init__()
         self.p = p
         self.scale = 1 / (1 - p) if p < 1 else 0.0
+        self.seed_dev = None
+        self._base = (next(_DROPOUT_SEEDS) * 0x9E3779B9) & 0x7FFFFFFF
+        self._calls = 0
 
     def forward(self, X: Tensor, mask=None) -> Tensor:
-        import torch
         if mask is None and (not self.training or self.p == 0):
             return X
-        if mask is None:
-            mask = (torch.rand_like(X.data) >= self.p).to(torch.float32) * self.scale
         out = X.xp.empty_like(X.data)
-        call_hip_function("nnhipMul", out, X.data if X.data.is_contiguous() else X.data.contiguous(), mask,
-                          out.numel(), get_current_stream_ptr())
+        xd = X.data if X.data.is_contiguous() else X.data.contiguous()
+        if mask is None:
+            self._calls += 1
+            seed = (self._base + self._calls * 0x632BE5AB) & 0xFFFFFFFF
+            call_hip_function("nnhipDropout", out, xd, out.numel(), float(self.p), seed, self.seed_dev, get_current_stream_ptr())
+            return _HIPDropoutTensor(out, (X, (self.p, seed, self.seed_dev)), "dropout", device=X.device)
+        call_hip_function("nnhipMul", out, xd, mask, out.numel(), get_current_stream_ptr())
         return _HIPDropoutTensor(out, (X, mask), "dropout", device=X.device)
 
     def train(self, mode=True):

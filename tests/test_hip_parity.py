@@ -2540,3 +2540,84 @@ def test_dropout_mask_and_rng(hip):
     d.eval()
     x = T(hip, X)
     assert d(x) is x
+
+
+# ------------------------------------------------------------------------------------------ Dropout (device hash RNG)
+def test_dropout_hash_mask_statistics_and_backward(hip):
+    """HIPDropout with p > 0 (neunet/nn/layers/dropout.py:17-37): the mask is a counter hash of (seed, index), never stored.
+    Checked: every output is 0 or x/(1-p); the keep rate is 1-p within 4 sigma; the backward pass regenerates the SAME mask
+    (dx == dy * y/x); two calls draw different masks; a device seed word changes the mask without a new launch argument;
+    eval mode and p = 0 are the identity."""
+    import neunet_hip.nn as nn
+    rng = np.random.default_rng(12)
+    n, p = 1 << 18, 0.1
+    X = (rng.uniform(1.0, 2.0, (512, n // 512))).astype(np.float32)          # no zeros: y/x identifies the mask
+    dY = rng.standard_normal(X.shape).astype(np.float32)
+    drop = nn.Dropout(p)
+    x = T(hip, X)
+    y = drop(x)
+    Y = host(y.data)
+    m = Y / X
+    keep = m != 0
+    np.testing.assert_allclose(m[keep], 1.0 / (1.0 - p), rtol=1e-6)
+    rate = keep.mean()
+    assert abs(rate - (1 - p)) < 4 * np.sqrt(p * (1 - p) / n), rate
+    y.backward(dY)
+    np.testing.assert_allclose(host(x.grad), dY * m, rtol=1e-6, atol=0)
+    m2 = host(drop(T(hip, X)).data) / X
+    assert 0.15 < np.mean((m2 != 0) != keep) < 0.21                           # independent masks differ on 2 p (1-p) = 18 %
+    # rows of the mask are not copies of each other (the index enters the hash, not the column alone)
+    assert np.mean(keep[0] != keep[1]) > 0.1
+    seed = torch.zeros(1, dtype=torch.int32, device="cuda")
+    drop.seed_dev = seed
+    drop._calls = 100
+    a = host(drop(T(hip, X)).data)
+    drop._calls = 100                                                          # same host seed ...
+    seed.fill_(7)                                                              # ... different device word
+    b = host(drop(T(hip, X)).data)
+    assert 0.15 < np.mean((a != 0) != (b != 0)) < 0.21
+    drop.eval()
+    assert drop(x) is x
+    assert nn.Dropout(0.0)(x) is x
+
+
+def test_graphed_step_draws_fresh_dropout_masks(hip):
+    """A captured training step with dropout: GraphedTrainStep(step_seed=attach_step_seed(model)) advances the device seed
+    word before every replay, so two replays on the same input differ (a captured host seed alone would replay one mask)."""
+    import neunet_hip.nn as nn
+    from neunet_hip.distributed import GradBucket
+    from neunet_hip.graph import GraphedTrainStep, attach_step_seed
+    from neunet_hip.optim import Adam
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.l1 = nn.Linear(32, 64)
+            self.drop = nn.Dropout(0.5)
+            self.l2 = nn.Linear(64, 8)
+
+        def forward(self, x):
+            self.h = self.drop(self.l1(x))
+            return self.l2(self.h)
+
+    np.random.seed(3)
+    model = Net()
+    seed = attach_step_seed(model)
+    assert model.drop.seed_dev is seed
+    opt = Adam(model.parameters(), lr=0.0)                                     # lr 0: the parameters stay put, only the mask changes
+    xs = T(hip, np.random.default_rng(1).uniform(1, 2, (16, 32)).astype(np.float32), requires_grad=False)
+    ys = T(hip, np.zeros(16, np.int32), dtype=np.int32, requires_grad=False)
+    loss_fn = nn.CrossEntropyLoss()
+
+    def fb():
+        loss = loss_fn(model(xs), ys)
+        loss.backward()
+        return loss
+
+    step = GraphedTrainStep(fb, opt, GradBucket(model.parameters()), warmup=1, step_seed=seed)
+    step()
+    h1 = host(model.h.data).copy()
+    step()
+    h2 = host(model.h.data).copy()
+    step.release()
+    assert 0.3 < np.mean((h1 != 0) != (h2 != 0)) < 0.7
