@@ -1156,6 +1156,43 @@ def test_conv2d_vs_oracle(hip, xshape, cout, ks, stride, pad, dil):
     assert_close_scaled(host(layer.bias.grad), db)
 
 
+def test_conv2d_igemm_random_geometries(hip):
+    """The implicit-GEMM forward / dgrad kernels (channels > 16: block tiles of 32 / 64 / 128 channels x 256 pixels, scalar
+    (cs, r, s) counters, buffer-load gather with out-of-range offsets) on 24 random geometries -- kernel sizes 1..4, strides
+    1..3, dilations 1..2, asymmetric padding, channel counts on both sides of every tile edge -- against the oracle."""
+    from neunet_hip.nn.experimental import HIPConv2d
+    rng = np.random.default_rng(77)
+    done = 0
+    while done < 24:
+        cin, cout = int(rng.choice([17, 20, 31, 33, 48, 64, 65, 96, 130])), int(rng.choice([17, 24, 32, 40, 64, 72, 128, 129]))
+        kh, kw = int(rng.integers(1, 5)), int(rng.integers(1, 5))
+        sh, sw = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+        dh, dw = int(rng.integers(1, 3)), int(rng.integers(1, 3))
+        ph, pw = int(rng.integers(0, 3)), int(rng.integers(0, 3))
+        H, W = int(rng.integers(5, 15)), int(rng.integers(5, 15))
+        if H + 2 * ph < dh * (kh - 1) + 1 or W + 2 * pw < dw * (kw - 1) + 1:
+            continue
+        B = int(rng.integers(1, 4))
+        X = rng.uniform(-1, 1, (B, cin, H, W)).astype(np.float32)
+        layer = HIPConv2d(cin, cout, (kh, kw), (sh, sw), (ph, pw), (dh, dw))
+        Wt = host(layer.weight.data)
+        b = rng.uniform(-0.3, 0.3, cout).astype(np.float32)
+        layer.bias.data.copy_(dev(b))
+        x = T(hip, X)
+        y = layer(x)
+        Or = O.conv2d_forward(X, Wt, b, (sh, sw), (ph, pw), (dh, dw))
+        tag = f"cin {cin} cout {cout} k {kh}x{kw} s {sh},{sw} d {dh},{dw} p {ph},{pw} in {B}x{H}x{W}"
+        assert y.shape == Or.shape, tag
+        np.testing.assert_allclose(host(y.data), Or, err_msg=tag, **TOL)
+        dO = rng.uniform(-1, 1, Or.shape).astype(np.float32)
+        y.backward(dO)
+        dX, dW, db = O.conv2d_backward(X, Wt, True, dO, (sh, sw), (ph, pw), (dh, dw))
+        np.testing.assert_allclose(host(x.grad), dX, err_msg=tag, **TOL)
+        assert_close_scaled(host(layer.weight.grad), dW, err_msg=tag)
+        assert_close_scaled(host(layer.bias.grad), db, err_msg=tag)
+        done += 1
+
+
 # -------------------------------------------------------------------------------------- optimizers
 @pytest.mark.parametrize("name", ["adam_wd0", "adam_wd1e-2", "adamw_wd0", "adamw_wd1e-2"])
 @pytest.mark.parametrize("multi", [False, True])
