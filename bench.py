@@ -291,6 +291,8 @@ def workload_c1(args, rank, world):
     bucket = GradBucket(params)
     opt = Adam(params, lr=1e-3)
     opt.grad_scale = 1.0 / world
+    if world == 1 and os.environ.get("NNHIP_C1_FUSE_OPT", "1") != "0":
+        opt.fuse_backward(True)     # one process: the backward launch applies Adam itself (bit-identical to the separate launch)
     loss_fn = nn.CrossEntropyLoss()
     drng = np.random.default_rng(3000 + rank)
     U = graph_unroll(args, world)                        # steps per captured graph, each reading its own static batch slot

@@ -141,6 +141,22 @@ int nnhipLinearInputGradReLU(const float* dO, const float* W, const float* F, fl
 int nnhipLinearModuleBackwardAct(const float* X, const float* W, const float* dO, const float* act_arg, int32_t act_grad,
                                  float beta, float* dZ, float* dW, float* db, int64_t rows, int64_t in_features,
                                  int64_t out_features, nnhipStream_t stream);
+/* Backward of out = Linear2(relu(Linear1(X1))) when X1 needs no gradient (README quick-start MLP, README.md:57-71): dW2 =
+ * dO^T H, db2, dW1 = dZ^T X1, db1 with dZ = (dO W2) (.) [H > 0] formed inside the dW1 tiles (never written) -- ONE launch where
+ * nnhipLinearModuleBackwardAct + nnhipLinearModuleBackward take two dependent ones.  H = the ReLU output [rows, hidden].
+ * rows <= 256, out2 <= 16, small layers only: NNHIP_EINVAL otherwise (use the two calls).  ABI 203 */
+int nnhipLinearReLULinearBackward(const float* X1, const float* H, const float* W2, const float* dO, float* dW2, float* db2,
+                                  float* dW1, float* db1, int64_t rows, int64_t in1, int64_t hidden, int64_t out2,
+                                  nnhipStream_t stream);
+/* The same with the optimizer inside: every gradient element is handed to Adam / AdamW (neunet/optim.py:17-33, 52-69) by the
+ * thread that produced it -- the README-MLP step then has no optimizer launch.  Gradients are still written.  pmv: 12 device
+ * pointers {param, m, v} x {W2, b2, W1, b1}.  step >= 1: host stepping; step == 0: device stepping through `opt`
+ * (nnhipCreateFusedOptimizer + SetStep / SetHyper).  Hyper-parameters as nnhipFusedAdamWMultiTensorStep.  ABI 203 */
+int nnhipLinearReLULinearBackwardAdam(const float* X1, const float* H, const float* W2, const float* dO, float* dW2, float* db2,
+                                      float* dW1, float* db1, int64_t rows, int64_t in1, int64_t hidden, int64_t out2,
+                                      void* opt, float* const* pmv, double lr, double beta1, double beta2, double eps,
+                                      double weight_decay, int32_t step, int32_t decay_mode, float grad_scale,
+                                      nnhipStream_t stream);
 /* O = act(X*W^T + b), activation in the GEMM epilogue: 1 = swish(beta) without saving z, 2 = relu, 3 = sigmoid.
  * One launch for what `act(Linear(x))` is on the reference's tape (linear.py:48-58 + activations.py); the host side
  * uses it when an activation module is applied to a Linear output nobody else has looked at yet. */

@@ -62,9 +62,15 @@ __device__ __forceinline__ float4 sg_fetch(__amdgpu_buffer_rsrc_t rs, unsigned l
 // against 4.5 now: tools/probes/small_gemm_phases.hip keeps both layouts side by side.)
 // U k-groups (2U float4 of operands) are in flight per wave before the first MFMA.
 typedef float sg_f32x4 __attribute__((ext_vector_type(4)));
-template <int NW, bool AKM, bool BKM, bool VEC, int U>
+// POST: called as post(c_index, value) after every C store and post.asum(row, value) after every asum store -- how a caller
+// applies an optimizer update to the element it has just produced (gemm_small.hip: the README-MLP backward with Adam inside).
+struct SgNoPost {
+    __device__ __forceinline__ void operator()(int64_t, float) const {}
+    __device__ __forceinline__ void asum(int64_t, float) const {}
+};
+template <int NW, bool AKM, bool BKM, bool VEC, int U, class POST = SgNoPost>
 __device__ __forceinline__ void sg_tile16(const SmallGemmParams& p, int bx, int by, float (*red)[16 * 16], float (*ared)[16],
-                                          float* lds_copy = nullptr) {   // lds_copy: also keep C[row][col] at lds_copy[row * 32 + col]
+                                          float* lds_copy = nullptr, POST post = POST()) {   // lds_copy: also keep C[row][col] at lds_copy[row * 32 + col]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l16 = lane & 15, kq = lane >> 4;
     const int64_t m0 = (int64_t)by * 16, n0 = (int64_t)bx * 16;
@@ -125,6 +131,7 @@ __device__ __forceinline__ void sg_tile16(const SmallGemmParams& p, int bx, int 
                 v = sigmoid_fast_(v);
             }
             p.C[row * p.ldc + col] = v;
+            post(row * p.ldc + col, v);
             if (lds_copy) lds_copy[row * 32 + col] = v;
         }
     }
@@ -132,7 +139,7 @@ __device__ __forceinline__ void sg_tile16(const SmallGemmParams& p, int bx, int 
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) s += ared[w][tid];
-        if (m0 + tid < p.M) p.asum[m0 + tid] = s;
+        if (m0 + tid < p.M) { p.asum[m0 + tid] = s; post.asum(m0 + tid, s); }
     }
 }
 

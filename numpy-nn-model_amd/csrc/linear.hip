@@ -19,6 +19,14 @@ int gemm_f32_asum(const float* A, const float* B, float* C, float* asum, int64_t
 int gemm_f32_linear_backward_small(const float* X, const float* W, const float* dO, float* dX, float* dW, float* db, int64_t rows,
                                    int64_t in, int64_t out, const float* addend, const float* dact_arg, int dact, float beta,
                                    hipStream_t st);
+struct SmallMlpAdam;
+int gemm_small_mlp_backward(const float* X1, const float* H, const float* W2, const float* dO, float* dW2, float* db2, float* dW1,
+                            float* db1, int64_t rows, int64_t in1, int64_t hid, int64_t out2, hipStream_t st,
+                            const SmallMlpAdam* adam);
+int gemm_small_mlp_backward_adam(const float* X1, const float* H, const float* W2, const float* dO, float* dW2, float* db2, float* dW1,
+                                 float* db1, int64_t rows, int64_t in1, int64_t hid, int64_t out2, void* opt, float* const* pmv,
+                                 double lr, double b1, double b2, double eps, double wd, int step, int decay_mode, float grad_scale,
+                                 hipStream_t st);
 int colsum(const float* X, int64_t rows, int64_t cols, int64_t ld, float* out, hipStream_t st);
 int swish_backward_inplace(float* z_inout, const float* dY, float beta, int64_t n, hipStream_t st);
 int fill_f32(float* p, float v, int64_t n, hipStream_t st);
@@ -187,4 +195,54 @@ extern "C" int nnhipLinearInputGradReLU(const float* dO, const float* W, const f
                     "nnhipLinearInputGradReLU: misaligned pointer");
     return gemm_f32_drelu(dO, W, dZ, F, rows, in_features, out_features, out_features, in_features, in_features, true, false,
                           (hipStream_t)stream);
+}
+
+// Backward of out = Linear2(relu(Linear1(X1))) for an input X1 that needs no gradient (the first layer of a model): dW2, db2,
+// dW1, db1 from dO, with the hidden gradient dZ = (dO W2) (.) [H > 0] formed inside the dW1 tiles and never written.  H = the
+// ReLU output.  Small problems only (rows <= 256, out2 <= 16, both weight gradients within gemm_small's range): returns
+// NNHIP_EINVAL otherwise -- callers fall back to nnhipLinearModuleBackwardAct + nnhipLinearModuleBackward, which compute the
+// same four tensors (dW1 / db1 up to the summation order of dZ's dot products).
+extern "C" int nnhipLinearReLULinearBackward(const float* X1, const float* H, const float* W2, const float* dO, float* dW2,
+                                             float* db2, float* dW1, float* db1, int64_t rows, int64_t in1, int64_t hidden,
+                                             int64_t out2, nnhipStream_t stream) {
+    NNHIP_CHECK_ARG(rows >= 0 && in1 > 0 && hidden > 0 && out2 > 0, NNHIP_EINVAL, "nnhipLinearReLULinearBackward: bad sizes");
+    NNHIP_CHECK_ARG(dW2 && db2 && dW1 && db1, NNHIP_EINVAL, "nnhipLinearReLULinearBackward: null output");
+    NNHIP_CHECK_ARG(rows == 0 || (X1 && H && W2 && dO), NNHIP_EINVAL, "nnhipLinearReLULinearBackward: null input");
+    NNHIP_CHECK_ARG(aligned4(X1) && aligned4(H) && aligned4(W2) && aligned4(dO) && aligned4(dW2) && aligned4(db2) && aligned4(dW1) &&
+                        aligned4(db1), NNHIP_EALIGN, "nnhipLinearReLULinearBackward: misaligned pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (rows == 0) {
+        int rc = fill_f32(dW2, 0.f, out2 * hidden, st);
+        if (!rc) rc = fill_f32(db2, 0.f, out2, st);
+        if (!rc) rc = fill_f32(dW1, 0.f, hidden * in1, st);
+        if (!rc) rc = fill_f32(db1, 0.f, hidden, st);
+        return rc;
+    }
+    const int rc = gemm_small_mlp_backward(X1, H, W2, dO, dW2, db2, dW1, db1, rows, in1, hidden, out2, st, nullptr);
+    if (rc < 0) return rc;
+    NNHIP_CHECK_ARG(rc == 1, NNHIP_EINVAL, "nnhipLinearReLULinearBackward: outside the small-problem range (rows <= 256, out2 <= 16)");
+    return 0;
+}
+
+// The same backward with the optimizer inside ("optimizer in backward"): every gradient element is handed to Adam / AdamW
+// (neunet/optim.py:17-33, 52-69) by the thread that produced it, so the README-MLP step needs no optimizer launch.  The
+// gradients are still written (param.grad semantics).  pmv: 12 device pointers, {param, m, v} for W2, b2, W1, b1 in that order.
+// step >= 1: host-side stepping (the caller's optimizer.t + 1); step == 0: device-side stepping through `opt` (a handle from
+// nnhipCreateFusedOptimizer with SetStep / SetHyper done), which is what a captured hipGraph needs.  Hyper-parameters as in
+// nnhipFusedAdamWMultiTensorStep.  rows >= 1 (an empty batch has nothing to fuse: call the optimizer).
+extern "C" int nnhipLinearReLULinearBackwardAdam(const float* X1, const float* H, const float* W2, const float* dO, float* dW2,
+                                                 float* db2, float* dW1, float* db1, int64_t rows, int64_t in1, int64_t hidden,
+                                                 int64_t out2, void* opt, float* const* pmv, double lr, double beta1, double beta2,
+                                                 double eps, double weight_decay, int32_t step, int32_t decay_mode,
+                                                 float grad_scale, nnhipStream_t stream) {
+    NNHIP_CHECK_ARG(rows >= 1 && in1 > 0 && hidden > 0 && out2 > 0 && step >= 0, NNHIP_EINVAL, "nnhipLinearReLULinearBackwardAdam: bad sizes");
+    NNHIP_CHECK_ARG(decay_mode == 0 || decay_mode == 1, NNHIP_EINVAL, "nnhipLinearReLULinearBackwardAdam: decay_mode must be 0 or 1");
+    NNHIP_CHECK_ARG(X1 && H && W2 && dO && dW2 && db2 && dW1 && db1 && pmv, NNHIP_EINVAL, "nnhipLinearReLULinearBackwardAdam: null pointer");
+    for (int i = 0; i < 12; ++i) NNHIP_CHECK_ARG(pmv[i] != nullptr && aligned4(pmv[i]), NNHIP_EINVAL, "nnhipLinearReLULinearBackwardAdam: null / misaligned optimizer tensor");
+    NNHIP_CHECK_ARG(pmv[0] == W2, NNHIP_EINVAL, "nnhipLinearReLULinearBackwardAdam: pmv[0] must be W2 (order: W2, b2, W1, b1)");
+    const int rc = gemm_small_mlp_backward_adam(X1, H, W2, dO, dW2, db2, dW1, db1, rows, in1, hidden, out2, opt, pmv, lr, beta1, beta2, eps,
+                                                weight_decay, step, decay_mode, grad_scale, (hipStream_t)stream);
+    if (rc < 0) return rc;
+    NNHIP_CHECK_ARG(rc == 1, NNHIP_EINVAL, "nnhipLinearReLULinearBackwardAdam: outside the small-problem range (rows <= 256, out2 <= 16)");
+    return 0;
 }

@@ -5,45 +5,10 @@
 
 #include <vector>
 
+#include "adam_device.h"
 #include "common.h"
 
 namespace nnhip {
-
-struct AdamHyper {
-    float lr, b1, b2, one_m_b1, one_m_b2, eps, wd, bc1, bc2, grad_scale;
-    int decay_mode;  // 0 decoupled (AdamW), 1 L2-on-grad (Adam)
-};
-
-static AdamHyper make_hyper(double lr, double b1, double b2, double eps, double wd, int step, int mode,
-                            float grad_scale) {
-    AdamHyper h;
-    // NumPy weak-scalar promotion: every python-double hyper-parameter is rounded to fp32 at the point
-    // it meets an fp32 array -- (1 - beta) is formed in double FIRST, then rounded.
-    h.lr = (float)lr; h.b1 = (float)b1; h.b2 = (float)b2; h.eps = (float)eps; h.wd = (float)wd;
-    h.grad_scale = grad_scale;
-    h.one_m_b1 = (float)(1.0 - b1);
-    h.one_m_b2 = (float)(1.0 - b2);
-    // bias corrections in double on the host, as the CPU path's python floats (optim.py:30-31);
-    // the reference kernel used powf in-kernel (fused_adamw_multitensor.cu:145-146)
-    h.bc1 = (float)(1.0 - pow(b1, (double)step));
-    h.bc2 = (float)(1.0 - pow(b2, (double)step));
-    h.decay_mode = mode;
-    return h;
-}
-
-__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, const AdamHyper& h) {
-    g *= h.grad_scale;
-    if (h.decay_mode == 1) {
-        g = g + h.wd * p;                 // optim.py:24-25
-    } else if (h.wd != 0.f) {
-        p = p - h.lr * h.wd * p;          // optim.py:59-60
-    }
-    m = h.b1 * m + h.one_m_b1 * g;        // optim.py:63
-    v = h.b2 * v + h.one_m_b2 * (g * g);  // optim.py:64
-    const float mh = m / h.bc1;
-    const float vh = v / h.bc2;
-    p = p - h.lr * mh / (sqrtf(vh) + h.eps);  // optim.py:69
-}
 
 __device__ __forceinline__ void adam_span(float* __restrict__ p, const float* __restrict__ g,
                                           float* __restrict__ m, float* __restrict__ v, int64_t n,
@@ -104,28 +69,7 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const unsigned char* _
     // next launch starts with clean caches.  The bias corrections of this step were left in dev_state by the previous step's
     // last block; only the first step after SetStep, or a change of the betas, computes the two double-precision pow()s here.
     __shared__ float sh[5];
-    if (dev_state || grad_div) {
-        if (threadIdx.x == 0) {
-            float gs = h.grad_scale;
-            if (dev_state) {
-                const float4 s0 = *reinterpret_cast<const float4*>(dev_state);        // step, lr, grad_scale, ticket
-                const float4 s1 = *reinterpret_cast<const float4*>(dev_state + 4);    // wd, bc_step, bc1, bc2
-                const float2 s2 = *reinterpret_cast<const float2*>(dev_state + 8);    // the betas bc1 / bc2 were computed for
-                const int step = __float_as_int(s0.x) + 1;
-                const bool cached = __float_as_int(s1.y) == step && s2.x == (float)b1 && s2.y == (float)b2;
-                sh[0] = cached ? s1.z : (float)(1.0 - pow(b1, (double)step));
-                sh[1] = cached ? s1.w : (float)(1.0 - pow(b2, (double)step));
-                sh[2] = s0.y;
-                sh[4] = s1.x;
-                gs = s0.z;
-            }
-            if (grad_div) gs = gs / grad_div[0];
-            sh[3] = gs;
-        }
-        __syncthreads();
-        if (dev_state) { h.bc1 = sh[0]; h.bc2 = sh[1]; h.lr = sh[2]; h.wd = sh[4]; }
-        h.grad_scale = sh[3];
-    }
+    adam_dev_begin(h, dev_state, b1, b2, grad_div, sh);
     float* const* P = reinterpret_cast<float* const*>(blob);
     const float* const* G = reinterpret_cast<const float* const*>(blob + sizeof(void*) * n);
     float* const* M = reinterpret_cast<float* const*>(blob + sizeof(void*) * 2 * n);
@@ -145,22 +89,7 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const unsigned char* _
     const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) |
                        reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15u) == 0;
     adam_span(p, g, m, v, cnt, threadIdx.x, 256, vec, h);
-    if (dev_state) {
-        __syncthreads();                                   // this block's reads of the step are long done
-        if (threadIdx.x == 0) {
-            int* si = reinterpret_cast<int*>(dev_state);
-            if (atomicAdd(&si[3], 1) == nblk - 1) {        // last block to finish
-                const int next = si[0] + 2;                // the step after the one that now ends
-                si[3] = 0;
-                si[0] = next - 1;
-                dev_state[6] = (float)(1.0 - pow(b1, (double)next));
-                dev_state[7] = (float)(1.0 - pow(b2, (double)next));
-                dev_state[8] = (float)b1;
-                dev_state[9] = (float)b2;
-                si[5] = next;
-            }
-        }
-    }
+    adam_dev_finish(dev_state, nblk, b1, b2);
 }
 
 // Host object behind CreateFusedOptimizer (replaces the reference's C++ FusedOptimizer,
@@ -214,6 +143,22 @@ extern "C" int nnhipFusedAdamWStep(float* p, const float* g, float* m, float* v,
     NNHIP_LAUNCH_CHECK("adamw_kernel");
     return 0;
 }
+
+namespace nnhip {
+// For kernels that apply the update in their own epilogue: the device state / gradient divisor of an optimizer handle.
+// step == 0 = device-driven stepping (needs SetStep + SetHyper first).  Returns 0 or an NNHIP_E* code.
+int fused_optimizer_state(void* opt, int step, float** dev_state, const float** grad_div) {
+    *dev_state = nullptr; *grad_div = nullptr;
+    if (!opt) return step == 0 ? NNHIP_EINVAL : 0;
+    FusedOptimizer* fo = static_cast<FusedOptimizer*>(opt);
+    *grad_div = fo->grad_div;
+    if (step == 0) {
+        if (!fo->dev_state || !fo->hyper_set) { set_last_error("fused optimizer: step == 0 needs nnhipFusedOptimizerSetStep and SetHyper first"); return NNHIP_EINVAL; }
+        *dev_state = fo->dev_state;
+    }
+    return 0;
+}
+}  // namespace nnhip
 
 extern "C" void* nnhipCreateFusedOptimizer(void) { return new (std::nothrow) FusedOptimizer(); }
 

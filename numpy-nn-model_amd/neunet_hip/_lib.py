@@ -54,6 +54,10 @@ _SIGNATURES = {
     "nnhipLinearModuleBackward": (ctypes.c_int, [P, P, P, P, P, P, c_int64, c_int64, c_int64, c_void_p]),
     "nnhipLinearInputGradSwish": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_float, c_void_p]),
     "nnhipLinearInputGradReLU": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_void_p]),
+    "nnhipLinearReLULinearBackward": (ctypes.c_int, [P, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_void_p]),
+    "nnhipLinearReLULinearBackwardAdam": (ctypes.c_int, [P, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_void_p,
+                                                          ctypes.POINTER(c_void_p), ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                                                          ctypes.c_double, ctypes.c_double, ctypes.c_int32, ctypes.c_int32, c_float, c_void_p]),
     "nnhipLinearModuleBackwardAct": (ctypes.c_int, [P, P, P, P, c_int32, c_float, P, P, P, c_int64, c_int64, c_int64, c_void_p]),
     "nnhipLinearActivationForward": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_int32, c_float, c_void_p]),
     "nnhipLinearModuleForwardEx": (ctypes.c_int, [P, P, P, P, P, c_int64, c_int64, c_int64, c_void_p]),

@@ -279,6 +279,9 @@ class Tensor:
                 if isinstance(child, Tensor):
                     child._consumers += 1
         for v in reversed(tape):
+            if getattr(v, "_bwd_done", False):      # a consumer's fused backward already produced this node's gradients
+                v._bwd_done = False                 # (experimental/linear.py: Linear2(relu(Linear1(x))) in one launch)
+                continue
             v.grad_fn(*v.args, grad=v.grad)
 
     # ---- the few shape / scalar ops callers of the hot path need ----------------------------------------

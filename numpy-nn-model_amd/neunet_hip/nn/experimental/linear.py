@@ -5,6 +5,7 @@ N-D inputs are flattened to rows = prod(shape[:-1]) exactly like the reference's
 (linear.py:193), which equals the CPU path's batched-dW-then-reverse-broadcast result
 (neunet/nn/layers/linear.py:17-24 + autograd.py:948-962).
 """
+import ctypes
 import os
 from typing import Union
 
@@ -13,6 +14,7 @@ import numpy as np
 from ...autograd import Tensor, param_epoch
 from ..modules import Module
 from ..parameter import Parameter
+from ..._lib import NeunetHipError
 from .utils import call_hip_function, get_current_stream_ptr
 
 
@@ -68,6 +70,50 @@ def _plan_fold(X):
     return None
 
 
+_MLP_CHAIN = os.environ.get("NNHIP_MLP_CHAIN", "1") != "0"
+
+
+def _mlp_chain_backward(relu_t, w2, b2, grad, rows, hid, out2):
+    """Linear2(relu(Linear1(x))) with x needing no gradient (the README quick-start MLP): dW2, db2, dW1, db1 from ONE launch
+    (nnhipLinearReLULinearBackward) -- the hidden gradient dZ is formed inside the dW1 tiles and never written, and the ReLU /
+    Linear1 tape nodes are marked done.  Returns False when the pattern or the sizes do not fit (caller takes the general path)."""
+    if not _LAZY or not _MLP_CHAIN or out2 > 16 or rows > 256:
+        return False
+    lin1 = relu_t.args[0]
+    if not isinstance(lin1, _HIPLinearTensor) or lin1.op != "linear" or lin1.grad is not None or getattr(lin1, "_consumers", 0) != 1:
+        return False
+    x1, w1, b1, rows1, in1, hid1, residual = lin1.args
+    if residual is not None or b1 is None or hid1 != hid or rows1 != rows or (isinstance(x1, Tensor) and x1.requires_grad):
+        return False
+    if any(getattr(p, "_grad_hook", None) is not None for p in (w1, b1, w2, b2)):
+        return False
+    if in1 * hid > (1 << 21) or rows * in1 > (1 << 22):       # the small-problem kernels' range (gemm_small_wanted)
+        return False
+    f_x = relu_t.args[1]
+    gw2, gb2 = _grad_out(w2, w2.data), _grad_out(b2, b2.data)
+    gw1, gb1 = _grad_out(w1, w1.data), _grad_out(b1, b1.data)
+    # optimizer.fuse_backward(): the same launch also applies Adam to the four parameters (when they are ALL the optimizer has)
+    fo = getattr(w2, "_fused_opt", None)
+    upd = fo[0].backward_update_args([w2, b2, w1, b1]) if fo is not None and all(p_.grad is None for p_ in (w1, b1, w2, b2)) else None
+    try:
+        if upd is not None:
+            opt_ptr, table, lr, be1, be2, eps, wd, step, mode, gscale = upd
+            call_hip_function("nnhipLinearReLULinearBackwardAdam", x1.data, f_x, w2.data, grad, gw2, gb2, gw1, gb1, rows, in1, hid,
+                              out2, opt_ptr, ctypes.cast(table, ctypes.POINTER(ctypes.c_void_p)), lr, be1, be2, eps, wd, step, mode,
+                              gscale, get_current_stream_ptr())
+            fo[0]._stepped_in_backward = True
+        else:
+            call_hip_function("nnhipLinearReLULinearBackward", x1.data, f_x, w2.data, grad, gw2, gb2, gw1, gb1, rows, in1, hid, out2,
+                              get_current_stream_ptr())
+    except NeunetHipError:                                     # outside the kernel's range: the general path computes the same
+        return False
+    for p_, g_ in ((w2, gw2), (b2, gb2), (w1, gw1), (b1, gb1)):
+        _finish_param(p_, g_)
+    relu_t._bwd_done = True
+    lin1._bwd_done = True
+    return True
+
+
 def _commit_fold(X, dz):
     """Hand dz to the activation's node marked as 'already the gradient of its input'."""
     X.grad = dz.reshape(X.data.shape)
@@ -110,6 +156,9 @@ class _HIPLinearTensor(Tensor):
             grad_weight = _grad_out(weight, weight.data)
             grad_bias = _grad_out(bias, bias.data) if bias is not None else None
             hook = getattr(weight, "_grad_hook", None)
+            if folded and hook is None and plan[0] == 2 and bias is not None and _mlp_chain_backward(X, weight, bias, grad,
+                                                                                                       in_rows_num, in_features, out_features):
+                return
             if folded and hook is None:
                 # dz, dW and db from one C call (one LAUNCH for a small layer)
                 kind, arg, dz, beta = plan

@@ -80,6 +80,42 @@ class HIPFusedMultiTensorAdamW:
         self.c_exp_avgs = (c_void_p * n)()
         self.c_exp_avg_sqs = (c_void_p * n)()
         self.c_sizes = (c_int64 * n)()
+        self._in_backward = False     # fuse_backward(): the layers' backward kernels apply the update themselves when they can
+        self._stepped_in_backward = False
+
+    def fuse_backward(self, enable: bool = True):
+        """"Optimizer in backward" (extension; single process only): a backward kernel that produces ALL of this optimizer's
+        gradients may apply the Adam update in its own epilogue -- today the README quick-start MLP's one-launch backward
+        (experimental/linear.py: _mlp_chain_backward -> nnhipLinearReLULinearBackwardAdam).  step() then launches nothing for
+        that iteration.  Same arithmetic, same results; call step() after every backward() (no gradient accumulation across
+        backward passes, no all-reduce between them -- a GradBucket with hooks keeps the ordinary path)."""
+        self._in_backward = bool(enable)
+        for i, p in enumerate(self.params):
+            if enable:
+                p._fused_opt = (self, i)
+            elif hasattr(p, "_fused_opt"):
+                del p._fused_opt
+
+    def backward_update_args(self, params):
+        """For a fused backward kernel: (optimizer handle, pointer table {p, m, v} x params, hyper-parameters, step) if `params`
+        are exactly this optimizer's parameters and nothing stands in the way; else None."""
+        if not self._in_backward or self._stepped_in_backward or self.grad_divisor is not None:
+            return None
+        from .distributed import collectives_live
+        if collectives_live():                 # data parallel: the gradients have to meet the other ranks' first
+            return None
+        if len(params) != len(self.params) or any(getattr(p, "_fused_opt", (None,))[0] is not self for p in params):
+            return None
+        table = (c_void_p * (3 * len(params)))()
+        for k, p in enumerate(params):
+            i = p._fused_opt[1]
+            if not p.data.is_contiguous():
+                return None
+            table[3 * k], table[3 * k + 1], table[3 * k + 2] = p.data.data_ptr(), self.m[i].data_ptr(), self.v[i].data_ptr()
+        if self.device_step:
+            self.sync_device_hyper()
+        return (self.opt_ptr, table, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                0 if self.device_step else self.t + 1, self.decay_mode, self.grad_scale)
 
     def __del__(self):
         ptr = getattr(self, "opt_ptr", None)
@@ -93,6 +129,9 @@ class HIPFusedMultiTensorAdamW:
     def step(self):
         self.t += 1
         bump_param_epoch()        # parameters change in place: deferred Linear outputs of this step are now stale
+        if self._stepped_in_backward:          # a fused backward kernel already applied this step's update (fuse_backward)
+            self._stepped_in_backward = False
+            return
         idx = 0
         keep = []        # contiguous copies of strided gradients must outlive the single launch below: a freed block
         #                  could be handed to the next .contiguous() and two table entries would alias one buffer

@@ -469,6 +469,119 @@ def test_rmsnorm_backward_addend(hip, rows, cols):
     assert_close_scaled(host(norm.weight.grad), dw)
 
 
+@pytest.mark.parametrize("rows,inf,hid,outf", [(32, 784, 128, 10), (37, 50, 33, 7), (256, 300, 64, 16), (5, 16, 16, 1)])
+def test_mlp_chain_backward_one_launch(hip, rows, inf, hid, outf):
+    """Linear2(relu(Linear1(x))) with x needing no gradient: nnhipLinearReLULinearBackward produces dW2, db2, dW1, db1 in one
+    launch (dZ formed inside the dW1 tiles).  Against the oracle, and against the general two-launch path (NNHIP_MLP_CHAIN off):
+    dW2 / db2 bit-identical (same tile code), dW1 / db1 to 1e-6 (dZ's 10-term dot products are summed in a different order)."""
+    from neunet_hip.nn.experimental import HIPLinear, HIPReLU
+    from neunet_hip.nn.experimental import linear as L
+    rng = np.random.default_rng(rows + hid)
+    X = rng.uniform(-1, 1, (rows, inf)).astype(np.float32)
+    dY = rng.standard_normal((rows, outf)).astype(np.float32)
+    l1, l2, relu = HIPLinear(inf, hid), HIPLinear(hid, outf), HIPReLU()
+    W1, b1, W2, b2 = (host(t.data) for t in (l1.weight, l1.bias, l2.weight, l2.bias))
+    res = {}
+    for chain in (True, False):
+        old, L._MLP_CHAIN = L._MLP_CHAIN, chain
+        try:
+            for t in (l1.weight, l1.bias, l2.weight, l2.bias):
+                t.grad = None
+            x = T(hip, X, requires_grad=False)
+            y = l2(relu(l1(x)))
+            n0 = None
+            y.backward(dY)
+            res[chain] = [host(t.grad).copy() for t in (l1.weight, l1.bias, l2.weight, l2.bias)]
+        finally:
+            L._MLP_CHAIN = old
+    z = O.linear_forward(X, W1, b1)
+    h = O.relu_forward(z)
+    dh, dW2, db2 = O.linear_backward(h, W2, b2, dY)
+    dz = O.relu_backward(h, dh)
+    _, dW1, db1 = O.linear_backward(X, W1, b1, dz)
+    for got, ref in zip(res[True], (dW1, db1, dW2, db2)):
+        assert_close_scaled(got, ref)
+    np.testing.assert_array_equal(res[True][2], res[False][2])
+    np.testing.assert_array_equal(res[True][3], res[False][3])
+    assert_close_scaled(res[True][0], res[False][0], tol=1e-5)
+    assert_close_scaled(res[True][1], res[False][1], tol=1e-5)
+    # with an input that DOES need its gradient the chain must not be taken (dX1 would be missing)
+    x = T(hip, X)
+    for t in (l1.weight, l1.bias, l2.weight, l2.bias):
+        t.grad = None
+    l2(relu(l1(x))).backward(dY)
+    np.testing.assert_allclose(host(x.grad), O.linear_backward(X, W1, b1, dz)[0], **TOL)
+
+
+@pytest.mark.parametrize("graphed", [False, True])
+@pytest.mark.parametrize("opt_name", ["Adam", "AdamW"])
+def test_mlp_optimizer_in_backward_is_bit_identical(hip, graphed, opt_name):
+    """optimizer.fuse_backward(): the README quick-start MLP's one-launch backward also applies Adam / AdamW to the four
+    parameters (W1 / b1 by the thread that produced the gradient element; W2 / b2 -- inputs of the same launch -- by the last
+    block to finish, from agent-scope published gradients).  Same arithmetic on the same gradients: parameters, m, v and the
+    gradients after 5 steps (an LR change in between) are BIT-IDENTICAL to the separate optimizer launch, eager and replayed."""
+    import neunet_hip.nn as nn
+    from neunet_hip import optim
+    from neunet_hip.distributed import GradBucket
+    from neunet_hip.graph import GraphedTrainStep
+    rng = np.random.default_rng(8)
+    Xs = rng.uniform(-1, 1, (6, 32, 784)).astype(np.float32)
+    Ys = rng.integers(0, 10, (6, 32)).astype(np.int32)
+
+    def run(fuse):
+        np.random.seed(11)
+
+        class MLP(nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.l1, self.relu, self.l2 = nn.Linear(784, 128), nn.ReLU(), nn.Linear(128, 10)
+
+            def forward(self, x):
+                return self.l2(self.relu(self.l1(x)))
+
+        model = MLP()
+        ps = model.parameters()
+        opt = getattr(optim, opt_name)(ps, lr=1e-3, weight_decay=1e-2)
+        if fuse:
+            opt.fuse_backward(True)
+        x = T(hip, Xs[0], requires_grad=False)
+        y = T(hip, Ys[0], dtype=np.int32, requires_grad=False)
+        loss_fn = nn.CrossEntropyLoss()
+
+        def fb():
+            loss = loss_fn(model(x), y)
+            loss.backward()
+            return loss
+
+        step = None
+        if graphed:
+            step = GraphedTrainStep(fb, opt, GradBucket(ps), warmup=1)
+        losses = []
+        for s_ in range(5):
+            x.data.copy_(dev(Xs[s_ + 1]))
+            y.data.copy_(dev(Ys[s_ + 1]))
+            if s_ == 3:
+                opt.lr = 5e-4
+            if graphed:
+                losses.append(step().item())
+            else:
+                opt.zero_grad()
+                losses.append(fb().item())
+                opt.step()
+        out = [host(p.data).copy() for p in ps] + [host(m).copy() for m in opt.m] + [host(v).copy() for v in opt.v] + \
+              [host(p.grad).copy() for p in ps]
+        if graphed:
+            step.release()
+        return out, losses, opt.t
+
+    a, la, ta = run(True)
+    b, lb, tb = run(False)
+    assert ta == tb
+    assert la == lb
+    for u, v in zip(a, b):
+        np.testing.assert_array_equal(u, v)
+
+
 def test_deferred_linear_output_read_late(hip):
     """A Linear output whose GEMM rode in its activation's launch is still pending.  Read within the same step it is
     z = XW^T + b of the forward-time operands (the reference's eager Linear holds exactly that,
