@@ -36,6 +36,12 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // Grow-only per-process device workspace (split-K slabs, column-sum partials).  Freed by
 // nnhipCleanup().  Growing it synchronises the device (hipFree) -- it happens at most a few times.
 void* workspace(size_t bytes);
+// one deferred parameter-gradient GEMM (gemm.hip: gemm_f32_wgrad_group): C[M,N] = A^T B with A [K, M] and B [K, N] dense
+struct WgradJob {
+    const float* A; const float* B; float* C; float* asum;
+    int64_t M, N, K;
+};
+
 // 256 bytes of device zeros, allocated once per process (never freed): where out-of-range GEMM lanes load from.
 const float* zero_block();
 // Library-owned, zero-initialised device words for in-launch arrival tickets (kSyncWords unsigned ints, never freed).

@@ -195,10 +195,16 @@ __device__ __forceinline__ void tail_mma(f32x16 (&acc)[2][2], const float* __res
 
 // CS (outer-major A only): every thread also accumulates the A elements it stages -- with the [BK][128] tile layout a
 // thread owns the same 4 A rows (m) in every k-tile -- and the tile_n == 0 blocks reduce them to asum[m] = sum_k A[m,k].
+// block id -> logical id: XCD-aware order.  Block b runs on XCD b % 8; each XCD gets a contiguous run of logical ids.  Bijective.
+__device__ __forceinline__ int xcd_order(int b, int nwg) {
+    const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
+
+// One block's work: logical block L of problem p (L in [0, tiles * splitk)), batch index `by`.
 template <int BK, bool AKC, bool BKC, bool VEC, bool CS = false>
-__global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const GemmParams p) {
+__device__ __forceinline__ void gemm_f32_block(const GemmParams& p, const int L, const int by, float* __restrict__ smem) {
     static_assert(!CS || !AKC, "row sums of A are only implemented for an outer-major A");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     using TA = Tile<BK, AKC>;
 
     const int tid = threadIdx.x;
@@ -216,12 +222,6 @@ __global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const 
     // (A persistent variant -- one block per resident slot walking tiles b, b + grid, ... so that a tile's stores drain under
     //  the same waves' next tile -- was measured in round 2 on top of the buffer-load fetch: no gain on any shape, and the
     //  outer loop cost the (k-major, outer-major) variant 7 % through register allocation.  One block per tile it stays.)
-    const int nwg = gridDim.x;
-    int L;
-    {
-        const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
-        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);  // bijective
-    }
     const int tiles = p.tiles_m * p.tiles_n;
     const int split = L / tiles;
     const int t = L - split * tiles;
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const 
     const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
     const int64_t kbeg = (int64_t)split * p.k_per_split;
     const int64_t kend = min(p.K, kbeg + p.k_per_split);
-    const int bz1 = blockIdx.y / p.batch2, bz2 = blockIdx.y - bz1 * p.batch2;
+    const int bz1 = by / p.batch2, bz2 = by - bz1 * p.batch2;
     const float* __restrict__ A = p.A + (int64_t)bz1 * p.sA + (int64_t)bz2 * p.sA2;
     const float* __restrict__ B = p.B + (int64_t)bz1 * p.sB + (int64_t)bz2 * p.sB2;
     const int64_t c_off = (int64_t)bz1 * p.sC + (int64_t)bz2 * p.sC2;
@@ -353,22 +353,56 @@ __global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const 
 #endif
 }
 
+template <int BK, bool AKC, bool BKC, bool VEC, bool CS = false>
+__global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    gemm_f32_block<BK, AKC, BKC, VEC, CS>(p, xcd_order((int)blockIdx.x, (int)gridDim.x), (int)blockIdx.y, smem);
+}
+
+// Several independent parameter-gradient GEMMs (C_i = A_i^T-view B_i, both operands outer-major, + row sums of A_i) as ONE grid:
+// logical ids [start[i], start[i+1]) belong to problem i.  Why: a transformer layer's four dW GEMMs (16-64 tiles each, a
+// 16384-long reduction) each paid a launch ramp, a split-K epilogue in which every block stores its slab at the same moment,
+// and a tail; queued behind each other in one grid the blocks of the next problem start as the previous one's finish
+// (measured on the equivalent single GEMM 16384x512->6144: 0.757 ms against 0.868 ms for the four launches).
+constexpr int GEMM_GROUP_MAX = 8;
+struct GemmGroup {
+    GemmParams p[GEMM_GROUP_MAX];
+    int start[GEMM_GROUP_MAX + 1];
+    int n;
+};
+template <int BK>
+__global__ __launch_bounds__(NT, 2) void gemm_f32_group_kernel(const GemmGroup g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int L = xcd_order((int)blockIdx.x, (int)gridDim.x);
+    int i = 0;
+#pragma unroll
+    for (int j = 1; j < GEMM_GROUP_MAX; ++j)
+        if (j < g.n && L >= g.start[j]) i = j;
+    gemm_f32_block<BK, false, false, true, true>(g.p[i], L - g.start[i], 0, smem);
+}
+
 // C[m,n] = sum_s slab[s][m][n] (+bias)(act).  One thread per float4 of a row (N%4 handled).
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab,
-                                                            float* __restrict__ C,
-                                                            float* __restrict__ preact,
-                                                            const float* __restrict__ bias,
-                                                            int64_t M, int64_t N, int64_t ldc,
-                                                            int splitk, int act, float beta, float alpha,
-                                                            const float* __restrict__ asum_slab, float* __restrict__ asum,
-                                                            const float* __restrict__ addend, int asum_blocks, int vec,
-                                                            const float* __restrict__ dswish, int dact) {
+struct ReduceArgs {
+    const float* slab; float* C; float* preact; const float* bias;
+    int64_t M, N, ldc;
+    int splitk, act; float beta, alpha;
+    const float* asum_slab; float* asum; const float* addend; int asum_blocks, vec;
+    const float* dswish; int dact;
+};
+// logical block `blk` of `nblk` (the last r.asum_blocks of them reduce the row-sum partials)
+__device__ __forceinline__ void splitk_reduce_body(const ReduceArgs& r, const int blk, const int nblk) {
+    const float* __restrict__ slab = r.slab; float* __restrict__ C = r.C; float* __restrict__ preact = r.preact;
+    const float* __restrict__ bias = r.bias; const float* __restrict__ asum_slab = r.asum_slab; float* __restrict__ asum = r.asum;
+    const float* __restrict__ addend = r.addend; const float* __restrict__ dswish = r.dswish;
+    const int64_t M = r.M, N = r.N, ldc = r.ldc;
+    const int splitk = r.splitk, act = r.act, vec = r.vec, dact = r.dact;
+    const float beta = r.beta, alpha = r.alpha;
     const int64_t total = M * N;
     // the last `asum_blocks` blocks reduce the row-sum partials (their splitk dependent loads must not sit in front of
     // the main loop of the first blocks: that put +5 us on the critical path of every split-K dW)
-    const int main_blocks = (int)gridDim.x - asum_blocks;
-    if ((int)blockIdx.x >= main_blocks) {
-        const int64_t i = (int64_t)(blockIdx.x - main_blocks) * blockDim.x + threadIdx.x;
+    const int main_blocks = nblk - r.asum_blocks;
+    if (blk >= main_blocks) {
+        const int64_t i = (int64_t)(blk - main_blocks) * blockDim.x + threadIdx.x;
         if (i < M) {
             float s = 0.f;
             for (int k = 0; k < splitk; ++k) s += asum_slab[(int64_t)k * M + i];
@@ -398,7 +432,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     if (vec) {   // N % 4 == 0, ldc % 4 == 0, 16-B aligned slab / C: one float4 per thread, 4 slab loads in flight
         const int64_t total4 = total >> 2;
         const float4* __restrict__ slab4 = reinterpret_cast<const float4*>(slab);
-        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
+        for (int64_t i = (int64_t)blk * blockDim.x + threadIdx.x; i < total4; i += stride) {
             float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
             int k = 0;
             for (; k + 4 <= splitk; k += 4) {
@@ -417,12 +451,29 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         }
         return;
     }
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    for (int64_t i = (int64_t)blk * blockDim.x + threadIdx.x; i < total; i += stride) {
         float s = 0.f;
         for (int k = 0; k < splitk; ++k) s += slab[(int64_t)k * total + i];
         const int64_t m = i / N, n = i - m * N;
         C[m * ldc + n] = finish(s, m, n);
     }
+}
+
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const ReduceArgs r) { splitk_reduce_body(r, (int)blockIdx.x, (int)gridDim.x); }
+
+struct ReduceGroup {
+    ReduceArgs r[GEMM_GROUP_MAX];
+    int start[GEMM_GROUP_MAX + 1];
+    int n;
+};
+__global__ __launch_bounds__(256) void splitk_reduce_group_kernel(const ReduceGroup g) {
+    const int b = (int)blockIdx.x;
+    int i = 0;
+#pragma unroll
+    for (int j = 1; j < GEMM_GROUP_MAX; ++j)
+        if (j < g.n && b >= g.start[j]) i = j;
+    splitk_reduce_body(g.r[i], b - g.start[i], g.start[i + 1] - g.start[i]);
 }
 
 template <int BK, bool AKC, bool BKC, bool VEC, bool CS = false>
@@ -575,11 +626,14 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
     // so the MNIST-MLP's 32x784x128 forward took 57 us in ONE block; 9 blocks of 3 slabs + the reduce take ~12.
     const int64_t tiles = (int64_t)p.tiles_m * p.tiles_n * batch;
     const bool few = tiles <= 16 && K >= 256;
-    if (batch == 1 && tiles < 192 && (K >= 1024 || few)) {
-        int64_t s = 512 / tiles;
+    static const int tile_lim = []() { const char* e = getenv("NNHIP_SPLITK_TILES"); return e ? atoi(e) : 192; }();
+    if (batch == 1 && tiles < tile_lim && (K >= 1024 || few)) {
+        static const int slots = []() { const char* e = getenv("NNHIP_SPLITK_SLOTS"); return e ? atoi(e) : 512; }();   // dev knobs
+        static const int smax = []() { const char* e = getenv("NNHIP_SPLITK_MAX"); return e ? atoi(e) : 32; }();
+        int64_t s = slots / tiles;
         const int64_t max_by_k = few ? K / 64 : K / 256;
         if (s > max_by_k) s = max_by_k;
-        if (s > 32) s = 32;
+        if (s > smax) s = smax;
         if (few && K < 1024 && s < 4) s = 1;       // not worth the extra launch
         if (s >= 2) {
             p.k_per_split = ceil_div(ceil_div(K, s), BK) * BK;
@@ -643,10 +697,88 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
         const int64_t work = rvec ? total / 4 : total;
         int blocks = (int)(ceil_div(work, 256) < 2048 ? ceil_div(work, 256) : 2048);
         const int asum_blocks = asum ? (int)ceil_div(M, 256) : 0;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks + asum_blocks), dim3(256), 0, st, p.slab, C, preact,
-                           bias, M, N, ldc, p.splitk, act, beta, alpha, p.asum_slab, asum, addend, asum_blocks, rvec, dswish, p.dact);
+        const ReduceArgs r{p.slab, C, preact, bias, M, N, ldc, p.splitk, act, beta, alpha, p.asum_slab, asum, addend, asum_blocks, rvec,
+                           dswish, p.dact};
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks + asum_blocks), dim3(256), 0, st, r);
         NNHIP_LAUNCH_CHECK("splitk_reduce_kernel");
     }
+    return 0;
+}
+
+
+// ---- grouped parameter-gradient GEMMs (linear.hip: the deferred dW queue) ------------------------------------------------------
+// Job i: C_i[M,N] = sum_k A_i[k][m] B_i[k][n] (dW = dO^T X: A = dO [K, M], B = X [K, N], dense), asum_i[m] = sum_k A_i[k][m] (db) or
+// null.  The reduction is cut into chunks of WGRAD_CHUNK rows whatever else is in the group, so a job's bits do not depend on
+// the company it is launched in (data-parallel and single-process steps flush the queue at different points).
+constexpr int64_t WGRAD_CHUNK = 2048;
+bool gemm_f32_wgrad_group_ok(const WgradJob& j) {
+    static const int on = []() { const char* e = getenv("NNHIP_WGRAD_GROUP_KERNEL"); return e ? atoi(e) : 1; }();
+    if (!on || gemm_mode() != 0) return false;
+    if (j.M <= 0 || j.N <= 0 || j.K < 2 * WGRAD_CHUNK || (j.K & 7)) return false;
+    if ((j.M & 3) || (j.N & 3) || !aligned16(j.A) || !aligned16(j.B) || !aligned16(j.C)) return false;
+    if (j.K * j.M + 128 >= ((int64_t)1 << 30) || j.K * j.N + 128 >= ((int64_t)1 << 30)) return false;     // 32-bit operand offsets
+    const int64_t tiles = ceil_div(j.M, BM) * ceil_div(j.N, BN);
+    return tiles <= 256;                                    // a GEMM that fills the chip on its own gains nothing from company
+}
+
+int gemm_f32_wgrad_group(const WgradJob* jobs, int n, hipStream_t st) {
+    if (n <= 0) return 0;
+    if (n > GEMM_GROUP_MAX) {
+        for (int i = 0; i < n; i += GEMM_GROUP_MAX)
+            if (int rc = gemm_f32_wgrad_group(jobs + i, n - i < GEMM_GROUP_MAX ? n - i : GEMM_GROUP_MAX, st)) return rc;
+        return 0;
+    }
+    constexpr int BK = 32;
+    GemmGroup g{};
+    ReduceGroup rg{};
+    size_t floats = 0;
+    for (int i = 0; i < n; ++i) {
+        const WgradJob& j = jobs[i];
+        const int64_t kps = ceil_div(WGRAD_CHUNK, BK) * BK;
+        floats += (size_t)ceil_div(j.K, kps) * (size_t)(j.M * j.N + (j.asum ? j.M : 0));
+    }
+    float* slab = static_cast<float*>(workspace(floats * sizeof(float)));
+    if (!slab) { set_last_error("grouped dW workspace allocation failed"); return NNHIP_ENOMEM; }
+    const float* zeros = zero_block();
+    if (!zeros) { set_last_error("zero block allocation failed"); return NNHIP_ENOMEM; }
+    g.n = rg.n = n;
+    int blocks = 0, rblocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const WgradJob& j = jobs[i];
+        GemmParams& p = g.p[i];
+        p = GemmParams{};
+        p.A = j.A; p.B = j.B; p.C = j.C; p.M = j.M; p.N = j.N; p.K = j.K; p.lda = j.M; p.ldb = j.N; p.ldc = j.N;
+        p.batch2 = 1; p.alpha = 1.f; p.beta = 1.f;
+        p.tiles_m = (int)ceil_div(j.M, BM); p.tiles_n = (int)ceil_div(j.N, BN);
+        p.k_per_split = ceil_div(WGRAD_CHUNK, BK) * BK;
+        p.splitk = (int)ceil_div(j.K, p.k_per_split);
+        p.slab = slab; p.zeros = zeros; p.cvec = 1; p.asum = j.asum;
+        slab += (size_t)p.splitk * j.M * j.N;
+        if (j.asum) { p.asum_slab = slab; slab += (size_t)p.splitk * j.M; }
+        g.start[i] = blocks;
+        blocks += p.tiles_m * p.tiles_n * p.splitk;
+        const int64_t work = j.M * j.N / 4;
+        const int main_blocks = (int)(ceil_div(work, 256) < 2048 ? ceil_div(work, 256) : 2048);
+        const int asum_blocks = j.asum ? (int)ceil_div(j.M, 256) : 0;
+        rg.r[i] = ReduceArgs{p.slab, j.C, nullptr, nullptr, j.M, j.N, j.N, p.splitk, ACT_NONE, 1.f, 1.f, p.asum_slab, j.asum, nullptr,
+                             asum_blocks, 1, nullptr, 0};
+        rg.start[i] = rblocks;
+        rblocks += main_blocks + asum_blocks;
+    }
+    for (int i = n; i <= GEMM_GROUP_MAX; ++i) { g.start[i] = blocks; rg.start[i] = rblocks; }
+    constexpr size_t lds = 2 * (Tile<BK, false>::SIZE + Tile<BK, false>::SIZE) * sizeof(float);
+    auto kern = gemm_f32_group_kernel<BK>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return hip_status(e, "hipFuncSetAttribute(gemm group)");
+        attr_set = true;
+    }
+    g_gemm_launches[0] += n;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NT), lds, st, g);
+    NNHIP_LAUNCH_CHECK("gemm_f32_group_kernel");
+    hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3((unsigned)rblocks), dim3(256), 0, st, rg);
+    NNHIP_LAUNCH_CHECK("splitk_reduce_group_kernel");
     return 0;
 }
 

@@ -1,9 +1,14 @@
 // linear.hip -- Linear and fused Linear->Swish entry points on top of the MFMA GEMM.
 // CPU semantics: neunet/nn/layers/linear.py:48-58 (fwd), :17-24 (bwd); fused path = Swish(Linear(x)),
 // neunet/nn/activations.py:208-233.
+#include <mutex>
+#include <vector>
+
 #include "common.h"
 
 namespace nnhip {
+bool gemm_f32_wgrad_group_ok(const WgradJob& j);
+int gemm_f32_wgrad_group(const WgradJob* jobs, int n, hipStream_t st);
 int gemm_f32(const float* A, const float* B, float* C, const float* bias, float* preact, int64_t M,
              int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc, bool a_kmajor,
              bool b_kmajor, int64_t batch, int64_t sA, int64_t sB, int64_t sC, int act, float beta,
@@ -31,6 +36,31 @@ int colsum(const float* X, int64_t rows, int64_t cols, int64_t ld, float* out, h
 int swish_backward_inplace(float* z_inout, const float* dY, float beta, int64_t n, hipStream_t st);
 int fill_f32(float* p, float v, int64_t n, hipStream_t st);
 enum { ACT_NONE = 0, ACT_SWISH = 1, ACT_RELU = 2, ACT_SIGMOID = 3 };
+
+// ---- the deferred parameter-gradient queue (nnhipWeightGradDefer) ------------------------------------------------------------
+// While deferral is on, a dW (+db) GEMM that would not fill the chip on its own is not launched by the backward call that asks
+// for it: the job is queued and nnhipWeightGradFlush launches everything queued as ONE grid + ONE reduce (gemm.hip:
+// gemm_f32_wgrad_group).  The caller keeps X and dO alive and unchanged until the flush.
+static std::mutex g_wq_mu;
+static std::vector<WgradJob> g_wq;
+static int g_wq_on = 0;
+static hipStream_t g_wq_stream = nullptr;
+static int wq_flush_locked() {
+    if (g_wq.empty()) return 0;
+    const int rc = gemm_f32_wgrad_group(g_wq.data(), (int)g_wq.size(), g_wq_stream);
+    g_wq.clear();
+    return rc;
+}
+// true: queued (*rc: status of a flush this forced); false: not a candidate -- launch it yourself
+static bool wq_offer(const WgradJob& j, hipStream_t st, int* rc) {
+    std::lock_guard<std::mutex> lk(g_wq_mu);
+    *rc = 0;
+    if (!g_wq_on || !gemm_f32_wgrad_group_ok(j)) return false;
+    if (!g_wq.empty() && g_wq_stream != st) *rc = wq_flush_locked();   // one queue, one stream
+    g_wq_stream = st;
+    g_wq.push_back(j);
+    return true;
+}
 
 // dact_arg / dact (optional): dX = (dO W + addend) (.) act'(dact_arg) -- 1: swish'(z; beta), 2: relu mask [f > 0] (gemm.hip)
 static int linear_backward(const float* X, const float* W, const float* dO, float* dX, float* dW,
@@ -62,7 +92,10 @@ static int linear_backward(const float* X, const float* W, const float* dO, floa
     // stages: ~4 % of that GEMM, cheaper than the two launches of a column-sum pass -- measured 9 vs 20 us at
     // 16384x512->512, 14 vs 33 us at 16384x512->2048); wider layers keep the separate HBM-bound pass (4096^2: 19 us vs +46).
     const bool fuse_db = dW && db && in <= 2048;
-    if (dW) rc = gemm_f32_asum(dO, X, dW, fuse_db ? db : nullptr, out, in, rows, out, in, in, false, st);
+    if (dW) {
+        if (!wq_offer(WgradJob{dO, X, dW, fuse_db ? db : nullptr, out, in, rows}, st, &rc))
+            rc = gemm_f32_asum(dO, X, dW, fuse_db ? db : nullptr, out, in, rows, out, in, in, false, st);
+    }
     if (rc) return rc;
     if (db && !fuse_db) rc = colsum(dO, rows, out, out, db, st);
     return rc;
@@ -94,6 +127,31 @@ extern "C" int nnhipLinearModuleForwardEx(const float* X, const float* W, const 
     NNHIP_CHECK_ARG(aligned4(addend), NNHIP_EALIGN, "nnhipLinearModuleForward: misaligned addend");
     return gemm_f32_add(X, W, O, b, addend, rows, out_features, in_features, in_features, in_features,
                         out_features, true, true, (hipStream_t)stream);
+}
+
+// Deferred parameter gradients (extension; the reference launches each layer's dW where its backward runs, linear.py:17-24).
+// enable != 0: from now on the Linear backward entry points QUEUE their dW/db GEMMs when those are too small to fill the chip
+// alone (everything else about the calls is unchanged: dX is computed at once) and nnhipWeightGradFlush(stream) launches the queue
+// as one grid.  Until the flush the caller must keep the X and dO buffers of the queued calls alive and unmodified, and must not
+// read dW/db.  enable == 0: flush what is queued on `stream`, then launch every later dW where it is asked for.  ABI 204
+extern "C" int nnhipWeightGradDefer(int32_t enable, nnhipStream_t stream) {
+    std::lock_guard<std::mutex> lk(g_wq_mu);
+    int rc = 0;
+    if (!enable) {
+        if (!g_wq.empty()) g_wq_stream = (hipStream_t)stream;
+        rc = wq_flush_locked();
+    }
+    g_wq_on = enable ? 1 : 0;
+    return rc;
+}
+extern "C" int nnhipWeightGradFlush(nnhipStream_t stream) {
+    std::lock_guard<std::mutex> lk(g_wq_mu);
+    if (!g_wq.empty() && g_wq_stream != (hipStream_t)stream) g_wq_stream = (hipStream_t)stream;
+    return wq_flush_locked();
+}
+extern "C" int nnhipWeightGradPending(void) {
+    std::lock_guard<std::mutex> lk(g_wq_mu);
+    return (int)g_wq.size();
 }
 
 extern "C" int nnhipLinearModuleBackward(const float* X, const float* W, const float* dO, float* dX,

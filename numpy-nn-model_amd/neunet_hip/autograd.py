@@ -278,11 +278,19 @@ class Tensor:
             for child in v.args:
                 if isinstance(child, Tensor):
                     child._consumers += 1
-        for v in reversed(tape):
-            if getattr(v, "_bwd_done", False):      # a consumer's fused backward already produced this node's gradients
-                v._bwd_done = False                 # (experimental/linear.py: Linear2(relu(Linear1(x))) in one launch)
-                continue
-            v.grad_fn(*v.args, grad=v.grad)
+        # small parameter-gradient GEMMs are queued by the library while the tape is walked and launched a layer's worth at a
+        # time (_lib.py: deferred parameter gradients); everything is launched by the time backward() returns
+        from ._lib import wgrad_begin, wgrad_end
+        deferring = self.device != "cpu" and wgrad_begin()
+        try:
+            for v in reversed(tape):
+                if getattr(v, "_bwd_done", False):      # a consumer's fused backward already produced this node's gradients
+                    v._bwd_done = False                 # (experimental/linear.py: Linear2(relu(Linear1(x))) in one launch)
+                    continue
+                v.grad_fn(*v.args, grad=v.grad)
+        finally:
+            if deferring:
+                wgrad_end()
 
     # ---- the few shape / scalar ops callers of the hot path need ----------------------------------------
     def reshape(self, *shape):

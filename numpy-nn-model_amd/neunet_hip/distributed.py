@@ -136,6 +136,8 @@ class GradBucket:
 
     def _launch(self, k):
         import torch.distributed as dist
+        from ._lib import wgrad_flush
+        wgrad_flush()                         # queued parameter-gradient GEMMs of this segment go out before it is exchanged
         self._launched[k] = True
         if self._capture_cb is not None:      # hipGraph capture: the step is cut here; the replay launches the exchange
             self._capture_cb(k)
@@ -154,6 +156,8 @@ class GradBucket:
         v = param._grad_slot
         g = param.grad
         if g is not None and g.data_ptr() != v.data_ptr():
+            from ._lib import wgrad_flush
+            wgrad_flush()                     # the gradient may still be a queued GEMM
             v.copy_(g.reshape(v.shape))
             param.grad = v
         self._pending[k] -= 1

@@ -14,7 +14,7 @@ import numpy as np
 from ...autograd import Tensor, param_epoch
 from ..modules import Module
 from ..parameter import Parameter
-from ..._lib import NeunetHipError
+from ..._lib import NeunetHipError, wgrad_flush
 from .utils import call_hip_function, get_current_stream_ptr
 
 
@@ -122,6 +122,8 @@ def _commit_fold(X, dz):
 
 def _finish_param(param, grad):
     """apply_grad + the DP bucket's gradient-ready hook (GradBucket(overlap=True))."""
+    if param.grad is not None:      # accumulation reads `grad` NOW: it must not still be a queued GEMM (_lib.py: wgrad_*)
+        wgrad_flush()
     param.apply_grad(grad)
     hook = getattr(param, "_grad_hook", None)
     if hook is not None:

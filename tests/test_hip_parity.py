@@ -2771,3 +2771,113 @@ def test_graphed_step_draws_fresh_dropout_masks(hip):
     h2 = host(model.h.data).copy()
     step.release()
     assert 0.3 < np.mean((h1 != 0) != (h2 != 0)) < 0.7
+
+
+# ------------------------------------------------------------------------------------------- deferred parameter gradients
+def _wgrad_problem(rows, inf, outf, seed, bias=True):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    X = torch.rand(rows, inf, device="cuda", generator=g) * 2 - 1
+    W = (torch.rand(outf, inf, device="cuda", generator=g) * 2 - 1) / 16
+    dO = torch.rand(rows, outf, device="cuda", generator=g) * 2 - 1
+    dW, db = torch.empty(outf, inf, device="cuda"), (torch.empty(outf, device="cuda") if bias else None)
+    return X, W, dO, dW, db
+
+
+@pytest.mark.gpu
+def test_deferred_weight_grads_grouped_launch(hip):
+    """nnhipWeightGradDefer / Flush: the dW (+db) GEMMs of several Linear backward calls leave as ONE grid + ONE reduce.  Checked
+    against float64 at the dot-product bound, against the undeferred calls, and for the contract's corners: a job's bits do not
+    depend on its company (alone == in a group of four), small layers are not queued, dX is produced by the call itself."""
+    from neunet_hip._lib import call_hip_function as call, get_current_stream_ptr
+    st = get_current_stream_ptr()
+    shapes = [(4096, 512, 512), (4096, 512, 1536), (8192, 256, 384), (4096, 2048, 512)]   # rows, in, out
+    probs = [_wgrad_problem(*s, seed=i, bias=(i != 2)) for i, s in enumerate(shapes)]
+    ref = []
+    for (X, W, dO, dW, db), (r, i, o) in zip(probs, shapes):
+        call("nnhipLinearModuleBackward", X, W, dO, None, dW, db, r, i, o, st)
+        ref.append((dW.clone(), None if db is None else db.clone()))
+        dW.fill_(float("nan"))
+        if db is not None:
+            db.fill_(float("nan"))
+    before = call("nnhipGemmLaunchCount", 0)
+    call("nnhipWeightGradDefer", 1, st)
+    try:
+        dXs = []
+        for (X, W, dO, dW, db), (r, i, o) in zip(probs, shapes):
+            dX = torch.empty(r, i, device="cuda")
+            call("nnhipLinearModuleBackward", X, W, dO, dX, dW, db, r, i, o, st)
+            dXs.append(dX)
+        assert call("nnhipWeightGradPending") == 4
+        assert bool(torch.isnan(probs[0][3]).all()), "a queued dW was written before the flush"
+        # a layer that is too small for the queue is served at once
+        Xs, Ws, dOs, dWs, dbs = _wgrad_problem(64, 32, 16, seed=9)
+        call("nnhipLinearModuleBackward", Xs, Ws, dOs, None, dWs, dbs, 64, 32, 16, st)
+        assert call("nnhipWeightGradPending") == 4
+        np.testing.assert_allclose(host(dWs), host(dOs).astype(np.float64).T @ host(Xs).astype(np.float64), rtol=1e-5, atol=1e-5)
+        call("nnhipWeightGradFlush", st)
+        assert call("nnhipWeightGradPending") == 0
+    finally:
+        call("nnhipWeightGradDefer", 0, st)
+    assert call("nnhipGemmLaunchCount", 0) - before >= 4 + 4       # 4 dX GEMMs + 4 grouped jobs
+    for (X, W, dO, dW, db), (rW, rb), dX, (r, i, o) in zip(probs, ref, dXs, shapes):
+        assert_dot_close(host(dW), host(dO).T, host(X), err_msg=f"grouped dW {r}x{i}->{o}")
+        assert_close_scaled(host(dW), host(rW), err_msg="grouped dW vs the undeferred call")
+        assert_dot_close(host(dX), host(dO), host(W), err_msg="dX next to a queued dW")
+        if db is not None:
+            assert_within(host(db), host(dO).astype(np.float64).sum(0), 32 * U24 * np.abs(host(dO)).astype(np.float64).sum(0), "grouped db")
+    # alone == in company
+    X, W, dO, dW, db = probs[1]
+    grouped = (dW.clone(), db.clone())
+    dW.zero_(); db.zero_()
+    call("nnhipWeightGradDefer", 1, st)
+    try:
+        call("nnhipLinearModuleBackward", X, W, dO, None, dW, db, *shapes[1], st)
+        assert call("nnhipWeightGradPending") == 1
+    finally:
+        call("nnhipWeightGradDefer", 0, st)       # switching off flushes
+    assert call("nnhipWeightGradPending") == 0
+    assert torch.equal(dW, grouped[0]) and torch.equal(db, grouped[1])
+
+
+@pytest.mark.gpu
+def test_deferred_weight_grads_in_backward(hip, monkeypatch):
+    """Tensor.backward() with the queue on (default, groups of four) == with it off, on a model whose layers qualify (4096 rows):
+    every parameter gradient and the input gradient, within the gradient tolerance; torch's allocator is given every chance to
+    recycle a queued job's dO (fresh temporaries between the layers), so a missing keep-alive shows up as garbage."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import gpt_tiny
+    import neunet_hip.nn as nn
+    from neunet_hip import _lib
+    rng = np.random.default_rng(5)
+    B, Tn, V = 16, 256, 1000
+    ids = rng.integers(1, V, (B, Tn)).astype(np.int32)
+    tgt = rng.integers(1, V, (B * Tn,)).astype(np.int32)
+    init = None
+
+    def run(group):
+        nonlocal init
+        monkeypatch.setitem(_lib._wgrad, "group", group)
+        model = gpt_tiny.build_gpt(V, 256, 4, 1024, 2, pad_idx=0, max_len=Tn, fused=True)
+        params = model.parameters()
+        if init is None:
+            init = [p.data.clone() for p in params]
+        for p, v in zip(params, init):
+            p.data.copy_(v)
+        loss_fn = nn.CrossEntropyLoss(ignore_index=0)
+        before = _lib.call_hip_function("nnhipGemmLaunchCount", 0)
+        out, _ = model.forward(ids)
+        loss = loss_fn(out.reshape(B * Tn, V), T(hip, tgt, dtype=np.int32, requires_grad=False))
+        loss.backward()
+        assert _lib.call_hip_function("nnhipWeightGradPending") == 0 and not _lib._wgrad["on"] and not _lib._wgrad["keep"]
+        return [None if p.grad is None else host(p.grad) for p in params], loss.item(), \
+            _lib.call_hip_function("nnhipGemmLaunchCount", 0) - before
+
+    g_on, l_on, n_on = run(4)
+    g_off, l_off, n_off = run(0)
+    assert l_on == l_off and n_on == n_off
+    scale = grad_list_scale([a for a in g_off if a is not None])
+    for k, (a, b) in enumerate(zip(g_on, g_off)):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert_close_scaled(a, b, err_msg=f"parameter {k}", scale=scale)

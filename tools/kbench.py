@@ -82,6 +82,13 @@ def main():
             report(f"linear db  {tag}", *bench(lambda: call("nnhipLinearModuleBackward", X, W, dO, None, None, db, M, K, N, st), args.iters), nbytes=4.0 * M * N)
             del X, W, O_, dO, dX, dW
 
+    if "dwsweep" in only:         # the parameter-gradient GEMMs of the C4 step (split-K candidates)
+        for (M, N, K) in [(16384, 512, 512), (16384, 1536, 512), (16384, 2048, 512), (16384, 512, 2048), (16384, 15000, 512), (16384, 6144, 512)]:
+            X, W, dO = rnd(M, K), rnd(N, K) / 64, rnd(M, N)
+            dW, db = torch.empty(N, K, device=dev), torch.empty(N, device=dev)
+            report(f"linear dW+db {M}x{K}->{N}", *bench(lambda: call("nnhipLinearModuleBackward", X, W, dO, None, dW, db, M, K, N, st), args.iters), flops=2.0 * M * N * K)
+            del X, W, dO, dW
+
     R, D = 8192, 4096
     n = R * D
     if want("lswish"):
