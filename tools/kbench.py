@@ -89,6 +89,27 @@ def main():
             report(f"linear dW+db {M}x{K}->{N}", *bench(lambda: call("nnhipLinearModuleBackward", X, W, dO, None, dW, db, M, K, N, st), args.iters), flops=2.0 * M * N * K)
             del X, W, dO, dW
 
+    if want("wgroup"):            # a GPT-tiny decoder layer's four dW+db GEMMs: four launches vs the deferred queue's one grid
+        M = 16384
+        jobs = []
+        for (N, K) in [(512, 2048), (2048, 512), (512, 512), (1536, 512)]:      # out, in -- the order backward meets them
+            jobs.append((rnd(M, K), rnd(N, K) / 64, rnd(M, N), torch.empty(N, K, device=dev), torch.empty(N, device=dev), K, N))
+        fl = sum(2.0 * M * N * K for (*_, K, N) in jobs)
+
+        def separate():
+            for (X, W, dO, dW, db, K, N) in jobs:
+                call("nnhipLinearModuleBackward", X, W, dO, None, dW, db, M, K, N, st)
+
+        def grouped():
+            call("nnhipWeightGradDefer", 1, st)
+            for (X, W, dO, dW, db, K, N) in jobs:
+                call("nnhipLinearModuleBackward", X, W, dO, None, dW, db, M, K, N, st)
+            call("nnhipWeightGradDefer", 0, st)
+
+        report("4 x linear dW+db, GPT-tiny layer (4 launches + 4 reduces)", *bench(separate, args.iters), flops=fl)
+        report("4 x linear dW+db, GPT-tiny layer (deferred: 1 grid + 1 reduce)", *bench(grouped, args.iters), flops=fl)
+        del jobs
+
     R, D = 8192, 4096
     n = R * D
     if want("lswish"):
