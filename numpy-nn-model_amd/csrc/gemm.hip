@@ -369,16 +369,20 @@ struct GemmGroup {
     GemmParams p[GEMM_GROUP_MAX];
     int start[GEMM_GROUP_MAX + 1];
     int n;
+    int by_job;      // 0: one XCD-aware order over the whole grid (an XCD works on one or two jobs);  1: jobs in DISPATCH order, the
+                     // XCD-aware order inside each (all of job 0's blocks are handed out before any of job 1's)
 };
 template <int BK>
 __global__ __launch_bounds__(NT, 2) void gemm_f32_group_kernel(const GemmGroup g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int L = xcd_order((int)blockIdx.x, (int)gridDim.x);
+    const int b = (int)blockIdx.x;
+    const int L = g.by_job ? b : xcd_order(b, (int)gridDim.x);
     int i = 0;
 #pragma unroll
     for (int j = 1; j < GEMM_GROUP_MAX; ++j)
         if (j < g.n && L >= g.start[j]) i = j;
-    gemm_f32_block<BK, false, false, true, true>(g.p[i], L - g.start[i], 0, smem);
+    const int local = L - g.start[i];
+    gemm_f32_block<BK, false, false, true, true>(g.p[i], g.by_job ? xcd_order(local, g.start[i + 1] - g.start[i]) : local, 0, smem);
 }
 
 // C[m,n] = sum_s slab[s][m][n] (+bias)(act).  One thread per float4 of a row (N%4 handled).
@@ -505,6 +509,8 @@ int gemm_bf3_launch(const GemmParams& p, bool a_kmajor, bool b_kmajor, bool vec,
 // launches per kernel family since load (nnhipGemmLaunchCount): 0 classic fp32 128x128, 1 persistent fp32, 2 small, 3 split-bf16.
 // Host-side counters for tests that must know WHICH kernel produced a result (a "bf16x3" test that only ever reaches the
 // small kernel proves nothing about gemm_bf3_kernel).
+static int gemm_f32_uneven_split(const float* A, const float* B, float* C, float* asum, int64_t M, int64_t N, int64_t K, int64_t lda,
+                                 int64_t ldb, int64_t ldc, int64_t K1, hipStream_t st);
 static long long g_gemm_launches[4] = {0, 0, 0, 0};
 static int g_gemm_mode = -1;    // -1: not initialised (NNHIP_GEMM_MODE decides), 0: exact fp32 MFMA, 1: split-bf16
 static int gemm_mode() {
@@ -603,6 +609,23 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
         ++g_gemm_launches[2];
         return gemm_small(A, B, C, bias, preact, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, alpha, act, beta, asum, addend,
                           dswish, dact, st);
+    }
+    {   // one under-filled generation of a dW-type GEMM: uneven two-way split (gemm_f32_uneven_split)
+        static const int uneven_on = []() { const char* e = getenv("NNHIP_GEMM_UNEVEN"); return e ? atoi(e) : 1; }();
+        const int64_t t = ceil_div(M, BM) * ceil_div(N, BN);
+        if (uneven_on && gemm_mode() == 0 && !a_kmajor && !b_kmajor && batch == 1 && !bias && !preact && !addend && !dswish &&
+            act == ACT_NONE && alpha == 1.0f && t > 256 && t <= 496 && K >= 4096 && (K & 7) == 0 && (M & 3) == 0 && (N & 3) == 0 &&
+            (lda & 3) == 0 && (ldb & 3) == 0 && aligned16(A) && aligned16(B) && K * lda + 128 < ((int64_t)1 << 30) &&
+            K * ldb + 128 < ((int64_t)1 << 30)) {
+            // (the split that finishes both kinds together is ~3.4 % below K t / 512: a long block runs a little faster while the
+            //  other slot of its CU is between short blocks -- swept on the head's 472 tiles: 456 of 512 k-tiles, not 472)
+            static const int bias_tiles = []() { const char* e = getenv("NNHIP_UNEVEN_BIAS"); return e ? atoi(e) : 0; }();   // dev knob
+            const int64_t K1 = (K * t * 966 / ((int64_t)512 * 1000) + 31) / 32 * 32 + 32 * bias_tiles;
+            if (K - K1 >= 256) {
+                ++g_gemm_launches[0];
+                return gemm_f32_uneven_split(A, B, C, asum, M, N, K, lda, ldb, ldc, K1, st);
+            }
+        }
     }
     constexpr int BK = 32;     // (a BK = 16 / 3-blocks-per-CU variant was measured in rounds 1 and 2: never ahead; dropped)
     GemmParams p;
@@ -705,6 +728,57 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
     return 0;
 }
 
+
+// ---- one generation that does not fill the chip: uneven two-way split of the reduction -------------------------------------------
+// A dW-type GEMM (both operands outer-major) with t tiles, 256 < t < 512, runs ONE generation on the 512 resident slots (2 per CU):
+// every CU with two blocks takes the full K while 512 - t slots idle -- the GPT-tiny head's dW[15000, 512] has 472 tiles and ran at
+// 0.83 of the peak.  Here every tile's reduction is cut at K1 = K t / 512: t long blocks (k < K1) are dispatched first, the t short
+// ones (k >= K1) follow through the spare slots (t (K - K1) = (512 - t) K1: they are done when the long ones are), and the two
+// partial results meet in the split-K reduce.  Same kernel as the grouped launch: the two pieces are two "jobs" on one tile set.
+static int gemm_f32_uneven_split(const float* A, const float* B, float* C, float* asum, int64_t M, int64_t N, int64_t K, int64_t lda,
+                                 int64_t ldb, int64_t ldc, int64_t K1, hipStream_t st) {
+    constexpr int BK = 32;
+    const size_t floats = 2 * (size_t)(M * N + (asum ? M : 0));
+    float* slab = static_cast<float*>(workspace(floats * sizeof(float)));
+    if (!slab) { set_last_error("split-K workspace allocation failed"); return NNHIP_ENOMEM; }
+    const float* zeros = zero_block();
+    if (!zeros) { set_last_error("zero block allocation failed"); return NNHIP_ENOMEM; }
+    float* asum_slab = asum ? slab + 2 * (size_t)(M * N) : nullptr;
+    GemmGroup g{};
+    g.n = 2;
+    g.by_job = 1;
+    const int tiles_m = (int)ceil_div(M, BM), tiles_n = (int)ceil_div(N, BN), tiles = tiles_m * tiles_n;
+    for (int i = 0; i < 2; ++i) {
+        GemmParams& p = g.p[i];
+        const int64_t k0 = i ? K1 : 0, kn = i ? K - K1 : K1;
+        p.A = A + k0 * lda; p.B = B + k0 * ldb; p.C = C; p.M = M; p.N = N; p.K = kn; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+        p.batch2 = 1; p.alpha = 1.f; p.beta = 1.f; p.tiles_m = tiles_m; p.tiles_n = tiles_n;
+        p.k_per_split = ceil_div(kn, BK) * BK;
+        p.splitk = 2;                                        // "write a slab": each piece is split 0 of its own slab pointer
+        p.slab = slab + (size_t)i * M * N; p.zeros = zeros; p.cvec = 1; p.asum = asum;
+        p.asum_slab = asum ? asum_slab + (size_t)i * M : nullptr;
+        g.start[i] = i * tiles;
+    }
+    for (int i = 2; i <= GEMM_GROUP_MAX; ++i) g.start[i] = 2 * tiles;
+    constexpr size_t lds = 2 * (Tile<BK, false>::SIZE + Tile<BK, false>::SIZE) * sizeof(float);
+    auto kern = gemm_f32_group_kernel<BK>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return hip_status(e, "hipFuncSetAttribute(gemm group)");
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(2 * tiles)), dim3(NT), lds, st, g);
+    NNHIP_LAUNCH_CHECK("gemm_f32_group_kernel");
+    const int rvec = (ldc & 3) == 0 && aligned16(C);
+    const int64_t work = rvec ? M * N / 4 : M * N;
+    const int blocks = (int)(ceil_div(work, 256) < 2048 ? ceil_div(work, 256) : 2048);
+    const int asum_blocks = asum ? (int)ceil_div(M, 256) : 0;
+    const ReduceArgs r{slab, C, nullptr, nullptr, M, N, ldc, 2, ACT_NONE, 1.f, 1.f, asum_slab, asum, nullptr, asum_blocks, rvec, nullptr, 0};
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks + asum_blocks), dim3(256), 0, st, r);
+    NNHIP_LAUNCH_CHECK("splitk_reduce_kernel");
+    return 0;
+}
 
 // ---- grouped parameter-gradient GEMMs (linear.hip: the deferred dW queue) ------------------------------------------------------
 // Job i: C_i[M,N] = sum_k A_i[k][m] B_i[k][n] (dW = dO^T X: A = dO [K, M], B = X [K, N], dense), asum_i[m] = sum_k A_i[k][m] (db) or

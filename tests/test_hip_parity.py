@@ -2881,3 +2881,18 @@ def test_deferred_weight_grads_in_backward(hip, monkeypatch):
         assert (a is None) == (b is None)
         if a is not None:
             assert_close_scaled(a, b, err_msg=f"parameter {k}", scale=scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,inf,outf,bias", [(4096, 512, 8320, True), (4096, 512, 15000, True), (8192, 384, 11000, False)])
+def test_linear_dw_uneven_split(hip, rows, inf, outf, bias):
+    """A dW GEMM whose tiles make ONE under-filled generation (256 < tiles <= 496; the GPT-tiny head has 472) is cut unevenly
+    along the reduction: long blocks first, the short remainders through the idle slots, two slabs, one reduce.  dW and db against
+    float64 at the dot-product bound -- including the ragged last tile row (15000 = 117 x 128 + 24)."""
+    from neunet_hip._lib import call_hip_function as call, get_current_stream_ptr
+    X, W, dO, dW, db = _wgrad_problem(rows, inf, outf, seed=rows + outf, bias=bias)
+    dW.fill_(float("nan"))
+    call("nnhipLinearModuleBackward", X, W, dO, None, dW, db, rows, inf, outf, get_current_stream_ptr())
+    assert_dot_close(host(dW), host(dO).T, host(X), err_msg="uneven-split dW")
+    if bias:
+        assert_within(host(db), host(dO).astype(np.float64).sum(0), 32 * U24 * np.abs(host(dO)).astype(np.float64).sum(0), "db")

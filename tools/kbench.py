@@ -202,6 +202,31 @@ def main():
             report(f"attn fwd B{B_} T{T_} H{H_} dh{dh} causal", *bench(f, args.iters), flops=fwd_fl)
             report(f"attn bwd B{B_} T{T_} H{H_} dh{dh} causal", *bench(bw, args.iters), flops=2.5 * fwd_fl)
 
+    if "attnlayout" in only:
+        # the same attention work (512 heads of T256 dh64) from three layouts: fused [B,T,3D] (row stride 6 KB, 256-B head
+        # segments), separate [B,T,D] tensors (2 KB stride) and head-major [B*H,T,dh] (contiguous): is the strided gather the cost?
+        T_, dh = 256, 64
+        sc = 1.0 / float(np.sqrt(512))
+        fwd_fl = 4.0 * 512 * T_ * T_ * dh / 2
+        for name, B_, H_, packed in [("fused qkv [B,T,3D]", 64, 8, True), ("separate [B,T,D]", 64, 8, False), ("head-major [BH,T,dh]", 512, 1, False)]:
+            Dm = H_ * dh
+            kvalid = torch.ones(B_, T_, dtype=torch.int32, device=dev)
+            ctx, dctx = torch.empty(B_, T_, Dm, device=dev), randn(B_, T_, Dm)
+            lse = torch.empty(B_, H_, T_, 2, device=dev)
+            if packed:
+                qkv = randn(B_, T_, 3 * Dm); dqkv = torch.empty_like(qkv)
+                q_, k_, v_ = (_lib.StridedView(qkv[..., i * Dm:(i + 1) * Dm]) for i in range(3))
+                dq_, dk_, dv_ = (_lib.StridedView(dqkv[..., i * Dm:(i + 1) * Dm]) for i in range(3))
+                LQ = 3 * Dm
+            else:
+                q_, k_, v_ = randn(B_, T_, Dm), randn(B_, T_, Dm), randn(B_, T_, Dm)
+                dq_, dk_, dv_ = torch.empty_like(q_), torch.empty_like(q_), torch.empty_like(q_)
+                LQ = Dm
+            f = lambda: call("nnhipAttentionForward", q_, k_, v_, kvalid, ctx, lse, B_, H_, T_, T_, dh, LQ, sc, 1, st)  # noqa: E731
+            bw = lambda: call("nnhipAttentionBackward", q_, k_, v_, kvalid, ctx, dctx, lse, dq_, dk_, dv_, B_, H_, T_, T_, dh, LQ, sc, 1, st)  # noqa: E731
+            report(f"attn fwd {name}", *bench(f, args.iters), flops=fwd_fl)
+            report(f"attn bwd {name}", *bench(bw, args.iters), flops=2.5 * fwd_fl)
+
     if want("lssweep"):
         # The reference's own Linear->Swish sweep (scripts/benchmark_linear_swish_cuda.py:127-138) with its methodology
         # (:16-56, :59-118): 50 warm-up + 200 timed iterations between two events, and INSIDE the timed loop a device copy
