@@ -209,7 +209,7 @@ __device__ __forceinline__ bool map_block(int id, int BH, int nblk, bool heavy_i
 }
 // (Round 2, measured and dropped: a mirrored wave -> row-group map in every other block, so that a SIMD's two resident waves
 //  carry complementary causal work: +-0; starting every slot with one heavy and one light block so that later prologues run
-//  under somebody else's MFMA phase: 80 -> 84 us.  See DESIGN.md 5.8.)
+//  under somebody else's MFMA phase: 80 -> 84 us.  See EXPERIMENTS.md 5.8.)
 __host__ inline unsigned mapped_grid(int64_t BH, int64_t nblk) { return (unsigned)(ceil_div(BH, 8) * 8 * nblk); }
 
 // ---- MFMA phases -------------------------------------------------------------------------------------------------

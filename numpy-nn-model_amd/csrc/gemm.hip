@@ -106,7 +106,7 @@ __device__ __forceinline__ void gemm_k_loop(f32x16 (&acc)[2][2], float4 (&ra)[BK
 // being multiplied (the committed one is one ahead): a load has two iterations (~7 us with two blocks per CU) to land, so
 // the loop rides through the latency spike of a generation of blocks storing their C tiles together -- with a one-deep
 // prefetch that store burst (33.5 MB per 512 tiles = 6.7 us at 5 TB/s) was fully exposed in grids of a few generations
-// (a build without stores ran exactly that much faster).
+// (a build without stores ran exactly that much faster, EXPERIMENTS.md 5.1d).
 // SUM: cs += csf[q] * (the committed A tile) -- csf = 1 for a whole tile, the new-rows mask for the shifted partial tile,
 // 0 for the never-used tiles fetched past the end.
 template <int BK, bool AKC, bool BKC, bool SUM>
