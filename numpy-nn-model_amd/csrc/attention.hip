@@ -175,14 +175,15 @@ __device__ __forceinline__ void tile_commit(float* __restrict__ S, const TileReg
 // padding flag of key kv0 + lane (1 = real token); the wave ballots it into a 64-bit mask per tile
 __device__ __forceinline__ int key_flag(const int32_t* __restrict__ kv, int kv0, int Tk, int lane) {
     if (!kv) return 1;
-    return kv0 + lane < Tk ? kv[kv0 + lane] : 0;
+    const int i = kv0 + lane;
+    const int v = kv[i < Tk ? i : Tk - 1];                   // unconditional load of a clamped index: no exec-masked region (a
+    return i < Tk ? v : 0;                                   // conditional load is its own basic block and may end in vmcnt(0))
 }
 
 // first key index of batch b that is not padding (block-wide min; Tk if none) -- decides where causal skipping is legal:
 // a query q has a visible unmasked key iff first_valid <= q + shift; a row without one is uniform over ALL keys.
 template <int NT>
-__device__ __forceinline__ int first_valid_key(const int32_t* __restrict__ kv, int Tk, int tid, int* sh) {
-    if (!kv) return 0;
+__device__ __forceinline__ int first_valid_key_scan(const int32_t* __restrict__ kv, int Tk, int tid, int* sh) {
     int best = Tk;
     for (int j = tid; j < Tk; j += NT)
         if (kv[j] != 0) { best = j; break; }
@@ -191,6 +192,16 @@ __device__ __forceinline__ int first_valid_key(const int32_t* __restrict__ kv, i
     atomicMin(sh, best);
     __syncthreads();
     return *sh;
+}
+// `flag0`: key_flag(kv, 0, Tk, lane) of the calling lane -- the same 64 values in every wave.  Almost always the first real token
+// is among keys 0..63 (no left padding): then every wave reads it off its own ballot -- no scan loop (a dependent load), no LDS
+// atomic, no block barriers in the prologue.  Otherwise all waves take the block-wide scan (the decision is block-uniform).
+template <int NT>
+__device__ __forceinline__ int first_valid_key(const int32_t* __restrict__ kv, int Tk, int tid, int* sh, int flag0) {
+    if (!kv) return 0;
+    const unsigned long long m = __ballot(flag0 != 0);
+    if (m != 0ull) return (int)__builtin_ctzll(m);
+    return first_valid_key_scan<NT>(kv, Tk, tid, sh);
 }
 
 // Block -> (batch*head, tile block) map.  Hardware deals consecutive blockIdx round-robin over the 8 XCDs, so a plain
@@ -431,15 +442,15 @@ __global__ __launch_bounds__(64 * NW, DH <= 64 ? 2 : 1) void attn_fwd_kernel(con
     const float qs = p.scale * AT_LOG2E;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (q < p.Tq) v = *reinterpret_cast<const float4*>(Qb + (int64_t)q * p.LQ + 8 * g + 4 * lh);
+        // a query past the end re-reads the last one (finite values; nothing of it is stored): no exec-masked load regions
+        const float4 v = *reinterpret_cast<const float4*>(Qb + (int64_t)(q < p.Tq ? q : p.Tq - 1) * p.LQ + 8 * g + 4 * lh);
         qf[g][0] = v.x; qf[g][1] = v.y; qf[g][2] = v.z; qf[g][3] = v.w;
     }
 
     // How many key tiles does this block visit?  Causal tiles above the block's last query contribute exp(-1e9-m)=0
     // and are skipped -- unless some query of the block has NO visible unmasked key: then the reference's softmax is
     // uniform over ALL keys (every score is the same -1e9) and nothing may be skipped.
-    const int fv = first_valid_key<NT>(kv, p.Tk, tid, &sh_fv);
+    const int fv = first_valid_key<NT>(kv, p.Tk, tid, &sh_fv, kflag);
     int n_tiles = (p.Tk + AT_BK - 1) / AT_BK;
     const bool skip_ok = !dense && p.causal && fv <= qb * BQ + shift;   // every query of the block sees a non-padding key
     if (skip_ok) {
@@ -611,6 +622,7 @@ __global__ __launch_bounds__(64 * NW, DH <= 64 ? 2 : 1) void attn_bwd_dkdv_kerne
     const int32_t* kv = p.key_valid ? p.key_valid + (int64_t)b * p.Tk : nullptr;
     const int shift = p.Tk - p.Tq;
     const bool key_in = key < p.Tk;
+    const int keyc = key_in ? key : p.Tk - 1;
     const bool dense = GEN && p.x.mask_bitsT != nullptr;
     const bool dropping = GEN && (p.x.drop_mask != nullptr || p.x.drop_threshold != 0u);
     const int nwq = (p.Tq + 63) >> 6;
@@ -623,16 +635,14 @@ __global__ __launch_bounds__(64 * NW, DH <= 64 ? 2 : 1) void attn_bwd_dkdv_kerne
     const float sl2 = p.scale * AT_LOG2E;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
-        if (key_in) {
-            a = *reinterpret_cast<const float4*>(Kb + (int64_t)key * p.LQ + 8 * g + 4 * lh);
-            c = *reinterpret_cast<const float4*>(Vb + (int64_t)key * p.LQ + 8 * g + 4 * lh);
-        }
+        // a key past the end re-reads the last one (finite values, its dK / dV columns are not stored): no exec-masked loads
+        const float4 a = *reinterpret_cast<const float4*>(Kb + (int64_t)keyc * p.LQ + 8 * g + 4 * lh);
+        const float4 c = *reinterpret_cast<const float4*>(Vb + (int64_t)keyc * p.LQ + 8 * g + 4 * lh);
         kf[g][0] = a.x; kf[g][1] = a.y; kf[g][2] = a.z; kf[g][3] = a.w;
         vf[g][0] = c.x; vf[g][1] = c.y; vf[g][2] = c.z; vf[g][3] = c.w;
     }
-    const bool key_pad = kv && key_in && kv[key] == 0;
-    const int fv = first_valid_key<NT>(kv, p.Tk, tid, &sh_fv);      // (after the fragment loads were issued: one round trip)
+    const bool key_pad = kv && kv[keyc] == 0 && key_in;
+    const int fv = first_valid_key<NT>(kv, p.Tk, tid, &sh_fv, key_flag(kv, 0, p.Tk, lane));
 #pragma unroll
     for (int g = 0; g < G; ++g)
 #pragma unroll
@@ -656,12 +666,12 @@ __global__ __launch_bounds__(64 * NW, DH <= 64 ? 2 : 1) void attn_bwd_dkdv_kerne
     tile_offsets<DH, NT>(goff, p.D, tid);
     float2 ml = make_float2(0.f, 0.f);
     float dsv = 0.f, anyv = 1.f;
-    auto fetch_rows = [&](int qs) {
-        ml = make_float2(0.f, 0.f); dsv = 0.f; anyv = 1.f;
-        if (tid < QT && qs + tid < p.Tq) {
-            ml = LSEb[qs + tid]; dsv = Dsb[qs + tid];
-            if (GEN && dense && p.x.row_any) anyv = p.x.row_any[(int64_t)b * p.Tq + qs + tid] ? 1.f : 0.f;
-        }
+    int rows_qs = 0;
+    auto fetch_rows = [&](int qs) {                             // unconditional loads of clamped rows (every thread): no exec-masked
+        rows_qs = qs;                                           // region; rows past the end are zeroed when they are committed
+        const int r = min(qs + (tid & (QT - 1)), p.Tq - 1);
+        ml = LSEb[r]; dsv = Dsb[r]; anyv = 1.f;
+        if (GEN && dense && p.x.row_any) anyv = p.x.row_any[(int64_t)b * p.Tq + r] ? 1.f : 0.f;
     };
     int qt = next_tile(0);
     if (qt < n_qt) {
@@ -674,7 +684,10 @@ __global__ __launch_bounds__(64 * NW, DH <= 64 ? 2 : 1) void attn_bwd_dkdv_kerne
         __syncthreads();
         tile_commit<DH, NT>(Qs, qr, tid);
         tile_commit<DH, NT>(dOs, gr, tid);
-        if (tid < QT) { Ms[tid] = ml.x; Ls[tid] = ml.y; Ds[tid] = dsv; As[tid] = anyv; }
+        if (tid < QT) {
+            const bool ok = rows_qs + tid < p.Tq;
+            Ms[tid] = ok ? ml.x : 0.f; Ls[tid] = ok ? ml.y : 0.f; Ds[tid] = ok ? dsv : 0.f; As[tid] = ok ? anyv : 1.f;
+        }
         __syncthreads();
         const int qn = next_tile(qt + 1);
         if (qn < n_qt) {
@@ -798,7 +811,8 @@ __global__ __launch_bounds__(64 * NW, DH <= 64 ? 2 : 1) void attn_bwd_dq_kernel(
     tile_fetch<DH, NT>(kr, toff, Kb, p.LQ, 0, p.Tk, tid);
     tile_fetch<DH, NT>(vr, toff, Vb, p.LQ, 0, p.Tk, tid);
     kflag = key_flag(kv, 0, p.Tk, lane);
-    const float2 ml = q_in ? reinterpret_cast<const float2*>(p.LSE)[((int64_t)b * p.H + h) * p.Tq + q] : make_float2(0.f, 0.f);
+    const int qc = q_in ? q : p.Tq - 1;
+    const float2 ml = reinterpret_cast<const float2*>(p.LSE)[((int64_t)b * p.H + h) * p.Tq + qc];
     const float* Ob = p.O + ((int64_t)b * p.Tq) * p.D + (int64_t)h * DH;
     const bool dense = GEN && p.x.mask_bits != nullptr;
     const bool dropping = GEN && (p.x.drop_mask != nullptr || p.x.drop_threshold != 0u);
@@ -813,17 +827,15 @@ __global__ __launch_bounds__(64 * NW, DH <= 64 ? 2 : 1) void attn_bwd_dq_kernel(
     float4 og[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a, o4 = a;
-        if (q_in) {
-            a = *reinterpret_cast<const float4*>(Qb + (int64_t)q * p.LQ + 8 * g + 4 * lh);
-            c = *reinterpret_cast<const float4*>(dOb + (int64_t)q * p.D + 8 * g + 4 * lh);
-            o4 = *reinterpret_cast<const float4*>(Ob + (int64_t)q * p.D + 8 * g + 4 * lh);
-        }
+        // a query past the end re-reads the last one (finite values; nothing of it is stored): no exec-masked load regions
+        const float4 a = *reinterpret_cast<const float4*>(Qb + (int64_t)qc * p.LQ + 8 * g + 4 * lh);
+        const float4 c = *reinterpret_cast<const float4*>(dOb + (int64_t)qc * p.D + 8 * g + 4 * lh);
+        const float4 o4 = *reinterpret_cast<const float4*>(Ob + (int64_t)qc * p.D + 8 * g + 4 * lh);
         qf[g][0] = a.x; qf[g][1] = a.y; qf[g][2] = a.z; qf[g][3] = a.w;
         gf[g][0] = c.x; gf[g][1] = c.y; gf[g][2] = c.z; gf[g][3] = c.w;
         og[g] = o4;
     }
-    const int fv = first_valid_key<NT>(kv, p.Tk, tid, &sh_fv);
+    const int fv = first_valid_key<NT>(kv, p.Tk, tid, &sh_fv, kflag);
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         dpart += gf[g][0] * og[g].x + gf[g][1] * og[g].y + gf[g][2] * og[g].z + gf[g][3] * og[g].w;
