@@ -1040,6 +1040,23 @@ def c4_family_rooflines(iters=20):
     linear_family(f"Linear {D}->{D} (attention projections), rows {M}", D, D, "4 x 6 layers")
     linear_family(f"Linear {D}->{F} / {F}->{D} (FFN), rows {M}", D, F, "2 x 6 layers")
     linear_family(f"Linear {D}->{V} (vocabulary head), rows {M}", D, V, "1")
+    # what the step really launches for a decoder layer's parameter gradients: the four dW+db GEMMs as ONE grid + ONE reduce
+    # (deferred parameter gradients); the three Linear families above time each dW on its own
+    jobs = [(rnd(M, K), rnd(N, K) / 16, rnd(M, N), torch.empty(N, K, device="cuda"), torch.empty(1, N, device="cuda"), K, N)
+            for (N, K) in ((D, F), (F, D), (D, D), (3 * D, D))]
+
+    def grouped():
+        call("nnhipWeightGradDefer", 1, st)
+        for (X, W, dO, dW, db, K, N) in jobs:
+            call("nnhipLinearModuleBackward", X, W, dO, None, dW, db, M, K, N, st)
+        call("nnhipWeightGradDefer", 0, st)
+
+    tg = med(grouped)
+    fl = sum(2.0 * M * K * N for (*_, K, N) in jobs)
+    fams.append({"family": f"dW+db of one decoder layer (4 GEMMs, rows {M}), deferred", "kernels": "gemm_f32_group_kernel + splitk_reduce_group_kernel",
+                 "launches_per_step": "1 x 6 layers", "flops": fl, "ms": round(tg, 4), "tflops": round(fl / (tg * 1e-3) / 1e12, 2),
+                 "frac_of_mfma_peak": round(fl / (tg * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)})
+    del jobs
     qkv = rnd(Bq, T, 3 * D)
     dqkv = torch.empty_like(qkv)
     kval = torch.ones(Bq, T, dtype=torch.int32, device="cuda")

@@ -80,57 +80,91 @@ struct SmallMlpAdam {
     double b1, b2;
     int enabled;
 };
-struct SgAdamPost {                                        // W1 / b1: nothing in this launch reads them -- update in place, at once
-    float* p; float* m; float* v; float* pb; float* mb; float* vb;
-    AdamHyper h;                                           // by value: a pointer to it forced the struct into scratch memory
-    bool on;
-    __device__ __forceinline__ void operator()(int64_t i, float g) const { if (on) adam1(p[i], g, m[i], v[i], h); }
-    __device__ __forceinline__ void asum(int64_t i, float g) const { if (on) adam1(pb[i], g, mb[i], vb[i], h); }
-};
-// W2 / b2 are INPUTS of the dW1 blocks (dZ = dO W2): they may only change once every block has read them.  Their gradients are
-// re-stored with agent-scope (write-through) stores and the LAST block of the launch to finish applies their update (ticket).
-struct SgPublishPost {
-    float* g; float* gb;
-    __device__ __forceinline__ void operator()(int64_t i, float v) const { __hip_atomic_store(&g[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    __device__ __forceinline__ void asum(int64_t i, float v) const { __hip_atomic_store(&gb[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-};
-
 constexpr int SG_MLP_MAXROWS = 256;
+// dW2 / db2 blocks: sg_tile16 hands the element (and row sum) a thread has just produced back to the kernel
+struct SgCapturePost {
+    float* v; float* s;
+    __device__ __forceinline__ void operator()(int64_t, float x) const { *v = x; }
+    __device__ __forceinline__ void asum(int64_t, float x) const { *s = x; }
+};
 
-template <int NW>
+// One dW1 tile (bx, by) = dZ^T X1 with the block's [rows] x 16 slice of dZ built in LDS first.  Every global load the tile needs
+// -- the optimizer state of the element a thread will produce, the W2 slice, dO, H, the X1 fragments -- is ISSUED before the first
+// wait (`after_issue()` runs there: the optimizer's device state is resolved behind the same round trip), `w2_read()` is called
+// once the block's W2 values have arrived (the arrival ticket of the optimizer-inside variant).
+template <int NW, class F1, class F2>
 __device__ __forceinline__ void sg_tile16_dz(const SmallMlpBwd& q, int bx, int by, float (*red)[16 * 16], float (*ared)[16],
                                              float* __restrict__ dOs, float* __restrict__ dZs, float* __restrict__ w2s,
-                                             const SgAdamPost& post) {
-    constexpr int U = 8, BS = NW * 64;
+                                             float* const (&pmv)[6], bool adam_on, const AdamHyper& h, F1 after_issue, F2 w2_read) {
+    constexpr int U = 8, BS = NW * 64, PRE = 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l16 = lane & 15, kq = lane >> 4;
     const int64_t m0 = (int64_t)by * 16, n0 = (int64_t)bx * 16;               // m = hidden unit, n = input feature, k = batch row
     const unsigned K = (unsigned)q.rows, groups = (K + 15) >> 4;
-    // the optimizer state of the element this thread will produce: fetched now, a memory round trip before it is needed
+    const int total = q.rows * 16;
+    // (1) optimizer state of this thread's element, (2) W2 slice, (3) dO, (4) H, (5) X1 fragments: all in flight together
     const int64_t orow = m0 + ((tid & 255) >> 4), ocol = n0 + (tid & 15), oidx = orow * q.in1 + ocol;
     const bool omine = tid < 256 && orow < q.hid && ocol < q.in1;
-    float pw = 0.f, mw = 0.f, vw = 0.f;
-    if (post.on && omine) { pw = post.p[oidx]; mw = post.m[oidx]; vw = post.v[oidx]; }
-    // ---- the block's slice of dZ, computed together: dZ[b][o] = (sum_c dO[b][c] W2[c][o]) [H[b][o] > 0], o = m0 .. m0+15 ------
-    for (int i = tid; i < q.rows * 16; i += BS) {
-        const int b = i >> 4, c = i & 15;
-        dOs[i] = c < q.out2 ? q.dO[(int64_t)b * q.out2 + c] : 0.f;
+    const bool bmine = bx == 0 && tid < 16 && m0 + tid < q.hid;
+    float pw = 0.f, mw = 0.f, vw = 0.f, pbv = 0.f, mbv = 0.f, vbv = 0.f;
+    if (adam_on) {
+        const int64_t oi = omine ? oidx : 0, bi = bmine ? m0 + tid : 0;       // clamped: unconditional loads, no exec-masked regions
+        pw = pmv[0][oi]; mw = pmv[1][oi]; vw = pmv[2][oi];
+        pbv = pmv[3][bi]; mbv = pmv[4][bi]; vbv = pmv[5][bi];
     }
-    __syncthreads();                                                           // (w2s: loaded by the caller)
-    for (int i = tid; i < q.rows * 16; i += BS) {
-        const int b = i >> 4, oo = i & 15;
-        const float h = m0 + oo < q.hid ? q.H[(int64_t)b * q.hid + m0 + oo] : 0.f;
-        float sacc = 0.f;
+    float w2r = 0.f;
+    {
+        const int c = (tid & 255) >> 4, oo = tid & 15;
+        const bool ok = tid < 256 && c < q.out2 && m0 + oo < q.hid;
+        w2r = q.W2[ok ? (int64_t)c * q.hid + m0 + oo : 0];
+        w2r = ok ? w2r : 0.f;
+    }
+    float dOr[PRE], Hr[PRE];
 #pragma unroll
-        for (int c = 0; c < SG_MLP_MAXC; ++c) sacc = fmaf(dOs[b * 16 + c], w2s[c * 16 + oo], sacc);
-        dZs[b * 17 + oo] = h > 0.f ? sacc : 0.f;
+    for (int e = 0; e < PRE; ++e) {
+        const int i = tid + e * BS, b = i >> 4, c = i & 15;
+        const bool okd = i < total && c < q.out2, okh = i < total && m0 + c < q.hid;
+        dOr[e] = q.dO[okd ? (int64_t)b * q.out2 + c : 0];
+        Hr[e] = q.H[okh ? (int64_t)b * q.hid + m0 + c : 0];
     }
-    __syncthreads();
-    // ---- dW1 tile = dZ^T X1 on the 16x16x4 MFMA, the waves splitting the batch rows; A comes from LDS, B (X1) from global ---
     const unsigned lb4 = (unsigned)q.in1 * 4u;
     const __amdgpu_buffer_rsrc_t rsb = sg_rsrc(q.X1, (unsigned)((int64_t)q.rows * q.in1 * 4));
     const bool b_ok = n0 + l16 < q.in1;
     const unsigned b_row = (unsigned)(n0 + l16) * 4u;
+    float4 bf[U];                                                              // first (for rows <= 512: only) pass of the k loop
+#pragma unroll
+    for (int u = 0; u < U; ++u) bf[u] = sg_fetch<false, false>(rsb, lb4, b_row, b_ok, 16u * ((unsigned)wave + (unsigned)u * NW) + 4u * kq, K);
+    __builtin_amdgcn_sched_barrier(0);
+    after_issue();
+    // ---- the block's slice of dZ, computed together: dZ[b][o] = (sum_c dO[b][c] W2[c][o]) [H[b][o] > 0], o = m0 .. m0+15 ------
+    if (tid < 256) w2s[tid] = w2r;
+#pragma unroll
+    for (int e = 0; e < PRE; ++e) {
+        const int i = tid + e * BS, c = i & 15;
+        if (i < total) dOs[i] = c < q.out2 ? dOr[e] : 0.f;
+    }
+    for (int i = tid + PRE * BS; i < total; i += BS) {
+        const int b = i >> 4, c = i & 15;
+        dOs[i] = c < q.out2 ? q.dO[(int64_t)b * q.out2 + c] : 0.f;
+    }
+    __syncthreads();
+    w2_read();
+    auto dz_of = [&](int i, float hval) {
+        const int b = i >> 4, oo = i & 15;
+        float sacc = 0.f;
+#pragma unroll
+        for (int c = 0; c < SG_MLP_MAXC; ++c) sacc = fmaf(dOs[b * 16 + c], w2s[c * 16 + oo], sacc);
+        dZs[b * 17 + oo] = hval > 0.f ? sacc : 0.f;
+    };
+#pragma unroll
+    for (int e = 0; e < PRE; ++e) {
+        const int i = tid + e * BS;
+        if (i < total) dz_of(i, m0 + (i & 15) < q.hid ? Hr[e] : 0.f);
+    }
+    for (int i = tid + PRE * BS; i < total; i += BS)
+        dz_of(i, m0 + (i & 15) < q.hid ? q.H[(int64_t)(i >> 4) * q.hid + m0 + (i & 15)] : 0.f);
+    __syncthreads();
+    // ---- dW1 tile = dZ^T X1 on the 16x16x4 MFMA, the waves splitting the batch rows; A comes from LDS, B (X1) from global ---
     sg_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     float asum = 0.f;
     auto dz = [&](unsigned b) -> float { return b < K ? dZs[b * 17 + l16] : 0.f; };
@@ -139,7 +173,8 @@ __device__ __forceinline__ void sg_tile16_dz(const SmallMlpBwd& q, int bx, int b
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const unsigned k0 = 16u * (gb + (unsigned)u * NW) + 4u * kq;
-            b[u] = sg_fetch<false, false>(rsb, lb4, b_row, b_ok, k0, K);
+            if (gb == (unsigned)wave) b[u] = bf[u];
+            else b[u] = sg_fetch<false, false>(rsb, lb4, b_row, b_ok, k0, K);
             a[u] = make_float4(dz(k0), dz(k0 + 1), dz(k0 + 2), dz(k0 + 3));
         }
 #pragma unroll
@@ -163,109 +198,131 @@ __device__ __forceinline__ void sg_tile16_dz(const SmallMlpBwd& q, int bx, int b
         for (int w = 1; w < NW; ++w) v += red[w][tid];
         if (omine) {
             q.dW1[oidx] = v;
-            if (post.on) {
-                adam1(pw, v, mw, vw, post.h);
-                post.p[oidx] = pw; post.m[oidx] = mw; post.v[oidx] = vw;
+#ifndef MLP_NO_W1ADAM
+            if (adam_on) {
+                adam1(pw, v, mw, vw, h);
+                pmv[0][oidx] = pw; pmv[1][oidx] = mw; pmv[2][oidx] = vw;
             }
+#endif
         }
     }
     if (q.db1 && bx == 0 && tid < 16) {
         float sacc = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) sacc += ared[w][tid];
-        if (m0 + tid < q.hid) {
+        if (bmine) {
             q.db1[m0 + tid] = sacc;
-            post.asum(m0 + tid, sacc);
+            if (adam_on) {
+                adam1(pbv, sacc, mbv, vbv, h);
+                pmv[3][m0 + tid] = pbv; pmv[4][m0 + tid] = mbv; pmv[5][m0 + tid] = vbv;
+            }
         }
     }
 }
 
+// Optimizer inside (ad.enabled): every gradient element is handed to Adam by the thread that produced it, its state fetched
+// before the GEMM.  W1 / b1 are read by nobody in this launch.  W2 / b2 are inputs of the dW1 blocks (dZ = dO W2): a dW2 block
+// applies its update only once EVERY block of the launch has checked in at the arrival counter -- a dW1 block checks in when its W2
+// slice has arrived, a dW2 block at once -- which normally happened long before the dW2 block's GEMM ends (it polls, it never
+// depends on a block dispatched after it doing anything but run).  The block that completes the counter also advances the
+// optimizer's device state: everyone has read it by then.  Counter = two levels (block b -> word 1 + b % 28, a word's last arrival
+// -> word 0: ~400 read-modify-writes of ONE address retire at ~25 M/s = 16 us); word 0 is cleared by the last dW2 block to pass.
+// (First version: dW2 / db2 published with agent-scope stores, the launch's last block applied their update -- store drain,
+// two dependent atomics and a reload on the kernel's tail: 11.4 us against 7 for the gradients alone.)
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void gemm_small_mlp_bwd_kernel(const SmallMlpBwd q, const SmallMlpAdam ad) {
     __shared__ float red[NW][16 * 16];
     __shared__ float ared[NW][16];
     __shared__ float ash[5];
-    // 1-D grid: the dW2 tiles first, then the dW1 tiles -- every block has work (and every block takes the arrival ticket below)
+    __shared__ int flag;
+    // 1-D grid: the dW2 tiles first, then the dW1 tiles
     const int tx0 = (q.hid + 15) >> 4, ty0 = (q.out2 + 15) >> 4, tx1 = (q.in1 + 15) >> 4;
-    const int nb0 = tx0 * ty0, id = (int)blockIdx.x;
+    const int nb0 = tx0 * ty0, id = (int)blockIdx.x, tid = (int)threadIdx.x;
     const bool first = id < nb0;
     const int bx = first ? id % tx0 : (id - nb0) % tx1, by = first ? id / tx0 : (id - nb0) / tx1;
     AdamHyper h = ad.h;                                    // (a local copy: modifying the by-value argument put it in scratch)
-    __shared__ int last;
-    if (threadIdx.x == 0) last = 0;
-    if (ad.enabled) adam_dev_begin(h, ad.dev_state, ad.b1, ad.b2, ad.grad_div, ash);
-    // Arrival ticket (optimizer inside): W2 / b2 are INPUTS of the dW1 blocks, so they may only change once every dW1 block has
-    // read them and every dW2 block has published its gradients.  A dW1 block checks in as soon as its W2 slice is in LDS (the
-    // atomics then run under its GEMM), a dW2 block when its stores have left; the last arrival updates W2 / b2 and advances the
-    // optimizer's device state.  Two levels: block b checks in at word 1 + b % 28 and the last arrival of each word at word 0
-    // (one word for all ~400 blocks made this kernel 33 us instead of 7: read-modify-writes on ONE address retire at ~25 M/s).
-    // The thread that checks in is lane 0 of the LAST wave: with 32 batch rows that wave has no k-group of the GEMM to wait for.
-    auto arrive = [&]() -> int {
-        const unsigned n = gridDim.x, b = blockIdx.x;
-        const unsigned ways = n < 28u ? n : 28u, s1 = b % ways;
+    const bool on = ad.enabled != 0;
+    const bool usher = tid == (NW - 1) * 64;               // lane 0 of the LAST wave: with 32 batch rows it has no k-group to wait for
+    const bool stepper = on && ad.dev_state != nullptr;    // one extra block (the last) whose only job is the optimizer's step
+    const unsigned n = gridDim.x - (stepper ? 1u : 0u), ways = n < 28u ? n : 28u;
+    if (stepper && (unsigned)id == n) {
+        // The next step's bias corrections are two double-precision pow(): ~3 us on one lane.  Done by the block that completed
+        // the arrival counter they sat on that block's (and so the launch's) critical path: 12.1 us against 6.1 for the gradients
+        // alone.  Here they are computed while everybody else works and stored once everybody has read the state.
+        if (tid == 0) {
+#ifdef MLP_NO_POW
+            AdamDevNext nx; nx.next = reinterpret_cast<const int*>(ad.dev_state)[0] + 2; nx.bc1 = 0.5f; nx.bc2 = 0.5f;
+#else
+            const AdamDevNext nx = adam_dev_next(ad.dev_state, ad.b1, ad.b2);
+#endif
+            for (int spin = 0; spin < (1 << 22); ++spin) {
+                if (__hip_atomic_load(ad.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= ways) {
+                    adam_dev_commit(ad.dev_state, nx, ad.b1, ad.b2);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (atomicAdd(ad.ticket + 30, 1u) == (unsigned)nb0) {           // counted with the dW2 blocks: the last to pass clears
+                __hip_atomic_store(ad.ticket + 30, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ad.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        return;
+    }
+    auto arrive = [&]() {
+        const unsigned b = blockIdx.x, s1 = b % ways;
         const unsigned n1 = n / ways + (s1 < n % ways ? 1u : 0u);
-        if (atomicAdd(ad.ticket + 1 + s1, 1u) != n1 - 1) return 0;
+        if (atomicAdd(ad.ticket + 1 + s1, 1u) != n1 - 1) return;
         __hip_atomic_store(ad.ticket + 1 + s1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return atomicAdd(ad.ticket, 1u) == ways - 1 ? 1 : 0;
+        atomicAdd(ad.ticket, 1u);
     };
-    const bool usher = threadIdx.x == (NW - 1) * 64;
+    AdamDevRaw raw;
+    if (on) adam_dev_issue(raw, ad.dev_state, ad.grad_div);
     if (first) {                                           // dW2[out2, hid] = dO^T[out2, rows] H[rows, hid],  db2 = row sums of dO^T
         SmallGemmParams p{};
         p.A = q.dO; p.lda = q.out2; p.B = q.H; p.ldb = q.hid; p.C = q.dW2; p.ldc = q.hid; p.asum = q.db2;
         p.M = q.out2; p.N = q.hid; p.K = q.rows; p.alpha = 1.f; p.beta = 1.f;
-        if (ad.enabled) {
-            const SgPublishPost post{q.dW2, q.db2};
-            sg_tile16<NW, false, false, false, 8, SgPublishPost>(p, bx, by, red, ared, nullptr, post);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the agent-scope gradient stores above are in L2 after this
-            __syncthreads();
-            if (usher) last = arrive();
-        } else {
+        if (!on) {
             sg_tile16<NW, false, false, false, 8>(p, bx, by, red, ared);
+            return;
+        }
+        const int64_t row = (int64_t)by * 16 + ((tid & 255) >> 4), col = (int64_t)bx * 16 + (tid & 15), idx = row * q.hid + col;
+        const bool mine = tid < 256 && row < q.out2 && col < q.hid;
+        const bool bmine = bx == 0 && tid < 16 && (int64_t)by * 16 + tid < q.out2;
+        const int64_t wi = mine ? idx : 0, bi = bmine ? (int64_t)by * 16 + tid : 0;
+        float pw = ad.p[0][wi], mw = ad.m[0][wi], vw = ad.v[0][wi];
+        float pb = ad.p[1][bi], mb = ad.m[1][bi], vb = ad.v[1][bi];
+        adam_dev_resolve(h, raw, ad.dev_state, ad.b1, ad.b2, ad.grad_div, ash);
+        if (usher) arrive();                               // this block has read the optimizer's state (and reads no W2)
+        float g = 0.f, gb = 0.f;
+        const SgCapturePost post{&g, &gb};
+        sg_tile16<NW, false, false, false, 8, SgCapturePost>(p, bx, by, red, ared, nullptr, post);
+        if (usher) {                                       // everyone checked in?  (normally long ago)
+            int ok = 0;
+#ifdef MLP_NO_SPIN
+            ok = 1;
+#endif
+            for (int spin = 0; spin < (1 << 22) && !ok; ++spin) {
+                if (__hip_atomic_load(ad.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= ways) { ok = 1; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            flag = ok;
+        }
+        __syncthreads();
+        if (flag) {                                        // (a block that gave up waiting leaves W2 / b2 alone: never seen)
+            if (mine) { adam1(pw, g, mw, vw, h); ad.p[0][idx] = pw; ad.m[0][idx] = mw; ad.v[0][idx] = vw; }
+            if (bmine) { adam1(pb, gb, mb, vb, h); ad.p[1][bi] = pb; ad.m[1][bi] = mb; ad.v[1][bi] = vb; }
+        }
+        if (usher && atomicAdd(ad.ticket + 30, 1u) == (unsigned)nb0 - 1 + (stepper ? 1u : 0u)) {   // the last poller to pass clears the counter
+            __hip_atomic_store(ad.ticket + 30, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ad.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     } else {
         __shared__ float dOs[SG_MLP_MAXROWS * 16], dZs[SG_MLP_MAXROWS * 17], w2s[256];
-        if (threadIdx.x < 256) {
-            const int c = threadIdx.x >> 4, oo = threadIdx.x & 15;
-            const int64_t m0 = (int64_t)by * 16;
-            w2s[threadIdx.x] = (c < q.out2 && m0 + oo < q.hid) ? q.W2[(int64_t)c * q.hid + m0 + oo] : 0.f;
-        }
-        if (ad.enabled) {
-            __syncthreads();                               // every thread's W2 element has arrived (the LDS write waited for it)
-            if (usher) last = arrive();
-        }
-        const SgAdamPost post{ad.p[2], ad.m[2], ad.v[2], ad.p[3], ad.m[3], ad.v[3], h, ad.enabled != 0};
-        sg_tile16_dz<NW>(q, bx, by, red, ared, dOs, dZs, w2s, post);
-    }
-    if (ad.enabled) {
-        __syncthreads();
-        if (last) {
-            constexpr int BS = NW * 64, E = 4;
-            const int n2 = q.out2 * q.hid, n = n2 + q.out2;
-            for (int base = 0; base < n; base += BS * E) {     // all loads of E elements per thread in flight together
-                float g[E], pp[E], mm[E], vv[E];
-                float *ptr_p[E], *ptr_m[E], *ptr_v[E];
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    const int i = base + e * BS + (int)threadIdx.x;
-                    const bool ok = i < n, w = i < n2;
-                    const int j = ok ? (w ? i : i - n2) : 0;
-                    ptr_p[e] = (w ? ad.p[0] : ad.p[1]) + j; ptr_m[e] = (w ? ad.m[0] : ad.m[1]) + j; ptr_v[e] = (w ? ad.v[0] : ad.v[1]) + j;
-                    g[e] = ok ? __hip_atomic_load((w ? q.dW2 : q.db2) + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
-                    pp[e] = ok ? *ptr_p[e] : 0.f; mm[e] = ok ? *ptr_m[e] : 0.f; vv[e] = ok ? *ptr_v[e] : 0.f;
-                }
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    if (base + e * BS + (int)threadIdx.x < n) {
-                        adam1(pp[e], g[e], mm[e], vv[e], h);
-                        *ptr_p[e] = pp[e]; *ptr_m[e] = mm[e]; *ptr_v[e] = vv[e];
-                    }
-                }
-            }
-            if (threadIdx.x == 0) {
-                __hip_atomic_store(ad.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (ad.dev_state) adam_dev_advance(ad.dev_state, ad.b1, ad.b2);
-            }
-        }
+        float* const pmv[6] = {ad.p[2], ad.m[2], ad.v[2], ad.p[3], ad.m[3], ad.v[3]};
+        sg_tile16_dz<NW>(q, bx, by, red, ared, dOs, dZs, w2s, pmv, on, h,
+                         [&]() { if (on) adam_dev_resolve(h, raw, ad.dev_state, ad.b1, ad.b2, ad.grad_div, ash); },
+                         [&]() { if (on && usher) arrive(); });
     }
 }
 
@@ -283,6 +340,7 @@ int gemm_small_mlp_backward(const float* X1, const float* H, const float* W2, co
     dim3 grid((unsigned)(ceil_div(hid, 16) * ceil_div(out2, 16) + ceil_div(in1, 16) * ceil_div(hid, 16)));
     SmallMlpAdam ad{};
     if (adam) ad = *adam;
+    if (ad.enabled && ad.dev_state) grid.x += 1;           // the stepper block
     if (nw == 8) hipLaunchKernelGGL((gemm_small_mlp_bwd_kernel<8>), grid, dim3(512), 0, st, q, ad);
     else hipLaunchKernelGGL((gemm_small_mlp_bwd_kernel<4>), grid, dim3(256), 0, st, q, ad);
     NNHIP_LAUNCH_CHECK("gemm_small_mlp_bwd_kernel");

@@ -727,6 +727,23 @@ template <int BS>
 __device__ __forceinline__ void ce_epilogue(const CeArgs& a, float lsum, float denom, float* red, int* ired) {
     if (!a.loss_out) return;
     const int nblk = (int)gridDim.x;
+    if (nblk == 2) {
+        // Two blocks (the README MLP's 32-row head): ONE exchange both publishes this block's sum and fetches the other's if it
+        // is there -- one L2 round trip instead of three (store + drain, ticket, reload: ~3 us of an 8 us kernel).  Whoever comes
+        // second adds the two sums in block order, the same bits as the general path below.
+        if (threadIdx.x == 0) {
+            unsigned long long* w = reinterpret_cast<unsigned long long*>(a.sync + 2);
+            const unsigned long long mine = (1ull << 63) | ((unsigned long long)blockIdx.x << 32) | (unsigned long long)__float_as_uint(lsum);
+            const unsigned long long old = atomicExch(w, mine);
+            if (old >> 63) {
+                const float other = __uint_as_float((unsigned)(old & 0xffffffffull));
+                const float s = ((old >> 32) & 1ull) == 0 ? other + lsum : lsum + other;
+                a.loss_out[0] = a.mode == 1 ? s / denom : s;
+                __hip_atomic_store(w, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        return;
+    }
     if (threadIdx.x == 0) {
         // one dword per block: agent-scope (write-through) store + drain, no L2-wide release needed for it
         __hip_atomic_store(&a.partial[blockIdx.x], lsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -105,6 +105,28 @@ class GraphedTrainStep:
         self.g_opt = None
         self.mode = "single" if self.single else "pieces"
         self.ingraph_error = None
+        # No garbage collection while this thread captures: a collection that happens to run inside the capture region may
+        # finalise an EARLIER step object's hipGraph (its private pool is released with hipFree) -- a capture-unsafe call on the
+        # capturing thread that invalidates the capture (seen as hipErrorStreamCaptureInvalidated at the next launch, once in a
+        # few runs of the test suite, depending on where the collector's allocation counters stood).
+        import gc
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            self._capture_all(s, bucket, pre_optim, capture_collectives)
+        finally:
+            if gc_was_on:
+                gc.enable()
+        torch.cuda.synchronize()
+        # the captured kernels hold these addresses
+        self._addr = self._addresses()
+        self._locked = True
+        GraphedTrainStep._live += 1
+        call_hip_function("nnhipWorkspaceLock", 1)
+
+    def _capture_all(self, s, bucket, pre_optim, capture_collectives):
+        torch = self._torch
         overlap = bool(getattr(bucket, "overlap", False)) and not self.single
         if capture_collectives and not self.single and pre_optim is None:
             try:
@@ -140,12 +162,6 @@ class GraphedTrainStep:
             self._bind_grads()
             with torch.cuda.graph(self.g_opt, pool=self.pieces[0][0].pool(), capture_error_mode=self._CAPTURE_MODE):
                 self.opt.step()
-        torch.cuda.synchronize()
-        # the captured kernels hold these addresses
-        self._addr = self._addresses()
-        self._locked = True
-        GraphedTrainStep._live += 1
-        call_hip_function("nnhipWorkspaceLock", 1)
 
     # ---- capture of the overlapped variant: one graph per bucket segment ------------------------------------------
     def _capture_overlapped(self, side_stream):
