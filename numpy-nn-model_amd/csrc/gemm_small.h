@@ -82,6 +82,16 @@ __device__ __forceinline__ void sg_tile16(const SmallGemmParams& p, int bx, int 
     const unsigned a_row = (unsigned)(m0 + l16) * (AKM ? la4 : 4u), b_row = (unsigned)(n0 + l16) * (BKM ? lb4 : 4u);
     sg_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     float asum = 0.f;
+    // the epilogue's operands of the element this thread will finish (bias, addend, activation-gradient argument): fetched NOW,
+    // under the operand loads -- loaded where they are used they were one more dependent L2 round trip (~1 us) on the tail of
+    // every small GEMM.  Clamped index: unconditional loads.
+    const int64_t erow = m0 + ((tid & 255) >> 4), ecol = n0 + (tid & 15);
+    const bool emine = tid < 256 && erow < p.M && ecol < p.N;
+    const int64_t eidx = emine ? erow * p.ldc + ecol : 0;
+    float e_bias = 0.f, e_add = 0.f, e_dact = 0.f;
+    if (p.bias) e_bias = p.bias[emine ? ecol : 0];
+    if (p.addend) e_add = p.addend[eidx];
+    if (p.dact_arg) e_dact = p.dact_arg[eidx];
     for (unsigned gb = wave; gb < groups; gb += (unsigned)NW * U) {
         float4 a[U], b[U];
 #pragma unroll
@@ -116,10 +126,10 @@ __device__ __forceinline__ void sg_tile16(const SmallGemmParams& p, int bx, int 
         for (int w = 1; w < NW; ++w) v += red[w][o];
         const int64_t row = m0 + (o >> 4), col = n0 + (o & 15);
         if (row < p.M && col < p.N) {
-            v = p.alpha * v + (p.bias ? p.bias[col] : 0.f);
-            if (p.addend) v += p.addend[row * p.ldc + col];
+            v = p.alpha * v + e_bias;
+            if (p.addend) v += e_add;
             if (p.dact_arg) {
-                const float x = p.dact_arg[row * p.ldc + col];
+                const float x = e_dact;
                 v = p.dact == 2 ? (x > 0.f ? v : 0.f) : v * swish_grad_(x, p.beta);
             }
             if (p.act == SG_ACT_SWISH) {

@@ -960,15 +960,17 @@ __global__ __launch_bounds__(1024) void reduce_loss_kernel(const float* __restri
 // The whole problem in one block of BS threads (one wave per row, waves striding the rows).
 // Rows [r0, r1) of a small problem, one wave per row (waves striding the rows); xs / xld: where row r0 is READ and the pitch
 // there (the logits themselves, or a copy of them in LDS).  Returns the wave's loss sum (meaningful on lane 0).
-template <int BS>
-__device__ __forceinline__ float ce_rows_range(const CeArgs& a, float scale, const float* xs, int64_t xld, int64_t r0, int64_t r1) {
+// ypre (optional): the labels of this wave's rows r0 + wave, + NWV, ... fetched by the caller ahead of time; then the range holds at
+// most NPRE rows per wave (the loop has a compile-time trip count: ypre stays in registers).
+template <int BS, int NPRE = 0>
+__device__ __forceinline__ float ce_rows_range(const CeArgs& a, float scale, const float* xs, int64_t xld, int64_t r0, int64_t r1,
+                                               const int64_t* ypre = nullptr) {
     constexpr int NWV = BS / 64;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float lsum = 0.f;
-    for (int64_t r = r0 + wave; r < r1; r += NWV) {
+    auto one_row = [&](int64_t r, int64_t y) {
         const float* x = xs + (r - r0) * xld;
         float* dx = a.dlogits + r * a.ld;
-        const int64_t y = load_label(a.labels, r, a.lbytes);
         const bool live = y != a.ignore && y >= 0 && y < a.cols;   // same guard as the large kernels (cross_entropy.cu:176)
         const float wy = live ? (a.cw ? a.cw[y] : 1.f) : 0.f;
         float mx = -INFINITY;
@@ -993,6 +995,15 @@ __device__ __forceinline__ float ce_rows_range(const CeArgs& a, float scale, con
             a.lse[r] = lse;
             lsum += l;
         }
+    };
+    if constexpr (NPRE > 0) {
+#pragma unroll
+        for (int j = 0; j < NPRE; ++j) {
+            const int64_t r = r0 + wave + (int64_t)j * NWV;
+            if (r < r1) one_row(r, ypre[j]);
+        }
+    } else {
+        for (int64_t r = r0 + wave; r < r1; r += NWV) one_row(r, load_label(a.labels, r, a.lbytes));
     }
     return lsum;
 }
@@ -1031,15 +1042,39 @@ __global__ __launch_bounds__(NW * 64) void linear_ce_small_kernel(const SmallGem
     __shared__ int ired[17];
     __shared__ float red[16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float scale, denom;
-    ce_prologue<BS>(a, red, ired, scale, denom);
     const int by = (int)blockIdx.x;
     const int64_t r0 = (int64_t)by * 16, r1 = min(r0 + 16, a.rows);
+    // Every label this block needs is requested BEFORE the GEMM's operands: the label of row `tid` for the 'mean' denominator
+    // (rows <= 256 < BS... or <= BS: one label per thread) and the labels of the rows this wave will finish.  Where they were
+    // loaded at their point of use, the count and each row's label were dependent L2 round trips in front of / behind the GEMM.
+    constexpr int NPRE = 16 / NW;
+    const bool counting = a.mode == 1 && a.count_in_kernel && a.rows <= BS;
+    int64_t lcount = a.ignore;
+    if (counting) lcount = load_label(a.labels, (int64_t)threadIdx.x < a.rows ? (int64_t)threadIdx.x : a.rows - 1, a.lbytes);
+    int64_t ypre[NPRE];
+#pragma unroll
+    for (int j = 0; j < NPRE; ++j) {
+        const int64_t r = r0 + wave + (int64_t)j * NW;
+        ypre[j] = load_label(a.labels, r < r1 ? r : r1 - 1, a.lbytes);
+    }
     for (int bx = 0; (int64_t)bx * 16 < p.N; ++bx) {
         sg_tile16<NW, true, true, VEC, 8>(p, bx, by, gred, ared, tile - r0 * 32);   // row r of C also lands at tile[(r - r0) * 32 + col]
         __syncthreads();                                   // gred is reused by the next tile; after the last one: tile is complete
     }
-    const float lsum = ce_rows_range<BS>(a, scale, tile, 32, r0, r1);
+    float scale, denom;
+    if (counting) {                                        // ce_prologue's count_in_kernel branch on the prefetched labels
+        const bool cnt = (int64_t)threadIdx.x < a.rows && lcount != a.ignore;
+        float ws = 0.f;
+        if (a.cw && cnt && lcount >= 0 && lcount < a.cols) ws = a.cw[lcount];
+        const int ci = block_sum_int<BS / 64>(cnt ? 1 : 0, ired);
+        if (a.cw) ws = block_sum<BS / 64>(ws, red);
+        denom = a.cw ? ws : (float)ci;
+        if (a.count_out && blockIdx.x == 0 && threadIdx.x == 0) a.count_out[0] = ci;
+        scale = denom > 0.f ? 1.0f / denom : 0.0f;
+    } else {
+        ce_prologue<BS>(a, red, ired, scale, denom);
+    }
+    const float lsum = ce_rows_range<BS, NPRE>(a, scale, tile, 32, r0, r1, ypre);
     if (!a.loss_out) return;
     __syncthreads();
     if (lane == 0) red[wave] = lsum;
