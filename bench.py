@@ -344,7 +344,7 @@ def workload_c1(args, rank, world):
         "config": {"workload": "C1: MNIST-MLP 784->128->10 training step (Linear+ReLU+CrossEntropy+Adam), batch 32 per GPU",
                    "global_batch": Bsz * world, "parallelism": f"dp{world}",
                    "launch": (f"hipGraph replay, {U} steps per graph" if U > 1 else "hipGraph replay") if args.graph else "eager"},
-        "roofline": {"kernel": "whole step (5 launches, launch-latency bound)", "bound": "mfma",
+        "roofline": {"kernel": "whole step (3 launches: Linear+ReLU, Linear+CrossEntropy, backward+Adam; dependent-latency bound)", "bound": "mfma",
                      "achieved": round(flops / (dev_ms * 1e-3) / 1e12, 5), "peak": PEAK_F32_MFMA_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(flops / (dev_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 6),
                      "traffic": None, "avg_step_device_ms": round(dev_ms, 4)},
