@@ -2896,3 +2896,39 @@ def test_linear_dw_uneven_split(hip, rows, inf, outf, bias):
     assert_dot_close(host(dW), host(dO).T, host(X), err_msg="uneven-split dW")
     if bias:
         assert_within(host(db), host(dO).astype(np.float64).sum(0), 32 * U24 * np.abs(host(dO)).astype(np.float64).sum(0), "db")
+
+
+@pytest.mark.gpu
+def test_deferred_weight_grads_accumulate_across_backward_calls(hip, monkeypatch):
+    """Two backward() calls without zero_grad(): the second call's parameter gradients are ADDED to the first's
+    (neunet/autograd.py:85-93).  With the queue on, that addition must not read a gradient that is still a queued GEMM
+    (`_finish_param` flushes first): same sums as with the queue off."""
+    from neunet_hip import _lib
+    from neunet_hip.nn.experimental import HIPLinear
+    rng = np.random.default_rng(11)
+    rows, inf, hid = 4096, 256, 384
+    x1, x2 = (rng.standard_normal((rows, inf)) * 0.5).astype(np.float32), (rng.standard_normal((rows, inf)) * 0.5).astype(np.float32)
+    g1, g2 = rng.standard_normal((rows, inf)).astype(np.float32), rng.standard_normal((rows, inf)).astype(np.float32)
+    init = None
+
+    def run(group):
+        nonlocal init
+        monkeypatch.setitem(_lib._wgrad, "group", group)
+        l1, l2 = HIPLinear(inf, hid), HIPLinear(hid, inf)
+        params = [l1.weight, l1.bias, l2.weight, l2.bias]
+        if init is None:
+            init = [p.data.clone() for p in params]
+        for p, v in zip(params, init):
+            p.data.copy_(v)
+        for x, g in ((x1, g1), (x2, g2)):
+            out = l2(l1(T(hip, x)))
+            out.backward(g)
+        return [host(p.grad) for p in params]
+
+    on, off = run(4), run(0)
+    for k, (a, b) in enumerate(zip(on, off)):
+        assert_close_scaled(a, b, err_msg=f"accumulated gradient {k}")
+    # and against float64 for the last layer's weight: dW2 = sum over both passes of dO^T h
+    W1, b1 = host(init[0]).astype(np.float64), host(init[1]).astype(np.float64)
+    ref = sum(g.astype(np.float64).T @ (x.astype(np.float64) @ W1.T + b1) for x, g in ((x1, g1), (x2, g2)))
+    assert_close_scaled(on[2], ref, err_msg="accumulated dW2 vs float64")
