@@ -1492,6 +1492,8 @@ static int ce_launch(CeArgs a, hipStream_t st) {
         //  arrival word: 200 us for 1792 blocks, read-modify-writes on one address retire at ~25 M/s; 64 sharded 64-bit
         //  words polled by one lane each: +20 us, a grid barrier costs the launch ramp of the last block.)  The cost grows
         //  with the grid, so a counting launch caps its grid at four blocks per compute unit.
+        //  Also slower: 2 / 8 / 32 "counter" blocks that publish {count, flag} while every other block polls the flag after issuing
+        //  its first rows' loads (falls back to its own count): 56.1 / 56.1 / 58.6 us against 53.1 at 8192 x 4096.)
         const int64_t capped = nblk > 1024 ? 1024 : nblk;
         if ((double)capped * (double)a.rows * a.lbytes <= 64.0 * 1024 * 1024) {
             a.count_in_kernel = 1;
