@@ -85,7 +85,7 @@ int nnhipLinearModuleBackwardEx(const float* X, const float* W, const float* dO,
  * a dW/db GEMM that is too small to fill the chip alone (<= 256 output tiles of 128x128, >= 4096 rows, 16-B aligned operands,
  * exact-fp32 mode); dX is still computed by the call itself.  nnhipWeightGradFlush launches everything queued as ONE grid and
  * ONE reduce -- a transformer layer's four dW GEMMs stop paying four launch ramps, four simultaneous slab epilogues and four
- * tails.  The reduction is cut into fixed 2048-row chunks, so a gradient's bits do not depend on what else was in the queue.
+ * tails.  A job's reduction is always cut into four chunks, so a gradient's bits do not depend on what else was in the queue.
  * Contract while a job is queued: its X and dO stay alive and unmodified, its dW/db are not read.  enable == 0: flush on
  * `stream`, then every later dW is launched where it is asked for (the default).  nnhipWeightGradPending: queued jobs.  ABI 204 */
 int nnhipWeightGradDefer(int32_t enable, nnhipStream_t stream);

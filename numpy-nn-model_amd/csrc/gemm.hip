@@ -782,13 +782,21 @@ static int gemm_f32_uneven_split(const float* A, const float* B, float* C, float
 
 // ---- grouped parameter-gradient GEMMs (linear.hip: the deferred dW queue) ------------------------------------------------------
 // Job i: C_i[M,N] = sum_k A_i[k][m] B_i[k][n] (dW = dO^T X: A = dO [K, M], B = X [K, N], dense), asum_i[m] = sum_k A_i[k][m] (db) or
-// null.  The reduction is cut into chunks of WGRAD_CHUNK rows whatever else is in the group, so a job's bits do not depend on
-// the company it is launched in (data-parallel and single-process steps flush the queue at different points).
-constexpr int64_t WGRAD_CHUNK = 2048;
+// null.  A job's reduction is always cut into FOUR chunks (>= 1024 rows each), whatever else is in the group, so its bits do not
+// depend on the company it is launched in (data-parallel and single-process steps flush the queue at different points).  Swept on
+// the C4 step (chunk rows x jobs per flush): 2048 x 4 jobs 21.66 ms, 4096 x 4: 21.61, 4096 x 8: 21.58, 8192 x 8: 21.55, 8192 x 4 (384
+// blocks, an under-filled generation): 22.99 -- few fat chunks (a quarter of the slab traffic) win as long as a flush has >= ~700
+// blocks; four chunks keep a small flush (a DP segment boundary) from falling under that.
+static int64_t wgrad_chunk(int64_t K) {
+    static const int64_t forced = []() { const char* e = getenv("NNHIP_WGRAD_CHUNK"); return (int64_t)(e ? atoi(e) : 0); }();   // dev knob
+    if (forced > 0) return ceil_div(forced, (int64_t)32) * 32;
+    const int64_t c = ceil_div(ceil_div(K, (int64_t)4), (int64_t)32) * 32;
+    return c < 1024 ? 1024 : c;
+}
 bool gemm_f32_wgrad_group_ok(const WgradJob& j) {
     static const int on = []() { const char* e = getenv("NNHIP_WGRAD_GROUP_KERNEL"); return e ? atoi(e) : 1; }();
     if (!on || gemm_mode() != 0) return false;
-    if (j.M <= 0 || j.N <= 0 || j.K < 2 * WGRAD_CHUNK || (j.K & 7)) return false;
+    if (j.M <= 0 || j.N <= 0 || j.K < 4096 || (j.K & 7)) return false;
     if ((j.M & 3) || (j.N & 3) || !aligned16(j.A) || !aligned16(j.B) || !aligned16(j.C)) return false;
     if (j.K * j.M + 128 >= ((int64_t)1 << 30) || j.K * j.N + 128 >= ((int64_t)1 << 30)) return false;     // 32-bit operand offsets
     const int64_t tiles = ceil_div(j.M, BM) * ceil_div(j.N, BN);
@@ -808,7 +816,7 @@ int gemm_f32_wgrad_group(const WgradJob* jobs, int n, hipStream_t st) {
     size_t floats = 0;
     for (int i = 0; i < n; ++i) {
         const WgradJob& j = jobs[i];
-        const int64_t kps = ceil_div(WGRAD_CHUNK, BK) * BK;
+        const int64_t kps = wgrad_chunk(j.K);
         floats += (size_t)ceil_div(j.K, kps) * (size_t)(j.M * j.N + (j.asum ? j.M : 0));
     }
     float* slab = static_cast<float*>(workspace(floats * sizeof(float)));
@@ -824,7 +832,7 @@ int gemm_f32_wgrad_group(const WgradJob* jobs, int n, hipStream_t st) {
         p.A = j.A; p.B = j.B; p.C = j.C; p.M = j.M; p.N = j.N; p.K = j.K; p.lda = j.M; p.ldb = j.N; p.ldc = j.N;
         p.batch2 = 1; p.alpha = 1.f; p.beta = 1.f;
         p.tiles_m = (int)ceil_div(j.M, BM); p.tiles_n = (int)ceil_div(j.N, BN);
-        p.k_per_split = ceil_div(WGRAD_CHUNK, BK) * BK;
+        p.k_per_split = wgrad_chunk(j.K);
         p.splitk = (int)ceil_div(j.K, p.k_per_split);
         p.slab = slab; p.zeros = zeros; p.cvec = 1; p.asum = j.asum;
         slab += (size_t)p.splitk * j.M * j.N;

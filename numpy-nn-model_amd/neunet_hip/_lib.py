@@ -226,12 +226,12 @@ def call_hip_function(name: str, *args):
 
 # ---- deferred parameter gradients (include/neunet_hip.h: nnhipWeightGradDefer) ---------------------------------------------------
 # During Tensor.backward() the library queues the dW/db GEMMs of layers too small to fill the chip alone and launches them a
-# layer's worth at a time as ONE grid (GPT-tiny: four GEMMs per decoder layer; measured 0.76 vs 0.87 ms).  The queued jobs read
+# two layers' worth at a time as ONE grid (GPT-tiny: four GEMMs per decoder layer, eight per flush).  The queued jobs read
 # the X and dO buffers of the calls that queued them, so every array argument of those calls is kept referenced here until the
 # flush -- otherwise torch's caching allocator could hand a dO buffer to the next kernel while a queued GEMM still has to read it.
 _WGRAD_ENTRIES = {"nnhipLinearModuleBackward", "nnhipLinearModuleBackwardEx", "nnhipLinearModuleBackwardAct",
                   "nnhipLinearSwishBackward"}
-_wgrad = {"on": False, "keep": [], "group": int(os.environ.get("NNHIP_WGRAD_GROUP", "4"))}
+_wgrad = {"on": False, "keep": [], "group": int(os.environ.get("NNHIP_WGRAD_GROUP", "8"))}
 
 
 def _wgrad_after_call(args):

@@ -1,4 +1,8 @@
 cd /tmp; export TMPDIR=/tmp
-timeout 900 python -m pytest $GRAFT_REPO_ROOT/tests -q -m gpu -x -k "cross_entropy or ce_ or loss or gpt" 2>&1 | tail -3
+timeout 2400 python -m pytest $GRAFT_REPO_ROOT/tests -q -m gpu -x 2>&1 | tail -3
 cd $GRAFT_REPO_ROOT
-for s in 8 0 2 32; do echo "share=$s"; NNHIP_CE_SHARE=$s python tools/kbench.py --only ce --iters 60 2>&1 | grep "ce "; done
+python bench.py --workload c4 --no-cpu-baseline > gpurun_out/c4_x.json 2>gpurun_out/c4.err; python -c "
+import json; d=json.load(open('gpurun_out/c4_x.json')); print('c4', d['value'], d['ms_per_step'])"
+python bench.py --workload c4 --no-cpu-baseline --force-dp > gpurun_out/c4_dp.json 2>gpurun_out/c4.err; python -c "
+import json; d=json.load(open('gpurun_out/c4_dp.json')); print('c4 forced dp', d['value'], d['ms_per_step'])"
+python tools/kbench.py --only wgroup --iters 40 2>&1 | grep "linear"
