@@ -2790,7 +2790,7 @@ def test_deferred_weight_grads_grouped_launch(hip):
     depend on its company (alone == in a group of four), small layers are not queued, dX is produced by the call itself."""
     from neunet_hip._lib import call_hip_function as call, get_current_stream_ptr
     st = get_current_stream_ptr()
-    shapes = [(4096, 512, 512), (4096, 512, 1536), (8192, 256, 384), (4096, 2048, 512)]   # rows, in, out
+    shapes = [(4096, 512, 512), (4104, 260, 388), (8192, 256, 384), (5000, 2048, 516)]   # rows, in, out (two of them ragged: partial tiles, a partial last k-chunk)
     probs = [_wgrad_problem(*s, seed=i, bias=(i != 2)) for i, s in enumerate(shapes)]
     ref = []
     for (X, W, dO, dW, db), (r, i, o) in zip(probs, shapes):
