@@ -1,2 +1,2 @@
-cd /tmp; export TMPDIR=/tmp
-timeout 900 python -m pytest $GRAFT_REPO_ROOT/tests -q -m gpu -x -k "deferred_weight" 2>&1 | tail -8
+cd $GRAFT_REPO_ROOT
+timeout 600 python examples/conv_classifier.py --steps 40 2>&1 | tail -6
