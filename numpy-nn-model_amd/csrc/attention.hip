@@ -175,6 +175,7 @@ __device__ __forceinline__ void tile_commit(float* __restrict__ S, const TileReg
 // padding flag of key kv0 + lane (1 = real token); the wave ballots it into a 64-bit mask per tile
 __device__ __forceinline__ int key_flag(const int32_t* __restrict__ kv, int kv0, int Tk, int lane) {
     if (!kv) return 1;
+    if (Tk <= 0) return 0;                                   // (no keys at all: nothing to clamp to)
     const int i = kv0 + lane;
     const int v = kv[i < Tk ? i : Tk - 1];                   // unconditional load of a clamped index: no exec-masked region (a
     return i < Tk ? v : 0;                                   // conditional load is its own basic block and may end in vmcnt(0))
