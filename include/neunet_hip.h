@@ -82,8 +82,8 @@ int nnhipLinearModuleBackwardEx(const float* X, const float* W, const float* dO,
 
 /* Deferred parameter gradients (extension; the reference computes each layer's dW where its backward runs, linear.py:17-24).
  * enable != 0: from now on the Linear backward entry points (nnhipLinearModuleBackward[Ex|Act], nnhipLinearSwishBackward) QUEUE
- * a dW/db GEMM that is too small to fill the chip alone (<= 256 output tiles of 128x128, >= 4096 rows, 16-B aligned operands,
- * exact-fp32 mode); dX is still computed by the call itself.  nnhipWeightGradFlush launches everything queued as ONE grid and
+ * a dW/db GEMM that is too small to fill the chip alone (<= 256 output tiles of 128x128, >= 4096 rows, 16-B aligned operands;
+ * either GEMM mode); dX is still computed by the call itself.  nnhipWeightGradFlush launches everything queued as ONE grid and
  * ONE reduce -- a transformer layer's four dW GEMMs stop paying four launch ramps, four simultaneous slab epilogues and four
  * tails.  A job's reduction is always cut into four chunks, so a gradient's bits do not depend on what else was in the queue.
  * Contract while a job is queued: its X and dO stay alive and unmodified, its dW/db are not read.  enable == 0: flush on

@@ -195,12 +195,6 @@ __device__ __forceinline__ void tail_mma(f32x16 (&acc)[2][2], const float* __res
 
 // CS (outer-major A only): every thread also accumulates the A elements it stages -- with the [BK][128] tile layout a
 // thread owns the same 4 A rows (m) in every k-tile -- and the tile_n == 0 blocks reduce them to asum[m] = sum_k A[m,k].
-// block id -> logical id: XCD-aware order.  Block b runs on XCD b % 8; each XCD gets a contiguous run of logical ids.  Bijective.
-__device__ __forceinline__ int xcd_order(int b, int nwg) {
-    const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-}
-
 // One block's work: logical block L of problem p (L in [0, tiles * splitk)), batch index `by`.
 template <int BK, bool AKC, bool BKC, bool VEC, bool CS = false>
 __device__ __forceinline__ void gemm_f32_block(const GemmParams& p, const int L, const int by, float* __restrict__ smem) {
@@ -364,14 +358,6 @@ __global__ __launch_bounds__(NT, (BK <= 16) ? 3 : 2) void gemm_f32_kernel(const 
 // 16384-long reduction) each paid a launch ramp, a split-K epilogue in which every block stores its slab at the same moment,
 // and a tail; queued behind each other in one grid the blocks of the next problem start as the previous one's finish
 // (measured on the equivalent single GEMM 16384x512->6144: 0.757 ms against 0.868 ms for the four launches).
-constexpr int GEMM_GROUP_MAX = 8;
-struct GemmGroup {
-    GemmParams p[GEMM_GROUP_MAX];
-    int start[GEMM_GROUP_MAX + 1];
-    int n;
-    int by_job;      // 0: one XCD-aware order over the whole grid (an XCD works on one or two jobs);  1: jobs in DISPATCH order, the
-                     // XCD-aware order inside each (all of job 0's blocks are handed out before any of job 1's)
-};
 template <int BK>
 __global__ __launch_bounds__(NT, 2) void gemm_f32_group_kernel(const GemmGroup g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -506,6 +492,7 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
 
 // gemm_bf3.hip: the same tiles on the bf16 matrix cores (exact 3-way bf16 split of every fp32 operand, 6 products)
 int gemm_bf3_launch(const GemmParams& p, bool a_kmajor, bool b_kmajor, bool vec, bool cs, int64_t batch, hipStream_t st);
+int gemm_bf3_group_launch(const GemmGroup& g, int blocks, hipStream_t st);
 // launches per kernel family since load (nnhipGemmLaunchCount): 0 classic fp32 128x128, 1 persistent fp32, 2 small, 3 split-bf16.
 // Host-side counters for tests that must know WHICH kernel produced a result (a "bf16x3" test that only ever reaches the
 // small kernel proves nothing about gemm_bf3_kernel).
@@ -613,7 +600,7 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
     {   // one under-filled generation of a dW-type GEMM: uneven two-way split (gemm_f32_uneven_split)
         static const int uneven_on = []() { const char* e = getenv("NNHIP_GEMM_UNEVEN"); return e ? atoi(e) : 1; }();
         const int64_t t = ceil_div(M, BM) * ceil_div(N, BN);
-        if (uneven_on && gemm_mode() == 0 && !a_kmajor && !b_kmajor && batch == 1 && !bias && !preact && !addend && !dswish &&
+        if (uneven_on && !a_kmajor && !b_kmajor && batch == 1 && !bias && !preact && !addend && !dswish &&
             act == ACT_NONE && alpha == 1.0f && t > 256 && t <= 496 && K >= 4096 && (K & 7) == 0 && (M & 3) == 0 && (N & 3) == 0 &&
             (lda & 3) == 0 && (ldb & 3) == 0 && aligned16(A) && aligned16(B) && K * lda + 128 < ((int64_t)1 << 30) &&
             K * ldb + 128 < ((int64_t)1 << 30)) {
@@ -622,7 +609,7 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
             static const int bias_tiles = []() { const char* e = getenv("NNHIP_UNEVEN_BIAS"); return e ? atoi(e) : 0; }();   // dev knob
             const int64_t K1 = (K * t * 966 / ((int64_t)512 * 1000) + 31) / 32 * 32 + 32 * bias_tiles;
             if (K - K1 >= 256) {
-                ++g_gemm_launches[0];
+                ++g_gemm_launches[gemm_mode() == 1 ? 3 : 0];
                 return gemm_f32_uneven_split(A, B, C, asum, M, N, K, lda, ldb, ldc, K1, st);
             }
         }
@@ -729,6 +716,23 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
 }
 
 
+// launch a planned group with the kernel of the current GEMM mode (exact fp32 MFMA / split-bf16)
+static int launch_group(const GemmGroup& g, int blocks, hipStream_t st) {
+    if (gemm_mode() == 1) return gemm_bf3_group_launch(g, blocks, st);
+    constexpr int BK = 32;
+    constexpr size_t lds = 2 * (Tile<BK, false>::SIZE + Tile<BK, false>::SIZE) * sizeof(float);
+    auto kern = gemm_f32_group_kernel<BK>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return hip_status(e, "hipFuncSetAttribute(gemm group)");
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NT), lds, st, g);
+    NNHIP_LAUNCH_CHECK("gemm_f32_group_kernel");
+    return 0;
+}
+
 // ---- one generation that does not fill the chip: uneven two-way split of the reduction -------------------------------------------
 // A dW-type GEMM (both operands outer-major) with t tiles, 256 < t < 512, runs ONE generation on the 512 resident slots (2 per CU):
 // every CU with two blocks takes the full K while 512 - t slots idle -- the GPT-tiny head's dW[15000, 512] has 472 tiles and ran at
@@ -760,16 +764,7 @@ static int gemm_f32_uneven_split(const float* A, const float* B, float* C, float
         g.start[i] = i * tiles;
     }
     for (int i = 2; i <= GEMM_GROUP_MAX; ++i) g.start[i] = 2 * tiles;
-    constexpr size_t lds = 2 * (Tile<BK, false>::SIZE + Tile<BK, false>::SIZE) * sizeof(float);
-    auto kern = gemm_f32_group_kernel<BK>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return hip_status(e, "hipFuncSetAttribute(gemm group)");
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(2 * tiles)), dim3(NT), lds, st, g);
-    NNHIP_LAUNCH_CHECK("gemm_f32_group_kernel");
+    if (int rc = launch_group(g, 2 * tiles, st)) return rc;
     const int rvec = (ldc & 3) == 0 && aligned16(C);
     const int64_t work = rvec ? M * N / 4 : M * N;
     const int blocks = (int)(ceil_div(work, 256) < 2048 ? ceil_div(work, 256) : 2048);
@@ -795,7 +790,7 @@ static int64_t wgrad_chunk(int64_t K) {
 }
 bool gemm_f32_wgrad_group_ok(const WgradJob& j) {
     static const int on = []() { const char* e = getenv("NNHIP_WGRAD_GROUP_KERNEL"); return e ? atoi(e) : 1; }();
-    if (!on || gemm_mode() != 0) return false;
+    if (!on) return false;                                   // (both GEMM modes: the group kernel exists for each)
     if (j.M <= 0 || j.N <= 0 || j.K < 4096 || (j.K & 7)) return false;
     if ((j.M & 3) || (j.N & 3) || !aligned16(j.A) || !aligned16(j.B) || !aligned16(j.C)) return false;
     if (j.K * j.M + 128 >= ((int64_t)1 << 30) || j.K * j.N + 128 >= ((int64_t)1 << 30)) return false;     // 32-bit operand offsets
@@ -810,7 +805,6 @@ int gemm_f32_wgrad_group(const WgradJob* jobs, int n, hipStream_t st) {
             if (int rc = gemm_f32_wgrad_group(jobs + i, n - i < GEMM_GROUP_MAX ? n - i : GEMM_GROUP_MAX, st)) return rc;
         return 0;
     }
-    constexpr int BK = 32;
     GemmGroup g{};
     ReduceGroup rg{};
     size_t floats = 0;
@@ -848,17 +842,8 @@ int gemm_f32_wgrad_group(const WgradJob* jobs, int n, hipStream_t st) {
         rblocks += main_blocks + asum_blocks;
     }
     for (int i = n; i <= GEMM_GROUP_MAX; ++i) { g.start[i] = blocks; rg.start[i] = rblocks; }
-    constexpr size_t lds = 2 * (Tile<BK, false>::SIZE + Tile<BK, false>::SIZE) * sizeof(float);
-    auto kern = gemm_f32_group_kernel<BK>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return hip_status(e, "hipFuncSetAttribute(gemm group)");
-        attr_set = true;
-    }
-    g_gemm_launches[0] += n;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(NT), lds, st, g);
-    NNHIP_LAUNCH_CHECK("gemm_f32_group_kernel");
+    g_gemm_launches[gemm_mode() == 1 ? 3 : 0] += n;
+    if (int rc = launch_group(g, blocks, st)) return rc;
     hipLaunchKernelGGL(splitk_reduce_group_kernel, dim3((unsigned)rblocks), dim3(256), 0, st, rg);
     NNHIP_LAUNCH_CHECK("splitk_reduce_group_kernel");
     return 0;

@@ -288,22 +288,15 @@ __device__ __forceinline__ void b3_step_fast(f32x16 (&acc)[2][2], StageRegs& fa,
 }
 
 // CS (outer-major A only): every thread also sums the A elements it stages (8 k of ONE row) -> asum[m] = sum_k A[m,k].
+// One block's work: logical block L of problem p (the XCD-aware grouped order of gemm.hip over L), batch index `by`.
 template <bool AKC, bool BKC, bool VEC, bool CS>
-__global__ __launch_bounds__(NT, 2) void gemm_bf3_kernel(const GemmParams p) {
+__device__ __forceinline__ void gemm_bf3_block(const GemmParams& p, const int L, const int by, unsigned char* __restrict__ smem_b) {
     static_assert(!CS || !AKC, "row sums of A are only implemented for an outer-major A");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, lh = lane >> 5;
 
-    // ---- block id -> (split, tile_m, tile_n): the XCD-aware grouped order of gemm.hip -------------------------------
-    const int nwg = gridDim.x;
-    int L;
-    {
-        const int b = blockIdx.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
-        L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-    }
     const int tiles = p.tiles_m * p.tiles_n;
     const int split = L / tiles;
     const int t = L - split * tiles;
@@ -318,7 +311,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf3_kernel(const GemmParams p) {
     const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
     const int64_t kbeg = (int64_t)split * p.k_per_split;
     const int64_t kend = min(p.K, kbeg + p.k_per_split);
-    const int bz1 = blockIdx.y / p.batch2, bz2 = blockIdx.y - bz1 * p.batch2;
+    const int bz1 = by / p.batch2, bz2 = by - bz1 * p.batch2;
     const float* __restrict__ A = p.A + (int64_t)bz1 * p.sA + (int64_t)bz2 * p.sA2;
     const float* __restrict__ B = p.B + (int64_t)bz1 * p.sB + (int64_t)bz2 * p.sB2;
     const int64_t c_off = (int64_t)bz1 * p.sC + (int64_t)bz2 * p.sC2;
@@ -477,6 +470,25 @@ __global__ __launch_bounds__(NT, 2) void gemm_bf3_kernel(const GemmParams p) {
 }
 
 template <bool AKC, bool BKC, bool VEC, bool CS>
+__global__ __launch_bounds__(NT, 2) void gemm_bf3_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    gemm_bf3_block<AKC, BKC, VEC, CS>(p, xcd_order((int)blockIdx.x, (int)gridDim.x), (int)blockIdx.y, smem_b);
+}
+
+// the grouped parameter-gradient launch of gemm.hip (gemm_f32_group_kernel) in the split-bf16 mode: same grid layout, same jobs
+__global__ __launch_bounds__(NT, 2) void gemm_bf3_group_kernel(const GemmGroup g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    const int b = (int)blockIdx.x;
+    const int L = g.by_job ? b : xcd_order(b, (int)gridDim.x);
+    int i = 0;
+#pragma unroll
+    for (int j = 1; j < GEMM_GROUP_MAX; ++j)
+        if (j < g.n && L >= g.start[j]) i = j;
+    const int local = L - g.start[i];
+    gemm_bf3_block<false, false, true, true>(g.p[i], g.by_job ? xcd_order(local, g.start[i + 1] - g.start[i]) : local, 0, smem_b);
+}
+
+template <bool AKC, bool BKC, bool VEC, bool CS>
 static int launch_bf3(const GemmParams& p, int64_t batch, hipStream_t st) {
     constexpr size_t lds = 2 * B3_STAGE;
     static_assert(lds >= 4 * 32 * 68 * sizeof(float), "the epilogue's per-wave transposition area must fit");
@@ -490,6 +502,19 @@ static int launch_bf3(const GemmParams& p, int64_t batch, hipStream_t st) {
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n * p.splitk), (unsigned)batch);
     hipLaunchKernelGGL(kern, grid, dim3(NT), lds, st, p);
     NNHIP_LAUNCH_CHECK("gemm_bf3_kernel");
+    return 0;
+}
+
+int gemm_bf3_group_launch(const GemmGroup& g, int blocks, hipStream_t st) {
+    constexpr size_t lds = 2 * B3_STAGE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf3_group_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return hip_status(e, "hipFuncSetAttribute(gemm_bf3 group)");
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_bf3_group_kernel, dim3((unsigned)blocks), dim3(NT), lds, st, g);
+    NNHIP_LAUNCH_CHECK("gemm_bf3_group_kernel");
     return 0;
 }
 

@@ -301,4 +301,21 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[2][2], const GemmPar
     }
 }
 
+// block id -> logical id: XCD-aware order.  Block b runs on XCD b % 8; each XCD gets a contiguous run of logical ids.  Bijective.
+__device__ __forceinline__ int xcd_order(int b, int nwg) {
+    const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+}
+
+
+// a group of independent parameter-gradient GEMMs launched as one grid (gemm.hip: gemm_f32_group_kernel, gemm_bf3.hip)
+constexpr int GEMM_GROUP_MAX = 8;
+struct GemmGroup {
+    GemmParams p[GEMM_GROUP_MAX];
+    int start[GEMM_GROUP_MAX + 1];
+    int n;
+    int by_job;      // 0: one XCD-aware order over the whole grid (an XCD works on one or two jobs);  1: jobs in DISPATCH order, the
+                     // XCD-aware order inside each (all of job 0's blocks are handed out before any of job 1's)
+};
+
 }  // namespace nnhip

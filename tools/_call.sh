@@ -1,2 +1,2 @@
-cd $GRAFT_REPO_ROOT
-timeout 600 python examples/conv_classifier.py --steps 40 2>&1 | tail -6
+cd /tmp; export TMPDIR=/tmp
+timeout 2400 python -m pytest $GRAFT_REPO_ROOT/tests -q -m gpu -x 2>&1 | tail -2
