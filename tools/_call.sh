@@ -1,2 +1,2 @@
-cd /tmp; export TMPDIR=/tmp
-timeout 2400 python -m pytest $GRAFT_REPO_ROOT/tests -q -m gpu -x 2>&1 | tail -2
+cd $GRAFT_REPO_ROOT
+timeout 900 python tools/soak_c1.py 60000 10000 2>&1 | tail -8
