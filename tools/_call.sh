@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python tools/soak_c1.py 60000 10000 2>&1 | tail -8
+S=$(date +%s); python bench.py > gpurun_out/default.json 2> gpurun_out/default.err; E=$(date +%s); echo "elapsed $((E-S)) s"; wc -l gpurun_out/default.json; python -c "
+import json; d=json.load(open('gpurun_out/default.json')); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d['cpu_baseline'])"
