@@ -222,60 +222,65 @@ __device__ __forceinline__ void sg_tile16_dz(const SmallMlpBwd& q, int bx, int b
 
 // Optimizer inside (ad.enabled): every gradient element is handed to Adam by the thread that produced it, its state fetched
 // before the GEMM.  W1 / b1 are read by nobody in this launch.  W2 / b2 are inputs of the dW1 blocks (dZ = dO W2): a dW2 block
-// applies its update only once EVERY block of the launch has checked in at the arrival counter -- a dW1 block checks in when its W2
-// slice has arrived, a dW2 block at once -- which normally happened long before the dW2 block's GEMM ends (it polls, it never
-// depends on a block dispatched after it doing anything but run).  The block that completes the counter also advances the
-// optimizer's device state: everyone has read it by then.  Counter = two levels (block b -> word 1 + b % 28, a word's last arrival
-// -> word 0: ~400 read-modify-writes of ONE address retire at ~25 M/s = 16 us); word 0 is cleared by the last dW2 block to pass.
-// (First version: dW2 / db2 published with agent-scope stores, the launch's last block applied their update -- store drain,
-// two dependent atomics and a reload on the kernel's tail: 11.4 us against 7 for the gradients alone.)
+// applies its update only once EVERY block of the launch has checked in -- a dW1 block when its W2 slice has arrived, a dW2 block
+// at once -- which it learns by polling (it only ever waits for blocks that wait for nobody).  A stepper block computes the next
+// step's bias corrections (two double pow) while everybody works and stores them once everybody has read the state.
+// The arrival board has NO read-modify-write whose result anyone waits for: block b adds 1 to word b % 28 of the launch's bank
+// (fire and forget), a poller loads the 28 words with one wave-load and compares each with the number of blocks that map to it.
+// Two banks alternate by a launch epoch (a device word, so graph replays advance it): the closer -- dW2 block 0, once it has
+// seen everybody -- clears the OTHER bank (last used by the previous launch, which is over) and advances the epoch; nothing is
+// ever reset under a poller's eyes.  In-kernel stamps of the first version (one returning atomic per block into 28 counters, their
+// last arrivals into one more; a "last poller clears" counter): a dW1 block spent 3.8 us between its W2 slice and its stores,
+// most of it the usher's atomic round trips in front of the block's next barrier; "everybody is here" became visible 3 us after
+// the last block was, and the stepper's returning atomic + clears added 1.4 us behind that: 9.8 us for 6.1 us of gradients.
+constexpr int SG_MLP_WAYS = 28, SG_MLP_BANK0 = 32, SG_MLP_BANK1 = 64;    // word offsets from ad.ticket (word 0 = the epoch)
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void gemm_small_mlp_bwd_kernel(const SmallMlpBwd q, const SmallMlpAdam ad) {
     __shared__ float red[NW][16 * 16];
     __shared__ float ared[NW][16];
     __shared__ float ash[5];
     __shared__ int flag;
-    // 1-D grid: the dW2 tiles first, then the dW1 tiles
+    // 1-D grid: the dW2 tiles first, then the dW1 tiles, then (device stepping) the stepper
     const int tx0 = (q.hid + 15) >> 4, ty0 = (q.out2 + 15) >> 4, tx1 = (q.in1 + 15) >> 4;
-    const int nb0 = tx0 * ty0, id = (int)blockIdx.x, tid = (int)threadIdx.x;
+    const int nb0 = tx0 * ty0, id = (int)blockIdx.x, tid = (int)threadIdx.x, lane = tid & 63;
     const bool first = id < nb0;
     const int bx = first ? id % tx0 : (id - nb0) % tx1, by = first ? id / tx0 : (id - nb0) / tx1;
     AdamHyper h = ad.h;                                    // (a local copy: modifying the by-value argument put it in scratch)
     const bool on = ad.enabled != 0;
-    const bool usher = tid == (NW - 1) * 64;               // lane 0 of the LAST wave: with 32 batch rows it has no k-group to wait for
     const bool stepper = on && ad.dev_state != nullptr;    // one extra block (the last) whose only job is the optimizer's step
-    const unsigned n = gridDim.x - (stepper ? 1u : 0u), ways = n < 28u ? n : 28u;
-    if (stepper && (unsigned)id == n) {
-        // The next step's bias corrections are two double-precision pow(): ~3 us on one lane.  Done by the block that completed
-        // the arrival counter they sat on that block's (and so the launch's) critical path: 12.1 us against 6.1 for the gradients
-        // alone.  Here they are computed while everybody else works and stored once everybody has read the state.
-        if (tid == 0) {
-#ifdef MLP_NO_POW
-            AdamDevNext nx; nx.next = reinterpret_cast<const int*>(ad.dev_state)[0] + 2; nx.bc1 = 0.5f; nx.bc2 = 0.5f;
-#else
-            const AdamDevNext nx = adam_dev_next(ad.dev_state, ad.b1, ad.b2);
-#endif
-            for (int spin = 0; spin < (1 << 22); ++spin) {
-                if (__hip_atomic_load(ad.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= ways) {
-                    adam_dev_commit(ad.dev_state, nx, ad.b1, ad.b2);
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(2);
+    const unsigned n = gridDim.x - (stepper ? 1u : 0u);    // blocks that check in
+    // the launch epoch: requested now by every thread that will need it (same address: one request per wave), used much later
+    // (only by the threads that will: every wave of 400 blocks asking for one address is a queue at one L2 channel)
+    unsigned epoch = 0;
+    const bool stepper_blk = stepper && (unsigned)id == n;
+    if (on && (tid == 0 || (stepper_blk && tid < 64) || (first && (tid >= (NW - 1) * 64 || (id == 0 && tid < 64)))))
+        epoch = __hip_atomic_load(ad.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    auto bank = [&](unsigned e) { return ad.ticket + ((e & 1u) ? SG_MLP_BANK1 : SG_MLP_BANK0); };
+    auto arrive = [&]() {                                  // one thread; nobody waits for the add
+        __hip_atomic_fetch_add(bank(epoch) + (unsigned)id % SG_MLP_WAYS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto everybody_here = [&]() -> bool {                  // a whole wave: lane w looks at word w
+        bool ok = true;
+        for (int spin = 0; spin < (1 << 20); ++spin) {
+            unsigned seen = 0, want = 0;
+            if (lane < SG_MLP_WAYS) {
+                seen = __hip_atomic_load(bank(epoch) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                want = n / SG_MLP_WAYS + ((unsigned)lane < n % SG_MLP_WAYS ? 1u : 0u);
             }
-            if (atomicAdd(ad.ticket + 30, 1u) == (unsigned)nb0) {           // counted with the dW2 blocks: the last to pass clears
-                __hip_atomic_store(ad.ticket + 30, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(ad.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+            ok = __ballot(seen < want) == 0ull;
+            if (ok) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        return ok;                                         // false: gave up (never seen): the caller leaves W2 / b2 alone
+    };
+    if (stepper_blk) {
+        if (tid < 64) {
+            AdamDevNext nx{};
+            if (tid == 0) nx = adam_dev_next(ad.dev_state, ad.b1, ad.b2);      // while everybody else works
+            if (everybody_here() && tid == 0) adam_dev_commit(ad.dev_state, nx, ad.b1, ad.b2);
         }
         return;
     }
-    auto arrive = [&]() {
-        const unsigned b = blockIdx.x, s1 = b % ways;
-        const unsigned n1 = n / ways + (s1 < n % ways ? 1u : 0u);
-        if (atomicAdd(ad.ticket + 1 + s1, 1u) != n1 - 1) return;
-        __hip_atomic_store(ad.ticket + 1 + s1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        atomicAdd(ad.ticket, 1u);
-    };
     AdamDevRaw raw;
     if (on) adam_dev_issue(raw, ad.dev_state, ad.grad_div);
     if (first) {                                           // dW2[out2, hid] = dO^T[out2, rows] H[rows, hid],  db2 = row sums of dO^T
@@ -293,36 +298,30 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_mlp_bwd_kernel(const Small
         float pw = ad.p[0][wi], mw = ad.m[0][wi], vw = ad.v[0][wi];
         float pb = ad.p[1][bi], mb = ad.m[1][bi], vb = ad.v[1][bi];
         adam_dev_resolve(h, raw, ad.dev_state, ad.b1, ad.b2, ad.grad_div, ash);
-        if (usher) arrive();                               // this block has read the optimizer's state (and reads no W2)
+        if (tid == 0) arrive();                            // this block has read the optimizer's state (and reads no W2)
         float g = 0.f, gb = 0.f;
         const SgCapturePost post{&g, &gb};
         sg_tile16<NW, false, false, false, 8, SgCapturePost>(p, bx, by, red, ared, nullptr, post);
-        if (usher) {                                       // everyone checked in?  (normally long ago)
-            int ok = 0;
-#ifdef MLP_NO_SPIN
-            ok = 1;
-#endif
-            for (int spin = 0; spin < (1 << 22) && !ok; ++spin) {
-                if (__hip_atomic_load(ad.ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= ways) { ok = 1; break; }
-                __builtin_amdgcn_s_sleep(2);
-            }
-            flag = ok;
+        if (tid >= (NW - 1) * 64) {                        // the last wave polls (normally everybody checked in long ago)
+            const bool ok = everybody_here();
+            if (lane == 0) flag = ok ? 1 : 0;
         }
         __syncthreads();
-        if (flag) {                                        // (a block that gave up waiting leaves W2 / b2 alone: never seen)
+        if (flag) {
             if (mine) { adam1(pw, g, mw, vw, h); ad.p[0][idx] = pw; ad.m[0][idx] = mw; ad.v[0][idx] = vw; }
             if (bmine) { adam1(pb, gb, mb, vb, h); ad.p[1][bi] = pb; ad.m[1][bi] = mb; ad.v[1][bi] = vb; }
-        }
-        if (usher && atomicAdd(ad.ticket + 30, 1u) == (unsigned)nb0 - 1 + (stepper ? 1u : 0u)) {   // the last poller to pass clears the counter
-            __hip_atomic_store(ad.ticket + 30, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(ad.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (id == 0 && tid < 64) {                     // the closer: the other bank for the next launch, then the epoch
+                if (lane < SG_MLP_WAYS) __hip_atomic_store(bank(epoch + 1u) + lane, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_store(ad.ticket, epoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     } else {
         __shared__ float dOs[SG_MLP_MAXROWS * 16], dZs[SG_MLP_MAXROWS * 17], w2s[256];
         float* const pmv[6] = {ad.p[2], ad.m[2], ad.v[2], ad.p[3], ad.m[3], ad.v[3]};
         sg_tile16_dz<NW>(q, bx, by, red, ared, dOs, dZs, w2s, pmv, on, h,
                          [&]() { if (on) adam_dev_resolve(h, raw, ad.dev_state, ad.b1, ad.b2, ad.grad_div, ash); },
-                         [&]() { if (on && usher) arrive(); });
+                         [&]() { if (on && tid == 0) arrive(); });
     }
 }
 
