@@ -92,11 +92,11 @@ struct SgCapturePost {
 // -- the optimizer state of the element a thread will produce, the W2 slice, dO, H, the X1 fragments -- is ISSUED before the first
 // wait (`after_issue()` runs there: the optimizer's device state is resolved behind the same round trip), `w2_read()` is called
 // once the block's W2 values have arrived (the arrival ticket of the optimizer-inside variant).
-template <int NW, class F1, class F2>
+template <int NW, int U, class F1, class F2>
 __device__ __forceinline__ void sg_tile16_dz(const SmallMlpBwd& q, int bx, int by, float (*red)[16 * 16], float (*ared)[16],
                                              float* __restrict__ dOs, float* __restrict__ dZs, float* __restrict__ w2s,
                                              float* const (&pmv)[6], bool adam_on, const AdamHyper& h, F1 after_issue, F2 w2_read) {
-    constexpr int U = 8, BS = NW * 64, PRE = 4;
+    constexpr int BS = NW * 64, PRE = 4;                    // U: k-groups in flight per wave (1 when every wave has at most one)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l16 = lane & 15, kq = lane >> 4;
     const int64_t m0 = (int64_t)by * 16, n0 = (int64_t)bx * 16;               // m = hidden unit, n = input feature, k = batch row
@@ -288,7 +288,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_mlp_bwd_kernel(const Small
         p.A = q.dO; p.lda = q.out2; p.B = q.H; p.ldb = q.hid; p.C = q.dW2; p.ldc = q.hid; p.asum = q.db2;
         p.M = q.out2; p.N = q.hid; p.K = q.rows; p.alpha = 1.f; p.beta = 1.f;
         if (!on) {
-            sg_tile16<NW, false, false, false, 8>(p, bx, by, red, ared);
+            if (((q.rows + 15) >> 4) <= NW) sg_tile16<NW, false, false, false, 1>(p, bx, by, red, ared);
+            else sg_tile16<NW, false, false, false, 8>(p, bx, by, red, ared);
             return;
         }
         const int64_t row = (int64_t)by * 16 + ((tid & 255) >> 4), col = (int64_t)bx * 16 + (tid & 15), idx = row * q.hid + col;
@@ -301,7 +302,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_mlp_bwd_kernel(const Small
         if (tid == 0) arrive();                            // this block has read the optimizer's state (and reads no W2)
         float g = 0.f, gb = 0.f;
         const SgCapturePost post{&g, &gb};
-        sg_tile16<NW, false, false, false, 8, SgCapturePost>(p, bx, by, red, ared, nullptr, post);
+        if (((q.rows + 15) >> 4) <= NW) sg_tile16<NW, false, false, false, 1, SgCapturePost>(p, bx, by, red, ared, nullptr, post);
+        else sg_tile16<NW, false, false, false, 8, SgCapturePost>(p, bx, by, red, ared, nullptr, post);
         if (tid >= (NW - 1) * 64) {                        // the last wave polls (normally everybody checked in long ago)
             const bool ok = everybody_here();
             if (lane == 0) flag = ok ? 1 : 0;
@@ -319,9 +321,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_mlp_bwd_kernel(const Small
     } else {
         __shared__ float dOs[SG_MLP_MAXROWS * 16], dZs[SG_MLP_MAXROWS * 17], w2s[256];
         float* const pmv[6] = {ad.p[2], ad.m[2], ad.v[2], ad.p[3], ad.m[3], ad.v[3]};
-        sg_tile16_dz<NW>(q, bx, by, red, ared, dOs, dZs, w2s, pmv, on, h,
-                         [&]() { if (on) adam_dev_resolve(h, raw, ad.dev_state, ad.b1, ad.b2, ad.grad_div, ash); },
-                         [&]() { if (on && tid == 0) arrive(); });
+        auto resolve = [&]() { if (on) adam_dev_resolve(h, raw, ad.dev_state, ad.b1, ad.b2, ad.grad_div, ash); };
+        auto checkin = [&]() { if (on && tid == 0) arrive(); };
+        // a short batch (rows <= 16 NW: the README MLP's 32 rows on 4 waves) leaves a wave at most ONE k-group: the 1-group body --
+        // the 8-group body multiplies the seven groups past the end as zeros, 28 dependent MFMAs (1.5 of the tile's 2.4 us)
+        if (((q.rows + 15) >> 4) <= NW) sg_tile16_dz<NW, 1>(q, bx, by, red, ared, dOs, dZs, w2s, pmv, on, h, resolve, checkin);
+        else sg_tile16_dz<NW, 8>(q, bx, by, red, ared, dOs, dZs, w2s, pmv, on, h, resolve, checkin);
     }
 }
 

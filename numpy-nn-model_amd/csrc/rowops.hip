@@ -1057,8 +1057,12 @@ __global__ __launch_bounds__(NW * 64) void linear_ce_small_kernel(const SmallGem
         const int64_t r = r0 + wave + (int64_t)j * NW;
         ypre[j] = load_label(a.labels, r < r1 ? r : r1 - 1, a.lbytes);
     }
+    // (at most one k-group per wave -- a 128-wide hidden layer on 8 waves: the 1-group variant of the tile.  The 8-group body
+    //  multiplies the seven groups past the end as zeros: 28 dependent MFMAs, ~0.4 us on the tail of the tile)
+    const bool one_group = ((p.K + 15) >> 4) <= NW;
     for (int bx = 0; (int64_t)bx * 16 < p.N; ++bx) {
-        sg_tile16<NW, true, true, VEC, 8>(p, bx, by, gred, ared, tile - r0 * 32);   // row r of C also lands at tile[(r - r0) * 32 + col]
+        if (one_group) sg_tile16<NW, true, true, VEC, 1>(p, bx, by, gred, ared, tile - r0 * 32);
+        else sg_tile16<NW, true, true, VEC, 8>(p, bx, by, gred, ared, tile - r0 * 32);   // row r of C also lands at tile[(r - r0) * 32 + col]
         __syncthreads();                                   // gred is reused by the next tile; after the last one: tile is complete
     }
     float scale, denom;
