@@ -138,8 +138,29 @@ __device__ __forceinline__ void tile_offsets(TileOffs<NV>& t, int64_t D, int tid
         t.o[p] = (unsigned)(idx / C4) * (unsigned)D + (unsigned)(idx % C4) * 4u;
     }
 }
+// One buffer descriptor over rows [0, nrows) of this (batch, head) slice, the tile's first row as the SCALAR offset, the thread's
+// (row-in-tile, column) offset computed once (TileOffs): a fetch is NV `buffer_load_dwordx4 v, v_off, s[rsrc], s_row0 offen` with no
+// vector instruction at all, and rows past the end read 0 through the descriptor's bounds check (finite data whose scores are
+// masked / whose probabilities are zero downstream) -- no clamping code, no zero default, no branch.  (Round 3: the per-tile fetch
+// was 14 % of a heavy forward block's life -- 64-bit address pairs and register defaults next to the other wave's fp32 MFMAs,
+// whose lanes the vector ALU shares.)  The host refuses slices beyond 4 GiB of byte offsets.
+typedef unsigned at_u32x4 __attribute__((ext_vector_type(4)));
 template <int DH, int NT, int NV>
 __device__ __forceinline__ void tile_fetch(TileRegsN<NV>& r, const TileOffs<NV>& t, const float* __restrict__ base, int64_t D, int row0,
+                                           int nrows, int tid) {
+    const unsigned bytes = nrows > 0 ? (unsigned)(((int64_t)(nrows - 1) * D + DH) * 4) : 0u;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
+    const unsigned soff = (unsigned)row0 * (unsigned)D * 4u;            // wave-uniform
+#pragma unroll
+    for (int p = 0; p < NV; ++p) {
+        const at_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, t.o[p] * 4u, soff, 0);
+        r.v[p].x = __uint_as_float(v.x); r.v[p].y = __uint_as_float(v.y); r.v[p].z = __uint_as_float(v.z); r.v[p].w = __uint_as_float(v.w);
+    }
+}
+// The pointer form (64-bit address per load, clamped rows): kept for the dK/dV kernel, which is out of scalar registers -- two more
+// descriptors there spill (36 B/lane).
+template <int DH, int NT, int NV>
+__device__ __forceinline__ void tile_fetch_ptr(TileRegsN<NV>& r, const TileOffs<NV>& t, const float* __restrict__ base, int64_t D, int row0,
                                            int nrows, int tid) {
     constexpr int C4 = DH / 4, ROWS = NV * 4 * NT / DH;
     const float* __restrict__ tb = base + (int64_t)row0 * D;          // wave-uniform
@@ -676,8 +697,8 @@ __global__ __launch_bounds__(64 * NW, DH <= 64 ? 2 : 1) void attn_bwd_dkdv_kerne
     };
     int qt = next_tile(0);
     if (qt < n_qt) {
-        tile_fetch<DH, NT>(qr, qoff, Qb, p.LQ, qt * QT, p.Tq, tid);
-        tile_fetch<DH, NT>(gr, goff, dOb, p.D, qt * QT, p.Tq, tid);
+        tile_fetch_ptr<DH, NT>(qr, qoff, Qb, p.LQ, qt * QT, p.Tq, tid);
+        tile_fetch_ptr<DH, NT>(gr, goff, dOb, p.D, qt * QT, p.Tq, tid);
         fetch_rows(qt * QT);
     }
     while (qt < n_qt) {
@@ -692,8 +713,8 @@ __global__ __launch_bounds__(64 * NW, DH <= 64 ? 2 : 1) void attn_bwd_dkdv_kerne
         __syncthreads();
         const int qn = next_tile(qt + 1);
         if (qn < n_qt) {
-            tile_fetch<DH, NT>(qr, qoff, Qb, p.LQ, qn * QT, p.Tq, tid);
-            tile_fetch<DH, NT>(gr, goff, dOb, p.D, qn * QT, p.Tq, tid);
+            tile_fetch_ptr<DH, NT>(qr, qoff, Qb, p.LQ, qn * QT, p.Tq, tid);
+            tile_fetch_ptr<DH, NT>(gr, goff, dOb, p.D, qn * QT, p.Tq, tid);
             fetch_rows(qn * QT);
         }
         // wave-uniform skip: this wave's 32 keys are above the diagonal for all queries of the tile (which all see a real key)
@@ -981,6 +1002,11 @@ static int attn_check(const char* fn, const void* Q, const void* K, const void* 
     NNHIP_CHECK_ARG(B >= 0 && H > 0 && Tq >= 0 && Tk >= 0, NNHIP_EINVAL, "%s: bad sizes", fn);
     NNHIP_CHECK_ARG(dh == 32 || dh == 64 || dh == 128, NNHIP_EINVAL, "%s: the fused kernels support head_dim 32, 64 and 128", fn);
     NNHIP_CHECK_ARG(Tq < (1 << 24) && Tk < (1 << 24) && B * H < (1 << 24), NNHIP_EINVAL, "%s: sizes too large", fn);
+    {   // a (batch, head) slice is addressed through one buffer descriptor with 32-bit byte offsets
+        const int64_t ld = ld_qkv > 0 ? ld_qkv : H * dh, tmax = Tq > Tk ? Tq : Tk;
+        NNHIP_CHECK_ARG(tmax * (ld > H * dh ? ld : H * dh) * 4 < ((int64_t)1 << 32), NNHIP_EINVAL,
+                        "%s: one sequence's rows span more than 4 GiB (T x row stride): split the sequence", fn);
+    }
     if (B == 0 || Tq == 0) return 0;
     NNHIP_CHECK_ARG(Q && K && V, NNHIP_EINVAL, "%s: null pointer", fn);
     NNHIP_CHECK_ARG(aligned16(Q) && aligned16(K) && aligned16(V), NNHIP_EALIGN, "%s: Q/K/V must be 16-byte aligned", fn);
