@@ -46,11 +46,20 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_pair_kernel(const SmallLin
     if (blockIdx.z == 0) {                                 // dX[rows, in] = dO[rows, out] W[out, in]   (+ addend, (.) act')
         p.B = q.W; p.C = q.dX; p.addend = q.addend; p.dact_arg = q.dact_arg; p.dact = q.dact; p.beta = q.beta;
         p.M = q.rows; p.K = q.out; p.a_kmajor = 1;
-        if ((int64_t)bx * 16 < p.N && (int64_t)by * 16 < p.M) sg_tile16<NW, true, false, VEC0, 8>(p, bx, by, red, ared);
+        // (k-groups in flight per wave sized to the problem: a body that fetches 8 multiplies the groups past the end as zeros)
+        if ((int64_t)bx * 16 < p.N && (int64_t)by * 16 < p.M) {
+            if (((p.K + 15) >> 4) <= NW) sg_tile16<NW, true, false, VEC0, 1>(p, bx, by, red, ared);
+            else sg_tile16<NW, true, false, VEC0, 8>(p, bx, by, red, ared);
+        }
     } else {                                               // dW[out, in] = dO^T[out, rows] X[rows, in],  db = row sums of dO^T
         p.B = q.X; p.C = q.dW; p.asum = q.db; p.beta = 1.f;
         p.M = q.out; p.K = q.rows;
-        if ((int64_t)bx * 16 < p.N && (int64_t)by * 16 < p.M) sg_tile16<NW, false, false, false, 8>(p, bx, by, red, ared);
+        if ((int64_t)bx * 16 < p.N && (int64_t)by * 16 < p.M) {
+            const int64_t g = (p.K + 15) >> 4;
+            if (g <= NW) sg_tile16<NW, false, false, false, 1>(p, bx, by, red, ared);
+            else if (g <= 2 * NW) sg_tile16<NW, false, false, false, 2>(p, bx, by, red, ared);
+            else sg_tile16<NW, false, false, false, 8>(p, bx, by, red, ared);
+        }
     }
 }
 
