@@ -69,7 +69,9 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const unsigned char* _
     // next launch starts with clean caches.  The bias corrections of this step were left in dev_state by the previous step's
     // last block; only the first step after SetStep, or a change of the betas, computes the two double-precision pow()s here.
     __shared__ float sh[5];
-    adam_dev_begin(h, dev_state, b1, b2, grad_div, sh);
+    AdamDevRaw raw;
+    adam_dev_issue(raw, dev_state, grad_div);              // thread 0's state loads leave now; the plan lookups below (a chain of
+                                                           // dependent scalar loads: block -> tensor -> pointers) run behind them
     float* const* P = reinterpret_cast<float* const*>(blob);
     const float* const* G = reinterpret_cast<const float* const*>(blob + sizeof(void*) * n);
     float* const* M = reinterpret_cast<float* const*>(blob + sizeof(void*) * 2 * n);
@@ -88,6 +90,7 @@ __global__ __launch_bounds__(256) void adamw_multi_kernel(const unsigned char* _
     // chunk offsets are multiples of 2048 elements, so 16-B alignment of the chunk == of the tensor
     const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) |
                        reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15u) == 0;
+    adam_dev_resolve(h, raw, dev_state, b1, b2, grad_div, sh);
     adam_span(p, g, m, v, cnt, threadIdx.x, 256, vec, h);
     adam_dev_finish(dev_state, nblk, b1, b2);
 }
