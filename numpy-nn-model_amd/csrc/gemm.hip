@@ -635,7 +635,11 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
     // >= 256: a lone block walks its k-tiles at ~2 us each (one 64-MFMA slab, nothing to hide the load latency behind),
     // so the MNIST-MLP's 32x784x128 forward took 57 us in ONE block; 9 blocks of 3 slabs + the reduce take ~12.
     const int64_t tiles = (int64_t)p.tiles_m * p.tiles_n * batch;
-    const bool few = tiles <= 16 && K >= 256;
+    // (few = up to 64 tiles: 48 lone blocks of a 430 x 512 -> 1536 projection -- the notebook's batch-4 GPT -- walk 16 k-tiles at
+    //  ~1.7 us each, 27 us for 0.7 GFLOP; split 8 ways + reduce they take ~12: that workload 242 -> 262 it/s.  16 / 48 / 64 / 96 / 128
+    //  swept: 242 / 254 / 262 / 263 / 262.)
+    static const int few_tiles = []() { const char* e = getenv("NNHIP_SPLITK_FEW"); return e ? atoi(e) : 64; }();   // dev knob
+    const bool few = tiles <= few_tiles && K >= 256;
     static const int tile_lim = []() { const char* e = getenv("NNHIP_SPLITK_TILES"); return e ? atoi(e) : 192; }();
     if (batch == 1 && tiles < tile_lim && (K >= 1024 || few)) {
         static const int slots = []() { const char* e = getenv("NNHIP_SPLITK_SLOTS"); return e ? atoi(e) : 512; }();   // dev knobs

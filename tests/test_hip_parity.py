@@ -197,7 +197,8 @@ def test_gemm_persistent_forward(hip, rows, inf, outf):
     got = host(o)
     assert_dot_close(got, X, W.T, plus=b)
     tiles_n = -(-outf // 128)
-    chunk = max(128, (400 // tiles_n) * 128)                   # <= 400 tiles per call: the classic kernel
+    chunk = max(128, (400 // tiles_n) * 128)
+    chunk = -(-(-(-rows // -(-rows // chunk))) // 128) * 128   # <= 400 tiles per call: the classic kernel; even chunks (a short last one would take split-K)
     o2 = torch.full((rows, outf), float("nan"), device="cuda")
     for r0 in range(0, rows, chunk):
         n = min(chunk, rows - r0)
@@ -232,6 +233,7 @@ def test_gemm_persistent_swish(hip, rows, inf, outf, beta, save):
         assert bool(torch.isnan(z).all())                      # nothing may be written without save_preactivation
     tiles_n = -(-outf // 128)
     chunk = max(128, (400 // tiles_n) * 128)
+    chunk = -(-(-(-rows // -(-rows // chunk))) // 128) * 128   # even chunks: a short last one (<= 64 tiles) would take split-K
     o2, z2 = torch.empty_like(o), torch.empty_like(z)
     for r0 in range(0, rows, chunk):
         n = min(chunk, rows - r0)
@@ -261,6 +263,7 @@ def test_gemm_persistent_input_grad(hip, rows, inf, outf, inplace):
     g, w, x = dev(dO), dev(W), dev(X)
     tiles_n = -(-inf // 128)
     chunk = max(128, (400 // tiles_n) * 128)
+    chunk = -(-(-(-rows // -(-rows // chunk))) // 128) * 128   # even chunks: a short last one (<= 64 tiles) would take split-K
     dx64 = dO.astype(np.float64) @ W.astype(np.float64)
     # plain dX
     dx = torch.full((rows, inf), float("nan"), device="cuda")
