@@ -1,6 +1,10 @@
 cd /tmp; export TMPDIR=/tmp
-timeout 2400 python -m pytest $GRAFT_REPO_ROOT/tests -q -m gpu -x -p no:cacheprovider 2>&1 | tail -1
-timeout 600 python -c "import sys; sys.path.insert(0,'$GRAFT_REPO_ROOT'); import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-cd $GRAFT_REPO_ROOT
-python bench.py --no-cpu-baseline > gpurun_out/head.json 2>gpurun_out/head.err; python -c "
-import json; d=json.load(open('gpurun_out/head.json')); print('headline', d['value'], d['ms_per_step'], d['roofline']['frac'])"
+for v in -1 0; do rm -rf /tmp/pc4
+NNHIP_ATTN_PAIR=$v timeout 600 rocprofv3 --kernel-trace --stats -f csv -d /tmp/pc4 -o c4 -- python $GRAFT_REPO_ROOT/bench.py --workload c4 --steps 8 --warmup 3 --no-cpu-baseline > /dev/null 2>&1
+python - <<PY
+import csv,glob
+f=glob.glob('/tmp/pc4/**/*kernel_stats.csv', recursive=True)[0]
+for r in csv.DictReader(open(f)):
+    if 'attn_fwd' in r['Name']: print('pair=$v', r['Name'][:50], r['Calls'], round(float(r['AverageNs'])/1e3,1), round(float(r['MinNs'])/1e3,1))
+PY
+done
