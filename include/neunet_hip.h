@@ -53,6 +53,13 @@ int nnhipWorkspaceLock(int locked);
  *                NNHIP_GEMM_MODE=1 in the environment.  Small problems (gemm_small) stay exact either way. */
 int nnhipSetGemmMode(int mode);
 int nnhipGetGemmMode(void);
+/* Lock-step mode of the exact-fp32 128x128-tile kernel for reductions of >= 2048 (off by default; also NNHIP_GEMM_LOCKSTEP=1):
+ * the two blocks resident on a CU hold each other to within a few k-tiles through issue priorities, so the tiles that share an
+ * operand panel in an XCD's L2 fetch it from the fabric once instead of twice (4096^3 forward: 808 -> 575 MB of L2->fabric
+ * reads, dW 655 -> 574; dX, already at 541, is left alone) at +2.7 % kernel time (dW +0.6 %).  Results are bit-identical either way (the arithmetic and its order do not change).  For
+ * deployments where the fabric is shared with collectives.  ABI 205 */
+int nnhipSetGemmLockstep(int enable);
+int nnhipGetGemmLockstep(void);
 /* Launches since the library was loaded, per GEMM kernel family: 0 = classic fp32 128x128 tiles (gemm_f32_kernel),
  * 1 = persistent fp32 (gemm_pst_kernel), 2 = small-problem kernel (gemm_small*), 3 = split-bf16 (gemm_bf3_kernel);
  * -1 for any other argument.  Host-side bookkeeping for tests that must know which kernel produced a result.  ABI 203 */

@@ -30,6 +30,8 @@
 
 namespace nnhip {
 
+__device__ int g_gemm_progress[8192];      // k-loop progress per (XCD, SE, SH, CU, wave slot parity): see gemm_f32_block
+
 
 // K loop.  One basic block per iteration; the issue order is pinned with sched_group_barrier so that the
 // 2*BK/8 global loads of tile t+1 ride in the shadow of the first MFMAs of tile t (one load per 64-cycle
@@ -294,7 +296,37 @@ __device__ __forceinline__ void gemm_f32_block(const GemmParams& p, const int L,
         __syncthreads();
         GP_STAMP(1);
         int cur = 0, kt = 0;
+        // Lock-step mode (nnhipSetGemmLockstep / NNHIP_GEMM_LOCKSTEP=1, off by default).  Left alone, the older of
+        // the two blocks of a CU wins the MFMA issue arbitration (its k-loop takes 0.80 M ticks, its mate's 1.15 M), so the 64 tiles
+        // resident on an XCD run as two cohorts of 32 that drift apart by more than the 16 k-tiles the 4 MiB L2 holds, and every
+        // operand panel the cohorts share is fetched from the fabric twice.  Here each wave publishes its k-tile on a board indexed
+        // by the physical CU and reads its mate's; a block that got LOCK_LEAD k-tiles ahead runs at the low issue priority until it
+        // is as far behind.  Fabric reads of a 4096^3 forward 808 -> 575 MB (dW 655 -> 574); the price is the stagger that hid one
+        // block's epilogue behind its mate's MFMAs: +2.7 % time (dW +0.6 %), which is why it is opt-in.
+        constexpr int LOCK_LEAD = 4;
+        const bool plock = p.lockstep && nfull >= 64 && AKC == BKC;     // (mixed layouts -- dX -- already sit at 541 MB: no gain there)
+        int *pmine = nullptr, *ptheirs = nullptr;
+        int pmate = 0, pstate = 1;
+        if (plock) {
+            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);   // HW_ID, XCC_ID
+            const unsigned cuslot = (xcc << 9) | (((hw >> 13) & 7) << 6) | (((hw >> 12) & 1) << 5) | (((hw >> 8) & 15) << 1);
+            pmine = g_gemm_progress + (cuslot | (hw & 1));                 // wave slot parity tells the two blocks of a CU apart
+            ptheirs = g_gemm_progress + (cuslot | ((hw & 1) ^ 1));
+        }
         for (; kt + 1 < nfull; kt += 2) {
+            if (plock) {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(pmate));      // the scalar load issued one pair ago (below)
+                const int d = kt - pmate;          // pmate: the mate's k-tile as of one pair ago
+                // bang-bang with hysteresis: a block that got LOCK_LEAD k-tiles ahead runs at the low priority until it is as far behind
+                // (2 = what the mate has done since the read: both see the same lag)
+                if (d >= 48 || d <= -48) { if (pstate != 1) { pstate = 1; __builtin_amdgcn_s_setprio(1); } }
+                else if (d > 2 + LOCK_LEAD) { if (pstate != 0) { pstate = 0; __builtin_amdgcn_s_setprio(0); } }
+                else if (d < 2 - LOCK_LEAD) { if (pstate != 3) { pstate = 3; __builtin_amdgcn_s_setprio(3); } }
+                __hip_atomic_store(pmine, kt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // scalar, past the scalar cache; consumed at the top of the next pair (a vector load here made the compiler wait for
+                // vmcnt(0) at once -- the operand prefetch with it: 0.94 -> 1.32 ms)
+                asm volatile("s_load_dword %0, %1, 0x0 glc" : "=&s"(pmate) : "s"(ptheirs));
+            }
             set_csf(kt + 1);
             gemm_k_step<BK, AKC, BKC, CS>(acc, ra2, rb2, ra, rb, cs, csf, smem, cur, rsa, rsb, ka_of(kt + 2), kb_of(kt + 2), offa, offb,
                                           tid, wm, wn, l31, lh);
@@ -308,6 +340,7 @@ __device__ __forceinline__ void gemm_f32_block(const GemmParams& p, const int L,
                                           tid, wm, wn, l31, lh);
             cur ^= 1;
         }
+        if (plock) __builtin_amdgcn_s_setprio(0);
         if (has_tail) {
             tail_mma<BK, AKC, BKC>(acc, smem, cur, (BK - rem) >> 3, wm, wn, l31, lh);
             __syncthreads();                                  // the epilogue re-uses the LDS block
@@ -339,9 +372,11 @@ __device__ __forceinline__ void gemm_f32_block(const GemmParams& p, const int L,
         __builtin_amdgcn_s_waitcnt(0);                        // ... and its stores acknowledged
         GP_STAMP(4);
         if (p.prof && lane == 0) {
-            long long* o = p.prof + ((int64_t)blockIdx.x * 4 + wave) * 10;
+            long long* o = p.prof + ((int64_t)blockIdx.x * 4 + wave) * 12;
             o[0] = ts_[0]; o[1] = ts_[1]; o[2] = ts_[2]; o[3] = ts_[3]; o[4] = ts_[4];
             for (int q_ = 0; q_ < 5; ++q_) o[5 + q_] = ets_[q_];
+            o[10] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID: wave/simd/pipe/cu/sh/se
+            o[11] = ((long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)(tm * 65536 + tn);   // XCC_ID, tile
         }
     }
 #endif
@@ -499,6 +534,7 @@ int gemm_bf3_group_launch(const GemmGroup& g, int blocks, hipStream_t st);
 static int gemm_f32_uneven_split(const float* A, const float* B, float* C, float* asum, int64_t M, int64_t N, int64_t K, int64_t lda,
                                  int64_t ldb, int64_t ldc, int64_t K1, hipStream_t st);
 static long long g_gemm_launches[4] = {0, 0, 0, 0};
+static int g_gemm_lockstep = []() { const char* e = getenv("NNHIP_GEMM_LOCKSTEP"); return e && atoi(e) == 1 ? 1 : 0; }();
 static int g_gemm_mode = -1;    // -1: not initialised (NNHIP_GEMM_MODE decides), 0: exact fp32 MFMA, 1: split-bf16
 static int gemm_mode() {
     if (g_gemm_mode < 0) {
@@ -622,6 +658,7 @@ int gemm_f32_ex(const float* A, const float* B, float* C, const float* bias, flo
     p.sA2 = sA2; p.sB2 = sB2; p.sC2 = sC2; p.batch2 = (int)batch2; p.alpha = alpha;
     p.tiles_m = (int)ceil_div(M, BM);
     p.tiles_n = (int)ceil_div(N, BN);
+    p.lockstep = g_gemm_lockstep;
     p.act = act; p.beta = beta;
     p.splitk = 1; p.k_per_split = ceil_div(K > 0 ? K : 1, BK) * BK; p.slab = nullptr;
     p.asum = asum; p.asum_slab = nullptr; p.addend = addend; p.dswish = dswish; p.dact = dact;
@@ -861,6 +898,12 @@ extern "C" int nnhipSetGemmMode(int mode) {
     return 0;
 }
 extern "C" int nnhipGetGemmMode(void) { return nnhip::gemm_mode(); }
+extern "C" int nnhipSetGemmLockstep(int enable) {
+    NNHIP_CHECK_ARG(enable == 0 || enable == 1, NNHIP_EINVAL, "nnhipSetGemmLockstep: 0 = off (default), 1 = the two blocks of a CU keep step");
+    nnhip::g_gemm_lockstep = enable;
+    return 0;
+}
+extern "C" int nnhipGetGemmLockstep(void) { return nnhip::g_gemm_lockstep; }
 extern "C" int64_t nnhipGemmLaunchCount(int family) {
     return family >= 0 && family < 4 ? (int64_t)nnhip::g_gemm_launches[family] : -1;
 }

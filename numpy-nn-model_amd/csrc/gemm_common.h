@@ -22,6 +22,7 @@ struct GemmParams {
     int batch2;
     float alpha;            // C = alpha * (A B) + bias
     int tiles_m, tiles_n, splitk;
+    int lockstep = 0;     // 1: the two blocks of a CU keep step through the k-loop (gemm.hip, lock-step mode)
 #ifdef GEMM_PROF
     long long* prof;      // developer instrumentation (tools/gemm_prof.py): per-block cycle stamps
 #endif

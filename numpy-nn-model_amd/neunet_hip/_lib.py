@@ -47,6 +47,8 @@ _SIGNATURES = {
     "nnhipCleanup": (ctypes.c_int, []),
     "nnhipSetGemmMode": (ctypes.c_int, [ctypes.c_int]),
     "nnhipGetGemmMode": (ctypes.c_int, []),
+    "nnhipSetGemmLockstep": (ctypes.c_int, [ctypes.c_int]),
+    "nnhipGetGemmLockstep": (ctypes.c_int, []),
     "nnhipGemmLaunchCount": (c_int64, [ctypes.c_int]),
     "nnhipWorkspaceReserve": (ctypes.c_int, [c_int64]),
     "nnhipWorkspaceLock": (ctypes.c_int, [ctypes.c_int]),
@@ -134,7 +136,7 @@ _SIGNATURES = {
     "nnhipScale": (ctypes.c_int, [P, c_float, c_int64, c_void_p]),
     "nnhipAdd": (ctypes.c_int, [P, P, P, c_int64, c_void_p]),
 }
-_NO_STATUS = {"nnhipVersion", "nnhipGetLastErrorString", "nnhipCreateFusedOptimizer", "nnhipGetGemmMode", "nnhipGemmLaunchCount",
+_NO_STATUS = {"nnhipVersion", "nnhipGetLastErrorString", "nnhipCreateFusedOptimizer", "nnhipGetGemmMode", "nnhipGetGemmLockstep", "nnhipGemmLaunchCount",
               "nnhipWeightGradPending"}
 
 _dll = None

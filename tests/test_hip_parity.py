@@ -690,6 +690,38 @@ def test_relu_backward_folded_into_next_linear(hip):
     assert_close_scaled(host(l2.weight.grad), 2 * dW2)
 
 
+# ------------------------------------------------------------------------------ lock-step GEMM mode (opt-in)
+@pytest.mark.parametrize("rows,inf,outf", [(2048, 4096, 2048), (1100, 2048, 515), (4096, 2304, 1024)])
+def test_gemm_lockstep_is_bit_identical(hip, rows, inf, outf):
+    """nnhipSetGemmLockstep(1) only changes WHEN the two blocks of a CU issue (s_setprio driven by a progress board), never what
+    they compute: Linear forward / dX / dW (+db) with reductions >= 2048 give the same bits as the default mode, twice over (the
+    board holds the previous launch's values when the next one starts)."""
+    from neunet_hip._lib import call_hip_function
+    from neunet_hip.nn.experimental import HIPLinear
+    rng = np.random.default_rng(rows + outf)
+    X = rng.standard_normal((rows, inf)).astype(np.float32)
+    dO = rng.standard_normal((rows, outf)).astype(np.float32)
+    np.random.seed(inf + outf)
+    layer = HIPLinear(inf, outf)
+    assert call_hip_function("nnhipGetGemmLockstep") == 0
+    got = []
+    try:
+        for mode in (0, 1, 1):
+            call_hip_function("nnhipSetGemmLockstep", mode)
+            layer.weight.grad = layer.bias.grad = None
+            x = T(hip, X)
+            out = layer(x)
+            o = host(out.data)
+            out.backward(dO)
+            got.append((o, host(x.grad), host(layer.weight.grad), host(layer.bias.grad)))
+    finally:
+        call_hip_function("nnhipSetGemmLockstep", 0)
+    for other in got[1:]:
+        for name, a, b in zip(("O", "dX", "dW", "db"), got[0], other):
+            assert np.array_equal(a, b), name
+    assert_close_scaled(got[0][0], X.astype(np.float64) @ host(layer.weight.data).astype(np.float64).T + host(layer.bias.data))
+
+
 # ------------------------------------------------------------------------------ split-bf16 GEMM mode (opt-in)
 @pytest.fixture
 def bf16x3(hip):

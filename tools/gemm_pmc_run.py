@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Workload for tools/gemm_pmc.sh: a few launches of one Linear forward GEMM (mode from argv[1], shape argv[2:5])."""
+"""Workload for tools/gemm_pmc.sh / gemm_fetch.sh: a few launches of one Linear GEMM (mode from argv[1], shape argv[2:5];
+GEMM_PMC_OP = fwd (default) | dx | dw)."""
 import os
 import sys
 
@@ -15,6 +16,14 @@ call("nnhipSetGemmMode", mode)
 st = _lib.get_current_stream_ptr()
 X, W = torch.randn(M, K, device="cuda"), torch.randn(N, K, device="cuda") / 64
 O = torch.empty(M, N, device="cuda")
+op = os.environ.get("GEMM_PMC_OP", "fwd")
+dO = torch.randn(M, N, device="cuda")
+dX, dW = torch.empty(M, K, device="cuda"), torch.empty(N, K, device="cuda")
 for _ in range(6):
-    call("nnhipLinearModuleForward", X, W, None, O, M, K, N, st)
+    if op == "fwd":
+        call("nnhipLinearModuleForward", X, W, None, O, M, K, N, st)
+    elif op == "dx":
+        call("nnhipLinearModuleBackward", X, W, dO, dX, None, None, M, K, N, st)
+    else:
+        call("nnhipLinearModuleBackward", X, W, dO, None, dW, None, M, K, N, st)
 torch.cuda.synchronize()

@@ -82,6 +82,17 @@ def main():
             report(f"linear db  {tag}", *bench(lambda: call("nnhipLinearModuleBackward", X, W, dO, None, None, db, M, K, N, st), args.iters), nbytes=4.0 * M * N)
             del X, W, O_, dO, dX, dW
 
+    if "gemmfwd" in only:         # forward only, the two big shapes (tile-order / priority experiments)
+        for (M, N, K) in [(4096, 4096, 4096), (8192, 4096, 4096), (16384, 2048, 512)]:
+            X, W, b, O_ = rnd(M, K), rnd(N, K) / 64, rnd(N), torch.empty(M, N, device=dev)
+            report(f"linear fwd {M}x{K}->{N}", *bench(lambda: call("nnhipLinearModuleForward", X, W, b, O_, M, K, N, st), args.iters), flops=2.0 * M * N * K)
+            if M * N * K >= 2 ** 36:
+                dO, dX, dW = rnd(M, N), torch.empty(M, K, device=dev), torch.empty(N, K, device=dev)
+                report(f"linear dX  {M}x{K}->{N}", *bench(lambda: call("nnhipLinearModuleBackward", X, W, dO, dX, None, None, M, K, N, st), args.iters), flops=2.0 * M * N * K)
+                report(f"linear dW  {M}x{K}->{N}", *bench(lambda: call("nnhipLinearModuleBackward", X, W, dO, None, dW, None, M, K, N, st), args.iters), flops=2.0 * M * N * K)
+                del dO, dX, dW
+            del X, W, O_
+
     if "dwsweep" in only:         # the parameter-gradient GEMMs of the C4 step (split-K candidates)
         for (M, N, K) in [(16384, 512, 512), (16384, 1536, 512), (16384, 2048, 512), (16384, 512, 2048), (16384, 15000, 512), (16384, 6144, 512)]:
             X, W, dO = rnd(M, K), rnd(N, K) / 64, rnd(M, N)
