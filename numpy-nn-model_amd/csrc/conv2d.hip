@@ -569,6 +569,169 @@ __global__ __launch_bounds__(256) void conv_direct_dgrad_kernel(const float* __r
         if (c < g.Cin) dX[((int64_t)b * g.Cin + c) * HW + p] = acc[c];
 }
 
+// ---- "quad" variants of the two direct kernels, 3x3 only, for grids that leave most SIMDs with less than one wave ------------
+// (C5's second conv layer: 256 x 14 x 14 = 50176 positions = 196 blocks on 256 CUs, each thread a serial chain of 144 loads and
+// 1152 FMAs).  Four adjacent lanes share one position and split the REDUCTION channels (lane s takes channels s, s + 4, ...):
+// four times the waves, a quarter of the chain each; the partial sums meet in two DPP quad-permute steps (x + swap1(x), then
+// + swap2: every lane of the quad ends with the same bits) and each lane stores a quarter of the position's outputs.
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    return v;
+}
+
+// forward: Wl[ci * CSTR + tap * CO + co]; CSTR = 9 CO (+ 8 for CO = 16: the four lanes of a quad read four different ci at once,
+// and a stride of 144 floats would put two of them on the same LDS banks)
+template <int CO>
+__global__ __launch_bounds__(256) void conv_direct_fwd_quad_kernel(const float* __restrict__ Wt, const float* __restrict__ X,
+                                                                   const float* __restrict__ bias, float* __restrict__ O,
+                                                                   const ConvGeom g) {
+    constexpr int CSTR = 9 * CO + (CO == 16 ? 8 : 0), CPL = CD_MAXC / 4;      // channels per lane
+    __shared__ __attribute__((aligned(16))) float Wl[CD_MAXC * CSTR];
+    const int K = g.Cin * 9;
+    stage_to_lds(Wl, Wt, g.Cin * CSTR, threadIdx.x, [&](int i) -> int64_t {
+        const int ci = i / CSTR, r = i - ci * CSTR, t = r / CO, co = r - t * CO;
+        return (t < 9 && co < g.Cout) ? (int64_t)co * K + ci * 9 + t : -1;
+    });
+    __syncthreads();
+    const int64_t HWo = (int64_t)g.Ho * g.Wo, N = (int64_t)g.B * HWo;
+    const int64_t n = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 2;
+    const int s = threadIdx.x & 3;
+    if (n >= N) return;                                   // whole quads leave together
+    const int b = (int)(n / HWo), p = (int)(n - (int64_t)b * HWo);
+    const int ho = p / g.Wo, wo = p - ho * g.Wo;
+    float acc[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+    const int HWi = g.H * g.W;
+    const __amdgpu_buffer_rsrc_t rx = cd_rsrc(X, (unsigned)((int64_t)g.B * g.Cin * HWi) * 4u);
+    unsigned vo[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int hi = ho * g.sh - g.pu + r * g.dh, wi = wo * g.sw - g.pl + q * g.dw;
+            vo[r * 3 + q] = (hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) ? (unsigned)(b * g.Cin * HWi + hi * g.W + wi) * 4u : CD_OOB;
+        }
+    float x[CPL][9];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        const int ci = 4 * j + s;
+        const bool live = ci < g.Cin;
+        const unsigned chan = (unsigned)(ci * HWi) * 4u;                          // per-lane channel: a vector offset here
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            x[j][t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, (live && vo[t] != CD_OOB) ? vo[t] + chan : CD_OOB, 0, 0));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        if (4 * j >= g.Cin) break;                          // uniform
+        const int ci = min(4 * j + s, g.Cin - 1);           // (a lane past Cin multiplies zeros by staged weights)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float4* w4 = reinterpret_cast<const float4*>(&Wl[ci * CSTR + t * CO]);
+#pragma unroll
+            for (int c4 = 0; c4 < CO / 4; ++c4) {
+                const float4 w = w4[c4];
+                acc[4 * c4] += x[j][t] * w.x; acc[4 * c4 + 1] += x[j][t] * w.y; acc[4 * c4 + 2] += x[j][t] * w.z; acc[4 * c4 + 3] += x[j][t] * w.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] = quad_sum(acc[c]);
+#pragma unroll
+    for (int c = 0; c < CO / 4; ++c) {                      // lane s stores outputs s CO/4 ... (selects: no dynamic register index)
+        float a0 = acc[c], a1 = acc[CO / 4 + c], a2 = acc[2 * (CO / 4) + c], a3 = acc[3 * (CO / 4) + c];
+        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));      // (or the selects become acc[f(s)]: a scratch array)
+        const float v = s == 0 ? a0 : s == 1 ? a1 : s == 2 ? a2 : a3;
+        const int co = s * (CO / 4) + c;
+        if (co < g.Cout) O[((int64_t)b * g.Cout + co) * HWo + p] = v + (bias ? bias[co] : 0.f);
+    }
+}
+
+// dgrad: Wl[(co * 9 + tap) * CI + ci] as in conv_direct_dgrad_kernel (CI <= 8: the quad's four co sit 9 CI floats apart, on
+// different banks); lane s takes output channels s, s + 4, ...
+template <int CI>
+__global__ __launch_bounds__(256) void conv_direct_dgrad_quad_kernel(const float* __restrict__ Wt, const float* __restrict__ dO,
+                                                                     float* __restrict__ dX, const ConvGeom g) {
+    constexpr int CPL = CD_MAXC / 4;
+    __shared__ __attribute__((aligned(16))) float Wl[CD_MAXC * 9 * CI];
+    stage_to_lds(Wl, Wt, g.Cout * 9 * CI, threadIdx.x, [&](int i) -> int64_t {
+        const int ci = i % CI, k = i / CI, co = k / 9, rs = k - co * 9;
+        return ci < g.Cin ? ((int64_t)co * g.Cin + ci) * 9 + rs : -1;
+    });
+    __syncthreads();
+    const int64_t HW = (int64_t)g.H * g.W, N = (int64_t)g.B * HW;
+    const int HWo = g.Ho * g.Wo;
+    const int64_t n = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 2;
+    const int s = threadIdx.x & 3;
+    if (n >= N) return;
+    const int b = (int)(n / HW), p = (int)(n - (int64_t)b * HW);
+    const int h = p / g.W, w = p - h * g.W;
+    float acc[CI];
+#pragma unroll
+    for (int c = 0; c < CI; ++c) acc[c] = 0.f;
+    const __amdgpu_buffer_rsrc_t rg = cd_rsrc(dO, (unsigned)((int64_t)g.B * g.Cout * HWo) * 4u);
+    int off[9];
+    if (g.sh == 1 && g.sw == 1) {                          // unit stride: no divisions (18 div + 18 mod per thread otherwise -- more
+#pragma unroll                                             // instructions than the FMAs)
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int th = h + g.pu - r * g.dh, tw = w + g.pl - q * g.dw;
+                off[r * 3 + q] = (th >= 0 && tw >= 0 && th < g.Ho && tw < g.Wo) ? th * g.Wo + tw : -1;
+            }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int th = h + g.pu - r * g.dh, tw = w + g.pl - q * g.dw;
+                const bool ok = th >= 0 && tw >= 0 && th % g.sh == 0 && tw % g.sw == 0 && th / g.sh < g.Ho && tw / g.sw < g.Wo;
+                off[r * 3 + q] = ok ? (th / g.sh) * g.Wo + tw / g.sw : -1;
+            }
+    }
+    unsigned vo[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) vo[t] = off[t] >= 0 ? (unsigned)(b * g.Cout * HWo + off[t]) * 4u : CD_OOB;
+    float v[CPL][9];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        const int co = 4 * j + s;
+        const bool live = co < g.Cout;
+        const unsigned chan = (unsigned)(co * HWo) * 4u;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+            v[j][t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, (live && vo[t] != CD_OOB) ? vo[t] + chan : CD_OOB, 0, 0));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        // (no early exit for Cout < 16: a channel past Cout multiplies zeros by staged weights)
+        const int co = min(4 * j + s, g.Cout - 1);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float4* w4 = reinterpret_cast<const float4*>(&Wl[(co * 9 + t) * CI]);
+#pragma unroll
+            for (int c4 = 0; c4 < CI / 4; ++c4) {
+                const float4 ww = w4[c4];
+                acc[4 * c4] += v[j][t] * ww.x; acc[4 * c4 + 1] += v[j][t] * ww.y; acc[4 * c4 + 2] += v[j][t] * ww.z; acc[4 * c4 + 3] += v[j][t] * ww.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CI; ++c) acc[c] = quad_sum(acc[c]);
+#pragma unroll
+    for (int c = 0; c < CI / 4; ++c) {
+        float a0 = acc[c], a1 = acc[CI / 4 + c], a2 = acc[2 * (CI / 4) + c], a3 = acc[3 * (CI / 4) + c];
+        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));      // (or the selects become acc[f(s)]: a scratch array)
+        const float o = s == 0 ? a0 : s == 1 ? a1 : s == 2 ? a2 : a3;
+        const int ci = s * (CI / 4) + c;
+        if (ci < g.Cin) dX[((int64_t)b * g.Cin + ci) * HW + p] = o;
+    }
+}
+
 // wgrad, 3x3 kernels, <= 16 channels: one block per image (grid-strided) with X[b] and dO[b] staged in LDS.  Thread <->
 // (input channel ci, pixel slice): it owns dW[0..CO)[ci][3x3] for its pixels -- CO*9 accumulators, the 9 taps of a pixel
 // loaded once and used for every co, dO[co][p] a broadcast read shared by the CIP threads of the slice.  The slices lie
@@ -781,6 +944,10 @@ static int launch_mfma_wgrad(const float* X, const float* dO, float* part, const
     return 0;
 }
 
+static bool conv_quad_on() {      // NNHIP_CONV_QUAD=0: the one-thread-per-position kernels everywhere (A/B switch)
+    static const bool on = []() { const char* e = getenv("NNHIP_CONV_QUAD"); return !e || atoi(e) != 0; }();
+    return on;
+}
 static bool conv_direct_ok(const ConvGeom& g) {
     static const bool off = []() { const char* e = getenv("NNHIP_CONV_DIRECT"); return e && atoi(e) == 0; }();
     // (both activation tensors are addressed with 32-bit byte offsets below CD_OOB)
@@ -821,6 +988,14 @@ extern "C" int nnhipConv2dForward(const float* X, const float* W, const float* b
     const int64_t N = (int64_t)g.B * g.Ho * g.Wo;
     if (conv_direct_ok(g)) {
         const dim3 dgrid((unsigned)ceil_div(N, 256));
+        // under two blocks per CU and a reduction worth splitting: four lanes per position (conv_direct_fwd_quad_kernel)
+        if (conv_quad_on() && g.kh == 3 && g.kw == 3 && N <= 512 * 256 && g.Cin >= 4 && g.Cout > 4) {
+            const dim3 qgrid((unsigned)ceil_div(4 * N, 256));
+            if (g.Cout <= 8) hipLaunchKernelGGL(conv_direct_fwd_quad_kernel<8>, qgrid, dim3(256), 0, (hipStream_t)s, W, X, bias, O, g);
+            else hipLaunchKernelGGL(conv_direct_fwd_quad_kernel<16>, qgrid, dim3(256), 0, (hipStream_t)s, W, X, bias, O, g);
+            NNHIP_LAUNCH_CHECK("conv_direct_fwd_quad_kernel");
+            return 0;
+        }
         if (g.Cout <= 4) hipLaunchKernelGGL(conv_direct_fwd_kernel<4>, dgrid, dim3(256), 0, (hipStream_t)s, W, X, bias, O, g);
         else if (g.Cout <= 8) hipLaunchKernelGGL(conv_direct_fwd_kernel<8>, dgrid, dim3(256), 0, (hipStream_t)s, W, X, bias, O, g);
         else hipLaunchKernelGGL(conv_direct_fwd_kernel<16>, dgrid, dim3(256), 0, (hipStream_t)s, W, X, bias, O, g);
@@ -840,6 +1015,13 @@ extern "C" int nnhipConv2dBackward(const float* X, const float* W, const float* 
     const bool direct = conv_direct_ok(g);
     if (dX && direct) {
         const dim3 dgrid((unsigned)ceil_div((int64_t)g.B * g.H * g.W, 256));
+        const int64_t Nd = (int64_t)g.B * g.H * g.W;
+        if (conv_quad_on() && g.kh == 3 && g.kw == 3 && Nd <= 512 * 256 && g.Cout >= 4 && g.Cin > 2 && g.Cin <= 8) {
+            const dim3 qgrid((unsigned)ceil_div(4 * Nd, 256));
+            if (g.Cin <= 4) hipLaunchKernelGGL(conv_direct_dgrad_quad_kernel<4>, qgrid, dim3(256), 0, st, W, dO, dX, g);
+            else hipLaunchKernelGGL(conv_direct_dgrad_quad_kernel<8>, qgrid, dim3(256), 0, st, W, dO, dX, g);
+            NNHIP_LAUNCH_CHECK("conv_direct_dgrad_quad_kernel");
+        } else
         if (g.Cin <= 4) hipLaunchKernelGGL(conv_direct_dgrad_kernel<4>, dgrid, dim3(256), 0, st, W, dO, dX, g);
         else if (g.Cin <= 8) hipLaunchKernelGGL(conv_direct_dgrad_kernel<8>, dgrid, dim3(256), 0, st, W, dO, dX, g);
         else hipLaunchKernelGGL(conv_direct_dgrad_kernel<16>, dgrid, dim3(256), 0, st, W, dO, dX, g);

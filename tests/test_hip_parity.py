@@ -1282,6 +1282,10 @@ def test_conv2d_golden(hip, golden, name):
     ((4, 7, 10, 15), 9, 3, (1, 1), (0, 2), (1, 1)),
     ((2, 16, 8, 8), 16, 3, (1, 1), (1, 1), (1, 1)),
     ((5, 2, 7, 5), 3, 3, (1, 2), (2, 2), (2, 1)),
+    # 3x3, few positions: the "quad" direct kernels (four lanes per position, reduction channels split, DPP sum) -- also layer 2 above
+    ((3, 5, 9, 11), 6, 3, (1, 1), (1, 1), (1, 1)),         # forward <8>, dgrad <8>, channel counts that are no multiple of four
+    ((2, 4, 6, 7), 16, 3, (2, 1), (0, 1), (1, 2)),         # forward <16> with one channel per lane, dgrad <4>, stride + dilation
+    ((1, 8, 3, 3), 13, 3, (1, 1), (2, 2), (1, 1)),         # nine positions: a block with a ragged last quad; padding wider than the image
 ])
 def test_conv2d_vs_oracle(hip, xshape, cout, ks, stride, pad, dil):
     from neunet_hip.nn.experimental import HIPConv2d
