@@ -445,6 +445,20 @@ int nnhipMaxPool2dLeakyForward(float* out, int32_t* argmax, const float* X, floa
                                nnhipStream_t stream);
 int nnhipMaxPool2dLeakyBackward(float* dX, const float* dY, const int32_t* argmax, const float* pooled, float alpha,
                                 const nnhipPool2dDesc* d, nnhipStream_t stream);
+/* Conv2d weight / bias gradient straight from the gradient of a MaxPool2d that consumed the conv's output, through an optional
+ * LeakyReLU (the backward of conv2d.py:16-115 composed with maxpool2d.py:11-82 and activations.py:72-84, restricted to dW, db):
+ *   dW, db of   P = MaxPool2d([LeakyReLU(] Conv2d(X) [; alpha)])   given dP, the pool's window-local arg-max and -- with the
+ *   activation -- the pooled output P (its sign is the activation's slope at the arg-max); pooled = NULL: no activation.
+ * For a conv whose INPUT needs no gradient and whose output nobody else reads (the conv classifier's first layer): the conv-output
+ * gradient [B,Cout,Ho,Wo] is never materialised and the pool's backward launch is not needed.  Pool windows must tile the conv
+ * output exactly (kernel == stride, no padding, no dilation, Ho % kh == Wo % kw == 0, kh*kw <= 16) and the conv must be in the
+ * small-channel 3x3 domain of the LDS-resident weight-gradient kernel: nnhipConv2dWeightGradPooledOk(conv, pool) = 1 says so
+ * (0 otherwise; the pool descriptor's B, C, H, W are the conv output's).  Same values as nnhipMaxPool2d[Leaky]Backward followed by
+ * nnhipConv2dBackward(dX = NULL).  ABI 206 */
+int nnhipConv2dWeightGradPooledOk(const nnhipConv2dDesc* conv, const nnhipPool2dDesc* pool);
+int nnhipConv2dWeightGradPooled(const float* X, const float* dP, const int32_t* argmax, const float* pooled, float alpha,
+                                float* dW, float* db, const nnhipConv2dDesc* conv, const nnhipPool2dDesc* pool,
+                                nnhipStream_t stream);
 /* BatchNorm2d (neunet/nn/layers/batchnorm2d.py:57-115, 11-54), X [B,C,HW].  training != 0: batch mean / biased
  * variance per channel, running = momentum*running + (1-momentum)*stat (the reference's convention; running_*
  * may be NULL); else the running statistics are used.  save_mean / save_inv [C] feed the backward.

@@ -840,10 +840,23 @@ static int launch_direct_wgrad(const float* X, const float* dO, float* part, con
 // per-block partials go to conv_wgrad_reduce_kernel as before.  The direct kernel this replaces (thread <-> (ci, pixel slice),
 // CO*9 accumulators per thread, a 3-stage shuffle tree over 160 values) spent its time in LDS latency and that tree: C5 conv2
 // 18.5 us, conv1 13.1.
+//
+// POOL: the conv's output went through [LeakyReLU ->] MaxPool2d with windows that tile it exactly, and NOTHING else reads its
+// gradient (the layer's input needs none: C5's first layer).  dO[b] is then never written to memory: the block builds it in LDS
+// from the pool's gradient, arg-max and (for the LeakyReLU factor) pooled output -- a quarter of the bytes, and the pool's
+// backward launch disappears (nnhipConv2dWeightGradPooled).
+struct PoolGrad {
+    const float* dP;          // [B, Cout, Hq, Wq] gradient of the pooled output
+    const int32_t* arg;       // [B, Cout, Hq, Wq] window-local arg-max (r * kw + s)
+    const float* P;           // pooled output of MaxPool(LeakyReLU(.)) or null (no activation in between)
+    float alpha;
+    int Hq, Wq, kh, kw;
+};
 typedef float cw_f32x4 __attribute__((ext_vector_type(4)));
-template <int NT>
+template <int NT, bool POOL>
 __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(const float* __restrict__ X, const float* __restrict__ dO,
-                                                              float* __restrict__ part, const ConvGeom g, int ncols) {
+                                                              float* __restrict__ part, const ConvGeom g, int ncols,
+                                                              const PoolGrad pg) {
     extern __shared__ __attribute__((aligned(16))) float wsm[];
     const int HW = g.H * g.W, HWo = g.Ho * g.Wo;
     const int Hp = (g.Ho - 1) * g.sh + 2 * g.dh + 1, Wp = (g.Wo - 1) * g.sw + 2 * g.dw + 1;   // padded extent the taps reach
@@ -881,11 +894,72 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(const float* __res
             return (h >= 0 && h < g.H && w >= 0 && w < g.W) ? (int64_t)c * HW + h * g.W + w : -1;
         });
         if (tid == 0) Xp[nXp] = 1.0f;
-        const float* gb = dO + (int64_t)b * g.Cout * HWo;
-        stage_to_lds(Gs, gb, g.Cout * Lg, tid, [&](int i) -> int64_t {
-            const int c = i / Lg, pz = i - c * Lg;
-            return pz < HWo ? (int64_t)c * HWo + pz : -1;
-        });
+        if constexpr (POOL) {
+            const int HWq = pg.Hq * pg.Wq, nq = g.Cout * HWq, tail = Lg - HWo;
+            const int64_t qb = (int64_t)b * nq;
+            for (int i = tid; i < g.Cout * tail; i += 256) Gs[(i / tail) * Lg + HWo + i % tail] = 0.f;      // the rows' padding
+            if (pg.kh == 2 && pg.kw == 2 && ((nXp | g.Wo) & 1) == 0) {
+                // 2x2 windows (the usual case): eight windows per thread in flight, index arithmetic through reciprocals (exact
+                // for the sizes that fit LDS, as below), the window's two rows as two 8-byte stores
+                constexpr int D2 = 8;
+                const float inv_hwq = 1.0f / (float)HWq, inv_wq = 1.0f / (float)pg.Wq;
+                for (int base = 0; base < nq; base += 256 * D2) {
+                    float gv[D2], pv[D2];
+                    int av[D2];
+#pragma unroll
+                    for (int j = 0; j < D2; ++j) {
+                        const int i = min(base + tid + 256 * j, nq - 1);
+                        gv[j] = pg.dP[qb + i];
+                        av[j] = pg.arg[qb + i];
+                        pv[j] = pg.P ? pg.P[qb + i] : 1.f;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < D2; ++j) {
+                        const int i = base + tid + 256 * j;
+                        if (i < nq) {
+                            const int c = (int)(((float)i + 0.5f) * inv_hwq), rem = i - c * HWq;
+                            const int hq = (int)(((float)rem + 0.5f) * inv_wq), wq = rem - hq * pg.Wq;
+                            const float gg = pv[j] <= 0.f ? gv[j] * pg.alpha : gv[j];
+                            float* cell = Gs + c * Lg + 2 * hq * g.Wo + 2 * wq;
+                            *reinterpret_cast<float2*>(cell) = make_float2(av[j] == 0 ? gg : 0.f, av[j] == 1 ? gg : 0.f);
+                            *reinterpret_cast<float2*>(cell + g.Wo) = make_float2(av[j] == 2 ? gg : 0.f, av[j] == 3 ? gg : 0.f);
+                        }
+                    }
+                }
+            } else {
+            constexpr int D = 4;                            // one thread per pool window: all its loads first, then kh x kw cells
+            for (int base = 0; base < nq; base += 256 * D) {
+                float gv[D], pv[D];
+                int av[D];
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    const int i = base + tid + 256 * j;
+                    const bool ok = i < nq;
+                    gv[j] = pg.dP[qb + (ok ? i : 0)];
+                    av[j] = pg.arg[qb + (ok ? i : 0)];
+                    pv[j] = pg.P ? pg.P[qb + (ok ? i : 0)] : 1.f;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    const int i = base + tid + 256 * j;
+                    if (i >= nq) break;
+                    const int c = i / HWq, rem = i - c * HWq, hq = rem / pg.Wq, wq = rem - hq * pg.Wq;
+                    const float gg = pv[j] <= 0.f ? gv[j] * pg.alpha : gv[j];        // LeakyReLU factor read off the pooled output
+                    float* cell = Gs + c * Lg + hq * pg.kh * g.Wo + wq * pg.kw;
+                    for (int r = 0; r < pg.kh; ++r)
+                        for (int q = 0; q < pg.kw; ++q) cell[r * g.Wo + q] = (av[j] == r * pg.kw + q) ? gg : 0.f;
+                }
+            }
+            }
+        } else {
+            const float* gb = dO + (int64_t)b * g.Cout * HWo;
+            stage_to_lds(Gs, gb, g.Cout * Lg, tid, [&](int i) -> int64_t {
+                const int c = i / Lg, pz = i - c * Lg;
+                return pz < HWo ? (int64_t)c * HWo + pz : -1;
+            });
+        }
         __syncthreads();
         // four steps per iteration, all their LDS reads issued before the first MFMA (one step at a time is address -> LDS
         // latency -> MFMA, 49 times over for a 28x28 image); a step past the last one multiplies a = 0
@@ -929,17 +1003,17 @@ __global__ __launch_bounds__(256) void conv_mfma_wgrad_kernel(const float* __res
     }
 }
 
-template <int NT>
+template <int NT, bool POOL = false>
 static int launch_mfma_wgrad(const float* X, const float* dO, float* part, const ConvGeom& g, int ncols, int blocks, size_t lds,
-                             hipStream_t st) {
-    auto kern = conv_mfma_wgrad_kernel<NT>;
+                             hipStream_t st, const PoolGrad pg = PoolGrad{}) {
+    auto kern = conv_mfma_wgrad_kernel<NT, POOL>;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         if (e != hipSuccess) return hip_status(e, "hipFuncSetAttribute(conv_mfma_wgrad_kernel)");
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, X, dO, part, g, ncols);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, X, dO, part, g, ncols, pg);
     NNHIP_LAUNCH_CHECK("conv_mfma_wgrad_kernel");
     return 0;
 }
@@ -1003,6 +1077,64 @@ extern "C" int nnhipConv2dForward(const float* X, const float* W, const float* b
         return 0;
     }
     return launch_conv_igemm<false>(W, X, bias, O, g, (hipStream_t)s);
+}
+
+// the LDS plan of conv_mfma_wgrad_kernel for geometry g: true iff that kernel can run it
+static bool mfma_wgrad_plan(const ConvGeom& g, int& ncols, int& nt, size_t& m_lds) {
+    static const bool mfma_on = []() { const char* e = getenv("NNHIP_CONV_WGRAD_MFMA"); return !e || atoi(e) != 0; }();
+    if (!mfma_on || !conv_direct_ok(g) || g.kh != 3 || g.kw != 3) return false;
+    ncols = g.Cin * 9 + 1;
+    nt = (ncols + 15) / 16;
+    const int Hp = (g.Ho - 1) * g.sh + 2 * g.dh + 1, Wp = (g.Wo - 1) * g.sw + 2 * g.dw + 1;
+    const int Lg = 4 * ((g.Ho * g.Wo + 3) / 4);
+    const int nt_inst = nt <= 3 ? nt : nt <= 5 ? 5 : 10;
+    m_lds = ((size_t)g.Cin * Hp * Wp + 4 + (size_t)g.Cout * Lg) * sizeof(float);
+    const size_t m_red = (size_t)4 * 16 * 16 * nt_inst * sizeof(float);
+    if (m_lds < m_red) m_lds = m_red;
+    return nt <= 10 && m_lds <= 60 * 1024;
+}
+static bool pooled_wgrad_ok(const ConvGeom& g, const nnhipPool2dDesc* pd) {
+    static const bool on = []() { const char* e = getenv("NNHIP_CONV_POOLED_WGRAD"); return !e || atoi(e) != 0; }();
+    int ncols, nt; size_t lds;
+    return on && pd && pd->kh == pd->sh && pd->kw == pd->sw && pd->pu + pd->pd + pd->pl + pd->pr == 0 && pd->dh <= 1 && pd->dw <= 1 &&
+           pd->kh >= 1 && pd->kw >= 1 && pd->kh * pd->kw <= 16 && pd->B == g.B && pd->C == g.Cout && pd->H == g.Ho && pd->W == g.Wo &&
+           g.Ho % pd->kh == 0 && g.Wo % pd->kw == 0 && mfma_wgrad_plan(g, ncols, nt, lds);
+}
+
+extern "C" int nnhipConv2dWeightGradPooledOk(const nnhipConv2dDesc* d, const nnhipPool2dDesc* pd) {
+    ConvGeom g;
+    if (!d || !pd || make_geom(d, g) || g.B == 0) return 0;
+    return pooled_wgrad_ok(g, pd) ? 1 : 0;
+}
+
+extern "C" int nnhipConv2dWeightGradPooled(const float* X, const float* dP, const int32_t* argmax, const float* pooled, float alpha,
+                                           float* dW, float* db, const nnhipConv2dDesc* d, const nnhipPool2dDesc* pd,
+                                           nnhipStream_t s) {
+    ConvGeom g;
+    if (int rc = make_geom(d, g)) return rc;
+    if (g.B == 0) return 0;
+    NNHIP_CHECK_ARG(X && dP && argmax && (dW || db), NNHIP_EINVAL, "nnhipConv2dWeightGradPooled: null pointer");
+    NNHIP_CHECK_ARG(pooled_wgrad_ok(g, pd), NNHIP_EINVAL,
+                    "nnhipConv2dWeightGradPooled: unsupported geometry (ask nnhipConv2dWeightGradPooledOk first)");
+    hipStream_t st = (hipStream_t)s;
+    int ncols, nt; size_t m_lds;
+    mfma_wgrad_plan(g, ncols, nt, m_lds);
+    const int Nw = g.Cin * 9, total = g.Cout * ncols, blocks = g.B < 512 ? g.B : 512;
+    float* part = static_cast<float*>(workspace((size_t)blocks * total * sizeof(float)));
+    NNHIP_CHECK_ARG(part != nullptr, NNHIP_ENOMEM, "nnhipConv2dWeightGradPooled: workspace allocation failed");
+    PoolGrad pg;
+    pg.dP = dP; pg.arg = argmax; pg.P = pooled; pg.alpha = alpha;
+    pg.Hq = g.Ho / (int)pd->kh; pg.Wq = g.Wo / (int)pd->kw; pg.kh = (int)pd->kh; pg.kw = (int)pd->kw;
+    int rc = nt <= 1 ? launch_mfma_wgrad<1, true>(X, nullptr, part, g, ncols, blocks, m_lds, st, pg)
+           : nt <= 2 ? launch_mfma_wgrad<2, true>(X, nullptr, part, g, ncols, blocks, m_lds, st, pg)
+           : nt <= 3 ? launch_mfma_wgrad<3, true>(X, nullptr, part, g, ncols, blocks, m_lds, st, pg)
+           : nt <= 5 ? launch_mfma_wgrad<5, true>(X, nullptr, part, g, ncols, blocks, m_lds, st, pg)
+                     : launch_mfma_wgrad<10, true>(X, nullptr, part, g, ncols, blocks, m_lds, st, pg);
+    if (rc) return rc;
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)ceil_div(total, 4)), dim3(256), 0, st, part, dW, db, blocks,
+                       g.Cout, Nw, ncols);
+    NNHIP_LAUNCH_CHECK("conv_wgrad_reduce_kernel");
+    return 0;
 }
 
 extern "C" int nnhipConv2dBackward(const float* X, const float* W, const float* dO, float* dX, float* dW,

@@ -124,11 +124,37 @@ class HIPSigmoid(Module):
 
 
 # ----------------------------------------------------------------------------------------------- MaxPool2d
+def _pooled_conv_wgrad(X, argmax, desc, pooled, alpha, grad) -> bool:
+    """X is the output of a Conv2d whose input needs no gradient and which nobody else consumes (the conv classifier's first
+    layer), and the pool's windows tile it exactly: dW, db come straight from the pool's gradient (nnhipConv2dWeightGradPooled) --
+    the conv-output gradient is never written, this pool's backward launch and the conv node's own backward are not needed."""
+    from .conv2d import _HIPConv2dTensor
+    if not _FUSE or not isinstance(X, _HIPConv2dTensor) or getattr(X, "_consumers", 0) != 1 or X.args is None or X.grad is not None:
+        return False
+    cx, weight, bias, cdesc = X.args
+    if cx.requires_grad or not (weight.requires_grad or (bias is not None and bias.requires_grad)):
+        return False
+    if not call_hip_function("nnhipConv2dWeightGradPooledOk", ctypes.byref(cdesc), ctypes.byref(desc)):
+        return False
+    from .linear import _finish_param, _grad_out
+    grad_W = _grad_out(weight, weight.data)
+    grad_b = _grad_out(bias, bias.data) if bias is not None else None
+    call_hip_function("nnhipConv2dWeightGradPooled", cx.data, contiguous(grad), argmax, pooled, float(alpha), grad_W, grad_b,
+                      ctypes.byref(cdesc), ctypes.byref(desc), get_current_stream_ptr())
+    _finish_param(weight, grad_W)
+    if bias is not None:
+        _finish_param(bias, grad_b)
+    X._bwd_done = True                      # the tape skips the conv node (autograd.py: backward)
+    return True
+
+
 class _HIPMaxPool2dTensor(Tensor):
     def __init__(self, data, args, op, device):
         super().__init__(data, args, op, device=device, _nocopy=True)
 
         def grad_fn(X: Tensor, argmax, desc, pooled, alpha, grad):
+            if _pooled_conv_wgrad(X, argmax, desc, pooled, alpha, grad):
+                return
             grad_X = X.xp.empty(tuple(X.shape), dtype=np.float32)
             if pooled is None:
                 call_hip_function("nnhipMaxPool2dBackward", grad_X, contiguous(grad), argmax, ctypes.byref(desc),

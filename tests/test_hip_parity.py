@@ -2535,6 +2535,62 @@ def test_maxpool_dilated_golden(hip, golden):
         nn.MaxPool2d(2, 2, 0, 0)
 
 
+@pytest.mark.parametrize("xshape,cout,pool,leaky", [((16, 1, 28, 28), 8, (2, 2), True),      # C5 layer 1 (one column tile)
+                                                    ((5, 3, 12, 18), 16, (2, 3), True),       # 28 columns, non-square windows
+                                                    ((4, 7, 8, 8), 9, (2, 2), False),         # no activation in between, 64 columns
+                                                    ((3, 2, 6, 6), 4, (3, 3), True),
+                                                    ((2, 4, 5, 7), 6, (1, 1), True)])         # 1x1 "pool": every cell routed
+def test_conv_pooled_weight_grad(hip, xshape, cout, pool, leaky):
+    """Conv2d -> [LeakyReLU ->] MaxPool2d with a conv input that needs no gradient: the pool's backward hands dW, db to the conv
+    straight from its own gradient (nnhipConv2dWeightGradPooled; the conv-output gradient is never written, the conv node's
+    backward is skipped).  Bit-identical to the unfused chain (the same values meet the same MFMAs in the same order), equal to
+    the oracle chain within the conv tolerance; with an input that DOES need a gradient the fused path must not run."""
+    import neunet_hip
+    import neunet_hip.nn as nn
+    from neunet_hip.nn.experimental import HIPConv2d, vision
+    rng = np.random.default_rng(sum(xshape) + cout)
+    X = rng.uniform(-1, 1, xshape).astype(np.float32)
+    conv = HIPConv2d(xshape[1], cout, 3, (1, 1), (1, 1))
+    conv.bias.data.copy_(dev(rng.uniform(-0.3, 0.3, cout).astype(np.float32)))
+    act, mp = nn.LeakyReLU(0.01), nn.MaxPool2d(pool, pool)
+    Hq, Wq = xshape[2] // pool[0], xshape[3] // pool[1]
+    dY = rng.standard_normal((xshape[0], cout, Hq, Wq)).astype(np.float32)
+    res = {}
+    for fused in (True, False):
+        old, vision._FUSE = vision._FUSE, fused
+        try:
+            conv.weight.grad = conv.bias.grad = None
+            x = neunet_hip.Tensor(X, device="cuda", requires_grad=False)
+            c = conv(x)
+            y = mp(act(c) if leaky else c)
+            y.backward(dY)
+            res[fused] = (host(conv.weight.grad), host(conv.bias.grad), host(y.data))
+            assert (c.grad is None) == fused                  # fused: the conv-output gradient was never materialised
+        finally:
+            vision._FUSE = old
+    for a, b in zip(res[True], res[False]):
+        np.testing.assert_array_equal(a, b)
+    W, b = host(conv.weight.data), host(conv.bias.data)
+    Oc = O.conv2d_forward(X, W, b, (1, 1), (1, 1), (1, 1))
+    A = O.leaky_relu_forward(Oc, 0.01) if leaky else Oc
+    Yr, arg = O.maxpool2d_forward(A, pool, pool)
+    np.testing.assert_allclose(res[True][2], Yr, **TOL)
+    dA = O.maxpool2d_backward(A.shape, arg, dY, pool, pool)
+    dOc = O.leaky_relu_backward(A, dA, 0.01) if leaky else dA
+    _, dW, db = O.conv2d_backward(X, W, True, dOc, (1, 1), (1, 1), (1, 1))
+    assert_close_scaled(res[True][0], dW)
+    assert_close_scaled(res[True][1], db)
+    # an input that needs its gradient: the ordinary path (the conv node runs its own backward)
+    conv.weight.grad = conv.bias.grad = None
+    x = T(hip, X)
+    c = conv(x)
+    (mp(act(c) if leaky else c)).backward(dY)
+    assert c.grad is not None
+    np.testing.assert_array_equal(host(conv.weight.grad), res[True][0])
+    dX, _, _ = O.conv2d_backward(X, W, True, dOc, (1, 1), (1, 1), (1, 1))
+    np.testing.assert_allclose(host(x.grad), dX, **TOL)
+
+
 @pytest.mark.parametrize("ks,st,pad,shape", [(2, 2, 0, (3, 4, 12, 12)), (3, 2, 1, (2, 3, 11, 9)), (2, 1, 0, (2, 2, 7, 7)),
                                               (2, 2, 0, (256, 8, 28, 28))])
 def test_leaky_relu_maxpool_fusion(hip, ks, st, pad, shape):
