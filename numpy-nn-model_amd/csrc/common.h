@@ -36,6 +36,13 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // Grow-only per-process device workspace (split-K slabs, column-sum partials).  Freed by
 // nnhipCleanup().  Growing it synchronises the device (hipFree) -- it happens at most a few times.
 void* workspace(size_t bytes);
+bool workspace_locked();               // nnhipWorkspaceLock(1): a captured hipGraph holds library-owned addresses -- nothing may move
+// Deferred parameter gradients (nnhipWeightGradDefer, linear.hip): on while Tensor.backward() walks the tape.  conv2d.hip queues the
+// REDUCE of a small-channel conv's per-image partial weight gradients behind it (the partials sit in an arena of their own, not
+// in the shared workspace) and launches the queued reduces as one grid at the flush.
+bool wgrad_defer_on();
+int conv_reduce_flush(void* stream);
+void conv_reduce_cleanup();            // frees the partials arena (nnhipCleanup)
 // one deferred parameter-gradient GEMM (gemm.hip: gemm_f32_wgrad_group): C[M,N] = A^T B with A [K, M] and B [K, N] dense
 struct WgradJob {
     const float* A; const float* B; float* C; float* asum;

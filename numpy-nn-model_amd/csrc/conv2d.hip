@@ -18,6 +18,8 @@
 // just keeps the FMA work off the VALU while the waves gather.
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "common.h"
 
 namespace nnhip {
@@ -354,6 +356,125 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __r
             db[m] = s;
         }
     }
+}
+
+// ---- the reduces of several layers as one launch (deferred parameter gradients, common.h) ----------------------------------
+// During Tensor.backward() the per-image partials of a small-channel conv go to an arena of their own and the reduce is queued;
+// the queue is launched as ONE grid when it is full, at nnhipWeightGradFlush (before anybody reads a gradient) or when deferral
+// ends.  C5: the two conv layers' reduces, 2 x 4.8 us, become one launch.  Same arithmetic, same order per output.
+constexpr int CRQ_MAX = 4;
+struct ConvReduceJob { const float* part; float* dW; float* db; int chunks, Cout, Nw, ncols; };
+struct ConvReduceGroup { ConvReduceJob j[CRQ_MAX]; int start[CRQ_MAX + 1]; };
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_group_kernel(const ConvReduceGroup grp) {
+    int k = 0;
+#pragma unroll
+    for (int i = 1; i < CRQ_MAX; ++i) k += (int)blockIdx.x >= grp.start[i] ? 1 : 0;
+    const float* __restrict__ part = k == 0 ? grp.j[0].part : k == 1 ? grp.j[1].part : k == 2 ? grp.j[2].part : grp.j[3].part;
+    float* __restrict__ dW = k == 0 ? grp.j[0].dW : k == 1 ? grp.j[1].dW : k == 2 ? grp.j[2].dW : grp.j[3].dW;
+    float* __restrict__ db = k == 0 ? grp.j[0].db : k == 1 ? grp.j[1].db : k == 2 ? grp.j[2].db : grp.j[3].db;
+    const int chunks = k == 0 ? grp.j[0].chunks : k == 1 ? grp.j[1].chunks : k == 2 ? grp.j[2].chunks : grp.j[3].chunks;
+    const int Cout = k == 0 ? grp.j[0].Cout : k == 1 ? grp.j[1].Cout : k == 2 ? grp.j[2].Cout : grp.j[3].Cout;
+    const int Nw = k == 0 ? grp.j[0].Nw : k == 1 ? grp.j[1].Nw : k == 2 ? grp.j[2].Nw : grp.j[3].Nw;
+    const int ncols = k == 0 ? grp.j[0].ncols : k == 1 ? grp.j[1].ncols : k == 2 ? grp.j[2].ncols : grp.j[3].ncols;
+    const int first = k == 0 ? 0 : k == 1 ? grp.start[1] : k == 2 ? grp.start[2] : grp.start[3];
+    const int idx = ((int)blockIdx.x - first) * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int total = Cout * ncols;
+    if (idx >= total) return;
+    const int m = idx / ncols, n = idx - m * ncols;
+    float s = 0.f;
+    for (int c = lane; c < chunks; c += 64) s += part[(int64_t)c * total + idx];
+    s = wave_sum(s);
+    if (lane == 0) {
+        if (n < Nw) {
+            if (dW) dW[(int64_t)m * Nw + n] = s;
+        } else if (db) {
+            db[m] = s;
+        }
+    }
+}
+
+static std::mutex g_crq_mu;
+static ConvReduceJob g_crq[CRQ_MAX];
+static int g_crq_n = 0;
+static hipStream_t g_crq_st = nullptr;
+static float* g_crq_arena = nullptr;
+static size_t g_crq_cap = 0, g_crq_used = 0;              // floats
+
+static int crq_flush_locked(hipStream_t st) {
+    if (g_crq_n == 0) return 0;
+    ConvReduceGroup grp;
+    int blocks = 0;
+    for (int i = 0; i < CRQ_MAX; ++i) {
+        grp.start[i] = blocks;
+        if (i < g_crq_n) { grp.j[i] = g_crq[i]; blocks += (int)ceil_div((int64_t)g_crq[i].Cout * g_crq[i].ncols, 4); }
+        else grp.j[i] = g_crq[0];
+    }
+    grp.start[CRQ_MAX] = blocks;
+    for (int i = g_crq_n; i < CRQ_MAX; ++i) grp.start[i] = blocks;      // no block maps to an unused slot
+    const int n = g_crq_n;
+    g_crq_n = 0;
+    g_crq_used = 0;
+    if (n == 1)
+        hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, grp.j[0].part, grp.j[0].dW, grp.j[0].db,
+                           grp.j[0].chunks, grp.j[0].Cout, grp.j[0].Nw, grp.j[0].ncols);
+    else
+        hipLaunchKernelGGL(conv_wgrad_reduce_group_kernel, dim3((unsigned)blocks), dim3(256), 0, st, grp);
+    NNHIP_LAUNCH_CHECK("conv_wgrad_reduce_group_kernel");
+    return 0;
+}
+int conv_reduce_flush(void* stream) {
+    std::lock_guard<std::mutex> lk(g_crq_mu);
+    return crq_flush_locked(g_crq_n ? g_crq_st : (hipStream_t)stream);
+}
+void conv_reduce_cleanup() {
+    std::lock_guard<std::mutex> lk(g_crq_mu);
+    g_crq_n = 0;
+    g_crq_used = g_crq_cap = 0;
+    if (g_crq_arena) (void)hipFree(g_crq_arena);
+    g_crq_arena = nullptr;
+}
+// Where a weight-gradient kernel writes its `floats` partials: the arena when its reduce can wait for the flush (*deferred),
+// else the shared workspace (reduce launched at once).  nullptr: out of memory.
+static float* conv_partials(size_t floats, hipStream_t st, bool* deferred, int* rc) {
+    static const bool on = []() { const char* e = getenv("NNHIP_CONV_DEFER_REDUCE"); return !e || atoi(e) != 0; }();
+    *deferred = false;
+    *rc = 0;
+    if (on && wgrad_defer_on()) {
+        std::lock_guard<std::mutex> lk(g_crq_mu);
+        if (g_crq_n && (g_crq_st != st || g_crq_n == CRQ_MAX || g_crq_used + floats > g_crq_cap)) *rc = crq_flush_locked(g_crq_st);
+        if (floats > g_crq_cap && !workspace_locked()) {      // grow (nothing is queued here); never while a captured graph holds the address
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            (void)hipStreamIsCapturing(st, &cs);
+            if (cs == hipStreamCaptureStatusNone) {
+                if (g_crq_arena) (void)hipFree(g_crq_arena);  // (synchronises: earlier reduces are done with it)
+                g_crq_arena = nullptr;
+                g_crq_cap = 0;
+                const size_t want = floats + (floats >> 1);
+                if (hipMalloc(&g_crq_arena, want * sizeof(float)) == hipSuccess) g_crq_cap = want;
+                else g_crq_arena = nullptr;
+            }
+        }
+        if (floats <= g_crq_cap - g_crq_used) {
+            float* p = g_crq_arena + g_crq_used;
+            g_crq_used += (floats + 63) & ~(size_t)63;
+            g_crq_st = st;
+            *deferred = true;
+            return p;
+        }
+    }
+    return static_cast<float*>(workspace(floats * sizeof(float)));
+}
+static int conv_reduce(const float* part, float* dW, float* db, int chunks, int Cout, int Nw, int ncols, hipStream_t st, bool deferred) {
+    if (deferred) {
+        std::lock_guard<std::mutex> lk(g_crq_mu);
+        g_crq[g_crq_n++] = ConvReduceJob{part, dW, db, chunks, Cout, Nw, ncols};
+        return 0;
+    }
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)ceil_div((int64_t)Cout * ncols, 4)), dim3(256), 0, st, part, dW, db, chunks,
+                       Cout, Nw, ncols);
+    NNHIP_LAUNCH_CHECK("conv_wgrad_reduce_kernel");
+    return 0;
 }
 
 // =================================================================================================
@@ -1120,7 +1241,10 @@ extern "C" int nnhipConv2dWeightGradPooled(const float* X, const float* dP, cons
     int ncols, nt; size_t m_lds;
     mfma_wgrad_plan(g, ncols, nt, m_lds);
     const int Nw = g.Cin * 9, total = g.Cout * ncols, blocks = g.B < 512 ? g.B : 512;
-    float* part = static_cast<float*>(workspace((size_t)blocks * total * sizeof(float)));
+    bool deferred;
+    int frc;
+    float* part = conv_partials((size_t)blocks * total, st, &deferred, &frc);
+    if (frc) return frc;
     NNHIP_CHECK_ARG(part != nullptr, NNHIP_ENOMEM, "nnhipConv2dWeightGradPooled: workspace allocation failed");
     PoolGrad pg;
     pg.dP = dP; pg.arg = argmax; pg.P = pooled; pg.alpha = alpha;
@@ -1131,10 +1255,7 @@ extern "C" int nnhipConv2dWeightGradPooled(const float* X, const float* dP, cons
            : nt <= 5 ? launch_mfma_wgrad<5, true>(X, nullptr, part, g, ncols, blocks, m_lds, st, pg)
                      : launch_mfma_wgrad<10, true>(X, nullptr, part, g, ncols, blocks, m_lds, st, pg);
     if (rc) return rc;
-    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)ceil_div(total, 4)), dim3(256), 0, st, part, dW, db, blocks,
-                       g.Cout, Nw, ncols);
-    NNHIP_LAUNCH_CHECK("conv_wgrad_reduce_kernel");
-    return 0;
+    return conv_reduce(part, dW, db, blocks, g.Cout, Nw, ncols, st, deferred);
 }
 
 extern "C" int nnhipConv2dBackward(const float* X, const float* W, const float* dO, float* dX, float* dW,
@@ -1165,7 +1286,10 @@ extern "C" int nnhipConv2dBackward(const float* X, const float* W, const float* 
     if ((dW || db) && direct && g.kh == 3 && g.kw == 3 && wg_lds <= 60 * 1024) {
         const int Nw = g.Cin * 9, ncols = Nw + 1, total = g.Cout * ncols;
         const int blocks = g.B < 512 ? g.B : 512;
-        float* part = static_cast<float*>(workspace((size_t)blocks * total * sizeof(float)));
+        bool deferred;
+        int frc;
+        float* part = conv_partials((size_t)blocks * total, st, &deferred, &frc);     // arena (reduce queued) or shared workspace
+        if (frc) return frc;
         NNHIP_CHECK_ARG(part != nullptr, NNHIP_ENOMEM, "nnhipConv2dBackward: workspace allocation failed");
         // the 16x16x4-MFMA kernel when its padded image + zero-padded dO fit LDS (NNHIP_CONV_WGRAD_MFMA=0: the direct kernel)
         static const bool mfma_on = []() { const char* e = getenv("NNHIP_CONV_WGRAD_MFMA"); return !e || atoi(e) != 0; }();
@@ -1183,10 +1307,7 @@ extern "C" int nnhipConv2dBackward(const float* X, const float* W, const float* 
                : nt <= 5 ? launch_mfma_wgrad<5>(X, dO, part, g, ncols, blocks, m_lds, st)
                          : launch_mfma_wgrad<10>(X, dO, part, g, ncols, blocks, m_lds, st);
             if (rc) return rc;
-            hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)ceil_div(total, 4)), dim3(256), 0, st, part, dW, db, blocks,
-                               g.Cout, Nw, ncols);
-            NNHIP_LAUNCH_CHECK("conv_wgrad_reduce_kernel");
-            return 0;
+            return conv_reduce(part, dW, db, blocks, g.Cout, Nw, ncols, st, deferred);
         }
         const int cip = g.Cin <= 1 ? 1 : g.Cin <= 2 ? 2 : g.Cin <= 4 ? 4 : g.Cin <= 8 ? 8 : 16;
         const size_t red = (size_t)4 * (g.Cout <= 8 ? 8 : 16) * (cip * 9 + 1) * sizeof(float);
@@ -1200,9 +1321,7 @@ extern "C" int nnhipConv2dBackward(const float* X, const float* W, const float* 
         rc = g.Cout <= 8 ? NNHIP_WG(8) : NNHIP_WG(16);
 #undef NNHIP_WG
         if (rc) return rc;
-        hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)ceil_div(total, 4)), dim3(256), 0, st, part, dW, db, blocks,
-                           g.Cout, Nw, ncols);
-        NNHIP_LAUNCH_CHECK("conv_wgrad_reduce_kernel");
+        return conv_reduce(part, dW, db, blocks, g.Cout, Nw, ncols, st, deferred);
     } else if (dW || db) {
         const int Nw = g.Cin * g.kh * g.kw;
         const int ncols = Nw + 1;

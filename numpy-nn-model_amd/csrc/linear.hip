@@ -44,6 +44,7 @@ enum { ACT_NONE = 0, ACT_SWISH = 1, ACT_RELU = 2, ACT_SIGMOID = 3 };
 static std::mutex g_wq_mu;
 static std::vector<WgradJob> g_wq;
 static int g_wq_on = 0;
+bool wgrad_defer_on() { return g_wq_on != 0; }
 static hipStream_t g_wq_stream = nullptr;
 static int wq_flush_locked() {
     if (g_wq.empty()) return 0;
@@ -140,6 +141,7 @@ extern "C" int nnhipWeightGradDefer(int32_t enable, nnhipStream_t stream) {
     if (!enable) {
         if (!g_wq.empty()) g_wq_stream = (hipStream_t)stream;
         rc = wq_flush_locked();
+        if (int rc2 = nnhip::conv_reduce_flush(stream)) rc = rc ? rc : rc2;
     }
     g_wq_on = enable ? 1 : 0;
     return rc;
@@ -147,7 +149,9 @@ extern "C" int nnhipWeightGradDefer(int32_t enable, nnhipStream_t stream) {
 extern "C" int nnhipWeightGradFlush(nnhipStream_t stream) {
     std::lock_guard<std::mutex> lk(g_wq_mu);
     if (!g_wq.empty() && g_wq_stream != (hipStream_t)stream) g_wq_stream = (hipStream_t)stream;
-    return wq_flush_locked();
+    int rc = wq_flush_locked();
+    if (int rc2 = nnhip::conv_reduce_flush(stream)) rc = rc ? rc : rc2;
+    return rc;
 }
 extern "C" int nnhipWeightGradPending(void) {
     std::lock_guard<std::mutex> lk(g_wq_mu);

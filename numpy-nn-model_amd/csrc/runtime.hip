@@ -56,6 +56,8 @@ void* workspace(size_t bytes) {
     return g_ws;
 }
 
+bool workspace_locked() { return g_ws_locked; }
+
 const float* zero_block() {
     static float* z = nullptr;
     static std::once_flag once;
@@ -97,6 +99,7 @@ extern "C" int nnhipWorkspaceLock(int locked) {
 extern "C" const char* nnhipGetLastErrorString(void) { return nnhip::g_err; }
 
 extern "C" int nnhipCleanup(void) {
+    nnhip::conv_reduce_cleanup();
     std::lock_guard<std::mutex> lk(nnhip::g_ws_mu);
     nnhip::g_ws_locked = false;
     if (nnhip::g_ws) {

@@ -2591,6 +2591,48 @@ def test_conv_pooled_weight_grad(hip, xshape, cout, pool, leaky):
     np.testing.assert_allclose(host(x.grad), dX, **TOL)
 
 
+def test_conv_weight_grad_reduces_deferred(hip):
+    """Inside Tensor.backward() the reduces of the small-channel convs' per-image partial weight gradients are queued and launched
+    as one grid (conv_wgrad_reduce_group_kernel; partials in an arena of their own).  Five stacked 3x3 convs -- more than the
+    queue holds, so it is flushed when full and again at the end -- plus a second backward that ACCUMULATES into the existing
+    gradients (the flush must come before the add): bit-identical to the same steps with deferral switched off."""
+    import neunet_hip
+    from neunet_hip import _lib
+    from neunet_hip.nn.experimental import HIPConv2d
+    rng = np.random.default_rng(321)
+    X = rng.uniform(-1, 1, (6, 1, 12, 10)).astype(np.float32)
+    np.random.seed(99)
+    chans = [1, 8, 16, 5, 12, 3]
+    convs = [HIPConv2d(chans[i], chans[i + 1], 3, (1, 1), (1, 1)) for i in range(5)]
+    dY = rng.standard_normal((6, 3, 12, 10)).astype(np.float32)
+    res = {}
+    for group in (8, 1):                                      # 1: wgrad_begin() declines, every reduce is launched where it is asked for
+        old, _lib._wgrad["group"] = _lib._wgrad["group"], group
+        try:
+            for c in convs:
+                c.weight.grad = c.bias.grad = None
+            for _ in range(2):
+                h = neunet_hip.Tensor(X, device="cuda", requires_grad=False)
+                for c in convs:
+                    h = c(h)
+                h.backward(dY)
+            res[group] = [host(c.weight.grad) for c in convs] + [host(c.bias.grad) for c in convs]
+        finally:
+            _lib._wgrad["group"] = old
+    for a, b in zip(res[8], res[1]):
+        np.testing.assert_array_equal(a, b)
+    # and against the oracle chain (one backward = half of the accumulated gradient)
+    acts, Ws = [X], [host(c.weight.data) for c in convs]
+    for c, W in zip(convs, Ws):
+        acts.append(O.conv2d_forward(acts[-1], W, host(c.bias.data), (1, 1), (1, 1), (1, 1)))
+    d = dY
+    for i in reversed(range(5)):
+        dX, dW, db = O.conv2d_backward(acts[i], Ws[i], True, d, (1, 1), (1, 1), (1, 1))
+        assert_close_scaled(res[8][i], 2 * dW)
+        assert_close_scaled(res[8][5 + i], 2 * db)
+        d = dX
+
+
 @pytest.mark.parametrize("ks,st,pad,shape", [(2, 2, 0, (3, 4, 12, 12)), (3, 2, 1, (2, 3, 11, 9)), (2, 1, 0, (2, 2, 7, 7)),
                                               (2, 2, 0, (256, 8, 28, 28))])
 def test_leaky_relu_maxpool_fusion(hip, ks, st, pad, shape):
