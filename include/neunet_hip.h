@@ -459,6 +459,15 @@ int nnhipConv2dWeightGradPooledOk(const nnhipConv2dDesc* conv, const nnhipPool2d
 int nnhipConv2dWeightGradPooled(const float* X, const float* dP, const int32_t* argmax, const float* pooled, float alpha,
                                 float* dW, float* db, const nnhipConv2dDesc* conv, const nnhipPool2dDesc* pool,
                                 nnhipStream_t stream);
+/* P = MaxPool2d(2, 2)(LeakyReLU(Conv2d(X); alpha)) and the pool's window-local arg-max in ONE launch (alpha = 1: no activation)
+ * -- conv2d.py:297-355 -> activations.py:79-81 -> maxpool2d.py:85-249 for a 3x3, unit-stride, unit-dilation conv with few input
+ * channels (Cin <= 4 < Cout <= 16) whose output the windows tile exactly and a batch large enough that one thread per window
+ * fills the chip (...Ok = 1; else 0: call the three entries).  The conv output is not written: the chain's backward needs only
+ * the arg-max and P (nnhipMaxPool2dLeakyBackward, nnhipConv2dWeightGradPooled).  The same products in the same order as the separate
+ * entries (values agree to an ulp or two: the compiler's choice of fused multiply-adds differs between the kernels).  ABI 207 */
+int nnhipConv2dLeakyMaxPoolForwardOk(const nnhipConv2dDesc* conv, const nnhipPool2dDesc* pool);
+int nnhipConv2dLeakyMaxPoolForward(const float* X, const float* W, const float* bias, float alpha, float* P, int32_t* argmax,
+                                   const nnhipConv2dDesc* conv, const nnhipPool2dDesc* pool, nnhipStream_t stream);
 /* BatchNorm2d (neunet/nn/layers/batchnorm2d.py:57-115, 11-54), X [B,C,HW].  training != 0: batch mean / biased
  * variance per channel, running = momentum*running + (1-momentum)*stat (the reference's convention; running_*
  * may be NULL); else the running statistics are used.  save_mean / save_inv [C] feed the backward.

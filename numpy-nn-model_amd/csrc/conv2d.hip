@@ -606,6 +606,86 @@ __global__ __launch_bounds__(256) void conv_direct_fwd_kernel(const float* __res
         if (c < g.Cout) O[((int64_t)b * g.Cout + c) * HWo + p] = acc[c] + (bias ? bias[c] : 0.f);
 }
 
+// forward of  MaxPool2d(2, 2)(LeakyReLU(Conv2d(X); alpha))  in one launch (alpha = 1: no activation): thread <-> one pool WINDOW, i.e.
+// the 2x2 conv outputs under it -- a 4x4 input patch per channel (16 loads where four separate positions take 36), every
+// weight read from LDS once for the four positions.  Per output the products run in conv_direct_fwd_kernel's order (ci, then taps;
+// values agree with the three-module chain to an ulp or two -- the compiler contracts the two kernels' multiply-adds differently);
+// the conv output itself is never written (the backward needs only the arg-max and the pooled output: the activation's slope is its
+// sign).  3x3, unit stride and dilation, windows
+// tiling the conv output exactly.
+template <int CO>
+__global__ __launch_bounds__(256) void conv_pool_fwd_kernel(const float* __restrict__ Wt, const float* __restrict__ X,
+                                                            const float* __restrict__ bias, float* __restrict__ P,
+                                                            int32_t* __restrict__ arg, const ConvGeom g, float alpha) {
+    __shared__ __attribute__((aligned(16))) float Wl[CD_MAXC * 9 * CO];
+    const int K = g.Cin * 9;
+    stage_to_lds(Wl, Wt, K * CO, threadIdx.x, [&](int i) -> int64_t {
+        const int co = i % CO, k = i / CO;
+        return co < g.Cout ? (int64_t)co * K + k : -1;
+    });
+    __syncthreads();
+    const int Hq = g.Ho >> 1, Wq = g.Wo >> 1, HWq = Hq * Wq;
+    const int64_t N = (int64_t)g.B * HWq;
+    const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int b = (int)(n / HWq), pq = (int)(n - (int64_t)b * HWq);
+    const int hq = pq / Wq, wq = pq - hq * Wq;
+    const int HWi = g.H * g.W;
+    const __amdgpu_buffer_rsrc_t rx = cd_rsrc(X, (unsigned)((int64_t)g.B * g.Cin * HWi) * 4u);
+    unsigned vo[16];                                        // the 4x4 patch: rows 2hq - pu + {0..3}, columns 2wq - pl + {0..3}
+#pragma unroll
+    for (int y = 0; y < 4; ++y)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const int hi = 2 * hq - g.pu + y, wi = 2 * wq - g.pl + x;
+            vo[y * 4 + x] = (hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) ? (unsigned)(b * g.Cin * HWi + hi * g.W + wi) * 4u : CD_OOB;
+        }
+    float acc[4][CO];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int c = 0; c < CO; ++c) acc[k][c] = 0.f;
+    for (int ci = 0; ci < g.Cin; ++ci) {
+        const unsigned so = (unsigned)(ci * HWi) * 4u;
+        float x[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) x[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vo[t], so, 0));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const float4* w4 = reinterpret_cast<const float4*>(&Wl[(ci * 9 + r * 3 + q) * CO]);
+#pragma unroll
+                for (int c4 = 0; c4 < CO / 4; ++c4) {
+                    const float4 w = w4[c4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float xv = x[((k >> 1) + r) * 4 + (k & 1) + q];
+                        acc[k][4 * c4] += xv * w.x; acc[k][4 * c4 + 1] += xv * w.y; acc[k][4 * c4 + 2] += xv * w.z; acc[k][4 * c4 + 3] += xv * w.w;
+                    }
+                }
+            }
+    }
+#pragma unroll
+    for (int c = 0; c < CO; ++c) {
+        if (c < g.Cout) {
+            const float bc = bias ? bias[c] : 0.f;
+            float best = -INFINITY;
+            int bi = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                   // MaxPool2d's scan order and first-max rule (maxpool_fwd_kernel)
+                float v = acc[k][c] + bc;
+                if (alpha != 1.0f) v = v <= 0.f ? alpha * v : v;
+                if (v > best) { best = v; bi = k; }
+            }
+            const int64_t o = ((int64_t)b * g.Cout + c) * HWq + pq;
+            P[o] = best;
+            arg[o] = bi;
+        }
+    }
+}
+
 // dgrad: thread <-> (b, h, w); acc[ci].   Wl[(co*khkw + rs) * CI + ci]
 template <int CI>
 __global__ __launch_bounds__(256) void conv_direct_dgrad_kernel(const float* __restrict__ Wt, const float* __restrict__ dO,
@@ -1256,6 +1336,36 @@ extern "C" int nnhipConv2dWeightGradPooled(const float* X, const float* dP, cons
                      : launch_mfma_wgrad<10, true>(X, nullptr, part, g, ncols, blocks, m_lds, st, pg);
     if (rc) return rc;
     return conv_reduce(part, dW, db, blocks, g.Cout, Nw, ncols, st, deferred);
+}
+
+static bool conv_pool_fwd_ok(const ConvGeom& g, const nnhipPool2dDesc* pd) {
+    static const bool on = []() { const char* e = getenv("NNHIP_CONV_POOL_FWD"); return !e || atoi(e) != 0; }();
+    // one thread per window: worth it while the windows still make a grid (the second C5 layer's 49 blocks do not)
+    return on && pd && pd->kh == 2 && pd->kw == 2 && pd->sh == 2 && pd->sw == 2 && pd->pu + pd->pd + pd->pl + pd->pr == 0 && pd->dh <= 1 &&
+           pd->dw <= 1 && pd->B == g.B && pd->C == g.Cout && pd->H == g.Ho && pd->W == g.Wo && g.Ho % 2 == 0 && g.Wo % 2 == 0 &&
+           conv_direct_ok(g) && g.kh == 3 && g.kw == 3 && g.sh == 1 && g.sw == 1 && g.dh == 1 && g.dw == 1 && g.Cout > 4 && g.Cin <= 4 &&
+           (int64_t)g.B * (g.Ho / 2) * (g.Wo / 2) >= 128 * 256;
+}
+extern "C" int nnhipConv2dLeakyMaxPoolForwardOk(const nnhipConv2dDesc* d, const nnhipPool2dDesc* pd) {
+    ConvGeom g;
+    if (!d || !pd || make_geom(d, g) || g.B == 0) return 0;
+    return conv_pool_fwd_ok(g, pd) ? 1 : 0;
+}
+extern "C" int nnhipConv2dLeakyMaxPoolForward(const float* X, const float* W, const float* bias, float alpha, float* P, int32_t* argmax,
+                                              const nnhipConv2dDesc* d, const nnhipPool2dDesc* pd, nnhipStream_t s) {
+    ConvGeom g;
+    if (int rc = make_geom(d, g)) return rc;
+    if (g.B == 0) return 0;
+    NNHIP_CHECK_ARG(X && W && P && argmax, NNHIP_EINVAL, "nnhipConv2dLeakyMaxPoolForward: null pointer");
+    NNHIP_CHECK_ARG(alpha > 0.f, NNHIP_EINVAL, "nnhipConv2dLeakyMaxPoolForward: alpha must be > 0 (1 = no activation)");
+    NNHIP_CHECK_ARG(conv_pool_fwd_ok(g, pd), NNHIP_EINVAL,
+                    "nnhipConv2dLeakyMaxPoolForward: unsupported geometry (ask nnhipConv2dLeakyMaxPoolForwardOk first)");
+    const int64_t N = (int64_t)g.B * (g.Ho / 2) * (g.Wo / 2);
+    const dim3 grid((unsigned)ceil_div(N, 256));
+    if (g.Cout <= 8) hipLaunchKernelGGL(conv_pool_fwd_kernel<8>, grid, dim3(256), 0, (hipStream_t)s, W, X, bias, P, argmax, g, alpha);
+    else hipLaunchKernelGGL(conv_pool_fwd_kernel<16>, grid, dim3(256), 0, (hipStream_t)s, W, X, bias, P, argmax, g, alpha);
+    NNHIP_LAUNCH_CHECK("conv_pool_fwd_kernel");
+    return 0;
 }
 
 extern "C" int nnhipConv2dBackward(const float* X, const float* W, const float* dO, float* dX, float* dW,

@@ -82,7 +82,7 @@ unsigned* sync_words() {
 
 }  // namespace nnhip
 
-extern "C" int nnhipVersion(void) { return 206; }
+extern "C" int nnhipVersion(void) { return 207; }
 
 extern "C" int nnhipWorkspaceReserve(int64_t bytes) {
     if (bytes < 0) { nnhip::set_last_error("nnhipWorkspaceReserve: negative size"); return NNHIP_EINVAL; }

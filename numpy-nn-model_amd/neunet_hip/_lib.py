@@ -131,6 +131,8 @@ _SIGNATURES = {
     "nnhipMaxPool2dLeakyBackward": (ctypes.c_int, [P, P, P, P, c_float, POINTER(Pool2dDesc), c_void_p]),
     "nnhipConv2dWeightGradPooledOk": (ctypes.c_int, [POINTER(Conv2dDesc), POINTER(Pool2dDesc)]),
     "nnhipConv2dWeightGradPooled": (ctypes.c_int, [P, P, P, P, c_float, P, P, POINTER(Conv2dDesc), POINTER(Pool2dDesc), c_void_p]),
+    "nnhipConv2dLeakyMaxPoolForwardOk": (ctypes.c_int, [POINTER(Conv2dDesc), POINTER(Pool2dDesc)]),
+    "nnhipConv2dLeakyMaxPoolForward": (ctypes.c_int, [P, P, P, c_float, P, P, POINTER(Conv2dDesc), POINTER(Pool2dDesc), c_void_p]),
     "nnhipBatchNorm2dForward": (ctypes.c_int, [P, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_float, c_float, ctypes.c_int, c_void_p]),
     "nnhipBatchNorm2dBackward": (ctypes.c_int, [P, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_void_p]),
     "nnhipMSELossForwardBackward": (ctypes.c_int, [P, P, P, P, c_int64, c_void_p]),
@@ -138,7 +140,7 @@ _SIGNATURES = {
     "nnhipScale": (ctypes.c_int, [P, c_float, c_int64, c_void_p]),
     "nnhipAdd": (ctypes.c_int, [P, P, P, c_int64, c_void_p]),
 }
-_NO_STATUS = {"nnhipVersion", "nnhipGetLastErrorString", "nnhipCreateFusedOptimizer", "nnhipGetGemmMode", "nnhipGetGemmLockstep", "nnhipConv2dWeightGradPooledOk", "nnhipGemmLaunchCount",
+_NO_STATUS = {"nnhipVersion", "nnhipGetLastErrorString", "nnhipCreateFusedOptimizer", "nnhipGetGemmMode", "nnhipGetGemmLockstep", "nnhipConv2dWeightGradPooledOk", "nnhipConv2dLeakyMaxPoolForwardOk", "nnhipGemmLaunchCount",
               "nnhipWeightGradPending"}
 
 _dll = None

@@ -3,6 +3,7 @@ CPU semantics: neunet/nn/layers/conv2d.py:120-355 (geometry in Conv2d.build :193
 :297-355, backward :16-115).  Unlike the reference, weight.data is never mutated (it dilates the
 weight in forward and un-dilates it in grad_fn, conv2d.py:307,108 -- SURVEY Appendix A.2)."""
 import ctypes
+import os
 from typing import Union
 
 import numpy as np
@@ -55,7 +56,13 @@ def hip_conv2d_backward(X, W, grad_O, grad_X, grad_W, grad_b, desc):
 
 
 class _HIPConv2dTensor(Tensor):
-    def __init__(self, data, args, op, device):
+    """Output of HIPConv2d.  With a thunk the kernel launch is DEFERRED until somebody reads `.data`: a MaxPool2d(2, 2) applied to
+    it first -- directly or through a deferred LeakyReLU -- may run conv, activation and pool as one kernel that never writes the
+    conv output (vision.py: nnhipConv2dLeakyMaxPoolForward); anything else that touches `.data` launches the plain forward then.
+    Values are identical either way.  The backward never needs the output itself."""
+
+    def __init__(self, data, args, op, device, thunk=None, shape=None):
+        self._data, self._thunk, self._lazy_shape = None, thunk, shape
         super().__init__(data, args, op, device=device, _nocopy=True)
 
         def grad_fn(X: Tensor, weight: Tensor, bias, desc, grad):
@@ -71,6 +78,35 @@ class _HIPConv2dTensor(Tensor):
                 _finish_param(bias, grad_b)
 
         self.grad_fn = grad_fn
+
+    @property
+    def data(self):
+        if self._data is None and self._thunk is not None:
+            thunk, self._thunk = self._thunk, None
+            self._data = thunk()
+        return self._data
+
+    @data.setter
+    def data(self, value):
+        self._data = value
+
+    def pending(self) -> bool:
+        return self._data is None and self._thunk is not None
+
+    @property
+    def shape(self):
+        return tuple(self._lazy_shape) if self._data is None and self._lazy_shape is not None else tuple(self._data.shape)
+
+    @property
+    def dtype(self):
+        return np.dtype(np.float32)
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+
+_LAZY_CONV = os.environ.get("NNHIP_VISION_FUSION", "1") != "0" and os.environ.get("NNHIP_LAZY_CONV", "1") != "0"
 
 
 class HIPConv2d(Module):
@@ -98,6 +134,14 @@ class HIPConv2d(Module):
         if not X.data.is_contiguous():
             raise ValueError("HIPConv2d needs a C-contiguous NCHW input")
         desc, (Ho, Wo) = conv2d_desc(X.shape, self.weight.shape, self.stride, self.padding, self.dilation)
-        O = X.xp.empty((X.shape[0], self.out_channels, Ho, Wo), dtype=np.float32)
-        hip_conv2d_forward(X.data, self.weight.data, self.bias.data if self.bias is not None else None, O, desc)
-        return _HIPConv2dTensor(O, (X, self.weight, self.bias, desc), "conv2d", self.device)
+        oshape = (X.shape[0], self.out_channels, Ho, Wo)
+        weight, bias = self.weight, self.bias
+
+        def thunk():
+            O = X.xp.empty(oshape, dtype=np.float32)
+            hip_conv2d_forward(X.data, weight.data, bias.data if bias is not None else None, O, desc)
+            return O
+
+        if _LAZY_CONV:
+            return _HIPConv2dTensor(None, (X, weight, bias, desc), "conv2d", self.device, thunk=thunk, shape=oshape)
+        return _HIPConv2dTensor(thunk(), (X, weight, bias, desc), "conv2d", self.device)

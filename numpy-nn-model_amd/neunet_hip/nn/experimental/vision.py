@@ -167,6 +167,20 @@ class _HIPMaxPool2dTensor(Tensor):
         self.grad_fn = grad_fn
 
 
+def _conv_pool_forward(src, alpha, O, argmax, desc) -> bool:
+    """src is the output of a Conv2d that has not been launched yet and the pool's 2x2 windows tile it: conv, activation and pool
+    as one kernel (nnhipConv2dLeakyMaxPoolForward); the conv output stays unwritten unless somebody asks for it later."""
+    from .conv2d import _HIPConv2dTensor
+    if not _FUSE or not isinstance(src, _HIPConv2dTensor) or not src.pending():
+        return False
+    cx, weight, bias, cdesc = src.args
+    if not call_hip_function("nnhipConv2dLeakyMaxPoolForwardOk", ctypes.byref(cdesc), ctypes.byref(desc)):
+        return False
+    call_hip_function("nnhipConv2dLeakyMaxPoolForward", cx.data, weight.data, bias.data if bias is not None else None, float(alpha),
+                      O, argmax, ctypes.byref(cdesc), ctypes.byref(desc), get_current_stream_ptr())
+    return True
+
+
 class HIPMaxPool2d(Module):
     """neunet/nn/layers/maxpool2d.py:85-249, dilation included (taps at r*dh, s*dw; :170-186)."""
 
@@ -199,9 +213,12 @@ class HIPMaxPool2d(Module):
         argmax = torch.empty((B, C, Ho, Wo), dtype=torch.int32, device=O.device)
         if isinstance(X, _HIPLeakyReLUTensor) and X.pending():
             src, alpha = X.args[0], float(X.args[2])       # pool over LeakyReLU(src) without materialising it
-            call_hip_function("nnhipMaxPool2dLeakyForward", O, argmax, contiguous(src.data), alpha, ctypes.byref(desc),
-                              get_current_stream_ptr())
+            if not _conv_pool_forward(src, alpha, O, argmax, desc):
+                call_hip_function("nnhipMaxPool2dLeakyForward", O, argmax, contiguous(src.data), alpha, ctypes.byref(desc),
+                                  get_current_stream_ptr())
             return _HIPMaxPool2dTensor(O, (src, argmax, desc, O, alpha), "maxpool2d", device=X.device)
+        if _conv_pool_forward(X, 1.0, O, argmax, desc):     # pool straight over a conv that has not run yet
+            return _HIPMaxPool2dTensor(O, (X, argmax, desc, None, 1.0), "maxpool2d", device=X.device)
         call_hip_function("nnhipMaxPool2dForward", O, argmax, contiguous(X.data), ctypes.byref(desc),
                           get_current_stream_ptr())
         return _HIPMaxPool2dTensor(O, (X, argmax, desc, None, 1.0), "maxpool2d", device=X.device)

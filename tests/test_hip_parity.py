@@ -2591,6 +2591,58 @@ def test_conv_pooled_weight_grad(hip, xshape, cout, pool, leaky):
     np.testing.assert_allclose(host(x.grad), dX, **TOL)
 
 
+@pytest.mark.parametrize("xshape,cout,leaky,pad,need_dx", [((170, 1, 28, 28), 8, True, 1, False),      # C5 layer 1 (smaller batch)
+                                                           ((64, 3, 46, 46), 16, True, 1, True),        # <16>, three input channels
+                                                           ((40, 2, 62, 60), 5, False, 0, True),        # no activation, unpadded conv
+                                                           ((150, 4, 32, 28), 7, True, 2, False)])      # padding 2: patches past every edge
+def test_conv_leaky_pool_forward_fusion(hip, xshape, cout, leaky, pad, need_dx):
+    """Conv2d -> [LeakyReLU ->] MaxPool2d(2, 2) with the conv launch deferred: one kernel computes the pooled output and the arg-max
+    and never writes the conv output (nnhipConv2dLeakyMaxPoolForward).  Pooled values and gradients against the three-module
+    chain and the oracle; the conv output materialises (identically) only if somebody reads it afterwards."""
+    import neunet_hip
+    import neunet_hip.nn as nn
+    from neunet_hip.nn.experimental import HIPConv2d, vision
+    rng = np.random.default_rng(sum(xshape) + cout)
+    X = rng.uniform(-1, 1, xshape).astype(np.float32)
+    conv = HIPConv2d(xshape[1], cout, 3, (1, 1), (pad, pad))
+    conv.bias.data.copy_(dev(rng.uniform(-0.3, 0.3, cout).astype(np.float32)))
+    act, mp = nn.LeakyReLU(0.01), nn.MaxPool2d(2, 2)
+    Ho, Wo = xshape[2] + 2 * pad - 2, xshape[3] + 2 * pad - 2
+    dY = rng.standard_normal((xshape[0], cout, Ho // 2, Wo // 2)).astype(np.float32)
+    res = {}
+    for fused in (True, False):
+        old, vision._FUSE = vision._FUSE, fused
+        try:
+            conv.weight.grad = conv.bias.grad = None
+            x = neunet_hip.Tensor(X, device="cuda", requires_grad=need_dx)
+            c = conv(x)
+            y = mp(act(c) if leaky else c)
+            assert c.pending() == fused                        # fused: the conv kernel never ran
+            y.backward(dY)
+            assert c.pending() == fused
+            res[fused] = [host(y.data), host(conv.weight.grad), host(conv.bias.grad)] + ([host(x.grad)] if need_dx else []) + [host(c.data)]
+        finally:
+            vision._FUSE = old
+    # the fused kernel and conv_direct_fwd_kernel run the same products in the same order, but the compiler contracts them into
+    # fused multiply-adds differently: pooled values agree to an ulp or two, not bit for bit (so do the gradients routed by them)
+    np.testing.assert_allclose(res[True][0], res[False][0], rtol=2e-6, atol=1e-6)
+    for a, b in zip(res[True][1:-1], res[False][1:-1]):
+        assert_close_scaled(a, b)
+    np.testing.assert_array_equal(res[True][-1], res[False][-1])        # the conv output, once somebody asks for it: the same kernel
+    W, b = host(conv.weight.data), host(conv.bias.data)
+    Oc = O.conv2d_forward(X, W, b, (1, 1), (pad, pad), (1, 1))
+    A = O.leaky_relu_forward(Oc, 0.01) if leaky else Oc
+    Yr, arg = O.maxpool2d_forward(A, (2, 2), (2, 2))
+    np.testing.assert_allclose(res[True][0], Yr, **TOL)
+    dA = O.maxpool2d_backward(A.shape, arg, dY, (2, 2), (2, 2))
+    dOc = O.leaky_relu_backward(A, dA, 0.01) if leaky else dA
+    dX, dW, db = O.conv2d_backward(X, W, True, dOc, (1, 1), (pad, pad), (1, 1))
+    assert_close_scaled(res[True][1], dW)
+    assert_close_scaled(res[True][2], db)
+    if need_dx:
+        np.testing.assert_allclose(res[True][3], dX, rtol=1e-4, atol=2e-4)
+
+
 def test_conv_weight_grad_reduces_deferred(hip):
     """Inside Tensor.backward() the reduces of the small-channel convs' per-image partial weight gradients are queued and launched
     as one grid (conv_wgrad_reduce_group_kernel; partials in an arena of their own).  Five stacked 3x3 convs -- more than the
