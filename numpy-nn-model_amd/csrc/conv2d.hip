@@ -783,10 +783,13 @@ __device__ __forceinline__ float quad_sum(float v) {
 
 // forward: Wl[ci * CSTR + tap * CO + co]; CSTR = 9 CO (+ 8 for CO = 16: the four lanes of a quad read four different ci at once,
 // and a stride of 144 floats would put two of them on the same LDS banks)
-template <int CO>
+// POOL: sixteen consecutive lanes are the four positions under one 2x2 pool window (position = 4-lane quad); after the quad sums
+// the four quads meet in two lane exchanges (xor 4, xor 8), keep the first maximum of LeakyReLU(conv + bias; alpha) and the quad of
+// position 0 stores pooled value and arg-max -- the conv output is not written (nnhipConv2dLeakyMaxPoolForward, second C5 layer).
+template <int CO, bool POOL = false>
 __global__ __launch_bounds__(256) void conv_direct_fwd_quad_kernel(const float* __restrict__ Wt, const float* __restrict__ X,
                                                                    const float* __restrict__ bias, float* __restrict__ O,
-                                                                   const ConvGeom g) {
+                                                                   const ConvGeom g, int32_t* __restrict__ arg = nullptr, float alpha = 1.f) {
     constexpr int CSTR = 9 * CO + (CO == 16 ? 8 : 0), CPL = CD_MAXC / 4;      // channels per lane
     __shared__ __attribute__((aligned(16))) float Wl[CD_MAXC * CSTR];
     const int K = g.Cin * 9;
@@ -798,9 +801,23 @@ __global__ __launch_bounds__(256) void conv_direct_fwd_quad_kernel(const float* 
     const int64_t HWo = (int64_t)g.Ho * g.Wo, N = (int64_t)g.B * HWo;
     const int64_t n = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 2;
     const int s = threadIdx.x & 3;
-    if (n >= N) return;                                   // whole quads leave together
-    const int b = (int)(n / HWo), p = (int)(n - (int64_t)b * HWo);
-    const int ho = p / g.Wo, wo = p - ho * g.Wo;
+    if (n >= N) return;                                   // whole quads leave together (POOL: whole windows, N = 4 * windows)
+    int b, p, ho, wo;
+    [[maybe_unused]] int pq = 0, HWq = 0;
+    if constexpr (POOL) {
+        const int Wq = g.Wo >> 1;
+        HWq = (g.Ho >> 1) * Wq;
+        const int64_t win = n >> 2;
+        const int pos = (int)(n & 3);
+        b = (int)(win / HWq);
+        pq = (int)(win - (int64_t)b * HWq);
+        const int hq = pq / Wq, wq = pq - hq * Wq;
+        ho = 2 * hq + (pos >> 1); wo = 2 * wq + (pos & 1);
+        p = ho * g.Wo + wo;
+    } else {
+        b = (int)(n / HWo); p = (int)(n - (int64_t)b * HWo);
+        ho = p / g.Wo; wo = p - ho * g.Wo;
+    }
     float acc[CO];
 #pragma unroll
     for (int c = 0; c < CO; ++c) acc[c] = 0.f;
@@ -847,7 +864,26 @@ __global__ __launch_bounds__(256) void conv_direct_fwd_quad_kernel(const float* 
         asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));      // (or the selects become acc[f(s)]: a scratch array)
         const float v = s == 0 ? a0 : s == 1 ? a1 : s == 2 ? a2 : a3;
         const int co = s * (CO / 4) + c;
-        if (co < g.Cout) O[((int64_t)b * g.Cout + co) * HWo + p] = v + (bias ? bias[co] : 0.f);
+        if constexpr (!POOL) {
+            if (co < g.Cout) O[((int64_t)b * g.Cout + co) * HWo + p] = v + (bias ? bias[co] : 0.f);
+        } else {
+            float f = v + ((bias && co < g.Cout) ? bias[co] : 0.f);
+            if (alpha != 1.0f) f = f <= 0.f ? alpha * f : f;
+            int k = (int)(n & 3);                           // this quad's cell of the window: MaxPool2d scans cells 0..3, first maximum wins
+#pragma unroll
+            for (int m = 4; m <= 8; m <<= 1) {
+                const float fo = __shfl_xor(f, m, 64);
+                const int ko = __shfl_xor(k, m, 64);
+                const bool take = fo > f || (fo == f && ko < k);
+                f = take ? fo : f;
+                k = take ? ko : k;
+            }
+            if ((n & 3) == 0 && co < g.Cout) {
+                const int64_t o = ((int64_t)b * g.Cout + co) * HWq + pq;
+                O[o] = f;
+                arg[o] = k;
+            }
+        }
     }
 }
 
@@ -1266,8 +1302,8 @@ extern "C" int nnhipConv2dForward(const float* X, const float* W, const float* b
         // under two blocks per CU and a reduction worth splitting: four lanes per position (conv_direct_fwd_quad_kernel)
         if (conv_quad_on() && g.kh == 3 && g.kw == 3 && N <= 512 * 256 && g.Cin >= 4 && g.Cout > 4) {
             const dim3 qgrid((unsigned)ceil_div(4 * N, 256));
-            if (g.Cout <= 8) hipLaunchKernelGGL(conv_direct_fwd_quad_kernel<8>, qgrid, dim3(256), 0, (hipStream_t)s, W, X, bias, O, g);
-            else hipLaunchKernelGGL(conv_direct_fwd_quad_kernel<16>, qgrid, dim3(256), 0, (hipStream_t)s, W, X, bias, O, g);
+            if (g.Cout <= 8) hipLaunchKernelGGL((conv_direct_fwd_quad_kernel<8, false>), qgrid, dim3(256), 0, (hipStream_t)s, W, X, bias, O, g, (int32_t*)nullptr, 1.f);
+            else hipLaunchKernelGGL((conv_direct_fwd_quad_kernel<16, false>), qgrid, dim3(256), 0, (hipStream_t)s, W, X, bias, O, g, (int32_t*)nullptr, 1.f);
             NNHIP_LAUNCH_CHECK("conv_direct_fwd_quad_kernel");
             return 0;
         }
@@ -1338,13 +1374,22 @@ extern "C" int nnhipConv2dWeightGradPooled(const float* X, const float* dP, cons
     return conv_reduce(part, dW, db, blocks, g.Cout, Nw, ncols, st, deferred);
 }
 
+// one thread per window (conv_pool_fwd_kernel): few input channels, and windows enough to make a grid
+static bool conv_pool_window_ok(const ConvGeom& g) {
+    return g.sh == 1 && g.sw == 1 && g.dh == 1 && g.dw == 1 && g.Cout > 4 && g.Cin <= 4 && (int64_t)g.B * (g.Ho / 2) * (g.Wo / 2) >= 128 * 256;
+}
+// sixteen lanes per window (conv_direct_fwd_quad_kernel<CO, POOL>): where the plain forward would take the quad kernel
+static bool conv_pool_quad_ok(const ConvGeom& g) {
+    return conv_quad_on() && (int64_t)g.B * g.Ho * g.Wo <= 512 * 256 && g.Cin >= 4 && g.Cout > 4;
+}
 static bool conv_pool_fwd_ok(const ConvGeom& g, const nnhipPool2dDesc* pd) {
     static const bool on = []() { const char* e = getenv("NNHIP_CONV_POOL_FWD"); return !e || atoi(e) != 0; }();
     // one thread per window: worth it while the windows still make a grid (the second C5 layer's 49 blocks do not)
-    return on && pd && pd->kh == 2 && pd->kw == 2 && pd->sh == 2 && pd->sw == 2 && pd->pu + pd->pd + pd->pl + pd->pr == 0 && pd->dh <= 1 &&
-           pd->dw <= 1 && pd->B == g.B && pd->C == g.Cout && pd->H == g.Ho && pd->W == g.Wo && g.Ho % 2 == 0 && g.Wo % 2 == 0 &&
-           conv_direct_ok(g) && g.kh == 3 && g.kw == 3 && g.sh == 1 && g.sw == 1 && g.dh == 1 && g.dw == 1 && g.Cout > 4 && g.Cin <= 4 &&
-           (int64_t)g.B * (g.Ho / 2) * (g.Wo / 2) >= 128 * 256;
+    if (!(on && pd && pd->kh == 2 && pd->kw == 2 && pd->sh == 2 && pd->sw == 2 && pd->pu + pd->pd + pd->pl + pd->pr == 0 && pd->dh <= 1 &&
+          pd->dw <= 1 && pd->B == g.B && pd->C == g.Cout && pd->H == g.Ho && pd->W == g.Wo && g.Ho % 2 == 0 && g.Wo % 2 == 0 &&
+          conv_direct_ok(g) && g.kh == 3 && g.kw == 3))
+        return false;
+    return conv_pool_window_ok(g) || conv_pool_quad_ok(g);
 }
 extern "C" int nnhipConv2dLeakyMaxPoolForwardOk(const nnhipConv2dDesc* d, const nnhipPool2dDesc* pd) {
     ConvGeom g;
@@ -1360,6 +1405,13 @@ extern "C" int nnhipConv2dLeakyMaxPoolForward(const float* X, const float* W, co
     NNHIP_CHECK_ARG(alpha > 0.f, NNHIP_EINVAL, "nnhipConv2dLeakyMaxPoolForward: alpha must be > 0 (1 = no activation)");
     NNHIP_CHECK_ARG(conv_pool_fwd_ok(g, pd), NNHIP_EINVAL,
                     "nnhipConv2dLeakyMaxPoolForward: unsupported geometry (ask nnhipConv2dLeakyMaxPoolForwardOk first)");
+    if (!conv_pool_window_ok(g)) {                           // the quad kernel, four quads per window
+        const dim3 qgrid((unsigned)ceil_div(4 * (int64_t)g.B * g.Ho * g.Wo, 256));
+        if (g.Cout <= 8) hipLaunchKernelGGL((conv_direct_fwd_quad_kernel<8, true>), qgrid, dim3(256), 0, (hipStream_t)s, W, X, bias, P, g, argmax, alpha);
+        else hipLaunchKernelGGL((conv_direct_fwd_quad_kernel<16, true>), qgrid, dim3(256), 0, (hipStream_t)s, W, X, bias, P, g, argmax, alpha);
+        NNHIP_LAUNCH_CHECK("conv_direct_fwd_quad_kernel");
+        return 0;
+    }
     const int64_t N = (int64_t)g.B * (g.Ho / 2) * (g.Wo / 2);
     const dim3 grid((unsigned)ceil_div(N, 256));
     if (g.Cout <= 8) hipLaunchKernelGGL(conv_pool_fwd_kernel<8>, grid, dim3(256), 0, (hipStream_t)s, W, X, bias, P, argmax, g, alpha);

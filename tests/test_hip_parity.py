@@ -2594,7 +2594,11 @@ def test_conv_pooled_weight_grad(hip, xshape, cout, pool, leaky):
 @pytest.mark.parametrize("xshape,cout,leaky,pad,need_dx", [((170, 1, 28, 28), 8, True, 1, False),      # C5 layer 1 (smaller batch)
                                                            ((64, 3, 46, 46), 16, True, 1, True),        # <16>, three input channels
                                                            ((40, 2, 62, 60), 5, False, 0, True),        # no activation, unpadded conv
-                                                           ((150, 4, 32, 28), 7, True, 2, False)])      # padding 2: patches past every edge
+                                                           ((150, 4, 32, 28), 7, True, 2, False),       # padding 2: patches past every edge
+                                                           # few positions, >= 4 input channels: the quad kernel, sixteen lanes per window
+                                                           ((16, 8, 14, 14), 16, True, 1, True),        # C5 layer 2
+                                                           ((3, 5, 10, 14), 7, False, 1, True),         # <8>, channel counts off the fours, no activation
+                                                           ((2, 16, 6, 6), 12, True, 2, False)])        # sixteen input channels, wide padding
 def test_conv_leaky_pool_forward_fusion(hip, xshape, cout, leaky, pad, need_dx):
     """Conv2d -> [LeakyReLU ->] MaxPool2d(2, 2) with the conv launch deferred: one kernel computes the pooled output and the arg-max
     and never writes the conv output (nnhipConv2dLeakyMaxPoolForward).  Pooled values and gradients against the three-module
