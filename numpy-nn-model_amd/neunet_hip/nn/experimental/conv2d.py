@@ -9,7 +9,7 @@ from typing import Union
 import numpy as np
 
 from ..._lib import Conv2dDesc
-from ...autograd import Tensor
+from ...autograd import Tensor, param_epoch
 from ..modules import Module
 from ..parameter import Parameter
 from .linear import _finish_param, _grad_out
@@ -63,6 +63,7 @@ class _HIPConv2dTensor(Tensor):
 
     def __init__(self, data, args, op, device, thunk=None, shape=None):
         self._data, self._thunk, self._lazy_shape = None, thunk, shape
+        self._epoch = param_epoch()
         super().__init__(data, args, op, device=device, _nocopy=True)
 
         def grad_fn(X: Tensor, weight: Tensor, bias, desc, grad):
@@ -82,6 +83,12 @@ class _HIPConv2dTensor(Tensor):
     @property
     def data(self):
         if self._data is None and self._thunk is not None:
+            if self._epoch != param_epoch():
+                # the conv would run NOW, on weights an optimizer step has since updated in place: not the forward-time value an
+                # eager Conv2d would hold (the same rule as the deferred Linear output, linear.py)
+                raise RuntimeError("this Conv2d output was never materialised during its forward pass (the pool that consumed it "
+                                   "computed it on the fly) and the parameters have been updated since; read `.data` before "
+                                   "optimizer.step(), or set NNHIP_LAZY_CONV=0 for eager Conv2d outputs")
             thunk, self._thunk = self._thunk, None
             self._data = thunk()
         return self._data

@@ -2645,6 +2645,16 @@ def test_conv_leaky_pool_forward_fusion(hip, xshape, cout, leaky, pad, need_dx):
     assert_close_scaled(res[True][2], db)
     if need_dx:
         np.testing.assert_allclose(res[True][3], dX, rtol=1e-4, atol=2e-4)
+    # ... but not after an optimizer step: the deferred launch would see updated weights (the deferred Linear's rule)
+    from neunet_hip.optim import Adam
+    x = neunet_hip.Tensor(X, device="cuda", requires_grad=False)
+    c = conv(x)
+    y = mp(act(c) if leaky else c)
+    y.backward(dY)
+    assert c.pending()
+    Adam(conv.parameters(), lr=1e-3).step()
+    with pytest.raises(RuntimeError, match="never materialised"):
+        c.data
 
 
 def test_conv_weight_grad_reduces_deferred(hip):
