@@ -916,7 +916,8 @@ def workload_c5(args, rank, world):
         "samples_per_step": Bsz * world, "dt": dt,
         "config": {"workload": "C5: Conv2d MNIST classifier training step (conv-LeakyReLU-MaxPool x2, BatchNorm2d, Linear, "
                                "Sigmoid, MSE, Adam), 28x28x1, batch 256 per GPU; at these shapes (Cin, Cout <= 16, 3x3) the DIRECT conv kernels run "
-                               "(conv_direct_fwd/dgrad/wgrad_kernel), not the implicit-GEMM MFMA ones",
+                               "(conv + LeakyReLU + MaxPool forward as one kernel per layer, conv_direct_dgrad_quad / conv_mfma_wgrad backward), "
+                               "not the implicit-GEMM MFMA ones",
                    "global_batch": Bsz * world, "parallelism": f"dp{world}",
                    "launch": (f"hipGraph replay, {U} steps per graph" if U > 1 else "hipGraph replay") if args.graph else "eager"},
         "roofline": {"kernel": "whole step vs the conv layers' algorithmic HBM bytes (K<=72, Cout<=16: HBM/latency bound)",
