@@ -5,6 +5,8 @@ Mirrors the reference's CUDA tests one-to-one: same shapes, tolerance
 fp32 MFMA path allows (LinearSwish 1e-4 instead of the reference's TF32 1e-3).
 Tolerances: fp32 outputs rtol=atol=1e-4 (north_star) unless a tighter one is written; argmax bit-exact.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -2535,6 +2537,13 @@ def test_maxpool_dilated_golden(hip, golden):
         nn.MaxPool2d(2, 2, 0, 0)
 
 
+def _skip_if_switched_off(*names):
+    """The fusion tests assert that the fused path RUNS: with its developer switch off in the environment there is nothing to test."""
+    off = [n for n in names if os.environ.get(n) == "0"]
+    if off:
+        pytest.skip("switched off in the environment: " + ", ".join(off))
+
+
 @pytest.mark.parametrize("xshape,cout,pool,leaky", [((16, 1, 28, 28), 8, (2, 2), True),      # C5 layer 1 (one column tile)
                                                     ((5, 3, 12, 18), 16, (2, 3), True),       # 28 columns, non-square windows
                                                     ((4, 7, 8, 8), 9, (2, 2), False),         # no activation in between, 64 columns
@@ -2545,6 +2554,7 @@ def test_conv_pooled_weight_grad(hip, xshape, cout, pool, leaky):
     straight from its own gradient (nnhipConv2dWeightGradPooled; the conv-output gradient is never written, the conv node's
     backward is skipped).  Bit-identical to the unfused chain (the same values meet the same MFMAs in the same order), equal to
     the oracle chain within the conv tolerance; with an input that DOES need a gradient the fused path must not run."""
+    _skip_if_switched_off("NNHIP_VISION_FUSION", "NNHIP_CONV_POOLED_WGRAD", "NNHIP_CONV_WGRAD_MFMA")
     import neunet_hip
     import neunet_hip.nn as nn
     from neunet_hip.nn.experimental import HIPConv2d, vision
@@ -2603,6 +2613,7 @@ def test_conv_leaky_pool_forward_fusion(hip, xshape, cout, leaky, pad, need_dx):
     """Conv2d -> [LeakyReLU ->] MaxPool2d(2, 2) with the conv launch deferred: one kernel computes the pooled output and the arg-max
     and never writes the conv output (nnhipConv2dLeakyMaxPoolForward).  Pooled values and gradients against the three-module
     chain and the oracle; the conv output materialises (identically) only if somebody reads it afterwards."""
+    _skip_if_switched_off("NNHIP_VISION_FUSION", "NNHIP_LAZY_CONV", "NNHIP_CONV_POOL_FWD", "NNHIP_CONV_QUAD")
     import neunet_hip
     import neunet_hip.nn as nn
     from neunet_hip.nn.experimental import HIPConv2d, vision
