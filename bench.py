@@ -47,7 +47,8 @@ def parse():
     ap.add_argument("--overlap", type=int, default=1, help="N>1: overlap the gradient exchange with the backward pass")
     ap.add_argument("--c4-batch", type=int, default=64, help="sequences per GPU for the GPT-tiny workload")
     ap.add_argument("--graph", type=int, default=1, help="c1/c4: replay the step as a captured hipGraph (1) or launch eagerly (0)")
-    ap.add_argument("--unroll", type=int, default=4, help="c1/c5, one process: training steps captured per hipGraph (1 = one step per replay)")
+    ap.add_argument("--unroll", type=int, default=16, help="c1/c5, one process: at most this many training steps captured per hipGraph "
+                                                          "(the largest divisor of --steps not above it is used; 1 = one step per replay)")
     ap.add_argument("--force-dp", action="store_true",
                     help="one rank: run the data-parallel machinery anyway (1-rank nccl = RCCL process group, bucket segments, "
                          "graph cuts, async all-reduce, 'sum' loss + device-side divisor)")
@@ -115,9 +116,10 @@ def graph_unroll(args, world):
     when the requested step counts are whole numbers of replays (EXACTLY --steps steps are timed either way)."""
     from neunet_hip.distributed import collectives_live
     U = max(1, int(args.unroll))
-    if world != 1 or collectives_live() or not args.graph or args.steps % U != 0 or args.steps < U:
+    if world != 1 or collectives_live() or not args.graph:
         return 1
-    return U
+    # the largest divisor of --steps that is <= --unroll: 500 steps -> 10 per graph, 8000 -> 16, 20 -> 10
+    return max(d for d in range(1, min(U, args.steps) + 1) if args.steps % d == 0)
 
 
 class EventTimer:
@@ -310,12 +312,14 @@ def workload_c1(args, rank, world):
     if args.graph:
         gstep = GraphedTrainStep(fwd_bwd, opt, bucket, warmup=3, world=world, unroll=U)
         tick = [0]
+        n_calls = max(1, args.steps // U)
+        every = 16 if n_calls >= 64 else max(1, n_calls // 4)      # short runs: still a few device-time samples
 
         def step(timed):
             # the device-time events go around every 16th step only: at ~0.06 ms per step two event records per step are a
             # measurable part of what they measure (host time and two more device-side nodes between the graph launches)
             tick[0] += 1
-            sample = timed and tick[0] % 16 == 0
+            sample = timed and tick[0] % every == 0
             if sample:
                 a, b = ev.span()
                 a.record()
@@ -882,12 +886,14 @@ def workload_c5(args, rank, world):
     if args.graph:
         gstep = GraphedTrainStep(fwd_bwd, opt, bucket, warmup=3, world=world, unroll=U)
         tick = [0]
+        n_calls = max(1, args.steps // U)
+        every = 16 if n_calls >= 64 else max(1, n_calls // 4)      # short runs: still a few device-time samples
 
         def step(timed):
             # the device-time events go around every 16th step only: at ~0.06 ms per step two event records per step are a
             # measurable part of what they measure (host time and two more device-side nodes between the graph launches)
             tick[0] += 1
-            sample = timed and tick[0] % 16 == 0
+            sample = timed and tick[0] % every == 0
             if sample:
                 a, b = ev.span()
                 a.record()
