@@ -783,13 +783,10 @@ __device__ __forceinline__ float quad_sum(float v) {
 
 // forward: Wl[ci * CSTR + tap * CO + co]; CSTR = 9 CO (+ 8 for CO = 16: the four lanes of a quad read four different ci at once,
 // and a stride of 144 floats would put two of them on the same LDS banks)
-// POOL: sixteen consecutive lanes are the four positions under one 2x2 pool window (position = 4-lane quad); after the quad sums
-// the four quads meet in two lane exchanges (xor 4, xor 8), keep the first maximum of LeakyReLU(conv + bias; alpha) and the quad of
-// position 0 stores pooled value and arg-max -- the conv output is not written (nnhipConv2dLeakyMaxPoolForward, second C5 layer).
-template <int CO, bool POOL = false>
+template <int CO>
 __global__ __launch_bounds__(256) void conv_direct_fwd_quad_kernel(const float* __restrict__ Wt, const float* __restrict__ X,
                                                                    const float* __restrict__ bias, float* __restrict__ O,
-                                                                   const ConvGeom g, int32_t* __restrict__ arg = nullptr, float alpha = 1.f) {
+                                                                   const ConvGeom g) {
     constexpr int CSTR = 9 * CO + (CO == 16 ? 8 : 0), CPL = CD_MAXC / 4;      // channels per lane
     __shared__ __attribute__((aligned(16))) float Wl[CD_MAXC * CSTR];
     const int K = g.Cin * 9;
@@ -801,23 +798,9 @@ __global__ __launch_bounds__(256) void conv_direct_fwd_quad_kernel(const float* 
     const int64_t HWo = (int64_t)g.Ho * g.Wo, N = (int64_t)g.B * HWo;
     const int64_t n = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 2;
     const int s = threadIdx.x & 3;
-    if (n >= N) return;                                   // whole quads leave together (POOL: whole windows, N = 4 * windows)
-    int b, p, ho, wo;
-    [[maybe_unused]] int pq = 0, HWq = 0;
-    if constexpr (POOL) {
-        const int Wq = g.Wo >> 1;
-        HWq = (g.Ho >> 1) * Wq;
-        const int64_t win = n >> 2;
-        const int pos = (int)(n & 3);
-        b = (int)(win / HWq);
-        pq = (int)(win - (int64_t)b * HWq);
-        const int hq = pq / Wq, wq = pq - hq * Wq;
-        ho = 2 * hq + (pos >> 1); wo = 2 * wq + (pos & 1);
-        p = ho * g.Wo + wo;
-    } else {
-        b = (int)(n / HWo); p = (int)(n - (int64_t)b * HWo);
-        ho = p / g.Wo; wo = p - ho * g.Wo;
-    }
+    if (n >= N) return;                                   // whole quads leave together
+    const int b = (int)(n / HWo), p = (int)(n - (int64_t)b * HWo);
+    const int ho = p / g.Wo, wo = p - ho * g.Wo;
     float acc[CO];
 #pragma unroll
     for (int c = 0; c < CO; ++c) acc[c] = 0.f;
@@ -864,26 +847,7 @@ __global__ __launch_bounds__(256) void conv_direct_fwd_quad_kernel(const float* 
         asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));      // (or the selects become acc[f(s)]: a scratch array)
         const float v = s == 0 ? a0 : s == 1 ? a1 : s == 2 ? a2 : a3;
         const int co = s * (CO / 4) + c;
-        if constexpr (!POOL) {
-            if (co < g.Cout) O[((int64_t)b * g.Cout + co) * HWo + p] = v + (bias ? bias[co] : 0.f);
-        } else {
-            float f = v + ((bias && co < g.Cout) ? bias[co] : 0.f);
-            if (alpha != 1.0f) f = f <= 0.f ? alpha * f : f;
-            int k = (int)(n & 3);                           // this quad's cell of the window: MaxPool2d scans cells 0..3, first maximum wins
-#pragma unroll
-            for (int m = 4; m <= 8; m <<= 1) {
-                const float fo = __shfl_xor(f, m, 64);
-                const int ko = __shfl_xor(k, m, 64);
-                const bool take = fo > f || (fo == f && ko < k);
-                f = take ? fo : f;
-                k = take ? ko : k;
-            }
-            if ((n & 3) == 0 && co < g.Cout) {
-                const int64_t o = ((int64_t)b * g.Cout + co) * HWq + pq;
-                O[o] = f;
-                arg[o] = k;
-            }
-        }
+        if (co < g.Cout) O[((int64_t)b * g.Cout + co) * HWo + p] = v + (bias ? bias[co] : 0.f);
     }
 }
 
@@ -966,6 +930,98 @@ __global__ __launch_bounds__(256) void conv_direct_dgrad_quad_kernel(const float
         const float o = s == 0 ? a0 : s == 1 ? a1 : s == 2 ? a2 : a3;
         const int ci = s * (CI / 4) + c;
         if (ci < g.Cin) dX[((int64_t)b * g.Cin + ci) * HW + p] = o;
+    }
+}
+
+// the same fused forward for layers with more input channels and too few windows for one thread each (C5's second layer: 12 544
+// windows): FOUR lanes per window, each a quarter of the input channels (ci = s, s + 4, ...) for all four positions -- a weight read
+// from LDS serves four positions (a position-per-quad variant read it per position: 72 ds_read_b128 per
+// position made it LDS-bandwidth-bound, 10 us against 8.9) -- then 4 x CO quad sums, and lane s finishes output channels
+// s CO/4 ...: bias, activation, first maximum over the four positions, pooled value + arg-max.  Unit stride and dilation.
+template <int CO>
+__global__ __launch_bounds__(256) void conv_pool_fwd_quad_kernel(const float* __restrict__ Wt, const float* __restrict__ X,
+                                                                 const float* __restrict__ bias, float* __restrict__ P,
+                                                                 int32_t* __restrict__ arg, const ConvGeom g, float alpha) {
+    constexpr int CSTR = 9 * CO + (CO == 16 ? 8 : 0), CPL = CD_MAXC / 4;
+    __shared__ __attribute__((aligned(16))) float Wl[CD_MAXC * CSTR];
+    const int K = g.Cin * 9;
+    stage_to_lds(Wl, Wt, g.Cin * CSTR, threadIdx.x, [&](int i) -> int64_t {
+        const int ci = i / CSTR, r = i - ci * CSTR, t = r / CO, co = r - t * CO;
+        return (t < 9 && co < g.Cout) ? (int64_t)co * K + ci * 9 + t : -1;
+    });
+    __syncthreads();
+    const int Hq = g.Ho >> 1, Wq = g.Wo >> 1, HWq = Hq * Wq;
+    const int64_t N = (int64_t)g.B * HWq;
+    const int64_t n = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 2;
+    const int s = threadIdx.x & 3;
+    if (n >= N) return;                                   // whole quads leave together
+    const int b = (int)(n / HWq), pq = (int)(n - (int64_t)b * HWq);
+    const int hq = pq / Wq, wq = pq - hq * Wq;
+    const int HWi = g.H * g.W;
+    const __amdgpu_buffer_rsrc_t rx = cd_rsrc(X, (unsigned)((int64_t)g.B * g.Cin * HWi) * 4u);
+    unsigned vo[16];
+#pragma unroll
+    for (int y = 0; y < 4; ++y)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const int hi = 2 * hq - g.pu + y, wi = 2 * wq - g.pl + x;
+            vo[y * 4 + x] = (hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) ? (unsigned)(b * g.Cin * HWi + hi * g.W + wi) * 4u : CD_OOB;
+        }
+    float acc[4][CO];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int c = 0; c < CO; ++c) acc[k][c] = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        if (4 * j >= g.Cin) break;                          // uniform
+        const bool live = 4 * j + s < g.Cin;
+        const int ci = min(4 * j + s, g.Cin - 1);           // (a lane past Cin multiplies zeros by staged weights)
+        const unsigned chan = (unsigned)(ci * HWi) * 4u;
+        float x[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+            x[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, (live && vo[t] != CD_OOB) ? vo[t] + chan : CD_OOB, 0, 0));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const float4* w4 = reinterpret_cast<const float4*>(&Wl[ci * CSTR + (r * 3 + q) * CO]);
+#pragma unroll
+                for (int c4 = 0; c4 < CO / 4; ++c4) {
+                    const float4 w = w4[c4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float xv = x[((k >> 1) + r) * 4 + (k & 1) + q];
+                        acc[k][4 * c4] += xv * w.x; acc[k][4 * c4 + 1] += xv * w.y; acc[k][4 * c4 + 2] += xv * w.z; acc[k][4 * c4 + 3] += xv * w.w;
+                    }
+                }
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int c = 0; c < CO; ++c) acc[k][c] = quad_sum(acc[k][c]);
+#pragma unroll
+    for (int c = 0; c < CO / 4; ++c) {                      // lane s finishes outputs s CO/4 ...
+        const int co = s * (CO / 4) + c;
+        const float bc = (bias && co < g.Cout) ? bias[co] : 0.f;
+        float best = -INFINITY;
+        int bi = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float a0 = acc[k][c], a1 = acc[k][CO / 4 + c], a2 = acc[k][2 * (CO / 4) + c], a3 = acc[k][3 * (CO / 4) + c];
+            asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));      // (or the selects become acc[f(s)]: a scratch array)
+            float v = (s == 0 ? a0 : s == 1 ? a1 : s == 2 ? a2 : a3) + bc;
+            if (alpha != 1.0f) v = v <= 0.f ? alpha * v : v;
+            if (v > best) { best = v; bi = k; }
+        }
+        if (co < g.Cout) {
+            const int64_t o = ((int64_t)b * g.Cout + co) * HWq + pq;
+            P[o] = best;
+            arg[o] = bi;
+        }
     }
 }
 
@@ -1302,8 +1358,8 @@ extern "C" int nnhipConv2dForward(const float* X, const float* W, const float* b
         // under two blocks per CU and a reduction worth splitting: four lanes per position (conv_direct_fwd_quad_kernel)
         if (conv_quad_on() && g.kh == 3 && g.kw == 3 && N <= 512 * 256 && g.Cin >= 4 && g.Cout > 4) {
             const dim3 qgrid((unsigned)ceil_div(4 * N, 256));
-            if (g.Cout <= 8) hipLaunchKernelGGL((conv_direct_fwd_quad_kernel<8, false>), qgrid, dim3(256), 0, (hipStream_t)s, W, X, bias, O, g, (int32_t*)nullptr, 1.f);
-            else hipLaunchKernelGGL((conv_direct_fwd_quad_kernel<16, false>), qgrid, dim3(256), 0, (hipStream_t)s, W, X, bias, O, g, (int32_t*)nullptr, 1.f);
+            if (g.Cout <= 8) hipLaunchKernelGGL(conv_direct_fwd_quad_kernel<8>, qgrid, dim3(256), 0, (hipStream_t)s, W, X, bias, O, g);
+            else hipLaunchKernelGGL(conv_direct_fwd_quad_kernel<16>, qgrid, dim3(256), 0, (hipStream_t)s, W, X, bias, O, g);
             NNHIP_LAUNCH_CHECK("conv_direct_fwd_quad_kernel");
             return 0;
         }
@@ -1378,9 +1434,10 @@ extern "C" int nnhipConv2dWeightGradPooled(const float* X, const float* dP, cons
 static bool conv_pool_window_ok(const ConvGeom& g) {
     return g.sh == 1 && g.sw == 1 && g.dh == 1 && g.dw == 1 && g.Cout > 4 && g.Cin <= 4 && (int64_t)g.B * (g.Ho / 2) * (g.Wo / 2) >= 128 * 256;
 }
-// sixteen lanes per window (conv_direct_fwd_quad_kernel<CO, POOL>): where the plain forward would take the quad kernel
+// four lanes per window (conv_pool_fwd_quad_kernel): where the plain forward would take the quad kernel
 static bool conv_pool_quad_ok(const ConvGeom& g) {
-    return conv_quad_on() && (int64_t)g.B * g.Ho * g.Wo <= 512 * 256 && g.Cin >= 4 && g.Cout > 4;
+    return conv_quad_on() && (int64_t)g.B * g.Ho * g.Wo <= 512 * 256 && g.Cin >= 4 && g.Cout > 4 && g.sh == 1 && g.sw == 1 && g.dh == 1 &&
+           g.dw == 1;
 }
 static bool conv_pool_fwd_ok(const ConvGeom& g, const nnhipPool2dDesc* pd) {
     static const bool on = []() { const char* e = getenv("NNHIP_CONV_POOL_FWD"); return !e || atoi(e) != 0; }();
@@ -1405,11 +1462,11 @@ extern "C" int nnhipConv2dLeakyMaxPoolForward(const float* X, const float* W, co
     NNHIP_CHECK_ARG(alpha > 0.f, NNHIP_EINVAL, "nnhipConv2dLeakyMaxPoolForward: alpha must be > 0 (1 = no activation)");
     NNHIP_CHECK_ARG(conv_pool_fwd_ok(g, pd), NNHIP_EINVAL,
                     "nnhipConv2dLeakyMaxPoolForward: unsupported geometry (ask nnhipConv2dLeakyMaxPoolForwardOk first)");
-    if (!conv_pool_window_ok(g)) {                           // the quad kernel, four quads per window
-        const dim3 qgrid((unsigned)ceil_div(4 * (int64_t)g.B * g.Ho * g.Wo, 256));
-        if (g.Cout <= 8) hipLaunchKernelGGL((conv_direct_fwd_quad_kernel<8, true>), qgrid, dim3(256), 0, (hipStream_t)s, W, X, bias, P, g, argmax, alpha);
-        else hipLaunchKernelGGL((conv_direct_fwd_quad_kernel<16, true>), qgrid, dim3(256), 0, (hipStream_t)s, W, X, bias, P, g, argmax, alpha);
-        NNHIP_LAUNCH_CHECK("conv_direct_fwd_quad_kernel");
+    if (!conv_pool_window_ok(g)) {                           // four lanes per window, each all four positions
+        const dim3 wgrid((unsigned)ceil_div(4 * (int64_t)g.B * (g.Ho / 2) * (g.Wo / 2), 256));
+        if (g.Cout <= 8) hipLaunchKernelGGL(conv_pool_fwd_quad_kernel<8>, wgrid, dim3(256), 0, (hipStream_t)s, W, X, bias, P, argmax, g, alpha);
+        else hipLaunchKernelGGL(conv_pool_fwd_quad_kernel<16>, wgrid, dim3(256), 0, (hipStream_t)s, W, X, bias, P, argmax, g, alpha);
+        NNHIP_LAUNCH_CHECK("conv_pool_fwd_quad_kernel");
         return 0;
     }
     const int64_t N = (int64_t)g.B * (g.Ho / 2) * (g.Wo / 2);
