@@ -933,6 +933,90 @@ __global__ __launch_bounds__(256) void conv_direct_dgrad_quad_kernel(const float
     }
 }
 
+// dgrad, unit stride and dilation, four lanes per 2x2 BLOCK of input positions (each lane a quarter of the output channels for all
+// four positions): the four positions' taps reach a 4x4 patch of dO per channel (16 loads where four separate positions take
+// 36) and a weight read from LDS serves four positions -- the position-per-quad kernel above re-reads its 72 ds_read_b128 per
+// position and is LDS-bandwidth-bound at C5's second layer.  Same products in the same order per output (co = s, s + 4, ...; taps
+// in order; quad tree).
+template <int CI>
+__global__ __launch_bounds__(256) void conv_direct_dgrad_quad2_kernel(const float* __restrict__ Wt, const float* __restrict__ dO,
+                                                                      float* __restrict__ dX, const ConvGeom g) {
+    constexpr int CPL = CD_MAXC / 4;
+    __shared__ __attribute__((aligned(16))) float Wl[CD_MAXC * 9 * CI];
+    stage_to_lds(Wl, Wt, g.Cout * 9 * CI, threadIdx.x, [&](int i) -> int64_t {
+        const int ci = i % CI, k = i / CI, co = k / 9, rs = k - co * 9;
+        return ci < g.Cin ? ((int64_t)co * g.Cin + ci) * 9 + rs : -1;
+    });
+    __syncthreads();
+    const int Hb = (g.H + 1) >> 1, Wb = (g.W + 1) >> 1, HWb = Hb * Wb;
+    const int64_t N = (int64_t)g.B * HWb, HW = (int64_t)g.H * g.W;
+    const int HWo = g.Ho * g.Wo;
+    const int64_t n = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 2;
+    const int s = threadIdx.x & 3;
+    if (n >= N) return;
+    const int b = (int)(n / HWb), pb = (int)(n - (int64_t)b * HWb);
+    const int h0 = 2 * (pb / Wb), w0 = 2 * (pb % Wb);
+    const __amdgpu_buffer_rsrc_t rg = cd_rsrc(dO, (unsigned)((int64_t)g.B * g.Cout * HWo) * 4u);
+    unsigned vo[16];                                        // patch rows h0 + pu - 2 + {0..3}, columns w0 + pl - 2 + {0..3} of dO
+#pragma unroll
+    for (int y = 0; y < 4; ++y)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const int th = h0 + g.pu - 2 + y, tw = w0 + g.pl - 2 + x;
+            vo[y * 4 + x] = (th >= 0 && th < g.Ho && tw >= 0 && tw < g.Wo) ? (unsigned)(b * g.Cout * HWo + th * g.Wo + tw) * 4u : CD_OOB;
+        }
+    float acc[4][CI];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int c = 0; c < CI; ++c) acc[k][c] = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+        if (4 * j >= g.Cout) break;                         // uniform
+        const bool live = 4 * j + s < g.Cout;
+        const int co = min(4 * j + s, g.Cout - 1);          // (a lane past Cout multiplies zeros by staged weights)
+        const unsigned chan = (unsigned)(co * HWo) * 4u;
+        float v[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+            v[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, (live && vo[t] != CD_OOB) ? vo[t] + chan : CD_OOB, 0, 0));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const float4* w4 = reinterpret_cast<const float4*>(&Wl[(co * 9 + r * 3 + q) * CI]);
+#pragma unroll
+                for (int c4 = 0; c4 < CI / 4; ++c4) {
+                    const float4 ww = w4[c4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {             // position (k >> 1, k & 1) of the block: dO row (k >> 1) + 2 - r of the patch
+                        const float xv = v[((k >> 1) + 2 - r) * 4 + (k & 1) + 2 - q];
+                        acc[k][4 * c4] += xv * ww.x; acc[k][4 * c4 + 1] += xv * ww.y; acc[k][4 * c4 + 2] += xv * ww.z; acc[k][4 * c4 + 3] += xv * ww.w;
+                    }
+                }
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int c = 0; c < CI; ++c) acc[k][c] = quad_sum(acc[k][c]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int h = h0 + (k >> 1), w = w0 + (k & 1);
+        if (h < g.H && w < g.W) {
+#pragma unroll
+            for (int c = 0; c < CI / 4; ++c) {
+                float a0 = acc[k][c], a1 = acc[k][CI / 4 + c], a2 = acc[k][2 * (CI / 4) + c], a3 = acc[k][3 * (CI / 4) + c];
+                asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));      // (or the selects become acc[f(s)]: a scratch array)
+                const float o = s == 0 ? a0 : s == 1 ? a1 : s == 2 ? a2 : a3;
+                const int ci = s * (CI / 4) + c;
+                if (ci < g.Cin) dX[((int64_t)b * g.Cin + ci) * HW + (int64_t)h * g.W + w] = o;
+            }
+        }
+    }
+}
+
 // the same fused forward for layers with more input channels and too few windows for one thread each (C5's second layer: 12 544
 // windows): FOUR lanes per window, each a quarter of the input channels (ci = s, s + 4, ...) for all four positions -- a weight read
 // from LDS serves four positions (a position-per-quad variant read it per position: 72 ds_read_b128 per
@@ -1489,10 +1573,18 @@ extern "C" int nnhipConv2dBackward(const float* X, const float* W, const float* 
         const dim3 dgrid((unsigned)ceil_div((int64_t)g.B * g.H * g.W, 256));
         const int64_t Nd = (int64_t)g.B * g.H * g.W;
         if (conv_quad_on() && g.kh == 3 && g.kw == 3 && Nd <= 512 * 256 && g.Cout >= 4 && g.Cin > 2 && g.Cin <= 8) {
+            static const bool quad2 = []() { const char* e = getenv("NNHIP_CONV_DGRAD_QUAD2"); return !e || atoi(e) != 0; }();
+            if (quad2 && g.sh == 1 && g.sw == 1 && g.dh == 1 && g.dw == 1) {      // 2x2 positions per quad of lanes
+                const dim3 bgrid((unsigned)ceil_div(4 * (int64_t)g.B * ((g.H + 1) / 2) * ((g.W + 1) / 2), 256));
+                if (g.Cin <= 4) hipLaunchKernelGGL(conv_direct_dgrad_quad2_kernel<4>, bgrid, dim3(256), 0, st, W, dO, dX, g);
+                else hipLaunchKernelGGL(conv_direct_dgrad_quad2_kernel<8>, bgrid, dim3(256), 0, st, W, dO, dX, g);
+                NNHIP_LAUNCH_CHECK("conv_direct_dgrad_quad2_kernel");
+            } else {
             const dim3 qgrid((unsigned)ceil_div(4 * Nd, 256));
             if (g.Cin <= 4) hipLaunchKernelGGL(conv_direct_dgrad_quad_kernel<4>, qgrid, dim3(256), 0, st, W, dO, dX, g);
             else hipLaunchKernelGGL(conv_direct_dgrad_quad_kernel<8>, qgrid, dim3(256), 0, st, W, dO, dX, g);
             NNHIP_LAUNCH_CHECK("conv_direct_dgrad_quad_kernel");
+            }
         } else
         if (g.Cin <= 4) hipLaunchKernelGGL(conv_direct_dgrad_kernel<4>, dgrid, dim3(256), 0, st, W, dO, dX, g);
         else if (g.Cin <= 8) hipLaunchKernelGGL(conv_direct_dgrad_kernel<8>, dgrid, dim3(256), 0, st, W, dO, dX, g);
