@@ -2209,6 +2209,72 @@ def test_graphed_step_unrolled(hip):
             np.testing.assert_array_equal(a, b)
 
 
+def test_graphed_conv_classifier_equals_eager(hip):
+    """The conv classifier's step with every round-3 shortcut on (deferred conv launches, conv + LeakyReLU + MaxPool forward as one
+    kernel per layer, first-layer weight gradient off the pool's gradient, the layers' reduces queued and launched as one grid out
+    of their own arena) captured into hipGraphs -- one step per graph and four -- leaves exactly the parameters of the eager
+    loop: nothing the capture bakes in (arena and workspace addresses, queue state) differs between replays."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import conv_classifier
+    import neunet_hip.nn as nn
+    from neunet_hip.distributed import GradBucket
+    from neunet_hip.graph import GraphedTrainStep
+    from neunet_hip.optim import Adam
+    U, R, B = 4, 2, 176                                   # 176 x 14 x 14 windows: enough for the first layer's one-thread-per-window kernel
+    rng = np.random.default_rng(12)
+    data = [(rng.uniform(-1, 1, (B, 1, 28, 28)).astype(np.float32), np.eye(10, dtype=np.float32)[rng.integers(0, 10, B)])
+            for _ in range(2 + U * R)]
+
+    def make(unroll):
+        np.random.seed(43)
+        model = conv_classifier.Conv2dClassifier()
+        xs = [hip.Tensor(data[0][0], device="cuda", requires_grad=False) for _ in range(unroll)]
+        ts = [hip.Tensor(data[0][1], device="cuda", requires_grad=False) for _ in range(unroll)]
+        loss_fn = nn.MSELoss()
+
+        def fb(k=0):
+            loss = loss_fn(model(xs[k]), ts[k])
+            loss.backward()
+            return loss
+
+        opt = Adam(model.parameters(), lr=1e-3)
+        return model, xs, ts, fb, opt, GradBucket(model.parameters())
+
+    def feed(xs, ts, k, item):
+        xs[k].data.copy_(dev(item[0]))
+        ts[k].data.copy_(dev(item[1]))
+
+    m0, xs0, ts0, fb0, opt0, _ = make(1)
+    for item in data:
+        feed(xs0, ts0, 0, item)
+        opt0.zero_grad()
+        fb0()
+        opt0.step()
+    want = [host(p.data) for p in m0.parameters()]
+    for unroll in (1, U):
+        m, xs, ts, fb, opt, bk = make(unroll)
+        warm = iter(data[:2])
+
+        def fb_warm(k=0, fb=fb, xs=xs, ts=ts, warm=warm):
+            item = next(warm, None)
+            if item is not None:
+                feed(xs, ts, 0, item)
+            return fb(k)
+
+        g = GraphedTrainStep(fb_warm, opt, bk, warmup=2, unroll=unroll)
+        rest = data[2:]
+        for r in range(len(rest) // unroll):
+            for k in range(unroll):
+                feed(xs, ts, k, rest[r * unroll + k])
+            g()
+        got = [host(p.data) for p in m.parameters()]
+        g.release()
+        for a, b in zip(got, want):
+            np.testing.assert_array_equal(a, b)
+
+
 def test_graphed_step_equals_eager(hip):
     """A hipGraph-replayed GPT step (neunet_hip.graph.GraphedTrainStep, device-side Adam step counter) produces
     the same parameters as the eager step, step after step, with fresh data copied into the static buffers."""
