@@ -57,6 +57,18 @@ def parse():
     ap.add_argument("--dp-op", default="sum", choices=["sum", "avg"],
                     help="reduction of the gradient all-reduce (avg: RCCL pre-scales by 1/world; on a forced 1-rank group it is "
                          "what makes RCCL launch a device kernel -- a 1-rank in-place SUM is elided by the library)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: 64 sequences (C4) per GPU; strong: the global batch of 64 sequences divided over the ranks "
+                         "(SURVEY 8e asks for both curves; an N > 1 headline run reports the other one under also.c4_strong)")
+    ap.add_argument("--comm", default=os.environ.get("NNHIP_COMM", "torch"), choices=["torch", "native"],
+                    help="gradient exchange backend of the C4 step: torch.distributed (nccl = RCCL) or the library's own RCCL "
+                         "entry points (nnhipCommInitRank / nnhipAllReduceSumF32 behind neunet_hip.distributed.NativeComm)")
+    ap.add_argument("--c1-input-copy", type=int, default=0,
+                    help="c1: 1 = every step first copies its batch (100 KB pinned host -> the static device slot), as the "
+                         "reference's benches do (benchmark_linear_swish_cuda.py:31)")
+    ap.add_argument("--c1-fuse-opt", type=int, default=int(os.environ.get("NNHIP_C1_FUSE_OPT", "1")),
+                    help="c1: 1 = optimizer.fuse_backward(True), Adam inside the backward launch (opt-in semantics: no gradient "
+                         "clipping / accumulation between backward and step); 0 = the separate optimizer launch a README user gets")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--cpu-full-batch", action="store_true",
@@ -293,7 +305,8 @@ def workload_c1(args, rank, world):
     bucket = GradBucket(params)
     opt = Adam(params, lr=1e-3)
     opt.grad_scale = 1.0 / world
-    if world == 1 and os.environ.get("NNHIP_C1_FUSE_OPT", "1") != "0":
+    fused_opt = world == 1 and bool(getattr(args, "c1_fuse_opt", 1))
+    if fused_opt:
         opt.fuse_backward(True)     # one process: the backward launch applies Adam itself (bit-identical to the separate launch)
     loss_fn = nn.CrossEntropyLoss()
     drng = np.random.default_rng(3000 + rank)
@@ -303,6 +316,22 @@ def workload_c1(args, rank, world):
           for _ in range(U)]
     ev = EventTimer()
     from neunet_hip.graph import GraphedTrainStep
+    # --c1-input-copy 1: the batch of every step crosses PCIe inside the timed region (pinned host -> static device slot,
+    # asynchronous on the launch stream), as in the reference's benches (scripts/benchmark_linear_swish_cuda.py:31 copies its
+    # input every iteration); 0: the batches are resident (the bench contract's "inputs already in HBM")
+    feed = bool(getattr(args, "c1_input_copy", 0))
+    launches = None
+    if feed:
+        hX = [torch.from_numpy(drng.uniform(-1, 1, (Bsz, 784)).astype(np.float32)).pin_memory() for _ in range(U)]
+        hY = [torch.from_numpy(drng.integers(0, 10, Bsz).astype(np.int32)).pin_memory() for _ in range(U)]
+
+        def copy_in():
+            for k in range(U):
+                Xs[k].data.copy_(hX[k], non_blocking=True)
+                Ys[k].data.copy_(hY[k], non_blocking=True)
+    else:
+        def copy_in():
+            pass
 
     def fwd_bwd(k=0):
         loss = loss_fn(model(Xs[k]), Ys[k])
@@ -310,7 +339,9 @@ def workload_c1(args, rank, world):
         return loss
 
     if args.graph:
-        gstep = GraphedTrainStep(fwd_bwd, opt, bucket, warmup=3, world=world, unroll=U)
+        gstep = GraphedTrainStep(fwd_bwd, opt, bucket, warmup=3, world=world, unroll=U, count_nodes=True)
+        if gstep.kernel_nodes:
+            launches = round(gstep.kernel_nodes / U, 2)
         tick = [0]
         n_calls = max(1, args.steps // U)
         every = 16 if n_calls >= 64 else max(1, n_calls // 4)      # short runs: still a few device-time samples
@@ -323,6 +354,7 @@ def workload_c1(args, rank, world):
             if sample:
                 a, b = ev.span()
                 a.record()
+            copy_in()
             gstep()
             if sample:
                 b.record()
@@ -331,6 +363,7 @@ def workload_c1(args, rank, world):
             if timed:
                 a, b = ev.span()
                 a.record()
+            copy_in()
             opt.zero_grad()
             fwd_bwd()
             bucket.all_reduce()
@@ -347,12 +380,16 @@ def workload_c1(args, rank, world):
         "samples_per_step": Bsz * world, "dt": dt,
         "config": {"workload": "C1: MNIST-MLP 784->128->10 training step (Linear+ReLU+CrossEntropy+Adam), batch 32 per GPU",
                    "global_batch": Bsz * world, "parallelism": f"dp{world}",
+                   "optimizer_launch": "inside the backward launch (optimizer.fuse_backward(True), opt-in)" if fused_opt
+                                       else "separate fused-Adam launch (the default a README user gets)",
+                   "input": "pinned host batch copied into the device slot every step (inside the timed region)" if feed
+                            else "batches resident in HBM",
                    "launch": (f"hipGraph replay, {U} steps per graph" if U > 1 else "hipGraph replay") if args.graph else "eager"},
         "roofline": {"kernel": "whole step (3 launches: Linear+ReLU, Linear+CrossEntropy, backward+Adam; dependent-latency bound)", "bound": "mfma",
                      "achieved": round(flops / (dev_ms * 1e-3) / 1e12, 5), "peak": PEAK_F32_MFMA_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(flops / (dev_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 6),
                      "traffic": None, "avg_step_device_ms": round(dev_ms, 4)},
-        "extra": {},
+        "extra": {"launches_per_step": launches},
     }
 
 
@@ -411,6 +448,16 @@ def workload_c3(args, rank, world):
     Wl = torch.from_numpy((rng.uniform(-1, 1, (D, D)) / 64).astype(np.float32)).cuda()
     bl = torch.from_numpy((rng.uniform(-1, 1, (1, D)) / 64).astype(np.float32)).cuda()
     z, ls_out, dXl, dWl, dbl = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x), torch.empty_like(Wl), torch.empty_like(bl)
+    # the many-tensor optimizer case of scripts/profile_adam.py:11-14: 200 parameters of (512, 1024), one launch
+    NT, TS = 200, (512, 1024)
+    g_many = torch.Generator(device="cuda").manual_seed(1003 + rank)
+    many = []
+    for _ in range(NT):
+        q = Parameter(neunet_hip.Tensor(np.zeros(TS, np.float32), device="cuda"))
+        q.data.normal_(generator=g_many)
+        q.grad = torch.randn(TS, device="cuda", generator=g_many)
+        many.append(q)
+    opt_many = HIPFusedMultiTensorAdamW(many, lr=1e-3, weight_decay=1e-2)
     # Order matters for cold-cache timing: a kernel that follows AdamW also pays for the write-back of AdamW's
     # 402 MB of dirty lines (+12 us measured on ANY streaming kernel placed there, tools/order_check.py), so
     # AdamW goes last, the two MFMA-bound Linear->Swish ops first, and the fused CE follows a GEMM -- as it does in a
@@ -425,13 +472,14 @@ def workload_c3(args, rank, world):
         ("rmsnorm_bwd", lambda: rmsnorm_backward(x, w, None, dY, dx, dw, None, None, std)),
         ("softmax_fwd", lambda: hip_softmax_forward(x, y, -1)),
         ("softmax_bwd", lambda: hip_softmax_backward(dx, dY, y, -1)),
+        ("adamw_200x512x1024", lambda: opt_many.step()),
         ("adamw", lambda: opt.step()),
     ]
     timers = {k: EventTimer() for k, _ in ops}
     n = R * D
     bytes_per = {"swish_fwd": 8 * n, "swish_bwd": 12 * n, "rmsnorm_fwd": 8 * n + 4 * R + 4 * D,
                  "rmsnorm_bwd": 12 * n + 4 * R + 8 * D, "softmax_fwd": 8 * n, "softmax_bwd": 12 * n,
-                 "ce_fwd_bwd": 8 * n + 12 * R, "adamw": 28 * n}
+                 "ce_fwd_bwd": 8 * n + 12 * R, "adamw": 28 * n, "adamw_200x512x1024": 28 * NT * TS[0] * TS[1]}
     flops_per = {"linear_swish_fwd": 2.0 * R * D * D, "linear_swish_bwd": 4.0 * R * D * D}
 
     def step(timed):
@@ -526,8 +574,16 @@ def workload_c4(args, rank, world):
     from neunet_hip.graph import GraphedTrainStep
     from neunet_hip.optim import Adam
     from neunet_hip.distributed import collectives_live
-    B, T = args.c4_batch, C4["seq"]
+    strong = getattr(args, "scaling", "weak") == "strong"
+    if strong and args.c4_batch % world:
+        raise ValueError(f"--scaling strong: the global batch ({args.c4_batch}) must divide over {world} ranks")
+    B, T = (args.c4_batch // world if strong else args.c4_batch), C4["seq"]
     dp = world > 1 or collectives_live()                          # a gradient exchange is part of the step
+    comm = None
+    if dp and getattr(args, "comm", "torch") == "native":
+        # the exchange through the library's own RCCL entry points (include/neunet_hip.h, ABI 208) instead of ProcessGroupNCCL
+        from neunet_hip.distributed import NativeComm
+        comm = NativeComm.from_env()
     np.random.seed(1004)                                          # identical init on every rank
     model = gpt_tiny.build_gpt(C4["vocab"], C4["d_model"], C4["n_heads"], C4["d_ff"], C4["n_layers"], pad_idx=0,
                                max_len=1024, fused=True)
@@ -561,7 +617,7 @@ def workload_c4(args, rank, world):
     def make(overlap, use_graph, ingraph=False):
         """Bucket + step function for one exchange / launch mode, exercised once."""
         opt.zero_grad()
-        bucket = GradBucket(active, extra_scalars=1, overlap=overlap, reduce_op=args.dp_op)
+        bucket = GradBucket(active, extra_scalars=1, overlap=overlap, reduce_op=args.dp_op, comm=comm)
         state["bucket"] = bucket
         if dp:
             opt.grad_divisor = bucket.extra              # g / (all-reduced non-PAD count), inside the Adam kernel
@@ -629,11 +685,18 @@ def workload_c4(args, rank, world):
     pieces = len(getattr(gstep, "pieces", [])) if use_graph else 0
     if use_graph:
         gstep.release()
+    comm_lib = None
+    if comm is not None:
+        from neunet_hip.distributed import NativeComm
+        comm_lib = "%s (version %d)" % NativeComm.library()
+        comm.destroy()
     return {
-        "samples_per_step": B * world, "dt": dt,
+        "samples_per_step": B * world, "dt": dt, "scaling": "strong" if strong else "weak",
         "config": {"workload": f"C4: GPT-tiny d512 L6 H8 d_ff2048 vocab15000 training step, batch {B} x seq {T} per GPU, "
                                "Adam(1.5e-4), dropout 0", "global_batch": B * world, "seq_len": T,
-                   "parallelism": f"dp{world}", "launch": "hipGraph replay" if use_graph else "eager"},
+                   "parallelism": f"dp{world}", "launch": "hipGraph replay" if use_graph else "eager",
+                   "scaling": ("strong: global batch %d divided over the ranks" % (B * world)) if strong
+                              else "weak: %d sequences per GPU" % B},
         "roofline": {"kernel": "whole step, GEMM flops only (fp32 MFMA gemm_f32_kernel family: Linear fwd/dX/dW + attention)",
                      "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "flops_per_step": fl,
@@ -644,7 +707,8 @@ def workload_c4(args, rank, world):
                                    + (f" ({pieces} graph pieces)" if use_graph else "") if overlap
                                    else "one blocking all-reduce of the flat bucket")),
                   "dp_mode": ({"forced_one_rank": world == 1, "overlap": bool(overlap), "launch": graph_mode or "eager",
-                               "ingraph_error": ingraph_error, "modes_that_failed": tried, "reduce_op": args.dp_op} if dp else None)},
+                               "ingraph_error": ingraph_error, "modes_that_failed": tried, "reduce_op": args.dp_op,
+                               "comm": ("nnhipAllReduce*F32 over " + comm_lib) if comm_lib else "torch.distributed"} if dp else None)},
     }
 
 
@@ -877,6 +941,7 @@ def workload_c5(args, rank, world):
           for _ in range(U)]
     loss_fn = nn.MSELoss()
     ev = EventTimer()
+    launches = None
 
     def fwd_bwd(k=0):
         loss = loss_fn(model(Xs[k]), Ts[k])
@@ -884,7 +949,9 @@ def workload_c5(args, rank, world):
         return loss
 
     if args.graph:
-        gstep = GraphedTrainStep(fwd_bwd, opt, bucket, warmup=3, world=world, unroll=U)
+        gstep = GraphedTrainStep(fwd_bwd, opt, bucket, warmup=3, world=world, unroll=U, count_nodes=True)
+        if gstep.kernel_nodes:
+            launches = round(gstep.kernel_nodes / U, 2)
         tick = [0]
         n_calls = max(1, args.steps // U)
         every = 16 if n_calls >= 64 else max(1, n_calls // 4)      # short runs: still a few device-time samples
@@ -916,6 +983,7 @@ def workload_c5(args, rank, world):
     if args.graph:
         gstep.release()
     dev_ms = ev.mean_ms() / U
+    conv_layers = c5_conv_layers(Bsz) if (rank == 0 or world == 1) else None
     # algorithmic HBM bytes of the two conv layers fwd + bwd: 4*(|X|+|O|+|W|) forward, x2 backward
     conv_bytes = 3 * 4.0 * ((Bsz * 784 + Bsz * 8 * 784 + 72) + (Bsz * 8 * 196 + Bsz * 16 * 196 + 1152))
     return {
@@ -930,8 +998,54 @@ def workload_c5(args, rank, world):
                      "bound": "hbm", "achieved": round(conv_bytes / (dev_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
                      "unit": "GB/s", "frac": round(conv_bytes / (dev_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 5), "traffic": None,
                      "avg_step_device_ms": round(dev_ms, 4)},
-        "extra": {},
+        "extra": {"launches_per_step": launches, "conv_layers": conv_layers},
     }
+
+
+def c5_conv_layers(Bsz, iters=30):
+    """The two conv layers of C5 on their own through the plain C-ABI entries (nnhipConv2dForward / nnhipConv2dBackward with dX,
+    dW, db), median of HIP-event timed launches: algorithmic bytes 4(|X|+|O|+|W|) forward, 4(|dO|+|X|+|W|+|dX|+|dW|) backward
+    against the 8 TB/s HBM peak (K <= 72, Cout <= 16 can never be MFMA bound).  The training step itself runs fused
+    variants of these (conv + LeakyReLU + MaxPool forward, weight gradient off the pool's gradient)."""
+    import ctypes
+    import torch
+    from neunet_hip._lib import Conv2dDesc, call_hip_function as call, get_current_stream_ptr
+    st = get_current_stream_ptr()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    out = []
+    for name, (Cin, H, Cout) in (("conv1 1->8 28x28", (1, 28, 8)), ("conv2 8->16 14x14", (8, 14, 16))):
+        d = Conv2dDesc(Bsz, Cin, H, H, Cout, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1)
+        X = torch.rand(Bsz, Cin, H, H, device="cuda", generator=g) * 2 - 1
+        W = (torch.rand(Cout, Cin, 3, 3, device="cuda", generator=g) * 2 - 1) / 3
+        b = torch.zeros(Cout, device="cuda")
+        O_ = torch.empty(Bsz, Cout, H, H, device="cuda")
+        dO = torch.rand(Bsz, Cout, H, H, device="cuda", generator=g) * 2 - 1
+        dX, dW, db = torch.empty_like(X), torch.empty_like(W), torch.empty_like(b)
+
+        def med(fn):
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+            ev = []
+            for _ in range(iters):
+                a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                fn()
+                e.record()
+                ev.append((a, e))
+            torch.cuda.synchronize()
+            return float(np.median([a.elapsed_time(e) for a, e in ev]))
+
+        tf = med(lambda: call("nnhipConv2dForward", X, W, b, O_, ctypes.byref(d), st))
+        tb = med(lambda: call("nnhipConv2dBackward", X, W, dO, dX, dW, db, ctypes.byref(d), st))
+        bf = 4.0 * (X.numel() + O_.numel() + W.numel())
+        bb = 4.0 * (dO.numel() + X.numel() + W.numel() + dX.numel() + dW.numel())
+        fl = 2.0 * Bsz * H * H * Cout * Cin * 9
+        out.append({"layer": name, "fwd_ms": round(tf, 4), "bwd_ms": round(tb, 4),
+                    "fwd_frac_of_hbm_peak": round(bf / (tf * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                    "bwd_frac_of_hbm_peak": round(bb / (tb * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                    "fwd_gflops": round(fl / (tf * 1e-3) / 1e9, 1), "bwd_gflops": round(2 * fl / (tb * 1e-3) / 1e9, 1)})
+    return out
 
 
 def cpu_c5(seconds):
@@ -943,16 +1057,26 @@ def cpu_c5(seconds):
     model = O.ConvClassifier(params)
     X = rng.uniform(-1, 1, (256, 1, 28, 28)).astype(np.float32)
     Tt = np.eye(10, dtype=np.float32)[rng.integers(0, 10, 256)]
-    model.forward_backward(X, Tt)
+    ms, vs = [np.zeros_like(q) for q in model.p], [np.zeros_like(q) for q in model.p]
+    t = [0]
+
+    def step():
+        # forward + backward + Adam(1e-3) on all eight parameter tensors (neunet/optim.py:17-33): the whole training step
+        _, _, grads = model.forward_backward(X, Tt)
+        t[0] += 1
+        for i, g in enumerate(grads):
+            ms[i], vs[i] = O.adam_step(model.p[i], np.asarray(g, np.float32).reshape(model.p[i].shape), ms[i], vs[i], t[0], 1e-3)
+
+    step()
     times, t0 = [], time.perf_counter()
     while time.perf_counter() - t0 < min(seconds, 10.0) and len(times) < 20:
         t1 = time.perf_counter()
-        model.forward_backward(X, Tt)
+        step()
         times.append(time.perf_counter() - t1)
     best = min(times)
     return {"value": round(256 / best, 1), "unit": "samples/s", "cores": blas_threads(), "kind": "port",
-            "sample": f"{len(times)} forward+backward passes of the NumPy-oracle conv classifier at batch 256 "
-                      f"(optimizer excluded), min {best * 1e3:.1f} ms"}
+            "sample": f"{len(times)} FULL training steps (forward + backward + Adam on all 8 parameter tensors) of the "
+                      f"NumPy-oracle conv classifier at batch 256, min {best * 1e3:.1f} ms"}
 
 
 def blas_threads():
@@ -1124,8 +1248,69 @@ def workload_headline(args, rank, world):
         r1 = workload_c1(a1, rank, world)
         also["c1"] = {"workload": r1["config"]["workload"], "samples_per_s": round(r1["samples_per_step"] * a1.steps / r1["dt"], 1),
                       "ms_per_step": round(r1["dt"] / a1.steps * 1e3, 5), "steps": a1.steps,
-                      "device_ms_per_step": r1["roofline"].get("avg_step_device_ms"), "launch": r1["config"].get("launch")}
+                      "device_ms_per_step": r1["roofline"].get("avg_step_device_ms"), "launch": r1["config"].get("launch"),
+                      "launches_per_step": r1["extra"].get("launches_per_step")}
     guarded("c1", run_c1)
+
+    def run_c1_variants():
+        # (a) with the per-step input copy the reference's benches include; (b) with the separate
+        # optimizer launch a README user gets without opting into optimizer.fuse_backward (advisor, round 3)
+        for key, kw in (("with_input_copy", {"c1_input_copy": 1}), ("separate_optimizer_launch", {"c1_fuse_opt": 0})):
+            av = copy.copy(a1)
+            for k, v in kw.items():
+                setattr(av, k, v)
+            rv = workload_c1(av, rank, world)
+            also["c1"][key] = {"samples_per_s": round(rv["samples_per_step"] * av.steps / rv["dt"], 1),
+                               "ms_per_step": round(rv["dt"] / av.steps * 1e3, 5),
+                               "device_ms_per_step": rv["roofline"].get("avg_step_device_ms"),
+                               "launches_per_step": rv["extra"].get("launches_per_step"),
+                               "input": rv["config"]["input"], "optimizer_launch": rv["config"]["optimizer_launch"]}
+        also["c1"]["input"], also["c1"]["optimizer_launch"] = "batches resident in HBM", (
+            "inside the backward launch (optimizer.fuse_backward(True), opt-in)" if world == 1 and a1.c1_fuse_opt else "separate launch")
+    if "error" not in also.get("c1", {"error": 1}):
+        guarded("c1_variants", run_c1_variants)
+
+    def run_c3():
+        # BASELINE config 3 / north_star's HBM target (">= 60 % HBM-BW roofline on fused Swish/RMSNorm"): every op of the fused
+        # micro-bench at rows 8192 x d 4096, HIP-event timed per launch inside one pass over all of them (cold caches: each
+        # op streams 270-940 MB between two launches of itself)
+        a3 = copy.copy(args)
+        a3.steps, a3.warmup = 20, 5
+        r3 = workload_c3(a3, rank, world)
+        also["c3"] = {"workload": r3["config"]["workload"], "ms_per_pass": round(r3["dt"] / a3.steps * 1e3, 4),
+                      "ops": r3["extra"]["ops"], "hbm_peak_GBps": PEAK_HBM_GBS, "mfma_peak_tflops": PEAK_F32_MFMA_TFLOPS,
+                      "methodology": "scripts/benchmark_swish_cuda.py:65-69 shape: pre-allocated buffers, functional C-ABI calls, "
+                                     "warm-up then timed iterations; bytes = algorithmic (SURVEY 8d), time = HIP events on the launch stream"}
+    if os.environ.get("NNHIP_BENCH_C3", "1") != "0":
+        guarded("c3", run_c3)
+
+    def run_c5():
+        a5 = copy.copy(args)
+        a5.steps, a5.warmup = 480, 32
+        r5 = workload_c5(a5, rank, world)
+        also["c5"] = {"workload": r5["config"]["workload"], "samples_per_s": round(r5["samples_per_step"] * a5.steps / r5["dt"], 1),
+                      "ms_per_step": round(r5["dt"] / a5.steps * 1e3, 5), "steps": a5.steps,
+                      "device_ms_per_step": r5["roofline"].get("avg_step_device_ms"), "launch": r5["config"].get("launch"),
+                      "launches_per_step": r5["extra"].get("launches_per_step"),
+                      "conv_layers": r5["extra"].get("conv_layers"),
+                      "frac_of_hbm_peak_on_conv_bytes": r5["roofline"]["frac"]}
+    if os.environ.get("NNHIP_BENCH_C5", "1") != "0":
+        guarded("c5", run_c5)
+
+    def run_strong():
+        # SURVEY 8e wants both curves: the line's `value` is the weak-scaling step (64 sequences per GPU); this is the
+        # strong-scaling one (the global batch of 64 divided over the ranks) -- or the reverse under --scaling strong
+        a_s = copy.copy(args)
+        a_s.scaling = "weak" if args.scaling == "strong" else "strong"
+        a_s.steps, a_s.warmup = args.steps, max(2, args.warmup // 2)
+        rs = workload_c4(a_s, rank, world)
+        also["c4_" + a_s.scaling] = {"workload": rs["config"]["workload"], "scaling": rs["config"]["scaling"],
+                                     "global_batch": rs["config"]["global_batch"],
+                                     "samples_per_s": round(rs["samples_per_step"] * a_s.steps / rs["dt"], 2),
+                                     "ms_per_step": round(rs["dt"] / a_s.steps * 1e3, 4),
+                                     "dp_exchange": rs["extra"]["dp_exchange"]}
+    if world > 1 and args.c4_batch % world == 0:
+        guarded("c4_other_scaling", run_strong)
     # C2: the whole Linear training step
     a2 = copy.copy(args)
     a2.steps, a2.warmup = 20, 5
@@ -1261,7 +1446,7 @@ def main():
     out = {
         "metric": "samples/sec training step", "value": round(value, 2), "unit": "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": res.get("scaling", "weak"),
         "vs_baseline": None, "dtype": "f32", "data": "synthetic", "config": res["config"],
         "roofline": res["roofline"], "rccl_ranks": rccl_ranks,
     }

@@ -268,6 +268,11 @@ int nnhipAttentionPackMask(const int32_t* mask, uint64_t* mask_bits, uint64_t* m
 /* out [B,H,Tq,Tk] = the hash dropout multipliers the fused kernels use for (dropout_p, seed). */
 int nnhipAttentionDropoutMask(float* out, int64_t B, int64_t H, int64_t Tq, int64_t Tk, float dropout_p, uint32_t seed,
                               nnhipStream_t stream);
+/* The same with an optional device word added to the seed (the fused kernels' dropout_seed_dev: a per-step counter that lets a
+ * captured hipGraph draw a fresh mask on every replay) -- what the UNFUSED attention path (need_weights = True) multiplies its
+ * attention map by, so that both paths draw from the library's one counter hash.  ABI 208 */
+int nnhipAttentionDropoutMaskEx(float* out, int64_t B, int64_t H, int64_t Tq, int64_t Tk, float dropout_p, uint32_t seed,
+                                const uint32_t* seed_dev, nnhipStream_t stream);
 
 /* ---- a9 fused CrossEntropy forward+backward  (replaces cudaCrossEntropyForwardBackward,
  *      cross_entropy.cu:249-260).
@@ -409,6 +414,12 @@ int nnhipEmbeddingBackward(float* dW, const float* grad_out, const int32_t* ids,
 /* out[i] = (ids[i] != value) as int32: the key-padding mask of examples/gpt.ipynb cell 7 (get_pad_mask:
  * (x != pad_idx).astype(int)) without leaving the library (torch would run a compare and a cast kernel).  ABI 203 */
 int nnhipNotEqualInt32(int32_t* out, const int32_t* ids, int64_t n, int32_t value, nnhipStream_t stream);
+/* neunet.argmax (neunet/__init__.py:132-139 = np.argmax cast to int32): out[o, j] = index of the FIRST maximum of
+ * x[o, :, j] over the middle axis of the C-contiguous view [outer, n, inner] (axis = -1: inner = 1; axis = None: outer = inner
+ * = 1, n = numel); a NaN counts as the maximum, the first NaN wins (NumPy's rule).  out int32 [outer, inner].  Bit-exact: a
+ * comparison network on (value, index) pairs, no arithmetic.  n == 0 with outer * inner > 0 is NNHIP_EINVAL (NumPy raises
+ * ValueError).  ABI 208 */
+int nnhipArgmaxF32(int32_t* out, const float* x, int64_t outer, int64_t n, int64_t inner, nnhipStream_t stream);
 /* Dropout (neunet/nn/layers/dropout.py:17-37): out[i] = in[i] * m(i), m(i) = 1/(1-p) with probability 1-p, else 0, from a
  * counter-based hash of (seed + *seed_dev, i) -- never stored: the backward pass calls the same entry with the upstream
  * gradient as `in` (same seed) and gets dX = dY * m.  seed_dev (optional device uint32, e.g. a step counter) makes a
@@ -493,6 +504,36 @@ int nnhipScale(float* x, float alpha, int64_t n, nnhipStream_t stream);
 int nnhipAdd(float* out, const float* a, const float* b, int64_t n, nnhipStream_t stream);
 /* out[i] = a[i] * b[i]   (Dropout mask application, neunet/nn/layers/dropout.py:17-37) */
 int nnhipMul(float* out, const float* a, const float* b, int64_t n, nnhipStream_t stream);
+
+/* ---- (e) the data-parallel exchange: RCCL behind this ABI (net-new; SURVEY 8b "add AllReduce*", 8e, 7 step 7) ------------
+ * The reference has no collective (neunet/autograd.py:8-14: device is "cpu" | "cuda"); these are what a binder that holds
+ * plain device pointers (CuPy arrays through neunet/nn/experimental/utils.py:64-92) needs for the ONE exchange of the path:
+ * a SUM all-reduce of the flat fp32 gradient bucket (Module.parameters() order, neunet/nn/modules.py:23-39) after
+ * backward() and before optimizer.step() -- the optimizer's grad_scale = 1/world (or nnhipFusedOptimizerSetGradDivisor)
+ * turns the sum into the mean.  One process per GPU; hipSetDevice(LOCAL_RANK) before nnhipCommInitRank.
+ * librccl is bound with dlopen at the first call here (a copy already mapped into the process -- e.g. torch's -- is
+ * shared; NNHIP_RCCL_LIB overrides the path): libneunet_hip.so itself loads on a box without RCCL.  Failures return
+ * NNHIP_ECOMM with RCCL's text in nnhipGetLastErrorString().  Collectives are enqueued on the caller's stream, in
+ * order with the kernels that produced the buffer; they may be captured into a hipGraph like any other launch.  ABI 208 */
+#define NNHIP_ECOMM (-4)             /* RCCL missing, or an RCCL call failed */
+#define NNHIP_UNIQUE_ID_BYTES 128    /* sizeof(ncclUniqueId) */
+typedef struct nnhipComm* nnhipComm_t;
+/* Rank 0: fill `id` (NNHIP_UNIQUE_ID_BYTES HOST bytes) -- ncclGetUniqueId; ship it to every rank out of band
+ * (a file, a socket, MPI_Bcast, torch's TCPStore). */
+int nnhipCommUniqueId(void* id);
+/* Every rank, collectively: join the communicator `id` names as `rank` of `world` on the current device. */
+int nnhipCommInitRank(nnhipComm_t* comm, const void* id, int rank, int world);
+int nnhipCommDestroy(nnhipComm_t comm);                    /* NULL is a no-op */
+int nnhipCommRank(nnhipComm_t comm, int* rank, int* world); /* either out pointer may be NULL */
+/* Which librccl was bound (path as passed to dlopen; `version` = ncclGetVersion or 0); both out arguments may be NULL. */
+int nnhipCommLibrary(char* path, int64_t path_bytes, int* version);
+/* buf[i] = sum over ranks of buf[i], in place, n floats (n == 0: no call).  Deterministic for a fixed communicator
+ * (same algorithm, same rank order every step), so replicas that start identical stay bit-identical. */
+int nnhipAllReduceSumF32(nnhipComm_t comm, float* buf, int64_t n, nnhipStream_t stream);
+/* Same with RCCL's pre-scaled average (sum / world). */
+int nnhipAllReduceAvgF32(nnhipComm_t comm, float* buf, int64_t n, nnhipStream_t stream);
+/* buf on every rank = buf of `root` (identical initial parameters: SURVEY 8e "broadcast from rank 0 or same seed"). */
+int nnhipBroadcastF32(nnhipComm_t comm, float* buf, int64_t n, int root, nnhipStream_t stream);
 
 #ifdef __cplusplus
 }

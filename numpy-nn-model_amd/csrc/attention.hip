@@ -996,9 +996,10 @@ __global__ __launch_bounds__(256) void attn_pack_mask_kernel(const int32_t* __re
 
 // materialise the hash dropout multipliers (tests: the unfused path / the oracle run with exactly this mask)
 __global__ __launch_bounds__(256) void attn_dropout_mask_kernel(float* __restrict__ out, int64_t rows, int Tk, unsigned seed,
-                                                                unsigned threshold, float scale) {
+                                                                unsigned threshold, float scale, const unsigned* __restrict__ seed_dev) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= rows * Tk) return;
+    if (seed_dev) seed += __hip_atomic_load(seed_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // as the fused kernels do
     const int64_t row = i / Tk;
     const int key = (int)(i - row * Tk);
     out[i] = at_hash(at_rowkey(seed, (unsigned)row), (unsigned)key) >= threshold ? scale : 0.f;
@@ -1165,8 +1166,15 @@ extern "C" int nnhipAttentionPackMask(const int32_t* mask, uint64_t* mask_bits, 
     return 0;
 }
 
+extern "C" int nnhipAttentionDropoutMaskEx(float* out, int64_t B, int64_t H, int64_t Tq, int64_t Tk, float dropout_p,
+                                           uint32_t seed, const uint32_t* seed_dev, nnhipStream_t s);
 extern "C" int nnhipAttentionDropoutMask(float* out, int64_t B, int64_t H, int64_t Tq, int64_t Tk, float dropout_p,
                                          uint32_t seed, nnhipStream_t s) {
+    return nnhipAttentionDropoutMaskEx(out, B, H, Tq, Tk, dropout_p, seed, nullptr, s);
+}
+
+extern "C" int nnhipAttentionDropoutMaskEx(float* out, int64_t B, int64_t H, int64_t Tq, int64_t Tk, float dropout_p,
+                                           uint32_t seed, const uint32_t* seed_dev, nnhipStream_t s) {
     NNHIP_CHECK_ARG(B >= 0 && H >= 0 && Tq >= 0 && Tk >= 0 && Tk < (1 << 24), NNHIP_EINVAL, "nnhipAttentionDropoutMask: bad sizes");
     NNHIP_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, NNHIP_EINVAL, "nnhipAttentionDropoutMask: dropout_p must be in [0, 1)");
     const int64_t rows = B * H * Tq;
@@ -1174,7 +1182,8 @@ extern "C" int nnhipAttentionDropoutMask(float* out, int64_t B, int64_t H, int64
     NNHIP_CHECK_ARG(out != nullptr, NNHIP_EINVAL, "nnhipAttentionDropoutMask: null pointer");
     const double th = (double)dropout_p * 4294967296.0;
     hipLaunchKernelGGL(attn_dropout_mask_kernel, dim3((unsigned)ceil_div(rows * Tk, 256)), dim3(256), 0, (hipStream_t)s, out, rows,
-                       (int)Tk, seed, (unsigned)(th < 4294967295.0 ? th : 4294967295.0), dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f);
+                       (int)Tk, seed, (unsigned)(th < 4294967295.0 ? th : 4294967295.0), dropout_p > 0.f ? 1.0f / (1.0f - dropout_p) : 1.0f,
+                       seed_dev);
     NNHIP_LAUNCH_CHECK("attn_dropout_mask_kernel");
     return 0;
 }

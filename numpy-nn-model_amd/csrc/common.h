@@ -57,6 +57,8 @@ const float* zero_block();
 constexpr int kSyncWords = 1024;
 enum SyncSlot { SYNC_CE = 0, SYNC_MLP = 24 };
 unsigned* sync_words();
+// Order this launch behind the previous user of the sync words / ticket partials when it arrives on another stream (runtime.hip).
+int serialize_shared_state(hipStream_t st);
 
 // ---- device helpers ----------------------------------------------------------------------------
 // Wave64 all-reduce on the DPP lanes, no LDS traffic and no address registers: four row-local steps (quad_perm xor 1,

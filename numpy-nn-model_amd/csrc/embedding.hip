@@ -91,6 +91,96 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(float* __restrict__ 
     }
 }
 
+// ---- argmax (neunet.argmax -> int32, neunet/__init__.py:132-139 = np.argmax): index of the FIRST maximum along one axis of an
+// [outer, n, inner] view; a NaN counts as the maximum (NumPy: the first NaN wins).  Index results are bit-exact by construction:
+// a pure comparison network, (value, index) pairs ordered by (value desc, index asc).
+struct ArgBest {
+    float v;
+    int32_t i;
+};
+__device__ __forceinline__ bool arg_better(float v, int32_t i, float bv, int32_t bi) {
+    const bool vn = v != v, bn = bv != bv;
+    if (vn != bn) return vn;                     // a NaN beats any number
+    if (vn || v == bv) return i < bi;            // two NaNs, or a tie: the earlier index
+    return v > bv;
+}
+__device__ __forceinline__ ArgBest arg_wave_reduce(ArgBest b) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const float ov = __shfl_xor(b.v, m);
+        const int32_t oi = __shfl_xor(b.i, m);
+        if (arg_better(ov, oi, b.v, b.i)) { b.v = ov; b.i = oi; }
+    }
+    return b;
+}
+
+// last-axis rows (inner == 1): blockDim = 256; ROWS_PER_BLOCK = 4 (one wave per row, n <= 4096) or 1 (the block strides the row).
+// chunks > 1 (one long row, e.g. axis=None): block (row, c) scans its slice and writes a partial pair; arg_finish_kernel closes.
+template <int RPB>
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, int32_t* __restrict__ out, int64_t rows,
+                                                          int64_t n, int chunks, float* __restrict__ pv, int32_t* __restrict__ pi) {
+    __shared__ float sv[4];
+    __shared__ int32_t si[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    ArgBest b{-INFINITY, 0x7fffffff};
+    if constexpr (RPB == 4) {
+        const int64_t r = (int64_t)blockIdx.x * 4 + w;
+        if (r >= rows) return;
+        const float* p = x + r * n;
+        for (int64_t i = lane; i < n; i += 64) {
+            const float v = p[i];
+            if (arg_better(v, (int32_t)i, b.v, b.i)) { b.v = v; b.i = (int32_t)i; }
+        }
+        b = arg_wave_reduce(b);
+        if (lane == 0) out[r] = b.i;
+    } else {
+        const int64_t r = blockIdx.x / chunks;
+        const int c = blockIdx.x % chunks;
+        const int64_t per = (n + chunks - 1) / chunks, lo = c * per, hi = lo + per < n ? lo + per : n;
+        const float* p = x + r * n;
+        for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+            const float v = p[i];
+            if (arg_better(v, (int32_t)i, b.v, b.i)) { b.v = v; b.i = (int32_t)i; }
+        }
+        b = arg_wave_reduce(b);
+        if (lane == 0) { sv[w] = b.v; si[w] = b.i; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 1; k < 4; ++k)
+                if (arg_better(sv[k], si[k], b.v, b.i)) { b.v = sv[k]; b.i = si[k]; }
+            if (chunks == 1) out[r] = b.i;
+            else { pv[blockIdx.x] = b.v; pi[blockIdx.x] = b.i; }
+        }
+    }
+}
+__global__ __launch_bounds__(64) void arg_finish_kernel(const float* __restrict__ pv, const int32_t* __restrict__ pi,
+                                                        int32_t* __restrict__ out, int chunks) {
+    const int64_t r = blockIdx.x;
+    ArgBest b{-INFINITY, 0x7fffffff};
+    for (int c = threadIdx.x; c < chunks; c += 64) {
+        const float v = pv[r * chunks + c];
+        const int32_t i = pi[r * chunks + c];
+        if (arg_better(v, i, b.v, b.i)) { b.v = v; b.i = i; }
+    }
+    b = arg_wave_reduce(b);
+    if (threadIdx.x == 0) out[r] = b.i;
+}
+// inner > 1: one thread per output element (o, j), walking n with stride `inner` (coalesced across j)
+__global__ __launch_bounds__(256) void argmax_strided_kernel(const float* __restrict__ x, int32_t* __restrict__ out,
+                                                             int64_t outer, int64_t n, int64_t inner) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= outer * inner) return;
+    const int64_t o = t / inner, j = t - o * inner;
+    const float* p = x + o * n * inner + j;
+    ArgBest b{-INFINITY, 0x7fffffff};
+    for (int64_t i = 0; i < n; ++i) {
+        const float v = p[i * inner];
+        if (arg_better(v, (int32_t)i, b.v, b.i)) { b.v = v; b.i = (int32_t)i; }
+    }
+    out[t] = b.i;
+}
+
 }  // namespace nnhip
 
 using namespace nnhip;
@@ -138,5 +228,48 @@ extern "C" int nnhipNotEqualInt32(int32_t* out, const int32_t* ids, int64_t n, i
     NNHIP_CHECK_ARG(out && ids, NNHIP_EINVAL, "nnhipNotEqualInt32: null pointer");
     hipLaunchKernelGGL(not_equal_i32_kernel, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, (hipStream_t)s, out, ids, n, value);
     NNHIP_LAUNCH_CHECK("not_equal_i32_kernel");
+    return 0;
+}
+
+extern "C" int nnhipArgmaxF32(int32_t* out, const float* x, int64_t outer, int64_t n, int64_t inner, nnhipStream_t s) {
+    NNHIP_CHECK_ARG(outer >= 0 && n >= 0 && inner >= 0, NNHIP_EINVAL, "nnhipArgmaxF32: negative size");
+    NNHIP_CHECK_ARG(n > 0 || outer * inner == 0, NNHIP_EINVAL, "nnhipArgmaxF32: attempt to get argmax of an empty sequence");
+    NNHIP_CHECK_ARG(n < ((int64_t)1 << 31), NNHIP_EINVAL, "nnhipArgmaxF32: axis longer than int32 indices can address");
+    if (outer * inner == 0) return 0;
+    NNHIP_CHECK_ARG(out && x, NNHIP_EINVAL, "nnhipArgmaxF32: null pointer");
+    hipStream_t st = (hipStream_t)s;
+    if (inner > 1) {
+        hipLaunchKernelGGL(argmax_strided_kernel, dim3((unsigned)ceil_div(outer * inner, 256)), dim3(256), 0, st, x, out, outer, n, inner);
+        NNHIP_LAUNCH_CHECK("argmax_strided_kernel");
+        return 0;
+    }
+    if (n <= 4096 && outer >= 4) {
+        hipLaunchKernelGGL(argmax_rows_kernel<4>, dim3((unsigned)ceil_div(outer, 4)), dim3(256), 0, st, x, out, outer, n, 1, nullptr, nullptr);
+        NNHIP_LAUNCH_CHECK("argmax_rows_kernel");
+        return 0;
+    }
+    // few long rows: cut each into chunks so that ~1024 blocks exist
+    int chunks = 1;
+    if (outer < 256 && n >= (1 << 16)) {
+        chunks = (int)(1024 / outer);
+        const int64_t cap = n / 4096;
+        if (chunks > cap) chunks = (int)cap;
+        if (chunks < 1) chunks = 1;
+    }
+    NNHIP_CHECK_ARG(outer * chunks < ((int64_t)1 << 31), NNHIP_EINVAL, "nnhipArgmaxF32: too many rows");
+    float* pv = nullptr;
+    int32_t* pi = nullptr;
+    if (chunks > 1) {
+        void* ws = workspace((size_t)outer * chunks * 8);
+        NNHIP_CHECK_ARG(ws != nullptr, NNHIP_ENOMEM, "nnhipArgmaxF32: workspace allocation failed");
+        pv = static_cast<float*>(ws);
+        pi = reinterpret_cast<int32_t*>(pv + outer * chunks);
+    }
+    hipLaunchKernelGGL(argmax_rows_kernel<1>, dim3((unsigned)(outer * chunks)), dim3(256), 0, st, x, out, outer, n, chunks, pv, pi);
+    NNHIP_LAUNCH_CHECK("argmax_rows_kernel");
+    if (chunks > 1) {
+        hipLaunchKernelGGL(arg_finish_kernel, dim3((unsigned)outer), dim3(64), 0, st, pv, pi, out, chunks);
+        NNHIP_LAUNCH_CHECK("arg_finish_kernel");
+    }
     return 0;
 }

@@ -270,7 +270,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_mlp_bwd_kernel(const Small
     };
     auto everybody_here = [&]() -> bool {                  // a whole wave: lane w looks at word w
         bool ok = true;
-        for (int spin = 0; spin < (1 << 20); ++spin) {
+        for (int spin = 0; spin < (1 << 22); ++spin) {
             unsigned seen = 0, want = 0;
             if (lane < SG_MLP_WAYS) {
                 seen = __hip_atomic_load(bank(epoch) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -280,7 +280,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_mlp_bwd_kernel(const Small
             if (ok) break;
             __builtin_amdgcn_s_sleep(2);
         }
-        return ok;                                         // false: gave up (never seen): the caller leaves W2 / b2 alone
+        // The host only launches this variant when every block that polls fits on the chip next to blocks that wait for nobody
+        // (mlp_adam_grid_fits below), so "everybody is here" must come true; several seconds without it means the device state
+        // is broken (a stale ticket bank, a foreign writer).  Skipping the W2 / b2 update silently would leave the optimizer
+        // half-stepped and the banks dirty for the next launch (advisor, round 3): abort the kernel instead -- the host sees
+        // hipErrorLaunchFailure at its next synchronisation.
+        if (!ok) __builtin_trap();
+        return ok;
     };
     if (stepper_blk) {
         if (tid < 64) {
@@ -339,6 +345,24 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_mlp_bwd_kernel(const Small
     }
 }
 
+// The optimizer-in-backward launch holds an in-kernel arrival barrier: the dW2 blocks (and the stepper) poll until every block has
+// checked in.  That is only safe while the pollers cannot occupy every resident slot -- the blocks they wait for (dW1 tiles, which
+// wait for nobody) must always find room.  Pollers are dispatched first (lowest block ids), so the rule is: pollers <= half of the
+// blocks the chip holds at once (occupancy query, cached per block size).
+static bool mlp_adam_grid_fits(int nw, int64_t pollers) {
+    static int cap[2] = {0, 0};
+    int& c = cap[nw == 8];
+    if (c == 0) {
+        int dev = 0, cus = 0, per = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+        const hipError_t e = nw == 8 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, gemm_small_mlp_bwd_kernel<8>, 512, 0)
+                                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, gemm_small_mlp_bwd_kernel<4>, 256, 0);
+        if (e != hipSuccess || per <= 0 || cus <= 0) return false;
+        c = per * cus;
+    }
+    return pollers * 2 <= c;
+}
+
 // rows <= 256, out2 <= 16, operands below 2 GiB; returns 1 when it did the work, 0 when the caller should take the general path
 int gemm_small_mlp_backward(const float* X1, const float* H, const float* W2, const float* dO, float* dW2, float* db2, float* dW1,
                             float* db1, int64_t rows, int64_t in1, int64_t hid, int64_t out2, hipStream_t st,
@@ -354,6 +378,9 @@ int gemm_small_mlp_backward(const float* X1, const float* H, const float* W2, co
     SmallMlpAdam ad{};
     if (adam) ad = *adam;
     if (ad.enabled && ad.dev_state) grid.x += 1;           // the stepper block
+    // a hidden layer so wide that its dW2 tiles (the polling blocks) could fill the chip: no in-kernel barrier -- the caller
+    // runs the plain backward launch and the separate optimizer step (same values)
+    if (ad.enabled && !mlp_adam_grid_fits(nw, ceil_div(hid, 16) * ceil_div(out2, 16) + 1)) return 0;
     if (nw == 8) hipLaunchKernelGGL((gemm_small_mlp_bwd_kernel<8>), grid, dim3(512), 0, st, q, ad);
     else hipLaunchKernelGGL((gemm_small_mlp_bwd_kernel<4>), grid, dim3(256), 0, st, q, ad);
     NNHIP_LAUNCH_CHECK("gemm_small_mlp_bwd_kernel");
@@ -374,6 +401,7 @@ int gemm_small_mlp_backward_adam(const float* X1, const float* H, const float* W
     unsigned* sync = sync_words();
     if (!sync) { set_last_error("mlp backward: sync words allocation failed"); return NNHIP_ENOMEM; }
     ad.ticket = sync + SYNC_MLP;
+    if (int rc = serialize_shared_state(st)) return rc;     // one arrival board per process (runtime.hip)
     if (int rc = fused_optimizer_state(opt, step, &ad.dev_state, &ad.grad_div)) return rc;
     return gemm_small_mlp_backward(X1, H, W2, dO, dW2, db2, dW1, db1, rows, in1, hid, out2, st, &ad);
 }

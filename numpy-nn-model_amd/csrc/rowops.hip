@@ -600,7 +600,8 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_dwdb_cols(const float* __rest
 // Round 1 ran count / rows / reduce as three launches (61.5 us for a 45 us kernel at 8192x4096).
 // Labels may be int16 / int32 / int64 (losses.py:100); class weights are optional.
 // A label outside [0, cols) that is not ignore_index contributes zero loss and zero gradient (the reference would
-// raise IndexError / Python-wrap it: losses.py:104 TODO) but still counts in the unweighted 'mean' denominator.
+// raise IndexError / Python-wrap it: losses.py:104 TODO) and is left out of the 'mean' denominator: exactly as if the row
+// carried ignore_index.
 // =================================================================================================
 struct CeArgs {
     float* logits;
@@ -651,9 +652,12 @@ __device__ __forceinline__ void count_labels(const T* __restrict__ lab, int64_t 
                                              int64_t cols, int& ci, float& ws) {
     constexpr int U = 8;
     auto one = [&](int64_t l) {
-        const bool live = l != ignore;
+        // ONE predicate for "this row takes part", the rows kernels' `valid`: not ignore_index and inside [0, cols).  A row the
+        // kernels treat as inert must not sit in the 'mean' denominator either (round-3 review).  cols <= 0: no class bound
+        // (nnhipCountNotEqual, whose contract is its name).
+        const bool live = l != ignore && (cols <= 0 || (l >= 0 && l < cols));
         ci += live ? 1 : 0;
-        if (cw && live && l >= 0 && l < cols) ws += cw[l];
+        if (cw && live) ws += cw[l];
     };
     int64_t done = 0;
     if constexpr (sizeof(T) == 4) {
@@ -1067,9 +1071,9 @@ __global__ __launch_bounds__(NW * 64) void linear_ce_small_kernel(const SmallGem
     }
     float scale, denom;
     if (counting) {                                        // ce_prologue's count_in_kernel branch on the prefetched labels
-        const bool cnt = (int64_t)threadIdx.x < a.rows && lcount != a.ignore;
+        const bool cnt = (int64_t)threadIdx.x < a.rows && lcount != a.ignore && lcount >= 0 && lcount < a.cols;   // count_labels' predicate
         float ws = 0.f;
-        if (a.cw && cnt && lcount >= 0 && lcount < a.cols) ws = a.cw[lcount];
+        if (a.cw && cnt) ws = a.cw[lcount];
         const int ci = block_sum_int<BS / 64>(cnt ? 1 : 0, ired);
         if (a.cw) ws = block_sum<BS / 64>(ws, red);
         denom = a.cw ? ws : (float)ci;
@@ -1465,6 +1469,7 @@ namespace nnhip {
 static int ce_launch(CeArgs a, hipStream_t st) {
     unsigned* sync = sync_words();
     if (!sync) { set_last_error("cross entropy: sync words allocation failed"); return NNHIP_ENOMEM; }
+    if (int rc = serialize_shared_state(st)) return rc;     // one ticket word / partial array per process: see runtime.hip
     a.sync = sync + SYNC_CE;
     a.nt = row_streaming(a.rows, a.cols, a.ld);
     float* denom_scratch = reinterpret_cast<float*>(sync + SYNC_CE + 4);
@@ -1591,6 +1596,7 @@ extern "C" int nnhipLinearCrossEntropyLoss(const float* X, const float* W, const
         unsigned* sync = sync_words();
         a.partial = static_cast<float*>(workspace((size_t)nblk * sizeof(float)));
         if (!sync || !a.partial) { set_last_error("nnhipLinearCrossEntropyLoss: workspace allocation failed"); return NNHIP_ENOMEM; }
+        if (int rc = serialize_shared_state((hipStream_t)s)) return rc;
         a.sync = sync + SYNC_CE;
     }
     const bool vec = (in_features & 3) == 0 && aligned16(X) && aligned16(W);

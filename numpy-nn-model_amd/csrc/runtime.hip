@@ -68,6 +68,37 @@ const float* zero_block() {
     return z;
 }
 
+// Library-owned device words (arrival tickets, the CE denominator scratch) and the workspace partials behind them are ONE set
+// per process: two launches that use them must not overlap.  On one stream that is program order.  A launch that arrives on a
+// DIFFERENT stream than the previous user is ordered behind it with an event (record on the old stream, wait on the new): the
+// single-stream assumption is enforced instead of assumed (round-3 review).  Costs a pointer compare when the stream is the same.
+// While either stream is being captured into a hipGraph nothing is inserted (a cross-stream edge to work outside the capture is
+// not expressible there; a captured step is single-stream by construction, neunet_hip/graph.py).
+int serialize_shared_state(hipStream_t st) {
+    static std::mutex mu;
+    static hipStream_t last = nullptr;
+    static bool have_last = false;
+    static hipEvent_t ev = nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    if (have_last && last != st) {
+        hipStreamCaptureStatus a = hipStreamCaptureStatusNone, b = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(st, &a);
+        (void)hipStreamIsCapturing(last, &b);
+        if (a == hipStreamCaptureStatusNone && b == hipStreamCaptureStatusNone) {
+            if (!ev) {
+                hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+                if (e != hipSuccess) return hip_status(e, "hipEventCreate(shared-state guard)");
+            }
+            hipError_t e = hipEventRecord(ev, last);
+            if (e == hipSuccess) e = hipStreamWaitEvent(st, ev, 0);
+            if (e != hipSuccess) return hip_status(e, "shared-state guard (event record / wait)");
+        }
+    }
+    last = st;
+    have_last = true;
+    return 0;
+}
+
 unsigned* sync_words() {
     static unsigned* w = nullptr;
     static std::once_flag once;
@@ -82,7 +113,7 @@ unsigned* sync_words() {
 
 }  // namespace nnhip
 
-extern "C" int nnhipVersion(void) { return 207; }
+extern "C" int nnhipVersion(void) { return 208; }
 
 extern "C" int nnhipWorkspaceReserve(int64_t bytes) {
     if (bytes < 0) { nnhip::set_last_error("nnhipWorkspaceReserve: negative size"); return NNHIP_EINVAL; }

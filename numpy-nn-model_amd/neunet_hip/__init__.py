@@ -25,7 +25,24 @@ def argmax(x: Tensor, axis=None, keepdims=False):
         out = np.argmax(x.data, axis=axis, keepdims=keepdims).astype(np.int32)
         return Tensor(out, dtype=np.int32, requires_grad=False, device="cpu")
     import torch
-    out = torch.argmax(x.data, dim=axis, keepdim=keepdims).to(torch.int32)
+    from ._lib import call_hip_function, get_current_stream_ptr
+    d = x.data
+    if d.dtype != torch.float32:
+        raise NotImplementedError("neunet_hip.argmax on the device takes float32 tensors")
+    d = d.contiguous()
+    shape = tuple(d.shape)
+    if axis is None:
+        outer, n, inner, oshape = 1, d.numel(), 1, ((1,) * len(shape) if keepdims else ())
+    else:
+        ax = axis + len(shape) if axis < 0 else axis
+        if not 0 <= ax < len(shape):
+            raise ValueError(f"axis {axis} is out of bounds for array of dimension {len(shape)}")
+        outer, n, inner = int(np.prod(shape[:ax], dtype=np.int64)), shape[ax], int(np.prod(shape[ax + 1:], dtype=np.int64))
+        oshape = shape[:ax] + ((1,) if keepdims else ()) + shape[ax + 1:]
+    if n == 0 and outer * inner > 0:
+        raise ValueError("attempt to get argmax of an empty sequence")
+    out = torch.empty(oshape, dtype=torch.int32, device=d.device)
+    call_hip_function("nnhipArgmaxF32", out, d, outer, n, inner, get_current_stream_ptr())
     return Tensor(out, dtype=np.int32, requires_grad=False, device="cuda")
 
 

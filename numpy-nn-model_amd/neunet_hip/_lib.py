@@ -85,9 +85,11 @@ _SIGNATURES = {
                                                 ctypes.c_int, POINTER(AttentionOptions), c_void_p]),
     "nnhipAttentionPackMask": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_void_p]),
     "nnhipAttentionDropoutMask": (ctypes.c_int, [P, c_int64, c_int64, c_int64, c_int64, c_float, ctypes.c_uint32, c_void_p]),
+    "nnhipAttentionDropoutMaskEx": (ctypes.c_int, [P, c_int64, c_int64, c_int64, c_int64, c_float, ctypes.c_uint32, P, c_void_p]),
     "nnhipEmbeddingForward": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_float, c_void_p]),
     "nnhipEmbeddingBackward": (ctypes.c_int, [P, P, P, c_int64, c_int64, c_int64, c_float, c_void_p]),
     "nnhipNotEqualInt32": (ctypes.c_int, [P, P, c_int64, ctypes.c_int32, c_void_p]),
+    "nnhipArgmaxF32": (ctypes.c_int, [P, P, c_int64, c_int64, c_int64, c_void_p]),
     "nnhipDropout": (ctypes.c_int, [P, P, c_int64, c_float, ctypes.c_uint32, P, c_void_p]),
     "nnhipIncrementU32": (ctypes.c_int, [P, ctypes.c_uint32, c_void_p]),
     "nnhipMul": (ctypes.c_int, [P, P, P, c_int64, c_void_p]),
@@ -139,6 +141,14 @@ _SIGNATURES = {
     "nnhipMSELossSigmoidForwardBackward": (ctypes.c_int, [P, P, P, P, c_int64, c_void_p]),
     "nnhipScale": (ctypes.c_int, [P, c_float, c_int64, c_void_p]),
     "nnhipAdd": (ctypes.c_int, [P, P, P, c_int64, c_void_p]),
+    "nnhipCommUniqueId": (ctypes.c_int, [ctypes.c_char_p]),
+    "nnhipCommInitRank": (ctypes.c_int, [POINTER(c_void_p), ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),
+    "nnhipCommDestroy": (ctypes.c_int, [c_void_p]),
+    "nnhipCommRank": (ctypes.c_int, [c_void_p, POINTER(ctypes.c_int), POINTER(ctypes.c_int)]),
+    "nnhipCommLibrary": (ctypes.c_int, [ctypes.c_char_p, c_int64, POINTER(ctypes.c_int)]),
+    "nnhipAllReduceSumF32": (ctypes.c_int, [c_void_p, P, c_int64, c_void_p]),
+    "nnhipAllReduceAvgF32": (ctypes.c_int, [c_void_p, P, c_int64, c_void_p]),
+    "nnhipBroadcastF32": (ctypes.c_int, [c_void_p, P, c_int64, ctypes.c_int, c_void_p]),
 }
 _NO_STATUS = {"nnhipVersion", "nnhipGetLastErrorString", "nnhipCreateFusedOptimizer", "nnhipGetGemmMode", "nnhipGetGemmLockstep", "nnhipConv2dWeightGradPooledOk", "nnhipConv2dLeakyMaxPoolForwardOk", "nnhipGemmLaunchCount",
               "nnhipWeightGradPending"}

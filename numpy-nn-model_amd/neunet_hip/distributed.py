@@ -13,7 +13,9 @@ the exchange of dW rides under the dX GEMM and the rest of the backward pass; `a
 launches what is left and waits.  RCCL runs the collective on its own stream, ordered after the producing
 kernels by an event.
 
-Backend: torch.distributed -- "nccl" is RCCL on ROCm (xGMI); "gloo" for the CPU tests.
+Backends: torch.distributed -- "nccl" is RCCL on ROCm (xGMI); "gloo" for the CPU tests -- or `NativeComm`, an RCCL
+communicator held through the library's own C ABI (nnhipComm*, include/neunet_hip.h): `GradBucket(params, comm=NativeComm.
+from_env())` exchanges through nnhipAllReduceSumF32 on a side stream of this process, no ProcessGroup involved.
 """
 from __future__ import annotations
 
@@ -27,8 +29,10 @@ force_collectives = os.environ.get("NNHIP_FORCE_DP", "0") == "1"
 
 
 def collectives_live(group=None) -> bool:
-    """True when a gradient exchange has to be issued: an initialised process group with more than one rank, or with
-    one rank and `force_collectives` set."""
+    """True when a gradient exchange has to be issued: an initialised process group (or a NativeComm passed as `group`)
+    with more than one rank, or with one rank and `force_collectives` set."""
+    if isinstance(group, NativeComm):
+        return group.world > 1 or force_collectives
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return False
@@ -59,11 +63,136 @@ def init_process_group(backend: str | None = None, force: bool = False):
     return rank, world
 
 
+class _StreamWork:
+    """Handle of a collective enqueued on a side stream: wait() orders torch's current stream after it (stream-ordered, the
+    host does not block) -- the same contract as the Work object dist.all_reduce(async_op=True) returns."""
+
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        import torch
+        torch.cuda.current_stream().wait_event(self.event)
+
+
+class NativeComm:
+    """An RCCL communicator held through libneunet_hip.so's C ABI (nnhipCommUniqueId / nnhipCommInitRank /
+    nnhipAllReduceSumF32 / nnhipBroadcastF32 / nnhipCommDestroy) -- the binding a reference-side caller with plain device
+    pointers would use ("data-parallel loop").  torch is only the allocator and the stream here.
+
+        comm = NativeComm.from_env()                 # RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT
+        bucket = GradBucket(params, comm=comm)       # or comm.all_reduce(tensor) directly
+    """
+
+    def __init__(self, unique_id: bytes, rank: int, world: int):
+        import ctypes
+        from ._lib import call_hip_function
+        if len(unique_id) != 128:
+            raise ValueError("unique_id must be the 128 bytes nnhipCommUniqueId wrote on rank 0")
+        self.rank, self.world = int(rank), int(world)
+        h = ctypes.c_void_p()
+        call_hip_function("nnhipCommInitRank", ctypes.byref(h), unique_id, self.rank, self.world)
+        self._h = h
+        self._stream = None
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes
+        from ._lib import call_hip_function
+        buf = ctypes.create_string_buffer(128)
+        call_hip_function("nnhipCommUniqueId", buf)
+        return buf.raw
+
+    @staticmethod
+    def library():
+        """(path, version) of the librccl the C ABI bound."""
+        import ctypes
+        from ._lib import call_hip_function
+        buf, v = ctypes.create_string_buffer(256), ctypes.c_int(0)
+        call_hip_function("nnhipCommLibrary", buf, 256, ctypes.byref(v))
+        return buf.value.decode(), int(v.value)
+
+    @classmethod
+    def from_env(cls, port_offset: int = 17):
+        """One process per GPU under torchrun (or a lone process: rank 0 of 1).  Rank 0 draws the id; it travels through
+        the torch process group when one is up, else through a TCPStore on MASTER_PORT + port_offset (rendezvous only --
+        no torch collective is created)."""
+        import torch
+        rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+        if torch.cuda.is_available():
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
+            torch.cuda.current_stream()                 # the HIP context exists before RCCL asks for the device
+        if world == 1:
+            return cls(cls.unique_id(), 0, 1)
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            box = [cls.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            uid = box[0]
+        else:
+            from datetime import timedelta
+            store = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")) + port_offset,
+                                  world, rank == 0, timeout=timedelta(seconds=120))
+            if rank == 0:
+                store.set("nnhip_comm_id", cls.unique_id())
+            uid = bytes(store.get("nnhip_comm_id"))
+        return cls(uid, rank, world)
+
+    # ---- collectives (in place, fp32) --------------------------------------------------------------------------------------
+    def _check(self, t):
+        import torch
+        if self._h is None:
+            raise RuntimeError("NativeComm: communicator already destroyed")
+        if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+            raise TypeError("NativeComm collectives take contiguous fp32 device tensors")
+
+    def all_reduce(self, t, op: str = "sum", async_op: bool = False):
+        """In-place all-reduce of `t`.  async_op=False: on torch's current stream, in order with the producers.
+        async_op=True: on this communicator's side stream, ordered after everything enqueued on the current stream so far;
+        returns a handle whose wait() orders the current stream after the collective (overlap with later kernels)."""
+        import torch
+        from ._lib import call_hip_function
+        self._check(t)
+        name = {"sum": "nnhipAllReduceSumF32", "avg": "nnhipAllReduceAvgF32"}[op]
+        if not async_op:
+            call_hip_function(name, self._h, t, t.numel(), torch.cuda.current_stream().cuda_stream)
+            return None
+        if self._stream is None:
+            self._stream = torch.cuda.Stream()
+        ready = torch.cuda.Event()
+        ready.record()
+        self._stream.wait_event(ready)
+        call_hip_function(name, self._h, t, t.numel(), self._stream.cuda_stream)
+        done = torch.cuda.Event()
+        done.record(self._stream)
+        return _StreamWork(done)
+
+    def broadcast(self, t, root: int = 0):
+        import torch
+        from ._lib import call_hip_function
+        self._check(t)
+        call_hip_function("nnhipBroadcastF32", self._h, t, t.numel(), int(root), torch.cuda.current_stream().cuda_stream)
+
+    def destroy(self):
+        if getattr(self, "_h", None) is not None:
+            from ._lib import call_hip_function
+            import torch
+            torch.cuda.synchronize()
+            h, self._h = self._h, None
+            call_hip_function("nnhipCommDestroy", h)
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
 class GradBucket:
     """Flat gradient bucket over `params` (any objects with .data (torch tensor) and .grad)."""
 
     def __init__(self, params, extra_scalars: int = 0, overlap: bool = False, segment_bytes: int = 32 << 20,
-                 group=None, reduce_op: str = "sum"):
+                 group=None, reduce_op: str = "sum", comm: "NativeComm | None" = None):
         import torch
         # "sum" (default; the optimizer folds 1/world or 1/global_count into its gradient load) or "avg" (RCCL pre-scales
         # by 1/world inside the collective: numerator and extra-slot count shrink together, so g/count is unchanged and
@@ -74,7 +203,11 @@ class GradBucket:
         self.reduce_op = reduce_op
         self.params = list(params)
         self.overlap = overlap
-        self.group = group
+        # comm = a NativeComm: the exchange goes through the library's own RCCL entry points (nnhipAllReduce*F32) instead of
+        # torch.distributed; it rides in `group` so that every "is a collective live / which ranks" question has one answer
+        if comm is not None and group is not None:
+            raise ValueError("GradBucket: pass either a torch process group or a NativeComm, not both")
+        self.group = comm if comm is not None else group
         self.sizes = [int(p.data.numel()) for p in self.params]
         # Slot layout: `Module.parameters()` order, except that a parameter carrying `_bucket_group` (a list of
         # parameters, e.g. the q/k/v projection weights of a fused attention block) pulls its group next to itself so a
@@ -134,6 +267,18 @@ class GradBucket:
         import torch.distributed as dist
         return dist.ReduceOp.AVG if self.reduce_op == "avg" else dist.ReduceOp.SUM
 
+    def exchange(self, lo: int, hi: int, async_op: bool = False, group=None):
+        """All-reduce flat[lo:hi] over the bucket's backend (a NativeComm or a torch process group); async_op=True returns a
+        handle with wait().  The one place a collective is issued: eager steps, hooks and graph replays all come here."""
+        group = group if group is not None else self.group
+        if isinstance(group, NativeComm):
+            return group.all_reduce(self.flat[lo:hi], op=self.reduce_op, async_op=async_op)
+        import torch.distributed as dist
+        if self.reduce_op == "avg" and dist.get_backend(group) == "gloo":
+            raise ValueError("GradBucket(reduce_op='avg'): gloo has no AVG reduction; use 'sum' (the optimizer's grad_scale "
+                             "= 1/world gives the mean)")
+        return dist.all_reduce(self.flat[lo:hi], op=self.op(), group=group, async_op=async_op)
+
     def _launch(self, k):
         import torch.distributed as dist
         from ._lib import wgrad_flush
@@ -144,7 +289,7 @@ class GradBucket:
             return
         if self._live():
             lo, hi, _ = self.segments[k]
-            self._works.append(dist.all_reduce(self.flat[lo:hi], op=self.op(), group=self.group, async_op=True))
+            self._works.append(self.exchange(lo, hi, async_op=True))
 
     def _on_grad(self, param):
         """Called by a layer right after it wrote `param`'s gradient (into the slot, or elsewhere -> copied in)."""
@@ -216,8 +361,7 @@ class GradBucket:
         import torch.distributed as dist
         self._close_segments()
         if self.extra is not None and self._live():
-            self._works.append(dist.all_reduce(self.flat[self.extra_offset:], op=self.op(), group=self.group,
-                                               async_op=True))
+            self._works.append(self.exchange(self.extra_offset, self.numel, async_op=True))
         for w in self._works:
             w.wait()
         for p, v, hg in zip(self.params, self.views, self.has_grad):
@@ -233,7 +377,7 @@ class GradBucket:
         group = group if group is not None else self.group     # a bucket built for a sub-group reduces over THAT group
         self.collect()
         if collectives_live(group):
-            dist.all_reduce(self.flat, op=self.op(), group=group)
+            self.exchange(0, self.numel, group=group)
         for p, v, hg in zip(self.params, self.views, self.has_grad):
             p.grad = v if hg else None
 

@@ -65,6 +65,26 @@ def attach_step_seed(model):
     return seed
 
 
+def count_graph_nodes(raw_graph: int):
+    """(kernel nodes, all nodes) of a captured hipGraph_t (torch.cuda.CUDAGraph(keep_graph=True).raw_cuda_graph()) --
+    hipGraphGetNodes + hipGraphNodeGetType of the HIP runtime already mapped into the process."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    n = ctypes.c_size_t(0)
+    g = ctypes.c_void_p(raw_graph)
+    if hip.hipGraphGetNodes(g, None, ctypes.byref(n)) != 0:
+        return None, None
+    nodes = (ctypes.c_void_p * max(1, n.value))()
+    if hip.hipGraphGetNodes(g, nodes, ctypes.byref(n)) != 0:
+        return None, None
+    kernels = 0
+    for i in range(n.value):
+        t = ctypes.c_int(-1)
+        if hip.hipGraphNodeGetType(ctypes.c_void_p(nodes[i]), ctypes.byref(t)) == 0 and t.value == 0:   # hipGraphNodeTypeKernel
+            kernels += 1
+    return kernels, int(n.value)
+
+
 class GraphedTrainStep:
     _live = 0          # captured steps alive in this process: the library workspace stays locked while > 0
     # Every capture is thread-local.  torch's default ("global") makes ANY thread's capture-unsafe HIP call fail while this
@@ -74,8 +94,12 @@ class GraphedTrainStep:
     _CAPTURE_MODE = "thread_local"
 
     def __init__(self, forward_backward, optimizer, bucket, warmup: int = 3, world: int = 1, pre_optim=None,
-                 group=None, check_every: int = 256, unroll: int = 1, capture_collectives: bool = False, step_seed=None):
+                 group=None, check_every: int = 256, unroll: int = 1, capture_collectives: bool = False, step_seed=None,
+                 count_nodes: bool = False):
         import torch
+        # count_nodes (one-graph steps): keep the hipGraph_t after capture and count its kernel nodes -> self.kernel_nodes
+        # (per captured graph, i.e. `unroll` steps) -- what bench.py reports as launches per step
+        self._count_nodes, self.kernel_nodes, self.graph_nodes = bool(count_nodes), None, None
         self.fb, self.opt, self.bucket, self.world = forward_backward, optimizer, bucket, world
         self.pre_optim = pre_optim                    # host-side hook between exchange and optimizer (kept for callers)
         # unroll = U > 1 (one process only): U consecutive steps are captured into ONE graph, so a replay costs the host one
@@ -144,7 +168,7 @@ class GraphedTrainStep:
         elif overlap:
             self._capture_overlapped(s)
         else:
-            g = torch.cuda.CUDAGraph()
+            g = torch.cuda.CUDAGraph(keep_graph=True) if self._count_nodes else torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode=self._CAPTURE_MODE):
                 for k in range(self.unroll):
                     if k:
@@ -156,6 +180,12 @@ class GraphedTrainStep:
                         self.opt.step()
                     if getattr(self.bucket, "overlap", False) and self.bucket.segments:
                         self.bucket._reset_step()     # an overlap bucket on the one-process path: per-step hook state
+            if self._count_nodes:
+                try:
+                    self.kernel_nodes, self.graph_nodes = count_graph_nodes(g.raw_cuda_graph())
+                except Exception:  # noqa: BLE001 -- a diagnostic, never a reason to lose the step
+                    pass
+                g.instantiate()
             self.pieces.append((g, None))
         if self.mode == "pieces":
             self.g_opt = torch.cuda.CUDAGraph()
@@ -257,22 +287,20 @@ class GraphedTrainStep:
         if self.single or self.mode == "ingraph":
             self.pieces[0][0].replay()
             return self.loss
-        import torch.distributed as dist
         live = collectives_live(self.group)
         works = []
-        op = self.bucket.op() if hasattr(self.bucket, "op") else dist.ReduceOp.SUM
+        bk = self.bucket
         for g, k in self.pieces:
             g.replay()
             if k is not None and live:
-                lo, hi, _ = self.bucket.segments[k]
-                works.append(dist.all_reduce(self.bucket.flat[lo:hi], op=op, group=self.group, async_op=True))
+                lo, hi, _ = bk.segments[k]
+                works.append(bk.exchange(lo, hi, async_op=True, group=self.group))
         if live:
-            if getattr(self.bucket, "overlap", False):
-                if self.bucket.extra is not None:
-                    works.append(dist.all_reduce(self.bucket.flat[self.bucket.extra_offset:], op=op,
-                                                 group=self.group, async_op=True))
+            if getattr(bk, "overlap", False):
+                if bk.extra is not None:
+                    works.append(bk.exchange(bk.extra_offset, bk.numel, async_op=True, group=self.group))
             else:
-                dist.all_reduce(self.bucket.flat, op=op, group=self.group)
+                bk.exchange(0, bk.numel, group=self.group)
         for w in works:
             w.wait()                                  # stream-ordered: the host does not block on the GPU
         if self.pre_optim is not None:

@@ -15,7 +15,7 @@ import numpy as np
 
 from ...autograd import Tensor
 from ..modules import Module
-from .embedding import HIPDropout
+from .embedding import HIPDropout, check_capture_seed, process_dropout_seed
 from .linear import HIPLinear, _finish_param, hip_linear_module_backward, hip_linear_module_forward
 from ..._lib import AttentionOptions, StridedView
 from .utils import call_hip_function, get_current_stream_ptr
@@ -362,8 +362,10 @@ class HIPMultiHeadAttention(Module):
         if drop_mask is not None:
             opts.dropout_mask = drop_mask if drop_mask.is_contiguous() else drop_mask.contiguous()
         elif dropping:
+            check_capture_seed(self.dropout_seed_dev, "HIPMultiHeadAttention")
             self._calls += 1
-            opts.dropout_p, opts.seed, opts.seed_dev = self.dropout.p, self._seed_base + self._calls, self.dropout_seed_dev
+            opts.dropout_p, opts.seed, opts.seed_dev = (self.dropout.p, (self._seed_base + self._calls + process_dropout_seed()) & 0xFFFFFFFF,
+                                                        self.dropout_seed_dev)
         return opts
 
     def forward(self, q: Tensor, k: Tensor, v: Tensor, key_valid=None, causal=True, need_weights=True, residual=None,
@@ -398,10 +400,17 @@ class HIPMultiHeadAttention(Module):
             dense = (dense[:, 0] if dense.dim() == 4 else dense).to(torch.int32).contiguous()
             key_valid, causal = None, False
         qp, kp, vp = self.wq(q), self.wk(k), self.wv(v)
-        if dropping and drop_mask is None:   # attention dropout (cell 2: self.dropout(softmax(scores))), device RNG
+        if dropping and drop_mask is None:
+            # attention dropout (cell 2: self.dropout(softmax(scores))): the multipliers of the library's counter hash of
+            # (seed [+ device step word], b, h, q, k) -- the very ones the fused kernels would draw for this call
             import torch
             shape = (qp.shape[0], self.n_heads, qp.shape[1], kp.shape[1])
-            drop_mask = (torch.rand(shape, device=qp.data.device) >= self.dropout.p).to(torch.float32) * self.dropout.scale
+            drop_mask = torch.empty(shape, dtype=torch.float32, device=qp.data.device)
+            check_capture_seed(self.dropout_seed_dev, "HIPMultiHeadAttention")
+            self._calls += 1
+            call_hip_function("nnhipAttentionDropoutMaskEx", drop_mask, *shape, float(self.dropout.p),
+                              (self._seed_base + self._calls + process_dropout_seed()) & 0xFFFFFFFF, self.dropout_seed_dev,
+                              get_current_stream_ptr())
         ctx, attn, used = attention_forward(qp.data, kp.data, vp.data, key_valid, self.n_heads, self.scale, causal, drop_mask,
                                             dense)
         ctx_t = _HIPAttentionTensor(ctx, (qp, kp, vp, attn, key_valid, self.n_heads, self.scale, causal, drop_mask,

@@ -105,6 +105,41 @@ class _HIPDropoutTensor(Tensor):
 
 
 _DROPOUT_SEEDS = itertools.count(1)
+_seed_cache = {}
+
+
+def process_dropout_seed() -> int:
+    """32-bit word mixed into every hash-dropout seed of this process: torch.initial_seed() -- what `torch.manual_seed(s)` set,
+    read at call time so a seed set after the model was built still counts -- and the data-parallel rank, so that a run is
+    reproducible under the user's seed and the ranks of a DP job drop DIFFERENT positions (advisor, round 3: the bare module
+    counter gave every run and every rank the same masks).  The reference draws its masks from the host NumPy generator
+    (neunet/nn/layers/dropout.py:17-37); drawing from it here would shift the layers' weight initialisation, which comes
+    from the same generator, so the device RNG keys off torch's seed instead."""
+    import os
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            rank = dist.get_rank()
+    except Exception:  # noqa: BLE001
+        pass
+    key = (torch.initial_seed(), rank)
+    v = _seed_cache.get(key)
+    if v is None:
+        x = (key[0] ^ (key[0] >> 32)) & 0xFFFFFFFF
+        x = (x * 0x85EBCA6B + 0x9E3779B9 * (rank + 1)) & 0xFFFFFFFF
+        x ^= x >> 15
+        v = _seed_cache[key] = (x * 0xC2B2AE35) & 0xFFFFFFFF
+    return v
+
+
+def check_capture_seed(seed_dev, what):
+    """A hash-dropout launch recorded into a hipGraph without a device step word replays the SAME mask on every step."""
+    import torch
+    if seed_dev is None and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        raise RuntimeError(f"{what}: dropout inside a captured step needs a device step seed, or every replay draws the same mask "
+                           "-- build the step as GraphedTrainStep(..., step_seed=attach_step_seed(model))")
 
 
 class HIPDropout(Module):
@@ -129,8 +164,9 @@ class HIPDropout(Module):
         out = X.xp.empty_like(X.data)
         xd = X.data if X.data.is_contiguous() else X.data.contiguous()
         if mask is None:
+            check_capture_seed(self.seed_dev, "HIPDropout")
             self._calls += 1
-            seed = (self._base + self._calls * 0x632BE5AB) & 0xFFFFFFFF
+            seed = (self._base + self._calls * 0x632BE5AB + process_dropout_seed()) & 0xFFFFFFFF
             call_hip_function("nnhipDropout", out, xd, out.numel(), float(self.p), seed, self.seed_dev, get_current_stream_ptr())
             return _HIPDropoutTensor(out, (X, (self.p, seed, self.seed_dev)), "dropout", device=X.device)
         call_hip_function("nnhipMul", out, xd, mask, out.numel(), get_current_stream_ptr())

@@ -11,7 +11,7 @@ from typing import Union
 
 import numpy as np
 
-from ...autograd import Tensor, param_epoch
+from ...autograd import Tensor, bump_param_epoch, param_epoch
 from ..modules import Module
 from ..parameter import Parameter
 from ..._lib import NeunetHipError, wgrad_flush
@@ -102,6 +102,10 @@ def _mlp_chain_backward(relu_t, w2, b2, grad, rows, hid, out2):
                               out2, opt_ptr, ctypes.cast(table, ctypes.POINTER(ctypes.c_void_p)), lr, be1, be2, eps, wd, step, mode,
                               gscale, get_current_stream_ptr())
             fo[0]._stepped_in_backward = True
+            # the parameters changed NOW, inside this launch: a deferred output still pending (the logits whose GEMM went into
+            # the fused CrossEntropy, a lazy Conv2d output) must raise on a later read instead of recomputing with the updated
+            # W2 / b2 -- optimizer.step() bumps again, harmlessly (advisor, round 3)
+            bump_param_epoch()
         else:
             call_hip_function("nnhipLinearReLULinearBackward", x1.data, f_x, w2.data, grad, gw2, gb2, gw1, gb1, rows, in1, hid, out2,
                               get_current_stream_ptr())

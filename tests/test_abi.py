@@ -85,3 +85,25 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setenv(_lib.LIB_ENV, "/nonexistent/libneunet_hip.so")
     with pytest.raises(_lib.NeunetHipError, match="no CPU fallback"):
         _lib.load_hip_function("nnhipVersion")
+
+
+def test_comm_unique_id_needs_no_gpu(lib):
+    """The RCCL entry points bind librccl lazily (dlopen): the id for nnhipCommInitRank can be drawn on a GPU-less host, bad
+    arguments are status codes, and the library that got bound is an RCCL."""
+    import ctypes
+    from neunet_hip import _lib
+    buf = ctypes.create_string_buffer(128)
+    try:
+        _lib.call_hip_function("nnhipCommUniqueId", buf)
+    except _lib.NeunetHipError as exc:
+        pytest.skip(f"no RCCL on this host: {exc}")
+    assert any(buf.raw), "ncclGetUniqueId left the buffer untouched"
+    path, ver = ctypes.create_string_buffer(256), ctypes.c_int(0)
+    _lib.call_hip_function("nnhipCommLibrary", path, 256, ctypes.byref(ver))
+    assert b"rccl" in path.value and ver.value > 0
+    with pytest.raises(_lib.NeunetHipError, match="null communicator"):
+        _lib.call_hip_function("nnhipAllReduceSumF32", None, 16, 4, None)
+    with pytest.raises(_lib.NeunetHipError, match="rank"):
+        h = ctypes.c_void_p()
+        _lib.call_hip_function("nnhipCommInitRank", ctypes.byref(h), buf.raw, 3, 2)
+    assert _lib.call_hip_function("nnhipCommDestroy", None) == 0

@@ -272,7 +272,14 @@ def _run_gpt_dp(rank, world, port, q, launch, force):
     from neunet_hip.optim import Adam
     torch.cuda.set_device(0)
     info = {}
-    if force:
+    comm = None
+    if force == "native":                                  # RCCL through the library's own C ABI: no torch process group
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        comm = D.NativeComm.from_env()
+        D.force_collectives = True
+        info["backend"] = "native:" + D.NativeComm.library()[0]
+        info["rccl_version"] = D.NativeComm.library()[1]
+    elif force:
         import torch.distributed as dist
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
         D.init_process_group("nccl", force=True)
@@ -304,7 +311,7 @@ def _run_gpt_dp(rank, world, port, q, launch, force):
     active = [p for p in model.parameters() if p.grad is not None]
     opt = Adam(model.parameters(), lr=1.5e-4, betas=(0.9, 0.98), eps=1e-9)
     opt.zero_grad()
-    bucket = D.GradBucket(active, extra_scalars=1, overlap=force, segment_bytes=1 << 18)
+    bucket = D.GradBucket(active, extra_scalars=1, overlap=bool(force), segment_bytes=1 << 18, comm=comm)
     state["bucket"] = bucket
     opt.grad_divisor = bucket.extra
 
@@ -332,7 +339,11 @@ def _run_gpt_dp(rank, world, port, q, launch, force):
     res = [p.numpy().copy() for p in model.parameters()]
     if launch != "eager":
         step.release()
-    if force:
+    if comm is not None:
+        info["live"] = D.collectives_live(comm)
+        comm.destroy()
+        D.force_collectives = False
+    elif force:
         import torch.distributed as dist
         dist.destroy_process_group()
         D.force_collectives = False
@@ -358,3 +369,89 @@ def test_gpt_forced_nccl_dp_step_is_bit_identical_to_the_local_step(launch):
     local = _run_gpt_dp(0, 1, 0, None, "eager", False)
     for a, b in zip(res, local):
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.parametrize("launch", ["eager", "pieces", "ingraph"])
+def test_gpt_native_comm_dp_step_is_bit_identical_to_the_local_step(launch):
+    """The same GPT DP step with the exchange going through the library's OWN RCCL entry points (nnhipCommInitRank /
+    nnhipAllReduceSumF32 behind `NativeComm`, SURVEY 8b "add AllReduce*") instead of torch.distributed: a 1-rank communicator,
+    collectives forced, per-segment all-reduces on the communicator's side stream -- eager, between graph pieces, and captured
+    into the step graph.  Bit-identical to the recipe without any communicator."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no HIP device is visible")
+    res, info = _spawn1(_run_gpt_dp, (launch, "native"))
+    assert info["backend"].startswith("native:") and "rccl" in info["backend"] and info["live"] is True, info
+    if launch == "pieces":
+        assert info["mode"] == "pieces" and info["segments"] > 1 and info["pieces"] == info["segments"] + 1, info
+    if launch == "ingraph":
+        assert info["mode"] == "ingraph" or info["ingraph_error"], info
+    local = _run_gpt_dp(0, 1, 0, None, "eager", False)
+    for a, b in zip(res, local):
+        np.testing.assert_array_equal(a, b)
+
+
+def _native_collectives(rank, world, port, q):
+    from neunet_hip import distributed as D
+    from neunet_hip._lib import NeunetHipError
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    comm = D.NativeComm.from_env()
+    x = torch.arange(1, 1025, dtype=torch.float32, device="cuda") * (rank + 1)
+    ref = x.clone()
+    out = {}
+    comm.all_reduce(x)                                    # SUM over ranks of (rank+1) * v
+    out["sum"] = x.cpu().numpy().copy()
+    y = ref.clone()
+    w = comm.all_reduce(y, op="avg", async_op=True)       # side stream + join
+    w.wait()
+    out["avg"] = y.cpu().numpy().copy()
+    z = ref.clone()
+    comm.broadcast(z, root=0)
+    out["bcast"] = z.cpu().numpy().copy()
+    try:
+        comm.all_reduce(torch.zeros(4, dtype=torch.float64, device="cuda"))
+        out["typeerr"] = False
+    except TypeError:
+        out["typeerr"] = True
+    comm.destroy()
+    try:
+        comm.all_reduce(x)
+        out["dead"] = False
+    except RuntimeError:
+        out["dead"] = True
+    q.put((rank, out, D.NativeComm.library()))
+
+
+def test_native_comm_collectives_one_rank():
+    """nnhipCommUniqueId -> nnhipCommInitRank -> nnhipAllReduceSumF32 / AvgF32 / BroadcastF32 -> nnhipCommDestroy on a 1-rank
+    communicator: every collective is the identity, the handle dies loudly, the bound library is an RCCL."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no HIP device is visible")
+    out, lib = _spawn1(_native_collectives, ())
+    v = np.arange(1, 1025, dtype=np.float32)
+    for k in ("sum", "avg", "bcast"):
+        np.testing.assert_array_equal(out[k], v)
+    assert out["typeerr"] and out["dead"]
+    assert "rccl" in lib[0] and lib[1] > 20000, lib
+
+
+def test_native_comm_two_ranks_when_two_gpus_are_visible():
+    """Two ranks, two GPUs, the id shipped through a TCPStore (no torch process group): SUM / AVG / broadcast values."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no HIP device is visible")
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (the driver's multi-GPU tier)")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q, port = ctx.Queue(), _free_port()
+    ps = [ctx.Process(target=_native_collectives, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = dict((r, o) for r, o, _ in (q.get(timeout=300) for _ in ps))
+    for p in ps:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    v = np.arange(1, 1025, dtype=np.float32)
+    for r in range(2):
+        np.testing.assert_array_equal(got[r]["sum"], 3 * v)
+        np.testing.assert_array_equal(got[r]["avg"], 1.5 * v)
+        np.testing.assert_array_equal(got[r]["bcast"], v)
