@@ -588,10 +588,10 @@ def test_mlp_optimizer_in_backward_is_bit_identical(hip, graphed, opt_name):
 
 
 def test_fused_backward_adam_makes_pending_outputs_stale(hip):
-    """optimizer.fuse_backward(True): the backward launch itself updates W2 / b2, so the MLP's logits -- whose GEMM went into the
-    fused CrossEntropy launch and which are still pending -- must raise when read between backward() and step(), not silently
-    recompute with the updated weights (advisor, round 3).  Without fuse_backward the same read is legal and returns the
-    forward-time logits."""
+    """optimizer.fuse_backward(True): the backward launch itself updates the parameters, so an output that is still pending --
+    the hidden Linear's, whose GEMM rode in the ReLU's launch -- must raise when read between backward() and step(), not
+    silently recompute with the updated W1 / b1 (advisor, round 3).  Without fuse_backward the same read is legal and returns the
+    forward-time pre-activation."""
     import neunet_hip.nn as nn
     from neunet_hip.optim import Adam
     rng = np.random.default_rng(5)
@@ -607,7 +607,8 @@ def test_fused_backward_adam_makes_pending_outputs_stale(hip):
                 self.l1, self.relu, self.l2 = nn.Linear(784, 128), nn.ReLU(), nn.Linear(128, 10)
 
             def forward(self, x):
-                return self.l2(self.relu(self.l1(x)))
+                self.z1 = self.l1(x)
+                return self.l2(self.relu(self.z1))
 
         m = MLP()
         opt = Adam(m.parameters(), lr=1e-2)
@@ -617,18 +618,18 @@ def test_fused_backward_adam_makes_pending_outputs_stale(hip):
 
     for fuse in (False, True):
         model, opt = build(fuse)
-        ref = O.MLPState(*[p.numpy().copy() for p in model.parameters()], lr=1e-2)
+        W1, b1 = host(model.l1.weight.data).copy(), host(model.l1.bias.data).copy()
         opt.zero_grad()
         out = model(T(hip, X, requires_grad=False))
         loss = nn.CrossEntropyLoss()(out, T(hip, Y, dtype=np.int32, requires_grad=False))
-        pending = out.pending()
+        assert model.z1.pending()
         loss.backward()
         if fuse:
-            assert pending and opt._stepped_in_backward        # the one-launch backward + Adam really ran
+            assert opt._stepped_in_backward                    # the one-launch backward + Adam really ran
             with pytest.raises(RuntimeError, match="never materialised"):
-                out.data
+                model.z1.data
         else:
-            np.testing.assert_allclose(host(out.data), ref.forward(X)[1], **TOL)
+            np.testing.assert_allclose(host(model.z1.data), O.linear_forward(X, W1, b1), **TOL)
         opt.step()
 
 
