@@ -18,8 +18,8 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIBDIR = os.path.join(HERE, "neunet_hip", "lib")
 LIB = os.path.join(LIBDIR, "libneunet_hip.so")
-SOURCES = ["runtime.hip", "gemm.hip", "gemm_small.hip", "gemm_bf3.hip", "gemm_pst.hip", "elementwise.hip", "rowops.hip", "optim.hip", "linear.hip", "conv2d.hip", "embedding.hip", "pool_norm.hip", "attention.hip", "comm.hip"]
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(CSRC, "adam_device.h"), os.path.join(CSRC, "gemm_small.h"),
+SOURCES = ["runtime.hip", "gemm.hip", "gemm_small.hip", "gemm_bf3.hip", "gemm_pst.hip", "elementwise.hip", "rowops.hip", "optim.hip", "linear.hip", "conv2d.hip", "conv_mfma.hip", "embedding.hip", "pool_norm.hip", "attention.hip", "comm.hip"]
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_common.h"), os.path.join(CSRC, "adam_device.h"), os.path.join(CSRC, "gemm_small.h"), os.path.join(CSRC, "conv_common.h"),
            os.path.join(os.path.dirname(HERE), "include", "neunet_hip.h")]
 ARCH = "gfx950"
 

@@ -1,339 +1,27 @@
-// conv2d.hip -- Conv2d forward / backward as implicit GEMM on fp32 MFMA (gfx950).
+// conv2d.hip -- Conv2d entry points (nnhipConv2dForward / Backward and the fused small-layer variants), the direct kernels of the
+// <= 16-channel 3x3 layers (the conv classifier, C5) and the partial-sum reduces.  Layers above 16 channels run as implicit GEMM on
+// the fp32 MFMA: conv_mfma.hip.
 // CPU semantics: neunet/nn/layers/conv2d.py:297-355 (forward: zero-pad, dilate W, 6-D strided view,
 // einsum "bihwkl,oikl->bohw") and :16-115 (backward: dW / db / dX einsums).  No im2col buffer ever
-// exists in HBM: the B operand of each GEMM is gathered from the NCHW tensor straight into LDS.
+// exists in HBM.
 //
 //   forward : O[b,co,ho,wo]  = sum_{ci,r,s} W[co,ci,r,s] * X[b,ci, ho*sh-pu+r*dh, wo*sw-pl+s*dw] + bias[co]
-//             GEMM  M = Cout, K = Cin*kh*kw, N = B*Ho*Wo      (A = W, k-major;  B = gathered X)
 //   dgrad   : dX[b,ci,h,w]   = sum_{co,r,s} W[co,ci,r,s] * dO[b,co,(h+pu-r*dh)/sh,(w+pl-s*dw)/sw]
 //             (terms exist only where the divisions are exact and in range)
-//             GEMM  M = Cin,  K = Cout*kh*kw, N = B*H*W        (A = gathered W;  B = gathered dO)
-//   wgrad   : dW[co,(ci,r,s)] = sum_{b,ho,wo} dO[b,co,ho,wo] * X[b,ci,ho*sh-pu+r*dh, wo*sw-pl+s*dw]
-//             GEMM  M = Cout, N = Cin*kh*kw (+1), K = B*Ho*Wo  -- long reduction, tiny output:
-//             split over K-chunks (one per block), deterministic partials + reduce kernel.
-//             db[co] = sum dO is the same GEMM against an extra all-ones column (column N).
-//
-// Tiles: M-tile 32 (one 32x32x2 MFMA row tile; Cout/Cin > 32 loop over blockIdx.y).  At the C5 shapes
-// (K = 9/72, Cout = 8/16) these kernels are HBM/latency bound, not MFMA bound -- the MFMA
-// just keeps the FMA work off the VALU while the waves gather.
+//   wgrad   : dW[co,(ci,r,s)] = sum_{b,ho,wo} dO[b,co,ho,wo] * X[b,ci,ho*sh-pu+r*dh, wo*sw-pl+s*dw];  db[co] = sum dO
+// At the C5 shapes (K = 9/72, Cout = 8/16) the work is HBM/latency bound, not MFMA bound.
 #include <stdlib.h>
 
 #include <mutex>
 
-#include "common.h"
+#include "conv_common.h"
 
 namespace nnhip {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-struct ConvGeom {
-    int B, Cin, H, W, Cout, kh, kw, sh, sw, dh, dw, pu, pl, Ho, Wo;
-};
-
-// =================================================================================================
-// forward / dgrad: implicit GEMM, block tile (32 MT) x 256, BK = 16, two LDS stages, one barrier per k-step
-// =================================================================================================
-// MT = 32-row tiles per block (1 / 2 / 4 by the number of output channels of the GEMM: Cout forward, Cin dgrad).  Wave w
-// owns columns [64 w, 64 w + 64) of the block's 256 pixels and ALL MT row tiles: every gathered source element feeds MT
-// MFMAs, so at MT = 4 a k-step is 64 fp32 MFMAs per wave (4096 matrix-pipe cycles) against 16 gathered elements and 8
-// weights per thread.  (Round 2's kernel had MT = 1 with per-element integer divisions in the gather and both barriers
-// exposed: the vector work of the gather -- on gfx950 paid in matrix-pipe time, DESIGN 5 -- was larger than the MFMAs.)
-//   * the reduction index k = (source channel, r, s) is block-uniform: (cs, r, s) are carried as SCALAR counters and
-//     stepped, no division anywhere in the loop (dgrad with stride > 1 keeps one per element: the output pixel exists
-//     only where (y + pu - r dh) is a multiple of the stride);
-//   * a thread gathers ONE pixel column (consecutive lanes = consecutive pixels: coalesced rows of the source image)
-//     for the 16 k of a tile, next tile's loads are issued before this tile's MFMAs and written to the other LDS stage
-//     after them.
-constexpr int CF_BK = 16;
-constexpr int CF_BN = 256;
-
-template <bool DGRAD, int MT>
-__global__ __launch_bounds__(256, MT == 4 ? 2 : 3) void conv_igemm_kernel(const float* __restrict__ Wt,
-                                                                          const float* __restrict__ Src,
-                                                                          const float* __restrict__ bias,
-                                                                          float* __restrict__ Dst, const ConvGeom g) {
-    constexpr int BMT = 32 * MT;
-    constexpr int ALD = CF_BK + 4;
-    constexpr int APT = BMT * CF_BK / 256;           // weights per thread per tile: 2 / 4 / 8
-    __shared__ __attribute__((aligned(16))) float As[2][BMT * ALD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][CF_BK * CF_BN];
-
-    const int khkw = g.kh * g.kw;
-    const int M = DGRAD ? g.Cin : g.Cout;
-    const int Cs = DGRAD ? g.Cout : g.Cin;          // source channels (reduction)
-    const int Hs = DGRAD ? g.Ho : g.H, Ws = DGRAD ? g.Wo : g.W;
-    const int Hd = DGRAD ? g.H : g.Ho, Wd = DGRAD ? g.W : g.Wo;
-    const int K = Cs * khkw;
-    const int64_t HWd = (int64_t)Hd * Wd, HWs = (int64_t)Hs * Ws;
-    const int64_t N = (int64_t)g.B * HWd;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, lh = lane >> 5;
-    const int m0 = blockIdx.y * BMT;
-
-    // this thread gathers column n = blockIdx.x*256 + tid for every k of a tile
-    const int64_t n = (int64_t)blockIdx.x * CF_BN + tid;
-    const bool n_ok = n < N;
-    int b = 0, yd = 0, xd = 0;
-    if (n_ok) {
-        b = (int)(n / HWd);
-        const int rem = (int)(n - (int64_t)b * HWd);
-        yd = rem / Wd;
-        xd = rem - yd * Wd;
-    }
-    // forward: source pixel of tap (r, s) = (y0 + r dh, x0 + s dw);  dgrad: output pixel = ((y0 - r dh) / sh, (x0 - s dw) / sw)
-    const int y0 = DGRAD ? yd + g.pu : yd * g.sh - g.pu;
-    const int x0 = DGRAD ? xd + g.pl : xd * g.sw - g.pl;
-    const bool unit = g.sh == 1 && g.sw == 1;
-    // Branch-free gather: both operands are read through buffer descriptors whose num_records is the tensor's size, and an
-    // element that does not exist (padding, a k or m past the end, a pixel past N) is given the offset 0xFFFFFFFF -- the
-    // hardware returns 0 for it.  Byte offset of tap (cs, r, s) for this thread's pixel = pbase + koff, koff block-uniform.
-    const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Src), 0, (int)((int64_t)g.B * Cs * HWs * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Wt), 0, (int)((int64_t)g.Cout * g.Cin * khkw * 4), 0x00020000);
-    const unsigned pbase = n_ok ? (unsigned)(((int64_t)b * Cs * HWs + (int64_t)y0 * Ws + x0) * 4) : 0u;   // wraps for negative y0 / x0: only used when in range
-    const int sgn = DGRAD ? -1 : 1;
-
-    // A-tile slots of this thread: element a (0..APT-1) is weight (m = am, kk = ak + a) with APT consecutive k of one row
-    const int am = tid / (CF_BK / APT), ak = (tid % (CF_BK / APT)) * APT;
-    const bool m_ok = m0 + am < M;
-
-    f32x16 acc[MT][2];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][t][e] = 0.f;
-
-    float ra[APT], rb[CF_BK];
-    // scalar reduction counters of the NEXT tile to fetch: k = (cs, r, s)
-    int fk = 0, fcs = 0, fr = 0, fs = 0;
-    auto fetch = [&]() {
-        // ---- weights ------------------------------------------------------------------------------
-#pragma unroll
-        for (int a = 0; a < APT; ++a) {
-            const int k = fk + ak + a;
-            unsigned off;
-            if constexpr (DGRAD) {
-                const int co = k / khkw, rs = k - co * khkw;              // (per thread, APT per tile: not the hot part)
-                off = (unsigned)((((int64_t)co * g.Cin + (m0 + am)) * khkw + rs) * 4);
-            } else {
-                off = (unsigned)(((int64_t)(m0 + am) * K + k) * 4);
-            }
-            off = (m_ok && k < K) ? off : 0xFFFFFFFFu;
-            ra[a] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_w, off, 0, 0));
-        }
-        // ---- gathered source pixels: k steps through (cs, r, s) with scalar counters, no branches ---------------
-        int cs = fcs, r = fr, sx = fs;
-#pragma unroll
-        for (int kk = 0; kk < CF_BK; ++kk) {
-            const int dy = r * g.dh * sgn, dx = sx * g.dw * sgn;          // scalar
-            unsigned off;
-            bool ok;
-            if (unit || !DGRAD) {
-                const int ys = y0 + dy, xs = x0 + dx;
-                ok = (unsigned)ys < (unsigned)Hs && (unsigned)xs < (unsigned)Ws;
-                off = pbase + (unsigned)((cs * (int)HWs + dy * Ws + dx) * 4);
-            } else {
-                const int ty = y0 + dy, tx = x0 + dx;
-                const int ys = ty / g.sh, xs = tx / g.sw;
-                ok = ty >= 0 && tx >= 0 && ys * g.sh == ty && xs * g.sw == tx && ys < Hs && xs < Ws;
-                off = (unsigned)((((int64_t)b * Cs + cs) * HWs + (int64_t)ys * Ws + xs) * 4);
-            }
-            off = (ok && n_ok && cs < Cs) ? off : 0xFFFFFFFFu;
-            rb[kk] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_src, off, 0, 0));
-            const int w1 = sx + 1 == g.kw;
-            sx = w1 ? 0 : sx + 1;
-            const int w2 = w1 && (r + 1 == g.kh);
-            r = w2 ? 0 : r + w1;
-            cs += w2;
-        }
-        fcs = cs; fr = r; fs = sx; fk += CF_BK;
-    };
-    auto commit = [&](int st) {
-#pragma unroll
-        for (int a = 0; a < APT; ++a) As[st][am * ALD + ak + a] = ra[a];
-#pragma unroll
-        for (int kk = 0; kk < CF_BK; ++kk) Bs[st][kk * CF_BN + tid] = rb[kk];
-    };
-
-    const int nk = (K + CF_BK - 1) / CF_BK;
-    fetch();
-    commit(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        fetch();                                           // next tile's loads travel under this tile's MFMAs (past the end: zeros)
-#pragma unroll
-        for (int gq = 0; gq < CF_BK / 8; ++gq) {
-            float a[MT][4];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const float4 av = *reinterpret_cast<const float4*>(&As[cur][(i * 32 + l31) * ALD + gq * 8 + lh * 4]);
-                a[i][0] = av.x; a[i][1] = av.y; a[i][2] = av.z; a[i][3] = av.w;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const float bv = Bs[cur][(gq * 8 + j + 4 * lh) * CF_BN + wave * 64 + t * 32 + l31];
-#pragma unroll
-                    for (int i = 0; i < MT; ++i) acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], bv, acc[i][t], 0, 0, 0);
-                }
-        }
-        commit(cur ^ 1);
-        __syncthreads();
-    }
-
-    // ---- epilogue: acc[i][t][e] -> row m = 32 i + (e&3)+8*(e>>2)+4*lh, column l31 of n-tile t ------------------
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int64_t nn = (int64_t)blockIdx.x * CF_BN + wave * 64 + t * 32 + l31;
-        if (nn >= N) continue;
-        const int bb = (int)(nn / HWd);
-        const int64_t sp = nn - (int64_t)bb * HWd;
-        float* dst = Dst + (int64_t)bb * M * HWd + sp;
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (m < M) {
-                    float v = acc[i][t][e];
-                    if (!DGRAD && bias) v += bias[m];
-                    dst[(int64_t)m * HWd] = v;
-                }
-            }
-    }
-}
-template <bool DGRAD>
-static int launch_conv_igemm(const float* Wt, const float* Src, const float* bias, float* Dst, const ConvGeom& g, hipStream_t st) {
-    const int M = DGRAD ? g.Cin : g.Cout;
-    const int64_t N = DGRAD ? (int64_t)g.B * g.H * g.W : (int64_t)g.B * g.Ho * g.Wo;
-    const unsigned gx = (unsigned)ceil_div(N, CF_BN);
-    // 32-bit byte offsets into both operands (buffer loads): each tensor below 2 GiB
-    const int64_t src_elems = DGRAD ? (int64_t)g.B * g.Cout * g.Ho * g.Wo : (int64_t)g.B * g.Cin * g.H * g.W;
-    NNHIP_CHECK_ARG(src_elems < ((int64_t)1 << 29) && (int64_t)g.Cout * g.Cin * g.kh * g.kw < ((int64_t)1 << 29), NNHIP_EINVAL,
-                    "conv2d: the implicit-GEMM kernel addresses each operand with 32-bit byte offsets (tensor >= 2 GiB)");
-    if (M <= 32) hipLaunchKernelGGL((conv_igemm_kernel<DGRAD, 1>), dim3(gx, (unsigned)ceil_div(M, 32)), dim3(256), 0, st, Wt, Src, bias, Dst, g);
-    else if (M <= 64) hipLaunchKernelGGL((conv_igemm_kernel<DGRAD, 2>), dim3(gx, (unsigned)ceil_div(M, 64)), dim3(256), 0, st, Wt, Src, bias, Dst, g);
-    else hipLaunchKernelGGL((conv_igemm_kernel<DGRAD, 4>), dim3(gx, (unsigned)ceil_div(M, 128)), dim3(256), 0, st, Wt, Src, bias, Dst, g);
-    NNHIP_LAUNCH_CHECK(DGRAD ? "conv_igemm_kernel<dgrad>" : "conv_igemm_kernel<fwd>");
-    return 0;
-}
-
-// =================================================================================================
-// wgrad (+ db through an all-ones column)
-// =================================================================================================
-constexpr int CW_BK = 32;
-constexpr int CW_BN = 128;  // 4 n-tiles, one per wave
-
-struct ColInfo {
-    int ci, dy, dx, kind;  // kind: 0 = gather column, 1 = all-ones column (db), 2 = padding (zero)
-};
-
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict__ X,
-                                                         const float* __restrict__ dO,
-                                                         float* __restrict__ part, const ConvGeom g,
-                                                         int64_t k_per_block, int ncols) {
-    __shared__ __attribute__((aligned(16))) float As[32 * (CW_BK + 4)];
-    __shared__ __attribute__((aligned(16))) float Bs[CW_BN * (CW_BK + 4)];
-    __shared__ ColInfo tab[CW_BN];
-
-    const int khkw = g.kh * g.kw;
-    const int Nw = g.Cin * khkw;  // real dW columns; column Nw is the ones column
-    const int64_t HWo = (int64_t)g.Ho * g.Wo, HW = (int64_t)g.H * g.W;
-    const int64_t K = (int64_t)g.B * HWo;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, lh = lane >> 5;
-    const int m0 = blockIdx.y * 32, n0 = blockIdx.z * CW_BN;
-
-    if (tid < CW_BN) {
-        const int n = n0 + tid;
-        ColInfo c;
-        if (n < Nw) {
-            const int ci = n / khkw, rs = n - ci * khkw;
-            const int r = rs / g.kw, s = rs - r * g.kw;
-            c.ci = ci; c.dy = r * g.dh - g.pu; c.dx = s * g.dw - g.pl; c.kind = 0;
-        } else {
-            c.ci = 0; c.dy = 0; c.dx = 0; c.kind = (n == Nw) ? 1 : 2;
-        }
-        tab[tid] = c;
-    }
-    __syncthreads();
-
-    const bool wave_active = n0 + wave * 32 < ncols;  // wave-uniform: does my n-tile hold any column?
-    f32x16 acc;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-
-    const int64_t kbeg = (int64_t)blockIdx.x * k_per_block;
-    const int64_t kend = min(K, kbeg + k_per_block);
-    const int kk = tid & 31, rg = tid >> 5;  // thread <-> position kk of the k-step, row group rg (0..7)
-
-    for (int64_t k0 = kbeg; k0 < kend; k0 += CW_BK) {
-        const int64_t k = k0 + kk;
-        const bool k_ok = k < kend;
-        int b = 0, ho = 0, wo = 0;
-        if (k_ok) {
-            b = (int)(k / HWo);
-            const int rem = (int)(k - (int64_t)b * HWo);
-            ho = rem / g.Wo;
-            wo = rem - ho * g.Wo;
-        }
-        // A tile: dO[b, m0+m, ho, wo], rows m = rg + 8 i
-        const float* dO_b = dO + (int64_t)b * g.Cout * HWo + (int64_t)ho * g.Wo + wo;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = rg + 8 * i;
-            As[m * (CW_BK + 4) + kk] = (k_ok && m0 + m < g.Cout) ? dO_b[(int64_t)(m0 + m) * HWo] : 0.f;
-        }
-        // B tile: gathered X, columns c = rg + 8 i
-        const float* X_b = X + (int64_t)b * g.Cin * HW;
-        const int y0 = ho * g.sh, x0 = wo * g.sw;
-#pragma unroll
-        for (int i = 0; i < CW_BN / 8; ++i) {
-            const int c = rg + 8 * i;
-            const ColInfo ci = tab[c];
-            float v = 0.f;
-            if (k_ok) {
-                if (ci.kind == 0) {
-                    const int ys = y0 + ci.dy, xs = x0 + ci.dx;
-                    if (ys >= 0 && ys < g.H && xs >= 0 && xs < g.W) v = X_b[(int64_t)ci.ci * HW + (int64_t)ys * g.W + xs];
-                } else if (ci.kind == 1) {
-                    v = 1.f;
-                }
-            }
-            Bs[c * (CW_BK + 4) + kk] = v;
-        }
-        __syncthreads();
-        if (wave_active) {
-#pragma unroll
-            for (int gq = 0; gq < CW_BK / 8; ++gq) {
-                const float4 av = *reinterpret_cast<const float4*>(&As[l31 * (CW_BK + 4) + gq * 8 + lh * 4]);
-                const float4 bv = *reinterpret_cast<const float4*>(&Bs[(wave * 32 + l31) * (CW_BK + 4) + gq * 8 + lh * 4]);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
-            }
-        }
-        __syncthreads();
-    }
-
-    // partial tile -> part[chunk][Cout][ncols]
-    if (wave_active) {
-        const int n = n0 + wave * 32 + l31;
-        if (n < ncols) {
-            float* dst = part + ((int64_t)blockIdx.x * g.Cout) * ncols + n;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (m < g.Cout) dst[(int64_t)m * ncols] = acc[e];
-            }
-        }
-    }
-}
+// The MFMA implicit-GEMM kernels (any layer above 16 channels) live in conv_mfma.hip; this file holds the entry points, the
+// direct kernels of the small-channel 3x3 layers (C5) and the partial-sum reduces they share.
 
 // dW[m][n] = sum_c part[c][m][n] (n < Nw);  db[m] = sum_c part[c][m][Nw].  One wave per output element:
 // the 64 lanes stride over the chunks and meet in a shuffle reduction (fixed order: deterministic).
@@ -1453,7 +1141,7 @@ extern "C" int nnhipConv2dForward(const float* X, const float* W, const float* b
         NNHIP_LAUNCH_CHECK("conv_direct_fwd_kernel");
         return 0;
     }
-    return launch_conv_igemm<false>(W, X, bias, O, g, (hipStream_t)s);
+    return conv_mfma_forward(X, W, bias, O, g, (hipStream_t)s);
 }
 
 // the LDS plan of conv_mfma_wgrad_kernel for geometry g: true iff that kernel can run it
@@ -1591,7 +1279,7 @@ extern "C" int nnhipConv2dBackward(const float* X, const float* W, const float* 
         else hipLaunchKernelGGL(conv_direct_dgrad_kernel<16>, dgrid, dim3(256), 0, st, W, dO, dX, g);
         NNHIP_LAUNCH_CHECK("conv_direct_dgrad_kernel");
     } else if (dX) {
-        if (int rc = launch_conv_igemm<true>(W, dO, nullptr, dX, g, st)) return rc;
+        if (int rc = conv_mfma_dgrad(dO, W, dX, g, st)) return rc;
     }
     size_t wg_lds = ((size_t)g.Cin * g.H * g.W + (size_t)g.Cout * g.Ho * g.Wo) * sizeof(float);
     if ((dW || db) && direct && g.kh == 3 && g.kw == 3 && wg_lds <= 60 * 1024) {
@@ -1634,21 +1322,7 @@ extern "C" int nnhipConv2dBackward(const float* X, const float* W, const float* 
         if (rc) return rc;
         return conv_reduce(part, dW, db, blocks, g.Cout, Nw, ncols, st, deferred);
     } else if (dW || db) {
-        const int Nw = g.Cin * g.kh * g.kw;
-        const int ncols = Nw + 1;
-        const int64_t K = (int64_t)g.B * g.Ho * g.Wo;
-        int64_t kpb = ceil_div(ceil_div(K, 768), CW_BK) * CW_BK;
-        if (kpb < 256) kpb = 256;
-        const int chunks = (int)ceil_div(K, kpb);
-        float* part = static_cast<float*>(workspace((size_t)chunks * g.Cout * ncols * sizeof(float)));
-        NNHIP_CHECK_ARG(part != nullptr, NNHIP_ENOMEM, "nnhipConv2dBackward: workspace allocation failed");
-        dim3 grid((unsigned)chunks, (unsigned)ceil_div(g.Cout, 32), (unsigned)ceil_div(ncols, CW_BN));
-        hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, st, X, dO, part, g, kpb, ncols);
-        NNHIP_LAUNCH_CHECK("conv_wgrad_kernel");
-        const int total = g.Cout * ncols;
-        hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)ceil_div(total, 4)), dim3(256), 0, st,
-                           part, dW, db, chunks, g.Cout, Nw, ncols);
-        NNHIP_LAUNCH_CHECK("conv_wgrad_reduce_kernel");
+        if (int rc = conv_mfma_wgrad(X, dO, dW, db, g, st)) return rc;
     }
     return 0;
 }

@@ -1399,9 +1399,10 @@ def test_conv2d_vs_oracle(hip, xshape, cout, ks, stride, pad, dil):
 
 
 def test_conv2d_igemm_random_geometries(hip):
-    """The implicit-GEMM forward / dgrad kernels (channels > 16: block tiles of 32 / 64 / 128 channels x 256 pixels, scalar
-    (cs, r, s) counters, buffer-load gather with out-of-range offsets) on 24 random geometries -- kernel sizes 1..4, strides
-    1..3, dilations 1..2, asymmetric padding, channel counts on both sides of every tile edge -- against the oracle."""
+    """The MFMA implicit-GEMM kernels of conv_mfma.hip (channels > 16: forward / dgrad with the tap outermost and repacked
+    weights, 128 x 128 or 64 x 256 block tiles; wgrad over (image, pixel) k-tiles with (tap slot, channel) columns) on 24 random
+    geometries -- kernel sizes 1..4, strides 1..3, dilations 1..2, asymmetric padding, channel counts on both sides of every tile
+    edge, pixel counts that are and are not multiples of four (16-byte and dword dO loads) -- against the oracle."""
     from neunet_hip.nn.experimental import HIPConv2d
     rng = np.random.default_rng(77)
     done = 0
@@ -1433,6 +1434,51 @@ def test_conv2d_igemm_random_geometries(hip):
         assert_close_scaled(host(layer.weight.grad), dW, err_msg=tag)
         assert_close_scaled(host(layer.bias.grad), db, err_msg=tag)
         done += 1
+
+
+@pytest.mark.parametrize("B,cin,H,W,cout,k,stride,pad,dil", [
+    (3, 160, 20, 18, 96, 3, 1, 1, 1),      # 128-row tile; Cin > 128: two channel blocks per tap; even k-tiles per chunk; float4 dO loads
+    (3, 160, 20, 17, 96, 3, 1, 1, 1),      # odd k-tiles per chunk (the pipeline's look-ahead tile must not enter db)
+    (2, 300, 9, 11, 40, 3, 1, 1, 1),       # 64-row tile, 256-channel tap slots, two channel blocks; 99 pixels: dword dO loads
+    (5, 64, 13, 13, 128, 3, 2, 1, 1),      # stride 2: dgrad's exact-division test per tap; 49 output pixels per image
+    (2, 48, 16, 16, 80, (1, 5), 1, (0, 2), (1, 2)),   # 1 x 5 taps with dilation 2, Cin no multiple of the 32-deep k-tile
+    (1, 32, 40, 40, 64, 1, 1, 0, 1),       # 1 x 1 convolution: one tap, TPT = 8 slots of which one is used
+])
+def test_conv2d_mfma_kernels_through_the_c_abi(hip, B, cin, H, W, cout, k, stride, pad, dil):
+    """nnhipConv2dForward / nnhipConv2dBackward on layers that take conv_mfma.hip, called with every output combination the ABI
+    allows (dX only, dW only, db only, all three): each must equal the oracle (conv2d.py:297-355, 16-115), and the separately
+    requested outputs must be bit-identical to the jointly requested ones (same kernels, same reduction order)."""
+    import ctypes
+    from neunet_hip._lib import Conv2dDesc, call_hip_function as call, get_current_stream_ptr
+    kh, kw = (k, k) if isinstance(k, int) else k
+    st2 = (stride, stride) if isinstance(stride, int) else stride
+    pd2 = (pad, pad) if isinstance(pad, int) else pad
+    dl2 = (dil, dil) if isinstance(dil, int) else dil
+    rng = np.random.default_rng(B * 1000 + cin)
+    X = rng.uniform(-1, 1, (B, cin, H, W)).astype(np.float32)
+    Wt = (rng.uniform(-1, 1, (cout, cin, kh, kw)) / np.sqrt(cin * kh * kw)).astype(np.float32)
+    bias = rng.uniform(-0.3, 0.3, cout).astype(np.float32)
+    Or = O.conv2d_forward(X, Wt, bias, st2, pd2, dl2)
+    dO = rng.uniform(-1, 1, Or.shape).astype(np.float32)
+    dXr, dWr, dbr = O.conv2d_backward(X, Wt, True, dO, st2, pd2, dl2)
+    d = Conv2dDesc(B, cin, H, W, cout, kh, kw, st2[0], st2[1], dl2[0], dl2[1], pd2[0], pd2[0], pd2[1], pd2[1])
+    st = get_current_stream_ptr()
+    x, w, b_, do = dev(X), dev(Wt), dev(bias), dev(dO)
+    out = torch.empty(Or.shape, device="cuda")
+    call("nnhipConv2dForward", x, w, b_, out, ctypes.byref(d), st)
+    np.testing.assert_allclose(host(out), Or, **TOL)
+    call("nnhipConv2dForward", x, w, None, out, ctypes.byref(d), st)                       # bias = NULL
+    np.testing.assert_allclose(host(out), Or - bias[None, :, None, None], **TOL)
+    dx, dw, db = torch.empty_like(x), torch.empty_like(w), torch.empty_like(b_)
+    call("nnhipConv2dBackward", x, w, do, dx, dw, db, ctypes.byref(d), st)
+    np.testing.assert_allclose(host(dx), dXr, **TOL)
+    assert_close_scaled(host(dw), dWr)
+    assert_close_scaled(host(db), dbr)
+    dx2, dw2, db2 = torch.full_like(dx, 7.0), torch.full_like(dw, 7.0), torch.full_like(db, 7.0)
+    call("nnhipConv2dBackward", x, w, do, dx2, None, None, ctypes.byref(d), st)
+    call("nnhipConv2dBackward", x, w, do, None, dw2, None, ctypes.byref(d), st)
+    call("nnhipConv2dBackward", x, w, do, None, None, db2, ctypes.byref(d), st)
+    assert torch.equal(dx2, dx) and torch.equal(dw2, dw) and torch.equal(db2, db)
 
 
 # -------------------------------------------------------------------------------------- optimizers

@@ -296,8 +296,8 @@ def main():
             print(f"{f'{Bn} x {I} x {Od}':>20s} {t_ff:10.4f} {t_f2:10.4f} {t_bf:10.4f} {t_b2:10.4f} {tk:11.4f} {2.0 * Bn * I * Od / (tk * 1e-3) / 1e12:8.2f}", flush=True)
 
     if want("convg"):
-        # the implicit-GEMM conv kernels at MFMA-bound shapes (channels > 16: conv_igemm_kernel<fwd|dgrad, MT>)
-        for (B, Cin, H, Cout) in [(64, 64, 56, 128), (128, 128, 28, 128), (64, 32, 56, 64)]:
+        # the implicit-GEMM conv kernels at MFMA-bound shapes (channels > 16: conv_mfma.hip)
+        for (B, Cin, H, Cout) in [(64, 64, 56, 128), (128, 128, 28, 128), (64, 32, 56, 64), (64, 256, 14, 256), (32, 512, 7, 512)]:
             X = rnd(B, Cin, H, H)
             W = rnd(Cout, Cin, 3, 3) / 24
             bb = rnd(Cout)
