@@ -99,6 +99,11 @@ struct ConvTapArgs {
     int sh, sw, dh, dw, pu, pl;
     int tiles_m, tiles_n;
     int cvec;            // Hd*Wd % 4 == 0 and Dst 16-B aligned: float4 stores
+    // The grid: `main_blocks` blocks that each own a whole tile (pixel tiles [0, tn0) x all channel tiles), then the tail -- pixel
+    // tiles [tn0, tiles_n) with the reduction cut into `splits` ranges of `ktps` k-tiles, one block each, whose partial results go to
+    // slab[split][m][n - n_start] (n_start = tn0 * BN, row pitch `scnt`); conv_tap_reduce_kernel adds them (+ bias) into Dst
+    int main_blocks, tn0, splits, ktps, scnt;
+    float* slab;
 };
 
 template <int WM>
@@ -163,8 +168,12 @@ __global__ __launch_bounds__(256, WM == 2 ? 2 : 3) void conv_tap_kernel(const Co
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / C::WN, wn = wave % C::WN, l31 = lane & 31, lh = lane >> 5;
     // m fastest: the tiles_m blocks that share a pixel tile are neighbours on one XCD (they read the same source pixels)
-    const int L = xcd_order((int)blockIdx.x, (int)gridDim.x);
-    const int tm = L % a.tiles_m, tn = L / a.tiles_m;
+    // (each part of the grid has its own XCD-aware order: blocks go to XCDs round-robin by blockIdx, so both parts stay balanced)
+    const bool is_tail = (int)blockIdx.x >= a.main_blocks;
+    const int L = is_tail ? xcd_order((int)blockIdx.x - a.main_blocks, (int)gridDim.x - a.main_blocks) : xcd_order((int)blockIdx.x, a.main_blocks);
+    const int split = is_tail ? L % a.splits : 0, tL = is_tail ? L / a.splits : L;   // the splits of a tile are neighbours too (same pixels)
+    const int tm = tL % a.tiles_m, tn = (is_tail ? a.tn0 : 0) + tL / a.tiles_m;
+    const int ktps = is_tail ? a.ktps : 1 << 30;
     const int m0 = tm * C::BM;
     const int64_t n0 = (int64_t)tn * C::BN;
     const int HWd = a.Hd * a.Wd, HWs = a.Hs * a.Ws;
@@ -234,9 +243,10 @@ __global__ __launch_bounds__(256, WM == 2 ? 2 : 3) void conv_tap_kernel(const Co
 
     // fetch state: the tile to be fetched NEXT is (ftap, fc0); it runs two tiles ahead of the multiply
     const int ctiles = a.Csp / C::BK;
-    const int T = taps * ctiles;
-    int ftap = 0, fc0 = 0;
-    unsigned fvoff = tap_voff(0);
+    const int kt0 = split * (is_tail ? a.ktps : 0);                        // this block's k-tiles: [kt0, kt0 + T)
+    const int T = (ktps < taps * ctiles - kt0 ? ktps : taps * ctiles - kt0);
+    int ftap = kt0 / ctiles, fc0 = (kt0 - (kt0 / ctiles) * ctiles) * C::BK;
+    unsigned fvoff = tap_voff(ftap);
     auto advance = [&]() {
         fc0 += C::BK;
         if (fc0 >= a.Csp) {
@@ -279,18 +289,23 @@ __global__ __launch_bounds__(256, WM == 2 ? 2 : 3) void conv_tap_kernel(const Co
                        fc0 + khalf * C::KPT, a.Cs, HWs4, sA, sB, wm, wn, l31, lh);
     }
 
-    // ---- epilogue: rows = channels m, columns = pixels n -> Dst[b][m][p] ------------------------------------------------------------
+    // ---- epilogue: rows = channels m, columns = pixels n -> Dst[b][m][p]  (split launch: slab[split][m][n - n_start]) -----------------
+    const bool to_slab = is_tail;
+    const int64_t n_start = (int64_t)a.tn0 * C::BN;
+    float* sbase = to_slab ? a.slab + (int64_t)split * a.M * a.scnt : nullptr;
     if (a.cvec) {
         const int64_t col = n0 + wn * 64 + (lane & 15) * 4;              // 4 consecutive pixels of one image (HWd % 4 == 0)
         const bool col_ok = col < N;
         const int cb_ = col_ok ? (int)(col / HWd) : 0;
-        float* dst = a.Dst + ((int64_t)cb_ * a.M) * HWd + (col - (int64_t)cb_ * HWd);
+        float* dst = to_slab ? sbase + (col - n_start) : a.Dst + ((int64_t)cb_ * a.M) * HWd + (col - (int64_t)cb_ * HWd);
+        const int64_t pitch = to_slab ? a.scnt : HWd;
         const int rbase = m0 + wm * 64;
+        const float* bias = to_slab ? nullptr : a.bias;
         conv_store_tile(acc, smem, wave, lane, l31, lh, [&](int row, int, float4 v) {
             const int m = rbase + row;
             if (m < a.M && col_ok) {
-                if (a.bias) { const float bv = a.bias[m]; v.x += bv; v.y += bv; v.z += bv; v.w += bv; }
-                *reinterpret_cast<float4*>(dst + (int64_t)m * HWd) = v;
+                if (bias) { const float bv = bias[m]; v.x += bv; v.y += bv; v.z += bv; v.w += bv; }
+                *reinterpret_cast<float4*>(dst + (int64_t)m * pitch) = v;
             }
         });
         return;
@@ -300,15 +315,34 @@ __global__ __launch_bounds__(256, WM == 2 ? 2 : 3) void conv_tap_kernel(const Co
         const int64_t col = n0 + wn * 64 + nn * 32 + l31;
         if (col >= N) continue;
         const int cb_ = (int)(col / HWd);
-        float* dst = a.Dst + ((int64_t)cb_ * a.M) * HWd + (col - (int64_t)cb_ * HWd);
+        float* dst = to_slab ? sbase + (col - n_start) : a.Dst + ((int64_t)cb_ * a.M) * HWd + (col - (int64_t)cb_ * HWd);
+        const int64_t pitch = to_slab ? a.scnt : HWd;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lh;
-                if (m < a.M) dst[(int64_t)m * HWd] = acc[i][nn][e] + (a.bias ? a.bias[m] : 0.f);
+                if (m < a.M) dst[(int64_t)m * pitch] = acc[i][nn][e] + ((a.bias && !to_slab) ? a.bias[m] : 0.f);
             }
     }
+}
+
+// Dst[b][m][p] = bias[m] + sum_s slab[s][m][n - n_start]  for the pixels n = b HWd + p >= n_start of a split launch (splits added in
+// order: deterministic).  One thread per (m, pixel); consecutive threads = consecutive pixels.
+__global__ __launch_bounds__(256) void conv_tap_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias,
+                                                              float* __restrict__ Dst, int splits, int M, int scnt, int64_t n_start,
+                                                              int64_t N, int HWd) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t cnt = N - n_start;
+    if (idx >= cnt * M) return;
+    const int m = (int)(idx / cnt);
+    const int64_t j = idx - (int64_t)m * cnt, n = n_start + j;
+    const float* src = slab + (int64_t)m * scnt + j;
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += src[(int64_t)k * M * scnt];
+    if (bias) s += bias[m];
+    const int64_t b = n / HWd;
+    Dst[(b * M + m) * HWd + (n - b * HWd)] = s;
 }
 
 // Wr[tap][m][c] (Mp x Csp per tap, zero padded) from W[Cout][Cin][taps]:  forward m = co, c = ci;  dgrad m = ci, c = co
@@ -338,22 +372,62 @@ static int launch_conv_tap(const float* W, const float* Src, const float* bias, 
     const int64_t src_bytes = (int64_t)g.B * Cs * Hs * Ws * 4;
     NNHIP_CHECK_ARG(src_bytes < ((int64_t)1 << 31) && wr_floats * 4 < ((int64_t)1 << 31), NNHIP_EINVAL,
                     "conv2d: the implicit-GEMM kernel addresses each operand with 32-bit byte offsets (tensor >= 2 GiB)");
-    float* Wr = static_cast<float*>(workspace((size_t)wr_floats * sizeof(float)));
+    const int64_t N = (int64_t)g.B * Hd * Wd;
+    const int tiles_m = Mp / BM;
+    const int64_t tiles_n = ceil_div(N, BN);
+    NNHIP_CHECK_ARG(tiles_n * tiles_m < ((int64_t)1 << 27), NNHIP_EINVAL, "conv2d: too many tiles");
+
+    // ---- plan ---------------------------------------------------------------------------------------------------------------------------
+    // Every block does the same work, so a grid runs in rounds of the chip's resident blocks (2 per CU at the 128-row tile, 3 at the
+    // 64-row one) and a last round with a handful of tiles costs a whole round (64->128 ch 56x56 B64: 1568 tiles = 3.06 rounds
+    // of 512 -> 4; measured 0.62 of the MFMA peak where the blocks themselves run at 0.8).  The tiles of the whole rounds get one
+    // block each; the pixel tiles of the ragged last round (or of a grid that never fills the chip: 7x7 feature maps) follow in the
+    // SAME grid with the reduction cut `splits` ways along the k-tiles -- short blocks that fill the slots the last full round
+    // frees -- each split a partial tile in a slab, added in order by a small reduce.
+    static const int cus = []() {
+        int d = 0, n = 0;
+        return (hipGetDevice(&d) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) == hipSuccess && n > 0) ? n : 256;
+    }();
+    static const bool split_on = []() { const char* e = getenv("NNHIP_CONV_TAIL_SPLIT"); return !e || atoi(e) != 0; }();
+    const int64_t slots = (int64_t)cus * (wm == 2 ? 2 : 3);
+    const int T = taps * (Csp / BK);
+    int64_t tn_main = (((tiles_n * tiles_m) / slots) * slots) / tiles_m;   // pixel tiles of the whole rounds
+    int64_t tail = tiles_n - tn_main;                                      // pixel tiles left
+    int splits = 1, ktps = T;
+    if (split_on && tail > 0) {
+        // the cut that finishes the tail soonest: s splits of k = ceil(T / s) k-tiles run in ceil(tail blocks * s / slots) rounds of
+        // (k + ~1.5) tile times each (a block's pipeline prologue costs about a tile and a half); a split keeps >= 3 k-tiles
+        double best = 1e30;
+        for (int sp = 1; sp <= 16 && sp <= (T >= 3 ? T / 3 : 1); ++sp) {
+            const int k = (int)ceil_div(T, sp), se = (int)ceil_div(T, k);
+            const double cost = (double)ceil_div(tail * tiles_m * se, slots) * (k + 1.5);
+            if (cost < best - 1e-9) { best = cost; splits = se; ktps = k; }
+        }
+    }
+    if (splits <= 1) { tn_main = tiles_n; tail = 0; splits = 1; ktps = T; }
+    const int64_t n_start = tn_main * BN, cnt = N - n_start, scnt = (cnt + 3) / 4 * 4;
+    NNHIP_CHECK_ARG(scnt < ((int64_t)1 << 31), NNHIP_EINVAL, "conv2d: too many pixels in the split tail");
+
+    // ---- one workspace reservation: repacked weights, then the tail's slab ----------------------------------------------------------------
+    const size_t wr_pad = ((size_t)wr_floats + 63) / 64 * 64;
+    const size_t slab_floats = tail > 0 ? (size_t)splits * M * scnt : 0;
+    float* Wr = static_cast<float*>(workspace((wr_pad + slab_floats) * sizeof(float)));
     NNHIP_CHECK_ARG(Wr != nullptr, NNHIP_ENOMEM, "conv2d: workspace allocation failed");
     hipLaunchKernelGGL(conv_repack_kernel, dim3((unsigned)ceil_div(wr_floats, 256)), dim3(256), 0, st, W, Wr, g.Cout, g.Cin, taps, Mp, Csp,
                        DGRAD ? 1 : 0);
     NNHIP_LAUNCH_CHECK("conv_repack_kernel");
+
     ConvTapArgs a;
     a.Wr = Wr; a.Src = Src; a.bias = bias; a.Dst = Dst;
     a.B = g.B; a.M = M; a.Mp = Mp; a.Cs = Cs; a.Csp = Csp; a.Hs = Hs; a.Ws = Ws; a.Hd = Hd; a.Wd = Wd; a.kh = g.kh; a.kw = g.kw;
     a.sh = g.sh; a.sw = g.sw; a.dh = g.dh; a.dw = g.dw; a.pu = g.pu; a.pl = g.pl;
-    const int64_t N = (int64_t)g.B * Hd * Wd;
-    a.tiles_m = Mp / BM;
-    const int64_t tiles_n = ceil_div(N, BN);
-    NNHIP_CHECK_ARG(tiles_n * a.tiles_m < ((int64_t)1 << 31), NNHIP_EINVAL, "conv2d: too many tiles");
-    a.tiles_n = (int)tiles_n;
+    a.tiles_m = tiles_m; a.tiles_n = (int)tiles_n;
     a.cvec = ((int64_t)Hd * Wd) % 4 == 0 && aligned16(Dst) ? 1 : 0;
-    const dim3 grid((unsigned)(tiles_n * a.tiles_m));
+    a.slab = nullptr; a.scnt = 0;
+    a.main_blocks = (int)(tn_main * tiles_m);
+    a.tn0 = (int)tn_main; a.splits = splits; a.ktps = ktps;
+    if (tail > 0) { a.slab = Wr + wr_pad; a.scnt = (int)scnt; }
+    const dim3 grid((unsigned)(a.main_blocks + tail * tiles_m * splits));
     if (wm == 2) {
         auto kern = conv_tap_kernel<DGRAD, 2>;
         static bool attr = false;
@@ -367,6 +441,11 @@ static int launch_conv_tap(const float* W, const float* Src, const float* bias, 
         hipLaunchKernelGGL((conv_tap_kernel<DGRAD, 1>), grid, dim3(256), TapCfg<1>::LDS, st, a);
     }
     NNHIP_LAUNCH_CHECK(DGRAD ? "conv_tap_kernel<dgrad>" : "conv_tap_kernel<fwd>");
+    if (tail > 0) {
+        hipLaunchKernelGGL(conv_tap_reduce_kernel, dim3((unsigned)ceil_div(cnt * M, 256)), dim3(256), 0, st, a.slab, bias, Dst, splits, M,
+                           (int)scnt, n_start, N, Hd * Wd);
+        NNHIP_LAUNCH_CHECK("conv_tap_reduce_kernel");
+    }
     return 0;
 }
 

@@ -1442,7 +1442,8 @@ def test_conv2d_igemm_random_geometries(hip):
     (2, 300, 9, 11, 40, 3, 1, 1, 1),       # 64-row tile, 256-channel tap slots, two channel blocks; 99 pixels: dword dO loads
     (5, 64, 13, 13, 128, 3, 2, 1, 1),      # stride 2: dgrad's exact-division test per tap; 49 output pixels per image
     (2, 48, 16, 16, 80, (1, 5), 1, (0, 2), (1, 2)),   # 1 x 5 taps with dilation 2, Cin no multiple of the 32-deep k-tile
-    (1, 32, 40, 40, 64, 1, 1, 0, 1),       # 1 x 1 convolution: one tap, TPT = 8 slots of which one is used
+    (1, 32, 40, 40, 64, 1, 1, 0, 1),       # 1 x 1 convolution: one tap, TPT = 8 slots of which one is used; too few k-tiles to split
+    (18, 32, 62, 62, 72, 3, 1, 1, 1),      # 541 pixel tiles: one whole round of 512 in the plain launch + 29 tiles in the split-K tail launch
 ])
 def test_conv2d_mfma_kernels_through_the_c_abi(hip, B, cin, H, W, cout, k, stride, pad, dil):
     """nnhipConv2dForward / nnhipConv2dBackward on layers that take conv_mfma.hip, called with every output combination the ABI
