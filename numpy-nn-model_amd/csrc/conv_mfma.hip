@@ -110,8 +110,10 @@ template <int WM>
 struct TapCfg {
     static constexpr int WN = 4 / WM, BM = 64 * WM, BN = 64 * WN, BK = WM == 2 ? 32 : 16;
     static constexpr int ALD = BK + 4, NVA = BM * BK / 1024, KPT = 16;      // KPT: source channels per thread per tile
-    static constexpr int A_SIZE = BM * ALD, B_SIZE = BK * BN, STAGE = A_SIZE + B_SIZE;
-    static constexpr int NMF = 16 * (BK / 8), NLD = NVA + KPT, NDW = NVA + KPT;
+    // both tiles k-major, rows of BK + 4 floats (conflict-free 16-byte LDS accesses with lane = row): a thread's 16 gathered
+    // channels of one pixel are 16 consecutive k of one B row -- four ds_write_b128 -- and the MFMA fragments are ds_read_b128
+    static constexpr int A_SIZE = BM * ALD, B_SIZE = BN * ALD, STAGE = A_SIZE + B_SIZE;
+    static constexpr int NMF = 16 * (BK / 8), NLD = NVA + KPT, NDW = NVA + KPT / 4;
     static constexpr size_t LDS = (size_t)2 * STAGE * sizeof(float);
 };
 
@@ -140,8 +142,8 @@ __device__ __forceinline__ void tap_k_step(f32x16 (&acc)[2][2], float4 (&fa)[Tap
         for (int i = 0; i < 2; ++i) {
             const float4 v = *reinterpret_cast<const float4*>(&As[(wm * 64 + i * 32 + l31) * C::ALD + g * 8 + lh * 4]);
             a[i][0] = v.x; a[i][1] = v.y; a[i][2] = v.z; a[i][3] = v.w;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b[i][j] = Bs[(g * 8 + j + 4 * lh) * C::BN + wn * 64 + i * 32 + l31];
+            const float4 w = *reinterpret_cast<const float4*>(&Bs[(wn * 64 + i * 32 + l31) * C::ALD + g * 8 + lh * 4]);
+            b[i][0] = w.x; b[i][1] = w.y; b[i][2] = w.z; b[i][3] = w.w;
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
@@ -156,7 +158,7 @@ __device__ __forceinline__ void tap_k_step(f32x16 (&acc)[2][2], float4 (&fa)[Tap
 #pragma unroll
     for (int p = 0; p < C::NVA; ++p) *reinterpret_cast<float4*>(&An[sA[p]]) = ca[p];
 #pragma unroll
-    for (int j = 0; j < C::KPT; ++j) Bn[sB + j * C::BN] = cb[j];
+    for (int j = 0; j < C::KPT; j += 4) *reinterpret_cast<float4*>(&Bn[sB + j]) = make_float4(cb[j], cb[j + 1], cb[j + 2], cb[j + 3]);
     conv_pin_pipeline<C::NMF, C::NLD, C::NDW>();
     __syncthreads();
 }
@@ -217,7 +219,7 @@ __global__ __launch_bounds__(256, WM == 2 ? 2 : 3) void conv_tap_kernel(const Co
         return (ok && n_ok && r < a.kh) ? (img + (unsigned)(ys * a.Ws + xs)) * 4u : CV_SENT;
     };
     const __amdgpu_buffer_rsrc_t rsB = conv_rsrc(a.Src, (int64_t)a.B * a.Cs * HWs * 4);
-    const int sB = (khalf * C::KPT) * C::BN + px;                        // LDS slot of this thread's first element of a tile
+    const int sB = px * C::ALD + khalf * C::KPT;                         // LDS slot of this thread's first element of a tile
 
     // ---- A side: NVA float4 of the repacked weights per tile ----------------------------------------------------------------------
     const int taps = a.kh * a.kw;
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(256, WM == 2 ? 2 : 3) void conv_tap_kernel(const Co
 #pragma unroll
     for (int p = 0; p < C::NVA; ++p) *reinterpret_cast<float4*>(&smem[sA[p]]) = ra[p];
 #pragma unroll
-    for (int j = 0; j < C::KPT; ++j) smem[C::A_SIZE + sB + j * C::BN] = rb[j];
+    for (int j = 0; j < C::KPT; j += 4) *reinterpret_cast<float4*>(&smem[C::A_SIZE + sB + j]) = make_float4(rb[j], rb[j + 1], rb[j + 2], rb[j + 3]);
     fetch(ra, rb);
     advance();
     __syncthreads();
@@ -671,43 +673,67 @@ __global__ __launch_bounds__(256, WM == 2 ? 2 : 3) void conv_wgrad_mfma_kernel(c
     }
 }
 
-// dW[co][ci][tap] = sum_chunks slab[c][co][column of (tap, ci)];  db[co] = sum_chunks bslab[c][co].  One thread per float4 of slab
-// columns (coalesced slab reads, chunks added in order: deterministic), scattered into dW's layout (dW is small).
+// dW[co][ci][tap] = sum_chunks slab[c][co][column of (tap, ci)];  db[co] = sum_chunks bslab[c][co].  A block = 32 float4 column
+// groups x 8 chunk lanes: lane l adds chunks l, l + 8, ... (coalesced 512-byte slab rows, 8x the threads of one-thread-per-column:
+// the slab is 30 MB and 80 blocks could not pull it at HBM speed -- 24.6 us), the 8 lane sums meet in LDS in lane order.  Fixed
+// order: deterministic.  The results are scattered into dW's [co][ci][tap] layout (dW is small).
 __global__ __launch_bounds__(256) void conv_wgrad_mfma_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bslab,
                                                                      float* __restrict__ dW, float* __restrict__ db, int chunks, int Cout,
                                                                      int Cin, int taps, int ncols, int BN, int CB, int cblks, int w_blocks) {
-    if ((int)blockIdx.x >= w_blocks) {                                     // the db part
-        const int co = ((int)blockIdx.x - w_blocks) * 256 + threadIdx.x;
-        if (co < Cout && db && bslab) {
-            float s = 0.f;
-            for (int c = 0; c < chunks; ++c) s += bslab[(int64_t)c * Cout + co];
+    if ((int)blockIdx.x >= w_blocks) {                                     // the db part: 32 channels x 8 chunk lanes per block
+        __shared__ float bred[8][32];
+        const int cl = threadIdx.x >> 5, co = ((int)blockIdx.x - w_blocks) * 32 + (threadIdx.x & 31);
+        float s = 0.f;
+        if (co < Cout && bslab) {
+            int c = cl;                                                    // (a one-thread chain of `chunks` dependent L2 round trips took 20 us)
+            for (; c + 24 < chunks; c += 32) {
+                const float v0 = bslab[(int64_t)c * Cout + co], v1 = bslab[(int64_t)(c + 8) * Cout + co];
+                const float v2 = bslab[(int64_t)(c + 16) * Cout + co], v3 = bslab[(int64_t)(c + 24) * Cout + co];
+                s += v0; s += v1; s += v2; s += v3;
+            }
+            for (; c < chunks; c += 8) s += bslab[(int64_t)c * Cout + co];
+        }
+        bred[cl][threadIdx.x & 31] = s;
+        __syncthreads();
+        if (cl == 0 && co < Cout && db && bslab) {
+#pragma unroll
+            for (int l = 1; l < 8; ++l) s += bred[l][threadIdx.x & 31];
             db[co] = s;
         }
         return;
     }
     if (!dW) return;
+    __shared__ float4 red[8][32];
     const int n4 = ncols / 4;
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (int64_t)Cout * n4) return;
-    const int co = (int)(idx / n4), q = (int)(idx - (int64_t)co * n4);
+    const int cl = threadIdx.x >> 5, qq = threadIdx.x & 31;
+    const int64_t idx = (int64_t)blockIdx.x * 32 + qq;
+    const bool live = idx < (int64_t)Cout * n4;
+    const int co = live ? (int)(idx / n4) : 0, q = live ? (int)(idx - (int64_t)co * n4) : 0;
     const float* src = slab + (int64_t)co * ncols + q * 4;
     const int64_t cstride = (int64_t)Cout * ncols;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    int c = 0;
-    for (; c + 4 <= chunks; c += 4) {
-        const float4 v0 = *reinterpret_cast<const float4*>(src + (int64_t)c * cstride);
-        const float4 v1 = *reinterpret_cast<const float4*>(src + (int64_t)(c + 1) * cstride);
-        const float4 v2 = *reinterpret_cast<const float4*>(src + (int64_t)(c + 2) * cstride);
-        const float4 v3 = *reinterpret_cast<const float4*>(src + (int64_t)(c + 3) * cstride);
-        s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
-        s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
-        s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
-        s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
+    if (live) {
+        int c = cl;
+        for (; c + 24 < chunks; c += 32) {
+            const float4 v0 = *reinterpret_cast<const float4*>(src + (int64_t)c * cstride);
+            const float4 v1 = *reinterpret_cast<const float4*>(src + (int64_t)(c + 8) * cstride);
+            const float4 v2 = *reinterpret_cast<const float4*>(src + (int64_t)(c + 16) * cstride);
+            const float4 v3 = *reinterpret_cast<const float4*>(src + (int64_t)(c + 24) * cstride);
+            s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+            s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
+            s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
+            s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
+        }
+        for (; c < chunks; c += 8) {
+            const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)c * cstride);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
     }
-    for (; c < chunks; ++c) {
-        const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)c * cstride);
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-    }
+    red[cl][qq] = s;
+    __syncthreads();
+    if (cl != 0 || !live) return;
+#pragma unroll
+    for (int l = 1; l < 8; ++l) { const float4 v = red[l][qq]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
     const float out[4] = {s.x, s.y, s.z, s.w};
     const int TPT = BN / CB;
 #pragma unroll
@@ -790,8 +816,8 @@ int conv_mfma_wgrad(const float* X, const float* dO, float* dW, float* db, const
              : CB == 128 ? launch_wgrad_cfg<1, 128>(a, avec, grid, st) : launch_wgrad_cfg<1, 256>(a, avec, grid, st);
     }
     if (rc) return rc;
-    const int w_blocks = dW ? (int)ceil_div((int64_t)g.Cout * (ncols / 4), 256) : 0;
-    const int b_blocks = db ? (int)ceil_div(g.Cout, 256) : 0;
+    const int w_blocks = dW ? (int)ceil_div((int64_t)g.Cout * (ncols / 4), 32) : 0;
+    const int b_blocks = db ? (int)ceil_div(g.Cout, 32) : 0;
     hipLaunchKernelGGL(conv_wgrad_mfma_reduce_kernel, dim3((unsigned)(w_blocks + b_blocks)), dim3(256), 0, st, a.slab, a.bslab, dW, db, a.chunks,
                        g.Cout, g.Cin, taps, ncols, BN, CB, cblks, w_blocks);
     NNHIP_LAUNCH_CHECK("conv_wgrad_mfma_reduce_kernel");
