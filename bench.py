@@ -1454,6 +1454,11 @@ def main():
         import torch.distributed as dist
         out["dist_backend"] = dist.get_backend()
     out.update(res.get("extra", {}))
+    try:
+        from neunet_hip._lib import call_hip_function as _call
+        out["gemm_lockstep"] = int(_call("nnhipGetGemmLockstep"))     # 1 by default when more than one rank exchanges gradients
+    except Exception:  # noqa: BLE001
+        pass
     if rank == 0:
         if not args.no_cpu_baseline:        # N > 1 too: timed on rank 0's host cores while the other ranks wait at the barrier
             out["cpu_baseline"] = {"headline": cpu_headline, "c1": cpu_c1, "c2": cpu_c2, "c3": cpu_c3, "c4": cpu_c4,

@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r04b
-timeout 900 python -m pytest tests/test_hip_parity.py -m gpu -q -k "conv" -x > gpurun_out/r04b/conv_tests.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r04b/conv_tests.log
-tail -4 gpurun_out/r04b/conv_tests.log
-timeout 300 python tools/kbench.py --only convg > gpurun_out/r04b/kbench_convg.log 2>&1
-grep -v amdgpu.ids gpurun_out/r04b/kbench_convg.log | grep wgrad
+mkdir -p gpurun_out/r04c
+export NNHIP_ALLOW_OVERSUBSCRIBE=1 NNHIP_DIST_BACKEND=gloo
+timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 6 --warmup 2 --cpu-seconds 3 > gpurun_out/r04c/bench_2ranks_gloo.json 2> gpurun_out/r04c/bench_2ranks_gloo.err; echo "rc=$?"
+tail -c 1500 gpurun_out/r04c/bench_2ranks_gloo.err
+head -c 600 gpurun_out/r04c/bench_2ranks_gloo.json
