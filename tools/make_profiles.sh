@@ -14,7 +14,7 @@ done
 FF=$(find $G/pmc_fetch_c2 -name "*counter_collection.csv" | head -1); WW=$(find $G/pmc_write_c2 -name "*counter_collection.csv" | head -1)
 python tools/prof_summary.py traffic $FF $WW /tmp/t_c2.json "gemm_f32_kernel<32, true, true, true, false>=gemm_fwd_c2" "gemm_f32_kernel<32, true, false, true, false>=gemm_dx_c2" "gemm_f32_kernel<32, false, false, true, false>=gemm_dw_c2" "adamw_multi=adamw_c2" > /dev/null
 FF=$(find $G/pmc_fetch_c3 -name "*counter_collection.csv" | head -1); WW=$(find $G/pmc_write_c3 -name "*counter_collection.csv" | head -1)
-python tools/prof_summary.py traffic $FF $WW /tmp/t_c3.json "map1_kernel<SwishF>=swish_fwd_c3" "map2_kernel<SwishB>=swish_bwd_c3" "rmsnorm_fwd_rows=rmsnorm_fwd_c3" "rmsnorm_bwd_rows=rmsnorm_bwd_c3" "softmax_fwd_rows=softmax_fwd_c3" "softmax_bwd_rows=softmax_bwd_c3" "ce_rows_kernel=ce_c3" "adamw_multi=adamw_c3" > /dev/null
+python tools/prof_summary.py traffic $FF $WW /tmp/t_c3.json "map1_kernel<SwishF>=swish_fwd_c3" "map2_kernel<SwishB>=swish_bwd_c3" "rmsnorm_fwd_rows=rmsnorm_fwd_c3" "rmsnorm_bwd_rows=rmsnorm_bwd_c3" "softmax_fwd_rows=softmax_fwd_c3" "softmax_bwd_rows=softmax_bwd_c3" "ce_rows_kernel=ce_c3" "adamw_multi@524288=adamw_c3" "adamw_multi@1638400=adamw_200x512x1024_c3" > /dev/null
 python - <<PY
 import json
 t = {}
@@ -34,6 +34,35 @@ for W in headline c1 c2 c3 c4 c5 nb c4_forced_nccl c4_forced_nccl_ingraph; do [ 
 [ -f $G/dp_timeline.md ] && cp $G/dp_timeline.md $P/${TAG}_dp_forced_nccl_timeline.md
 F=$(find $G/prof_dp -name "*_kernel_stats.csv" 2>/dev/null | head -1)
 [ -n "$F" ] && python tools/prof_summary.py stats $F $P/${TAG}_c4_forced_nccl_kernel_stats.md "Round ${TAG#r} -- rocprofv3 --kernel-trace --stats -- python bench.py --workload c4 --force-dp --dp-op avg (1-rank nccl group; MI355X)"
+# round 4: native-comm DP step, lock-step on/off (step time + fabric reads of the step's GEMM kernels), MFMA conv layer
+for W in c4_native_comm c4_forced_lockstep0 c4_forced_lockstep1; do [ -f $G/bench_$W.json ] && cp $G/bench_$W.json $P/${TAG}_bench_$W.json; done
+F=$(find $G/prof_conv -name "*_kernel_stats.csv" 2>/dev/null | head -1)
+[ -n "$F" ] && python tools/prof_summary.py stats $F $P/${TAG}_conv_mfma_kernel_stats.md "Round ${TAG#r} -- rocprofv3 --kernel-trace --stats -- python tools/conv_prof.py 64 64 56 128 (Conv2d 64->128 ch, 56x56, batch 64: forward, dgrad, wgrad+db; 29.6 GFLOP each; MI355X)"
+C=$(find $G/pmc_conv -name "*counter_collection.csv" 2>/dev/null | head -1)
+[ -n "$C" ] && python tools/prof_summary.py pmc $C $P/${TAG}_conv_mfma_pmc_sq.md
+python - <<PY
+import csv, glob, json, collections
+out = {}
+for ls in (0, 1):
+    fs = glob.glob("$G/pmc_fetch_c4_ls%d/**/*counter_collection.csv" % ls, recursive=True)
+    if not fs: continue
+    per = collections.defaultdict(float); n = collections.Counter()
+    for r in csv.DictReader(open(fs[0])):
+        if r["Counter_Name"] != "FETCH_SIZE": continue
+        k = r["Kernel_Name"].split("(")[0].replace("void nnhip::", "")
+        if not k.startswith("gemm"): continue
+        per[k] += float(r["Counter_Value"]); n[k] += 1
+    steps = 3.0   # 1 warm-up + 2 timed steps + the discovery pass run eagerly: report per-launch means instead of per-step sums
+    out["lockstep%d" % ls] = {k: {"launches": n[k], "fetch_MB_per_launch": round(2 * per[k] * 1024 / n[k] / 1e6, 1)} for k in sorted(per)}
+    b = "$G/bench_c4_forced_lockstep%d.json" % ls
+    try: out["lockstep%d" % ls]["_ms_per_step"] = json.load(open(b))["ms_per_step"]
+    except Exception: pass
+if out:
+    out["_note"] = "C4 GPT-tiny step through the forced 1-rank nccl group (--force-dp --dp-op avg), NNHIP_GEMM_LOCKSTEP=0/1: L2->fabric reads per GEMM launch = 2*FETCH_SIZE KiB (gfx950 half-count correction), rocprofv3 --pmc FETCH_SIZE pass; ms_per_step from the un-profiled run"
+    json.dump(out, open("$P/${TAG}_c4_lockstep_fabric.json", "w"), indent=1)
+    for k, v in out.items():
+        if not k.startswith("_"): print(k, v.get("_ms_per_step"), {kk: vv for kk, vv in v.items() if not kk.startswith("_")})
+PY
 for f in gemm_pmc_bf3.txt gemm_pmc_f32.txt; do [ -f $G/$f ] && cp $G/$f $P/${TAG}_$f; done
 cp $G/kbench.log $P/${TAG}_kbench.txt
 cp $G/stream_roof.txt $P/${TAG}_stream_roof.txt
