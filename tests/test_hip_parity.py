@@ -1482,6 +1482,50 @@ def test_conv2d_mfma_kernels_through_the_c_abi(hip, B, cin, H, W, cout, k, strid
     assert torch.equal(dx2, dx) and torch.equal(dw2, dw) and torch.equal(db2, db)
 
 
+def test_conv2d_mfma_full_size_samples(hip):
+    """The MFMA conv kernels at the size the kernel bench quotes (Conv2d 64 -> 128 channels, 3x3, 56 x 56, batch 64: 29.6 GFLOP per
+    pass; 1568 pixel tiles = three whole rounds + a split-K tail in one grid; wgrad in 102 K chunks) -- too large for the NumPy
+    oracle's einsum, so sampled entries are recomputed in float64 straight from the definition (conv2d.py:297-355, 16-115):
+    forward and dX entries as dot products over (ci, r, s) / (co, r, s), dW entries as sums over all 200 704 (b, ho, wo), db in full."""
+    import ctypes
+    from neunet_hip._lib import Conv2dDesc, call_hip_function as call, get_current_stream_ptr
+    B, Cin, H, Cout = 64, 64, 56, 128
+    rng = np.random.default_rng(2024)
+    X = rng.uniform(-1, 1, (B, Cin, H, H)).astype(np.float32)
+    Wt = (rng.uniform(-1, 1, (Cout, Cin, 3, 3)) / 24).astype(np.float32)
+    bias = rng.uniform(-0.3, 0.3, Cout).astype(np.float32)
+    dO = rng.uniform(-1, 1, (B, Cout, H, H)).astype(np.float32)
+    d = Conv2dDesc(B, Cin, H, H, Cout, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1)
+    st = get_current_stream_ptr()
+    x, w, b_, do = dev(X), dev(Wt), dev(bias), dev(dO)
+    out, dx, dw, db = torch.empty_like(do), torch.empty_like(x), torch.empty_like(w), torch.empty_like(b_)
+    call("nnhipConv2dForward", x, w, b_, out, ctypes.byref(d), st)
+    call("nnhipConv2dBackward", x, w, do, dx, dw, db, ctypes.byref(d), st)
+    out, dx, dw, db = host(out), host(dx), host(dw), host(db)
+    Xp = np.pad(X, ((0, 0), (0, 0), (1, 1), (1, 1))).astype(np.float64)
+    dOp = np.pad(dO, ((0, 0), (0, 0), (1, 1), (1, 1))).astype(np.float64)
+    W64 = Wt.astype(np.float64)
+    # forward: edge pixels, pixels of the last (split) tiles, random ones
+    pts = [(0, 0, 0, 0), (B - 1, Cout - 1, H - 1, H - 1), (B - 1, 5, H - 1, 0), (B - 1, 77, 40, 55)]
+    pts += [tuple(int(v) for v in (rng.integers(B), rng.integers(Cout), rng.integers(H), rng.integers(H))) for _ in range(60)]
+    for (bb, co, y, xx) in pts:
+        ref = float(np.sum(Xp[bb, :, y:y + 3, xx:xx + 3] * W64[co])) + float(bias[co])
+        bound = 32 * U24 * float(np.sum(np.abs(Xp[bb, :, y:y + 3, xx:xx + 3] * W64[co]))) + 4 * U24 * abs(ref) + 1e-7
+        assert abs(float(out[bb, co, y, xx]) - ref) <= bound, ("forward", bb, co, y, xx, out[bb, co, y, xx], ref)
+    # dX[b, ci, y, x] = sum_{co, r, s} W[co, ci, r, s] dO[b, co, y + 1 - r, x + 1 - s]  (unit stride, padding 1)
+    Wf = W64[:, :, ::-1, ::-1]
+    for (bb, ci, y, xx) in [(0, 0, 0, 0), (B - 1, Cin - 1, H - 1, H - 1)] + [tuple(int(v) for v in (rng.integers(B), rng.integers(Cin), rng.integers(H), rng.integers(H))) for _ in range(60)]:
+        terms = dOp[bb, :, y:y + 3, xx:xx + 3] * Wf[:, ci]
+        ref = float(np.sum(terms))
+        assert abs(float(dx[bb, ci, y, xx]) - ref) <= 32 * U24 * float(np.sum(np.abs(terms))) + 1e-7, ("dX", bb, ci, y, xx)
+    # dW entries: sums over batch x pixels (K = 200 704)
+    rms_dw = rms_of(dw)
+    for (co, ci, r, s_) in [(0, 0, 0, 0), (Cout - 1, Cin - 1, 2, 2)] + [tuple(int(v) for v in (rng.integers(Cout), rng.integers(Cin), rng.integers(3), rng.integers(3))) for _ in range(24)]:
+        ref = float(np.sum(Xp[:, ci, r:r + H, s_:s_ + H] * dO[:, co].astype(np.float64)))
+        assert abs(float(dw[co, ci, r, s_]) - ref) <= 1e-4 * max(abs(ref), rms_dw), ("dW", co, ci, r, s_, dw[co, ci, r, s_], ref)
+    assert_close_scaled(db, dO.astype(np.float64).sum(axis=(0, 2, 3)), err_msg="db")
+
+
 # -------------------------------------------------------------------------------------- optimizers
 @pytest.mark.parametrize("name", ["adam_wd0", "adam_wd1e-2", "adamw_wd0", "adamw_wd1e-2"])
 @pytest.mark.parametrize("multi", [False, True])

@@ -1,4 +1,2 @@
 cd $GRAFT_REPO_ROOT
-python bench.py --workload c3 --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys; d=json.load(sys.stdin)
-for k,v in d['ops'].items(): print(k, v)"
+timeout 900 python -m pytest tests/test_hip_parity.py -m gpu -q -k "conv2d_mfma" -x 2>&1 | tail -8
