@@ -500,6 +500,10 @@ int nnhipMSELossSigmoidForwardBackward(const float* pred, const float* target, f
 /* ---- gradient-bucket helpers for data-parallel training (net-new) ---------------- */
 /* x[i] *= alpha */
 int nnhipScale(float* x, float alpha, int64_t n, nnhipStream_t stream);
+/* out[r,c] = in[r,c] * scale[r * scale_stride], scale_stride 0 (one device scalar) or 1 (a factor per row): a loss node's product
+ * with its upstream gradient (cross_entropy.py:111-114 `y_pred.apply_grad(grad_y_pred * grad)`).  ABI 208 */
+int nnhipScaleRows(float* out, const float* in, const float* scale, int64_t rows, int64_t cols, int64_t scale_stride,
+                   nnhipStream_t stream);
 /* out[i] = a[i] + b[i]   (Tensor.apply_grad accumulation, neunet/autograd.py:85-93) */
 int nnhipAdd(float* out, const float* a, const float* b, int64_t n, nnhipStream_t stream);
 /* out[i] = a[i] * b[i]   (Dropout mask application, neunet/nn/layers/dropout.py:17-37) */

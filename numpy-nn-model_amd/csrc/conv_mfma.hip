@@ -372,7 +372,8 @@ static int launch_conv_tap(const float* W, const float* Src, const float* bias, 
     const int Mp = (int)ceil_div(M, BM) * BM, Csp = (int)ceil_div(Cs, BK) * BK;
     const int64_t wr_floats = (int64_t)taps * Mp * Csp;
     const int64_t src_bytes = (int64_t)g.B * Cs * Hs * Ws * 4;
-    NNHIP_CHECK_ARG(src_bytes < ((int64_t)1 << 31) && wr_floats * 4 < ((int64_t)1 << 31), NNHIP_EINVAL,
+    // (+ one k-tile of channels: the scalar channel offset of a padded channel, added to the out-of-range marker, must not wrap)
+    NNHIP_CHECK_ARG(src_bytes + (int64_t)BK * Hs * Ws * 4 < ((int64_t)1 << 31) && wr_floats * 4 < ((int64_t)1 << 31), NNHIP_EINVAL,
                     "conv2d: the implicit-GEMM kernel addresses each operand with 32-bit byte offsets (tensor >= 2 GiB)");
     const int64_t N = (int64_t)g.B * Hd * Wd;
     const int tiles_m = Mp / BM;
@@ -780,7 +781,8 @@ int conv_mfma_wgrad(const float* X, const float* dO, float* dW, float* db, const
     const int TPT = BN / CB, taps = g.kh * g.kw;
     const int cblks = (int)ceil_div(g.Cin, CB), tgroups = (int)ceil_div(taps, TPT);
     const int HWo = g.Ho * g.Wo;
-    NNHIP_CHECK_ARG((int64_t)g.B * g.Cin * g.H * g.W * 4 < ((int64_t)1 << 31) && (int64_t)g.B * g.Cout * HWo * 4 < ((int64_t)1 << 31),
+    // (+ one tile of channels / rows: scalar offsets of padded channels, added to the out-of-range marker, must not wrap)
+    NNHIP_CHECK_ARG(((int64_t)g.B * g.Cin + BN) * g.H * g.W * 4 < ((int64_t)1 << 31) && ((int64_t)g.B * g.Cout + BM) * HWo * 4 < ((int64_t)1 << 31),
                     NNHIP_EINVAL, "conv2d: the implicit-GEMM kernel addresses each operand with 32-bit byte offsets (tensor >= 2 GiB)");
     ConvWgArgs a;
     a.X = X; a.dO = dO;

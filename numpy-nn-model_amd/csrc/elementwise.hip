@@ -367,6 +367,24 @@ extern "C" int nnhipScale(float* x, float alpha, int64_t n, nnhipStream_t s) {
     NNHIP_PTRS("nnhipScale", x);
     return launch_map1(x, x, n, ScaleF{alpha}, (hipStream_t)s, "scale");
 }
+// out[r, c] = in[r, c] * scale[r * scale_stride]: the product with an upstream gradient that a loss node's backward forms
+// (cross_entropy.py:111-114 `grad_y_pred * grad`, losses.py:9-22): scale_stride = 0 -- one DEVICE scalar (loss.backward(g) on a
+// reduced loss), 1 -- one factor per row (reduction 'none').  One thread per element group of 4 along a row.
+__global__ __launch_bounds__(256) void scale_rows_kernel(float* __restrict__ out, const float* __restrict__ in, const float* __restrict__ scale,
+                                                         int64_t rows, int64_t cols, int64_t scale_stride) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * cols) return;
+    out[i] = in[i] * scale[(i / cols) * scale_stride];
+}
+extern "C" int nnhipScaleRows(float* out, const float* in, const float* scale, int64_t rows, int64_t cols, int64_t scale_stride, nnhipStream_t s) {
+    NNHIP_CHECK_ARG(rows >= 0 && cols >= 0 && (scale_stride == 0 || scale_stride == 1), NNHIP_EINVAL, "nnhipScaleRows: bad sizes");
+    if (rows * cols == 0) return 0;
+    NNHIP_PTRS("nnhipScaleRows", out, in, scale);
+    hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)ceil_div(rows * cols, 256)), dim3(256), 0, (hipStream_t)s, out, in, scale, rows, cols,
+                       scale_stride);
+    NNHIP_LAUNCH_CHECK("scale_rows_kernel");
+    return 0;
+}
 extern "C" int nnhipAdd(float* out, const float* a, const float* b, int64_t n, nnhipStream_t s) {
     NNHIP_CHECK_ARG(n >= 0, NNHIP_EINVAL, "nnhipAdd: negative size");
     if (n == 0) return 0;

@@ -140,6 +140,7 @@ _SIGNATURES = {
     "nnhipMSELossForwardBackward": (ctypes.c_int, [P, P, P, P, c_int64, c_void_p]),
     "nnhipMSELossSigmoidForwardBackward": (ctypes.c_int, [P, P, P, P, c_int64, c_void_p]),
     "nnhipScale": (ctypes.c_int, [P, c_float, c_int64, c_void_p]),
+    "nnhipScaleRows": (ctypes.c_int, [P, P, P, c_int64, c_int64, c_int64, c_void_p]),
     "nnhipAdd": (ctypes.c_int, [P, P, P, c_int64, c_void_p]),
     "nnhipCommUniqueId": (ctypes.c_int, [ctypes.c_char_p]),
     "nnhipCommInitRank": (ctypes.c_int, [POINTER(c_void_p), ctypes.c_char_p, ctypes.c_int, ctypes.c_int]),

@@ -12,7 +12,7 @@ path, all on the side of the CPU semantics (neunet/nn/losses.py:59-126):
 import weakref
 from ...autograd import Tensor
 from ..modules import Module
-from .utils import call_hip_function, contiguous, get_current_stream_ptr
+from .utils import call_hip_function, contiguous, get_current_stream_ptr, times_upstream
 
 _RED = {"none": b"n", "mean": b"m", "sum": b"s"}
 
@@ -110,9 +110,7 @@ class _HIPCrossEntropyTensor(Tensor):
             if getattr(out_ref(), "_seeded_with_ones", False):
                 y_pred.apply_grad(grad_y_pred)
                 return
-            if grad.ndim == 1:
-                grad = grad[:, None]
-            y_pred.apply_grad(grad_y_pred * grad)
+            y_pred.apply_grad(times_upstream(grad_y_pred, grad))
 
         self.grad_fn = grad_fn
 

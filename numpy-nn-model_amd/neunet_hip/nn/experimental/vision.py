@@ -13,7 +13,7 @@ from ...autograd import Tensor
 from ..modules import Module
 from ..parameter import Parameter
 from .linear import ACT_SIGMOID, _HIPLinearTensor, _finish_param, _grad_out
-from .utils import call_hip_function, contiguous, get_current_stream_ptr, require_device_f32
+from .utils import call_hip_function, contiguous, get_current_stream_ptr, require_device_f32, times_upstream
 
 
 def _pair(v):
@@ -298,7 +298,7 @@ class _HIPMSETensor(Tensor):
             if getattr(out_ref(), "_seeded_with_ones", False):
                 y_pred.apply_grad(grad_pred)
             else:
-                y_pred.apply_grad(grad_pred * grad)
+                y_pred.apply_grad(times_upstream(grad_pred, grad))
 
         self.grad_fn = grad_fn
 

@@ -1285,6 +1285,38 @@ def test_cross_entropy_out_of_range_label_is_inert(hip, rows, C, inplace):
         assert_close_scaled(g[good], dl)
 
 
+@pytest.mark.parametrize("reduction", ["none", "mean", "sum"])
+def test_cross_entropy_backward_with_an_upstream_gradient(hip, reduction):
+    """loss.backward(g) with g != ones: the reference forms grad_y_pred * grad (cross_entropy.py:111-114) -- here on the library's
+    own nnhipScaleRows (a device scalar for a reduced loss, one factor per row for reduction 'none'), against the oracle's
+    `upstream` argument."""
+    from neunet_hip.nn.experimental import HIPCrossEntropyLoss
+    rng = np.random.default_rng(12)
+    rows, C = 48, 130
+    logits = (rng.standard_normal((rows, C)) * 2).astype(np.float32)
+    labels = rng.integers(0, C, rows).astype(np.int32)
+    labels[5] = 120
+    up = rng.uniform(0.5, 2.0, rows).astype(np.float32) if reduction == "none" else np.float32(1.75)
+    x = T(hip, logits)
+    loss = HIPCrossEntropyLoss(reduction=reduction, ignore_index=120)(x, T(hip, labels, dtype=np.int32, requires_grad=False))
+    loss.backward(dev(np.asarray(up, np.float32).reshape(-1) if reduction == "none" else np.asarray([up], np.float32)))
+    lr, dl = O.cross_entropy_forward_backward(logits, labels, None, 120, reduction, upstream=up)
+    np.testing.assert_allclose(host(loss.data).reshape(np.shape(lr)), lr, rtol=1e-5, atol=1e-6)
+    assert_close_scaled(host(x.grad), dl)
+
+
+def test_mse_backward_with_an_upstream_gradient(hip):
+    """MSELoss.backward(g): dpred * g (neunet/nn/losses.py:9-22 through the tape) on nnhipScaleRows."""
+    import neunet_hip.nn as nn
+    rng = np.random.default_rng(13)
+    P, Tt = rng.uniform(0, 1, (32, 10)).astype(np.float32), rng.uniform(0, 1, (32, 10)).astype(np.float32)
+    p = T(hip, P)
+    loss = nn.MSELoss()(p, T(hip, Tt, requires_grad=False))
+    loss.backward(dev(np.asarray([0.25], np.float32)))
+    _, dp = O.mse_forward_backward(P, Tt)
+    np.testing.assert_allclose(host(p.grad), 0.25 * dp, rtol=1e-6, atol=1e-8)
+
+
 def test_cross_entropy_tall_narrow_takes_the_two_launch_path(hip):
     """rows so many that a per-block label count would not be free (rows x blocks x 4 B > 64 MB): the denominator comes
     from its own small launch; results identical in kind."""
