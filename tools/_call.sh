@@ -1,5 +1,6 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_hip_parity.py -m gpu -q -k "conv" -x 2>&1 | tail -4
-for F in 0 1; do
-NNHIP_CONV_BWD_FORK=$F python bench.py --workload c5 --steps 4800 --warmup 320 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print('fork=$F c5', d['value'], d['ms_per_step'], d['roofline']['avg_step_device_ms'], d['launches_per_step'])"
-done
+mkdir -p gpurun_out/r04d
+timeout 2400 python -m pytest tests -m gpu -q > gpurun_out/r04d/gputest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r04d/gputest.log
+tail -6 gpurun_out/r04d/gputest.log
+( time timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/r04d/bench_headline.json 2> gpurun_out/r04d/bench_headline.err ) 2>&1 | grep real
+python __graft_entry__.py smoke 2>&1 | tail -2
