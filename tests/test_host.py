@@ -291,3 +291,90 @@ def test_forced_one_rank_group_issues_every_collective():
     p.join(timeout=60)
     assert p.exitcode == 0
     assert got is True, got
+
+
+def test_dropout_seed_follows_torch_seed_and_rank(monkeypatch):
+    """The word mixed into every hash-dropout seed (embedding.process_dropout_seed): reproducible under torch.manual_seed,
+    different for different seeds, different on every data-parallel rank (advisor, round 3)."""
+    import torch
+    from neunet_hip.nn.experimental.embedding import process_dropout_seed
+    monkeypatch.setenv("RANK", "0")
+    torch.manual_seed(1234)
+    a = process_dropout_seed()
+    torch.manual_seed(1234)
+    assert process_dropout_seed() == a
+    torch.manual_seed(1235)
+    b = process_dropout_seed()
+    monkeypatch.setenv("RANK", "3")
+    c = process_dropout_seed()
+    assert len({a, b, c}) == 3 and all(0 <= v < 2 ** 32 for v in (a, b, c))
+
+
+def test_grad_bucket_exchange_backends():
+    """GradBucket.exchange is the one place a collective is issued: a NativeComm-shaped backend gets the flat slice, the
+    reduction name and the async flag; `collectives_live` answers for it (world > 1, or forced); a torch group and a
+    communicator at once are refused."""
+    import torch
+    from neunet_hip import distributed as D
+
+    class FakeComm(D.NativeComm):
+        def __init__(self, world):               # no library call: only the bucket's side of the contract is under test
+            self.rank, self.world, self.calls = 0, world, []
+
+        def all_reduce(self, t, op="sum", async_op=False):
+            self.calls.append((int(t.numel()), op, async_op))
+            return None
+
+        def destroy(self):
+            pass
+
+    class P:
+        def __init__(self, n):
+            self.data = torch.zeros(n)
+            self.grad = torch.ones(n)
+
+    comm = FakeComm(4)
+    assert D.collectives_live(comm) is True and D.collectives_live(FakeComm(1)) is False
+    params = [P(8), P(5)]
+    bucket = D.GradBucket(params, extra_scalars=1, reduce_op="avg", comm=comm)
+    bucket.all_reduce()
+    assert comm.calls == [(bucket.numel, "avg", False)]
+    assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(params, bucket.views))
+    with pytest.raises(ValueError, match="either"):
+        D.GradBucket(params, group=object(), comm=comm)
+
+
+def _avg_on_gloo_worker(port, q):
+    import torch
+    import torch.distributed as dist
+    from neunet_hip import distributed as D
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    try:
+        D.init_process_group("gloo", force=True)
+
+        class P:
+            def __init__(self, n):
+                self.data = torch.zeros(n)
+                self.grad = torch.ones(n)
+
+        try:
+            D.GradBucket([P(4)], reduce_op="avg").all_reduce()
+            q.put("no error")
+        except ValueError as exc:
+            q.put("gloo has no AVG" in str(exc))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_reduce_op_avg_is_refused_on_gloo():
+    """ReduceOp.AVG exists on nccl (= RCCL) only: asking for it on a gloo group is a clear ValueError, not a backend crash
+    (advisor, round 3)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_avg_on_gloo_worker, args=(_free_port(), q))
+    p.start()
+    got = q.get(timeout=120)
+    p.join(timeout=60)
+    assert got is True, got

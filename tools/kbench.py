@@ -93,6 +93,16 @@ def main():
                 del dO, dX, dW
             del X, W, O_
 
+    if "headpad" in only:         # does the vocabulary head pay for rows of 15000 floats (60000 B: no multiple of a 128-B line)?
+        for (M, N, K) in [(16384, 15000, 512), (16384, 15008, 512), (16384, 15104, 512)]:
+            X, W, b = rnd(M, K), rnd(N, K) / 64, rnd(N)
+            O_, dO, dX, dW, db = torch.empty(M, N, device=dev), rnd(M, N), torch.empty(M, K, device=dev), torch.empty(N, K, device=dev), torch.empty(N, device=dev)
+            fl = 2.0 * M * N * K
+            report(f"linear fwd {M}x{K}->{N}", *bench(lambda: call("nnhipLinearModuleForward", X, W, b, O_, M, K, N, st), args.iters), flops=fl)
+            report(f"linear dX  {M}x{K}->{N}", *bench(lambda: call("nnhipLinearModuleBackward", X, W, dO, dX, None, None, M, K, N, st), args.iters), flops=fl)
+            report(f"linear dW+db {M}x{K}->{N}", *bench(lambda: call("nnhipLinearModuleBackward", X, W, dO, None, dW, db, M, K, N, st), args.iters), flops=fl)
+            del X, W, O_, dO, dX, dW
+
     if "dwsweep" in only:         # the parameter-gradient GEMMs of the C4 step (split-K candidates)
         for (M, N, K) in [(16384, 512, 512), (16384, 1536, 512), (16384, 2048, 512), (16384, 512, 2048), (16384, 15000, 512), (16384, 6144, 512)]:
             X, W, dO = rnd(M, K), rnd(N, K) / 64, rnd(M, N)
