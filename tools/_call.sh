@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 300 python tools/kbench.py --only headpad 2>&1 | grep -v amdgpu
+timeout 2400 bash tools/collect_profiles.sh r04b > /dev/null 2>&1
+ls gpurun_out/r04b | wc -l; du -sh gpurun_out/r04b
