@@ -94,7 +94,10 @@ int nnhipLinearModuleBackwardEx(const float* X, const float* W, const float* dO,
  * ONE reduce -- a transformer layer's four dW GEMMs stop paying four launch ramps, four simultaneous slab epilogues and four
  * tails.  A job's reduction is always cut into four chunks, so a gradient's bits do not depend on what else was in the queue.
  * Contract while a job is queued: its X and dO stay alive and unmodified, its dW/db are not read.  enable == 0: flush on
- * `stream`, then every later dW is launched where it is asked for (the default).  nnhipWeightGradPending: queued jobs.  ABI 204 */
+ * `stream`, then every later dW is launched where it is asked for (the default).  nnhipWeightGradPending: queued jobs.
+ * The switch and the queue are ONE per process, for ONE host thread and ONE stream at a time (like the workspace): while it is
+ * on, a backward entry called from another thread or on another stream is queued all the same -- a caller that defers must be
+ * the only caller until it has flushed (Tensor.backward() switches it on for the duration of its own tape walk only).  ABI 204 */
 int nnhipWeightGradDefer(int32_t enable, nnhipStream_t stream);
 int nnhipWeightGradFlush(nnhipStream_t stream);
 int nnhipWeightGradPending(void);
