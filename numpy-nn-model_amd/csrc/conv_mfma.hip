@@ -472,7 +472,25 @@ struct ConvWgArgs {
     float* bslab;        // [chunks][Cout] (row sums of dO) or null
     int B, Cin, H, W, Cout, Ho, Wo, kh, kw, sh, sw, dh, dw, pu, pl;
     int tiles_m, tiles_n, cblks, chunks, tpc, tpi;     // tpc: k-tiles per chunk, tpi: k-tiles per image
+    // FLAT mode (small or ragged feature maps): the reduction index is k = b * Ho*Wo + p with no padding per image; a k-tile is
+    // BK consecutive k and may span images (2x2 maps: 8 of them).  ktiles = ceil(B Ho Wo / BK); (mP, sP) / (mW, sW): magic
+    // numbers of the exact 32-bit divisions by Ho*Wo and by Wo (udiv_magic)
+    int ktiles;
+    unsigned mP, sP, mW, sW;
 };
+
+// n / d for every 32-bit n, d fixed: (m, s) from magic_u32(d) on the host (Granlund-Montgomery; s == 0 <=> d == 1)
+__device__ __forceinline__ unsigned udiv_magic(unsigned n, unsigned m, unsigned s) {
+    if (s == 0) return n;
+    const unsigned t = __umulhi(m, n);
+    return (t + ((n - t) >> 1)) >> (s - 1);
+}
+static void magic_u32(unsigned d, unsigned& m, unsigned& s) {
+    if (d <= 1) { m = 0; s = 0; return; }
+    s = 0;
+    while ((1ull << s) < d) ++s;
+    m = (unsigned)((((unsigned long long)1 << 32) * (((unsigned long long)1 << s) - d)) / d + 1);
+}
 
 template <int WM>
 struct WgCfg {
@@ -484,7 +502,7 @@ struct WgCfg {
 };
 
 // AVEC: dO rows can be read with 16-byte loads (Ho*Wo % 4 == 0, 16-B aligned base); else 4 dword loads per float4
-template <int WM, int CB, bool AVEC>
+template <int WM, int CB, bool AVEC, bool FLAT>
 __global__ __launch_bounds__(256, WM == 2 ? 2 : 3) void conv_wgrad_mfma_kernel(const ConvWgArgs a) {
     using C = WgCfg<WM>;
     constexpr int TPT = C::BN / CB;                      // tap slots per column tile
@@ -504,8 +522,9 @@ __global__ __launch_bounds__(256, WM == 2 ? 2 : 3) void conv_wgrad_mfma_kernel(c
 
     // ---- this block's k-tiles: [t0, t1) of the flattened (image, tile in image) sequence ----------------------------------------
     const int t0 = chunk * a.tpc;
-    const int tend = a.B * a.tpi;
+    const int tend = FLAT ? a.ktiles : a.B * a.tpi;
     const int T = (t0 + a.tpc < tend ? t0 + a.tpc : tend) - t0;
+    const unsigned Ktot = (unsigned)a.B * (unsigned)HWo;
 
     // ---- A side (dO): float4 slots (row rr, pixels k4..k4+3) ---------------------------------------------------------------------
     const __amdgpu_buffer_rsrc_t rsA = conv_rsrc(a.dO, (int64_t)a.B * a.Cout * HWo * 4);
@@ -534,9 +553,11 @@ __global__ __launch_bounds__(256, WM == 2 ? 2 : 3) void conv_wgrad_mfma_kernel(c
     }
 
     // fetch state (two tiles ahead of the multiply): image fb_, first pixel fp0, this thread's pixel (fho, fwo)
-    int fb_ = t0 / a.tpi, fp0 = (t0 - (t0 / a.tpi) * a.tpi) * C::BK;
+    int fb_ = FLAT ? 0 : t0 / a.tpi, fp0 = FLAT ? 0 : (t0 - (t0 / a.tpi) * a.tpi) * C::BK;
     int fho = (fp0 + kk) / a.Wo, fwo = (fp0 + kk) - ((fp0 + kk) / a.Wo) * a.Wo;
+    unsigned fk0 = (unsigned)t0 * C::BK;                                  // FLAT: first k of the tile to fetch
     auto advance = [&]() {
+        if constexpr (FLAT) { fk0 += C::BK; return; }
         fp0 += C::BK;
         fwo += step_wo;
         fho += step_ho;
@@ -549,6 +570,52 @@ __global__ __launch_bounds__(256, WM == 2 ? 2 : 3) void conv_wgrad_mfma_kernel(c
 #pragma unroll
     for (int p = 0; p < C::NVA; ++p) cs[p] = 0.f;
     auto fetch = [&](float4 (&fa)[C::NVA], float (&fbv)[C::NPB]) {
+        if constexpr (FLAT) {
+            // ---- A: this thread's float4 slots all sit at the same k4 (256 threads = a multiple of BK/4 slots per row) ----------------
+            const unsigned ka = fk0 + (unsigned)k4A[0];
+            const unsigned ba = udiv_magic(ka, a.mP, a.sP), pa = ka - ba * (unsigned)HWo;
+            const unsigned soffA = (unsigned)m0 * (unsigned)HWo * 4u;
+            if constexpr (AVEC) {                                         // Ho*Wo % 4 == 0: the four pixels are in one image
+                const unsigned va = ka < Ktot ? (ba * (unsigned)a.Cout * (unsigned)HWo + pa) * 4u : CV_SENT;
+#pragma unroll
+                for (int p = 0; p < C::NVA; ++p) fa[p] = bload4(rsA, ka < Ktot ? va + voffA[p] - (unsigned)k4A[0] * 4u : CV_SENT, soffA);
+            } else {
+                unsigned be = ba, pe = pa;
+                unsigned ve[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ve[e] = ka + e < Ktot ? (be * (unsigned)a.Cout * (unsigned)HWo + pe) * 4u : CV_SENT;
+                    if (++pe == (unsigned)HWo) { pe = 0; ++be; }
+                }
+#pragma unroll
+                for (int p = 0; p < C::NVA; ++p) {
+                    float t4[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t4[e] = bload1(rsA, ve[e] == CV_SENT ? CV_SENT : ve[e] + voffA[p] - (unsigned)k4A[0] * 4u, soffA);
+                    fa[p] = make_float4(t4[0], t4[1], t4[2], t4[3]);
+                }
+            }
+            // ---- B: pixel k = fk0 + kk -> (image, ho, wo) with two exact magic divisions --------------------------------------------
+            const unsigned kb = fk0 + (unsigned)kk;
+            const unsigned bb = udiv_magic(kb, a.mP, a.sP), pb = kb - bb * (unsigned)HWo;
+            const unsigned hb = udiv_magic(pb, a.mW, a.sW), wb = pb - hb * (unsigned)a.Wo;
+            unsigned vo[TPT];
+            const bool p_ok = kb < Ktot;
+            const unsigned imgb = (bb * (unsigned)a.Cin + (unsigned)cg) * (unsigned)HW;
+#pragma unroll
+            for (int ts = 0; ts < TPT; ++ts) {
+                const int ys = (int)hb * a.sh + dy[ts], xs = (int)wb * a.sw + dx[ts];
+                const bool ok = p_ok && (unsigned)ys < (unsigned)a.H && (unsigned)xs < (unsigned)a.W;
+                vo[ts] = ok ? (imgb + (unsigned)(ys * a.W + xs)) * 4u : CV_SENT;
+            }
+            const unsigned soffB = (unsigned)c0 * HW4;
+#pragma unroll
+            for (int i = 0; i < C::NPB; ++i) {
+                const int col = C::NCG * i;
+                fbv[i] = bload1(rsB, vo[col / CB], soffB + (unsigned)(col % CB) * HW4);
+            }
+            return;
+        }
         const int remk = HWo - fp0;                                       // pixels of this image left from the tile's first one
         const unsigned soffA = (unsigned)((fb_ * a.Cout + m0) * HWo + fp0) * 4u;
 #pragma unroll
@@ -746,29 +813,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_reduce_kernel(const float
     }
 }
 
-template <int WM, int CB>
-static int launch_wgrad_cfg(const ConvWgArgs& a, bool avec, dim3 grid, hipStream_t st) {
+template <int WM, int CB, bool AVEC, bool FLAT>
+static int launch_wgrad_one(const ConvWgArgs& a, dim3 grid, hipStream_t st) {
     using C = WgCfg<WM>;
-    auto set_attr = [](const void* k) -> hipError_t { return hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS); };
-    if (avec) {
-        auto kern = conv_wgrad_mfma_kernel<WM, CB, true>;
-        static bool attr = false;
-        if (!attr && C::LDS > 48 * 1024) {
-            if (hipError_t e = set_attr(reinterpret_cast<const void*>(kern)); e != hipSuccess) return hip_status(e, "hipFuncSetAttribute(conv wgrad)");
-            attr = true;
-        }
-        hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS, st, a);
-    } else {
-        auto kern = conv_wgrad_mfma_kernel<WM, CB, false>;
-        static bool attr = false;
-        if (!attr && C::LDS > 48 * 1024) {
-            if (hipError_t e = set_attr(reinterpret_cast<const void*>(kern)); e != hipSuccess) return hip_status(e, "hipFuncSetAttribute(conv wgrad)");
-            attr = true;
-        }
-        hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS, st, a);
+    auto kern = conv_wgrad_mfma_kernel<WM, CB, AVEC, FLAT>;
+    static bool attr = false;
+    if (!attr && C::LDS > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::LDS);
+        if (e != hipSuccess) return hip_status(e, "hipFuncSetAttribute(conv wgrad)");
+        attr = true;
     }
+    hipLaunchKernelGGL(kern, grid, dim3(256), C::LDS, st, a);
     NNHIP_LAUNCH_CHECK("conv_wgrad_mfma_kernel");
     return 0;
+}
+template <int WM, int CB>
+static int launch_wgrad_cfg(const ConvWgArgs& a, bool avec, bool flat, dim3 grid, hipStream_t st) {
+    if (flat) return avec ? launch_wgrad_one<WM, CB, true, true>(a, grid, st) : launch_wgrad_one<WM, CB, false, true>(a, grid, st);
+    return avec ? launch_wgrad_one<WM, CB, true, false>(a, grid, st) : launch_wgrad_one<WM, CB, false, false>(a, grid, st);
 }
 
 int conv_mfma_wgrad(const float* X, const float* dO, float* dW, float* db, const ConvGeom& g, hipStream_t st) {
@@ -792,13 +854,23 @@ int conv_mfma_wgrad(const float* X, const float* dO, float* dW, float* db, const
     a.cblks = cblks;
     a.tiles_n = dW ? tgroups * cblks : 1;                                  // db alone: one column tile carries the row sums
     a.tpi = (int)ceil_div(HWo, BK);
-    const int64_t ktiles = (int64_t)g.B * a.tpi;
+    // per-image k-tiles pad every image to a multiple of BK pixels (2x2 maps: 4 of 32 used); when that wastes more than ~3 % the
+    // reduction index is flattened over (image, pixel) instead (FLAT: exact divisions by Ho*Wo and Wo per tile, no padding)
+    static const int flat_mode = []() { const char* e = getenv("NNHIP_CONV_WGRAD_FLAT"); return e ? atoi(e) : -1; }();   // dev knob: 0 never, 1 always
+    const int64_t Ktot = (int64_t)g.B * HWo;
+    const bool flat = flat_mode >= 0 ? flat_mode != 0 : (int64_t)a.tpi * BK * 32 > (int64_t)HWo * 33;
+    a.ktiles = (int)ceil_div(Ktot, BK);
+    magic_u32((unsigned)HWo, a.mP, a.sP);
+    magic_u32((unsigned)g.Wo, a.mW, a.sW);
+    const int64_t ktiles = flat ? a.ktiles : (int64_t)g.B * a.tpi;
     const int tiles = a.tiles_m * a.tiles_n;
-    // one generation of the chip's 512 resident blocks (2 per CU), cut along K; a chunk has at least 8 k-tiles.  The cut depends on
+    // one generation of the chip's 512 resident blocks (2 per CU), cut along K; a chunk has at least 4 k-tiles (8: -15 % on the
+    // 8x8 ... 16x16 maps of a U-Net body, whose grids do not fill the chip otherwise).  The cut depends on
     // the layer only, not on which outputs were asked for: db alone sums the same chunks in the same order as db next to dW
     int64_t chunks = 512 / (a.tiles_m * tgroups * cblks);
     if (chunks < 1) chunks = 1;
-    if (chunks > ceil_div(ktiles, 8)) chunks = ceil_div(ktiles, 8);
+    static const int min_kt = []() { const char* e = getenv("NNHIP_CONV_WGRAD_MINKT"); const int v = e ? atoi(e) : 4; return v < 1 ? 1 : v; }();
+    if (chunks > ceil_div(ktiles, min_kt)) chunks = ceil_div(ktiles, min_kt);
     a.tpc = (int)ceil_div(ktiles, chunks);
     a.chunks = (int)ceil_div(ktiles, a.tpc);
     const int ncols = a.tiles_n * BN;
@@ -811,11 +883,11 @@ int conv_mfma_wgrad(const float* X, const float* dO, float* dW, float* db, const
     const dim3 grid((unsigned)(tiles * a.chunks));
     int rc;
     if (wm == 2) {
-        rc = CB == 32 ? launch_wgrad_cfg<2, 32>(a, avec, grid, st) : CB == 64 ? launch_wgrad_cfg<2, 64>(a, avec, grid, st)
-                                                                              : launch_wgrad_cfg<2, 128>(a, avec, grid, st);
+        rc = CB == 32 ? launch_wgrad_cfg<2, 32>(a, avec, flat, grid, st) : CB == 64 ? launch_wgrad_cfg<2, 64>(a, avec, flat, grid, st)
+                                                                              : launch_wgrad_cfg<2, 128>(a, avec, flat, grid, st);
     } else {
-        rc = CB == 32 ? launch_wgrad_cfg<1, 32>(a, avec, grid, st) : CB == 64 ? launch_wgrad_cfg<1, 64>(a, avec, grid, st)
-             : CB == 128 ? launch_wgrad_cfg<1, 128>(a, avec, grid, st) : launch_wgrad_cfg<1, 256>(a, avec, grid, st);
+        rc = CB == 32 ? launch_wgrad_cfg<1, 32>(a, avec, flat, grid, st) : CB == 64 ? launch_wgrad_cfg<1, 64>(a, avec, flat, grid, st)
+             : CB == 128 ? launch_wgrad_cfg<1, 128>(a, avec, flat, grid, st) : launch_wgrad_cfg<1, 256>(a, avec, flat, grid, st);
     }
     if (rc) return rc;
     const int w_blocks = dW ? (int)ceil_div((int64_t)g.Cout * (ncols / 4), 32) : 0;

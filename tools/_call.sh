@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
-python tools/kbench.py --only attn 2>&1 | grep "T256 H8 dh64"
-for n in 1 2 4; do echo skew$n; NEUNET_HIP_LIB=$PWD/numpy-nn-model_amd/neunet_hip/lib/libneunet_hip.skew$n.so python tools/kbench.py --only attn 2>&1 | grep "fwd B64 T256 H8 dh64"; done
+timeout 900 python -m pytest tests/test_hip_parity.py -m gpu -q -k "conv" -x 2>&1 | tail -3
+python tools/kbench.py --only convu 2>&1 | grep -v amdgpu > gpurun_out/r04c_kbench_convu.txt; cat gpurun_out/r04c_kbench_convu.txt | head -30

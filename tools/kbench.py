@@ -321,6 +321,17 @@ def main():
             dW, db = torch.empty_like(W), torch.empty_like(bb)
             report(f"conv wgrad+db    {B}x{Cin}x{H}x{H}->{Cout}", *bench(lambda: call("nnhipConv2dBackward", X, W, dO, None, dW, db, ctypes.byref(d), st), args.iters), flops=fl)
 
+    if "convu" in only:           # the reference's DDPM U-Net body (scripts/torch_ddpm.py:451-452: channels 32..512 on 32x32 images), batch 64
+        for (B, Cin, H, Cout) in [(64, 32, 32, 64), (64, 64, 16, 128), (64, 128, 8, 256), (64, 256, 4, 512), (64, 512, 2, 512), (64, 512, 4, 256), (64, 128, 16, 64)]:
+            X, W, bb = rnd(B, Cin, H, H), rnd(Cout, Cin, 3, 3) / 24, rnd(Cout)
+            O_, dO = torch.empty(B, Cout, H, H, device=dev), rnd(B, Cout, H, H)
+            dX, dW, db = torch.empty_like(X), torch.empty_like(W), torch.empty_like(bb)
+            d = Conv2dDesc(B, Cin, H, H, Cout, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1)
+            fl = 2.0 * B * H * H * Cout * Cin * 9
+            report(f"conv fwd      {B}x{Cin}x{H}x{H}->{Cout}", *bench(lambda: call("nnhipConv2dForward", X, W, bb, O_, ctypes.byref(d), st), args.iters), flops=fl)
+            report(f"conv dgrad    {B}x{Cin}x{H}x{H}->{Cout}", *bench(lambda: call("nnhipConv2dBackward", X, W, dO, dX, None, None, ctypes.byref(d), st), args.iters), flops=fl)
+            report(f"conv wgrad+db {B}x{Cin}x{H}x{H}->{Cout}", *bench(lambda: call("nnhipConv2dBackward", X, W, dO, None, dW, db, ctypes.byref(d), st), args.iters), flops=fl)
+
     if want("conv"):
         for (B, Cin, H, Cout) in [(256, 1, 28, 8), (256, 8, 14, 16)]:
             X = rnd(B, Cin, H, H)
