@@ -9,9 +9,11 @@ MFMA peak".  The default workload ("headline") therefore measures, in ONE proces
                           weak scaling): the W warm-up + exactly K timed steps of the contract;
   * roofline            : the C2 Linear(4096->4096) forward GEMM, batch 4096 -- the metric's "Linear fwd vs MFMA peak"
                           half: HIP-event timed launches of the same gemm_f32_kernel that does 86 % of the C4 step;
-  * also.c1             : MNIST-MLP (784->128->10, batch 32 per GPU) training-step samples/s, sustained over 500 steps;
+  * also.c1             : MNIST-MLP (784->128->10, batch 32 per GPU) training-step samples/s, sustained over 512 steps (16 per captured graph), also with the per-replay input copy and with the separate optimizer launch;
   * also.c2             : the whole C2 training step (fwd + bwd + AdamW) and a sustained (>= 2 s) forward figure;
   * also.c4_gemm        : GEMM-equivalent TFLOP/s of the whole C4 step;
+  * also.c3 / also.c5   : every op of the fused micro-bench (rows 8192 x d 4096) with its HBM / MFMA fraction; the conv classifier step;
+  * also.c4_strong      : (N > 1) the strong-scaling step next to the weak-scaling `value`;
   * cpu_baseline        : the NumPy oracle's FULL GPT-tiny step (forward, backward, Adam) on a stated fraction of the batch.
 `--workload c1..c5` runs one BASELINE config on its own with the per-config detail (C3: per-op HBM fractions).
 
@@ -43,7 +45,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="headline", choices=["headline", "c1", "c2", "c3", "c4", "c5", "nb"])
-    ap.add_argument("--c1-steps", type=int, default=500, help="headline: sustained MNIST-MLP steps")
+    ap.add_argument("--c1-steps", type=int, default=512, help="headline: sustained MNIST-MLP steps (a multiple of 16: 16 steps per captured graph)")
     ap.add_argument("--overlap", type=int, default=1, help="N>1: overlap the gradient exchange with the backward pass")
     ap.add_argument("--c4-batch", type=int, default=64, help="sequences per GPU for the GPT-tiny workload")
     ap.add_argument("--graph", type=int, default=1, help="c1/c4: replay the step as a captured hipGraph (1) or launch eagerly (0)")

@@ -1,6 +1,8 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r04e
-timeout 2400 python -m pytest tests -m gpu -q > gpurun_out/r04e/gputest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r04e/gputest.log
-tail -4 gpurun_out/r04e/gputest.log
-python __graft_entry__.py smoke 2>&1 | tail -1
-python tools/kbench.py --only convg > gpurun_out/r04e/kbench_convg.txt 2>&1; grep -v amdgpu gpurun_out/r04e/kbench_convg.txt | head -6
+( time python bench.py > gpurun_out/r04e/bench_headline.json 2> gpurun_out/r04e/bench_headline.err ) 2>&1 | grep real
+python -c "
+import json; d=json.load(open('gpurun_out/r04e/bench_headline.json')); a=d['also']
+print(d['value'], d['ms_per_step'], d['roofline']['frac'])
+print('c1', a['c1']['samples_per_s'], a['c1']['launch'], a['c1']['with_input_copy']['samples_per_s'], a['c1']['separate_optimizer_launch']['samples_per_s'])
+print('c5', a['c5']['ms_per_step'])"
