@@ -1,0 +1,633 @@
+// attention_sb.hip -- the "super-block" fused attention kernels: causal self-attention at T = 256, head dim 64 (the GPT-tiny
+// shape of BASELINE config C4: B64 x H8 x T256), exact fp32 MFMA.  Same semantics and the same LSE format as attention.hip
+// (examples/gpt.ipynb cell 2: masked scores are REPLACED by -1e9; a query whose every visible key is padding is uniform over
+// ALL keys); the general tiled kernels of attention.hip keep every other shape, dense masks and dropout.
+//
+// Why a second set of kernels (round 5).  At T = 256 the tiled kernels ran at 0.43 (forward) / 0.32 (backward) of the fp32
+// MFMA peak while their tile loops kept the matrix pipe saturated: what was lost were the per-block prologues / epilogues of
+// 1-4 tile blocks, two block barriers per tile, the causal imbalance between the waves of a block, and -- in the backward --
+// two kernels that each recompute S and dP (7 GEMM-units per tile pair where 5 are needed).  Here:
+//   * A block is 8 waves (one per SIMD pair, 1 block per CU) and owns TWO (batch, head) slices A and B.  The 8 x 8 causal
+//     triangle of 32 x 32 sub-tiles of A and the triangle of B are dealt so that EVERY wave gets exactly 9 units of work:
+//     forward -- wave w runs row group 7-w of A (8-w key groups) and then row group w of B (w+1 key groups);
+//     backward -- wave w owns key group w of A (pairs (i, w), i = w..7) and then key group 7-w of B.
+//     256 blocks of B64 x H8 are one resident generation: no tail, no second round, no imbalance.
+//   * Operands are streamed from L2 straight into the registers the MFMAs read (no LDS ring, no staging registers, no block
+//     barrier in the forward): a 32-key K group is 8 float4 per lane (lane <-> key row: the A operand of S^T = K Q^T), a V
+//     group 16 float2 per lane (lane <-> two adjacent head-dim columns: coalesced 512-byte wave loads, the A operand of
+//     O^T += V^T P^T).  Every operand register is refilled with the NEXT unit's value right behind the MFMAs that read it
+//     (a rolling prefetch: a load has a whole unit -- >= 4096 matrix-pipe cycles -- to land), all through one buffer
+//     descriptor per tensor slice with the group's row offset in a scalar register.
+//   * The softmax keeps a LAZY running maximum (rescale only when a row maximum grows by more than 2^8: the 32 multiplies of
+//     O per unit disappear; (m_ref, log2 sum) stays a consistent pair for the backward).
+//   * Backward: ONE pass.  The wave that owns key group j computes S, dP, P, dS for the pair (i, j) once (lane <-> key),
+//     feeds dV^T += dO^T P and dK^T += Q^T dS from the accumulator registers, transposes dS through 4.6 KB of wave-private
+//     LDS and multiplies dQ^T(i) += K_j^T dS^T.  The partial dQ of row group i is summed in an LDS slot in a FIXED order: the
+//     schedule is skewed (step s: wave w has pair (w + s, w)), so in every step all row groups in flight are distinct, a
+//     block barrier separates the steps, the first contributor stores, the last one adds its part and writes the row group
+//     out.  No atomics, deterministic bits, every wave busy in every one of the 9 steps.
+#include <math.h>
+#include <stdlib.h>
+
+#include "common.h"
+#include "attention.h"
+
+namespace nnhip {
+
+typedef unsigned sb_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned sb_u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SB_T = 256;        // the sequence length these kernels are built for: 8 groups of 32 rows <-> 8 waves
+constexpr int SB_NG = 8;
+constexpr int SB_DH = 64;
+constexpr int SB_LD = SB_DH + 4; // LDS row stride of a staged [32][64] tile (17 chunks of 16 B: conflict-free b128 rows)
+
+// ---- operand streaming --------------------------------------------------------------------------------------------------
+// The loads of the unit loops are inline asm with a read-write ("+v") destination: the refill of an operand register is
+// issued right behind the MFMAs that read it and lands IN PLACE, a whole unit later.  (Left to hipcc, the refill goes to a
+// second register set -- 64 more VGPRs -- and the loop ends in 32-64 v_mov behind a vmcnt that drains the prefetch.)  hipcc
+// does not count asm loads: every consumer is fenced by an explicit `s_waitcnt vmcnt(N)` that names the register ("+v": no
+// consumer can be scheduled above it).  Loads return in order, and in the steady state every operand register has exactly 23
+// younger loads in flight when it is needed (8 K + 16 V loads per unit, issued in consumption order), so N is 23 everywhere;
+// the last unit of an item issues nothing and counts down.
+typedef unsigned sb_rsrc __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ sb_rsrc sb_make_rsrc(const float* base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    sb_rsrc r;
+    // (readfirstlane: the words are uniform anyway, but only this makes hipcc keep the descriptor in scalar registers everywhere --
+    //  under register pressure it otherwise parks it in VGPRs, which a buffer instruction cannot encode)
+    r.x = __builtin_amdgcn_readfirstlane((unsigned)a); r.y = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xFFFFu);
+    r.z = __builtin_amdgcn_readfirstlane(bytes); r.w = 0x00020000u;
+    return r;
+}
+template <int IMM>
+__device__ __forceinline__ void sb_issue128(sb_u32x4& r, unsigned voff, sb_rsrc rs, unsigned soff) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "+v"(r) : "v"(voff), "s"(rs), "s"(soff), "i"(IMM));
+}
+template <int IMM>
+__device__ __forceinline__ void sb_first128(sb_u32x4& r, unsigned voff, sb_rsrc rs, unsigned soff) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(r) : "v"(voff), "s"(rs), "s"(soff), "i"(IMM));
+}
+__device__ __forceinline__ void sb_issue64(sb_u32x2& r, unsigned voff, sb_rsrc rs, unsigned soff) {
+    asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "+v"(r) : "v"(voff), "s"(rs), "s"(soff));
+}
+__device__ __forceinline__ void sb_first64(sb_u32x2& r, unsigned voff, sb_rsrc rs, unsigned soff) {
+    asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "=v"(r) : "v"(voff), "s"(rs), "s"(soff));
+}
+// column-type fetch with a RUNNING scalar offset: load, then advance the offset to the next row of the r(e) sequence inside the same
+// statement (rows 0 1 2 3 8 9 10 11 ...: + pitch, after every fourth + 5 pitch).  Written as `base + r(e) * pitch` hipcc hoists the
+// 3 x 16 products of a pair to its top and runs out of scalar registers (the buffer descriptors then land in VGPRs: no encoding).
+__device__ __forceinline__ void sb_issue64_adv(sb_u32x2& r, unsigned voff, sb_rsrc rs, unsigned& soff, unsigned step) {
+    asm volatile("buffer_load_dwordx2 %0, %2, %3, %1 offen\n\ts_add_u32 %1, %1, %4" : "+v"(r), "+s"(soff) : "v"(voff), "s"(rs), "s"(step) : "scc");   // (s_add writes SCC)
+}
+template <int N>
+__device__ __forceinline__ void sb_wait(sb_u32x4& r) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r) : "i"(N)); }
+template <int N>
+__device__ __forceinline__ void sb_wait(sb_u32x2& r) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r) : "i"(N)); }
+template <int N>
+__device__ __forceinline__ void sb_wait2(sb_u32x4& r, sb_u32x4& q) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r), "+v"(q) : "i"(N)); }
+// 32 staged rows of 64 floats (LDS row stride SB_LD) -> 32 tensor rows starting at byte offset `soff` of the slice behind `rs`, as
+// whole 256-byte rows: 16 lanes per row, 4 rows per wave-store, the row step in the SCALAR offset (a 64-bit address per store is
+// 16 VGPRs that hipcc hoists out of the pair loop)
+__device__ __forceinline__ void sb_rows_out(const float* __restrict__ E, sb_rsrc rs, unsigned soff, unsigned pitchB, int lane) {
+    const unsigned voff = (unsigned)(lane >> 4) * pitchB + (unsigned)(lane & 15) * 16u;
+    const float* __restrict__ src = E + (lane >> 4) * SB_LD + (lane & 15) * 4;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const float4 v = *reinterpret_cast<const float4*>(src + it * 4 * SB_LD);
+        sb_u32x4 u;
+        u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
+        // (the s_nop: hipcc does not know that a store is still reading its data registers when the statement ends)
+        asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" : : "v"(u), "v"(voff), "s"(rs), "s"(soff + (unsigned)it * 4u * pitchB) : "memory");
+    }
+}
+// acc[dt][e] = X^T[d = 2 (r(e) + 4 lh) + dt][row = l31]  ->  32 rows of 64 floats at byte offset soff of the slice behind rs, through the wave's rows E
+__device__ __forceinline__ void sb_store_rows(float* __restrict__ E, const f32x16 (&acc)[2], float mul, sb_rsrc rs, unsigned soff, unsigned pitchB, int lane) {
+    const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        *reinterpret_cast<float4*>(&E[l31 * SB_LD + 16 * c + 8 * lh]) =
+            make_float4(acc[0][4 * c] * mul, acc[1][4 * c] * mul, acc[0][4 * c + 1] * mul, acc[1][4 * c + 1] * mul);
+        *reinterpret_cast<float4*>(&E[l31 * SB_LD + 16 * c + 8 * lh + 4]) =
+            make_float4(acc[0][4 * c + 2] * mul, acc[1][4 * c + 2] * mul, acc[0][4 * c + 3] * mul, acc[1][4 * c + 3] * mul);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0): the staging rows are private to the wave
+    __builtin_amdgcn_wave_barrier();
+    sb_rows_out(E, rs, soff, pitchB, lane);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();          // the staging rows are free again
+}
+
+__device__ __forceinline__ float sb_f(unsigned u) { return __uint_as_float(u); }
+
+// row r(e) of a 32-row group that accumulator register e carries for the lower half-wave (the upper one: + 4)
+__device__ __forceinline__ constexpr int sb_row(int e) { return (e & 3) + 8 * (e >> 2); }
+
+// max / sum over the lane pair (l, l + 32) -- the two halves of one query / key column
+__device__ __forceinline__ float sb_pair_max(float v) { return fmaxf(v, __shfl_xor(v, 32, 64)); }
+__device__ __forceinline__ float sb_pair_sum(float v) { return v + __shfl_xor(v, 32, 64); }
+
+// padding bits of the 256 keys of a sequence as four scalars (an indexed array of them lands in scratch)
+struct SbKeyBits { unsigned long long w0, w1, w2, w3; };
+__device__ __forceinline__ unsigned sb_valid32(const SbKeyBits& k, int j) {
+    const unsigned long long lo = j < 2 ? k.w0 : k.w1, hi = j < 6 ? k.w2 : k.w3;
+    const unsigned long long w = j < 4 ? lo : hi;
+    return (unsigned)(w >> (32 * (j & 1)));
+}
+
+// ballots of the padding flags of one sequence; fv = its first real key (256 if none)
+__device__ __forceinline__ void sb_key_bits(const int32_t* __restrict__ kv, int lane, SbKeyBits& k, int& fv) {
+    const int f0 = kv[lane], f1 = kv[64 + lane], f2 = kv[128 + lane], f3 = kv[192 + lane];
+    k.w0 = __ballot(f0 != 0); k.w1 = __ballot(f1 != 0); k.w2 = __ballot(f2 != 0); k.w3 = __ballot(f3 != 0);
+    fv = k.w0 ? (int)__builtin_ctzll(k.w0) : k.w1 ? 64 + (int)__builtin_ctzll(k.w1)
+       : k.w2 ? 128 + (int)__builtin_ctzll(k.w2) : k.w3 ? 192 + (int)__builtin_ctzll(k.w3) : SB_T;
+}
+
+// =====================================================================================================
+// forward
+// =====================================================================================================
+// One unit = one 32-key group against this wave's 32 queries: S^T = K_j Q^T (32 MFMAs), online softmax (lane <-> query),
+// O^T += V_j^T P^T (32 MFMAs).  kreg / vreg hold group j on entry; unless LAST, group j + 1 is on its way into them on exit.
+#define SB_FWD_QK(g)                                                                      \
+    do {                                                                                  \
+        sb_wait<LAST ? 23 - (g) : 23>(kreg[g]);                                           \
+        s = AT_MFMA(sb_f(kreg[g].x), qf[g][0], s);                                        \
+        s = AT_MFMA(sb_f(kreg[g].y), qf[g][1], s);                                        \
+        s = AT_MFMA(sb_f(kreg[g].z), qf[g][2], s);                                        \
+        s = AT_MFMA(sb_f(kreg[g].w), qf[g][3], s);                                        \
+        if constexpr (!LAST) sb_issue128<32 * (g)>(kreg[g], voffK, rk, soff_next);        \
+    } while (0)
+#define SB_FWD_PV(e)                                                                      \
+    do {                                                                                  \
+        sb_wait<LAST ? 15 - (e) : 23>(vreg[e]);                                           \
+        o[0] = AT_MFMA(sb_f(vreg[e].x), s[e], o[0]);                                      \
+        o[1] = AT_MFMA(sb_f(vreg[e].y), s[e], o[1]);                                      \
+        if constexpr (!LAST) sb_issue64(vreg[e], voffV, rv, soff_next + (unsigned)sb_row(e) * pitchB); \
+    } while (0)
+
+template <bool MASKED, bool LAST>
+__device__ __forceinline__ void sb_fwd_unit(f32x16 (&o)[2], float& m, float& l, sb_u32x4 (&kreg)[8], sb_u32x2 (&vreg)[16], const float (&qf)[8][4],
+                                            const sb_rsrc rk, const sb_rsrc rv, const unsigned voffK, const unsigned voffV,
+                                            const unsigned soff_next, const unsigned pitchB, const int lim_causal, const unsigned valid) {
+    f32x16 s;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e] = 0.f;
+    SB_FWD_QK(0); SB_FWD_QK(1); SB_FWD_QK(2); SB_FWD_QK(3); SB_FWD_QK(4); SB_FWD_QK(5); SB_FWD_QK(6); SB_FWD_QK(7);
+    float mx = -INFINITY;
+    if constexpr (MASKED) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int r = sb_row(e);
+            if (r > lim_causal || !((valid >> r) & 1u)) s[e] = AT_MASKED2;
+            mx = fmaxf(mx, s[e]);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[e]);
+    }
+    mx = sb_pair_max(mx);
+    // lazy running maximum: m only moves when a row maximum outgrows it by more than 2^8 (always on the first unit: m = -inf)
+    if (__ballot(mx > m + 8.0f) != 0ull) {
+        const float m_new = fmaxf(m, mx);
+        const float alpha = m_new == m ? 1.0f : __builtin_amdgcn_exp2f(m - m_new);
+        m = m_new;
+        l *= alpha;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { o[0][e] *= alpha; o[1][e] *= alpha; }
+    }
+    float ps = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        s[e] = __builtin_amdgcn_exp2f(s[e] - m);
+        ps += s[e];
+    }
+    l += ps;
+    SB_FWD_PV(0); SB_FWD_PV(1); SB_FWD_PV(2); SB_FWD_PV(3); SB_FWD_PV(4); SB_FWD_PV(5); SB_FWD_PV(6); SB_FWD_PV(7);
+    SB_FWD_PV(8); SB_FWD_PV(9); SB_FWD_PV(10); SB_FWD_PV(11); SB_FWD_PV(12); SB_FWD_PV(13); SB_FWD_PV(14); SB_FWD_PV(15);
+}
+
+__global__ __launch_bounds__(512, 2) void attn_sb_fwd_kernel(const AttnParams p) {
+    __shared__ __attribute__((aligned(16))) float smem[8 * 32 * SB_LD];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: everything derived from it stays scalar
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int BH = p.B * p.H;
+    const unsigned pitchB = (unsigned)p.LQ * 4u;                                 // bytes between two rows of Q / K / V
+    const unsigned slice_bytes = (unsigned)(((int64_t)(SB_T - 1) * p.LQ + SB_DH) * 4);
+    const unsigned voffK = (unsigned)l31 * pitchB + 16u * lh;                    // lane <-> row l31, columns 8 g + 4 lh .. + 3
+    const unsigned voffV = 4u * lh * pitchB + 8u * l31;                          // lane <-> columns 2 l31, 2 l31 + 1 of row r(e) + 4 lh
+    const float qs = p.scale * AT_LOG2E;
+    float* E = smem + wave * (32 * SB_LD);
+
+#pragma unroll 1
+    for (int item = 0; item < 2; ++item) {
+        const int bh = 2 * blockIdx.x + item;
+        if (bh >= BH) break;
+        const int rg = item == 0 ? SB_NG - 1 - wave : wave;                      // this wave's row group: queries 32 rg .. 32 rg + 31
+        const int b = bh / p.H, h = bh - b * p.H;
+        const float* Qb = p.Q + ((int64_t)b * SB_T) * p.LQ + (int64_t)h * SB_DH;
+        const sb_rsrc rk = sb_make_rsrc(p.K + ((int64_t)b * SB_T) * p.LQ + (int64_t)h * SB_DH, slice_bytes);
+        const sb_rsrc rv = sb_make_rsrc(p.V + ((int64_t)b * SB_T) * p.LQ + (int64_t)h * SB_DH, slice_bytes);
+
+        // every load of the prologue is in flight before the first wait: key group 0, the Q fragments, the padding flags
+        sb_u32x4 kreg[8];
+        sb_u32x2 vreg[16];
+        sb_first128<0>(kreg[0], voffK, rk, 0u); sb_first128<32>(kreg[1], voffK, rk, 0u); sb_first128<64>(kreg[2], voffK, rk, 0u);
+        sb_first128<96>(kreg[3], voffK, rk, 0u); sb_first128<128>(kreg[4], voffK, rk, 0u); sb_first128<160>(kreg[5], voffK, rk, 0u);
+        sb_first128<192>(kreg[6], voffK, rk, 0u); sb_first128<224>(kreg[7], voffK, rk, 0u);
+        float qf[8][4];
+        {
+            const float* qrow = Qb + (int64_t)(32 * rg + l31) * p.LQ + 4 * lh;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const float4 v = *reinterpret_cast<const float4*>(qrow + 8 * g);
+                qf[g][0] = v.x; qf[g][1] = v.y; qf[g][2] = v.z; qf[g][3] = v.w;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sb_first64(vreg[e], voffV, rv, (unsigned)sb_row(e) * pitchB);
+        SbKeyBits kvbits = {~0ull, ~0ull, ~0ull, ~0ull};
+        int fv = 0;
+        if (p.key_valid) sb_key_bits(p.key_valid + (int64_t)b * SB_T, lane, kvbits, fv);
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) qf[g][j] *= qs;
+
+        // key groups above the diagonal contribute exp(-1e9 - m) = 0 and are skipped -- unless a query of this group has NO visible
+        // real key: its softmax is uniform over ALL keys (every score is the same -1e9), so nothing may be skipped
+        const int n_units = fv <= 32 * rg ? rg + 1 : SB_NG;
+        f32x16 o[2];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { o[0][e] = 0.f; o[1][e] = 0.f; }
+        float m = -INFINITY, l = 0.f;
+        // The order of the key groups is free (online softmax).  ONE loop body per kind of unit -- with the plain and the masked
+        // body as alternatives inside one loop, hipcc gives the operand registers different homes per path and copies them around
+        // while their loads are in flight: first every group that needs no masking (below the diagonal, all 32 keys real), then the
+        // masked ones (padding inside; above the diagonal for a group with fully-masked rows), the diagonal group last.
+        unsigned plain = 0u;
+#pragma unroll
+        for (int j = 0; j < SB_NG; ++j)
+            if (j < rg && sb_valid32(kvbits, j) == 0xFFFFFFFFu) plain |= 1u << j;
+        unsigned masked = (((1u << n_units) - 1u) & ~plain) & ~(1u << rg);
+        // (the prologue fetched group 0: right unless group 0 is not the first one in this order -- then refetch; rare: padding in
+        //  the first 32 keys of a sequence)
+        const int first = plain ? (int)__builtin_ctz(plain) : masked ? (int)__builtin_ctz(masked) : rg;
+        if (first != 0) {
+            const unsigned so = (unsigned)(32 * first) * pitchB;
+            sb_first128<0>(kreg[0], voffK, rk, so); sb_first128<32>(kreg[1], voffK, rk, so); sb_first128<64>(kreg[2], voffK, rk, so);
+            sb_first128<96>(kreg[3], voffK, rk, so); sb_first128<128>(kreg[4], voffK, rk, so); sb_first128<160>(kreg[5], voffK, rk, so);
+            sb_first128<192>(kreg[6], voffK, rk, so); sb_first128<224>(kreg[7], voffK, rk, so);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sb_first64(vreg[e], voffV, rv, so + (unsigned)sb_row(e) * pitchB);
+        }
+#pragma unroll 1
+        while (plain) {
+            plain &= plain - 1u;
+            const int jn = plain ? (int)__builtin_ctz(plain) : masked ? (int)__builtin_ctz(masked) : rg;
+            sb_fwd_unit<false, false>(o, m, l, kreg, vreg, qf, rk, rv, voffK, voffV, (unsigned)(32 * jn) * pitchB, pitchB, 0, 0u);
+        }
+#pragma unroll 1
+        while (masked) {
+            const int j = (int)__builtin_ctz(masked);
+            masked &= masked - 1u;
+            const int jn = masked ? (int)__builtin_ctz(masked) : rg;
+            sb_fwd_unit<true, false>(o, m, l, kreg, vreg, qf, rk, rv, voffK, voffV, (unsigned)(32 * jn) * pitchB, pitchB, j < rg ? (1 << 20) : -1,
+                                     sb_valid32(kvbits, j) >> (4 * lh));
+        }
+        // the diagonal group: key r(e) + 4 lh is visible to query l31 iff it is <= l31
+        sb_fwd_unit<true, true>(o, m, l, kreg, vreg, qf, rk, rv, voffK, voffV, 0u, pitchB, l31 - 4 * lh, sb_valid32(kvbits, rg) >> (4 * lh));
+        // ---- finish: O = O^T / l; (m, log2 sum) stay apart: a fully-masked row has m = -1e9 log2e, where fp32 cannot hold m + log2 l
+        const float lt = sb_pair_sum(l);
+        const float inv = lt > 0.f ? 1.0f / lt : 0.f;
+        const int q0 = 32 * rg;
+        if (lh == 0) *reinterpret_cast<float2*>(p.LSE + 2 * ((int64_t)bh * SB_T + q0 + l31)) = make_float2(m, log2f(lt));
+        // o[dt][e] = O^T[d = 2 (r(e) + 4 lh) + dt][q = l31] -> rows of the context tensor, through the wave's staging rows
+        sb_store_rows(E, o, inv, sb_make_rsrc(p.O + ((int64_t)b * SB_T) * p.D + (int64_t)h * SB_DH, (unsigned)(((int64_t)(SB_T - 1) * p.D + SB_DH) * 4)),
+                      (unsigned)q0 * (unsigned)p.D * 4u, (unsigned)p.D * 4u, lane);
+    }
+}
+
+
+// =====================================================================================================
+// backward: one pass, 5 GEMM-units per (row group i, key group j) pair
+// =====================================================================================================
+// The wave that owns key group j keeps K_j / V_j fragments (the B operands of S and dP: lane <-> key) and the dK_j^T / dV_j^T
+// accumulators in registers and walks the row groups i >= j.  Per pair, in this order:
+//   U1  S[q, key]  = Q_i K_j^T           A = Q_i rows   (lane <-> query row, float4)     B = K_j fragments (pre-scaled, log2 units)
+//   U2  dP[q, key] = dO_i V_j^T          A = dO_i rows                                   B = V_j fragments
+//       P = exp2(S_masked - m[q] - l[q]),  dS = P (dP - Dsum[q]) scale, 0 where masked  (lane <-> key, registers <-> queries)
+//   U3  dV_j^T[d, key] += dO_i^T P       A = dO_i columns (lane <-> two head-dim columns, float2)    B = P, from its registers
+//   U4  dK_j^T[d, key] += Q_i^T dS       A = Q_i columns                                             B = dS, from its registers
+//       dS -> wave-private LDS -> dS^T (lane <-> query)
+//   U5  dQ_i^T[d, q]  (+)= K_j^T dS^T    A = K_j columns                                             B = dS^T
+// Two rolling operand buffers: R (8 float4: Q_i rows -> dO_i rows -> Q_i' rows ...) and C (16 float2: dO_i columns -> Q_i columns
+// -> K_j columns -> dO_i' columns ...).  Every register is refilled in place right behind the MFMAs that read it; the refills with
+// a budget of only one unit (dO_i rows, Q_i columns, K_j columns) hit lines that the long-budget loads of the same tile (dO_i
+// columns, Q_i rows: issued three units ahead) have already brought in.  Loads return in order and are issued in consumption
+// order, 80 per pair, so every wait is a constant: U1 vmcnt(62), U2 vmcnt(14), U3 vmcnt(47), U4 / U5 vmcnt(15).
+#define SB_BWD_U1(g)                                                                      \
+    do {                                                                                  \
+        sb_wait2<62>(R[g], RB[g]);                                                        \
+        s = AT_MFMA(sb_f(R[g].x), sb_f(RB[g].x), s);                                      \
+        s = AT_MFMA(sb_f(R[g].y), sb_f(RB[g].y), s);                                      \
+        s = AT_MFMA(sb_f(R[g].z), sb_f(RB[g].z), s);                                      \
+        s = AT_MFMA(sb_f(R[g].w), sb_f(RB[g].w), s);                                      \
+        sb_issue128<32 * (g)>(R[g], voffRg, rg, soG_i);                               \
+        sb_issue128<32 * (g)>(RB[g], voffRq, rv, soK_j);                              \
+    } while (0)
+#define SB_BWD_U2(g)                                                                      \
+    do {                                                                                  \
+        sb_wait2<14>(R[g], RB[g]);                                                        \
+        dp = AT_MFMA(sb_f(R[g].x), sb_f(RB[g].x), dp);                                    \
+        dp = AT_MFMA(sb_f(R[g].y), sb_f(RB[g].y), dp);                                    \
+        dp = AT_MFMA(sb_f(R[g].z), sb_f(RB[g].z), dp);                                    \
+        dp = AT_MFMA(sb_f(R[g].w), sb_f(RB[g].w), dp);                                    \
+        sb_issue128<32 * (g)>(R[g], voffRq, rq, soQ_n);                               \
+        sb_issue128<32 * (g)>(RB[g], voffRq, rk, soK_j);                              \
+    } while (0)
+#define SB_BWD_U3(e)                                                                      \
+    do {                                                                                  \
+        sb_wait<47>(C[e]);                                                                \
+        dv[0] = AT_MFMA(sb_f(C[e].x), s[e], dv[0]);                                       \
+        dv[1] = AT_MFMA(sb_f(C[e].y), s[e], dv[1]);                                       \
+        sb_issue64_adv(C[e], voffCq, rq, so3, ((e) & 3) == 3 ? 5u * pitchQ : pitchQ); \
+    } while (0)
+#define SB_BWD_U4(e)                                                                      \
+    do {                                                                                  \
+        sb_wait<15>(C[e]);                                                                \
+        dk[0] = AT_MFMA(sb_f(C[e].x), dp[e], dk[0]);                                      \
+        dk[1] = AT_MFMA(sb_f(C[e].y), dp[e], dk[1]);                                      \
+        sb_issue64_adv(C[e], voffCq, rk, so4, ((e) & 3) == 3 ? 5u * pitchQ : pitchQ); \
+    } while (0)
+#define SB_BWD_U5(e)                                                                      \
+    do {                                                                                  \
+        sb_wait<15>(C[e]);                                                                \
+        dq[0] = AT_MFMA(sb_f(C[e].x), dst[e], dq[0]);                                     \
+        dq[1] = AT_MFMA(sb_f(C[e].y), dst[e], dq[1]);                                     \
+        sb_issue64_adv(C[e], voffCg, rg, so5, ((e) & 3) == 3 ? 5u * pitchG : pitchG); \
+    } while (0)
+
+// `slot`: the LDS rows where the partial dQ of row group i is summed (first: store, otherwise add; last: the sum goes out).
+// Everything that does not change while a wave works on one (slice, key group) is passed BY VALUE: gathered in a struct it stays in
+// memory across the four inlined copies of this body, and a buffer descriptor reloaded from scratch is a VGPR no buffer
+// instruction can encode.
+template <bool DIAG>
+__device__ __forceinline__ void sb_bwd_pair(f32x16 (&dk)[2], f32x16 (&dv)[2], sb_u32x4 (&R)[8], sb_u32x4 (&RB)[8], sb_u32x2 (&C)[16],
+                                            const sb_rsrc rq, const sb_rsrc rk, const sb_rsrc rv, const sb_rsrc rg,      // Q, K, V, dO rows of the slice
+                                            const unsigned voffRq, const unsigned voffRg, const unsigned voffCq, const unsigned voffCg,
+                                            const unsigned pitchQ, const unsigned pitchG,
+                                            const float* __restrict__ Mt,          // LDS: max | log2 sum | Dsum of the slice's 256 queries
+                                            float* __restrict__ scratch,           // LDS: this wave's staging rows
+                                            const sb_rsrc rdq,                     // global: dQ rows of the slice
+                                            const float scale, const float sl2, const bool key_pad, const int j, const int i, const int i_next,
+                                            float* __restrict__ slot, const bool first, const bool last, const int lane) {
+    const int l31 = lane & 31, lh = lane >> 5;
+    const float* __restrict__ Lt = Mt + SB_T;
+    const float* __restrict__ Dt = Mt + 2 * SB_T;
+    const unsigned soQ_i = (unsigned)(32 * i) * pitchQ, soG_i = (unsigned)(32 * i) * pitchG;
+    const unsigned soQ_n = (unsigned)(32 * i_next) * pitchQ, soG_n = (unsigned)(32 * i_next) * pitchG;
+    const unsigned soK_j = (unsigned)(32 * j) * pitchQ;
+    unsigned so3 = soQ_i, so4 = soK_j, so5 = soG_n;          // running row offsets of the three column-type streams
+    f32x16 s, dp;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+    SB_BWD_U1(0); SB_BWD_U1(1); SB_BWD_U1(2); SB_BWD_U1(3); SB_BWD_U1(4); SB_BWD_U1(5); SB_BWD_U1(6); SB_BWD_U1(7);
+    SB_BWD_U2(0); SB_BWD_U2(1); SB_BWD_U2(2); SB_BWD_U2(3); SB_BWD_U2(4); SB_BWD_U2(5); SB_BWD_U2(6); SB_BWD_U2(7);
+    // ---- P (into s) and dS (into dp); register e <-> query 32 i + r(e) + 4 lh, lane <-> key 32 j + l31 ----------------------------
+    const float kscale = key_pad ? 0.f : scale;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float4 M4 = *reinterpret_cast<const float4*>(&Mt[32 * i + 8 * c + 4 * lh]);
+        const float4 L4 = *reinterpret_cast<const float4*>(&Lt[32 * i + 8 * c + 4 * lh]);
+        const float4 D4 = *reinterpret_cast<const float4*>(&Dt[32 * i + 8 * c + 4 * lh]);
+        const float Mr[4] = {M4.x, M4.y, M4.z, M4.w}, Lr[4] = {L4.x, L4.y, L4.z, L4.w}, Dr[4] = {D4.x, D4.y, D4.z, D4.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = 4 * c + r;
+            bool masked = key_pad;
+            if constexpr (DIAG) masked = masked || (8 * c + r + 4 * lh < l31);      // the query comes before the key
+            const float pv = __builtin_amdgcn_exp2f((masked ? AT_MASKED2 - Mr[r] : fmaf(s[e], sl2, -Mr[r])) - Lr[r]);
+            s[e] = pv;
+            float ds = pv * ((dp[e] - Dr[r]) * kscale);
+            if constexpr (DIAG) ds = masked ? 0.f : ds;
+            dp[e] = ds;
+        }
+    }
+    SB_BWD_U3(0); SB_BWD_U3(1); SB_BWD_U3(2); SB_BWD_U3(3); SB_BWD_U3(4); SB_BWD_U3(5); SB_BWD_U3(6); SB_BWD_U3(7);
+    SB_BWD_U3(8); SB_BWD_U3(9); SB_BWD_U3(10); SB_BWD_U3(11); SB_BWD_U3(12); SB_BWD_U3(13); SB_BWD_U3(14); SB_BWD_U3(15);
+    // dS -> LDS [query][key] (row stride 36) while the dK MFMAs run; read back with lane <-> query
+#pragma unroll
+    for (int e = 0; e < 16; ++e) scratch[(sb_row(e) + 4 * lh) * 36 + l31] = dp[e];
+    SB_BWD_U4(0); SB_BWD_U4(1); SB_BWD_U4(2); SB_BWD_U4(3); SB_BWD_U4(4); SB_BWD_U4(5); SB_BWD_U4(6); SB_BWD_U4(7);
+    SB_BWD_U4(8); SB_BWD_U4(9); SB_BWD_U4(10); SB_BWD_U4(11); SB_BWD_U4(12); SB_BWD_U4(13); SB_BWD_U4(14); SB_BWD_U4(15);
+    __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0): the staging rows are private to the wave
+    __builtin_amdgcn_wave_barrier();
+    float dst[16];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float4 t = *reinterpret_cast<const float4*>(&scratch[l31 * 36 + 8 * c + 4 * lh]);
+        dst[4 * c] = t.x; dst[4 * c + 1] = t.y; dst[4 * c + 2] = t.z; dst[4 * c + 3] = t.w;
+    }
+    f32x16 dq[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { dq[0][e] = 0.f; dq[1][e] = 0.f; }
+    SB_BWD_U5(0); SB_BWD_U5(1); SB_BWD_U5(2); SB_BWD_U5(3); SB_BWD_U5(4); SB_BWD_U5(5); SB_BWD_U5(6); SB_BWD_U5(7);
+    SB_BWD_U5(8); SB_BWD_U5(9); SB_BWD_U5(10); SB_BWD_U5(11); SB_BWD_U5(12); SB_BWD_U5(13); SB_BWD_U5(14); SB_BWD_U5(15);
+    // ---- this pair's part of dQ_i: dq[dt][e] = dQ^T[d = 2 (r(e) + 4 lh) + dt][q = l31] -> slot row q, columns 16c + 8lh .. + 7 ------
+    float* __restrict__ row = slot + l31 * SB_LD + 8 * lh;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float4 x = make_float4(dq[0][4 * c], dq[1][4 * c], dq[0][4 * c + 1], dq[1][4 * c + 1]);
+        float4 y = make_float4(dq[0][4 * c + 2], dq[1][4 * c + 2], dq[0][4 * c + 3], dq[1][4 * c + 3]);
+        if (!first) {
+            const float4 px = *reinterpret_cast<const float4*>(row + 16 * c), py = *reinterpret_cast<const float4*>(row + 16 * c + 4);
+            x.x += px.x; x.y += px.y; x.z += px.z; x.w += px.w;
+            y.x += py.x; y.y += py.y; y.z += py.z; y.w += py.w;
+        }
+        *reinterpret_cast<float4*>(row + 16 * c) = x;
+        *reinterpret_cast<float4*>(row + 16 * c + 4) = y;
+    }
+    if (last) {                               // wave-uniform: the row group is complete -- write it out as whole rows
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        sb_rows_out(slot, rdq, soQ_i, pitchQ, lane);
+    }
+}
+
+// step barrier: LDS traffic of this step done, then meet -- and nothing else (a __syncthreads() would also wait for this wave's
+// global stores, i.e. drain the operand prefetch with them: vmcnt counts every kind of access)
+__device__ __forceinline__ void sb_step_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// phase 0: key group `wave` of slice A, pairs (i, j) for i = j .. 7 (steps 0 .. 7 - wave: diagonal first);
+// phase 1: key group 7 - wave of slice B, i = 7 down to j (steps 8 - wave .. 8: diagonal last).  7 step barriers in all for every wave
+// (phase 0: after each of its pairs; phase 1: after each pair but the last).
+template <int PH>
+__device__ __forceinline__ void sb_bwd_phase(const AttnBwdParams& p, float* __restrict__ smem, const int wave, const int lane, f32x16 (&dk)[2],
+                                             f32x16 (&dv)[2], sb_u32x4 (&R)[8], sb_u32x4 (&RB)[8], sb_u32x2 (&C)[16]) {
+    constexpr int SLOT = 32 * SB_LD;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int bh = 2 * blockIdx.x + PH;
+    const int j = PH == 0 ? wave : SB_NG - 1 - wave;
+    const int npairs = SB_NG - j;
+    if (bh >= p.B * p.H) {                    // block-uniform: an odd number of slices leaves the last block without a B
+        for (int s = 0; s < (PH == 0 ? npairs : npairs - 1); ++s) sb_step_barrier();
+        return;
+    }
+    float* __restrict__ slots = smem;
+    float* __restrict__ E = smem + (8 + wave) * SLOT;
+    const float* __restrict__ Mt = smem + 16 * SLOT + PH * 3 * SB_T;
+    const unsigned pitchQ = (unsigned)p.LQ * 4u, pitchG = (unsigned)p.D * 4u;
+    const unsigned bytesQ = (unsigned)(((int64_t)(SB_T - 1) * p.LQ + SB_DH) * 4), bytesG = (unsigned)(((int64_t)(SB_T - 1) * p.D + SB_DH) * 4);
+    const float sl2 = p.scale * AT_LOG2E;
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int64_t base = ((int64_t)b * SB_T) * p.LQ + (int64_t)h * SB_DH;
+    const sb_rsrc rq = sb_make_rsrc(p.Q + base, bytesQ), rk = sb_make_rsrc(p.K + base, bytesQ), rv = sb_make_rsrc(p.V + base, bytesQ);
+    const sb_rsrc rg = sb_make_rsrc(p.dO + ((int64_t)b * SB_T) * p.D + (int64_t)h * SB_DH, bytesG);
+    const unsigned voffRq = (unsigned)l31 * pitchQ + 16u * lh, voffRg = (unsigned)l31 * pitchG + 16u * lh;   // row-type fetch: lane <-> row l31
+    const unsigned voffCq = 4u * lh * pitchQ + 8u * l31, voffCg = 4u * lh * pitchG + 8u * l31;               // column-type: lane <-> columns 2 l31, + 1
+    const sb_rsrc rdq = sb_make_rsrc(p.dQ + base, bytesQ);
+    int fv = 0;
+    SbKeyBits kvbits = {~0ull, ~0ull, ~0ull, ~0ull};
+    if (p.key_valid) sb_key_bits(p.key_valid + (int64_t)b * SB_T, lane, kvbits, fv);
+    const bool key_pad = !((sb_valid32(kvbits, j) >> l31) & 1u);           // this lane's key is padding
+    // the first pair's operands: Q rows / dO columns of its row group, the K_j fragments (lane <-> key row: the B operand of S)
+    const int i0 = PH == 0 ? j : SB_NG - 1;
+    const unsigned so0 = (unsigned)(32 * i0) * pitchQ, sok = (unsigned)(32 * j) * pitchQ;
+    sb_first128<0>(R[0], voffRq, rq, so0); sb_first128<32>(R[1], voffRq, rq, so0); sb_first128<64>(R[2], voffRq, rq, so0);
+    sb_first128<96>(R[3], voffRq, rq, so0); sb_first128<128>(R[4], voffRq, rq, so0); sb_first128<160>(R[5], voffRq, rq, so0);
+    sb_first128<192>(R[6], voffRq, rq, so0); sb_first128<224>(R[7], voffRq, rq, so0);
+    sb_first128<0>(RB[0], voffRq, rk, sok); sb_first128<32>(RB[1], voffRq, rk, sok); sb_first128<64>(RB[2], voffRq, rk, sok);
+    sb_first128<96>(RB[3], voffRq, rk, sok); sb_first128<128>(RB[4], voffRq, rk, sok); sb_first128<160>(RB[5], voffRq, rk, sok);
+    sb_first128<192>(RB[6], voffRq, rk, sok); sb_first128<224>(RB[7], voffRq, rk, sok);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sb_first64(C[e], voffCg, rg, (unsigned)(32 * i0 + sb_row(e)) * pitchG);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { dk[0][e] = 0.f; dk[1][e] = 0.f; dv[0][e] = 0.f; dv[1][e] = 0.f; }
+    // the first pair's waits are written for the steady state (62 / 47 younger loads): have its operands landed instead
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(R[0]), "+v"(R[1]), "+v"(R[2]), "+v"(R[3]), "+v"(R[4]), "+v"(R[5]), "+v"(R[6]), "+v"(R[7]));
+    asm volatile("" : "+v"(RB[0]), "+v"(RB[1]), "+v"(RB[2]), "+v"(RB[3]), "+v"(RB[4]), "+v"(RB[5]), "+v"(RB[6]), "+v"(RB[7]));
+    asm volatile("" : "+v"(C[0]), "+v"(C[1]), "+v"(C[2]), "+v"(C[3]), "+v"(C[4]), "+v"(C[5]), "+v"(C[6]), "+v"(C[7]));
+    asm volatile("" : "+v"(C[8]), "+v"(C[9]), "+v"(C[10]), "+v"(C[11]), "+v"(C[12]), "+v"(C[13]), "+v"(C[14]), "+v"(C[15]));
+#define SB_PAIR_ARGS dk, dv, R, RB, C, rq, rk, rv, rg, voffRq, voffRg, voffCq, voffCg, pitchQ, pitchG, Mt, E, rdq, p.scale, sl2, key_pad, j
+    // dQ slot of row group i: phase 0 -> slot i (rows 0 .. i finish in this order), phase 1 -> slot 7 - i (free again by then)
+    if constexpr (PH == 0) {
+        // diagonal pair first: it opens slot j; the last contribution to a row group comes from key group 0
+        sb_bwd_pair<true>(SB_PAIR_ARGS, j, j + 1 < SB_NG ? j + 1 : j, slots + j * SLOT, true, j == 0, lane);
+        sb_step_barrier();
+#pragma unroll 1
+        for (int s = 1; s < npairs; ++s) {
+            const int i = j + s;
+            sb_bwd_pair<false>(SB_PAIR_ARGS, i, i + 1 < SB_NG ? i + 1 : i, slots + i * SLOT, false, j == 0, lane);
+            sb_step_barrier();
+        }
+    } else {
+#pragma unroll 1
+        for (int s = 0; s + 1 < npairs; ++s) {
+            const int i = SB_NG - 1 - s;
+            sb_bwd_pair<false>(SB_PAIR_ARGS, i, i - 1, slots + (SB_NG - 1 - i) * SLOT, j == 0, false, lane);
+            sb_step_barrier();
+        }
+        // diagonal pair last: it completes row group j
+        sb_bwd_pair<true>(SB_PAIR_ARGS, j, j, slots + (SB_NG - 1 - j) * SLOT, j == 0, true, lane);
+    }
+#undef SB_PAIR_ARGS
+    // the last pair's look-ahead loads re-read its own row group: let them land before their registers are anyone else's
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(R[0]), "+v"(R[1]), "+v"(R[2]), "+v"(R[3]), "+v"(R[4]), "+v"(R[5]), "+v"(R[6]), "+v"(R[7]));
+    asm volatile("" : "+v"(RB[0]), "+v"(RB[1]), "+v"(RB[2]), "+v"(RB[3]), "+v"(RB[4]), "+v"(RB[5]), "+v"(RB[6]), "+v"(RB[7]));
+    asm volatile("" : "+v"(C[0]), "+v"(C[1]), "+v"(C[2]), "+v"(C[3]), "+v"(C[4]), "+v"(C[5]), "+v"(C[6]), "+v"(C[7]));
+    asm volatile("" : "+v"(C[8]), "+v"(C[9]), "+v"(C[10]), "+v"(C[11]), "+v"(C[12]), "+v"(C[13]), "+v"(C[14]), "+v"(C[15]));
+    // Row groups i < j with a fully-masked query (q < fv: its softmax is uniform over ALL keys) reach this key group too:
+    // P = exp2(-1e9 log2e - m - l) is 1 / Tk for such a query and exactly 0 for every other one; dS = 0 (masked), so only dV
+    // gets something.  Rare (leading padding): plain loads, no pipeline.
+    for (int i = 0; i < j && 32 * i < fv; ++i) {
+        f32x16 pm;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 M4 = *reinterpret_cast<const float4*>(&Mt[32 * i + 8 * c + 4 * lh]);
+            const float4 L4 = *reinterpret_cast<const float4*>(&Mt[SB_T + 32 * i + 8 * c + 4 * lh]);
+            pm[4 * c] = __builtin_amdgcn_exp2f((AT_MASKED2 - M4.x) - L4.x); pm[4 * c + 1] = __builtin_amdgcn_exp2f((AT_MASKED2 - M4.y) - L4.y);
+            pm[4 * c + 2] = __builtin_amdgcn_exp2f((AT_MASKED2 - M4.z) - L4.z); pm[4 * c + 3] = __builtin_amdgcn_exp2f((AT_MASKED2 - M4.w) - L4.w);
+        }
+        const float* gcol = p.dO + ((int64_t)b * SB_T + 32 * i + 4 * lh) * p.D + (int64_t)h * SB_DH + 2 * l31;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float2 g2 = *reinterpret_cast<const float2*>(gcol + (int64_t)sb_row(e) * p.D);
+            dv[0] = AT_MFMA(g2.x, pm[e], dv[0]);
+            dv[1] = AT_MFMA(g2.y, pm[e], dv[1]);
+        }
+    }
+    sb_store_rows(E, dk, 1.0f, sb_make_rsrc(p.dK + base, bytesQ), sok, pitchQ, lane);
+    sb_store_rows(E, dv, 1.0f, sb_make_rsrc(p.dV + base, bytesQ), sok, pitchQ, lane);
+}
+
+__global__ __launch_bounds__(512, 2) void attn_sb_bwd_kernel(const AttnBwdParams p) {
+    // one LDS object: [8 dQ slots][32][68] | [8 waves][32][68] staging | (max, log2 sum, Dsum) of 2 x 256 queries
+    constexpr int SLOT = 32 * SB_LD;
+    __shared__ __attribute__((aligned(16))) float smem[16 * SLOT + 2 * 3 * SB_T];
+    float* tabs = smem + 16 * SLOT;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int BH = p.B * p.H;
+
+    // ---- row statistics of both slices into LDS: wave w takes queries 32 w .. 32 w + 31; Dsum[q] = sum_d dO[q,d] O[q,d] ------------
+#pragma unroll 1
+    for (int sl = 0; sl < 2; ++sl) {
+        const int bh = 2 * blockIdx.x + sl;
+        if (bh >= BH) break;
+        const int b = bh / p.H, h = bh - b * p.H;
+        const int q = 32 * wave + l31;
+        const float* go = p.dO + ((int64_t)b * SB_T + q) * p.D + (int64_t)h * SB_DH + 4 * lh;
+        const float* oo = p.O + ((int64_t)b * SB_T + q) * p.D + (int64_t)h * SB_DH + 4 * lh;
+        float part = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const float4 x = *reinterpret_cast<const float4*>(go + 8 * g), y = *reinterpret_cast<const float4*>(oo + 8 * g);
+            part += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+        }
+        const float ds = sb_pair_sum(part);
+        const float2 ml = reinterpret_cast<const float2*>(p.LSE)[(int64_t)bh * SB_T + q];
+        if (lh == 0) {
+            float* t = tabs + sl * 3 * SB_T;
+            t[q] = ml.x; t[SB_T + q] = ml.y; t[2 * SB_T + q] = ds;
+        }
+    }
+    __syncthreads();
+
+    f32x16 dk[2], dv[2];
+    sb_u32x4 R[8], RB[8];
+    sb_u32x2 C[16];
+    sb_bwd_phase<0>(p, smem, wave, lane, dk, dv, R, RB, C);
+    sb_bwd_phase<1>(p, smem, wave, lane, dk, dv, R, RB, C);
+}
+
+}  // namespace nnhip
+
+namespace nnhip {
+
+// NNHIP_ATTN_SB=0 keeps every shape on the tiled kernels of attention.hip (developer A/B switch, read on every call)
+static bool sb_enabled() {
+    const char* e = getenv("NNHIP_ATTN_SB");
+    return !(e && atoi(e) == 0);
+}
+
+bool attn_sb_applicable(int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t head_dim, int causal, bool gen) {
+    return sb_enabled() && !gen && causal && Tq == SB_T && Tk == SB_T && head_dim == SB_DH && B * H >= 1;
+}
+
+int attn_sb_backward(const AttnBwdParams& p, hipStream_t st) {
+    const int BH = p.B * p.H;
+    hipLaunchKernelGGL(attn_sb_bwd_kernel, dim3((unsigned)((BH + 1) / 2)), dim3(512), 0, st, p);
+    NNHIP_LAUNCH_CHECK("attn_sb_bwd_kernel");
+    return 0;
+}
+
+int attn_sb_forward(const AttnParams& p, hipStream_t st) {
+    const int BH = p.B * p.H;
+    hipLaunchKernelGGL(attn_sb_fwd_kernel, dim3((unsigned)((BH + 1) / 2)), dim3(512), 0, st, p);
+    NNHIP_LAUNCH_CHECK("attn_sb_fwd_kernel");
+    return 0;
+}
+
+}  // namespace nnhip
