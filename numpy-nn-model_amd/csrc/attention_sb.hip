@@ -42,14 +42,31 @@ constexpr int SB_NG = 8;
 constexpr int SB_DH = 64;
 constexpr int SB_LD = SB_DH + 4; // LDS row stride of a staged [32][64] tile (17 chunks of 16 B: conflict-free b128 rows)
 
+// Developer instrumentation (tools/attn_sb_prof.py; build.py --variant prof -D SB_PROF): per-wave cycle counts of the kernels' phases,
+// accumulated in registers and written to g_sb_prof[(block * 8 + wave) * 16 + phase] at the end.  Compiled out of the library.
+#ifdef SB_PROF
+__device__ long long* g_sb_prof = nullptr;
+#define SB_PROF_DECL long long pacc_[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long tlast_ = clock64()
+#define SB_T(i) do { const long long t_ = clock64(); pacc_[i] += t_ - tlast_; tlast_ = t_; } while (0)
+#define SB_PROF_STORE(wave) do { if (g_sb_prof && (threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 16; ++i_) g_sb_prof[((int64_t)blockIdx.x * 8 + (wave)) * 16 + i_] = pacc_[i_]; } } while (0)
+#define SB_PROF_ARG , long long (&pacc_)[16], long long& tlast_
+#define SB_PROF_PASS , pacc_, tlast_
+#else
+#define SB_PROF_DECL do {} while (0)
+#define SB_T(i) do {} while (0)
+#define SB_PROF_STORE(wave) do {} while (0)
+#define SB_PROF_ARG
+#define SB_PROF_PASS
+#endif
+
 // ---- operand streaming --------------------------------------------------------------------------------------------------
 // The loads of the unit loops are inline asm with a read-write ("+v") destination: the refill of an operand register is
 // issued right behind the MFMAs that read it and lands IN PLACE, a whole unit later.  (Left to hipcc, the refill goes to a
 // second register set -- 64 more VGPRs -- and the loop ends in 32-64 v_mov behind a vmcnt that drains the prefetch.)  hipcc
 // does not count asm loads: every consumer is fenced by an explicit `s_waitcnt vmcnt(N)` that names the register ("+v": no
 // consumer can be scheduled above it).  Loads return in order, and in the steady state every operand register has exactly 23
-// younger loads in flight when it is needed (8 K + 16 V loads per unit, issued in consumption order), so N is 23 everywhere;
-// the last unit of an item issues nothing and counts down.
+// younger loads in flight when it is needed (8 K + 16 V loads per unit, issued in consumption order), so N is 23 (a few more for the
+// K groups whose burst of refills has already gone out); the last unit of an item issues nothing and counts down.
 typedef unsigned sb_rsrc __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ sb_rsrc sb_make_rsrc(const float* base, unsigned bytes) {
     const unsigned long long a = (unsigned long long)base;
@@ -60,8 +77,13 @@ __device__ __forceinline__ sb_rsrc sb_make_rsrc(const float* base, unsigned byte
     r.z = __builtin_amdgcn_readfirstlane(bytes); r.w = 0x00020000u;
     return r;
 }
+// (developer ablations, tools/attn_sb_abl.sh: -DSB_ABL_NOLOAD drops the refills of the unit loops -- wrong results, the timing of everything
+//  but the operand stream; -DSB_ABL_NOBAR the step barriers of the backward; -DSB_ABL_NOSLOT its dQ slot traffic)
 template <int IMM>
 __device__ __forceinline__ void sb_issue128(sb_u32x4& r, unsigned voff, sb_rsrc rs, unsigned soff) {
+#if defined(SB_ABL_NOLOAD) || defined(SB_ABL_NOROWS)
+    return;
+#endif
     asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "+v"(r) : "v"(voff), "s"(rs), "s"(soff), "i"(IMM));
 }
 template <int IMM>
@@ -69,6 +91,9 @@ __device__ __forceinline__ void sb_first128(sb_u32x4& r, unsigned voff, sb_rsrc 
     asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen offset:%4" : "=v"(r) : "v"(voff), "s"(rs), "s"(soff), "i"(IMM));
 }
 __device__ __forceinline__ void sb_issue64(sb_u32x2& r, unsigned voff, sb_rsrc rs, unsigned soff) {
+#if defined(SB_ABL_NOLOAD) || defined(SB_ABL_NOCOLS)
+    return;
+#endif
     asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "+v"(r) : "v"(voff), "s"(rs), "s"(soff));
 }
 __device__ __forceinline__ void sb_first64(sb_u32x2& r, unsigned voff, sb_rsrc rs, unsigned soff) {
@@ -78,6 +103,9 @@ __device__ __forceinline__ void sb_first64(sb_u32x2& r, unsigned voff, sb_rsrc r
 // statement (rows 0 1 2 3 8 9 10 11 ...: + pitch, after every fourth + 5 pitch).  Written as `base + r(e) * pitch` hipcc hoists the
 // 3 x 16 products of a pair to its top and runs out of scalar registers (the buffer descriptors then land in VGPRs: no encoding).
 __device__ __forceinline__ void sb_issue64_adv(sb_u32x2& r, unsigned voff, sb_rsrc rs, unsigned& soff, unsigned step) {
+#if defined(SB_ABL_NOLOAD) || defined(SB_ABL_NOCOLS)
+    return;
+#endif
     asm volatile("buffer_load_dwordx2 %0, %2, %3, %1 offen\n\ts_add_u32 %1, %1, %4" : "+v"(r), "+s"(soff) : "v"(voff), "s"(rs), "s"(step) : "scc");   // (s_add writes SCC)
 }
 template <int N>
@@ -148,14 +176,22 @@ __device__ __forceinline__ void sb_key_bits(const int32_t* __restrict__ kv, int 
 // =====================================================================================================
 // One unit = one 32-key group against this wave's 32 queries: S^T = K_j Q^T (32 MFMAs), online softmax (lane <-> query),
 // O^T += V_j^T P^T (32 MFMAs).  kreg / vreg hold group j on entry; unless LAST, group j + 1 is on its way into them on exit.
+// Row-type refills go out in BURSTS OF FOUR: the four float4 of a lane pair's 128-byte line of each of the 32 rows.  One refill per MFMA
+// group (256+ cycles apart, other waves' loads in between) found its line evicted from the 32 KB L1 every time: 32 L2 requests per
+// instruction, 4x the useful bytes.  Back to back, the second to fourth load hit the line the first one is fetching.
 #define SB_FWD_QK(g)                                                                      \
     do {                                                                                  \
-        sb_wait<LAST ? 23 - (g) : 23>(kreg[g]);                                           \
+        sb_wait<LAST ? 23 - (g) : ((g) < 4 ? 23 - (g) : 27 - (g))>(kreg[g]);              \
         s = AT_MFMA(sb_f(kreg[g].x), qf[g][0], s);                                        \
         s = AT_MFMA(sb_f(kreg[g].y), qf[g][1], s);                                        \
         s = AT_MFMA(sb_f(kreg[g].z), qf[g][2], s);                                        \
         s = AT_MFMA(sb_f(kreg[g].w), qf[g][3], s);                                        \
-        if constexpr (!LAST) sb_issue128<32 * (g)>(kreg[g], voffK, rk, soff_next);        \
+        if constexpr (!LAST && ((g) & 3) == 3) {                                          \
+            sb_issue128<32 * ((g) - 3)>(kreg[(g) - 3], voffK, rk, soff_next);             \
+            sb_issue128<32 * ((g) - 2)>(kreg[(g) - 2], voffK, rk, soff_next);             \
+            sb_issue128<32 * ((g) - 1)>(kreg[(g) - 1], voffK, rk, soff_next);             \
+            sb_issue128<32 * (g)>(kreg[g], voffK, rk, soff_next);                         \
+        }                                                                                 \
     } while (0)
 #define SB_FWD_PV(e)                                                                      \
     do {                                                                                  \
@@ -168,11 +204,13 @@ __device__ __forceinline__ void sb_key_bits(const int32_t* __restrict__ kv, int 
 template <bool MASKED, bool LAST>
 __device__ __forceinline__ void sb_fwd_unit(f32x16 (&o)[2], float& m, float& l, sb_u32x4 (&kreg)[8], sb_u32x2 (&vreg)[16], const float (&qf)[8][4],
                                             const sb_rsrc rk, const sb_rsrc rv, const unsigned voffK, const unsigned voffV,
-                                            const unsigned soff_next, const unsigned pitchB, const int lim_causal, const unsigned valid) {
+                                            const unsigned soff_next, const unsigned pitchB, const int lim_causal, const unsigned valid SB_PROF_ARG) {
     f32x16 s;
 #pragma unroll
     for (int e = 0; e < 16; ++e) s[e] = 0.f;
+    SB_T(1);
     SB_FWD_QK(0); SB_FWD_QK(1); SB_FWD_QK(2); SB_FWD_QK(3); SB_FWD_QK(4); SB_FWD_QK(5); SB_FWD_QK(6); SB_FWD_QK(7);
+    SB_T(2);
     float mx = -INFINITY;
     if constexpr (MASKED) {
 #pragma unroll
@@ -202,8 +240,10 @@ __device__ __forceinline__ void sb_fwd_unit(f32x16 (&o)[2], float& m, float& l, 
         ps += s[e];
     }
     l += ps;
+    SB_T(3);
     SB_FWD_PV(0); SB_FWD_PV(1); SB_FWD_PV(2); SB_FWD_PV(3); SB_FWD_PV(4); SB_FWD_PV(5); SB_FWD_PV(6); SB_FWD_PV(7);
     SB_FWD_PV(8); SB_FWD_PV(9); SB_FWD_PV(10); SB_FWD_PV(11); SB_FWD_PV(12); SB_FWD_PV(13); SB_FWD_PV(14); SB_FWD_PV(15);
+    SB_T(4);
 }
 
 __global__ __launch_bounds__(512, 2) void attn_sb_fwd_kernel(const AttnParams p) {
@@ -218,6 +258,7 @@ __global__ __launch_bounds__(512, 2) void attn_sb_fwd_kernel(const AttnParams p)
     const unsigned voffV = 4u * lh * pitchB + 8u * l31;                          // lane <-> columns 2 l31, 2 l31 + 1 of row r(e) + 4 lh
     const float qs = p.scale * AT_LOG2E;
     float* E = smem + wave * (32 * SB_LD);
+    SB_PROF_DECL;
 
 #pragma unroll 1
     for (int item = 0; item < 2; ++item) {
@@ -261,6 +302,7 @@ __global__ __launch_bounds__(512, 2) void attn_sb_fwd_kernel(const AttnParams p)
 #pragma unroll
         for (int e = 0; e < 16; ++e) { o[0][e] = 0.f; o[1][e] = 0.f; }
         float m = -INFINITY, l = 0.f;
+        SB_T(0);
         // The order of the key groups is free (online softmax).  ONE loop body per kind of unit -- with the plain and the masked
         // body as alternatives inside one loop, hipcc gives the operand registers different homes per path and copies them around
         // while their loads are in flight: first every group that needs no masking (below the diagonal, all 32 keys real), then the
@@ -285,7 +327,7 @@ __global__ __launch_bounds__(512, 2) void attn_sb_fwd_kernel(const AttnParams p)
         while (plain) {
             plain &= plain - 1u;
             const int jn = plain ? (int)__builtin_ctz(plain) : masked ? (int)__builtin_ctz(masked) : rg;
-            sb_fwd_unit<false, false>(o, m, l, kreg, vreg, qf, rk, rv, voffK, voffV, (unsigned)(32 * jn) * pitchB, pitchB, 0, 0u);
+            sb_fwd_unit<false, false>(o, m, l, kreg, vreg, qf, rk, rv, voffK, voffV, (unsigned)(32 * jn) * pitchB, pitchB, 0, 0u SB_PROF_PASS);
         }
 #pragma unroll 1
         while (masked) {
@@ -293,10 +335,11 @@ __global__ __launch_bounds__(512, 2) void attn_sb_fwd_kernel(const AttnParams p)
             masked &= masked - 1u;
             const int jn = masked ? (int)__builtin_ctz(masked) : rg;
             sb_fwd_unit<true, false>(o, m, l, kreg, vreg, qf, rk, rv, voffK, voffV, (unsigned)(32 * jn) * pitchB, pitchB, j < rg ? (1 << 20) : -1,
-                                     sb_valid32(kvbits, j) >> (4 * lh));
+                                     sb_valid32(kvbits, j) >> (4 * lh) SB_PROF_PASS);
         }
         // the diagonal group: key r(e) + 4 lh is visible to query l31 iff it is <= l31
-        sb_fwd_unit<true, true>(o, m, l, kreg, vreg, qf, rk, rv, voffK, voffV, 0u, pitchB, l31 - 4 * lh, sb_valid32(kvbits, rg) >> (4 * lh));
+        sb_fwd_unit<true, true>(o, m, l, kreg, vreg, qf, rk, rv, voffK, voffV, 0u, pitchB, l31 - 4 * lh, sb_valid32(kvbits, rg) >> (4 * lh) SB_PROF_PASS);
+        SB_T(5);
         // ---- finish: O = O^T / l; (m, log2 sum) stay apart: a fully-masked row has m = -1e9 log2e, where fp32 cannot hold m + log2 l
         const float lt = sb_pair_sum(l);
         const float inv = lt > 0.f ? 1.0f / lt : 0.f;
@@ -305,7 +348,9 @@ __global__ __launch_bounds__(512, 2) void attn_sb_fwd_kernel(const AttnParams p)
         // o[dt][e] = O^T[d = 2 (r(e) + 4 lh) + dt][q = l31] -> rows of the context tensor, through the wave's staging rows
         sb_store_rows(E, o, inv, sb_make_rsrc(p.O + ((int64_t)b * SB_T) * p.D + (int64_t)h * SB_DH, (unsigned)(((int64_t)(SB_T - 1) * p.D + SB_DH) * 4)),
                       (unsigned)q0 * (unsigned)p.D * 4u, (unsigned)p.D * 4u, lane);
+        SB_T(6);
     }
+    SB_PROF_STORE(wave);
 }
 
 
@@ -325,37 +370,47 @@ __global__ __launch_bounds__(512, 2) void attn_sb_fwd_kernel(const AttnParams p)
 // -> K_j columns -> dO_i' columns ...).  Every register is refilled in place right behind the MFMAs that read it; the refills with
 // a budget of only one unit (dO_i rows, Q_i columns, K_j columns) hit lines that the long-budget loads of the same tile (dO_i
 // columns, Q_i rows: issued three units ahead) have already brought in.  Loads return in order and are issued in consumption
-// order, 80 per pair, so every wait is a constant: U1 vmcnt(62), U2 vmcnt(14), U3 vmcnt(47), U4 / U5 vmcnt(15).
+// order, 80 per pair, so every wait is a constant.  The units run in the order U1, P, U3, U2, dS, U4, U5: the buffers that U1 empties (R, RB)
+// are not needed again before U2 -- a unit and the P pass later -- and C's refill for U4 has U2 to land.
+#define SB_BWD_BURST(g, voffR, rsR, soR, rsB)                                            \
+    do {                                                                                  \
+        sb_issue128<32 * ((g) - 3)>(R[(g) - 3], voffR, rsR, soR);                         \
+        sb_issue128<32 * ((g) - 3)>(RB[(g) - 3], voffRq, rsB, soK_j);                     \
+        sb_issue128<32 * ((g) - 2)>(R[(g) - 2], voffR, rsR, soR);                         \
+        sb_issue128<32 * ((g) - 2)>(RB[(g) - 2], voffRq, rsB, soK_j);                     \
+        sb_issue128<32 * ((g) - 1)>(R[(g) - 1], voffR, rsR, soR);                         \
+        sb_issue128<32 * ((g) - 1)>(RB[(g) - 1], voffRq, rsB, soK_j);                     \
+        sb_issue128<32 * (g)>(R[g], voffR, rsR, soR);                                     \
+        sb_issue128<32 * (g)>(RB[g], voffRq, rsB, soK_j);                                 \
+    } while (0)
 #define SB_BWD_U1(g)                                                                      \
     do {                                                                                  \
-        sb_wait2<62>(R[g], RB[g]);                                                        \
+        sb_wait2<46 - 2 * ((g) & 3)>(R[g], RB[g]);                                        \
         s = AT_MFMA(sb_f(R[g].x), sb_f(RB[g].x), s);                                      \
         s = AT_MFMA(sb_f(R[g].y), sb_f(RB[g].y), s);                                      \
         s = AT_MFMA(sb_f(R[g].z), sb_f(RB[g].z), s);                                      \
         s = AT_MFMA(sb_f(R[g].w), sb_f(RB[g].w), s);                                      \
-        sb_issue128<32 * (g)>(R[g], voffRg, rg, soG_i);                               \
-        sb_issue128<32 * (g)>(RB[g], voffRq, rv, soK_j);                              \
+        if constexpr (((g) & 3) == 3) SB_BWD_BURST(g, voffRg, rg, soG_i, rv);             \
     } while (0)
 #define SB_BWD_U2(g)                                                                      \
     do {                                                                                  \
-        sb_wait2<14>(R[g], RB[g]);                                                        \
+        sb_wait2<30 - 2 * ((g) & 3)>(R[g], RB[g]);                                        \
         dp = AT_MFMA(sb_f(R[g].x), sb_f(RB[g].x), dp);                                    \
         dp = AT_MFMA(sb_f(R[g].y), sb_f(RB[g].y), dp);                                    \
         dp = AT_MFMA(sb_f(R[g].z), sb_f(RB[g].z), dp);                                    \
         dp = AT_MFMA(sb_f(R[g].w), sb_f(RB[g].w), dp);                                    \
-        sb_issue128<32 * (g)>(R[g], voffRq, rq, soQ_n);                               \
-        sb_issue128<32 * (g)>(RB[g], voffRq, rk, soK_j);                              \
+        if constexpr (((g) & 3) == 3) SB_BWD_BURST(g, voffRq, rq, soQ_n, rk);             \
     } while (0)
 #define SB_BWD_U3(e)                                                                      \
     do {                                                                                  \
-        sb_wait<47>(C[e]);                                                                \
+        sb_wait<31>(C[e]);                                                                \
         dv[0] = AT_MFMA(sb_f(C[e].x), s[e], dv[0]);                                       \
         dv[1] = AT_MFMA(sb_f(C[e].y), s[e], dv[1]);                                       \
         sb_issue64_adv(C[e], voffCq, rq, so3, ((e) & 3) == 3 ? 5u * pitchQ : pitchQ); \
     } while (0)
 #define SB_BWD_U4(e)                                                                      \
     do {                                                                                  \
-        sb_wait<15>(C[e]);                                                                \
+        sb_wait<31>(C[e]);                                                                \
         dk[0] = AT_MFMA(sb_f(C[e].x), dp[e], dk[0]);                                      \
         dk[1] = AT_MFMA(sb_f(C[e].y), dp[e], dk[1]);                                      \
         sb_issue64_adv(C[e], voffCq, rk, so4, ((e) & 3) == 3 ? 5u * pitchQ : pitchQ); \
@@ -381,7 +436,7 @@ __device__ __forceinline__ void sb_bwd_pair(f32x16 (&dk)[2], f32x16 (&dv)[2], sb
                                             float* __restrict__ scratch,           // LDS: this wave's staging rows
                                             const sb_rsrc rdq,                     // global: dQ rows of the slice
                                             const float scale, const float sl2, const bool key_pad, const int j, const int i, const int i_next,
-                                            float* __restrict__ slot, const bool first, const bool last, const int lane) {
+                                            float* __restrict__ slot, int* __restrict__ seq, const int turn, const bool first, const bool last, const int lane SB_PROF_ARG) {
     const int l31 = lane & 31, lh = lane >> 5;
     const float* __restrict__ Lt = Mt + SB_T;
     const float* __restrict__ Dt = Mt + 2 * SB_T;
@@ -392,35 +447,50 @@ __device__ __forceinline__ void sb_bwd_pair(f32x16 (&dk)[2], f32x16 (&dv)[2], sb
     f32x16 s, dp;
 #pragma unroll
     for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+    SB_T(11);
     SB_BWD_U1(0); SB_BWD_U1(1); SB_BWD_U1(2); SB_BWD_U1(3); SB_BWD_U1(4); SB_BWD_U1(5); SB_BWD_U1(6); SB_BWD_U1(7);
-    SB_BWD_U2(0); SB_BWD_U2(1); SB_BWD_U2(2); SB_BWD_U2(3); SB_BWD_U2(4); SB_BWD_U2(5); SB_BWD_U2(6); SB_BWD_U2(7);
-    // ---- P (into s) and dS (into dp); register e <-> query 32 i + r(e) + 4 lh, lane <-> key 32 j + l31 ----------------------------
-    const float kscale = key_pad ? 0.f : scale;
+    SB_T(1);
+    // ---- P (into s); register e <-> query 32 i + r(e) + 4 lh, lane <-> key 32 j + l31 -------------------------------------------------
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         const float4 M4 = *reinterpret_cast<const float4*>(&Mt[32 * i + 8 * c + 4 * lh]);
         const float4 L4 = *reinterpret_cast<const float4*>(&Lt[32 * i + 8 * c + 4 * lh]);
-        const float4 D4 = *reinterpret_cast<const float4*>(&Dt[32 * i + 8 * c + 4 * lh]);
-        const float Mr[4] = {M4.x, M4.y, M4.z, M4.w}, Lr[4] = {L4.x, L4.y, L4.z, L4.w}, Dr[4] = {D4.x, D4.y, D4.z, D4.w};
+        const float Mr[4] = {M4.x, M4.y, M4.z, M4.w}, Lr[4] = {L4.x, L4.y, L4.z, L4.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int e = 4 * c + r;
             bool masked = key_pad;
             if constexpr (DIAG) masked = masked || (8 * c + r + 4 * lh < l31);      // the query comes before the key
-            const float pv = __builtin_amdgcn_exp2f((masked ? AT_MASKED2 - Mr[r] : fmaf(s[e], sl2, -Mr[r])) - Lr[r]);
-            s[e] = pv;
-            float ds = pv * ((dp[e] - Dr[r]) * kscale);
-            if constexpr (DIAG) ds = masked ? 0.f : ds;
+            s[e] = __builtin_amdgcn_exp2f((masked ? AT_MASKED2 - Mr[r] : fmaf(s[e], sl2, -Mr[r])) - Lr[r]);
+        }
+    }
+    SB_T(3);
+    SB_BWD_U3(0); SB_BWD_U3(1); SB_BWD_U3(2); SB_BWD_U3(3); SB_BWD_U3(4); SB_BWD_U3(5); SB_BWD_U3(6); SB_BWD_U3(7);
+    SB_BWD_U3(8); SB_BWD_U3(9); SB_BWD_U3(10); SB_BWD_U3(11); SB_BWD_U3(12); SB_BWD_U3(13); SB_BWD_U3(14); SB_BWD_U3(15);
+    SB_T(4);
+    SB_BWD_U2(0); SB_BWD_U2(1); SB_BWD_U2(2); SB_BWD_U2(3); SB_BWD_U2(4); SB_BWD_U2(5); SB_BWD_U2(6); SB_BWD_U2(7);
+    SB_T(2);
+    // ---- dS = P (dP - Dsum[q]) scale (into dp), 0 where masked ----------------------------------------------------------------
+    const float kscale = key_pad ? 0.f : scale;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float4 D4 = *reinterpret_cast<const float4*>(&Dt[32 * i + 8 * c + 4 * lh]);
+        const float Dr[4] = {D4.x, D4.y, D4.z, D4.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int e = 4 * c + r;
+            float ds = s[e] * ((dp[e] - Dr[r]) * kscale);
+            if constexpr (DIAG) ds = (8 * c + r + 4 * lh < l31) ? 0.f : ds;
             dp[e] = ds;
         }
     }
-    SB_BWD_U3(0); SB_BWD_U3(1); SB_BWD_U3(2); SB_BWD_U3(3); SB_BWD_U3(4); SB_BWD_U3(5); SB_BWD_U3(6); SB_BWD_U3(7);
-    SB_BWD_U3(8); SB_BWD_U3(9); SB_BWD_U3(10); SB_BWD_U3(11); SB_BWD_U3(12); SB_BWD_U3(13); SB_BWD_U3(14); SB_BWD_U3(15);
+    SB_T(12);
     // dS -> LDS [query][key] (row stride 36) while the dK MFMAs run; read back with lane <-> query
 #pragma unroll
     for (int e = 0; e < 16; ++e) scratch[(sb_row(e) + 4 * lh) * 36 + l31] = dp[e];
     SB_BWD_U4(0); SB_BWD_U4(1); SB_BWD_U4(2); SB_BWD_U4(3); SB_BWD_U4(4); SB_BWD_U4(5); SB_BWD_U4(6); SB_BWD_U4(7);
     SB_BWD_U4(8); SB_BWD_U4(9); SB_BWD_U4(10); SB_BWD_U4(11); SB_BWD_U4(12); SB_BWD_U4(13); SB_BWD_U4(14); SB_BWD_U4(15);
+    SB_T(5);
     __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0): the staging rows are private to the wave
     __builtin_amdgcn_wave_barrier();
     float dst[16];
@@ -432,10 +502,23 @@ __device__ __forceinline__ void sb_bwd_pair(f32x16 (&dk)[2], f32x16 (&dv)[2], sb
     f32x16 dq[2];
 #pragma unroll
     for (int e = 0; e < 16; ++e) { dq[0][e] = 0.f; dq[1][e] = 0.f; }
+    SB_T(6);
     SB_BWD_U5(0); SB_BWD_U5(1); SB_BWD_U5(2); SB_BWD_U5(3); SB_BWD_U5(4); SB_BWD_U5(5); SB_BWD_U5(6); SB_BWD_U5(7);
     SB_BWD_U5(8); SB_BWD_U5(9); SB_BWD_U5(10); SB_BWD_U5(11); SB_BWD_U5(12); SB_BWD_U5(13); SB_BWD_U5(14); SB_BWD_U5(15);
+    SB_T(7);
     // ---- this pair's part of dQ_i: dq[dt][e] = dQ^T[d = 2 (r(e) + 4 lh) + dt][q = l31] -> slot row q, columns 16c + 8lh .. + 7 ------
+    // The contributions to a slot are added in a FIXED order (deterministic bits): `seq` counts them, this pair's turn is `turn`.
+    // The contributor before it ran one pair-time earlier on another wave, so the wait is a formality -- but it is what
+    // orders the waves, not a block barrier: the two waves of a SIMD stay out of phase and fill each other's bubbles.
+    {
+        volatile int* vs = seq;
+        while (*vs != turn) __builtin_amdgcn_s_sleep(1);
+    }
+    SB_T(9);
     float* __restrict__ row = slot + l31 * SB_LD + 8 * lh;
+#ifdef SB_ABL_NOSLOT
+    if (dq[0][0] == 12345.f && dq[1][5] == 54321.f)     // (keeps the MFMAs alive)
+#endif
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
         float4 x = make_float4(dq[0][4 * c], dq[1][4 * c], dq[0][4 * c + 1], dq[1][4 * c + 1]);
@@ -453,27 +536,31 @@ __device__ __forceinline__ void sb_bwd_pair(f32x16 (&dk)[2], f32x16 (&dv)[2], sb
         __builtin_amdgcn_wave_barrier();
         sb_rows_out(slot, rdq, soQ_i, pitchQ, lane);
     }
+    // LDS executes a wave's accesses in order: the count moves after this pair's writes (and, for the last one, its reads) of the slot
+    *reinterpret_cast<volatile int*>(seq) = turn + 1;
+    SB_T(8);
 }
 
 // step barrier: LDS traffic of this step done, then meet -- and nothing else (a __syncthreads() would also wait for this wave's
 // global stores, i.e. drain the operand prefetch with them: vmcnt counts every kind of access)
-__device__ __forceinline__ void sb_step_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void sb_step_barrier() {
+#ifdef SB_ABL_NOBAR
+    return;
+#endif
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 // phase 0: key group `wave` of slice A, pairs (i, j) for i = j .. 7 (steps 0 .. 7 - wave: diagonal first);
-// phase 1: key group 7 - wave of slice B, i = 7 down to j (steps 8 - wave .. 8: diagonal last).  7 step barriers in all for every wave
-// (phase 0: after each of its pairs; phase 1: after each pair but the last).
+// phase 1: key group 7 - wave of slice B, i = 7 down to j (diagonal last).  No block barrier: the dQ slots are ordered by their counts.
 template <int PH>
 __device__ __forceinline__ void sb_bwd_phase(const AttnBwdParams& p, float* __restrict__ smem, const int wave, const int lane, f32x16 (&dk)[2],
-                                             f32x16 (&dv)[2], sb_u32x4 (&R)[8], sb_u32x4 (&RB)[8], sb_u32x2 (&C)[16]) {
+                                             f32x16 (&dv)[2], sb_u32x4 (&R)[8], sb_u32x4 (&RB)[8], sb_u32x2 (&C)[16] SB_PROF_ARG) {
     constexpr int SLOT = 32 * SB_LD;
     const int l31 = lane & 31, lh = lane >> 5;
     const int bh = 2 * blockIdx.x + PH;
     const int j = PH == 0 ? wave : SB_NG - 1 - wave;
     const int npairs = SB_NG - j;
-    if (bh >= p.B * p.H) {                    // block-uniform: an odd number of slices leaves the last block without a B
-        for (int s = 0; s < (PH == 0 ? npairs : npairs - 1); ++s) sb_step_barrier();
-        return;
-    }
+    if (bh >= p.B * p.H) return;              // block-uniform: an odd number of slices leaves the last block without a B
     float* __restrict__ slots = smem;
     float* __restrict__ E = smem + (8 + wave) * SLOT;
     const float* __restrict__ Mt = smem + 16 * SLOT + PH * 3 * SB_T;
@@ -509,27 +596,27 @@ __device__ __forceinline__ void sb_bwd_phase(const AttnBwdParams& p, float* __re
     asm volatile("" : "+v"(RB[0]), "+v"(RB[1]), "+v"(RB[2]), "+v"(RB[3]), "+v"(RB[4]), "+v"(RB[5]), "+v"(RB[6]), "+v"(RB[7]));
     asm volatile("" : "+v"(C[0]), "+v"(C[1]), "+v"(C[2]), "+v"(C[3]), "+v"(C[4]), "+v"(C[5]), "+v"(C[6]), "+v"(C[7]));
     asm volatile("" : "+v"(C[8]), "+v"(C[9]), "+v"(C[10]), "+v"(C[11]), "+v"(C[12]), "+v"(C[13]), "+v"(C[14]), "+v"(C[15]));
+    SB_T(0);
 #define SB_PAIR_ARGS dk, dv, R, RB, C, rq, rk, rv, rg, voffRq, voffRg, voffCq, voffCg, pitchQ, pitchG, Mt, E, rdq, p.scale, sl2, key_pad, j
-    // dQ slot of row group i: phase 0 -> slot i (rows 0 .. i finish in this order), phase 1 -> slot 7 - i (free again by then)
+    // dQ slot of row group i: phase 0 -> slot i, contributions in the order of the key groups i, i - 1, .. 0 (turn = i - j; the last one,
+    // key group 0, writes the row group out and leaves the count at i + 1); phase 1 -> slot r = 7 - i, free again by then (A's row group r
+    // was complete before B's row group 7 - r got its first contribution in the barrier-stepped schedule this replaces, and the count
+    // says so now: r + 1), contributions in the order of the key groups 0, 1, .. i (turn = r + 1 + j; the diagonal pair writes it out)
+    int* __restrict__ seqs = reinterpret_cast<int*>(smem + 16 * SLOT + 2 * 3 * SB_T);
     if constexpr (PH == 0) {
-        // diagonal pair first: it opens slot j; the last contribution to a row group comes from key group 0
-        sb_bwd_pair<true>(SB_PAIR_ARGS, j, j + 1 < SB_NG ? j + 1 : j, slots + j * SLOT, true, j == 0, lane);
-        sb_step_barrier();
+        sb_bwd_pair<true>(SB_PAIR_ARGS, j, j + 1 < SB_NG ? j + 1 : j, slots + j * SLOT, seqs + j, 0, true, j == 0, lane SB_PROF_PASS);
 #pragma unroll 1
         for (int s = 1; s < npairs; ++s) {
             const int i = j + s;
-            sb_bwd_pair<false>(SB_PAIR_ARGS, i, i + 1 < SB_NG ? i + 1 : i, slots + i * SLOT, false, j == 0, lane);
-            sb_step_barrier();
+            sb_bwd_pair<false>(SB_PAIR_ARGS, i, i + 1 < SB_NG ? i + 1 : i, slots + i * SLOT, seqs + i, s, false, j == 0, lane SB_PROF_PASS);
         }
     } else {
 #pragma unroll 1
         for (int s = 0; s + 1 < npairs; ++s) {
-            const int i = SB_NG - 1 - s;
-            sb_bwd_pair<false>(SB_PAIR_ARGS, i, i - 1, slots + (SB_NG - 1 - i) * SLOT, j == 0, false, lane);
-            sb_step_barrier();
+            const int i = SB_NG - 1 - s, r = SB_NG - 1 - i;
+            sb_bwd_pair<false>(SB_PAIR_ARGS, i, i - 1, slots + r * SLOT, seqs + r, r + 1 + j, j == 0, false, lane SB_PROF_PASS);
         }
-        // diagonal pair last: it completes row group j
-        sb_bwd_pair<true>(SB_PAIR_ARGS, j, j, slots + (SB_NG - 1 - j) * SLOT, j == 0, true, lane);
+        sb_bwd_pair<true>(SB_PAIR_ARGS, j, j, slots + (SB_NG - 1 - j) * SLOT, seqs + (SB_NG - 1 - j), (SB_NG - 1 - j) + 1 + j, j == 0, true, lane SB_PROF_PASS);
     }
 #undef SB_PAIR_ARGS
     // the last pair's look-ahead loads re-read its own row group: let them land before their registers are anyone else's
@@ -559,13 +646,15 @@ __device__ __forceinline__ void sb_bwd_phase(const AttnBwdParams& p, float* __re
     }
     sb_store_rows(E, dk, 1.0f, sb_make_rsrc(p.dK + base, bytesQ), sok, pitchQ, lane);
     sb_store_rows(E, dv, 1.0f, sb_make_rsrc(p.dV + base, bytesQ), sok, pitchQ, lane);
+    SB_T(10);
 }
 
 __global__ __launch_bounds__(512, 2) void attn_sb_bwd_kernel(const AttnBwdParams p) {
-    // one LDS object: [8 dQ slots][32][68] | [8 waves][32][68] staging | (max, log2 sum, Dsum) of 2 x 256 queries
+    // one LDS object: [8 dQ slots][32][68] | [8 waves][32][68] staging | (max, log2 sum, Dsum) of 2 x 256 queries | 8 slot counts
     constexpr int SLOT = 32 * SB_LD;
-    __shared__ __attribute__((aligned(16))) float smem[16 * SLOT + 2 * 3 * SB_T];
+    __shared__ __attribute__((aligned(16))) float smem[16 * SLOT + 2 * 3 * SB_T + 8];
     float* tabs = smem + 16 * SLOT;
+    if (threadIdx.x < 8) reinterpret_cast<int*>(smem + 16 * SLOT + 2 * 3 * SB_T)[threadIdx.x] = 0;      // contribution counts of the dQ slots
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, lh = lane >> 5;
@@ -598,8 +687,16 @@ __global__ __launch_bounds__(512, 2) void attn_sb_bwd_kernel(const AttnBwdParams
     f32x16 dk[2], dv[2];
     sb_u32x4 R[8], RB[8];
     sb_u32x2 C[16];
-    sb_bwd_phase<0>(p, smem, wave, lane, dk, dv, R, RB, C);
-    sb_bwd_phase<1>(p, smem, wave, lane, dk, dv, R, RB, C);
+    SB_PROF_DECL;
+#ifndef SB_ABL_NOPRIO
+    // The SIMD arbiter issues oldest-first: waves 0-3 of a block would run ahead of their SIMD mates 4-7 -- and wave 3 WAITS for wave 4
+    // (the dQ contributions of a row group come in the order of the key groups i, i - 1, .. 0, i.e. of the waves 7 .. 0).  Static priority for
+    // the younger half turns that around: nobody waits for a slower wave.
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
+    sb_bwd_phase<0>(p, smem, wave, lane, dk, dv, R, RB, C SB_PROF_PASS);
+    sb_bwd_phase<1>(p, smem, wave, lane, dk, dv, R, RB, C SB_PROF_PASS);
+    SB_PROF_STORE(wave);
 }
 
 }  // namespace nnhip
@@ -615,6 +712,12 @@ static bool sb_enabled() {
 bool attn_sb_applicable(int64_t B, int64_t H, int64_t Tq, int64_t Tk, int64_t head_dim, int causal, bool gen) {
     return sb_enabled() && !gen && causal && Tq == SB_T && Tk == SB_T && head_dim == SB_DH && B * H >= 1;
 }
+
+#ifdef SB_PROF
+extern "C" int nnhipAttentionSbSetProfile(long long* buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_sb_prof), &buf, sizeof(buf));
+}
+#endif
 
 int attn_sb_backward(const AttnBwdParams& p, hipStream_t st) {
     const int BH = p.B * p.H;
