@@ -10,7 +10,12 @@
 // two RCCL instances in one process would each bootstrap and each own channels/IPC handles).  Every kernel entry point of
 // the library therefore keeps working on a box without RCCL; only these calls fail, with NNHIP_ECOMM and a message.
 #include <dlfcn.h>
+#if __has_include(<rccl/rccl.h>) && !defined(NNHIP_FORCE_NO_RCCL_HEADERS)
 #include <rccl/rccl.h>   // types and prototypes only (decltype below); no symbol of it is linked
+#define NNHIP_HAVE_RCCL_HEADERS 1
+#else
+#define NNHIP_HAVE_RCCL_HEADERS 0   // a box without the RCCL headers still builds the library: the nnhipComm* entry points answer NNHIP_ECOMM
+#endif
 #include <stdlib.h>
 #include <string.h>
 
@@ -18,6 +23,7 @@
 
 #include "common.h"
 
+#if NNHIP_HAVE_RCCL_HEADERS
 struct nnhipComm {
     ncclComm_t comm;
     int rank, world;
@@ -174,3 +180,14 @@ extern "C" int nnhipBroadcastF32(nnhipComm_t comm, float* buf, int64_t n, int ro
     return nnhip::rccl_status(nnhip::g_rccl.Broadcast(buf, buf, (size_t)n, ncclFloat32, root, comm->comm,
                                                       static_cast<hipStream_t>(stream)), "nnhipBroadcastF32");
 }
+#else   // no RCCL headers on the build box: the entry points exist (the ABI is the same) and say why they cannot work
+#define NNHIP_NO_RCCL(name) do { nnhip::set_last_error(name ": libneunet_hip.so was built without the RCCL headers"); return NNHIP_ECOMM; } while (0)
+extern "C" int nnhipCommUniqueId(void*) { NNHIP_NO_RCCL("nnhipCommUniqueId"); }
+extern "C" int nnhipCommInitRank(nnhipComm_t*, const void*, int, int) { NNHIP_NO_RCCL("nnhipCommInitRank"); }
+extern "C" int nnhipCommDestroy(nnhipComm_t) { NNHIP_NO_RCCL("nnhipCommDestroy"); }
+extern "C" int nnhipCommRank(nnhipComm_t, int*, int*) { NNHIP_NO_RCCL("nnhipCommRank"); }
+extern "C" int nnhipCommLibrary(char*, int64_t, int*) { NNHIP_NO_RCCL("nnhipCommLibrary"); }
+extern "C" int nnhipAllReduceSumF32(nnhipComm_t, float*, int64_t, nnhipStream_t) { NNHIP_NO_RCCL("nnhipAllReduceSumF32"); }
+extern "C" int nnhipAllReduceAvgF32(nnhipComm_t, float*, int64_t, nnhipStream_t) { NNHIP_NO_RCCL("nnhipAllReduceAvgF32"); }
+extern "C" int nnhipBroadcastF32(nnhipComm_t, float*, int64_t, int, nnhipStream_t) { NNHIP_NO_RCCL("nnhipBroadcastF32"); }
+#endif

@@ -369,7 +369,7 @@ extern "C" int nnhipScale(float* x, float alpha, int64_t n, nnhipStream_t s) {
 }
 // out[r, c] = in[r, c] * scale[r * scale_stride]: the product with an upstream gradient that a loss node's backward forms
 // (cross_entropy.py:111-114 `grad_y_pred * grad`, losses.py:9-22): scale_stride = 0 -- one DEVICE scalar (loss.backward(g) on a
-// reduced loss), 1 -- one factor per row (reduction 'none').  One thread per element group of 4 along a row.
+// reduced loss), 1 -- one factor per row (reduction 'none').  One thread per element.
 __global__ __launch_bounds__(256) void scale_rows_kernel(float* __restrict__ out, const float* __restrict__ in, const float* __restrict__ scale,
                                                          int64_t rows, int64_t cols, int64_t scale_stride) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;

@@ -270,14 +270,17 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_mlp_bwd_kernel(const Small
     };
     auto everybody_here = [&]() -> bool {                  // a whole wave: lane w looks at word w
         bool ok = true;
-        for (int spin = 0; spin < (1 << 22); ++spin) {
+        // bounded by WALL time (s_memrealtime: 100 MHz), not by a spin count: a legitimately slow arrival -- a debugger, a profiler
+        // replaying the kernel, a time-sliced device -- must not abort training (advisor, round 4); 20 s without it is a broken device
+        const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+        for (;;) {
             unsigned seen = 0, want = 0;
             if (lane < SG_MLP_WAYS) {
                 seen = __hip_atomic_load(bank(epoch) + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 want = n / SG_MLP_WAYS + ((unsigned)lane < n % SG_MLP_WAYS ? 1u : 0u);
             }
             ok = __ballot(seen < want) == 0ull;
-            if (ok) break;
+            if (ok || __builtin_amdgcn_s_memrealtime() - t_start > 2000000000ull) break;
             __builtin_amdgcn_s_sleep(2);
         }
         // The host only launches this variant when every block that polls fits on the chip next to blocks that wait for nobody
@@ -350,11 +353,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_mlp_bwd_kernel(const Small
 // wait for nobody) must always find room.  Pollers are dispatched first (lowest block ids), so the rule is: pollers <= half of the
 // blocks the chip holds at once (occupancy query, cached per block size).
 static bool mlp_adam_grid_fits(int nw, int64_t pollers) {
-    static int cap[2] = {0, 0};
-    int& c = cap[nw == 8];
+    static int cap[16][2] = {};                            // per device (the occupancy of one part says nothing about another)
+    int dev = 0, cus = 0, per = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
+    int& c = cap[dev][nw == 8];
     if (c == 0) {
-        int dev = 0, cus = 0, per = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
         const hipError_t e = nw == 8 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, gemm_small_mlp_bwd_kernel<8>, 512, 0)
                                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per, gemm_small_mlp_bwd_kernel<4>, 256, 0);
         if (e != hipSuccess || per <= 0 || cus <= 0) return false;

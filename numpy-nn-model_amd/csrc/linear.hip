@@ -305,6 +305,7 @@ extern "C" int nnhipLinearReLULinearBackwardAdam(const float* X1, const float* H
     const int rc = gemm_small_mlp_backward_adam(X1, H, W2, dO, dW2, db2, dW1, db1, rows, in1, hidden, out2, opt, pmv, lr, beta1, beta2, eps,
                                                 weight_decay, step, decay_mode, grad_scale, (hipStream_t)stream);
     if (rc < 0) return rc;
-    NNHIP_CHECK_ARG(rc == 1, NNHIP_EINVAL, "nnhipLinearReLULinearBackwardAdam: outside the small-problem range (rows <= 256, out2 <= 16)");
+    NNHIP_CHECK_ARG(rc == 1, NNHIP_EINVAL, "nnhipLinearReLULinearBackwardAdam: outside the small-problem range (rows <= 256, out2 <= 16), or a hidden "
+                    "layer so wide that its polling blocks would fill the chip: run nnhipLinearReLULinearBackward + the optimizer step instead");
     return 0;
 }

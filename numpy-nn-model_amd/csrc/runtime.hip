@@ -70,28 +70,28 @@ const float* zero_block() {
 
 // Library-owned device words (arrival tickets, the CE denominator scratch) and the workspace partials behind them are ONE set
 // per process: two launches that use them must not overlap.  On one stream that is program order.  A launch that arrives on a
-// DIFFERENT stream than the previous user is ordered behind it with an event (record on the old stream, wait on the new): the
-// single-stream assumption is enforced instead of assumed (round-3 review).  Costs a pointer compare when the stream is the same.
-// While either stream is being captured into a hipGraph nothing is inserted (a cross-stream edge to work outside the capture is
-// not expressible there; a captured step is single-stream by construction, neunet_hip/graph.py).
+// DIFFERENT stream than the previous user is ordered behind everything the device has been given so far (hipDeviceSynchronize):
+// the single-stream assumption is enforced instead of assumed (round-3 review).  The previous caller's stream handle is only ever
+// COMPARED, never used -- it is the caller's object and may be gone by now (CuPy destroys its streams on garbage collection;
+// round-4 advisor: an event recorded on a destroyed stream is undefined behaviour and left the guard failing for the rest of the
+// process).  Costs a pointer compare when the stream is the same; a stream change is rare (a few per process) and pays a device
+// sync.  While `st` is being captured into a hipGraph nothing is inserted (a sync is illegal there; a captured step is
+// single-stream by construction, neunet_hip/graph.py), and a sync refused because ANOTHER stream is capturing is skipped likewise.
 int serialize_shared_state(hipStream_t st) {
     static std::mutex mu;
     static hipStream_t last = nullptr;
     static bool have_last = false;
-    static hipEvent_t ev = nullptr;
     std::lock_guard<std::mutex> lk(mu);
     if (have_last && last != st) {
-        hipStreamCaptureStatus a = hipStreamCaptureStatusNone, b = hipStreamCaptureStatusNone;
-        (void)hipStreamIsCapturing(st, &a);
-        (void)hipStreamIsCapturing(last, &b);
-        if (a == hipStreamCaptureStatusNone && b == hipStreamCaptureStatusNone) {
-            if (!ev) {
-                hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-                if (e != hipSuccess) return hip_status(e, "hipEventCreate(shared-state guard)");
+        hipStreamCaptureStatus a = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &a) != hipSuccess) { (void)hipGetLastError(); a = hipStreamCaptureStatusNone; }
+        if (a == hipStreamCaptureStatusNone) {
+            const hipError_t e = hipDeviceSynchronize();
+            if (e != hipSuccess) {
+                (void)hipGetLastError();          // e.g. a capture in progress elsewhere: nothing to order against, carry on
+                if (e != hipErrorStreamCaptureUnsupported && e != hipErrorStreamCaptureImplicit && e != hipErrorStreamCaptureInvalidated)
+                    return hip_status(e, "shared-state guard (device synchronize)");
             }
-            hipError_t e = hipEventRecord(ev, last);
-            if (e == hipSuccess) e = hipStreamWaitEvent(st, ev, 0);
-            if (e != hipSuccess) return hip_status(e, "shared-state guard (event record / wait)");
         }
     }
     last = st;

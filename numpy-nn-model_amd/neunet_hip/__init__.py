@@ -28,7 +28,15 @@ def argmax(x: Tensor, axis=None, keepdims=False):
     from ._lib import call_hip_function, get_current_stream_ptr
     d = x.data
     if d.dtype != torch.float32:
-        raise NotImplementedError("neunet_hip.argmax on the device takes float32 tensors")
+        # np.argmax takes labels / ids / masks too (neunet/__init__.py:132-139).  Integers below 2^24 are exact in fp32: they ride on
+        # the library's kernel; anything else (wide integers, float64) keeps torch's argmax -- same first-maximum rule.
+        if d.dtype in (torch.int16, torch.int32, torch.int64, torch.uint8, torch.bool) and (d.numel() == 0 or int(d.abs().max() if d.dtype != torch.bool else 1) < (1 << 24)):
+            d = d.to(torch.float32)
+        else:
+            out = torch.argmax(d) if axis is None else torch.argmax(d, dim=axis, keepdim=keepdims)
+            if axis is None and keepdims:
+                out = out.reshape((1,) * d.dim())
+            return Tensor(out.to(torch.int32), dtype=np.int32, requires_grad=False, device="cuda")
     d = d.contiguous()
     shape = tuple(d.shape)
     if axis is None:
