@@ -10,26 +10,61 @@
 
 namespace nnhip {
 
+// ADAM_UNR float4 rounds of all four streams in flight per thread (developer A/B: -DADAM_UNR=1|2|4, -DADAM_NT_G=1 reads the gradient --
+// dead after this pass -- past L2 allocation, -DADAM_NT_ST=1 stores p / m / v non-temporally)
+#ifndef ADAM_UNR
+#define ADAM_UNR 2
+#endif
+#ifndef ADAM_NT_G
+#define ADAM_NT_G 1
+#endif
+#ifndef ADAM_NT_ST
+#define ADAM_NT_ST 0
+#endif
+typedef float adam_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void adam4(adam_f4& P, const adam_f4& G, adam_f4& M, adam_f4& V, const AdamHyper& h) {
+    float p0 = P.x, p1 = P.y, p2 = P.z, p3 = P.w, m0 = M.x, m1 = M.y, m2 = M.z, m3 = M.w, v0 = V.x, v1 = V.y, v2 = V.z, v3 = V.w;
+    adam1(p0, G.x, m0, v0, h); adam1(p1, G.y, m1, v1, h); adam1(p2, G.z, m2, v2, h); adam1(p3, G.w, m3, v3, h);
+    P.x = p0; P.y = p1; P.z = p2; P.w = p3; M.x = m0; M.y = m1; M.z = m2; M.w = m3; V.x = v0; V.y = v1; V.z = v2; V.w = v3;
+}
 __device__ __forceinline__ void adam_span(float* __restrict__ p, const float* __restrict__ g,
                                           float* __restrict__ m, float* __restrict__ v, int64_t n,
                                           int64_t first, int64_t stride_threads, bool vec,
                                           const AdamHyper& h) {
     if (vec) {
         const int64_t nv = n >> 2;
-        for (int64_t i = first; i < nv; i += stride_threads) {
-            float4 P = reinterpret_cast<float4*>(p)[i];
-            const float4 G = reinterpret_cast<const float4*>(g)[i];
-            float4 M = reinterpret_cast<float4*>(m)[i];
-            float4 V = reinterpret_cast<float4*>(v)[i];
-            adam1(P.x, G.x, M.x, V.x, h);
-            adam1(P.y, G.y, M.y, V.y, h);
-            adam1(P.z, G.z, M.z, V.z, h);
-            adam1(P.w, G.w, M.w, V.w, h);
-            reinterpret_cast<float4*>(p)[i] = P;
-            reinterpret_cast<float4*>(m)[i] = M;
-            reinterpret_cast<float4*>(v)[i] = V;
+        adam_f4* __restrict__ p4 = reinterpret_cast<adam_f4*>(p);
+        const adam_f4* __restrict__ g4 = reinterpret_cast<const adam_f4*>(g);
+        adam_f4* __restrict__ m4 = reinterpret_cast<adam_f4*>(m);
+        adam_f4* __restrict__ v4 = reinterpret_cast<adam_f4*>(v);
+        int64_t i = first;
+        for (; i + (ADAM_UNR - 1) * stride_threads < nv; i += ADAM_UNR * stride_threads) {
+            adam_f4 P[ADAM_UNR], G[ADAM_UNR], M[ADAM_UNR], V[ADAM_UNR];
+#pragma unroll
+            for (int u = 0; u < ADAM_UNR; ++u) {
+                const int64_t k = i + u * stride_threads;
+                P[u] = p4[k];
+                G[u] = ADAM_NT_G ? __builtin_nontemporal_load(&g4[k]) : g4[k];
+                M[u] = m4[k];
+                V[u] = v4[k];
+            }
+#pragma unroll
+            for (int u = 0; u < ADAM_UNR; ++u) {
+                const int64_t k = i + u * stride_threads;
+                adam4(P[u], G[u], M[u], V[u], h);
+                if (ADAM_NT_ST) {
+                    __builtin_nontemporal_store(P[u], &p4[k]); __builtin_nontemporal_store(M[u], &m4[k]); __builtin_nontemporal_store(V[u], &v4[k]);
+                } else {
+                    p4[k] = P[u]; m4[k] = M[u]; v4[k] = V[u];
+                }
+            }
         }
-        for (int64_t i = (nv << 2) + first; i < n; i += stride_threads) adam1(p[i], g[i], m[i], v[i], h);
+        for (; i < nv; i += stride_threads) {
+            adam_f4 P = p4[i], G = g4[i], M = m4[i], V = v4[i];
+            adam4(P, G, M, V, h);
+            p4[i] = P; m4[i] = M; v4[i] = V;
+        }
+        for (int64_t j = (nv << 2) + first; j < n; j += stride_threads) adam1(p[j], g[j], m[j], v[j], h);
     } else {
         for (int64_t i = first; i < n; i += stride_threads) adam1(p[i], g[i], m[i], v[i], h);
     }
