@@ -23,9 +23,9 @@
 //   * Backward: ONE pass.  The wave that owns key group j computes S, dP, P, dS for the pair (i, j) once (lane <-> key),
 //     feeds dV^T += dO^T P and dK^T += Q^T dS from the accumulator registers, transposes dS through 4.6 KB of wave-private
 //     LDS and multiplies dQ^T(i) += K_j^T dS^T.  The partial dQ of row group i is summed in an LDS slot in a FIXED order: the
-//     schedule is skewed (step s: wave w has pair (w + s, w)), so in every step all row groups in flight are distinct, a
-//     block barrier separates the steps, the first contributor stores, the last one adds its part and writes the row group
-//     out.  No atomics, deterministic bits, every wave busy in every one of the 9 steps.
+//     schedule is skewed (the s-th pair of wave w is (w + s, w)), so the row groups in flight at any time are distinct; a
+//     per-slot contribution count orders the adds (the first contributor stores, the last one adds its part and writes the
+//     row group out) -- no atomics, no block barrier in the pair loop, deterministic bits, nine pairs for every wave.
 #include <math.h>
 #include <stdlib.h>
 
@@ -120,13 +120,18 @@ __device__ __forceinline__ void sb_wait2(sb_u32x4& r, sb_u32x4& q) { asm volatil
 __device__ __forceinline__ void sb_rows_out(const float* __restrict__ E, sb_rsrc rs, unsigned soff, unsigned pitchB, int lane) {
     const unsigned voff = (unsigned)(lane >> 4) * pitchB + (unsigned)(lane & 15) * 16u;
     const float* __restrict__ src = E + (lane >> 4) * SB_LD + (lane & 15) * 4;
+    // all eight LDS reads first, then the eight stores: one LDS round trip, not eight (the stores touch memory nobody in these kernels
+    // reads, so they carry no "memory" clobber that would pin each of them behind its own read)
+    sb_u32x4 u[8];
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
         const float4 v = *reinterpret_cast<const float4*>(src + it * 4 * SB_LD);
-        sb_u32x4 u;
-        u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
+        u[it].x = __float_as_uint(v.x); u[it].y = __float_as_uint(v.y); u[it].z = __float_as_uint(v.z); u[it].w = __float_as_uint(v.w);
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
         // (the s_nop: hipcc does not know that a store is still reading its data registers when the statement ends)
-        asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" : : "v"(u), "v"(voff), "s"(rs), "s"(soff + (unsigned)it * 4u * pitchB) : "memory");
+        asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" : : "v"(u[it]), "v"(voff), "s"(rs), "s"(soff + (unsigned)it * 4u * pitchB));
     }
 }
 // acc[dt][e] = X^T[d = 2 (r(e) + 4 lh) + dt][row = l31]  ->  32 rows of 64 floats at byte offset soff of the slice behind rs, through the wave's rows E
@@ -550,6 +555,42 @@ __device__ __forceinline__ void sb_step_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// dK / dV rows of key group j of slice bh, through the wave's staging rows
+__device__ __forceinline__ void sb_bwd_store_kv(const AttnBwdParams& p, const int bh, const int j, float* __restrict__ E, const f32x16 (&dk)[2],
+                                                const f32x16 (&dv)[2], const int lane) {
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int64_t base = ((int64_t)b * SB_T) * p.LQ + (int64_t)h * SB_DH;
+    const unsigned pitchQ = (unsigned)p.LQ * 4u, bytesQ = (unsigned)(((int64_t)(SB_T - 1) * p.LQ + SB_DH) * 4);
+    sb_store_rows(E, dk, 1.0f, sb_make_rsrc(p.dK + base, bytesQ), (unsigned)(32 * j) * pitchQ, pitchQ, lane);
+    sb_store_rows(E, dv, 1.0f, sb_make_rsrc(p.dV + base, bytesQ), (unsigned)(32 * j) * pitchQ, pitchQ, lane);
+}
+
+// (max, log2 sum, Dsum[q] = sum_d dO[q,d] O[q,d]) of both slices' 256 queries into LDS: wave w takes queries 32 w .. 32 w + 31
+__device__ __forceinline__ void sb_bwd_row_tables(const AttnBwdParams& p, float* __restrict__ tabs, const int wave, const int lane) {
+    const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll 1
+    for (int sl = 0; sl < 2; ++sl) {
+        const int bh = 2 * blockIdx.x + sl;
+        if (bh >= p.B * p.H) break;
+        const int b = bh / p.H, h = bh - b * p.H;
+        const int q = 32 * wave + l31;
+        const float* go = p.dO + ((int64_t)b * SB_T + q) * p.D + (int64_t)h * SB_DH + 4 * lh;
+        const float* oo = p.O + ((int64_t)b * SB_T + q) * p.D + (int64_t)h * SB_DH + 4 * lh;
+        float part = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const float4 x = *reinterpret_cast<const float4*>(go + 8 * g), y = *reinterpret_cast<const float4*>(oo + 8 * g);
+            part += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+        }
+        const float ds = sb_pair_sum(part);
+        const float2 ml = reinterpret_cast<const float2*>(p.LSE)[(int64_t)bh * SB_T + q];
+        if (lh == 0) {
+            float* t = tabs + sl * 3 * SB_T;
+            t[q] = ml.x; t[SB_T + q] = ml.y; t[2 * SB_T + q] = ds;
+        }
+    }
+}
+
 // phase 0: key group `wave` of slice A, pairs (i, j) for i = j .. 7 (steps 0 .. 7 - wave: diagonal first);
 // phase 1: key group 7 - wave of slice B, i = 7 down to j (diagonal last).  No block barrier: the dQ slots are ordered by their counts.
 template <int PH>
@@ -560,9 +601,12 @@ __device__ __forceinline__ void sb_bwd_phase(const AttnBwdParams& p, float* __re
     const int bh = 2 * blockIdx.x + PH;
     const int j = PH == 0 ? wave : SB_NG - 1 - wave;
     const int npairs = SB_NG - j;
-    if (bh >= p.B * p.H) return;              // block-uniform: an odd number of slices leaves the last block without a B
     float* __restrict__ slots = smem;
     float* __restrict__ E = smem + (8 + wave) * SLOT;
+    if (bh >= p.B * p.H) {                    // block-uniform: an odd number of slices leaves the last block without a B
+        if constexpr (PH == 1) sb_bwd_store_kv(p, bh - 1, SB_NG - 1 - j, E, dk, dv, lane);
+        return;
+    }
     const float* __restrict__ Mt = smem + 16 * SLOT + PH * 3 * SB_T;
     const unsigned pitchQ = (unsigned)p.LQ * 4u, pitchG = (unsigned)p.D * 4u;
     const unsigned bytesQ = (unsigned)(((int64_t)(SB_T - 1) * p.LQ + SB_DH) * 4), bytesG = (unsigned)(((int64_t)(SB_T - 1) * p.D + SB_DH) * 4);
@@ -589,6 +633,14 @@ __device__ __forceinline__ void sb_bwd_phase(const AttnBwdParams& p, float* __re
     sb_first128<192>(RB[6], voffRq, rk, sok); sb_first128<224>(RB[7], voffRq, rk, sok);
 #pragma unroll
     for (int e = 0; e < 16; ++e) sb_first64(C[e], voffCg, rg, (unsigned)(32 * i0 + sb_row(e)) * pitchG);
+    // ... and while they fly: phase 0 -- the row statistics of both slices go to LDS (every wave 32 queries; one block barrier);
+    // phase 1 -- the dK / dV rows of phase 0 go out (their stores are younger than the loads above; the drain below takes both)
+    if constexpr (PH == 0) {
+        sb_bwd_row_tables(p, smem + 16 * SLOT, wave, lane);
+        __syncthreads();
+    } else {
+        sb_bwd_store_kv(p, bh - 1, wave, E, dk, dv, lane);
+    }
 #pragma unroll
     for (int e = 0; e < 16; ++e) { dk[0][e] = 0.f; dk[1][e] = 0.f; dv[0][e] = 0.f; dv[1][e] = 0.f; }
     // the first pair's waits are written for the steady state (62 / 47 younger loads): have its operands landed instead
@@ -644,8 +696,7 @@ __device__ __forceinline__ void sb_bwd_phase(const AttnBwdParams& p, float* __re
             dv[1] = AT_MFMA(g2.y, pm[e], dv[1]);
         }
     }
-    sb_store_rows(E, dk, 1.0f, sb_make_rsrc(p.dK + base, bytesQ), sok, pitchQ, lane);
-    sb_store_rows(E, dv, 1.0f, sb_make_rsrc(p.dV + base, bytesQ), sok, pitchQ, lane);
+    if constexpr (PH == 1) sb_bwd_store_kv(p, bh, j, E, dk, dv, lane);      // (phase 0's rows go out under phase 1's first loads)
     SB_T(10);
 }
 
@@ -653,47 +704,14 @@ __global__ __launch_bounds__(512, 2) void attn_sb_bwd_kernel(const AttnBwdParams
     // one LDS object: [8 dQ slots][32][68] | [8 waves][32][68] staging | (max, log2 sum, Dsum) of 2 x 256 queries | 8 slot counts
     constexpr int SLOT = 32 * SB_LD;
     __shared__ __attribute__((aligned(16))) float smem[16 * SLOT + 2 * 3 * SB_T + 8];
-    float* tabs = smem + 16 * SLOT;
     if (threadIdx.x < 8) reinterpret_cast<int*>(smem + 16 * SLOT + 2 * 3 * SB_T)[threadIdx.x] = 0;      // contribution counts of the dQ slots
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, lh = lane >> 5;
-    const int BH = p.B * p.H;
-
-    // ---- row statistics of both slices into LDS: wave w takes queries 32 w .. 32 w + 31; Dsum[q] = sum_d dO[q,d] O[q,d] ------------
-#pragma unroll 1
-    for (int sl = 0; sl < 2; ++sl) {
-        const int bh = 2 * blockIdx.x + sl;
-        if (bh >= BH) break;
-        const int b = bh / p.H, h = bh - b * p.H;
-        const int q = 32 * wave + l31;
-        const float* go = p.dO + ((int64_t)b * SB_T + q) * p.D + (int64_t)h * SB_DH + 4 * lh;
-        const float* oo = p.O + ((int64_t)b * SB_T + q) * p.D + (int64_t)h * SB_DH + 4 * lh;
-        float part = 0.f;
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            const float4 x = *reinterpret_cast<const float4*>(go + 8 * g), y = *reinterpret_cast<const float4*>(oo + 8 * g);
-            part += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
-        }
-        const float ds = sb_pair_sum(part);
-        const float2 ml = reinterpret_cast<const float2*>(p.LSE)[(int64_t)bh * SB_T + q];
-        if (lh == 0) {
-            float* t = tabs + sl * 3 * SB_T;
-            t[q] = ml.x; t[SB_T + q] = ml.y; t[2 * SB_T + q] = ds;
-        }
-    }
-    __syncthreads();
 
     f32x16 dk[2], dv[2];
     sb_u32x4 R[8], RB[8];
     sb_u32x2 C[16];
     SB_PROF_DECL;
-#ifndef SB_ABL_NOPRIO
-    // The SIMD arbiter issues oldest-first: waves 0-3 of a block would run ahead of their SIMD mates 4-7 -- and wave 3 WAITS for wave 4
-    // (the dQ contributions of a row group come in the order of the key groups i, i - 1, .. 0, i.e. of the waves 7 .. 0).  Static priority for
-    // the younger half turns that around: nobody waits for a slower wave.
-    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
     sb_bwd_phase<0>(p, smem, wave, lane, dk, dv, R, RB, C SB_PROF_PASS);
     sb_bwd_phase<1>(p, smem, wave, lane, dk, dv, R, RB, C SB_PROF_PASS);
     SB_PROF_STORE(wave);
