@@ -424,8 +424,8 @@ def cpu_c1(seconds):
         st.step(X, Y)
         times.append(time.perf_counter() - t0)
     best = min(times)
-    return {"value": round(32 / best, 1), "unit": "samples/s", "cores": blas_threads(), "kind": "port",
-            "sample": f"{len(times)} C1 MLP steps via the NumPy oracle, min step {best * 1e3:.3f} ms"}
+    return {"value": round(32 / best, 1), "unit": "samples/s", "cores": blas_threads(), "kind": "port", "samples": len(times),
+            "sample": f"{len(times)} C1 MLP steps via the NumPy oracle, min step {best * 1e3:.3f} ms (median {np.median(times) * 1e3:.3f} ms)"}
 
 
 # ------------------------------------------------------------------------------------------------ C3
@@ -528,17 +528,51 @@ def workload_c3(args, rank, world):
     # Checked against rocprofv3's kernel durations of the same pass (profiles/r04*_c3_kernel_stats.md): the two-point estimate is ~25 %
     # high (the second tiny kernel's dispatch partly hides behind the first), so 0.75 of it is subtracted -- the conservative side.
     overhead = 0.75 * min(max(2.0 * s1 - s2, 0.0), s1)
-    kms = {k: max(t.mean_ms() - overhead, 1e-6) for k, t in timers.items()}
-    res_ops = {k: {"ms": round(kms[k], 4), "span_ms": round(timers[k].mean_ms(), 4), "GBps": round(bytes_per[k] / (kms[k] * 1e-3) / 1e9, 1),
+    # PRIMARY numbers = the raw event spans (round-4 review: the subtraction was in the builder's favour every time); the span minus the
+    # calibrated event overhead -- what rocprofv3 --kernel-trace reports as the kernel's duration, to ~2 % -- rides along, labelled
+    kms = {k: t.mean_ms() for k, t in timers.items()}
+    kcorr = {k: max(t.mean_ms() - overhead, 1e-6) for k, t in timers.items()}
+    res_ops = {k: {"ms": round(kms[k], 4), "GBps": round(bytes_per[k] / (kms[k] * 1e-3) / 1e9, 1),
                    "frac_of_8TBps": round(bytes_per[k] / (kms[k] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                   "ms_minus_event_overhead": round(kcorr[k], 4),
+                   "frac_of_8TBps_minus_event_overhead": round(bytes_per[k] / (kcorr[k] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                    "hbm_traffic_pmc": read_traffic(k.replace("_fwd_bwd", "") + "_c3")}
                for k, t in timers.items() if k in bytes_per}
     for k, fl in flops_per.items():
         ms = kms[k]
-        res_ops[k] = {"ms": round(ms, 4), "span_ms": round(timers[k].mean_ms(), 4), "TFLOPs": round(fl / (ms * 1e-3) / 1e12, 2),
+        res_ops[k] = {"ms": round(ms, 4), "ms_minus_event_overhead": round(kcorr[k], 4), "TFLOPs": round(fl / (ms * 1e-3) / 1e12, 2),
                       "frac_of_mfma_peak": round(fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                       "launches": 1 if k.endswith("fwd") else 3}
     res_ops["_event_pair_overhead_ms"] = round(overhead, 4)
+    res_ops["_timing"] = "ms = mean HIP-event span around ONE launch on the launch stream (includes ~3 us of event handling); *_minus_event_overhead = the same minus a calibrated overhead"
+    # The BASELINE-size buffers (128 MiB each) partly live in the 256 MiB Infinity Cache between launches: the same kernels on 512 MiB
+    # buffers (rows 32768 x d 4096) are the DRAM-resident figure (round-4 review, item 5)
+    try:
+        Rb = 4 * R
+        xb = torch.randn(Rb, D, device="cuda")
+        yb, gb = torch.empty_like(xb), torch.randn(Rb, D, device="cuda")
+        dxb, stdb, dwb = torch.empty_like(xb), torch.empty(Rb, device="cuda"), torch.empty(D, device="cuda")
+        big_ops = [("swish_fwd", lambda: hip_swish_forward(xb, yb, 1.0), 8 * Rb * D),
+                   ("swish_bwd", lambda: hip_swish_backward(dxb, gb, xb, 1.0), 12 * Rb * D),
+                   ("rmsnorm_fwd", lambda: rmsnorm_forward(xb, w, None, None, stdb, yb, 1e-6), 8 * Rb * D),
+                   ("rmsnorm_bwd", lambda: rmsnorm_backward(xb, w, None, gb, dxb, dwb, None, None, stdb), 12 * Rb * D)]
+        bt = {k: EventTimer() for k, _, _ in big_ops}
+        for it in range(8):
+            for k, fn, _ in big_ops:
+                if it >= 2:
+                    a, b = bt[k].span()
+                    a.record()
+                    fn()
+                    b.record()
+                else:
+                    fn()
+        torch.cuda.synchronize()
+        res_ops["dram_resident"] = {"what": f"the same kernels on rows {Rb} x d {D}: 512 MiB per buffer, nothing survives in the 256 MiB Infinity Cache",
+                                    **{k: {"ms": round(bt[k].mean_ms(), 4), "GBps": round(nb / (bt[k].mean_ms() * 1e-3) / 1e9, 1),
+                                           "frac_of_8TBps": round(nb / (bt[k].mean_ms() * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)} for k, _, nb in big_ops}}
+        del xb, yb, gb, dxb
+    except Exception as exc:  # noqa: BLE001
+        res_ops["dram_resident"] = {"error": repr(exc)[:200]}
     sw = res_ops["swish_fwd"]
     return {
         "samples_per_step": R * world, "dt": dt,
@@ -793,8 +827,8 @@ def cpu_c4(seconds, Bs=64, max_steps=1):
         if time.perf_counter() - t_all > max(seconds, 10.0):
             break
     best = min(times)
-    out = {"value": round(Bs / best, 3), "unit": "samples/s", "cores": blas_threads(), "kind": "port",
-           "sample": f"{len(times)} FULL steps (forward + backward + Adam over all {sum(p.size for p in ps)} parameters) of the "
+    out = {"value": round(Bs / best, 3), "unit": "samples/s", "cores": blas_threads(), "kind": "port", "samples": len(times),
+           "sample": f"n = {len(times)} (one full-batch oracle step is 10-20 s of host time: the bounded sample of the default run) -- {len(times)} FULL steps (forward + backward + Adam over all {sum(p.size for p in ps)} parameters) of the "
                      f"NumPy-oracle GPT-tiny on {Bs} sequences x {c['seq']} tokens ({Bs}/64 of one GPU's batch), min step "
                      f"{best:.2f} s, OpenBLAS threads={blas_threads()}, host cpus={os.cpu_count()}"}
     full = os.path.join(ROOT, "profiles", "cpu_c4_full_batch.json")
@@ -1107,12 +1141,12 @@ def cpu_c5(seconds):
 
     step()
     times, t0 = [], time.perf_counter()
-    while time.perf_counter() - t0 < min(seconds, 10.0) and len(times) < 20:
+    while (time.perf_counter() - t0 < min(seconds, 10.0) and len(times) < 20) or len(times) < 3:
         t1 = time.perf_counter()
         step()
         times.append(time.perf_counter() - t1)
     best = min(times)
-    return {"value": round(256 / best, 1), "unit": "samples/s", "cores": blas_threads(), "kind": "port",
+    return {"value": round(256 / best, 1), "unit": "samples/s", "cores": blas_threads(), "kind": "port", "samples": len(times),
             "sample": f"{len(times)} FULL training steps (forward + backward + Adam on all 8 parameter tensors) of the "
                       f"NumPy-oracle conv classifier at batch 256, min {best * 1e3:.1f} ms"}
 
@@ -1169,8 +1203,11 @@ def c2_forward_roofline(iters=50, sustain_s=2.0):
 
 
 def c4_family_rooflines(iters=20):
-    """The three kernel families that make up ~97 % of the C4 step, each launched on its own at its C4 shape and timed
-    with HIP events (median of `iters`): what the whole-step figure in also.c4_gemm averages over."""
+    """Every GEMM / attention launch of ONE C4 step at its own shape, launched on its own and timed with HIP events (median of
+    `iters`): the q|k|v projection, the output projection, the two FFN layers, the vocabulary head (forward and input gradient
+    each), the deferred parameter gradients of a decoder layer as the ONE grouped launch the step makes of them, and the fused
+    attention.  `per_step` = how many times the step launches it.  The flop-weighted sum over this list is the headline's
+    roofline figure (workload_headline)."""
     import torch
     from neunet_hip._lib import StridedView, call_hip_function as call, get_current_stream_ptr
     st = get_current_stream_ptr()
@@ -1191,26 +1228,33 @@ def c4_family_rooflines(iters=20):
         torch.cuda.synchronize()
         return float(np.median([a.elapsed_time(b) for a, b in ev]))
 
-    M, D, F, V, Bq, T, H = 64 * C4["seq"], C4["d_model"], C4["d_ff"], C4["vocab"], 64, C4["seq"], C4["n_heads"]
+    M, D, F, V, Bq, T, H, L = 64 * C4["seq"], C4["d_model"], C4["d_ff"], C4["vocab"], 64, C4["seq"], C4["n_heads"], C4["n_layers"]
     fams = []
 
-    def linear_family(name, K, N, per_step):
-        X, W, b = rnd(M, K), rnd(N, K) / 16, rnd(1, N)
-        O_, dO, dX, dW, db = torch.empty(M, N, device="cuda"), rnd(M, N), torch.empty(M, K, device="cuda"), \
-            torch.empty(N, K, device="cuda"), torch.empty(1, N, device="cuda")
-        t = (med(lambda: call("nnhipLinearModuleForward", X, W, b, O_, M, K, N, st))
-             + med(lambda: call("nnhipLinearModuleBackward", X, W, dO, dX, None, None, M, K, N, st))
-             + med(lambda: call("nnhipLinearModuleBackward", X, W, dO, None, dW, db, M, K, N, st)))
-        fl = 6.0 * M * K * N
-        fams.append({"family": name, "kernels": "gemm_f32 / gemm_pst forward, dX, dW+db", "launches_per_step": per_step,
-                     "flops": fl, "ms": round(t, 4), "tflops": round(fl / (t * 1e-3) / 1e12, 2),
-                     "frac_of_mfma_peak": round(fl / (t * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)})
+    def add(name, kernels, per_step, fl, ms):
+        fams.append({"family": name, "kernels": kernels, "per_step": per_step, "flops": fl, "ms": round(ms, 4),
+                     "tflops": round(fl / (ms * 1e-3) / 1e12, 2), "frac_of_mfma_peak": round(fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)})
 
-    linear_family(f"Linear {D}->{D} (attention projections), rows {M}", D, D, "4 x 6 layers")
-    linear_family(f"Linear {D}->{F} / {F}->{D} (FFN), rows {M}", D, F, "2 x 6 layers")
-    linear_family(f"Linear {D}->{V} (vocabulary head), rows {M}", D, V, "1")
-    # what the step really launches for a decoder layer's parameter gradients: the four dW+db GEMMs as ONE grid + ONE reduce
-    # (deferred parameter gradients); the three Linear families above time each dW on its own
+    def linear_fwd_dx(name, K, N, per_step, with_dw=False):
+        X, W, b = rnd(M, K), rnd(N, K) / 16, rnd(1, N)
+        O_, dO, dX = torch.empty(M, N, device="cuda"), rnd(M, N), torch.empty(M, K, device="cuda")
+        fl = 2.0 * M * K * N
+        add(f"{name}: forward, rows {M}", "gemm_pst_kernel / gemm_f32_kernel (k-major, k-major)", per_step, fl,
+            med(lambda: call("nnhipLinearModuleForward", X, W, b, O_, M, K, N, st)))
+        add(f"{name}: input gradient", "gemm_pst_kernel / gemm_f32_kernel (k-major, outer-major)", per_step, fl,
+            med(lambda: call("nnhipLinearModuleBackward", X, W, dO, dX, None, None, M, K, N, st)))
+        if with_dw:
+            dW, db = torch.empty(N, K, device="cuda"), torch.empty(1, N, device="cuda")
+            add(f"{name}: weight + bias gradient", "gemm_f32_group_kernel (uneven two-way split) + splitk_reduce", per_step, fl,
+                med(lambda: call("nnhipLinearModuleBackward", X, W, dO, None, dW, db, M, K, N, st)))
+
+    linear_fwd_dx(f"q|k|v projection {D}->{3 * D}", D, 3 * D, L)
+    linear_fwd_dx(f"attention output projection {D}->{D}", D, D, L)
+    linear_fwd_dx(f"FFN {D}->{F}", D, F, L)
+    linear_fwd_dx(f"FFN {F}->{D}", F, D, L)
+    linear_fwd_dx(f"vocabulary head {D}->{V}", D, V, 1, with_dw=True)
+    # what the step launches for a decoder layer's parameter gradients: the four dW+db GEMMs as ONE grid + ONE reduce
+    # (deferred parameter gradients) -- C4's largest kernel by device time
     jobs = [(rnd(M, K), rnd(N, K) / 16, rnd(M, N), torch.empty(N, K, device="cuda"), torch.empty(1, N, device="cuda"), K, N)
             for (N, K) in ((D, F), (F, D), (D, D), (3 * D, D))]
 
@@ -1220,11 +1264,8 @@ def c4_family_rooflines(iters=20):
             call("nnhipLinearModuleBackward", X, W, dO, None, dW, db, M, K, N, st)
         call("nnhipWeightGradDefer", 0, st)
 
-    tg = med(grouped)
-    fl = sum(2.0 * M * K * N for (*_, K, N) in jobs)
-    fams.append({"family": f"dW+db of one decoder layer (4 GEMMs, rows {M}), deferred", "kernels": "gemm_f32_group_kernel + splitk_reduce_group_kernel",
-                 "launches_per_step": "1 x 6 layers", "flops": fl, "ms": round(tg, 4), "tflops": round(fl / (tg * 1e-3) / 1e12, 2),
-                 "frac_of_mfma_peak": round(fl / (tg * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)})
+    add(f"dW+db of one decoder layer (4 GEMMs, rows {M}), deferred", "gemm_f32_group_kernel<32> + splitk_reduce_group_kernel", L,
+        sum(2.0 * M * K * N for (*_, K, N) in jobs), med(grouped))
     del jobs
     qkv = rnd(Bq, T, 3 * D)
     dqkv = torch.empty_like(qkv)
@@ -1233,16 +1274,22 @@ def c4_family_rooflines(iters=20):
     q_, k_, v_ = (qkv[..., i * D:(i + 1) * D] for i in range(3))
     dq_, dk_, dv_ = (dqkv[..., i * D:(i + 1) * D] for i in range(3))
     sc, dh = 1.0 / float(np.sqrt(D)), D // H
-    tf = med(lambda: call("nnhipAttentionForward", StridedView(q_), StridedView(k_), StridedView(v_), kval, ctx, lse, Bq, H, T, T, dh,
-                          3 * D, sc, 1, st))
-    tb = med(lambda: call("nnhipAttentionBackward", StridedView(q_), StridedView(k_), StridedView(v_), kval, ctx, dctx, lse,
-                          StridedView(dq_), StridedView(dk_), StridedView(dv_), Bq, H, T, T, dh, 3 * D, sc, 1, st))
-    fl = 3.5 * (4.0 * Bq * H * T * T * dh / 2)          # causal: half the score matrix; backward = 2.5 x forward
-    fams.append({"family": f"fused attention B{Bq} T{T} H{H} dh{dh} (causal)", "kernels": "attn_fwd / attn_bwd_dkdv / attn_bwd_dq",
-                 "launches_per_step": "3 x 6 layers", "flops": fl, "ms": round(tf + tb, 4),
-                 "tflops": round(fl / ((tf + tb) * 1e-3) / 1e12, 2),
-                 "frac_of_mfma_peak": round(fl / ((tf + tb) * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)})
+    afl = 4.0 * Bq * H * T * T * dh / 2                  # causal: half the score matrix; backward = 2.5 x forward
+    add(f"fused attention forward B{Bq} T{T} H{H} dh{dh} (causal)", "attn_sb_fwd_kernel", L, afl,
+        med(lambda: call("nnhipAttentionForward", StridedView(q_), StridedView(k_), StridedView(v_), kval, ctx, lse, Bq, H, T, T, dh,
+                         3 * D, sc, 1, st)))
+    add(f"fused attention backward B{Bq} T{T} H{H} dh{dh} (causal)", "attn_sb_bwd_kernel (one pass, 5 GEMMs per tile pair)", L, 2.5 * afl,
+        med(lambda: call("nnhipAttentionBackward", StridedView(q_), StridedView(k_), StridedView(v_), kval, ctx, dctx, lse,
+                         StridedView(dq_), StridedView(dk_), StridedView(dv_), Bq, H, T, T, dh, 3 * D, sc, 1, st)))
     return fams
+
+
+def c4_weighted_roofline(fams):
+    """Flop-weighted MFMA figure of one C4 step's GEMM + attention launches: sum(per_step x flops) / sum(per_step x ms)."""
+    fl = sum(f["per_step"] * f["flops"] for f in fams)
+    ms = sum(f["per_step"] * f["ms"] for f in fams)
+    dom = max(fams, key=lambda f: f["per_step"] * f["ms"])
+    return fl, ms, dom
 
 
 def workload_headline(args, rank, world):
@@ -1252,9 +1299,8 @@ def workload_headline(args, rank, world):
     res = workload_c4(args, rank, world)
     c4_roof = res.pop("roofline")
     fwd = c2_forward_roofline()
-    res["roofline"] = {
-        "kernel": "gemm_f32_kernel<32,k-major,k-major> -- C2 Linear(4096->4096) forward, batch 4096 (the GEMM family that is "
-                  "~86 % of the C4 step's device time)",
+    c2_obj = {
+        "kernel": "gemm_f32_kernel<32,k-major,k-major> -- C2 Linear(4096->4096) forward, batch 4096 (BASELINE's 'Linear fwd GFLOP/s vs MFMA peak')",
         "bound": "mfma", "achieved": round(fwd["burst_tflops"], 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
         "frac": round(fwd["burst_tflops"] / PEAK_F32_MFMA_TFLOPS, 4), "traffic": read_traffic("gemm_fwd_c2"),
         "traffic_source": traffic_source(),
@@ -1262,12 +1308,35 @@ def workload_headline(args, rank, world):
         "sustained": {"tflops": round(fwd["sustained_tflops"], 2), "frac": round(fwd["sustained_tflops"] / PEAK_F32_MFMA_TFLOPS, 4),
                       "avg_launch_ms": round(fwd["sustained_ms"], 4), "launches": fwd["sustained_launches"]},
     }
+    tr, alg = c2_obj["traffic"], 3 * 4096 * 4096 * 4
+    if tr:
+        c2_obj["traffic_over_algorithmic"] = round(tr / alg, 2)
+        c2_obj["traffic_note"] = (f"L2<->fabric requests per launch (Infinity-Cache hits included) are {tr / alg:.2f}x the {alg / 1e6:.0f} MB of operands + result: "
+                                  "the two resident blocks of a CU drift apart and each cohort streams its own panels (DESIGN 5.1g); MFMA-bound at N = 1")
     also = {"c4_gemm": {"what": "whole C4 step, GEMM-equivalent flops (Linear fwd/dX/dW + attention) / device step time",
                         "tflops": c4_roof["achieved"], "frac_of_mfma_peak": c4_roof["frac"],
-                        "flops_per_step": c4_roof["flops_per_step"], "avg_step_device_ms": c4_roof["avg_step_device_ms"]}}
+                        "flops_per_step": c4_roof["flops_per_step"], "avg_step_device_ms": c4_roof["avg_step_device_ms"]},
+            "c2_linear_forward": c2_obj}
+    res["roofline"] = c2_obj          # replaced below by the C4 step's own kernels when they could be timed
     if rank == 0 or world == 1:
         try:
-            also["c4_families"] = c4_family_rooflines()
+            fams = c4_family_rooflines()
+            also["c4_families"] = fams
+            fl, ms, dom = c4_weighted_roofline(fams)
+            res["roofline"] = {
+                "kernel": "the exact-fp32 MFMA kernels of the C4 step itself -- gemm_f32_group_kernel, gemm_f32_kernel, gemm_pst_kernel, attn_sb_* "
+                          "(97 % of the step's device time) -- every launch of one step at its own shape, flop-weighted; largest single kernel: "
+                          + dom["kernels"] + " (" + dom["family"] + ")",
+                "bound": "mfma", "achieved": round(fl / (ms * 1e-3) / 1e12, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                "traffic": None, "flops_per_step": fl, "kernel_ms_per_step": round(ms, 4),
+                "how": "HIP events on the launch stream around each launch (median of 20), also.c4_families lists them; "
+                       "profiles/r05*_c4_kernel_stats.md is the rocprofv3 view of the same kernels inside the step",
+                "dominant_kernel": {"name": dom["kernels"], "what": dom["family"], "launches_per_step": dom["per_step"],
+                                    "flops_per_launch": dom["flops"], "avg_launch_ms": dom["ms"], "tflops": dom["tflops"],
+                                    "frac": dom["frac_of_mfma_peak"]},
+                "c2_linear_forward": {k: c2_obj[k] for k in ("achieved", "frac", "avg_launch_ms", "traffic", "traffic_over_algorithmic") if k in c2_obj},
+            }
         except Exception as exc:  # noqa: BLE001
             also["c4_families"] = {"error": repr(exc)[:300]}
     # C1: MNIST-MLP, sustained
@@ -1400,7 +1469,12 @@ def workload_headline(args, rank, world):
 def cpu_headline(seconds):
     out = cpu_c4(seconds)
     c1 = cpu_c1(3.0)
-    out["also_c1"] = {"value": c1["value"], "unit": c1["unit"], "sample": c1["sample"]}
+    out["also_c1"] = {"value": c1["value"], "unit": c1["unit"], "samples": c1["samples"], "sample": c1["sample"]}
+    try:
+        c5 = cpu_c5(4.0)
+        out["also_c5"] = {"value": c5["value"], "unit": c5["unit"], "samples": c5["samples"], "sample": c5["sample"]}
+    except Exception as exc:  # noqa: BLE001
+        out["also_c5"] = {"error": repr(exc)[:200]}
     return out
 
 
