@@ -611,6 +611,10 @@ def cpu_c3(seconds):
 
 # ------------------------------------------------------------------------------------------------ C4
 C4 = dict(vocab=15000, d_model=512, n_heads=8, d_ff=2048, n_layers=6, seq=256)
+if os.environ.get("NNHIP_BENCH_TOY", "0") == "1":
+    # functional rehearsal of the N > 1 code path (8 ranks sharing one GPU over gloo, tests/test_dp_gpu.py): same recipe, toy sizes.
+    # A line produced under this switch says so in config.workload and is not a measurement of anything.
+    C4 = dict(vocab=640, d_model=128, n_heads=2, d_ff=256, n_layers=2, seq=64)
 
 
 def c4_flops(B, T, c=C4):
@@ -647,9 +651,18 @@ def workload_c4(args, rank, world):
     from neunet_hip.optim import Adam
     from neunet_hip.distributed import collectives_live
     strong = getattr(args, "scaling", "weak") == "strong"
-    if strong and args.c4_batch % world:
-        raise ValueError(f"--scaling strong: the global batch ({args.c4_batch}) must divide over {world} ranks")
-    B, T = (args.c4_batch // world if strong else args.c4_batch), C4["seq"]
+    T = C4["seq"]
+    if strong:
+        # the global batch divided over the ranks; a remainder goes to the first ranks (distributed.shard_batch): every rank
+        # back-propagates the SUM loss of its own shard and the all-reduced target count divides, so uneven shards are exact
+        from neunet_hip.distributed import shard_batch
+        if args.c4_batch < world:
+            raise ValueError(f"--scaling strong: the global batch ({args.c4_batch}) has fewer sequences than ranks ({world})")
+        lo, hi = shard_batch(args.c4_batch, rank, world)
+        B = hi - lo
+    else:
+        B = args.c4_batch
+    global_batch = args.c4_batch if strong else B * world
     dp = world > 1 or collectives_live()                          # a gradient exchange is part of the step
     comm = None
     if dp and getattr(args, "comm", "torch") == "native":
@@ -763,17 +776,18 @@ def workload_c4(args, rank, world):
         comm_lib = "%s (version %d)" % NativeComm.library()
         comm.destroy()
     return {
-        "samples_per_step": B * world, "dt": dt, "scaling": "strong" if strong else "weak",
-        "config": {"workload": f"C4: GPT-tiny d512 L6 H8 d_ff2048 vocab15000 training step, batch {B} x seq {T} per GPU, "
-                               "Adam(1.5e-4), dropout 0", "global_batch": B * world, "seq_len": T,
+        "samples_per_step": global_batch, "dt": dt, "scaling": "strong" if strong else "weak",
+        "config": {"workload": ("TOY SIZES (NNHIP_BENCH_TOY=1, functional rehearsal only) " if os.environ.get("NNHIP_BENCH_TOY", "0") == "1" else "")
+                               + f"C4: GPT-tiny d{C4['d_model']} L{C4['n_layers']} H{C4['n_heads']} d_ff{C4['d_ff']} vocab{C4['vocab']} training step, "
+                               f"batch {B} x seq {T} per GPU, Adam(1.5e-4), dropout 0", "global_batch": global_batch, "seq_len": T,
                    "parallelism": f"dp{world}", "launch": "hipGraph replay" if use_graph else "eager",
-                   "scaling": ("strong: global batch %d divided over the ranks" % (B * world)) if strong
+                   "scaling": ("strong: global batch %d divided over the ranks" % global_batch) if strong
                               else "weak: %d sequences per GPU" % B},
         "roofline": {"kernel": "whole step, GEMM flops only (fp32 MFMA gemm_f32_kernel family: Linear fwd/dX/dW + attention)",
                      "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "flops_per_step": fl,
                      "avg_step_device_ms": round(dev_ms, 4)},
-        "extra": {"tokens_per_s": round(B * world * T * args.steps / dt, 1), "grad_floats": n_grad,
+        "extra": {"tokens_per_s": round(global_batch * T * args.steps / dt, 1), "grad_floats": n_grad,
                   "dp_exchange": ("none" if not dp else
                                   (f"{len(bucket.segments)} bucket segments, async all-reduce overlapped with backward"
                                    + (f" ({pieces} graph pieces)" if use_graph else "") if overlap
@@ -1416,7 +1430,7 @@ def workload_headline(args, rank, world):
                                      "samples_per_s": round(rs["samples_per_step"] * a_s.steps / rs["dt"], 2),
                                      "ms_per_step": round(rs["dt"] / a_s.steps * 1e3, 4),
                                      "dp_exchange": rs["extra"]["dp_exchange"]}
-    if world > 1 and args.c4_batch % world == 0:
+    if world > 1 and args.c4_batch >= world:
         guarded("c4_other_scaling", run_strong)
     # C2: the whole Linear training step
     a2 = copy.copy(args)
@@ -1541,6 +1555,10 @@ def main():
         probe = torch.ones(1, device="cuda")
         dist.all_reduce(probe)                          # a real collective before anything is reported
         rccl_ranks = int(round(float(probe.item())))
+        if rccl_ranks != world:
+            # the one number that says the ranks really talk to each other: a wrong sum is a broken job, not a slow one
+            print(f"bench.py: all-reduce of ones over {world} rank(s) on backend {dist.get_backend()} returned {probe.item()!r}", file=sys.stderr)
+            sys.exit(3)
         if rank == 0:
             print(f"[bench] backend={dist.get_backend()} world={dist.get_world_size()} all-reduce(1)={rccl_ranks}",
                   file=sys.stderr)

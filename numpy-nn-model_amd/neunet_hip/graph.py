@@ -85,6 +85,24 @@ def count_graph_nodes(raw_graph: int):
     return kernels, int(n.value)
 
 
+def _end_broken_capture(stream):
+    """hipStreamEndCapture on a stream whose capture was invalidated: returns the stream to the non-capturing state (the call
+    itself reports the invalidation -- that is expected -- and hands back no graph)."""
+    import ctypes
+    try:
+        rt = ctypes.CDLL("libamdhip64.so")
+        status = ctypes.c_int(0)
+        rt.hipStreamIsCapturing(ctypes.c_void_p(stream.cuda_stream), ctypes.byref(status))
+        if status.value != 0:
+            g = ctypes.c_void_p()
+            rt.hipStreamEndCapture(ctypes.c_void_p(stream.cuda_stream), ctypes.byref(g))
+            if g.value:
+                rt.hipGraphDestroy(g)
+        rt.hipGetLastError()
+    except Exception:  # noqa: BLE001 -- best effort: the fall-back uses a fresh stream either way
+        pass
+
+
 class GraphedTrainStep:
     _live = 0          # captured steps alive in this process: the library workspace stays locked while > 0
     # Every capture is thread-local.  torch's default ("global") makes ANY thread's capture-unsafe HIP call fail while this
@@ -152,6 +170,12 @@ class GraphedTrainStep:
     def _capture_all(self, s, bucket, pre_optim, capture_collectives):
         torch = self._torch
         overlap = bool(getattr(bucket, "overlap", False)) and not self.single
+        if capture_collectives and not self.single and pre_optim is None and not self._collectives_capturable(bucket):
+            # decided up front, not by trying: a capture that a backend invalidates half-way (gloo copies through the host) leaves
+            # the thread's capture state poisoned on ROCm 7.2 -- every later HIP call of the process fails with
+            # hipErrorStreamCaptureInvalidated, the fall-back included (8-rank rehearsal of bench.py, round 5)
+            self.ingraph_error = "the process group's backend cannot record collectives into a stream capture (only nccl = RCCL and the library's NativeComm can)"
+            capture_collectives = False
         if capture_collectives and not self.single and pre_optim is None:
             try:
                 self._capture_with_collectives(s)
@@ -159,6 +183,13 @@ class GraphedTrainStep:
             except Exception as exc:  # noqa: BLE001 -- the backend refused: keep the collectives between the pieces
                 self.ingraph_error = repr(exc)[:300]
                 self.pieces = []
+                # A refused capture leaves its stream in the INVALIDATED capture state (torch's capture_end raised before the
+                # runtime's EndCapture ran): a second capture_begin on it fails half-way and torch then aborts the process from
+                # CUDAGraph's destructor ("The graph should be registered to the state") -- found by the 8-rank rehearsal of
+                # bench.py, where gloo cannot be captured; on an RCCL node it would have turned "fall back to graph pieces" into a
+                # dead job.  End the broken capture by hand and give the fall-back a stream that never saw it.
+                _end_broken_capture(s)
+                s = torch.cuda.Stream()
                 torch.cuda.synchronize()
                 if overlap:
                     bucket._reset_step()
@@ -192,6 +223,15 @@ class GraphedTrainStep:
             self._bind_grads()
             with torch.cuda.graph(self.g_opt, pool=self.pieces[0][0].pool(), capture_error_mode=self._CAPTURE_MODE):
                 self.opt.step()
+
+    def _collectives_capturable(self, bucket):
+        if getattr(bucket, "comm", None) is not None:          # the library's own RCCL entry points: plain stream-ordered launches
+            return True
+        try:
+            import torch.distributed as dist
+            return dist.is_initialized() and dist.get_backend(self.group) == "nccl"
+        except Exception:  # noqa: BLE001
+            return False
 
     # ---- capture of the overlapped variant: one graph per bucket segment ------------------------------------------
     def _capture_overlapped(self, side_stream):

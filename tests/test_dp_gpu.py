@@ -455,3 +455,44 @@ def test_native_comm_two_ranks_when_two_gpus_are_visible():
         np.testing.assert_array_equal(got[r]["sum"], 3 * v)
         np.testing.assert_array_equal(got[r]["avg"], 1.5 * v)
         np.testing.assert_array_equal(got[r]["bcast"], v)
+
+
+def test_bench_eight_ranks_on_one_gpu_rehearsal():
+    """First-contact rehearsal of the run the driver makes on an 8-GPU node (round-4 review, item 5): `bench.py --gpus 8` at toy
+    sizes (NNHIP_BENCH_TOY=1), eight ranks sharing the one visible GPU over gloo (NNHIP_ALLOW_OVERSUBSCRIBE=1).  Covered: the
+    self-launch under torch.distributed.run with a free port on 127.0.0.1, the ONE JSON line on stdout with every key the driver
+    reads, strong scaling with a global batch that does NOT divide over the ranks (12 sequences on 8 ranks: shard_batch), the
+    other curve under also.c4_weak, the overlapped bucket segments, and the in-graph capture request falling back to graph
+    pieces with the reason recorded (gloo collectives cannot be captured)."""
+    import json
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no HIP device is visible")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NNHIP_ALLOW_OVERSUBSCRIBE="1", NNHIP_BENCH_TOY="1", NNHIP_BENCH_C3="0", NNHIP_BENCH_C5="0",
+               NNHIP_BENCH_NB="0", NNHIP_BENCH_BF16X3="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "4", "--warmup", "2", "--c4-batch", "12",
+                        "--scaling", "strong", "--dp-ingraph", "1", "--c1-steps", "32", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, f"stdout must carry exactly one JSON line, got {len(lines)}: {r.stdout[:500]}"
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "rccl_ranks"):
+        assert key in d, key
+    assert d["n_gpus"] == 8 and d["rccl_ranks"] == 8 and d["steps"] == 4 and d["scaling"] == "strong"
+    assert d["config"]["global_batch"] == 12 and d["config"]["parallelism"] == "dp8" and "TOY" in d["config"]["workload"]
+    assert d["value"] > 0 and abs(d["value"] - 12 / (d["ms_per_step"] * 1e-3)) < 1e-2 * d["value"]
+    assert d["dist_backend"] == "gloo"
+    assert "segments" in d["dp_exchange"] or "all-reduce" in d["dp_exchange"]
+    mode = d["dp_mode"]
+    assert mode["overlap"] in (True, False) and mode["launch"] is not None
+    assert mode["ingraph_error"] or mode["modes_that_failed"] or "graph" in str(mode["launch"]), mode      # the capture request was answered
+    weak = d["also"]["c4_weak"]
+    assert weak["global_batch"] == 96 and weak["samples_per_s"] > 0
+    assert d["also"]["c1"].get("samples_per_s", 0) > 0 or "error" in d["also"]["c1"]
+    assert "bound" in d["roofline"] and "frac" in d["roofline"]
