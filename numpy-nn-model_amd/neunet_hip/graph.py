@@ -225,9 +225,10 @@ class GraphedTrainStep:
                 self.opt.step()
 
     def _collectives_capturable(self, bucket):
-        if getattr(bucket, "comm", None) is not None:          # the library's own RCCL entry points: plain stream-ordered launches
-            return True
         try:
+            from .distributed import NativeComm
+            if isinstance(self.group, NativeComm):             # the library's own RCCL entry points: plain stream-ordered launches
+                return True
             import torch.distributed as dist
             return dist.is_initialized() and dist.get_backend(self.group) == "nccl"
         except Exception:  # noqa: BLE001
