@@ -68,9 +68,10 @@ def parse():
     ap.add_argument("--c1-input-copy", type=int, default=0,
                     help="c1: 1 = every step first copies its batch (100 KB pinned host -> the static device slot), as the "
                          "reference's benches do (benchmark_linear_swish_cuda.py:31)")
-    ap.add_argument("--c1-fuse-opt", type=int, default=int(os.environ.get("NNHIP_C1_FUSE_OPT", "1")),
-                    help="c1: 1 = optimizer.fuse_backward(True), Adam inside the backward launch (opt-in semantics: no gradient "
-                         "clipping / accumulation between backward and step); 0 = the separate optimizer launch a README user gets")
+    ap.add_argument("--c1-fuse-opt", type=int, default=int(os.environ.get("NNHIP_C1_FUSE_OPT", "2")),
+                    help="c1: 2 = the default a README user gets (no opt-in: the backward launch waits for optimizer.step() and "
+                         "takes Adam with it); 1 = optimizer.fuse_backward(True) (Adam inside the launch issued by backward()); "
+                         "0 = backward and Adam as two launches (NNHIP_AUTO_FUSE_STEP=0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--cpu-full-batch", action="store_true",
@@ -307,9 +308,13 @@ def workload_c1(args, rank, world):
     bucket = GradBucket(params)
     opt = Adam(params, lr=1e-3)
     opt.grad_scale = 1.0 / world
-    fused_opt = world == 1 and bool(getattr(args, "c1_fuse_opt", 1))
-    if fused_opt:
-        opt.fuse_backward(True)     # one process: the backward launch applies Adam itself (bit-identical to the separate launch)
+    opt_mode = int(getattr(args, "c1_fuse_opt", 2)) if world == 1 else 0
+    import neunet_hip.nn.experimental.linear as _lin
+    auto_was = _lin._AUTO_FUSE_STEP
+    _lin._AUTO_FUSE_STEP = auto_was and opt_mode != 0      # 0: the two-launch comparison line
+    if opt_mode == 1:
+        opt.fuse_backward(True)     # opt-in: the launch issued by backward() applies Adam itself (bit-identical to the separate launch)
+    fused_opt = opt_mode != 0 and (opt_mode == 1 or _lin._AUTO_FUSE_STEP)
     loss_fn = nn.CrossEntropyLoss()
     drng = np.random.default_rng(3000 + rank)
     U = graph_unroll(args, world)                        # steps per captured graph, each reading its own static batch slot
@@ -377,7 +382,8 @@ def workload_c1(args, rank, world):
             copy_in()
             opt.zero_grad()
             fwd_bwd()
-            bucket.all_reduce()
+            if world > 1:
+                bucket.all_reduce()
             opt.step()
             if timed:
                 b.record()
@@ -385,14 +391,17 @@ def workload_c1(args, rank, world):
     dt = timed_region(step, args.steps // U, max(1, args.warmup // U), world, min_warm_s=0.5)      # one call = U steps
     if args.graph:
         gstep.release()
+    _lin._AUTO_FUSE_STEP = auto_was
     dev_ms = ev.mean_ms() / U
     flops = 2.0 * 3 * Bsz * (784 * 128 + 128 * 10)
     return {
         "samples_per_step": Bsz * world, "dt": dt,
         "config": {"workload": "C1: MNIST-MLP 784->128->10 training step (Linear+ReLU+CrossEntropy+Adam), batch 32 per GPU",
                    "global_batch": Bsz * world, "parallelism": f"dp{world}",
-                   "optimizer_launch": "inside the backward launch (optimizer.fuse_backward(True), opt-in)" if fused_opt
-                                       else "separate fused-Adam launch (the default a README user gets)",
+                   "optimizer_launch": ("inside the backward launch, no opt-in (the launch waits for optimizer.step(): the default a README user gets)"
+                                        if opt_mode == 2 and fused_opt else
+                                        "inside the backward launch (optimizer.fuse_backward(True), opt-in)" if fused_opt
+                                        else "separate fused-Adam launch (NNHIP_AUTO_FUSE_STEP=0)"),
                    "input": (f"pinned host batches copied into the device slots inside the timed region (one {U * 100.5:.0f} KB H2D copy per "
                              f"replay of {U} steps)") if feed
                             else "batches resident in HBM",
@@ -1370,13 +1379,15 @@ def workload_headline(args, rank, world):
         also["c1"] = {"workload": r1["config"]["workload"], "samples_per_s": round(r1["samples_per_step"] * a1.steps / r1["dt"], 1),
                       "ms_per_step": round(r1["dt"] / a1.steps * 1e3, 5), "steps": a1.steps,
                       "device_ms_per_step": r1["roofline"].get("avg_step_device_ms"), "launch": r1["config"].get("launch"),
-                      "launches_per_step": r1["extra"].get("launches_per_step")}
+                      "launches_per_step": r1["extra"].get("launches_per_step"),
+                      "optimizer_launch": r1["config"].get("optimizer_launch")}
     guarded("c1", run_c1)
 
     def run_c1_variants():
-        # (a) with the per-step input copy the reference's benches include; (b) with the separate
-        # optimizer launch a README user gets without opting into optimizer.fuse_backward (advisor, round 3)
-        for key, kw in (("with_input_copy", {"c1_input_copy": 1}), ("separate_optimizer_launch", {"c1_fuse_opt": 0})):
+        # (a) with the per-step input copy the reference's benches include; (b) backward and Adam as two
+        # launches (what the default was before round 5; NNHIP_AUTO_FUSE_STEP=0); (c) the round-3 opt-in
+        for key, kw in (("with_input_copy", {"c1_input_copy": 1}), ("separate_optimizer_launch", {"c1_fuse_opt": 0}),
+                        ("opt_in_fuse_backward", {"c1_fuse_opt": 1})):
             av = copy.copy(a1)
             for k, v in kw.items():
                 setattr(av, k, v)
@@ -1386,8 +1397,7 @@ def workload_headline(args, rank, world):
                                "device_ms_per_step": rv["roofline"].get("avg_step_device_ms"),
                                "launches_per_step": rv["extra"].get("launches_per_step"),
                                "input": rv["config"]["input"], "optimizer_launch": rv["config"]["optimizer_launch"]}
-        also["c1"]["input"], also["c1"]["optimizer_launch"] = "batches resident in HBM", (
-            "inside the backward launch (optimizer.fuse_backward(True), opt-in)" if world == 1 and a1.c1_fuse_opt else "separate launch")
+        also["c1"]["input"] = "batches resident in HBM"
     if "error" not in also.get("c1", {"error": 1}):
         guarded("c1_variants", run_c1_variants)
 

@@ -179,6 +179,10 @@ int nnhipLinearReLULinearBackwardAdam(const float* X1, const float* H, const flo
                                       void* opt, float* const* pmv, double lr, double beta1, double beta2, double eps,
                                       double weight_decay, int32_t step, int32_t decay_mode, float grad_scale,
                                       nnhipStream_t stream);
+/* 1 when the two entries above (with_adam 0 / 1) take these sizes on the current device, 0 when they would answer NNHIP_EINVAL
+ * -- for a caller that decides BEFORE it defers the launch (neunet_hip defers it to optimizer.step() so that the README MLP's
+ * default training step gets the backward + Adam launch without opting in).  No device work.  ABI 209 */
+int nnhipLinearReLULinearBackwardFits(int64_t rows, int64_t in1, int64_t hidden, int64_t out2, int32_t with_adam);
 /* O = act(X*W^T + b), activation in the GEMM epilogue: 1 = swish(beta) without saving z, 2 = relu, 3 = sigmoid.
  * One launch for what `act(Linear(x))` is on the reference's tape (linear.py:48-58 + activations.py); the host side
  * uses it when an activation module is applied to a Linear output nobody else has looked at yet. */

@@ -368,12 +368,20 @@ static bool mlp_adam_grid_fits(int nw, int64_t pollers) {
 }
 
 // rows <= 256, out2 <= 16, operands below 2 GiB; returns 1 when it did the work, 0 when the caller should take the general path
-int gemm_small_mlp_backward(const float* X1, const float* H, const float* W2, const float* dO, float* dW2, float* db2, float* dW1,
-                            float* db1, int64_t rows, int64_t in1, int64_t hid, int64_t out2, hipStream_t st,
-                            const SmallMlpAdam* adam) {
+// The envelope of the launch below (with_adam: including the optimizer-in-backward variant's barrier rule); 1 = it will do the work
+int gemm_small_mlp_fits(int64_t rows, int64_t in1, int64_t hid, int64_t out2, int with_adam) {
     if (rows <= 0 || rows > SG_MLP_MAXROWS || out2 <= 0 || out2 > SG_MLP_MAXC || in1 <= 0 || hid <= 0) return 0;
     if (!gemm_small_wanted(out2, hid, rows, 1, out2, hid, false, false) || !gemm_small_wanted(hid, in1, rows, 1, hid, in1, false, false)) return 0;
     if (rows * in1 * 4 >= ((int64_t)1 << 31) || rows * hid * 4 >= ((int64_t)1 << 31)) return 0;
+    const int nw = ((rows + 15) >> 4) >= 8 ? 8 : 4;
+    if (with_adam && !mlp_adam_grid_fits(nw, ceil_div(hid, 16) * ceil_div(out2, 16) + 1)) return 0;
+    return 1;
+}
+
+int gemm_small_mlp_backward(const float* X1, const float* H, const float* W2, const float* dO, float* dW2, float* db2, float* dW1,
+                            float* db1, int64_t rows, int64_t in1, int64_t hid, int64_t out2, hipStream_t st,
+                            const SmallMlpAdam* adam) {
+    if (!gemm_small_mlp_fits(rows, in1, hid, out2, 0)) return 0;
     SmallMlpBwd q;
     q.X1 = X1; q.H = H; q.W2 = W2; q.dO = dO; q.dW2 = dW2; q.db2 = db2; q.dW1 = dW1; q.db1 = db1;
     q.rows = (int)rows; q.in1 = (int)in1; q.hid = (int)hid; q.out2 = (int)out2;

@@ -28,6 +28,7 @@ struct SmallMlpAdam;
 int gemm_small_mlp_backward(const float* X1, const float* H, const float* W2, const float* dO, float* dW2, float* db2, float* dW1,
                             float* db1, int64_t rows, int64_t in1, int64_t hid, int64_t out2, hipStream_t st,
                             const SmallMlpAdam* adam);
+int gemm_small_mlp_fits(int64_t rows, int64_t in1, int64_t hid, int64_t out2, int with_adam);
 int gemm_small_mlp_backward_adam(const float* X1, const float* H, const float* W2, const float* dO, float* dW2, float* db2, float* dW1,
                                  float* db1, int64_t rows, int64_t in1, int64_t hid, int64_t out2, void* opt, float* const* pmv,
                                  double lr, double b1, double b2, double eps, double wd, int step, int decay_mode, float grad_scale,
@@ -284,6 +285,13 @@ extern "C" int nnhipLinearReLULinearBackward(const float* X1, const float* H, co
     if (rc < 0) return rc;
     NNHIP_CHECK_ARG(rc == 1, NNHIP_EINVAL, "nnhipLinearReLULinearBackward: outside the small-problem range (rows <= 256, out2 <= 16)");
     return 0;
+}
+
+// 1 when nnhipLinearReLULinearBackward (with_adam 0) / ...BackwardAdam (with_adam 1) will take these sizes on the current device,
+// 0 when they would return NNHIP_EINVAL: lets a caller that defers the launch decide before it gives up the per-layer path.
+extern "C" int nnhipLinearReLULinearBackwardFits(int64_t rows, int64_t in1, int64_t hidden, int64_t out2, int32_t with_adam) {
+    if (rows <= 0 || in1 <= 0 || hidden <= 0 || out2 <= 0) return 0;
+    return gemm_small_mlp_fits(rows, in1, hidden, out2, with_adam != 0);
 }
 
 // The same backward with the optimizer inside ("optimizer in backward"): every gradient element is handed to Adam / AdamW

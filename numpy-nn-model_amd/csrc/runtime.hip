@@ -113,7 +113,7 @@ unsigned* sync_words() {
 
 }  // namespace nnhip
 
-extern "C" int nnhipVersion(void) { return 208; }
+extern "C" int nnhipVersion(void) { return 209; }
 
 extern "C" int nnhipWorkspaceReserve(int64_t bytes) {
     if (bytes < 0) { nnhip::set_last_error("nnhipWorkspaceReserve: negative size"); return NNHIP_EINVAL; }

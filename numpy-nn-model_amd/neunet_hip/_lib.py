@@ -63,6 +63,7 @@ _SIGNATURES = {
     "nnhipLinearReLULinearBackwardAdam": (ctypes.c_int, [P, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_void_p,
                                                           ctypes.POINTER(c_void_p), ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                                           ctypes.c_double, ctypes.c_double, ctypes.c_int32, ctypes.c_int32, c_float, c_void_p]),
+    "nnhipLinearReLULinearBackwardFits": (ctypes.c_int, [c_int64, c_int64, c_int64, c_int64, ctypes.c_int32]),
     "nnhipLinearModuleBackwardAct": (ctypes.c_int, [P, P, P, P, c_int32, c_float, P, P, P, c_int64, c_int64, c_int64, c_void_p]),
     "nnhipLinearActivationForward": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_int32, c_float, c_void_p]),
     "nnhipLinearModuleForwardEx": (ctypes.c_int, [P, P, P, P, P, c_int64, c_int64, c_int64, c_void_p]),
@@ -151,7 +152,7 @@ _SIGNATURES = {
     "nnhipAllReduceAvgF32": (ctypes.c_int, [c_void_p, P, c_int64, c_void_p]),
     "nnhipBroadcastF32": (ctypes.c_int, [c_void_p, P, c_int64, ctypes.c_int, c_void_p]),
 }
-_NO_STATUS = {"nnhipVersion", "nnhipGetLastErrorString", "nnhipCreateFusedOptimizer", "nnhipGetGemmMode", "nnhipGetGemmLockstep", "nnhipConv2dWeightGradPooledOk", "nnhipConv2dLeakyMaxPoolForwardOk", "nnhipGemmLaunchCount",
+_NO_STATUS = {"nnhipVersion", "nnhipLinearReLULinearBackwardFits", "nnhipGetLastErrorString", "nnhipCreateFusedOptimizer", "nnhipGetGemmMode", "nnhipGetGemmLockstep", "nnhipConv2dWeightGradPooledOk", "nnhipConv2dLeakyMaxPoolForwardOk", "nnhipGemmLaunchCount",
               "nnhipWeightGradPending"}
 
 _dll = None

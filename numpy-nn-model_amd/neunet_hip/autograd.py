@@ -141,6 +141,27 @@ class Tensor:
         self.device = device
         self.grad_fn: Callable = lambda *a, **k: None
 
+    # ---- gradient slot ------------------------------------------------------------------------------------------------
+    # `grad` is a plain slot except while a backward kernel that produces it is still PENDING (experimental/linear.py:
+    # _PendingMLPBackward -- the README MLP's one-launch backward waits for optimizer.step() so that the same launch can
+    # apply Adam; whoever reads a gradient first makes the launch happen, so a reader never sees anything but the
+    # finished gradient the reference's eager backward would have left, autograd.py:85-93).
+    _pending = None
+
+    @property
+    def grad(self):
+        pend = self._pending
+        if pend is not None:
+            pend.materialize()
+        return self._grad
+
+    @grad.setter
+    def grad(self, value):
+        pend = self._pending
+        if pend is not None:
+            pend.detach(self)       # the caller's value replaces what that backward pass would have left here
+        self._grad = value
+
     # ---- wrapping an already-allocated device buffer without a copy (outputs of kernels) --------
     @classmethod
     def _wrap(cls, array, args, op, device, requires_grad=True):

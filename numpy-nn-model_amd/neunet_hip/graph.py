@@ -205,6 +205,8 @@ class GraphedTrainStep:
                     if k:
                         self.opt.zero_grad()          # host bookkeeping only: the next step's kernels overwrite the gradients
                     self.loss = self.fb(k) if self.unroll > 1 else self.fb()
+                    if self.single and hasattr(self.opt, "take_pending_backward"):
+                        self.opt.take_pending_backward()      # a backward launch that waited for the optimizer: both, now
                     self.bucket.collect()
                     if self.single:
                         self._bind_grads()
@@ -306,6 +308,8 @@ class GraphedTrainStep:
     def _eager(self):
         self.opt.zero_grad()
         loss = self.fb(0) if self.unroll > 1 else self.fb()
+        if self.single and hasattr(self.opt, "take_pending_backward"):
+            self.opt.take_pending_backward()
         self.bucket.all_reduce(self.group)
         if self.pre_optim is not None:
             self.pre_optim()

@@ -14,7 +14,7 @@ import numpy as np
 from ...autograd import Tensor, bump_param_epoch, param_epoch
 from ..modules import Module
 from ..parameter import Parameter
-from ..._lib import NeunetHipError, wgrad_flush
+from ..._lib import NeunetHipError, load_hip_function, wgrad_flush
 from .utils import call_hip_function, get_current_stream_ptr
 
 
@@ -92,9 +92,22 @@ def _mlp_chain_backward(relu_t, w2, b2, grad, rows, hid, out2):
     f_x = relu_t.args[1]
     gw2, gb2 = _grad_out(w2, w2.data), _grad_out(b2, b2.data)
     gw1, gb1 = _grad_out(w1, w1.data), _grad_out(b1, b1.data)
+    params, grads = (w2, b2, w1, b1), (gw2, gb2, gw1, gb1)
+    clean = all(p_.grad is None for p_ in params)
     # optimizer.fuse_backward(): the same launch also applies Adam to the four parameters (when they are ALL the optimizer has)
     fo = getattr(w2, "_fused_opt", None)
-    upd = fo[0].backward_update_args([w2, b2, w1, b1]) if fo is not None and all(p_.grad is None for p_ in (w1, b1, w2, b2)) else None
+    upd = fo[0].backward_update_args(list(params)) if fo is not None and clean else None
+    fits = _mlp_fits(rows, in1, hid, out2)
+    if not fits[0]:
+        return False
+    if upd is None and clean and _AUTO_FUSE_STEP and fits[1] and _auto_fusable(params):
+        # The default path (no opt-in): the launch WAITS.  optimizer.step() on exactly these parameters runs it with Adam in its
+        # epilogue (one launch instead of two, the same arithmetic); anything that looks at one of the four gradients first
+        # -- the user, clipping, a bucket -- runs the plain backward at that moment and step() launches Adam as usual.
+        _PendingMLPBackward(x1.data, f_x, w2.data, grad, params, grads, rows, in1, hid, out2, fits[1])
+        relu_t._bwd_done = True
+        lin1._bwd_done = True
+        return True
     try:
         if upd is not None:
             opt_ptr, table, lr, be1, be2, eps, wd, step, mode, gscale = upd
@@ -111,11 +124,123 @@ def _mlp_chain_backward(relu_t, w2, b2, grad, rows, hid, out2):
                               get_current_stream_ptr())
     except NeunetHipError:                                     # outside the kernel's range: the general path computes the same
         return False
-    for p_, g_ in ((w2, gw2), (b2, gb2), (w1, gw1), (b1, gb1)):
+    for p_, g_ in zip(params, grads):
         _finish_param(p_, g_)
     relu_t._bwd_done = True
     lin1._bwd_done = True
     return True
+
+
+_AUTO_FUSE_STEP = os.environ.get("NNHIP_AUTO_FUSE_STEP", "1") != "0"
+_mlp_fits_cache: dict = {}
+
+
+def _mlp_fits(rows, in1, hid, out2):
+    """(plain launch fits, backward + Adam launch fits) on the current device -- nnhipLinearReLULinearBackwardFits, cached."""
+    import torch
+    key = (rows, in1, hid, out2, torch.cuda.current_device())
+    hit = _mlp_fits_cache.get(key)
+    if hit is None:
+        f = load_hip_function("nnhipLinearReLULinearBackwardFits")
+        hit = _mlp_fits_cache[key] = (bool(f(rows, in1, hid, out2, 0)), bool(f(rows, in1, hid, out2, 1)))
+    return hit
+
+
+def _auto_fusable(params):
+    """True when one multi-tensor Adam/AdamW owns exactly these parameters and could take the update into the backward launch
+    (optim.py: HIPFusedMultiTensorAdamW.pending_update_args decides again at step() time)."""
+    ref = getattr(params[0], "_opt_ref", None)
+    opt = ref() if ref is not None else None
+    if opt is None or len(opt.params) != len(params):
+        return False
+    if not all(getattr(p_, "_opt_ref", None) is ref for p_ in params) or not opt.can_fuse_into_backward():
+        return False
+    return True
+
+
+class _PendingMLPBackward:
+    """The README MLP's one-launch backward (nnhipLinearReLULinearBackward), not launched yet.  Attached to the four
+    parameters as `_pending` (autograd.Tensor.grad): reading any of their gradients launches the plain backward; the owning
+    optimizer's step() launches backward + Adam in one kernel instead (nnhipLinearReLULinearBackwardAdam).  Either way every
+    observable value is the one the eager sequence backward(); step() leaves -- only the launch count differs.
+
+    The operands are the forward pass's buffers, held by reference; torch's version counters catch an in-place write to one of
+    them between backward() and the launch (a refilled input batch): that raises instead of computing from the wrong data."""
+    __slots__ = ("ops", "versions", "params", "grads", "dims", "live", "adam_fits")
+
+    def __init__(self, x, f_x, w2, grad, params, grads, rows, in1, hid, out2, adam_fits):
+        self.adam_fits = adam_fits
+        self.ops = (x, f_x, w2, grad)
+        self.versions = tuple(getattr(t, "_version", 0) for t in self.ops)
+        self.params, self.grads = params, grads
+        self.dims = (rows, in1, hid, out2)
+        self.live = [True, True, True, True]
+        for p_ in params:
+            p_._pending = self
+
+    def detach(self, param):
+        """`param.grad = value` while pending: the assignment wins over the gradient this pass would have left."""
+        for k, p_ in enumerate(self.params):
+            if p_ is param:
+                self.live[k] = False
+        param._pending = None
+        if not any(self.live):
+            self.ops = None             # nobody is left to see these gradients (backward(); zero_grad()): nothing to launch
+
+    def _release(self):
+        for p_ in self.params:
+            if p_._pending is self:
+                p_._pending = None
+
+    def _check_operands(self):
+        if self.ops is None:
+            return False
+        if tuple(getattr(t, "_version", 0) for t in self.ops) != self.versions:
+            self._release()
+            raise RuntimeError("a buffer of the forward pass (the input batch, the hidden activation, W2 or the loss gradient) was "
+                               "written in place between loss.backward() and the first use of the parameter gradients; the deferred "
+                               "backward launch would read the new contents.  Read a gradient (or call optimizer.step()) before "
+                               "refilling the buffer, or set NNHIP_AUTO_FUSE_STEP=0 for an eager backward launch")
+        return True
+
+    def materialize(self):
+        """Somebody reads a gradient: the plain backward, now."""
+        if not self._check_operands():
+            self._release()
+            return
+        x, f_x, w2, grad = self.ops
+        rows, in1, hid, out2 = self.dims
+        gw2, gb2, gw1, gb1 = self.grads
+        self._release()                  # before the launch: an error below must not leave the parameters pointing here
+        call_hip_function("nnhipLinearReLULinearBackward", x, f_x, w2, grad, gw2, gb2, gw1, gb1, rows, in1, hid, out2,
+                          get_current_stream_ptr())
+        live, self.live = self.live, [False] * 4
+        for p_, g_, on in zip(self.params, self.grads, live):
+            if on:
+                _finish_param(p_, g_)
+        self.ops = None
+
+    def run_with_update(self, opt, step):
+        """optimizer.step(): backward + Adam in one launch when `opt` can (all four gradients still wanted, nothing between the
+        gradients and the update); returns True when the update has been applied."""
+        if not self.adam_fits or not all(self.live) or not self._check_operands():
+            return False
+        upd = opt.pending_update_args(list(self.params), step)
+        if upd is None:
+            return False
+        x, f_x, w2, grad = self.ops
+        rows, in1, hid, out2 = self.dims
+        gw2, gb2, gw1, gb1 = self.grads
+        opt_ptr, table, lr, be1, be2, eps, wd, step, mode, gscale = upd
+        self._release()
+        call_hip_function("nnhipLinearReLULinearBackwardAdam", x, f_x, w2, grad, gw2, gb2, gw1, gb1, rows, in1, hid, out2, opt_ptr,
+                          ctypes.cast(table, ctypes.POINTER(ctypes.c_void_p)), lr, be1, be2, eps, wd, step, mode, gscale,
+                          get_current_stream_ptr())
+        self.live = [False] * 4
+        for p_, g_ in zip(self.params, self.grads):
+            _finish_param(p_, g_)
+        self.ops = None
+        return True
 
 
 def _commit_fold(X, dz):

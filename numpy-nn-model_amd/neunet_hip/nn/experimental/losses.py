@@ -110,6 +110,8 @@ class _HIPCrossEntropyTensor(Tensor):
             if getattr(out_ref(), "_seeded_with_ones", False):
                 y_pred.apply_grad(grad_y_pred)
                 return
+            if getattr(grad, "ndim", 0) == 1 and grad.shape[0] != 1:
+                grad = grad[:, None]            # cross_entropy.py:112-113: a 1-D upstream gradient is one value per ROW
             y_pred.apply_grad(times_upstream(grad_y_pred, grad))
 
         self.grad_fn = grad_fn

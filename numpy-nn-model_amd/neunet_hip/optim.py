@@ -3,6 +3,7 @@ and CUDAFusedMultiTensorAdamW (.../fused_adamw_multitensor.py:47-148), plus `Ada
 select the L2-on-gradient (neunet/optim.py:17-33) or decoupled (optim.py:52-69) decay mode of the same
 fused kernel."""
 import ctypes
+import weakref
 from ctypes import c_int64, c_void_p
 
 from ._lib import call_hip_function, get_current_stream_ptr, load_hip_function
@@ -82,6 +83,12 @@ class HIPFusedMultiTensorAdamW:
         self.c_sizes = (c_int64 * n)()
         self._in_backward = False     # fuse_backward(): the layers' backward kernels apply the update themselves when they can
         self._stepped_in_backward = False
+        # the parameters know their optimizer (weakly): a backward kernel that produces ALL of its gradients may wait for
+        # step() and take the update into its own launch (experimental/linear.py: _PendingMLPBackward) -- the default path
+        self._ref = weakref.ref(self)
+        self._index = {id(p): i for i, p in enumerate(self.params)}
+        for p in self.params:
+            p._opt_ref = self._ref
 
     def fuse_backward(self, enable: bool = True):
         """"Optimizer in backward" (extension; single process only): a backward kernel that produces ALL of this optimizer's
@@ -96,26 +103,55 @@ class HIPFusedMultiTensorAdamW:
             elif hasattr(p, "_fused_opt"):
                 del p._fused_opt
 
-    def backward_update_args(self, params):
-        """For a fused backward kernel: (optimizer handle, pointer table {p, m, v} x params, hyper-parameters, step) if `params`
-        are exactly this optimizer's parameters and nothing stands in the way; else None."""
-        if not self._in_backward or self._stepped_in_backward or self.grad_divisor is not None:
-            return None
+    def can_fuse_into_backward(self):
+        """Nothing stands between this optimizer's gradients and its update: no gradient divisor (clipping), no live
+        collectives (data parallel: the gradients have to meet the other ranks' first)."""
+        if self.grad_divisor is not None:
+            return False
         from .distributed import collectives_live
-        if collectives_live():                 # data parallel: the gradients have to meet the other ranks' first
-            return None
-        if len(params) != len(self.params) or any(getattr(p, "_fused_opt", (None,))[0] is not self for p in params):
+        return not collectives_live()
+
+    def _update_table(self, params, step):
+        """(optimizer handle, pointer table {p, m, v} x params, hyper-parameters, step) for a backward kernel that applies the
+        update itself; None when `params` are not exactly this optimizer's parameters or one of them is not contiguous."""
+        if len(params) != len(self.params) or len({id(p) for p in params}) != len(params):
             return None
         table = (c_void_p * (3 * len(params)))()
         for k, p in enumerate(params):
-            i = p._fused_opt[1]
-            if not p.data.is_contiguous():
+            i = self._index.get(id(p))
+            if i is None or self.params[i] is not p or not p.data.is_contiguous():
                 return None
             table[3 * k], table[3 * k + 1], table[3 * k + 2] = p.data.data_ptr(), self.m[i].data_ptr(), self.v[i].data_ptr()
         if self.device_step:
             self.sync_device_hyper()
         return (self.opt_ptr, table, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
-                0 if self.device_step else self.t + 1, self.decay_mode, self.grad_scale)
+                0 if self.device_step else step, self.decay_mode, self.grad_scale)
+
+    def backward_update_args(self, params):
+        """fuse_backward(True): for a backward kernel launched INSIDE backward() (step() has not been called yet: step t + 1)."""
+        if not self._in_backward or self._stepped_in_backward or not self.can_fuse_into_backward():
+            return None
+        if any(getattr(p, "_fused_opt", (None,))[0] is not self for p in params):
+            return None
+        return self._update_table(params, self.t + 1)
+
+    def pending_update_args(self, params, step):
+        """For a backward launch that waited for the optimizer (the default path); `step` = the step number being applied."""
+        if not self.can_fuse_into_backward():
+            return None
+        return self._update_table(params, step)
+
+    def take_pending_backward(self):
+        """A backward launch that is still waiting for this optimizer (experimental/linear.py: _PendingMLPBackward): launch it
+        NOW with the update inside and let the coming step() only count.  For callers that look at the gradients between
+        backward() and step() without changing them (GraphedTrainStep binds them to its bucket) -- without this their first
+        look would run the plain backward and step() its own launch.  Returns True when the update has been applied."""
+        pend = self.params[0]._pending if self.params else None
+        if pend is None or self._stepped_in_backward or not pend.run_with_update(self, self.t + 1):
+            return False
+        self._stepped_in_backward = True
+        bump_param_epoch()
+        return True
 
     def __del__(self):
         ptr = getattr(self, "opt_ptr", None)
@@ -132,6 +168,9 @@ class HIPFusedMultiTensorAdamW:
         if self._stepped_in_backward:          # a fused backward kernel already applied this step's update (fuse_backward)
             self._stepped_in_backward = False
             return
+        pend = self.params[0]._pending if self.params else None
+        if pend is not None and pend.run_with_update(self, self.t):
+            return                             # the waiting backward launch took the update with it (one kernel, same values)
         idx = 0
         keep = []        # contiguous copies of strided gradients must outlive the single launch below: a freed block
         #                  could be handed to the next .contiguous() and two table entries would alias one buffer

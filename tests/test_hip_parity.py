@@ -520,12 +520,16 @@ def test_mlp_chain_backward_one_launch(hip, rows, inf, hid, outf):
 
 @pytest.mark.parametrize("graphed", [False, True])
 @pytest.mark.parametrize("opt_name", ["Adam", "AdamW"])
-def test_mlp_optimizer_in_backward_is_bit_identical(hip, graphed, opt_name):
-    """optimizer.fuse_backward(): the README quick-start MLP's one-launch backward also applies Adam / AdamW to the four
-    parameters (W1 / b1 by the thread that produced the gradient element; W2 / b2 -- inputs of the same launch -- by the last
-    block to finish, from agent-scope published gradients).  Same arithmetic on the same gradients: parameters, m, v and the
-    gradients after 5 steps (an LR change in between) are BIT-IDENTICAL to the separate optimizer launch, eager and replayed."""
+def test_mlp_optimizer_in_backward_is_bit_identical(hip, graphed, opt_name, monkeypatch):
+    """The README quick-start MLP's one-launch backward also applies Adam / AdamW to the four parameters (W1 / b1 by the thread
+    that produced the gradient element; W2 / b2 -- inputs of the same launch -- by the last block to finish, from agent-scope
+    published gradients).  Three ways to get there -- the DEFAULT path (the backward launch waits for optimizer.step(), round 5),
+    optimizer.fuse_backward(True) (launched inside backward()), and the default path with somebody reading a gradient in between
+    (plain backward at that moment + separate Adam launch) -- against backward and Adam as two launches (NNHIP_AUTO_FUSE_STEP=0).
+    Same arithmetic on the same gradients: parameters, m, v and the gradients after 5 steps (an LR change in between) are
+    BIT-IDENTICAL, eager and replayed."""
     import neunet_hip.nn as nn
+    import neunet_hip.nn.experimental.linear as L
     from neunet_hip import optim
     from neunet_hip.distributed import GradBucket
     from neunet_hip.graph import GraphedTrainStep
@@ -533,8 +537,9 @@ def test_mlp_optimizer_in_backward_is_bit_identical(hip, graphed, opt_name):
     Xs = rng.uniform(-1, 1, (6, 32, 784)).astype(np.float32)
     Ys = rng.integers(0, 10, (6, 32)).astype(np.int32)
 
-    def run(fuse):
+    def run(mode):
         np.random.seed(11)
+        monkeypatch.setattr(L, "_AUTO_FUSE_STEP", mode != "two-launches")
 
         class MLP(nn.Module):
             def __init__(self):
@@ -547,15 +552,19 @@ def test_mlp_optimizer_in_backward_is_bit_identical(hip, graphed, opt_name):
         model = MLP()
         ps = model.parameters()
         opt = getattr(optim, opt_name)(ps, lr=1e-3, weight_decay=1e-2)
-        if fuse:
+        if mode == "opt-in":
             opt.fuse_backward(True)
         x = T(hip, Xs[0], requires_grad=False)
         y = T(hip, Ys[0], dtype=np.int32, requires_grad=False)
         loss_fn = nn.CrossEntropyLoss()
+        seen = []
 
         def fb():
             loss = loss_fn(model(x), y)
             loss.backward()
+            seen.append((ps[0]._pending is not None, bool(opt._stepped_in_backward)))
+            if mode == "peek":
+                assert ps[2].grad is not None and ps[0]._pending is None    # the read ran the plain backward
             return loss
 
         step = None
@@ -577,14 +586,96 @@ def test_mlp_optimizer_in_backward_is_bit_identical(hip, graphed, opt_name):
               [host(p.grad).copy() for p in ps]
         if graphed:
             step.release()
+        # what happened after each backward(): (launch still waiting, update already applied)
+        want = {"auto": (True, False), "peek": (True, False), "opt-in": (False, True), "two-launches": (False, False)}[mode]
+        assert all(s_ == want for s_ in seen), (mode, seen)
         return out, losses, opt.t
 
-    a, la, ta = run(True)
-    b, lb, tb = run(False)
-    assert ta == tb
-    assert la == lb
-    for u, v in zip(a, b):
-        np.testing.assert_array_equal(u, v)
+    b, lb, tb = run("two-launches")
+    for mode in ("auto", "opt-in", "peek"):
+        a, la, ta = run(mode)
+        assert ta == tb and la == lb, mode
+        for u, v in zip(a, b):
+            np.testing.assert_array_equal(u, v)
+
+
+def test_mlp_backward_waiting_for_the_optimizer_is_unobservable(hip):
+    """Round 5: the README MLP's backward launch waits for optimizer.step() (so that ONE kernel does backward + Adam without any
+    opt-in).  Everything a user can do between backward() and step() must see what the reference's eager backward leaves
+    (autograd.py:85-93, optim.py:17-33): reading p.grad gives the finished gradient; zero_grad() drops it; assigning p.grad wins
+    over it; a second backward() accumulates; gradient clipping through grad_divisor keeps the two-launch path; an in-place
+    refill of the input batch before anybody asked for the gradients raises instead of differentiating the wrong batch."""
+    import neunet_hip.nn as nn
+    from neunet_hip.optim import Adam
+    rng = np.random.default_rng(23)
+    X = rng.uniform(-1, 1, (32, 784)).astype(np.float32)
+    X2 = rng.uniform(-1, 1, (32, 784)).astype(np.float32)
+    Y = rng.integers(0, 10, 32).astype(np.int32)
+
+    def build():
+        np.random.seed(5)
+
+        class MLP(nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.l1, self.relu, self.l2 = nn.Linear(784, 128), nn.ReLU(), nn.Linear(128, 10)
+
+            def forward(self, x):
+                return self.l2(self.relu(self.l1(x)))
+
+        m = MLP()
+        return m, m.parameters(), Adam(m.parameters(), lr=1e-2)
+
+    def backward(m, x):
+        loss = nn.CrossEntropyLoss()(m(x), T(hip, Y, dtype=np.int32, requires_grad=False))
+        loss.backward()
+        return loss
+
+    # 1. a read sees the finished gradient, and it equals the eager path's (NNHIP_AUTO_FUSE_STEP=0 equivalent: read right away)
+    m, ps, opt = build()
+    backward(m, T(hip, X, requires_grad=False))
+    assert all(p._pending is not None for p in ps)
+    g_first = [host(p.grad).copy() for p in ps]
+    assert all(p._pending is None for p in ps)
+    m2, ps2, opt2 = build()
+    backward(m2, T(hip, X, requires_grad=False))
+    opt2.step()                                              # the fused launch; gradients are still written
+    for a, b in zip(g_first, ps2):
+        np.testing.assert_array_equal(a, host(b.grad))
+    # 2. zero_grad() after backward(): nothing is launched, nothing is left, the next step is a first step
+    m3, ps3, opt3 = build()
+    backward(m3, T(hip, X2, requires_grad=False))
+    opt3.zero_grad()
+    assert all(p._pending is None and p.grad is None for p in ps3)
+    backward(m3, T(hip, X, requires_grad=False))
+    opt3.step()
+    opt.step()                                               # (model 1: separate launch on the gradients read above)
+    for a, b, c in zip(ps, ps2, ps3):
+        np.testing.assert_array_equal(host(a.data), host(b.data))
+        np.testing.assert_array_equal(host(a.data), host(c.data))
+    # 3. an assignment wins; the other three gradients are still produced
+    m4, ps4, opt4 = build()
+    backward(m4, T(hip, X, requires_grad=False))
+    mine = dev(np.full(host(ps4[1].data).shape, 0.5, np.float32))
+    ps4[1].grad = mine
+    assert ps4[1]._pending is None and ps4[0]._pending is not None
+    assert ps4[1].grad is mine
+    for k in (0, 2, 3):
+        np.testing.assert_array_equal(host(ps4[k].grad), g_first[k])
+    # 4. two backward() calls accumulate (the second finds a waiting launch: it runs, then the sum)
+    m5, ps5, opt5 = build()
+    backward(m5, T(hip, X, requires_grad=False))
+    backward(m5, T(hip, X, requires_grad=False))
+    for k in range(4):
+        np.testing.assert_allclose(host(ps5[k].grad), 2 * g_first[k], rtol=1e-6, atol=1e-7)
+    # 5. a refilled input batch before anybody asked for the gradients: loud, not wrong
+    m6, ps6, opt6 = build()
+    x6 = T(hip, X, requires_grad=False)
+    backward(m6, x6)
+    x6.data.copy_(dev(X2))
+    with pytest.raises(RuntimeError, match="written in place"):
+        opt6.step()
+    assert all(p._pending is None for p in ps6)
 
 
 def test_fused_backward_adam_makes_pending_outputs_stale(hip):
