@@ -6,51 +6,50 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
-python tools/kbench.py > $O/kbench.log 2>&1
-python tools/stream_roof.py > $O/stream_roof.txt 2>&1
-python tools/kbench.py --only gemm --gemm-mode 1 > $O/kbench_bf16x3.log 2>&1
-python tools/gemm_accuracy.py > $O/gemm_accuracy.txt 2>&1
+timeout 600 python tools/kbench.py > $O/kbench.log 2>&1
+timeout 600 python tools/stream_roof.py > $O/stream_roof.txt 2>&1
+timeout 600 python tools/kbench.py --only gemm --gemm-mode 1 > $O/kbench_bf16x3.log 2>&1
+timeout 600 python tools/gemm_accuracy.py > $O/gemm_accuracy.txt 2>&1
 [ -x tools/probes/mfma_valu_probe ] && tools/probes/mfma_valu_probe > $O/mfma_valu_probe.txt 2>&1
-python bench.py --steps 20 --warmup 5 > $O/bench_headline.json 2> $O/bench_headline.err
-python bench.py --workload c2 --steps 20 --warmup 5 > $O/bench_c2.json 2> $O/bench_c2.err
-python bench.py --workload c3 --steps 20 --warmup 5 > $O/bench_c3.json 2> $O/bench_c3.err
-python bench.py --workload c1 --steps 500 --warmup 50 > $O/bench_c1.json 2> $O/bench_c1.err
-python bench.py --workload c4 --steps 10 --warmup 3 > $O/bench_c4.json 2> $O/bench_c4.err
-python bench.py --workload c5 --steps 200 --warmup 20 > $O/bench_c5.json 2> $O/bench_c5.err
-python bench.py --workload nb --no-cpu-baseline > $O/bench_nb.json 2> $O/bench_nb.err
+timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench_headline.json 2> $O/bench_headline.err
+timeout 600 python bench.py --workload c2 --steps 20 --warmup 5 > $O/bench_c2.json 2> $O/bench_c2.err
+timeout 600 python bench.py --workload c3 --steps 20 --warmup 5 > $O/bench_c3.json 2> $O/bench_c3.err
+timeout 600 python bench.py --workload c1 --steps 500 --warmup 50 > $O/bench_c1.json 2> $O/bench_c1.err
+timeout 600 python bench.py --workload c4 --steps 10 --warmup 3 > $O/bench_c4.json 2> $O/bench_c4.err
+timeout 600 python bench.py --workload c5 --steps 200 --warmup 20 > $O/bench_c5.json 2> $O/bench_c5.err
+timeout 600 python bench.py --workload nb --no-cpu-baseline > $O/bench_nb.json 2> $O/bench_nb.err
 # the data-parallel step on the production backend with ONE rank: nccl (= RCCL) group, collectives forced
-python bench.py --workload c4 --force-dp --no-cpu-baseline > $O/bench_c4_forced_nccl.json 2> $O/bench_c4_forced_nccl.err
-python bench.py --workload c4 --force-dp --dp-ingraph 1 --no-cpu-baseline > $O/bench_c4_forced_nccl_ingraph.json 2> $O/bench_c4_forced_nccl_ingraph.err
+timeout 600 python bench.py --workload c4 --force-dp --no-cpu-baseline > $O/bench_c4_forced_nccl.json 2> $O/bench_c4_forced_nccl.err
+timeout 600 python bench.py --workload c4 --force-dp --dp-ingraph 1 --no-cpu-baseline > $O/bench_c4_forced_nccl_ingraph.json 2> $O/bench_c4_forced_nccl_ingraph.err
 cd /tmp && export TMPDIR=/tmp
 for W in headline c1 c2 c3 c4 c5; do
   S=30; [ $W = c4 ] && S=8; [ $W = headline ] && S=8; [ $W = c1 ] && S=200; [ $W = c5 ] && S=100
-  rocprofv3 --kernel-trace --stats -f csv -d $O/prof_$W -o $W -- python $R/bench.py --workload $W --steps $S --warmup 5 --no-cpu-baseline > $O/prof_$W.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $O/prof_$W -o $W -- python $R/bench.py --workload $W --steps $S --warmup 5 --no-cpu-baseline > $O/prof_$W.log 2>&1
 done
 for W in c2 c3; do
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $O/pmc_fetch_$W -o f -- python $R/bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_fetch_$W.log 2>&1
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $O/pmc_write_$W -o w -- python $R/bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_write_$W.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $O/pmc_fetch_$W -o f -- python $R/bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_fetch_$W.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $O/pmc_write_$W -o w -- python $R/bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_write_$W.log 2>&1
 done
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -f csv -d $O/pmc_sq_c2 -o sq -- python $R/bench.py --workload c2 --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_sq_c2.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -f csv -d $O/pmc_sq_c2 -o sq -- python $R/bench.py --workload c2 --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_sq_c2.log 2>&1
 # RCCL's kernels next to ours: kernel trace of the forced one-rank nccl step (--dp-op avg: a 1-rank in-place SUM is elided inside RCCL)
-rocprofv3 --kernel-trace --stats -f csv -d $O/prof_dp -o dp -- python $R/bench.py --workload c4 --force-dp --dp-op avg --steps 5 --warmup 2 --no-cpu-baseline > $O/prof_dp.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $O/prof_dp -o dp -- python $R/bench.py --workload c4 --force-dp --dp-op avg --steps 5 --warmup 2 --no-cpu-baseline > $O/prof_dp.log 2>&1
 # the same DP step with the exchange through the library's own RCCL entry points (nnhipAllReduce*F32, NativeComm), and the
 # lock-step GEMM default of N > 1 jobs on / off (step time; fabric bytes of the step's GEMMs in two FETCH_SIZE passes)
-python $R/bench.py --workload c4 --force-dp --comm native --dp-op avg --no-cpu-baseline > $O/bench_c4_native_comm.json 2> $O/bench_c4_native_comm.err
+timeout 600 python $R/bench.py --workload c4 --force-dp --comm native --dp-op avg --no-cpu-baseline > $O/bench_c4_native_comm.json 2> $O/bench_c4_native_comm.err
 for LS in 0 1; do
-  NNHIP_GEMM_LOCKSTEP=$LS python $R/bench.py --workload c4 --force-dp --dp-op avg --no-cpu-baseline > $O/bench_c4_forced_lockstep$LS.json 2> $O/bench_c4_forced_lockstep$LS.err
-  NNHIP_GEMM_LOCKSTEP=$LS rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $O/pmc_fetch_c4_ls$LS -o f -- python $R/bench.py --workload c4 --force-dp --dp-op avg --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_fetch_c4_ls$LS.log 2>&1
+  NNHIP_GEMM_LOCKSTEP=$LS timeout 600 python $R/bench.py --workload c4 --force-dp --dp-op avg --no-cpu-baseline > $O/bench_c4_forced_lockstep$LS.json 2> $O/bench_c4_forced_lockstep$LS.err
+  NNHIP_GEMM_LOCKSTEP=$LS timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $O/pmc_fetch_c4_ls$LS -o f -- python $R/bench.py --workload c4 --force-dp --dp-op avg --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_fetch_c4_ls$LS.log 2>&1
 done
 # MFMA-bound conv layers (conv_mfma.hip): kernel stats + SQ counters of one 64->128 ch 56x56 B64 layer
-rocprofv3 --kernel-trace --stats -f csv -d $O/prof_conv -o conv -- python $R/tools/conv_prof.py 64 64 56 128 20 > $O/prof_conv.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA -f csv -d $O/pmc_conv -o c -- python $R/tools/conv_prof.py 64 64 56 128 5 > $O/pmc_conv.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $O/prof_conv -o conv -- python $R/tools/conv_prof.py 64 64 56 128 20 > $O/prof_conv.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA -f csv -d $O/pmc_conv -o c -- python $R/tools/conv_prof.py 64 64 56 128 5 > $O/pmc_conv.log 2>&1
 cd $R
-bash tools/attn_pmc.sh > $O/attn_pmc.log 2>&1
-mkdir -p $O/attn_pmc && cp gpurun_out/attn_pmc/*.csv $O/attn_pmc/ 2>/dev/null
-bash tools/gemm_pmc.sh ${TAG}_bf3 1 8192 4096 4096 > $O/gemm_pmc_bf3.txt 2>&1
-bash tools/gemm_pmc.sh ${TAG}_f32 0 8192 4096 4096 > $O/gemm_pmc_f32.txt 2>&1
+timeout 1500 bash tools/attn_sb_pmc.sh $TAG > $O/attn_pmc.log 2>&1      # -> $O/attn_pmc_summary.md (balanced T=256 kernels of attention_sb.hip)
+timeout 900 bash tools/gemm_pmc.sh ${TAG}_bf3 1 8192 4096 4096 > $O/gemm_pmc_bf3.txt 2>&1
+timeout 900 bash tools/gemm_pmc.sh ${TAG}_f32 0 8192 4096 4096 > $O/gemm_pmc_f32.txt 2>&1
 cd /tmp
 # keep the merge under the 64 MiB limit: drop the raw traces, keep stats + counter CSVs
-python $R/tools/dp_timeline.py $(find $O/prof_dp -name "*_kernel_trace.csv" | head -1) $O/dp_timeline.md "C4 step, 1-rank nccl (RCCL) process group, collectives forced, --dp-op avg: RCCL kernels vs ours (rocprofv3 --kernel-trace)" > /dev/null 2>&1
+timeout 600 python $R/tools/dp_timeline.py $(find $O/prof_dp -name "*_kernel_trace.csv" | head -1) $O/dp_timeline.md "C4 step, 1-rank nccl (RCCL) process group, collectives forced, --dp-op avg: RCCL kernels vs ours (rocprofv3 --kernel-trace)" > /dev/null 2>&1
 find $O -name "*_kernel_trace.csv" -size +2M -delete
 find $O -name "*counter_collection.csv" -size +8M -delete
 find $O -name "*.db" -delete

@@ -67,3 +67,5 @@ for f in gemm_pmc_bf3.txt gemm_pmc_f32.txt; do [ -f $G/$f ] && cp $G/$f $P/${TAG
 cp $G/kbench.log $P/${TAG}_kbench.txt
 cp $G/stream_roof.txt $P/${TAG}_stream_roof.txt
 for f in kbench_bf16x3.log gemm_accuracy.txt mfma_valu_probe.txt; do [ -f $G/$f ] && grep -v amdgpu.ids $G/$f > $P/${TAG}_${f%.*}.txt; done
+# round 5: the balanced T = 256 attention kernels (attention_sb.hip): per-launch counter means (tools/attn_sb_pmc.sh)
+[ -f $G/attn_pmc_summary.md ] && cp $G/attn_pmc_summary.md $P/${TAG}_attention_pmc.md
