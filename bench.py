@@ -1425,6 +1425,19 @@ def workload_headline(args, rank, world):
                       "launches_per_step": r5["extra"].get("launches_per_step"),
                       "conv_layers": r5["extra"].get("conv_layers"),
                       "frac_of_hbm_peak_on_conv_bytes": r5["roofline"]["frac"]}
+        # the opt-in one-launch tail (NNHIP_BN_HEAD_FUSION=1; round 5): fewer launches, measured beside the default
+        import neunet_hip.nn.experimental.vision as _vis
+        was = _vis._FUSE_TAIL
+        _vis._FUSE_TAIL = True
+        try:
+            a5t = copy.copy(a5)
+            r5t = workload_c5(a5t, rank, world)
+            also["c5"]["tail_one_launch_opt_in"] = {"samples_per_s": round(r5t["samples_per_step"] * a5.steps / r5t["dt"], 1),
+                                                    "ms_per_step": round(r5t["dt"] / a5.steps * 1e3, 5),
+                                                    "launches_per_step": r5t["extra"].get("launches_per_step"),
+                                                    "what": "NNHIP_BN_HEAD_FUSION=1: conv2's launch leaves partial batch statistics; BatchNorm2d + Linear + Sigmoid + MSELoss as one kernel"}
+        finally:
+            _vis._FUSE_TAIL = was
     if os.environ.get("NNHIP_BENCH_C5", "1") != "0":
         guarded("c5", run_c5)
 

@@ -496,6 +496,24 @@ int nnhipBatchNorm2dForward(const float* X, const float* weight, const float* bi
 int nnhipBatchNorm2dBackward(const float* dY, const float* X, const float* weight, const float* save_mean,
                              const float* save_inv, float* dX, float* dW, float* db, int64_t B, int64_t C,
                              int64_t HW, nnhipStream_t stream);
+/* The tail of the reference's conv classifier (examples/convolutional_digits_classifier.ipynb cell 2) as ONE launch, without any block
+ * waiting for another.  Producer side: nnhipConv2dLeakyMaxPoolForwardStats = nnhipConv2dLeakyMaxPoolForward that also leaves, per block
+ * of 64 pooling windows and per output channel, (mean, M2 = sum of squared deviations) of the pooled values in stats
+ * [blocks][Cout][2]; nnhipConv2dLeakyMaxPoolStatsBlocks = that block count (0: no statistics variant for the geometry).
+ * Consumer side: nnhipBatchNorm2dLinearSigmoidMSE = BatchNorm2d(training) on X [B,C,HW] (statistics combined from the pairs, Chan
+ * et al., in a fixed order) -> reshape [B, C*HW] -> Linear(W [N, C*HW], b [N] or NULL) -> Sigmoid -> MSELoss against target [B,N].
+ * Y / save_mean / save_inv / running statistics as nnhipBatchNorm2dForward (equal to rounding: combined instead of two-pass
+ * statistics), pred [B,N] = the Sigmoid output, dz [B,N] = d(loss)/d(Linear output), loss[0] = mean squared error.
+ * C <= 16, N <= 16, C*HW % 4 == 0 and <= 2048, B <= 4096 (...Fits answers 1 / 0); nstat * count == B * HW.  ABI 209 */
+int nnhipConv2dLeakyMaxPoolStatsBlocks(const nnhipConv2dDesc* conv, const nnhipPool2dDesc* pool);
+int nnhipConv2dLeakyMaxPoolForwardStats(const float* X, const float* W, const float* bias, float alpha, float* P, int32_t* argmax,
+                                        const nnhipConv2dDesc* conv, const nnhipPool2dDesc* pool, float* stats, nnhipStream_t stream);
+int nnhipBatchNorm2dLinearSigmoidMSEFits(int64_t B, int64_t C, int64_t HW, int64_t N);
+int nnhipBatchNorm2dLinearSigmoidMSE(const float* X, const float* stats, int64_t nstat, int64_t count, const float* bn_weight,
+                                     const float* bn_bias, float* Y, float* save_mean, float* save_inv, float* running_mean,
+                                     float* running_var, int64_t B, int64_t C, int64_t HW, float eps, float momentum, const float* W,
+                                     const float* b, int64_t N, const float* target, float* pred, float* dz, float* loss,
+                                     nnhipStream_t stream);
 /* MSELoss (neunet/nn/losses.py:9-22): loss[0] = sum((pred-target)^2)/n ; dpred = 2 (pred-target)/n (may be NULL). */
 int nnhipMSELossForwardBackward(const float* pred, const float* target, float* loss, float* dpred, int64_t n,
                                 nnhipStream_t stream);

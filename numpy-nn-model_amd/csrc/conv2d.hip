@@ -710,12 +710,17 @@ __global__ __launch_bounds__(256) void conv_direct_dgrad_quad2_kernel(const floa
 // from LDS serves four positions (a position-per-quad variant read it per position: 72 ds_read_b128 per
 // position made it LDS-bandwidth-bound, 10 us against 8.9) -- then 4 x CO quad sums, and lane s finishes output channels
 // s CO/4 ...: bias, activation, first maximum over the four positions, pooled value + arg-max.  Unit stride and dilation.
-template <int CO>
+// STATS (the launch has whole blocks only: B Hq Wq a multiple of 64): the block also leaves (mean, M2 = sum of squared deviations)
+// of its 64 pooled values per output channel in stats[block][Cout][2] -- the partial batch statistics a BatchNorm2d behind this
+// layer needs; the consumer combines the blocks' pairs (Chan et al.), so nothing waits for anything here.
+template <int CO, bool STATS = false>
 __global__ __launch_bounds__(256) void conv_pool_fwd_quad_kernel(const float* __restrict__ Wt, const float* __restrict__ X,
                                                                  const float* __restrict__ bias, float* __restrict__ P,
-                                                                 int32_t* __restrict__ arg, const ConvGeom g, float alpha) {
+                                                                 int32_t* __restrict__ arg, const ConvGeom g, float alpha,
+                                                                 float* __restrict__ stats = nullptr) {
     constexpr int CSTR = 9 * CO + (CO == 16 ? 8 : 0), CPL = CD_MAXC / 4;
     __shared__ __attribute__((aligned(16))) float Wl[CD_MAXC * CSTR];
+    __shared__ float sred[STATS ? 4 * CO : 1];
     const int K = g.Cin * 9;
     stage_to_lds(Wl, Wt, g.Cin * CSTR, threadIdx.x, [&](int i) -> int64_t {
         const int ci = i / CSTR, r = i - ci * CSTR, t = r / CO, co = r - t * CO;
@@ -775,6 +780,7 @@ __global__ __launch_bounds__(256) void conv_pool_fwd_quad_kernel(const float* __
     for (int k = 0; k < 4; ++k)
 #pragma unroll
         for (int c = 0; c < CO; ++c) acc[k][c] = quad_sum(acc[k][c]);
+    float pooled[CO / 4];
 #pragma unroll
     for (int c = 0; c < CO / 4; ++c) {                      // lane s finishes outputs s CO/4 ...
         const int co = s * (CO / 4) + c;
@@ -789,10 +795,43 @@ __global__ __launch_bounds__(256) void conv_pool_fwd_quad_kernel(const float* __
             if (alpha != 1.0f) v = v <= 0.f ? alpha * v : v;
             if (v > best) { best = v; bi = k; }
         }
+        pooled[c] = best;
         if (co < g.Cout) {
             const int64_t o = ((int64_t)b * g.Cout + co) * HWq + pq;
             P[o] = best;
             arg[o] = bi;
+        }
+    }
+    if constexpr (STATS) {
+        // channel s CO/4 + c lives on the 16 lanes of a wave with this s (lane bits 2..5 = the window): xor tree over those
+        // bits, the four waves meet in LDS.  Two rounds: the block's mean, then the squared deviations from it.
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        float mean_b[CO / 4];
+#pragma unroll
+        for (int round = 0; round < 2; ++round) {
+            float t[CO / 4];
+#pragma unroll
+            for (int c = 0; c < CO / 4; ++c) {
+                const float d = pooled[c] - (round ? mean_b[c] : 0.f);
+                t[c] = round ? d * d : d;
+#pragma unroll
+                for (int m = 4; m < 64; m <<= 1) t[c] += __shfl_xor(t[c], m, 64);
+            }
+            if (round) __syncthreads();                      // sred is read below by everybody: the next round overwrites it
+            if ((lane >> 2) == 0)
+#pragma unroll
+                for (int c = 0; c < CO / 4; ++c) sred[wave * CO + s * (CO / 4) + c] = t[c];
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < CO / 4; ++c) {
+                const int co = s * (CO / 4) + c;
+                const float tot = (sred[co] + sred[CO + co]) + (sred[2 * CO + co] + sred[3 * CO + co]);
+                if (round == 0) mean_b[c] = tot * (1.0f / 64.0f);
+                else if (threadIdx.x < 4 && co < g.Cout) {
+                    stats[((int64_t)blockIdx.x * g.Cout + co) * 2] = mean_b[c];
+                    stats[((int64_t)blockIdx.x * g.Cout + co) * 2 + 1] = tot;
+                }
+            }
         }
     }
 }
@@ -1225,8 +1264,32 @@ extern "C" int nnhipConv2dLeakyMaxPoolForwardOk(const nnhipConv2dDesc* d, const 
     if (!d || !pd || make_geom(d, g) || g.B == 0) return 0;
     return conv_pool_fwd_ok(g, pd) ? 1 : 0;
 }
+// Number of 64-window blocks whose per-channel (mean, M2) pairs nnhipConv2dLeakyMaxPoolForwardStats leaves in `stats`
+// [blocks][Cout][2]; 0: this geometry has no statistics variant (not the four-lanes-per-window kernel, or a ragged last block).
+extern "C" int nnhipConv2dLeakyMaxPoolStatsBlocks(const nnhipConv2dDesc* d, const nnhipPool2dDesc* pd) {
+    ConvGeom g;
+    if (!d || !pd || make_geom(d, g) || g.B == 0) return 0;
+    if (!conv_pool_fwd_ok(g, pd) || conv_pool_window_ok(g)) return 0;
+    const int64_t N = (int64_t)g.B * (g.Ho / 2) * (g.Wo / 2);
+    return (N % 64 == 0 && N / 64 <= 65535) ? (int)(N / 64) : 0;
+}
+static int conv_pool_forward(const float* X, const float* W, const float* bias, float alpha, float* P, int32_t* argmax,
+                             const nnhipConv2dDesc* d, const nnhipPool2dDesc* pd, float* stats, nnhipStream_t s);
 extern "C" int nnhipConv2dLeakyMaxPoolForward(const float* X, const float* W, const float* bias, float alpha, float* P, int32_t* argmax,
                                               const nnhipConv2dDesc* d, const nnhipPool2dDesc* pd, nnhipStream_t s) {
+    return conv_pool_forward(X, W, bias, alpha, P, argmax, d, pd, nullptr, s);
+}
+// The same launch, which also leaves the partial batch statistics of the pooled output (see ...StatsBlocks): what a BatchNorm2d
+// behind this layer needs, produced where the values are still in registers.  ABI 209
+extern "C" int nnhipConv2dLeakyMaxPoolForwardStats(const float* X, const float* W, const float* bias, float alpha, float* P,
+                                                   int32_t* argmax, const nnhipConv2dDesc* d, const nnhipPool2dDesc* pd, float* stats,
+                                                   nnhipStream_t s) {
+    NNHIP_CHECK_ARG(stats != nullptr && nnhipConv2dLeakyMaxPoolStatsBlocks(d, pd) > 0, NNHIP_EINVAL,
+                    "nnhipConv2dLeakyMaxPoolForwardStats: no statistics variant for this geometry (ask nnhipConv2dLeakyMaxPoolStatsBlocks)");
+    return conv_pool_forward(X, W, bias, alpha, P, argmax, d, pd, stats, s);
+}
+static int conv_pool_forward(const float* X, const float* W, const float* bias, float alpha, float* P, int32_t* argmax,
+                             const nnhipConv2dDesc* d, const nnhipPool2dDesc* pd, float* stats, nnhipStream_t s) {
     ConvGeom g;
     if (int rc = make_geom(d, g)) return rc;
     if (g.B == 0) return 0;
@@ -1236,8 +1299,11 @@ extern "C" int nnhipConv2dLeakyMaxPoolForward(const float* X, const float* W, co
                     "nnhipConv2dLeakyMaxPoolForward: unsupported geometry (ask nnhipConv2dLeakyMaxPoolForwardOk first)");
     if (!conv_pool_window_ok(g)) {                           // four lanes per window, each all four positions
         const dim3 wgrid((unsigned)ceil_div(4 * (int64_t)g.B * (g.Ho / 2) * (g.Wo / 2), 256));
-        if (g.Cout <= 8) hipLaunchKernelGGL(conv_pool_fwd_quad_kernel<8>, wgrid, dim3(256), 0, (hipStream_t)s, W, X, bias, P, argmax, g, alpha);
-        else hipLaunchKernelGGL(conv_pool_fwd_quad_kernel<16>, wgrid, dim3(256), 0, (hipStream_t)s, W, X, bias, P, argmax, g, alpha);
+        if (stats) {
+            if (g.Cout <= 8) hipLaunchKernelGGL((conv_pool_fwd_quad_kernel<8, true>), wgrid, dim3(256), 0, (hipStream_t)s, W, X, bias, P, argmax, g, alpha, stats);
+            else hipLaunchKernelGGL((conv_pool_fwd_quad_kernel<16, true>), wgrid, dim3(256), 0, (hipStream_t)s, W, X, bias, P, argmax, g, alpha, stats);
+        } else if (g.Cout <= 8) hipLaunchKernelGGL((conv_pool_fwd_quad_kernel<8, false>), wgrid, dim3(256), 0, (hipStream_t)s, W, X, bias, P, argmax, g, alpha, nullptr);
+        else hipLaunchKernelGGL((conv_pool_fwd_quad_kernel<16, false>), wgrid, dim3(256), 0, (hipStream_t)s, W, X, bias, P, argmax, g, alpha, nullptr);
         NNHIP_LAUNCH_CHECK("conv_pool_fwd_quad_kernel");
         return 0;
     }

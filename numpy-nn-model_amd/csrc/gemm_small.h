@@ -68,9 +68,15 @@ struct SgNoPost {
     __device__ __forceinline__ void operator()(int64_t, float) const {}
     __device__ __forceinline__ void asum(int64_t, float) const {}
 };
-template <int NW, bool AKM, bool BKM, bool VEC, int U, class POST = SgNoPost>
+// ATR: called as atr(a, row, k0, ok) on every A operand quad (k0 .. k0 + 3 of row `row`; ok: the quad lies inside the operand) after
+// the loads of a batch have been issued and before its MFMAs -- how a caller transforms A on its way into the matrix pipe (rowops.hip:
+// BatchNorm applied to the classifier head's input).  Every A element passes exactly once per (bx, by) tile.  k-major A only.
+struct SgNoATransform {
+    __device__ __forceinline__ void operator()(float4&, int64_t, unsigned, bool) const {}
+};
+template <int NW, bool AKM, bool BKM, bool VEC, int U, class POST = SgNoPost, class ATR = SgNoATransform>
 __device__ __forceinline__ void sg_tile16(const SmallGemmParams& p, int bx, int by, float (*red)[16 * 16], float (*ared)[16],
-                                          float* lds_copy = nullptr, POST post = POST()) {   // lds_copy: also keep C[row][col] at lds_copy[row * 32 + col]
+                                          float* lds_copy = nullptr, POST post = POST(), ATR atr = ATR()) {   // lds_copy: also keep C[row][col] at lds_copy[row * 32 + col]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l16 = lane & 15, kq = lane >> 4;
     const int64_t m0 = (int64_t)by * 16, n0 = (int64_t)bx * 16;
@@ -101,6 +107,13 @@ __device__ __forceinline__ void sg_tile16(const SmallGemmParams& p, int bx, int 
             b[u] = sg_fetch<BKM, VEC>(rsb, lb4, b_row, b_ok, k0, K);
         }
         __builtin_amdgcn_sched_barrier(0);                 // all 2U loads in flight before the first MFMA (see sg_tile)
+        if constexpr (!__is_same(ATR, SgNoATransform)) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const unsigned k0 = 16u * (gb + (unsigned)u * NW) + 4u * kq;
+                atr(a[u], m0 + l16, k0, a_ok && k0 < K);
+            }
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, b[u].x, acc, 0, 0, 0);

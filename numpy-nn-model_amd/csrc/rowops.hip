@@ -1094,6 +1094,136 @@ __global__ __launch_bounds__(NW * 64) void linear_ce_small_kernel(const SmallGem
     ce_epilogue<BS>(a, t, denom, red, ired);
 }
 
+// ---- BatchNorm2d (training) -> flatten -> Linear(C*HW -> N <= 16) -> Sigmoid -> MSELoss: the head kernel -------------------
+// The tail of the reference's conv classifier (examples/convolutional_digits_classifier.ipynb cell 2).  No block waits for another
+// (round 5, first attempt: one block per channel + a ticket hand-off of the logits' shares -- 22 us, EXPERIMENTS.md): the layer in
+// front (nnhipConv2dLeakyMaxPoolForwardStats) has left per-block (mean, M2) pairs of its pooled output; EVERY block of this kernel
+// combines them to the batch statistics (Chan et al., fixed order: the same bits in every block) while its GEMM operands are on
+// their way, normalises the A operand between load and MFMA (sg_tile16's ATR hook) -- writing the BatchNorm output as it passes --
+// and finishes 16 rows of prediction, d(loss)/dz and squared error; only the scalar loss meets through ce_epilogue's ticket.
+struct BnHeadArgs {
+    const float* stats;        // [nstat][C][2]: (mean, M2) of `count` values each
+    const float* bn_w; const float* bn_b;
+    float* Y; float* save_mean; float* save_inv; float* run_mean; float* run_var;
+    const float* target; float* dz;
+    int nstat, C, HW;
+    float count, eps, momentum, invN, inv_hw;
+};
+struct BnApplyA {
+    const float4* tab;         // LDS: per channel {mean, inv, weight, bias}
+    float* Y;
+    int HW, C;
+    int64_t ld;
+    float inv_hw;
+    __device__ __forceinline__ float one(float x, int c) const {
+        const float4 t = tab[c < C ? c : C - 1];
+        return t.z * ((x - t.x) * t.y) + t.w;
+    }
+    __device__ __forceinline__ void operator()(float4& a, int64_t row, unsigned k0, bool ok) const {
+        unsigned c0 = (unsigned)((float)k0 * inv_hw);
+        if (c0 * (unsigned)HW > k0) --c0;
+        if ((c0 + 1) * (unsigned)HW <= k0) ++c0;
+        unsigned r = k0 - c0 * (unsigned)HW;
+        float v[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i) {
+                ++r;
+#pragma unroll
+                for (int q = 0; q < 1; ++q)
+                    if (r >= (unsigned)HW) { r -= (unsigned)HW; ++c0; }
+            }
+            v[i] = one(v[i], (int)c0);
+        }
+        a = make_float4(v[0], v[1], v[2], v[3]);
+        if (ok) *reinterpret_cast<float4*>(Y + row * ld + k0) = a;
+    }
+};
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void bn_linear_sigmoid_mse_kernel(const SmallGemmParams p, const BnHeadArgs h, const CeArgs a) {
+    constexpr int BS = NW * 64, TPC = BS / 16;              // threads per channel in the statistics phase (C <= 16)
+    __shared__ float gred[NW][16 * 16];
+    __shared__ float ared[NW][16];
+    __shared__ float tile[16 * 32];
+    __shared__ __attribute__((aligned(16))) float4 tab[16];
+    __shared__ int ired[17];
+    __shared__ float red[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int by = (int)blockIdx.x;
+    const int64_t r0 = (int64_t)by * 16;
+    // the target of the element this thread finishes: requested first
+    const int erow = tid >> 4, ecol = tid & 15;
+    const bool emine = tid < 256 && r0 + erow < p.M && ecol < p.N;
+    const float tv = emine ? h.target[(r0 + erow) * p.N + ecol] : 0.f;
+    // ---- batch statistics from the producer's per-block pairs ----
+    {
+        const int c = tid / TPC, j = tid % TPC;
+        const bool cok = c < h.C;
+        float n = 0.f, m = 0.f, M2 = 0.f;
+        auto merge = [&](float nb, float mb, float Mb) {
+            if (nb == 0.f) return;
+            if (n == 0.f) { n = nb; m = mb; M2 = Mb; return; }
+            const float nt = n + nb, d = mb - m;
+            m += d * (nb / nt);
+            M2 += Mb + d * d * (n * nb / nt);
+            n = nt;
+        };
+        for (int base = 0; base < h.nstat; base += 8 * TPC) {
+            float mb[8], Mb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int q = base + u * TPC + j;
+                const float2 v = *reinterpret_cast<const float2*>(h.stats + ((int64_t)(q < h.nstat ? q : 0) * h.C + (cok ? c : 0)) * 2);
+                mb[u] = v.x; Mb[u] = v.y;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (base + u * TPC + j < h.nstat) merge(h.count, mb[u], Mb[u]);
+        }
+#pragma unroll
+        for (int off = TPC / 2; off >= 1; off >>= 1) {
+            const float nb = __shfl_xor(n, off, 64), mb2 = __shfl_xor(m, off, 64), Mb2 = __shfl_xor(M2, off, 64);
+            if ((j & off) == 0) merge(nb, mb2, Mb2);         // the lower lane of a pair keeps the merged triple (fixed order)
+        }
+        if (cok && j == 0) {
+            const float var = M2 / n;
+            const float inv = 1.0f / sqrtf(var + h.eps);
+            tab[c] = make_float4(m, inv, h.bn_w ? h.bn_w[c] : 1.f, h.bn_w ? h.bn_b[c] : 0.f);
+            if (by == 0) {
+                h.save_mean[c] = m;
+                h.save_inv[c] = inv;
+                if (h.run_mean) {
+                    h.run_mean[c] = h.momentum * h.run_mean[c] + (1.0f - h.momentum) * m;
+                    h.run_var[c] = h.momentum * h.run_var[c] + (1.0f - h.momentum) * var;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    BnApplyA atr{tab, h.Y, h.HW, h.C, p.lda, h.inv_hw};
+    for (int bx = 0; (int64_t)bx * 16 < p.N; ++bx) {
+        if (bx == 0) sg_tile16<NW, true, true, true, 8, SgNoPost, BnApplyA>(p, bx, by, gred, ared, tile - r0 * 32, SgNoPost(), atr);
+        else sg_tile16<NW, true, true, true, 8>(p, bx, by, gred, ared, tile - r0 * 32);      // (N <= 16: never taken)
+        __syncthreads();
+    }
+    float lsum = 0.f;
+    if (emine) {
+        const float pr = tile[erow * 32 + ecol];
+        const float d = pr - tv;
+        h.dz[(r0 + erow) * p.N + ecol] = (2.0f * d * h.invN) * pr * (1.0f - pr);
+        lsum = d * d;
+    }
+    lsum = wave_sum(lsum);
+    __syncthreads();
+    if (lane == 0) red[wave] = lsum;
+    __syncthreads();
+    float t = 0.f;
+    if (tid == 0)
+        for (int i = 0; i < NW; ++i) t += red[i];
+    __syncthreads();
+    ce_epilogue<BS>(a, t, (float)((double)p.M * (double)p.N), red, ired);
+}
+
 // =================================================================================================
 // Column sums:  out[c] = sum_r X[r*ld + c]     (Linear db: neunet/nn/layers/linear.py:24)
 // Block = 4 waves; lane <-> one float4 column group (256 columns per block) or one column (scalar path,
@@ -1610,6 +1740,50 @@ extern "C" int nnhipLinearCrossEntropyLoss(const float* X, const float* W, const
         else hipLaunchKernelGGL((linear_ce_small_kernel<false, 4>), dim3(nblk), dim3(256), 0, st, p, a);
     }
     NNHIP_LAUNCH_CHECK("linear_ce_small_kernel");
+    return 0;
+}
+
+// BatchNorm2d(training) -> reshape(B, C*HW) -> Linear(W [N, C*HW], b) -> Sigmoid -> MSELoss(target [B, N]) as ONE launch
+// (bn_linear_sigmoid_mse_kernel).  X [B,C,HW] is the pooled output of nnhipConv2dLeakyMaxPoolForwardStats and `stats` its
+// [nstat][C][2] (mean, M2) pairs over `count` values each (nstat * count == B * HW).  Y = the BatchNorm output, save_mean / save_inv /
+// running statistics as nnhipBatchNorm2dForward (the statistics are combined from the pairs instead of summed in two passes: equal
+// to rounding); pred = the Sigmoid output; dz = d(loss)/d(Linear output); loss[0] = mean squared error.
+extern "C" int nnhipBatchNorm2dLinearSigmoidMSEFits(int64_t B, int64_t C, int64_t HW, int64_t N) {
+    return B >= 1 && B <= 4096 && C >= 1 && C <= 16 && HW >= 1 && N >= 1 && N <= 16 && ((C * HW) & 3) == 0 && C * HW <= 2048 ? 1 : 0;
+}
+extern "C" int nnhipBatchNorm2dLinearSigmoidMSE(const float* X, const float* stats, int64_t nstat, int64_t count, const float* bn_weight,
+                                                const float* bn_bias, float* Y, float* save_mean, float* save_inv, float* running_mean,
+                                                float* running_var, int64_t B, int64_t C, int64_t HW, float eps, float momentum,
+                                                const float* W, const float* b, int64_t N, const float* target, float* pred, float* dz,
+                                                float* loss, nnhipStream_t s) {
+    NNHIP_CHECK_ARG(nnhipBatchNorm2dLinearSigmoidMSEFits(B, C, HW, N), NNHIP_EINVAL,
+                    "nnhipBatchNorm2dLinearSigmoidMSE: needs C <= 16, N <= 16, C*HW a multiple of 4 and <= 2048, B <= 4096");
+    NNHIP_CHECK_ARG(X && stats && Y && save_mean && save_inv && W && target && pred && dz && loss, NNHIP_EINVAL,
+                    "nnhipBatchNorm2dLinearSigmoidMSE: null pointer");
+    NNHIP_CHECK_ARG(nstat >= 1 && count >= 1 && nstat * count == B * HW, NNHIP_EINVAL,
+                    "nnhipBatchNorm2dLinearSigmoidMSE: the statistics pairs must cover B*HW values per channel");
+    NNHIP_CHECK_ARG((bn_weight == nullptr) == (bn_bias == nullptr) && (running_mean == nullptr) == (running_var == nullptr), NNHIP_EINVAL,
+                    "nnhipBatchNorm2dLinearSigmoidMSE: weight / bias and running_mean / running_var go in pairs");
+    NNHIP_CHECK_ARG(aligned16(X) && aligned16(W) && aligned16(Y) && (reinterpret_cast<uintptr_t>(stats) & 7u) == 0, NNHIP_EALIGN,
+                    "nnhipBatchNorm2dLinearSigmoidMSE: X, W, Y must be 16-byte aligned");
+    const int64_t K = C * HW;
+    SmallGemmParams p{};
+    p.A = X; p.B = W; p.C = pred; p.bias = b; p.M = B; p.N = N; p.K = K; p.lda = K; p.ldb = K; p.ldc = N;
+    p.alpha = 1.f; p.beta = 1.f; p.a_kmajor = 1; p.b_kmajor = 1; p.act = SG_ACT_SIGMOID;
+    BnHeadArgs h{};
+    h.stats = stats; h.bn_w = bn_weight; h.bn_b = bn_bias; h.Y = Y; h.save_mean = save_mean; h.save_inv = save_inv;
+    h.run_mean = running_mean; h.run_var = running_var; h.target = target; h.dz = dz; h.nstat = (int)nstat; h.C = (int)C; h.HW = (int)HW;
+    h.count = (float)count; h.eps = eps; h.momentum = momentum; h.invN = 1.0f / (float)(B * N); h.inv_hw = 1.0f / (float)HW;
+    CeArgs a{};
+    a.mode = 1; a.loss_out = loss; a.rows = B; a.cols = N;
+    const unsigned nblk = (unsigned)ceil_div(B, 16);
+    unsigned* sync = sync_words();
+    a.partial = static_cast<float*>(workspace((size_t)nblk * sizeof(float)));
+    if (!sync || !a.partial) { set_last_error("nnhipBatchNorm2dLinearSigmoidMSE: workspace allocation failed"); return NNHIP_ENOMEM; }
+    if (int rc = serialize_shared_state((hipStream_t)s)) return rc;
+    a.sync = sync + SYNC_CE;
+    hipLaunchKernelGGL((bn_linear_sigmoid_mse_kernel<8>), dim3(nblk), dim3(512), 0, (hipStream_t)s, p, h, a);
+    NNHIP_LAUNCH_CHECK("bn_linear_sigmoid_mse_kernel");
     return 0;
 }
 

@@ -136,8 +136,13 @@ _SIGNATURES = {
     "nnhipConv2dWeightGradPooled": (ctypes.c_int, [P, P, P, P, c_float, P, P, POINTER(Conv2dDesc), POINTER(Pool2dDesc), c_void_p]),
     "nnhipConv2dLeakyMaxPoolForwardOk": (ctypes.c_int, [POINTER(Conv2dDesc), POINTER(Pool2dDesc)]),
     "nnhipConv2dLeakyMaxPoolForward": (ctypes.c_int, [P, P, P, c_float, P, P, POINTER(Conv2dDesc), POINTER(Pool2dDesc), c_void_p]),
+    "nnhipConv2dLeakyMaxPoolStatsBlocks": (ctypes.c_int, [POINTER(Conv2dDesc), POINTER(Pool2dDesc)]),
+    "nnhipConv2dLeakyMaxPoolForwardStats": (ctypes.c_int, [P, P, P, c_float, P, P, POINTER(Conv2dDesc), POINTER(Pool2dDesc), P, c_void_p]),
     "nnhipBatchNorm2dForward": (ctypes.c_int, [P, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_float, c_float, ctypes.c_int, c_void_p]),
     "nnhipBatchNorm2dBackward": (ctypes.c_int, [P, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_void_p]),
+    "nnhipBatchNorm2dLinearSigmoidMSEFits": (ctypes.c_int, [c_int64, c_int64, c_int64, c_int64]),
+    "nnhipBatchNorm2dLinearSigmoidMSE": (ctypes.c_int, [P, P, c_int64, c_int64, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_float,
+                                                         c_float, P, P, c_int64, P, P, P, P, c_void_p]),
     "nnhipMSELossForwardBackward": (ctypes.c_int, [P, P, P, P, c_int64, c_void_p]),
     "nnhipMSELossSigmoidForwardBackward": (ctypes.c_int, [P, P, P, P, c_int64, c_void_p]),
     "nnhipScale": (ctypes.c_int, [P, c_float, c_int64, c_void_p]),
@@ -152,7 +157,7 @@ _SIGNATURES = {
     "nnhipAllReduceAvgF32": (ctypes.c_int, [c_void_p, P, c_int64, c_void_p]),
     "nnhipBroadcastF32": (ctypes.c_int, [c_void_p, P, c_int64, ctypes.c_int, c_void_p]),
 }
-_NO_STATUS = {"nnhipVersion", "nnhipLinearReLULinearBackwardFits", "nnhipGetLastErrorString", "nnhipCreateFusedOptimizer", "nnhipGetGemmMode", "nnhipGetGemmLockstep", "nnhipConv2dWeightGradPooledOk", "nnhipConv2dLeakyMaxPoolForwardOk", "nnhipGemmLaunchCount",
+_NO_STATUS = {"nnhipVersion", "nnhipLinearReLULinearBackwardFits", "nnhipBatchNorm2dLinearSigmoidMSEFits", "nnhipConv2dLeakyMaxPoolStatsBlocks", "nnhipGetLastErrorString", "nnhipCreateFusedOptimizer", "nnhipGetGemmMode", "nnhipGetGemmLockstep", "nnhipConv2dWeightGradPooledOk", "nnhipConv2dLeakyMaxPoolForwardOk", "nnhipGemmLaunchCount",
               "nnhipWeightGradPending"}
 
 _dll = None

@@ -414,14 +414,21 @@ class HIPLinear(Module):
             raise NotImplementedError(f"Only float32 is supported, got {X.dtype} instead.")
         if X.shape[-1] != self.in_features:
             raise ValueError(f"Expected last dim {self.in_features}, got {X.shape[-1]}")
-        xdata = X.data if X.data.is_contiguous() else X.data.contiguous()
         input_rows = int(np.prod(X.shape[:-1]))
         out_shape = tuple(X.shape[:-1]) + (self.out_features,)
+        # an input that is itself still pending AND asks to stay so (vision.py: the flattened BatchNorm2d output in front of the
+        # conv classifier's head) is not read here: the GEMM's thunk reads it, or a consumer further down launches the whole
+        # chain at once (HIPMSELoss: nnhipBatchNorm2dLinearSigmoidMSE)
+        lazy_x = residual is None and _LAZY and getattr(X, "_keeps_pending", False) and X.pending()
+        xdata = None if lazy_x else (X.data if X.data.is_contiguous() else X.data.contiguous())
         if residual is None and _LAZY:
             weight, bias, in_f, out_f, xp = self.weight, self.bias, self.in_features, self.out_features, X.xp
             w_ptr, b_ptr = weight.data, bias.data if bias is not None else None   # the arrays as they are NOW
+            x_src = X
 
-            def launch(activation, beta, preact):
+            def launch(activation, beta, preact, xdata=xdata):
+                if xdata is None:
+                    xdata = x_src.data if x_src.data.is_contiguous() else x_src.data.contiguous()
                 out = xp.empty(out_shape, dtype=np.float32)
                 if activation == 0:
                     hip_linear_module_forward(xdata, w_ptr, b_ptr, out, input_rows, in_f, out_f)
@@ -433,11 +440,14 @@ class HIPLinear(Module):
                                       activation, float(beta), get_current_stream_ptr())
                 return out
 
-            if xdata is not X.data:
+            if not lazy_x and xdata is not X.data:
                 X = _ContiguousView(X, xdata)
             args = (X, self.weight, self.bias, input_rows, self.in_features, self.out_features, None)
             out = _HIPLinearTensor(None, args, "linear", device=self.device, thunk=launch, shape=out_shape)
-            out._operands = (xdata, w_ptr, b_ptr)     # for a consumer that fuses the pending GEMM into its own launch
+            # for a consumer that fuses the pending GEMM into its own launch (None: the input is not there yet)
+            out._operands = None if lazy_x else (xdata, w_ptr, b_ptr)
+            out._lazy_input = X if lazy_x else None
+            out._weights_now = (w_ptr, b_ptr)
             return out
         output = X.xp.empty(out_shape, dtype=np.float32)
         addend = None

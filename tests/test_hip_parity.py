@@ -3381,12 +3381,16 @@ def test_conv_classifier_golden(hip, golden):
     np.testing.assert_allclose(host(model.bnorm.running_mean.data), g["rm"], rtol=1e-3, atol=2e-3)
 
 
-def test_conv_classifier_c5_batch_vs_oracle(hip):
-    """Batch 256 (BASELINE config 5) forward+backward against the oracle."""
+@pytest.mark.parametrize("tail_one_launch", [False, True])
+def test_conv_classifier_c5_batch_vs_oracle(hip, monkeypatch, tail_one_launch):
+    """Batch 256 (BASELINE config 5) forward+backward against the oracle; also with the opt-in one-launch tail
+    (NNHIP_BN_HEAD_FUSION=1: conv2's launch leaves partial batch statistics, BatchNorm + fc1 + Sigmoid + MSE are one kernel)."""
     import sys, os
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
     import conv_classifier
     import neunet_hip.nn as nn
+    import neunet_hip.nn.experimental.vision as V
+    monkeypatch.setattr(V, "_FUSE_TAIL", tail_one_launch)
     rng = np.random.default_rng(1005)
     np.random.seed(1005)                       # the layers draw their initial weights from the global NumPy RNG
     model = conv_classifier.Conv2dClassifier()
@@ -3396,6 +3400,7 @@ def test_conv_classifier_c5_batch_vs_oracle(hip):
     X = rng.uniform(-1, 1, (256, 1, 28, 28)).astype(np.float32)
     Tt = np.eye(10, dtype=np.float32)[rng.integers(0, 10, 256)]
     out = model(T(hip, X))
+    assert getattr(out, "pending", lambda: False)() == tail_one_launch
     loss = nn.MSELoss()(out, T(hip, Tt, requires_grad=False))
     loss.backward()
     rl, ro, rg = ref.forward_backward(X, Tt)
@@ -3410,6 +3415,153 @@ def test_conv_classifier_c5_batch_vs_oracle(hip):
     np.testing.assert_allclose(host(out.data), ro64, rtol=1e-4, atol=1e-5)
     for i, p in enumerate(params):
         assert_close_scaled(host(p.grad), np.asarray(rg64[i]).reshape(tuple(p.shape)), tol=1e-4, err_msg=f"grad {i} vs float64")
+
+
+@pytest.mark.parametrize("B,C,HW,N,affine,nstat", [(256, 16, 49, 10, True, 196), (37, 5, 12, 3, True, 4), (16, 3, 64, 16, False, 1024),
+                                                   (2, 2, 2, 1, True, 1), (300, 16, 4, 7, True, 25)])
+def test_batchnorm_linear_sigmoid_mse_entry(hip, B, C, HW, N, affine, nstat):
+    """nnhipBatchNorm2dLinearSigmoidMSE (round 5): BatchNorm2d(training) -> flatten -> Linear -> Sigmoid -> MSELoss in one launch, the
+    batch statistics combined from (mean, M2) pairs of `nstat` groups of values per channel.  Against the oracle's chain
+    (batchnorm2d.py:84-100, linear.py:48-58, activations.py:19-28, losses.py:9-22) and against the library's own step-by-step entries."""
+    from neunet_hip._lib import call_hip_function, get_current_stream_ptr, load_hip_function
+    rng = np.random.default_rng(90 + B)
+    X = (rng.standard_normal((B, C, HW)) * 1.7 + 0.3 + 3.0 * rng.standard_normal((1, C, 1))).astype(np.float32)
+    Tt = rng.uniform(0, 1, (B, N)).astype(np.float32)
+    W = rng.uniform(-0.2, 0.2, (N, C * HW)).astype(np.float32)
+    bl = rng.uniform(-0.2, 0.2, N).astype(np.float32)
+    g = rng.uniform(0.5, 1.5, C).astype(np.float32) if affine else None
+    be = rng.uniform(-0.5, 0.5, C).astype(np.float32) if affine else None
+    assert load_hip_function("nnhipBatchNorm2dLinearSigmoidMSEFits")(B, C, HW, N) == 1
+    count = B * HW // nstat
+    assert nstat * count == B * HW
+    groups = X.transpose(1, 0, 2).reshape(C, nstat, count).astype(np.float64)     # any partition of a channel's values will do
+    gm = groups.mean(axis=2)
+    stats = np.stack([gm, ((groups - gm[:, :, None]) ** 2).sum(axis=2)], axis=-1).transpose(1, 0, 2).astype(np.float32)   # [nstat][C][2]
+    Xd, Y = dev(X), torch.empty(B, C, HW, device="cuda")
+    sm, si = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    rm, rv = dev(np.full(C, 0.25, np.float32)), dev(np.full(C, 2.0, np.float32))
+    pred, dz, loss = torch.empty(B, N, device="cuda"), torch.empty(B, N, device="cuda"), torch.empty((), device="cuda")
+    for rep in range(2):                                     # twice: the ticket words are left clean
+        call_hip_function("nnhipBatchNorm2dLinearSigmoidMSE", Xd, dev(stats), nstat, count, dev(g) if affine else None,
+                          dev(be) if affine else None, Y, sm, si, rm if rep == 0 else None, rv if rep == 0 else None, B, C, HW, 1e-5, 0.1,
+                          dev(W), dev(bl), N, dev(Tt), pred, dz, loss, get_current_stream_ptr())
+    mean = X.astype(np.float64).mean(axis=(0, 2))
+    var = X.astype(np.float64).var(axis=(0, 2))
+    yo = (X - mean[None, :, None]) / np.sqrt(var[None, :, None] + 1e-5)
+    if affine:
+        yo = yo * g[None, :, None] + be[None, :, None]
+    z = yo.reshape(B, -1) @ W.T.astype(np.float64) + bl
+    po = 1.0 / (1.0 + np.exp(-z))
+    np.testing.assert_allclose(host(sm), mean, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(host(si), 1.0 / np.sqrt(var + 1e-5), rtol=2e-5)
+    np.testing.assert_allclose(host(rm), 0.1 * 0.25 + 0.9 * mean, rtol=1e-5, atol=1e-6)       # momentum * running + (1 - momentum) * stat
+    np.testing.assert_allclose(host(rv), 0.1 * 2.0 + 0.9 * var, rtol=2e-5)
+    np.testing.assert_allclose(host(Y), yo, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(host(pred), po, rtol=1e-4, atol=1e-5)
+    assert abs(loss.item() - float(((po - Tt) ** 2).mean())) < 1e-5
+    np.testing.assert_allclose(host(dz), 2 * (po - Tt) / (B * N) * po * (1 - po), rtol=1e-3, atol=1e-7)
+    # the step-by-step entries on the same buffers
+    Y2, sm2, si2 = torch.empty_like(Y), torch.empty_like(sm), torch.empty_like(si)
+    call_hip_function("nnhipBatchNorm2dForward", Xd, dev(g) if affine else None, dev(be) if affine else None, Y2, sm2, si2, None, None, B, C,
+                      HW, 1e-5, 0.1, 1, get_current_stream_ptr())
+    np.testing.assert_allclose(host(Y), host(Y2), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(host(sm), host(sm2), rtol=1e-5, atol=1e-6)
+
+
+def _conv_tail_model(nn, cin=8, cout=16, feat=7 * 7 * 16, n_out=10):
+    class Tail(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv, self.act, self.pool = nn.Conv2d(cin, cout, 3, 1, 1), nn.LeakyReLU(), nn.MaxPool2d(2, 2)
+            self.bnorm, self.fc, self.sig = nn.BatchNorm2d(cout), nn.Linear(feat, n_out), nn.Sigmoid()
+
+        def forward(self, x):
+            self.y = self.bnorm(self.pool(self.act(self.conv(x))))
+            return self.sig(self.fc(self.y.reshape(x.shape[0], -1)))
+
+    return Tail()
+
+
+def test_conv_classifier_tail_one_launch_vs_step_by_step(hip, monkeypatch):
+    """conv2 -> LeakyReLU -> MaxPool -> BatchNorm2d -> flatten -> fc1 -> Sigmoid -> MSELoss (C5's second half): with the tail fusion the
+    conv + pool launch leaves partial batch statistics and the rest is ONE launch; NNHIP_BN_HEAD_FUSION=0 launches module by module.
+    Prediction, loss, the BatchNorm output / statistics and every gradient agree to rounding; the pending links are really pending."""
+    import neunet_hip.nn as nn
+    import neunet_hip.nn.experimental.vision as V
+    from neunet_hip._lib import load_hip_function
+    rng = np.random.default_rng(77)
+    X = rng.uniform(-1, 1, (64, 8, 14, 14)).astype(np.float32)
+    Tt = np.eye(10, dtype=np.float32)[rng.integers(0, 10, 64)]
+
+    def run(fuse):
+        monkeypatch.setattr(V, "_FUSE_TAIL", fuse)
+        np.random.seed(12)
+        m = _conv_tail_model(nn)
+        m.bnorm.weight.data.copy_(dev(np.linspace(0.5, 1.5, 16, dtype=np.float32).reshape(1, 16)))
+        x = T(hip, X)
+        out = m(x)
+        assert m.y.pending() == fuse and getattr(out, "pending", lambda: False)() == fuse
+        loss = nn.MSELoss()(out, T(hip, Tt, requires_grad=False))
+        assert not m.y.pending() and m.bnorm._pending_out is None
+        loss.backward()
+        res = {"y": host(m.y.data), "pred": host(out.data), "loss": np.float32(loss.item()), "dx": host(x.grad),
+               "rm": host(m.bnorm.running_mean.data), "rv": host(m.bnorm.running_var.data)}
+        for i, p_ in enumerate(m.parameters()):
+            res[f"g{i}"] = host(p_.grad)
+        return res
+
+    a, r = run(True), run(False)
+    for k in a:
+        if k.startswith("g") or k == "dx":
+            assert_close_scaled(a[k], r[k], err_msg=k, tol=2e-4)
+        else:
+            np.testing.assert_allclose(a[k], r[k], rtol=1e-4, atol=2e-5, err_msg=k)
+
+
+def test_pending_batchnorm_is_unobservable(hip, monkeypatch):
+    """A deferred BatchNorm2d launch must not be observable: a forward pass whose result is dropped still updates the running
+    statistics before anyone can read them (batchnorm2d.py:84-100), a reader of the output in the middle of the chain gets the
+    step-by-step launches, eval mode and inputs without producer statistics never defer."""
+    import neunet_hip.nn as nn
+    import neunet_hip.nn.experimental.vision as V
+    monkeypatch.setattr(V, "_FUSE_TAIL", True)               # NNHIP_BN_HEAD_FUSION=1
+    rng = np.random.default_rng(4)
+    X = rng.uniform(-1, 1, (64, 8, 14, 14)).astype(np.float32)
+    np.random.seed(3)
+    m = _conv_tail_model(nn)
+    bn = m.bnorm
+
+    def pooled(x):
+        return m.pool(m.act(m.conv(T(hip, x))))
+
+    P = pooled(X)
+    assert P._chan_stats is not None
+    ref_mean = host(P.data).mean(axis=(0, 2, 3))
+    out = bn(P)
+    assert out.pending()
+    del out                                                  # nobody ever reads it
+    np.testing.assert_allclose(host(bn.running_mean.data).ravel(), 0.9 * ref_mean, rtol=1e-4, atol=1e-6)   # momentum 0.1: 0.1 * 0 + 0.9 * mean
+    assert bn._pending_out is None
+    sd = bn.state_dict()
+    assert set(sd) == {"running_mean", "running_var", "weight", "bias"} and len(bn.parameters()) == 2
+    # two forwards in a row: the first is launched before the second reads the running statistics
+    o1 = bn(pooled(X))
+    o2 = bn(pooled(2 * X))
+    assert not o1.pending() and o2.pending()
+    bn.eval()
+    assert not o2.pending()
+    assert not getattr(bn(pooled(X)), "pending", lambda: False)()
+    bn.train()
+    assert not getattr(bn(T(hip, host(P.data))), "pending", lambda: False)()        # no producer statistics: launched at once
+    # a reader in the middle of the chain
+    y = bn(pooled(X))
+    flat = y.reshape(64, -1)
+    z = m.fc(flat)
+    zz = host(z.data)                                         # reads the Linear output: BatchNorm + GEMM launch now
+    assert not y.pending() and not flat.pending()
+    np.testing.assert_allclose(zz, O.linear_forward(host(y.data).reshape(64, -1), host(m.fc.weight.data), host(m.fc.bias.data)), rtol=1e-4, atol=1e-5)
+    with pytest.raises(ValueError):
+        bn(pooled(X)).reshape(7, 11)
 
 
 # =============================================================================================================
