@@ -1,9 +1,9 @@
 // gemm_bf3.hip -- fp32 GEMM on the bf16 matrix cores: every fp32 operand is split EXACTLY into three bf16 pieces
 // (x = hi + mid + lo, 8 + 8 + 8 significand bits, by truncation: no rounding anywhere in the split) and the product is
 // formed from the six largest of the nine piece products,
-//     a*b ~= hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi          (dropped: mid*lo, lo*mid, lo*lo <= 2^-23 |a b|)
+//     a*b ~= hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi          (dropped: mid*lo, lo*mid, lo*lo: < 2^-21 |a b| worst case, ~2^-23 typical)
 // each an exact bf16 x bf16 product accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  The result carries a relative
-// error of <= ~2^-23 per product -- the same order as fp32 rounding itself (an fp32 MFMA / sgemm dot product of length K
+// error of ~2^-23 per product -- the same order as fp32 rounding itself (an fp32 MFMA / sgemm dot product of length K
 // has a worst-case bound of K 2^-24) -- at 6 bf16 MFMAs per 16 k instead of 8 fp32 MFMAs of 4x the issue time:
 // 6 x 32 = 192 matrix-pipe cycles per 32x32x16 block instead of 8 x 64 = 512, i.e. a ceiling of 2.67x the fp32 MFMA
 // rate (~419 TFLOP/s fp32-equivalent).  gfx950 has no xf32/TF32 (MI355X_MICROARCH.md); this is the MI355X-native way
