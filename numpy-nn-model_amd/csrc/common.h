@@ -43,6 +43,8 @@ bool workspace_locked();               // nnhipWorkspaceLock(1): a captured hipG
 bool wgrad_defer_on();
 int conv_reduce_flush(void* stream);
 void conv_reduce_cleanup();            // frees the partials arena (nnhipCleanup)
+int colsum_flush(void* stream);        // rowops.hip: the queued RMSNorm dw / db column sums of a backward pass, as one launch
+void colsum_cleanup();
 // one deferred parameter-gradient GEMM (gemm.hip: gemm_f32_wgrad_group): C[M,N] = A^T B with A [K, M] and B [K, N] dense
 struct WgradJob {
     const float* A; const float* B; float* C; float* asum;

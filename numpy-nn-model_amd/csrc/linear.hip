@@ -143,6 +143,7 @@ extern "C" int nnhipWeightGradDefer(int32_t enable, nnhipStream_t stream) {
         if (!g_wq.empty()) g_wq_stream = (hipStream_t)stream;
         rc = wq_flush_locked();
         if (int rc2 = nnhip::conv_reduce_flush(stream)) rc = rc ? rc : rc2;
+        if (int rc3 = nnhip::colsum_flush(stream)) rc = rc ? rc : rc3;
     }
     g_wq_on = enable ? 1 : 0;
     return rc;
@@ -152,6 +153,7 @@ extern "C" int nnhipWeightGradFlush(nnhipStream_t stream) {
     if (!g_wq.empty() && g_wq_stream != (hipStream_t)stream) g_wq_stream = (hipStream_t)stream;
     int rc = wq_flush_locked();
     if (int rc2 = nnhip::conv_reduce_flush(stream)) rc = rc ? rc : rc2;
+    if (int rc3 = nnhip::colsum_flush(stream)) rc = rc ? rc : rc3;
     return rc;
 }
 extern "C" int nnhipWeightGradPending(void) {

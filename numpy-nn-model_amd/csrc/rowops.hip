@@ -411,6 +411,95 @@ static int colsum_tall(const float* part_a, float* out_a, const float* part_b, f
     return 0;
 }
 
+// ---- the column sums of several layers as ONE launch (deferred parameter gradients, common.h) ------------------------------------
+// During Tensor.backward() (nnhipWeightGradDefer) the per-block dw / db partials of a RMSNorm backward go to an arena of their own and
+// the finishing column sum is queued; nnhipWeightGradFlush launches the queue as one grid (GPT-tiny: 13 finishes of ~5 us each, every
+// one a launch-latency-bound kernel of 16 blocks, become one launch per flush).  Same arithmetic and order per output column.
+constexpr int CSQ_MAX = 16;
+struct ColsumJob { const float* part; float* out; int64_t prow, cols; };
+struct ColsumGroup { ColsumJob j[CSQ_MAX]; int start[CSQ_MAX + 1]; };
+template <int SW, bool VEC>
+__global__ __launch_bounds__(256) void colsum_group_kernel(const ColsumGroup grp) {
+    __shared__ float4 lds[4 * SW];
+    int k = 0;
+#pragma unroll
+    for (int i = 1; i < CSQ_MAX; ++i) k += (int)blockIdx.x >= grp.start[i] ? 1 : 0;
+    const ColsumJob jb = grp.j[k];
+    colsum_slices<256, SW, VEC>(jb.part, jb.prow, jb.cols, jb.out, (int)blockIdx.x - grp.start[k], grp.start[k + 1] - grp.start[k], lds);
+}
+static std::mutex g_csq_mu;
+static ColsumJob g_csq[CSQ_MAX];
+static int g_csq_n = 0, g_csq_sw = 0;
+static bool g_csq_vec = false;
+static hipStream_t g_csq_st = nullptr;
+static float* g_csq_arena = nullptr;
+static size_t g_csq_cap = 0, g_csq_used = 0;              // floats
+static int csq_flush_locked(hipStream_t st) {
+    if (g_csq_n == 0) return 0;
+    ColsumGroup grp;
+    int blocks = 0;
+    for (int i = 0; i < CSQ_MAX; ++i) {
+        grp.start[i] = blocks;
+        if (i < g_csq_n) { grp.j[i] = g_csq[i]; blocks += fin_slices(g_csq[i].cols, g_csq_vec); }
+        else grp.j[i] = g_csq[0];
+    }
+    grp.start[CSQ_MAX] = blocks;
+    g_csq_n = 0;
+    g_csq_used = 0;
+#define CSG(SW_, V_) hipLaunchKernelGGL((colsum_group_kernel<SW_, V_>), dim3((unsigned)blocks), dim3(256), 0, st, grp)
+    if (g_csq_vec) { if (g_csq_sw == 8) CSG(8, true); else CSG(4, true); }
+    else { if (g_csq_sw == 8) CSG(8, false); else CSG(4, false); }
+#undef CSG
+    NNHIP_LAUNCH_CHECK("colsum_group_kernel");
+    return 0;
+}
+int colsum_flush(void* stream) {
+    std::lock_guard<std::mutex> lk(g_csq_mu);
+    return csq_flush_locked(g_csq_n ? g_csq_st : (hipStream_t)stream);
+}
+void colsum_cleanup() {
+    std::lock_guard<std::mutex> lk(g_csq_mu);
+    g_csq_n = 0;
+    g_csq_used = g_csq_cap = 0;
+    if (g_csq_arena) (void)hipFree(g_csq_arena);
+    g_csq_arena = nullptr;
+}
+// Where a RMSNorm backward writes `floats` of partials whose column sums (`njobs` of them, slice width sw / vec) can wait for the
+// flush: the arena (*deferred), else nullptr (the caller uses the shared workspace and finishes at once).
+static float* colsum_partials(size_t floats, int njobs, int sw, bool vec, hipStream_t st, bool* deferred, int* rc) {
+    static const bool on = []() { const char* e = getenv("NNHIP_COLSUM_DEFER"); return !e || atoi(e) != 0; }();
+    *deferred = false;
+    *rc = 0;
+    if (!on || !wgrad_defer_on()) return nullptr;
+    std::lock_guard<std::mutex> lk(g_csq_mu);
+    if (g_csq_n && (g_csq_st != st || g_csq_n + njobs > CSQ_MAX || g_csq_used + floats > g_csq_cap || g_csq_sw != sw || g_csq_vec != vec))
+        *rc = csq_flush_locked(g_csq_st);
+    if (floats > g_csq_cap && !workspace_locked()) {          // grow (nothing is queued here); never while a captured graph holds the address
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(st, &cs);
+        if (cs == hipStreamCaptureStatusNone) {
+            if (g_csq_arena) (void)hipFree(g_csq_arena);      // (synchronises: earlier sums are done with it)
+            g_csq_arena = nullptr;
+            g_csq_cap = 0;
+            const size_t want = floats * CSQ_MAX;              // room for a whole queue of the same size
+            if (hipMalloc(&g_csq_arena, want * sizeof(float)) == hipSuccess) g_csq_cap = want;
+            else g_csq_arena = nullptr;
+        }
+    }
+    if (g_csq_arena && floats <= g_csq_cap - g_csq_used) {
+        float* p = g_csq_arena + g_csq_used;
+        g_csq_used += (floats + 63) & ~(size_t)63;
+        g_csq_st = st; g_csq_sw = sw; g_csq_vec = vec;
+        *deferred = true;
+        return p;
+    }
+    return nullptr;
+}
+static void colsum_queue(const float* part, float* out, int64_t prow, int64_t cols) {
+    std::lock_guard<std::mutex> lk(g_csq_mu);
+    g_csq[g_csq_n++] = ColsumJob{part, out, prow, cols};
+}
+
 // Backward: block b walks rows b*RPB+rslot + k*gridDim.x*RPB, one row per iteration with the next row's loads already
 // in flight, keeps per-thread column
 // partials of dw = sum dy*x/std and db = sum dy in registers (a thread always owns the same columns),
@@ -1583,13 +1672,23 @@ extern "C" int nnhipRMSNormBackwardEx(const float* dY, const float* X, const flo
         if (slots < 1) slots = 1;
     }
     if (nblk > slots) nblk = slots;
-    const size_t part_floats = ((size_t)nblk * cols + 3) / 4 * 4;
-    float* part = static_cast<float*>(workspace(part_floats * (db ? 2 : 1) * sizeof(float)));
+    const size_t part_floats = ((size_t)nblk * cols + 63) / 64 * 64;
+    // inside Tensor.backward() the finishing column sums wait for the flush (one launch for every RMSNorm of the pass)
+    bool deferred = false;
+    int rcq = 0;
+    float* part = colsum_partials(part_floats * (db ? 2 : 1), db ? 2 : 1, fin_sw(cols, vec), vec, st, &deferred, &rcq);
+    if (rcq) return rcq;
+    if (!part) part = static_cast<float*>(workspace(part_floats * (db ? 2 : 1) * sizeof(float)));
     NNHIP_CHECK_ARG(part != nullptr, NNHIP_ENOMEM, "nnhipRMSNormBackward: workspace allocation failed");
     float* part_dw = part;
     float* part_db = db ? part + part_floats : nullptr;
     ROW_DISPATCH_GRID(rmsnorm_bwd_rows, cols, vec, nblk, st, dY, X, weight, X_std, dX, part_dw, part_db, rows, cols, dX_addend, row_streaming(rows, cols, cols));
     NNHIP_LAUNCH_CHECK("rmsnorm_backward");
+    if (deferred) {
+        colsum_queue(part_dw, dW, nblk, cols);
+        if (db) colsum_queue(part_db, db, nblk, cols);
+        return 0;
+    }
     return colsum_tall(part_dw, dW, part_db, db, nblk, cols, vec, st);
 }
 

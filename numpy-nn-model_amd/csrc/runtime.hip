@@ -131,6 +131,7 @@ extern "C" const char* nnhipGetLastErrorString(void) { return nnhip::g_err; }
 
 extern "C" int nnhipCleanup(void) {
     nnhip::conv_reduce_cleanup();
+    nnhip::colsum_cleanup();
     std::lock_guard<std::mutex> lk(nnhip::g_ws_mu);
     nnhip::g_ws_locked = false;
     if (nnhip::g_ws) {

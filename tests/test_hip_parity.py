@@ -1225,6 +1225,49 @@ def test_softmax_vs_oracle(hip, shape, axis):
     assert_close_scaled(host(x.grad), O.softmax_backward(yr, dY, axis))
 
 
+def test_rmsnorm_backward_deferred_column_sums(hip):
+    """Round 5: while parameter gradients are deferred (nnhipWeightGradDefer, i.e. inside Tensor.backward()) a RMSNorm backward leaves
+    its per-block dw / db partials in an arena and the finishing column sums of ALL queued layers go out as one launch at the flush.
+    dx is there at once; dw / db are untouched until the flush and then BIT-identical to the immediate path."""
+    from neunet_hip._lib import call_hip_function, get_current_stream_ptr, load_hip_function
+    rng = np.random.default_rng(61)
+    st = get_current_stream_ptr()
+    shapes = [(64, 4096, False), (1024, 512, False), (300, 512, True), (2048, 512, False), (777, 512, True)]   # (a change of column width flushes)
+    jobs = []
+    for rows, cols, bias in shapes:
+        X, dY = dev(rng.standard_normal((rows, cols)).astype(np.float32)), dev(rng.standard_normal((rows, cols)).astype(np.float32))
+        w = dev(rng.uniform(0.5, 1.5, cols).astype(np.float32))
+        std = torch.sqrt((X * X).mean(dim=1) + 1e-6).contiguous()
+        jobs.append((rows, cols, bias, X, dY, w, std))
+
+    def run(defer):
+        outs = []
+        if defer:
+            call_hip_function("nnhipWeightGradDefer", 1, st)
+        for rows, cols, bias, X, dY, w, std in jobs:
+            dx = torch.empty_like(X)
+            dw = torch.full((cols,), 123.0, device="cuda")
+            db = torch.full((cols,), 321.0, device="cuda") if bias else None
+            call_hip_function("nnhipRMSNormBackward", dY, X, w, std, None, dx, dw, db, rows, cols, st)
+            outs.append((dx, dw, db))
+        if defer:
+            torch.cuda.synchronize()
+            assert all(float(o[1][0]) == 123.0 for o in outs[1:]), "a deferred column sum ran before the flush"
+            assert load_hip_function("nnhipWeightGradPending")() == 0          # (the GEMM queue's counter: column sums are not in it)
+            call_hip_function("nnhipWeightGradFlush", st)
+            call_hip_function("nnhipWeightGradDefer", 0, st)
+        torch.cuda.synchronize()
+        return outs
+
+    a, b = run(True), run(False)
+    for (dxa, dwa, dba), (dxb, dwb, dbb), (rows, cols, bias, X, dY, w, std) in zip(a, b, jobs):
+        assert torch.equal(dxa, dxb) and torch.equal(dwa, dwb)
+        if bias:
+            assert torch.equal(dba, dbb)
+        xn = host(X) / host(std)[:, None]
+        np.testing.assert_allclose(host(dwa), (host(dY) * xn).sum(0), rtol=2e-4, atol=2e-3)
+
+
 # ---------------------------------------------------------------------------------------- RMSNorm
 @pytest.mark.parametrize("name", ["rmsnorm_2d", "rmsnorm_3d_bias"])
 def test_rmsnorm_golden(hip, golden, name):
