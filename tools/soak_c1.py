@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Developer soak test: the README MLP trained for many graph-replayed steps with the optimizer inside the backward launch
-(arrival counters, polling blocks, stepper block) against the same run with the separate optimizer launch -- parameters and
+(arrival counters, polling blocks, stepper block; both the round-5 default path and the round-3 opt-in) against the same run with
+the separate optimizer launch -- parameters and
 optimizer state must stay BIT-IDENTICAL after every chunk of steps.  usage: python tools/soak_c1.py [steps] [chunk]"""
 import os
 import sys
@@ -26,12 +27,16 @@ class MLP(nn.Module):
         return self.l2(self.relu(self.l1(x)))
 
 
-def build(fuse, X, Y):
+def build(mode, X, Y):
+    """mode: "default" (round 5: the backward launch waits for optimizer.step() and takes Adam with it), "opt-in"
+    (optimizer.fuse_backward(True), round 3) or "two-launches" (NNHIP_AUTO_FUSE_STEP=0: the reference's sequence)."""
+    import neunet_hip.nn.experimental.linear as L
+    L._AUTO_FUSE_STEP = mode != "two-launches"               # read at capture time (GraphedTrainStep captures in here)
     np.random.seed(11)
     model = MLP()
     ps = model.parameters()
     opt = optim.Adam(ps, lr=1e-3)
-    if fuse:
+    if mode == "opt-in":
         opt.fuse_backward(True)
     x = Tensor(X[0], device="cuda", requires_grad=False)
     y = Tensor(Y[0], dtype=np.int32, device="cuda", requires_grad=False)
@@ -52,11 +57,12 @@ def main():
     X = rng.uniform(-1, 1, (64, 32, 784)).astype(np.float32)
     Y = rng.integers(0, 10, (64, 32)).astype(np.int32)
     Xd, Yd = torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda()
-    a = build(True, X, Y)
-    b = build(False, X, Y)
+    b = build("two-launches", X, Y)
+    a = build("default", X, Y)
+    c = build("opt-in", X, Y)
     done = 0
     while done < steps:
-        for (step, ps, opt, x, y) in (a, b):
+        for (step, ps, opt, x, y) in (a, b, c):
             for s in range(chunk):
                 i = (done + s) % 64
                 x.data.copy_(Xd[i])
@@ -64,8 +70,9 @@ def main():
                 step()
         done += chunk
         torch.cuda.synchronize()
-        same = all(torch.equal(p.data, q.data) for p, q in zip(a[1], b[1])) and \
-            all(torch.equal(m1, m2) for m1, m2 in zip(a[2].m, b[2].m)) and all(torch.equal(v1, v2) for v1, v2 in zip(a[2].v, b[2].v))
+        same = all(all(torch.equal(p.data, q.data) for p, q in zip(o[1], b[1])) and
+                   all(torch.equal(m1, m2) for m1, m2 in zip(o[2].m, b[2].m)) and
+                   all(torch.equal(v1, v2) for v1, v2 in zip(o[2].v, b[2].v)) for o in (a, c))
         print(f"{done:7d} steps: {'bit-identical' if same else 'MISMATCH'}", flush=True)
         if not same:
             sys.exit(1)
