@@ -16,7 +16,8 @@
 // Structure = gemm.hip's: 256 threads = 2x2 waves, 128x128 tile, wave tile 64x64 = 2x2 32x32 accumulators, 2-stage LDS
 // ring with one barrier per k-tile, the shared epilogue of gemm_common.h.  Differences:
 //   * BK = 16 (one MFMA k-step per tile); a stage holds the three bf16 planes of both operands:
-//     plane[128 rows][16 k] with a 48-byte row stride (conflict-free ds_read_b128 / ds_write_b128) = 36 KB per stage;
+//     plane[128 rows][16 k], 32-byte rows with the 16-byte halves of every second group of 8 rows swapped (conflict-free
+//     ds_read_b128 / ds_write_b128 / ds_write_b64) = 24 KB per stage;
 //   * a k-major operand is fetched as float4 (4 k of a row), split, and stored as three 8-byte pieces; an outer-major
 //     operand is fetched as 8 coalesced dwords (8 k of one row: lanes <-> rows), split and stored as three 16-byte
 //     pieces -- the transposition to k-major happens in the fetch pattern, not in LDS;
@@ -33,10 +34,14 @@ constexpr int B3_BK = 16;
 #ifndef B3_DEPTH
 #define B3_DEPTH 2
 #endif
-constexpr int B3_RS = 48;                               // bytes per LDS row: 16 bf16 + 16 bytes of padding
+constexpr int B3_RS = 32;                               // bytes per LDS row: 16 bf16, unpadded; the two 16-byte halves of rows 8-15 (mod 16) are swapped
+// (round 5: the 48-byte padded rows kept ds_read_b128 conflict-free but the 8-byte stores of a k-major operand hit 2-way conflicts --
+// SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.33 in profiles/r04*_gemm_pmc_bf3.txt.  Swizzled 32-byte rows: 16 lanes of a b128 read or
+// store touch 16 different 16-byte bank groups, and the 32 lanes of a b64 store pass cover 256 contiguous bytes.)
+__device__ __forceinline__ int b3_off(int row, int byte) { return row * B3_RS + (byte ^ ((row & 8) << 1)); }
 constexpr int B3_PLANE = 128 * B3_RS;                   // one plane of one operand
 constexpr int B3_OPERAND = 3 * B3_PLANE;
-constexpr int B3_STAGE = 2 * B3_OPERAND;                // 36864 bytes
+constexpr int B3_STAGE = 2 * B3_OPERAND;                // 24576 bytes
 
 // x = hi + mid + lo exactly; each piece has its low 16 bits clear (a bf16 in the high half)
 __device__ __forceinline__ void split3(float x, unsigned& hi, unsigned& mid, unsigned& lo) {
@@ -144,7 +149,7 @@ __device__ __forceinline__ void b3_commit(const StageRegs& r, unsigned char* __r
             unsigned h[2], m[2], l[2];
             split3_pair(r.v[p].x, r.v[p].y, h[0], m[0], l[0]);
             split3_pair(r.v[p].z, r.v[p].w, h[1], m[1], l[1]);
-            unsigned char* dst = S + rr * B3_RS + k4 * 2;
+            unsigned char* dst = S + b3_off(rr, k4 * 2);
             *reinterpret_cast<uint2*>(dst) = make_uint2(h[0], h[1]);
             *reinterpret_cast<uint2*>(dst + B3_PLANE) = make_uint2(m[0], m[1]);
             *reinterpret_cast<uint2*>(dst + 2 * B3_PLANE) = make_uint2(l[0], l[1]);
@@ -155,7 +160,7 @@ __device__ __forceinline__ void b3_commit(const StageRegs& r, unsigned char* __r
         split3_pair(r.v[0].z, r.v[0].w, h[1], m[1], l[1]);
         split3_pair(r.v[1].x, r.v[1].y, h[2], m[2], l[2]);
         split3_pair(r.v[1].z, r.v[1].w, h[3], m[3], l[3]);
-        unsigned char* dst = S + (tid & 127) * B3_RS + (tid >> 7) * 16;
+        unsigned char* dst = S + b3_off(tid & 127, (tid >> 7) * 16);
         *reinterpret_cast<uint4*>(dst) = make_uint4(h[0], h[1], h[2], h[3]);
         *reinterpret_cast<uint4*>(dst + B3_PLANE) = make_uint4(m[0], m[1], m[2], m[3]);
         *reinterpret_cast<uint4*>(dst + 2 * B3_PLANE) = make_uint4(l[0], l[1], l[2], l[3]);
@@ -163,7 +168,7 @@ __device__ __forceinline__ void b3_commit(const StageRegs& r, unsigned char* __r
 }
 
 __device__ __forceinline__ bf16x8 b3_frag(const unsigned char* __restrict__ S, int row, int lh) {
-    const uint4 v = *reinterpret_cast<const uint4*>(S + row * B3_RS + lh * 16);
+    const uint4 v = *reinterpret_cast<const uint4*>(S + b3_off(row, lh * 16));
     return __builtin_bit_cast(bf16x8, v);
 }
 
@@ -210,10 +215,10 @@ __device__ __forceinline__ void b3_store_one(unsigned char* __restrict__ S, int 
     const unsigned (&P)[4] = w == 0 ? H : (w == 1 ? M : L);
     if constexpr (KC) {
         const int idx = tid + NT * g;
-        unsigned char* dst = S + (idx >> 2) * B3_RS + (idx & 3) * 8 + w * B3_PLANE;
+        unsigned char* dst = S + b3_off(idx >> 2, (idx & 3) * 8) + w * B3_PLANE;
         *reinterpret_cast<uint2*>(dst) = make_uint2(P[2 * g], P[2 * g + 1]);
     } else {
-        unsigned char* dst = S + (tid & 127) * B3_RS + (tid >> 7) * 16 + w * B3_PLANE;
+        unsigned char* dst = S + b3_off(tid & 127, (tid >> 7) * 16) + w * B3_PLANE;
         *reinterpret_cast<uint4*>(dst) = make_uint4(P[0], P[1], P[2], P[3]);
     }
 }
