@@ -56,6 +56,10 @@ __device__ __forceinline__ unsigned pack_hi16(unsigned a, unsigned b) { return _
 // pair (split3 + packing: 11).  The split is issue-bound work next to the MFMAs (see the step schedule), so it counts.
 typedef float f32x2_ __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
+#ifdef B3_ABL_NOSPLIT      // diagnostic build (wrong values): no split arithmetic -- the ceiling of a kernel fed pre-split planes
+    hi = __float_as_uint(x0); mid = __float_as_uint(x1); lo = __float_as_uint(x0) ^ __float_as_uint(x1);
+    return;
+#endif
     const unsigned h0 = __float_as_uint(x0) & 0xFFFF0000u, h1 = __float_as_uint(x1) & 0xFFFF0000u;
     const f32x2_ r1 = f32x2_{x0, x1} - f32x2_{__uint_as_float(h0), __uint_as_float(h1)};
     const unsigned m0 = __float_as_uint(r1.x) & 0xFFFF0000u, m1 = __float_as_uint(r1.y) & 0xFFFF0000u;
@@ -197,11 +201,19 @@ __device__ __forceinline__ void b3_load_one(StageRegs& r, __amdgpu_buffer_rsrc_t
 // split of one pair in two halves (issue slots): A = hi / first remainder / mid, B = second remainder and the three packs
 struct PairSplit { f32x2_ r1; unsigned h0, h1, m0, m1; };
 __device__ __forceinline__ void split_pair_a(PairSplit& s, float x0, float x1) {
+#ifdef B3_ABL_NOSPLIT
+    s.h0 = __float_as_uint(x0); s.h1 = __float_as_uint(x1); s.m0 = s.h1; s.m1 = s.h0; s.r1 = f32x2_{x0, x1};
+    return;
+#endif
     s.h0 = __float_as_uint(x0) & 0xFFFF0000u; s.h1 = __float_as_uint(x1) & 0xFFFF0000u;
     s.r1 = f32x2_{x0, x1} - f32x2_{__uint_as_float(s.h0), __uint_as_float(s.h1)};
     s.m0 = __float_as_uint(s.r1.x) & 0xFFFF0000u; s.m1 = __float_as_uint(s.r1.y) & 0xFFFF0000u;
 }
 __device__ __forceinline__ void split_pair_b(const PairSplit& s, unsigned& hi, unsigned& mid, unsigned& lo) {
+#ifdef B3_ABL_NOSPLIT
+    hi = s.h0; mid = s.h1; lo = s.m0 ^ s.h0;
+    return;
+#endif
     const f32x2_ r2 = s.r1 - f32x2_{__uint_as_float(s.m0), __uint_as_float(s.m1)};
     hi = pack_hi16(s.h0, s.h1);
     mid = pack_hi16(s.m0, s.m1);
