@@ -1360,6 +1360,19 @@ def workload_headline(args, rank, world):
                                     "frac": dom["frac_of_mfma_peak"]},
                 "c2_linear_forward": {k: c2_obj[k] for k in ("achieved", "frac", "avg_launch_ms", "traffic", "traffic_over_algorithmic") if k in c2_obj},
             }
+            # fabric bytes of the dominant kernel as launched INSIDE the step (two decoder layers' eight dW GEMMs per launch):
+            # committed PMC passes over `bench.py --workload c4` (tools/collect_profiles.sh), halved to the one-layer unit of
+            # `dominant_kernel.flops_per_launch`; algorithmic = the eight operands read once + the four split-K slabs written
+            tr2 = read_traffic("gemm_group_dw2_c4") if "dW+db of one decoder layer" in dom["family"] else None
+            if tr2:
+                rows_, cols_ = 64 * 256, (1536 + 512) + (512 + 512) + (2048 + 512) + (512 + 2048)
+                outs_ = 512 * 1536 + 512 * 512 + 512 * 2048 + 2048 * 512
+                alg = 4.0 * (rows_ * cols_ + 4 * outs_)
+                res["roofline"]["traffic"] = round(tr2 / 2.0)
+                res["roofline"]["traffic_what"] = ("fabric bytes per launch of the dominant kernel (one decoder layer's share of the two-layer "
+                                                   "grouped dW launch), (2*FETCH_SIZE + WRITE_SIZE)*1024 / 2; " + (traffic_source() or ""))
+                res["roofline"]["traffic_over_algorithmic"] = round(tr2 / 2.0 / alg, 2)
+                res["roofline"]["dominant_kernel"]["algorithmic_bytes_per_launch"] = alg
         except Exception as exc:  # noqa: BLE001
             also["c4_families"] = {"error": repr(exc)[:300]}
     # C1: MNIST-MLP, sustained

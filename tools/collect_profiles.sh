@@ -30,6 +30,9 @@ for W in c2 c3; do
   timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $O/pmc_fetch_$W -o f -- python $R/bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_fetch_$W.log 2>&1
   timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $O/pmc_write_$W -o w -- python $R/bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_write_$W.log 2>&1
 done
+# the headline's dominant kernel (the grouped dW launch of two decoder layers) inside the C4 step: fabric reads and writes per launch
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $O/pmc_fetch_c4 -o f -- python $R/bench.py --workload c4 --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_fetch_c4.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $O/pmc_write_c4 -o w -- python $R/bench.py --workload c4 --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_write_c4.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -f csv -d $O/pmc_sq_c2 -o sq -- python $R/bench.py --workload c2 --steps 3 --warmup 1 --no-cpu-baseline > $O/pmc_sq_c2.log 2>&1
 # RCCL's kernels next to ours: kernel trace of the forced one-rank nccl step (--dp-op avg: a 1-rank in-place SUM is elided inside RCCL)
 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $O/prof_dp -o dp -- python $R/bench.py --workload c4 --force-dp --dp-op avg --steps 5 --warmup 2 --no-cpu-baseline > $O/prof_dp.log 2>&1
