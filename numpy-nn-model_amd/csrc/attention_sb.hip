@@ -106,7 +106,8 @@ __device__ __forceinline__ void sb_issue64_adv(sb_u32x2& r, unsigned voff, sb_rs
 #if defined(SB_ABL_NOLOAD) || defined(SB_ABL_NOCOLS)
     return;
 #endif
-    asm volatile("buffer_load_dwordx2 %0, %2, %3, %1 offen\n\ts_add_u32 %1, %1, %4" : "+v"(r), "+s"(soff) : "v"(voff), "s"(rs), "s"(step) : "scc");   // (s_add writes SCC)
+    // (readfirstlane: under scalar-register pressure hipcc parks the row step in a VGPR lane, which s_add_u32 cannot read)
+    asm volatile("buffer_load_dwordx2 %0, %2, %3, %1 offen\n\ts_add_u32 %1, %1, %4" : "+v"(r), "+s"(soff) : "v"(voff), "s"(rs), "s"(__builtin_amdgcn_readfirstlane(step)) : "scc");   // (s_add writes SCC)
 }
 template <int N>
 __device__ __forceinline__ void sb_wait(sb_u32x4& r) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r) : "i"(N)); }
@@ -152,6 +153,8 @@ __device__ __forceinline__ void sb_store_rows(float* __restrict__ E, const f32x1
 }
 
 __device__ __forceinline__ float sb_f(unsigned u) { return __uint_as_float(u); }
+// a wave-uniform value the compiler must keep in a vector register from here on
+__device__ __forceinline__ int sb_vec(int s) { int v; asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s)); return v; }
 
 // row r(e) of a 32-row group that accumulator register e carries for the lower half-wave (the upper one: + 4)
 __device__ __forceinline__ constexpr int sb_row(int e) { return (e & 3) + 8 * (e >> 2); }
@@ -591,8 +594,8 @@ __device__ __forceinline__ void sb_bwd_row_tables(const AttnBwdParams& p, float*
     }
 }
 
-// phase 0: key group `wave` of slice A, pairs (i, j) for i = j .. 7 (steps 0 .. 7 - wave: diagonal first);
-// phase 1: key group 7 - wave of slice B, i = 7 down to j (diagonal last).  No block barrier: the dQ slots are ordered by their counts.
+// phase 0: key group `wave` of slice A, pairs (i, j) for i = 7 down to j (steps 0 .. 7 - wave: diagonal last);
+// phase 1: key group 7 - wave of slice B, i = j .. 7 (diagonal first).  No block barrier: the dQ slots are ordered by their counts.
 template <int PH>
 __device__ __forceinline__ void sb_bwd_phase(const AttnBwdParams& p, float* __restrict__ smem, const int wave, const int lane, f32x16 (&dk)[2],
                                              f32x16 (&dv)[2], sb_u32x4 (&R)[8], sb_u32x4 (&RB)[8], sb_u32x2 (&C)[16] SB_PROF_ARG) {
@@ -623,7 +626,7 @@ __device__ __forceinline__ void sb_bwd_phase(const AttnBwdParams& p, float* __re
     if (p.key_valid) sb_key_bits(p.key_valid + (int64_t)b * SB_T, lane, kvbits, fv);
     const bool key_pad = !((sb_valid32(kvbits, j) >> l31) & 1u);           // this lane's key is padding
     // the first pair's operands: Q rows / dO columns of its row group, the K_j fragments (lane <-> key row: the B operand of S)
-    const int i0 = PH == 0 ? j : SB_NG - 1;
+    const int i0 = PH == 0 ? SB_NG - 1 : j;                // the first pair of the phase (see the order of the pairs below)
     const unsigned so0 = (unsigned)(32 * i0) * pitchQ, sok = (unsigned)(32 * j) * pitchQ;
     sb_first128<0>(R[0], voffRq, rq, so0); sb_first128<32>(R[1], voffRq, rq, so0); sb_first128<64>(R[2], voffRq, rq, so0);
     sb_first128<96>(R[3], voffRq, rq, so0); sb_first128<128>(R[4], voffRq, rq, so0); sb_first128<160>(R[5], voffRq, rq, so0);
@@ -650,25 +653,40 @@ __device__ __forceinline__ void sb_bwd_phase(const AttnBwdParams& p, float* __re
     asm volatile("" : "+v"(C[8]), "+v"(C[9]), "+v"(C[10]), "+v"(C[11]), "+v"(C[12]), "+v"(C[13]), "+v"(C[14]), "+v"(C[15]));
     SB_T(0);
 #define SB_PAIR_ARGS dk, dv, R, RB, C, rq, rk, rv, rg, voffRq, voffRg, voffCq, voffCg, pitchQ, pitchG, Mt, E, rdq, p.scale, sl2, key_pad, j
-    // dQ slot of row group i: phase 0 -> slot i, contributions in the order of the key groups i, i - 1, .. 0 (turn = i - j; the last one,
-    // key group 0, writes the row group out and leaves the count at i + 1); phase 1 -> slot r = 7 - i, free again by then (A's row group r
-    // was complete before B's row group 7 - r got its first contribution in the barrier-stepped schedule this replaces, and the count
-    // says so now: r + 1), contributions in the order of the key groups 0, 1, .. i (turn = r + 1 + j; the diagonal pair writes it out)
+    // Order of the pairs (round 5, second schedule): at step t of the block's nine steps EVERY phase-0 wave is on row group 7 - t of
+    // slice A (i = 7 down to j, the diagonal pair last) and EVERY phase-1 wave on row group t - 1 of slice B (i = j up to 7, the
+    // diagonal pair first; a wave enters phase 1 at step 8 - wave): the up to eight waves that need the same Q_i / dO_i tile ask for it
+    // at the same time and find each other's lines in L1 / L2 -- walked one step apart (first schedule: phase 0 upwards from the
+    // diagonal) a tile had left the XCD's L2 (128 KB per CU against 450 KB of requests per step) before its next reader came.
+    // dQ slots: only one row group per slice is being summed at a time, so four slots per slice, reused every fourth row group
+    // (A: slots 0-3, B: slots 4-7); the contribution COUNT of a slot orders everything -- phase 0: key groups 0, 1, .. i (the
+    // diagonal pair writes the row group out), phase 1: key groups i, i - 1, .. 0 (key group 0 writes it out); a slot's second
+    // row group starts at the count its first one ends with.  Within a step the waves contribute in ascending wave order in both
+    // phases, and a row group's first contribution comes four steps after the previous tenant's last: no wave waits for a later one.
+    // (slot index and turn live in VECTOR registers -- sb_vec: as scalars they were the handful of SGPRs too many, and the pair body's buffer
+    //  descriptors went to VGPRs, which no buffer instruction encodes)
     int* __restrict__ seqs = reinterpret_cast<int*>(smem + 16 * SLOT + 2 * 3 * SB_T);
     if constexpr (PH == 0) {
-        sb_bwd_pair<true>(SB_PAIR_ARGS, j, j + 1 < SB_NG ? j + 1 : j, slots + j * SLOT, seqs + j, 0, true, j == 0, lane SB_PROF_PASS);
+#pragma unroll 1
+        for (int s = 0; s + 1 < npairs; ++s) {
+            const int i = SB_NG - 1 - s;
+            const int iv = sb_vec(i), x = iv & 3;
+            sb_bwd_pair<false>(SB_PAIR_ARGS, i, i - 1, slots + x * SLOT, seqs + x, (iv < 4 ? iv + 5 : 0) + j, j == 0, false, lane SB_PROF_PASS);
+        }
+        const int jv = sb_vec(j), x = jv & 3;
+        sb_bwd_pair<true>(SB_PAIR_ARGS, j, j, slots + x * SLOT, seqs + x, (jv < 4 ? jv + 5 : 0) + jv, j == 0, true, lane SB_PROF_PASS);
+    } else {
+        {
+            const int jv = sb_vec(j), x = 4 + (jv & 3);
+            sb_bwd_pair<true>(SB_PAIR_ARGS, j, j + 1 < SB_NG ? j + 1 : j, slots + x * SLOT, seqs + x, jv < 4 ? 0 : jv - 3, true, j == 0, lane SB_PROF_PASS);
+        }
 #pragma unroll 1
         for (int s = 1; s < npairs; ++s) {
             const int i = j + s;
-            sb_bwd_pair<false>(SB_PAIR_ARGS, i, i + 1 < SB_NG ? i + 1 : i, slots + i * SLOT, seqs + i, s, false, j == 0, lane SB_PROF_PASS);
+            const int iv = sb_vec(i), x = 4 + (iv & 3);
+            sb_bwd_pair<false>(SB_PAIR_ARGS, i, i + 1 < SB_NG ? i + 1 : i, slots + x * SLOT, seqs + x, (iv < 4 ? 0 : iv - 3) + (iv - j), false, j == 0,
+                               lane SB_PROF_PASS);
         }
-    } else {
-#pragma unroll 1
-        for (int s = 0; s + 1 < npairs; ++s) {
-            const int i = SB_NG - 1 - s, r = SB_NG - 1 - i;
-            sb_bwd_pair<false>(SB_PAIR_ARGS, i, i - 1, slots + r * SLOT, seqs + r, r + 1 + j, j == 0, false, lane SB_PROF_PASS);
-        }
-        sb_bwd_pair<true>(SB_PAIR_ARGS, j, j, slots + (SB_NG - 1 - j) * SLOT, seqs + (SB_NG - 1 - j), (SB_NG - 1 - j) + 1 + j, j == 0, true, lane SB_PROF_PASS);
     }
 #undef SB_PAIR_ARGS
     // the last pair's look-ahead loads re-read its own row group: let them land before their registers are anyone else's
