@@ -41,6 +41,8 @@ constexpr int SB_T = 256;        // the sequence length these kernels are built 
 constexpr int SB_NG = 8;
 constexpr int SB_DH = 64;
 constexpr int SB_LD = SB_DH + 4; // LDS row stride of a staged [32][64] tile (17 chunks of 16 B: conflict-free b128 rows)
+constexpr int SB_WAVE_LDS = 32 * SB_LD + 32 * 36;           // backward, per wave: K_j tile + dS patch (floats)
+constexpr int SB_TABS = 4 * 32 * SB_LD + 8 * SB_WAVE_LDS;   // backward: offset of the row tables behind the 4 dQ slots and the waves' regions
 
 // Developer instrumentation (tools/attn_sb_prof.py; build.py --variant prof -D SB_PROF): per-wave cycle counts of the kernels' phases,
 // accumulated in registers and written to g_sb_prof[(block * 8 + wave) * 16 + phase] at the end.  Compiled out of the library.
@@ -380,34 +382,50 @@ __global__ __launch_bounds__(512, 2) void attn_sb_fwd_kernel(const AttnParams p)
 // columns, Q_i rows: issued three units ahead) have already brought in.  Loads return in order and are issued in consumption
 // order, 80 per pair, so every wait is a constant.  The units run in the order U1, P, U3, U2, dS, U4, U5: the buffers that U1 empties (R, RB)
 // are not needed again before U2 -- a unit and the P pass later -- and C's refill for U4 has U2 to land.
-#define SB_BWD_BURST(g, voffR, rsR, soR, rsB)                                            \
+// K_j lives in the wave's LDS tile kt[32 keys][SB_LD] for the whole phase (round 5, third step: its row fragments for U1 and its columns for
+// U5 were 24 of the 80 loads of a pair, re-fetched from L2 / fabric for every pair because 256 VGPRs cannot hold them).  RB[g] and C[e]
+// are refilled from LDS with plain loads (the compiler waits for those itself); the rolling VMEM stream of a pair is now 56 loads:
+//   A, B  (in U1, after g = 3 / 7):  R[g-3..g] <- dO_i rows, RB[g-3..g] <- V_j rows, interleaved          8 + 8
+//   C     (in U3):                   C[e] <- Q_i columns                                                   16
+//   D, E  (in U2, after g = 3 / 7):  R[g-3..g] <- Q_i' rows                                                4 + 4
+//   G     (in U5):                   C[e] <- dO_i' columns                                                 16
+// and every wait below counts the loads issued AFTER the one it needs.
+#define SB_BWD_BURST_RV(g)                                                                \
     do {                                                                                  \
-        sb_issue128<32 * ((g) - 3)>(R[(g) - 3], voffR, rsR, soR);                         \
-        sb_issue128<32 * ((g) - 3)>(RB[(g) - 3], voffRq, rsB, soK_j);                     \
-        sb_issue128<32 * ((g) - 2)>(R[(g) - 2], voffR, rsR, soR);                         \
-        sb_issue128<32 * ((g) - 2)>(RB[(g) - 2], voffRq, rsB, soK_j);                     \
-        sb_issue128<32 * ((g) - 1)>(R[(g) - 1], voffR, rsR, soR);                         \
-        sb_issue128<32 * ((g) - 1)>(RB[(g) - 1], voffRq, rsB, soK_j);                     \
-        sb_issue128<32 * (g)>(R[g], voffR, rsR, soR);                                     \
-        sb_issue128<32 * (g)>(RB[g], voffRq, rsB, soK_j);                                 \
+        sb_issue128<32 * ((g) - 3)>(R[(g) - 3], voffRg, rg, soG_i);                       \
+        sb_issue128<32 * ((g) - 3)>(RB[(g) - 3], voffRq, rv, soK_j);                      \
+        sb_issue128<32 * ((g) - 2)>(R[(g) - 2], voffRg, rg, soG_i);                       \
+        sb_issue128<32 * ((g) - 2)>(RB[(g) - 2], voffRq, rv, soK_j);                      \
+        sb_issue128<32 * ((g) - 1)>(R[(g) - 1], voffRg, rg, soG_i);                       \
+        sb_issue128<32 * ((g) - 1)>(RB[(g) - 1], voffRq, rv, soK_j);                      \
+        sb_issue128<32 * (g)>(R[g], voffRg, rg, soG_i);                                   \
+        sb_issue128<32 * (g)>(RB[g], voffRq, rv, soK_j);                                  \
+    } while (0)
+#define SB_BWD_BURST_R(g)                                                                 \
+    do {                                                                                  \
+        sb_issue128<32 * ((g) - 3)>(R[(g) - 3], voffRq, rq, soQ_n);                       \
+        sb_issue128<32 * ((g) - 2)>(R[(g) - 2], voffRq, rq, soQ_n);                       \
+        sb_issue128<32 * ((g) - 1)>(R[(g) - 1], voffRq, rq, soQ_n);                       \
+        sb_issue128<32 * (g)>(R[g], voffRq, rq, soQ_n);                                   \
+        RB[(g) - 3] = krow[2 * ((g) - 3)]; RB[(g) - 2] = krow[2 * ((g) - 2)]; RB[(g) - 1] = krow[2 * ((g) - 1)]; RB[g] = krow[2 * (g)];   \
     } while (0)
 #define SB_BWD_U1(g)                                                                      \
     do {                                                                                  \
-        sb_wait2<46 - 2 * ((g) & 3)>(R[g], RB[g]);                                        \
+        sb_wait<((g) < 4 ? 23 : 27) - ((g) & 3)>(R[g]);                                   \
         s = AT_MFMA(sb_f(R[g].x), sb_f(RB[g].x), s);                                      \
         s = AT_MFMA(sb_f(R[g].y), sb_f(RB[g].y), s);                                      \
         s = AT_MFMA(sb_f(R[g].z), sb_f(RB[g].z), s);                                      \
         s = AT_MFMA(sb_f(R[g].w), sb_f(RB[g].w), s);                                      \
-        if constexpr (((g) & 3) == 3) SB_BWD_BURST(g, voffRg, rg, soG_i, rv);             \
+        if constexpr (((g) & 3) == 3) SB_BWD_BURST_RV(g);                                 \
     } while (0)
 #define SB_BWD_U2(g)                                                                      \
     do {                                                                                  \
-        sb_wait2<30 - 2 * ((g) & 3)>(R[g], RB[g]);                                        \
+        sb_wait2<((g) < 4 ? 30 : 26) - 2 * ((g) & 3)>(R[g], RB[g]);                       \
         dp = AT_MFMA(sb_f(R[g].x), sb_f(RB[g].x), dp);                                    \
         dp = AT_MFMA(sb_f(R[g].y), sb_f(RB[g].y), dp);                                    \
         dp = AT_MFMA(sb_f(R[g].z), sb_f(RB[g].z), dp);                                    \
         dp = AT_MFMA(sb_f(R[g].w), sb_f(RB[g].w), dp);                                    \
-        if constexpr (((g) & 3) == 3) SB_BWD_BURST(g, voffRq, rq, soQ_n, rk);             \
+        if constexpr (((g) & 3) == 3) SB_BWD_BURST_R(g);                                  \
     } while (0)
 #define SB_BWD_U3(e)                                                                      \
     do {                                                                                  \
@@ -418,14 +436,13 @@ __global__ __launch_bounds__(512, 2) void attn_sb_fwd_kernel(const AttnParams p)
     } while (0)
 #define SB_BWD_U4(e)                                                                      \
     do {                                                                                  \
-        sb_wait<31>(C[e]);                                                                \
+        sb_wait<23 - (e)>(C[e]);                                                          \
         dk[0] = AT_MFMA(sb_f(C[e].x), dp[e], dk[0]);                                      \
         dk[1] = AT_MFMA(sb_f(C[e].y), dp[e], dk[1]);                                      \
-        sb_issue64_adv(C[e], voffCq, rk, so4, ((e) & 3) == 3 ? 5u * pitchQ : pitchQ); \
+        C[e] = kcol[sb_row(e) * (SB_LD / 2)];                                             \
     } while (0)
 #define SB_BWD_U5(e)                                                                      \
     do {                                                                                  \
-        sb_wait<15>(C[e]);                                                                \
         dq[0] = AT_MFMA(sb_f(C[e].x), dst[e], dq[0]);                                     \
         dq[1] = AT_MFMA(sb_f(C[e].y), dst[e], dq[1]);                                     \
         sb_issue64_adv(C[e], voffCg, rg, so5, ((e) & 3) == 3 ? 5u * pitchG : pitchG); \
@@ -441,7 +458,8 @@ __device__ __forceinline__ void sb_bwd_pair(f32x16 (&dk)[2], f32x16 (&dv)[2], sb
                                             const unsigned voffRq, const unsigned voffRg, const unsigned voffCq, const unsigned voffCg,
                                             const unsigned pitchQ, const unsigned pitchG,
                                             const float* __restrict__ Mt,          // LDS: max | log2 sum | Dsum of the slice's 256 queries
-                                            float* __restrict__ scratch,           // LDS: this wave's staging rows
+                                            float* __restrict__ scratch,           // LDS: this wave's dS patch [32][36]
+                                            const float* __restrict__ kt,          // LDS: this wave's K_j tile [32][SB_LD]
                                             const sb_rsrc rdq,                     // global: dQ rows of the slice
                                             const float scale, const float sl2, const bool key_pad, const int j, const int i, const int i_next,
                                             float* __restrict__ slot, int* __restrict__ seq, const int turn, const bool first, const bool last, const int lane SB_PROF_ARG) {
@@ -451,7 +469,10 @@ __device__ __forceinline__ void sb_bwd_pair(f32x16 (&dk)[2], f32x16 (&dv)[2], sb
     const unsigned soQ_i = (unsigned)(32 * i) * pitchQ, soG_i = (unsigned)(32 * i) * pitchG;
     const unsigned soQ_n = (unsigned)(32 * i_next) * pitchQ, soG_n = (unsigned)(32 * i_next) * pitchG;
     const unsigned soK_j = (unsigned)(32 * j) * pitchQ;
-    unsigned so3 = soQ_i, so4 = soK_j, so5 = soG_n;          // running row offsets of the three column-type streams
+    unsigned so3 = soQ_i, so5 = soG_n;                       // running row offsets of the two column-type streams
+    // K_j out of the wave's tile: row fragments (lane <-> key l31, 16 bytes at dh 8 g + 4 lh) and columns (key r(e) + 4 lh, dh 2 l31, + 1)
+    const sb_u32x4* __restrict__ krow = reinterpret_cast<const sb_u32x4*>(kt + l31 * SB_LD + 4 * lh);        // [g]: + 8 g floats = + 2 g
+    const sb_u32x2* __restrict__ kcol = reinterpret_cast<const sb_u32x2*>(kt + 4 * lh * SB_LD + 2 * l31);    // [row * SB_LD / 2]
     f32x16 s, dp;
 #pragma unroll
     for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
@@ -605,12 +626,13 @@ __device__ __forceinline__ void sb_bwd_phase(const AttnBwdParams& p, float* __re
     const int j = PH == 0 ? wave : SB_NG - 1 - wave;
     const int npairs = SB_NG - j;
     float* __restrict__ slots = smem;
-    float* __restrict__ E = smem + (8 + wave) * SLOT;
+    float* __restrict__ E = smem + 4 * SLOT + wave * SB_WAVE_LDS;      // the wave's K_j tile [32][SB_LD]; its dK / dV rows are staged here when the phase is over
+    float* __restrict__ patch = E + SLOT;                               // the wave's dS transposition patch [32][36]
     if (bh >= p.B * p.H) {                    // block-uniform: an odd number of slices leaves the last block without a B
         if constexpr (PH == 1) sb_bwd_store_kv(p, bh - 1, SB_NG - 1 - j, E, dk, dv, lane);
         return;
     }
-    const float* __restrict__ Mt = smem + 16 * SLOT + PH * 3 * SB_T;
+    const float* __restrict__ Mt = smem + SB_TABS + PH * 3 * SB_T;
     const unsigned pitchQ = (unsigned)p.LQ * 4u, pitchG = (unsigned)p.D * 4u;
     const unsigned bytesQ = (unsigned)(((int64_t)(SB_T - 1) * p.LQ + SB_DH) * 4), bytesG = (unsigned)(((int64_t)(SB_T - 1) * p.D + SB_DH) * 4);
     const float sl2 = p.scale * AT_LOG2E;
@@ -639,7 +661,7 @@ __device__ __forceinline__ void sb_bwd_phase(const AttnBwdParams& p, float* __re
     // ... and while they fly: phase 0 -- the row statistics of both slices go to LDS (every wave 32 queries; one block barrier);
     // phase 1 -- the dK / dV rows of phase 0 go out (their stores are younger than the loads above; the drain below takes both)
     if constexpr (PH == 0) {
-        sb_bwd_row_tables(p, smem + 16 * SLOT, wave, lane);
+        sb_bwd_row_tables(p, smem + SB_TABS, wave, lane);
         __syncthreads();
     } else {
         sb_bwd_store_kv(p, bh - 1, wave, E, dk, dv, lane);
@@ -651,40 +673,49 @@ __device__ __forceinline__ void sb_bwd_phase(const AttnBwdParams& p, float* __re
     asm volatile("" : "+v"(RB[0]), "+v"(RB[1]), "+v"(RB[2]), "+v"(RB[3]), "+v"(RB[4]), "+v"(RB[5]), "+v"(RB[6]), "+v"(RB[7]));
     asm volatile("" : "+v"(C[0]), "+v"(C[1]), "+v"(C[2]), "+v"(C[3]), "+v"(C[4]), "+v"(C[5]), "+v"(C[6]), "+v"(C[7]));
     asm volatile("" : "+v"(C[8]), "+v"(C[9]), "+v"(C[10]), "+v"(C[11]), "+v"(C[12]), "+v"(C[13]), "+v"(C[14]), "+v"(C[15]));
+    // K_j into the wave's tile (the staging use of these rows -- phase 0's dK / dV above -- has finished: sb_store_rows ends on lgkmcnt(0))
+#pragma unroll
+    for (int g = 0; g < 8; ++g) *reinterpret_cast<sb_u32x4*>(E + l31 * SB_LD + 8 * g + 4 * lh) = RB[g];
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
     SB_T(0);
-#define SB_PAIR_ARGS dk, dv, R, RB, C, rq, rk, rv, rg, voffRq, voffRg, voffCq, voffCg, pitchQ, pitchG, Mt, E, rdq, p.scale, sl2, key_pad, j
+#define SB_PAIR_ARGS dk, dv, R, RB, C, rq, rk, rv, rg, voffRq, voffRg, voffCq, voffCg, pitchQ, pitchG, Mt, patch, E, rdq, p.scale, sl2, key_pad, j
     // Order of the pairs (round 5, second schedule): at step t of the block's nine steps EVERY phase-0 wave is on row group 7 - t of
     // slice A (i = 7 down to j, the diagonal pair last) and EVERY phase-1 wave on row group t - 1 of slice B (i = j up to 7, the
     // diagonal pair first; a wave enters phase 1 at step 8 - wave): the up to eight waves that need the same Q_i / dO_i tile ask for it
     // at the same time and find each other's lines in L1 / L2 -- walked one step apart (first schedule: phase 0 upwards from the
     // diagonal) a tile had left the XCD's L2 (128 KB per CU against 450 KB of requests per step) before its next reader came.
-    // dQ slots: only one row group per slice is being summed at a time, so four slots per slice, reused every fourth row group
-    // (A: slots 0-3, B: slots 4-7); the contribution COUNT of a slot orders everything -- phase 0: key groups 0, 1, .. i (the
+    // dQ slots: only one row group per slice is being summed at a time, so two slots per slice, reused every second row group
+    // (A: slots 0-1, B: slots 2-3); the contribution COUNT of a slot orders everything -- phase 0: key groups 0, 1, .. i (the
     // diagonal pair writes the row group out), phase 1: key groups i, i - 1, .. 0 (key group 0 writes it out); a slot's second
     // row group starts at the count its first one ends with.  Within a step the waves contribute in ascending wave order in both
-    // phases, and a row group's first contribution comes four steps after the previous tenant's last: no wave waits for a later one.
+    // phases, and a row group's first contribution comes two steps after the previous tenant's last: no wave waits for a later one.
     // (slot index and turn live in VECTOR registers -- sb_vec: as scalars they were the handful of SGPRs too many, and the pair body's buffer
     //  descriptors went to VGPRs, which no buffer instruction encodes)
-    int* __restrict__ seqs = reinterpret_cast<int*>(smem + 16 * SLOT + 2 * 3 * SB_T);
+    int* __restrict__ seqs = reinterpret_cast<int*>(smem + SB_TABS + 2 * 3 * SB_T);
+    // turn of the first contribution of row group i in its slot (two slots per slice, a slot's tenants in time order -- A: 7 5 3 1 / 6 4 2 0
+    // with i + 1 contributions each, B: 1 3 5 7 / 0 2 4 6): eight 5-bit entries per table
+    constexpr unsigned long long TA = 15ull | 18ull << 5 | 12ull << 10 | 14ull << 15 | 7ull << 20 | 8ull << 25 | 0ull << 30 | 0ull << 35;
+    constexpr unsigned long long TB = 0ull | 0ull << 5 | 1ull << 10 | 2ull << 15 | 4ull << 20 | 6ull << 25 | 9ull << 30 | 12ull << 35;
     if constexpr (PH == 0) {
 #pragma unroll 1
         for (int s = 0; s + 1 < npairs; ++s) {
             const int i = SB_NG - 1 - s;
-            const int iv = sb_vec(i), x = iv & 3;
-            sb_bwd_pair<false>(SB_PAIR_ARGS, i, i - 1, slots + x * SLOT, seqs + x, (iv < 4 ? iv + 5 : 0) + j, j == 0, false, lane SB_PROF_PASS);
+            const int iv = sb_vec(i), x = iv & 1;
+            sb_bwd_pair<false>(SB_PAIR_ARGS, i, i - 1, slots + x * SLOT, seqs + x, (int)((TA >> (5 * iv)) & 31) + j, j == 0, false, lane SB_PROF_PASS);
         }
-        const int jv = sb_vec(j), x = jv & 3;
-        sb_bwd_pair<true>(SB_PAIR_ARGS, j, j, slots + x * SLOT, seqs + x, (jv < 4 ? jv + 5 : 0) + jv, j == 0, true, lane SB_PROF_PASS);
+        const int jv = sb_vec(j), x = jv & 1;
+        sb_bwd_pair<true>(SB_PAIR_ARGS, j, j, slots + x * SLOT, seqs + x, (int)((TA >> (5 * jv)) & 31) + jv, j == 0, true, lane SB_PROF_PASS);
     } else {
         {
-            const int jv = sb_vec(j), x = 4 + (jv & 3);
-            sb_bwd_pair<true>(SB_PAIR_ARGS, j, j + 1 < SB_NG ? j + 1 : j, slots + x * SLOT, seqs + x, jv < 4 ? 0 : jv - 3, true, j == 0, lane SB_PROF_PASS);
+            const int jv = sb_vec(j), x = 2 + (jv & 1);
+            sb_bwd_pair<true>(SB_PAIR_ARGS, j, j + 1 < SB_NG ? j + 1 : j, slots + x * SLOT, seqs + x, (int)((TB >> (5 * jv)) & 31), true, j == 0, lane SB_PROF_PASS);
         }
 #pragma unroll 1
         for (int s = 1; s < npairs; ++s) {
             const int i = j + s;
-            const int iv = sb_vec(i), x = 4 + (iv & 3);
-            sb_bwd_pair<false>(SB_PAIR_ARGS, i, i + 1 < SB_NG ? i + 1 : i, slots + x * SLOT, seqs + x, (iv < 4 ? 0 : iv - 3) + (iv - j), false, j == 0,
+            const int iv = sb_vec(i), x = 2 + (iv & 1);
+            sb_bwd_pair<false>(SB_PAIR_ARGS, i, i + 1 < SB_NG ? i + 1 : i, slots + x * SLOT, seqs + x, (int)((TB >> (5 * iv)) & 31) + (iv - j), false, j == 0,
                                lane SB_PROF_PASS);
         }
     }
@@ -719,10 +750,10 @@ __device__ __forceinline__ void sb_bwd_phase(const AttnBwdParams& p, float* __re
 }
 
 __global__ __launch_bounds__(512, 2) void attn_sb_bwd_kernel(const AttnBwdParams p) {
-    // one LDS object: [8 dQ slots][32][68] | [8 waves][32][68] staging | (max, log2 sum, Dsum) of 2 x 256 queries | 8 slot counts
-    constexpr int SLOT = 32 * SB_LD;
-    __shared__ __attribute__((aligned(16))) float smem[16 * SLOT + 2 * 3 * SB_T + 8];
-    if (threadIdx.x < 8) reinterpret_cast<int*>(smem + 16 * SLOT + 2 * 3 * SB_T)[threadIdx.x] = 0;      // contribution counts of the dQ slots
+    // one LDS object: [4 dQ slots][32][68] | [8 waves]{K_j tile [32][68] (dK / dV staging at the phase's end), dS patch [32][36]} |
+    // (max, log2 sum, Dsum) of 2 x 256 queries | slot counts
+    __shared__ __attribute__((aligned(16))) float smem[SB_TABS + 2 * 3 * SB_T + 8];
+    if (threadIdx.x < 8) reinterpret_cast<int*>(smem + SB_TABS + 2 * 3 * SB_T)[threadIdx.x] = 0;      // contribution counts of the dQ slots
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
