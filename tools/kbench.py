@@ -172,6 +172,9 @@ def main():
         w5, s5, dw5 = torch.ones(512, device=dev), torch.empty(16384, device=dev), torch.empty(512, device=dev)
         report("rmsnorm fwd 16384x512", *bench(lambda: call("nnhipRMSNormForward", x5, w5, None, y5, s5, None, 16384, 512, 1e-6, st), args.iters), nbytes=8.0 * x5.numel())
         report("rmsnorm bwd 16384x512", *bench(lambda: call("nnhipRMSNormBackward", dy5, x5, w5, s5, None, dx5, dw5, None, 16384, 512, st), args.iters), nbytes=12.0 * x5.numel())
+        add5 = randn(16384, 512)
+        # the form the C4 step launches 12 times: the residual branch's gradient added in the same pass (16 B per element), dw finished later
+        report("rmsnorm bwd 16384x512 +addend", *bench(lambda: call("nnhipRMSNormBackwardEx", dy5, x5, w5, s5, None, add5, dx5, dw5, None, 16384, 512, st), args.iters), nbytes=16.0 * x5.numel())
     if want("ce"):
         labels = torch.randint(0, D, (R,), device=dev, dtype=torch.int32)
         loss, lse = torch.empty(R, device=dev), torch.empty(R, device=dev)
