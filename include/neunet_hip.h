@@ -30,6 +30,8 @@ typedef void* nnhipStream_t; /* hipStream_t */
 #define NNHIP_EINVAL (-1)   /* bad argument (null pointer, negative size, bad enum) */
 #define NNHIP_EALIGN (-2)   /* pointer not 4-byte aligned */
 #define NNHIP_ENOMEM (-3)   /* workspace allocation failed */
+#define NNHIP_EDEVICE (-5)  /* a kernel of an EARLIER launch found the device state broken and raised the library's device error
+                             * word; sticky until nnhipClearDeviceError() (-4 is NNHIP_ECOMM, below) */
 
 /* ---- library ------------------------------------------------------------------------------ */
 int nnhipVersion(void);
@@ -39,6 +41,17 @@ const char* nnhipGetLastErrorString(void);
  * Replaces cleanupCudaMemory() (linear_cublaslt_no_manual_mem.cu:186, linear_cutlass.cu:107,
  * linear_swish_cutlass_evt_full.cu:820).  Synchronises the device. */
 int nnhipCleanup(void);
+/* Device-side errors (ABI 210).  A kernel cannot return a status, and the reference's convention for a failure inside its CUDA
+ * path is printf + exit(1) (linear_cublaslt_no_manual_mem.cu:91-94).  Here a kernel that finds the device state broken -- today
+ * only the optimizer-in-backward launch whose arrival barrier saw no progress for 20 s -- skips its side effect, stores a code in
+ * a library-owned word of pinned host memory and ends normally.  nnhipDeviceError() reads that word without synchronising:
+ * 0, or NNHIP_EDEVICE with the story in nnhipGetLastErrorString().  nnhipLinearReLULinearBackwardAdam and the optimizer step
+ * entries check it on entry, so a training loop stops at its next step instead of losing the context to a trap.
+ * nnhipClearDeviceError() resets the word.  nnhipRaiseDeviceErrorForTest() stores `code` from a one-block kernel on `stream`
+ * (the tests' way to exercise the path without a broken device). */
+int nnhipDeviceError(void);
+int nnhipClearDeviceError(void);
+int nnhipRaiseDeviceErrorForTest(int32_t code, nnhipStream_t stream);
 /* Grow the workspace to at least `bytes` now (e.g. before capturing a hipGraph). */
 int nnhipWorkspaceReserve(int64_t bytes);
 /* locked != 0: the workspace may no longer move -- a launch that needs more than it holds returns NNHIP_ENOMEM instead

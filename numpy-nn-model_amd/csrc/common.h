@@ -59,6 +59,13 @@ const float* zero_block();
 constexpr int kSyncWords = 1024;
 enum SyncSlot { SYNC_CE = 0, SYNC_MLP = 24 };
 unsigned* sync_words();
+// The library's device error word: 4 bytes of pinned, device-mapped host memory.  A kernel that detects a broken device state
+// (today: the optimizer-in-backward arrival barrier timing out, gemm_small.hip) stores a NNHIP_DEVERR_* code there with a
+// system-scope store and carries on WITHOUT its side effect; the host reads the word with a plain load -- no synchronisation --
+// and turns it into the sticky status NNHIP_EDEVICE.  nullptr when the allocation failed (kernels then just skip the store).
+enum DeviceErrorCode { NNHIP_DEVERR_NONE = 0, NNHIP_DEVERR_MLP_BARRIER = 1 };
+unsigned* device_error_word();                   // device-side address
+int device_error_status(const char* who);        // 0, or NNHIP_EDEVICE with the message set
 // Order this launch behind the previous user of the sync words / ticket partials when it arrives on another stream (runtime.hip).
 int serialize_shared_state(hipStream_t st);
 

@@ -86,6 +86,7 @@ struct SmallMlpAdam {
     AdamHyper h;
     float* dev_state; const float* grad_div;
     unsigned* ticket;                                      // a zeroed library word: arrival counter of the launch's blocks
+    unsigned* err;                                         // the library's device error word (host-mapped; runtime.hip)
     double b1, b2;
     int enabled;
 };
@@ -285,10 +286,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_small_mlp_bwd_kernel(const Small
         }
         // The host only launches this variant when every block that polls fits on the chip next to blocks that wait for nobody
         // (mlp_adam_grid_fits below), so "everybody is here" must come true; several seconds without it means the device state
-        // is broken (a stale ticket bank, a foreign writer).  Skipping the W2 / b2 update silently would leave the optimizer
-        // half-stepped and the banks dirty for the next launch (advisor, round 3): abort the kernel instead -- the host sees
-        // hipErrorLaunchFailure at its next synchronisation.
-        if (!ok) __builtin_trap();
+        // is broken (a stale ticket bank, a foreign writer).  The block then SKIPS its update and raises the library's device
+        // error word (pinned host memory, runtime.hip): the launch ends normally, the context survives, and every later library
+        // entry that checks the word -- this entry's next call, the optimizer's step, nnhipDeviceError() -- answers
+        // NNHIP_EDEVICE until nnhipClearDeviceError() (round-5 review: a status code, not __builtin_trap()).  The reference's
+        // error convention for the same class of failure is printf + exit(1) (linear_cublaslt_no_manual_mem.cu:91-94).
+        if (!ok && lane == 0 && ad.err)
+            __hip_atomic_store(ad.err, (unsigned)NNHIP_DEVERR_MLP_BARRIER, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return ok;
     };
     if (stepper_blk) {
@@ -413,6 +417,8 @@ int gemm_small_mlp_backward_adam(const float* X1, const float* H, const float* W
     unsigned* sync = sync_words();
     if (!sync) { set_last_error("mlp backward: sync words allocation failed"); return NNHIP_ENOMEM; }
     ad.ticket = sync + SYNC_MLP;
+    ad.err = device_error_word();
+    if (int rc = device_error_status("nnhipLinearReLULinearBackwardAdam")) return rc;   // an earlier launch timed out: say so, do not pile on
     if (int rc = serialize_shared_state(st)) return rc;     // one arrival board per process (runtime.hip)
     if (int rc = fused_optimizer_state(opt, step, &ad.dev_state, &ad.grad_div)) return rc;
     return gemm_small_mlp_backward(X1, H, W2, dO, dW2, db2, dW1, db1, rows, in1, hid, out2, st, &ad);

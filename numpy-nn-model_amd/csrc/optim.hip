@@ -211,6 +211,7 @@ extern "C" int nnhipFusedAdamWMultiTensorStep(void* opt, int32_t n_tensors, floa
                                               double eps, double weight_decay, int32_t step,
                                               int32_t decay_mode, float grad_scale, nnhipStream_t s) {
     NNHIP_CHECK_ARG(opt != nullptr, NNHIP_EINVAL, "nnhipFusedAdamWMultiTensorStep: null optimizer handle");
+    if (int rc = device_error_status("nnhipFusedAdamWMultiTensorStep")) return rc;     // an earlier kernel raised the device error word
     NNHIP_CHECK_ARG(n_tensors >= 0 && step >= 0, NNHIP_EINVAL, "nnhipFusedAdamWMultiTensorStep: bad n_tensors/step");
     NNHIP_CHECK_ARG(decay_mode == 0 || decay_mode == 1, NNHIP_EINVAL, "nnhipFusedAdamWMultiTensorStep: decay_mode must be 0 or 1");
     if (n_tensors == 0) return 0;

@@ -99,6 +99,40 @@ int serialize_shared_state(hipStream_t st) {
     return 0;
 }
 
+static unsigned* g_deverr_host = nullptr;
+static unsigned* g_deverr_dev = nullptr;
+static void device_error_init() {
+    static std::once_flag once;
+    std::call_once(once, []() {
+        void* h = nullptr;
+        void* d = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return; }
+        memset(h, 0, 64);
+        if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h); return; }
+        g_deverr_host = static_cast<unsigned*>(h);
+        g_deverr_dev = static_cast<unsigned*>(d);
+    });
+}
+unsigned* device_error_word() {
+    device_error_init();
+    return g_deverr_dev;
+}
+static const char* device_error_text(unsigned code) {
+    switch (code) {
+        case NNHIP_DEVERR_MLP_BARRIER:
+            return "the optimizer-in-backward launch (nnhipLinearReLULinearBackwardAdam) waited 20 s for its blocks to check in and gave up: "
+                   "the W2 / b2 update of that step was skipped, the optimizer state is half-stepped";
+        default: return "unknown device error code";
+    }
+}
+int device_error_status(const char* who) {
+    if (!g_deverr_host) return 0;
+    const unsigned code = *const_cast<volatile unsigned*>(g_deverr_host);
+    if (code == NNHIP_DEVERR_NONE) return 0;
+    set_last_error("%s: device error %u raised by an earlier kernel -- %s (nnhipClearDeviceError() resets it)", who, code, device_error_text(code));
+    return NNHIP_EDEVICE;
+}
+
 unsigned* sync_words() {
     static unsigned* w = nullptr;
     static std::once_flag once;
@@ -113,7 +147,26 @@ unsigned* sync_words() {
 
 }  // namespace nnhip
 
-extern "C" int nnhipVersion(void) { return 209; }
+extern "C" int nnhipVersion(void) { return 210; }
+
+extern "C" int nnhipDeviceError(void) { return nnhip::device_error_status("nnhipDeviceError"); }
+
+extern "C" int nnhipClearDeviceError(void) {
+    if (nnhip::g_deverr_host) *const_cast<volatile unsigned*>(nnhip::g_deverr_host) = 0u;
+    return 0;
+}
+
+// test hook: raise a device error code the way a kernel would (a system-scope store from the device), on `stream`
+__global__ void raise_device_error_kernel(unsigned* err, unsigned code) {
+    if (err) __hip_atomic_store(err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+extern "C" int nnhipRaiseDeviceErrorForTest(int32_t code, nnhipStream_t stream) {
+    unsigned* w = nnhip::device_error_word();
+    if (!w) { nnhip::set_last_error("nnhipRaiseDeviceErrorForTest: no device error word (pinned allocation failed)"); return NNHIP_ENOMEM; }
+    hipLaunchKernelGGL(raise_device_error_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, w, (unsigned)code);
+    NNHIP_LAUNCH_CHECK("raise_device_error_kernel");
+    return 0;
+}
 
 extern "C" int nnhipWorkspaceReserve(int64_t bytes) {
     if (bytes < 0) { nnhip::set_last_error("nnhipWorkspaceReserve: negative size"); return NNHIP_EINVAL; }

@@ -45,6 +45,9 @@ _SIGNATURES = {
     "nnhipVersion": (ctypes.c_int, []),
     "nnhipGetLastErrorString": (ctypes.c_char_p, []),
     "nnhipCleanup": (ctypes.c_int, []),
+    "nnhipDeviceError": (ctypes.c_int, []),
+    "nnhipClearDeviceError": (ctypes.c_int, []),
+    "nnhipRaiseDeviceErrorForTest": (ctypes.c_int, [ctypes.c_int32, ctypes.c_void_p]),
     "nnhipSetGemmMode": (ctypes.c_int, [ctypes.c_int]),
     "nnhipGetGemmMode": (ctypes.c_int, []),
     "nnhipSetGemmLockstep": (ctypes.c_int, [ctypes.c_int]),

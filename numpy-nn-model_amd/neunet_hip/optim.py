@@ -122,6 +122,11 @@ class HIPFusedMultiTensorAdamW:
             if i is None or self.params[i] is not p or not p.data.is_contiguous():
                 return None
             table[3 * k], table[3 * k + 1], table[3 * k + 2] = p.data.data_ptr(), self.m[i].data_ptr(), self.v[i].data_ptr()
+        # the fused kernel reads the divisor from the library handle: a divisor bound by an earlier ordinary step() (clipping
+        # switched on for a few steps, then back to None) must be unbound first -- it may point at freed memory by now
+        if self._bound_divisor is not None:
+            call_hip_function("nnhipFusedOptimizerSetGradDivisor", self.opt_ptr, None)
+            self._bound_divisor = None
         if self.device_step:
             self.sync_device_hyper()
         return (self.opt_ptr, table, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
@@ -169,8 +174,14 @@ class HIPFusedMultiTensorAdamW:
             self._stepped_in_backward = False
             return
         pend = self.params[0]._pending if self.params else None
-        if pend is not None and pend.run_with_update(self, self.t):
-            return                             # the waiting backward launch took the update with it (one kernel, same values)
+        if pend is not None:
+            try:
+                took = pend.run_with_update(self, self.t)
+            except Exception:
+                self.t -= 1                    # nothing was applied: the bias correction must not run one step ahead
+                raise
+            if took:
+                return                         # the waiting backward launch took the update with it (one kernel, same values)
         idx = 0
         keep = []        # contiguous copies of strided gradients must outlive the single launch below: a freed block
         #                  could be handed to the next .contiguous() and two table entries would alias one buffer

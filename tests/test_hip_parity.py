@@ -673,9 +673,30 @@ def test_mlp_backward_waiting_for_the_optimizer_is_unobservable(hip):
     x6 = T(hip, X, requires_grad=False)
     backward(m6, x6)
     x6.data.copy_(dev(X2))
+    t6 = opt6.t
     with pytest.raises(RuntimeError, match="written in place"):
         opt6.step()
     assert all(p._pending is None for p in ps6)
+    assert opt6.t == t6                                      # nothing was applied: the step counter did not run ahead (advisor, round 5)
+    # 6. a gradient divisor switched ON for a step and OFF again (conditional clipping): the fused launch of the third step must not
+    #    divide by the divisor the ordinary step() bound to the library handle (advisor, round 5: a stale, possibly freed, pointer)
+    def three_steps(toggle):
+        m7, ps7, opt7 = build()
+        for k in range(3):
+            backward(m7, T(hip, X if k != 1 else X2, requires_grad=False))
+            if k == 1:
+                if toggle:
+                    opt7.grad_divisor = dev(np.array([4.0], np.float32))
+                else:                                        # the same arithmetic without a divisor: pre-divided gradients
+                    for p in ps7:
+                        p.grad = p.grad / 4.0
+            opt7.step()
+            if toggle and k == 1:
+                opt7.grad_divisor.fill_(1e30)                # what a recycled allocation would hold
+                opt7.grad_divisor = None
+        return [host(p.data).copy() for p in ps7]
+    for a, b in zip(three_steps(True), three_steps(False)):
+        np.testing.assert_allclose(a, b, rtol=2e-6, atol=2e-7)
 
 
 def test_fused_backward_adam_makes_pending_outputs_stale(hip):
@@ -3664,6 +3685,43 @@ def test_error_status_not_exit(hip):
                           get_current_stream_ptr())
     # the library is still usable afterwards
     call_hip_function("nnhipScale", a, 2.0, 16, get_current_stream_ptr())
+
+
+def test_device_error_word_is_a_sticky_status_not_a_trap(hip):
+    """ABI 210 (round-5 review, hygiene): a kernel that finds the device state broken raises the library's device error word
+    (pinned host memory) and ends normally -- no __builtin_trap(), the context survives.  The word is read without synchronising;
+    nnhipDeviceError(), the optimizer step and the optimizer-in-backward entry answer NNHIP_EDEVICE (-5) until
+    nnhipClearDeviceError().  The reference's convention for a failure inside its CUDA path is printf + exit(1)
+    (linear_cublaslt_no_manual_mem.cu:91-94)."""
+    import neunet_hip.nn as nn
+    from neunet_hip._lib import NeunetHipError, call_hip_function, get_current_stream_ptr, load_hip_function
+    from neunet_hip.optim import Adam
+    assert load_hip_function("nnhipDeviceError")() == 0
+    np.random.seed(1)
+    lin = nn.Linear(64, 64)
+    opt = Adam(lin.parameters(), lr=1e-3)
+    x = T(hip, np.ones((128, 64), np.float32), requires_grad=False)
+    lin(x).backward(np.ones((128, 64), np.float32))
+    opt.step()                                               # fine
+    before = [host(p.data).copy() for p in lin.parameters()]
+    call_hip_function("nnhipRaiseDeviceErrorForTest", 1, get_current_stream_ptr())
+    torch.cuda.synchronize()                                 # (only so that the test knows the store has landed)
+    try:
+        assert load_hip_function("nnhipDeviceError")() == -5
+        with pytest.raises(NeunetHipError, match="device error 1"):
+            call_hip_function("nnhipDeviceError")
+        lin(x).backward(np.ones((128, 64), np.float32))
+        with pytest.raises(NeunetHipError, match="status -5"):
+            opt.step()
+        for a, p_ in zip(before, lin.parameters()):          # the refused step touched nothing
+            np.testing.assert_array_equal(a, host(p_.data))
+    finally:
+        load_hip_function("nnhipClearDeviceError")()
+    assert load_hip_function("nnhipDeviceError")() == 0
+    opt.zero_grad()
+    lin(x).backward(np.ones((128, 64), np.float32))
+    opt.step()                                               # the context is alive and the library usable
+    assert np.isfinite(host(lin.parameters()[0].data)).all()
 
 
 def test_dropout_mask_and_rng(hip):
