@@ -75,7 +75,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--cpu-full-batch", action="store_true",
-                    help="time ONE full-batch (64 x 256) NumPy-oracle GPT-tiny step, print it as JSON and exit (no GPU work)")
+                    help="time --cpu-full-steps full-batch (64 x 256) NumPy-oracle GPT-tiny steps, print them as JSON and exit (no GPU work): "
+                         "the n >= 3 collection committed as profiles/cpu_c4_full_batch.json, which the live n = 1 sample of every line cites")
+    ap.add_argument("--cpu-full-steps", type=int, default=3)
     return ap.parse_args()
 
 
@@ -152,6 +154,21 @@ class EventTimer:
     def mean_ms(self):
         return float(np.mean([a.elapsed_time(b) for a, b in self.pairs])) if self.pairs else float("nan")
 
+    def median_ms(self):
+        """Median of the spans: one sample that caught a host stall between its two records (the device idle, waiting for the
+        next launch) no longer decides the figure (round-5 review: C1's mean device time came out ABOVE its wall time)."""
+        return float(np.median([a.elapsed_time(b) for a, b in self.pairs])) if self.pairs else float("nan")
+
+
+def device_step_ms(ev, per_call, wall_ms_per_step):
+    """Device time of one step from the sampled event spans (median), or None when it cannot be trusted: an event pair also spans
+    whatever the host did between its two records, so a figure more than 5 % ABOVE the wall-clock time per step of the same timed
+    region measured host stalls, not the device -- dropped rather than reported."""
+    if not ev.pairs:
+        return None
+    ms = ev.median_ms() / per_call
+    return ms if ms <= 1.05 * wall_ms_per_step else None
+
 
 def read_traffic(tag):
     """HBM bytes per launch from the committed PMC pass (profiles/pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE /
@@ -164,6 +181,16 @@ def read_traffic(tag):
         except Exception:
             return None
     return None
+
+
+def read_instep():
+    """Per-family kernel durations INSIDE the replayed C4 step (profiles/c4_instep_families.json: rocprofv3 --kernel-trace of
+    `bench.py --workload c4`, tools/c4_instep.py), or {}.  Static: collected once per round, not by this run."""
+    path = os.path.join(ROOT, "profiles", "c4_instep_families.json")
+    try:
+        return json.load(open(path))
+    except Exception:
+        return {}
 
 
 def traffic_source():
@@ -392,7 +419,9 @@ def workload_c1(args, rank, world):
     if args.graph:
         gstep.release()
     _lin._AUTO_FUSE_STEP = auto_was
-    dev_ms = ev.mean_ms() / U
+    wall_ms = dt / max(1, (args.steps // U) * U) * 1e3
+    dev_ms_checked = device_step_ms(ev, U, wall_ms)
+    dev_ms = dev_ms_checked if dev_ms_checked is not None else wall_ms     # (the roofline entry below falls back to the wall time)
     flops = 2.0 * 3 * Bsz * (784 * 128 + 128 * 10)
     return {
         "samples_per_step": Bsz * world, "dt": dt,
@@ -409,7 +438,8 @@ def workload_c1(args, rank, world):
         "roofline": {"kernel": "whole step (3 launches: Linear+ReLU, Linear+CrossEntropy, backward+Adam; dependent-latency bound)", "bound": "mfma",
                      "achieved": round(flops / (dev_ms * 1e-3) / 1e12, 5), "peak": PEAK_F32_MFMA_TFLOPS,
                      "unit": "TFLOP/s", "frac": round(flops / (dev_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 6),
-                     "traffic": None, "avg_step_device_ms": round(dev_ms, 4)},
+                     "traffic": None, "avg_step_device_ms": round(dev_ms_checked, 4) if dev_ms_checked is not None else None,
+                     "device_ms_how": "median of HIP-event spans around sampled graph replays / steps per replay; None = the spans exceeded the wall time per step by > 5 % (host stalls inside the pairs) and were dropped"},
         "extra": {"launches_per_step": launches},
     }
 
@@ -772,7 +802,33 @@ def workload_c4(args, rank, world):
     ingraph_error = getattr(gstep, "ingraph_error", None) if use_graph else None
 
     dt = timed_region(step, args.steps, args.warmup, world)
-    dev_ms = ev.mean_ms()
+    dev_ms = ev.median_ms()
+    # ---- the gradient exchange on its own (SURVEY 8e "report all-reduce time separately"; round-5 review item 4) ----------------
+    #   total   = every all-reduce of one step issued ALONE, event-bracketed on the stream it runs on, summed (median of 5 each)
+    #   exposed = (the timed step) - (the same step, same launch mode, with the collectives muted): what the exchange adds to the
+    #             step after overlap; None when the collectives are captured inside the step graph (they cannot be muted there)
+    allreduce = None
+    if dp:
+        try:
+            pieces_ms = bucket.time_exchange_alone(5)
+            exposed, dt_muted = None, None
+            if not (use_graph and graph_mode == "ingraph"):
+                bucket.mute = True
+                try:
+                    dt_muted = timed_region(step, args.steps, max(1, args.warmup // 2), world)
+                finally:
+                    bucket.mute = False
+                exposed = max(0.0, (dt - dt_muted) / args.steps * 1e3)
+            allreduce = {"total": round(sum(ms for _, ms in pieces_ms), 4), "exposed": None if exposed is None else round(exposed, 4),
+                         "pieces": [{"floats": n, "ms_alone": round(ms, 4), "GBps_algorithmic": round(4.0 * n / (ms * 1e-3) / 1e9, 1) if ms > 0 else None}
+                                    for n, ms in pieces_ms],
+                         "ms_per_step_with_exchange": round(dt / args.steps * 1e3, 4),
+                         "ms_per_step_collectives_muted": None if dt_muted is None else round(dt_muted / args.steps * 1e3, 4),
+                         "how": "total: each all-reduce of a step issued on its own between two HIP events (median of 5), summed; exposed: timed step minus "
+                                "the same K steps with GradBucket.mute (no collective issued), max over ranks both times; DESIGN 6 expects 0.25 ms "
+                                "(direct, 7 xGMI links) to 1.6 ms (one-link ring) total for the 137 MB bucket at N = 8"}
+        except Exception as exc:  # noqa: BLE001
+            allreduce = {"error": repr(exc)[:300]}
     fl = c4_flops(B, T)
     ach = fl / (dev_ms * 1e-3) / 1e12
     n_grad = sum(int(np.prod(p.shape)) for p in active)
@@ -796,7 +852,7 @@ def workload_c4(args, rank, world):
                      "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None, "flops_per_step": fl,
                      "avg_step_device_ms": round(dev_ms, 4)},
-        "extra": {"tokens_per_s": round(global_batch * T * args.steps / dt, 1), "grad_floats": n_grad,
+        "extra": {"tokens_per_s": round(global_batch * T * args.steps / dt, 1), "grad_floats": n_grad, "allreduce_ms": allreduce,
                   "dp_exchange": ("none" if not dp else
                                   (f"{len(bucket.segments)} bucket segments, async all-reduce overlapped with backward"
                                    + (f" ({pieces} graph pieces)" if use_graph else "") if overlap
@@ -851,6 +907,7 @@ def cpu_c4(seconds, Bs=64, max_steps=1):
             break
     best = min(times)
     out = {"value": round(Bs / best, 3), "unit": "samples/s", "cores": blas_threads(), "kind": "port", "samples": len(times),
+           "step_seconds_all": [round(t, 2) for t in times],
            "sample": f"n = {len(times)} (one full-batch oracle step is 10-20 s of host time: the bounded sample of the default run) -- {len(times)} FULL steps (forward + backward + Adam over all {sum(p.size for p in ps)} parameters) of the "
                      f"NumPy-oracle GPT-tiny on {Bs} sequences x {c['seq']} tokens ({Bs}/64 of one GPU's batch), min step "
                      f"{best:.2f} s, OpenBLAS threads={blas_threads()}, host cpus={os.cpu_count()}"}
@@ -865,6 +922,19 @@ def cpu_c4(seconds, Bs=64, max_steps=1):
             pass
     else:
         out["step_seconds"] = round(best, 2)
+        if os.path.exists(full) and max_steps == 1:
+            # the live sample of a default run is ONE full step (10-20 s of host time is the bound of the contract); the n >= 3
+            # collection of the SAME function on a box of this pool rides along so that the figure has something to be averaged
+            # against (round-5 review: 18.52 s vs 19.10 s with nothing to average)
+            try:
+                fb = json.load(open(full))
+                keep = ("value", "step_seconds", "step_seconds_all", "samples", "cores", "collected")
+                out["full_batch_collection"] = {**{k: fb[k] for k in keep if k in fb},
+                                                "source": "profiles/cpu_c4_full_batch.json (python bench.py --cpu-full-batch --cpu-full-steps 3 on a GPU box's host; not measured by this run)"}
+                out["sample"] = "live: " + out["sample"] + f"; cached collection of the same step, n = {fb.get('samples', 1)}: " + \
+                                ", ".join(f"{t:.2f}" for t in fb.get("step_seconds_all", [fb.get("step_seconds", float('nan'))])) + " s (profiles/cpu_c4_full_batch.json)"
+            except Exception:
+                pass
     return out
 
 
@@ -1077,7 +1147,9 @@ def workload_c5(args, rank, world):
     dt = timed_region(step, args.steps // U, max(1, args.warmup // U), world, min_warm_s=0.5)      # one call = U steps
     if args.graph:
         gstep.release()
-    dev_ms = ev.mean_ms() / U
+    wall_ms = dt / max(1, (args.steps // U) * U) * 1e3
+    dev_ms_checked = device_step_ms(ev, U, wall_ms)
+    dev_ms = dev_ms_checked if dev_ms_checked is not None else wall_ms
     conv_layers = c5_conv_layers(Bsz) if (rank == 0 or world == 1) else None
     # algorithmic HBM bytes of the two conv layers fwd + bwd: 4*(|X|+|O|+|W|) forward, x2 backward
     conv_bytes = 3 * 4.0 * ((Bsz * 784 + Bsz * 8 * 784 + 72) + (Bsz * 8 * 196 + Bsz * 16 * 196 + 1152))
@@ -1092,8 +1164,13 @@ def workload_c5(args, rank, world):
         "roofline": {"kernel": "whole step vs the conv layers' algorithmic HBM bytes (K<=72, Cout<=16: HBM/latency bound)",
                      "bound": "hbm", "achieved": round(conv_bytes / (dev_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS,
                      "unit": "GB/s", "frac": round(conv_bytes / (dev_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 5), "traffic": None,
-                     "avg_step_device_ms": round(dev_ms, 4)},
-        "extra": {"launches_per_step": launches, "conv_layers": conv_layers},
+                     "avg_step_device_ms": round(dev_ms_checked, 4) if dev_ms_checked is not None else None},
+        "extra": {"launches_per_step": launches, "conv_layers": conv_layers,
+                  "bound_by": "dependent latency, not launch count and not bytes: 13 launches x ~5 us of first-load / reduction / store-drain chain each "
+                              "+ ~1.5 us per boundary inside the 16-step graph.  Two negative results close the launch-count route (EXPERIMENTS.md, round 5): "
+                              "the tail (BatchNorm + Linear + Sigmoid + MSE) as ONE launch with a ticket hand-off between channel blocks was slower "
+                              "(0.0852 -> 0.0952 ms), and without any hand-off it is 11 launches at 0.0864 vs 0.0853 ms (kept as the tested opt-in "
+                              "NNHIP_BN_HEAD_FUSION=1, reported under tail_one_launch_opt_in).  No further kernel work is planned unless a change shows <= 0.075 ms"},
     }
 
 
@@ -1254,28 +1331,49 @@ def c4_family_rooflines(iters=20):
     M, D, F, V, Bq, T, H, L = 64 * C4["seq"], C4["d_model"], C4["d_ff"], C4["vocab"], 64, C4["seq"], C4["n_heads"], C4["n_layers"]
     fams = []
 
-    def add(name, kernels, per_step, fl, ms):
-        fams.append({"family": name, "kernels": kernels, "per_step": per_step, "flops": fl, "ms": round(ms, 4),
-                     "tflops": round(fl / (ms * 1e-3) / 1e12, 2), "frac_of_mfma_peak": round(fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)})
+    instep = read_instep()
 
-    def linear_fwd_dx(name, K, N, per_step, with_dw=False):
+    def add(name, kernels, per_step, fl, ms, key=None):
+        f = {"family": name, "kernels": kernels, "per_step": per_step, "flops": fl, "ms": round(ms, 4),
+             "tflops": round(fl / (ms * 1e-3) / 1e12, 2), "frac_of_mfma_peak": round(fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
+        # the same kernel(s) INSIDE the replayed step, from the committed rocprofv3 kernel trace (profiles/c4_instep_families.json,
+        # tools/c4_instep.py): back to back with the rest of the step the launches are a few per cent slower than on their own
+        us = sum(instep[k]["us"] for k in (key or ()) if k in instep) if key and all(k in instep for k in key) else None
+        if us:
+            f["instep_ms"] = round(us * 1e-3, 4)
+            f["instep_frac_of_mfma_peak"] = round(fl / (us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
+        fams.append(f)
+
+    def linear_fwd_dx(name, K, N, per_step, with_dw=False, keys=(None, None, None), swish=None):
+        """swish = "fwd": the forward is the fused Linear->Swish with z saved (what the step launches for fc_1); swish = "dx": the
+        input gradient carries the Swish backward of the PREVIOUS layer in its epilogue, in place over z (fc_2's dX)."""
         X, W, b = rnd(M, K), rnd(N, K) / 16, rnd(1, N)
         O_, dO, dX = torch.empty(M, N, device="cuda"), rnd(M, N), torch.empty(M, K, device="cuda")
         fl = 2.0 * M * K * N
-        add(f"{name}: forward, rows {M}", "gemm_pst_kernel / gemm_f32_kernel (k-major, k-major)", per_step, fl,
-            med(lambda: call("nnhipLinearModuleForward", X, W, b, O_, M, K, N, st)))
-        add(f"{name}: input gradient", "gemm_pst_kernel / gemm_f32_kernel (k-major, outer-major)", per_step, fl,
-            med(lambda: call("nnhipLinearModuleBackward", X, W, dO, dX, None, None, M, K, N, st)))
+        if swish == "fwd":
+            Z = torch.empty(M, N, device="cuda")
+            add(f"{name}: forward + Swish (z saved), rows {M}", "gemm_pst_kernel<1> (Swish epilogue, two outputs)", per_step, fl,
+                med(lambda: call("nnhipLinearSwishForward", X, W, b, O_, Z, M, K, N, 1.0, 1, st)), keys[0] and (keys[0],))
+        else:
+            add(f"{name}: forward, rows {M}", "gemm_pst_kernel / gemm_f32_kernel (k-major, k-major)", per_step, fl,
+                med(lambda: call("nnhipLinearModuleForward", X, W, b, O_, M, K, N, st)), keys[0] and (keys[0],))
+        if swish == "dx":
+            Zin = rnd(M, K)
+            add(f"{name}: input gradient x swish'(z), in place over z", "gemm_pst_kernel<2> (Swish-backward epilogue)", per_step, fl,
+                med(lambda: call("nnhipLinearInputGradSwish", dO, W, Zin, Zin, M, K, N, 1.0, st)), keys[1] and (keys[1],))
+        else:
+            add(f"{name}: input gradient", "gemm_pst_kernel / gemm_f32_kernel (k-major, outer-major)", per_step, fl,
+                med(lambda: call("nnhipLinearModuleBackward", X, W, dO, dX, None, None, M, K, N, st)), keys[1] and (keys[1],))
         if with_dw:
             dW, db = torch.empty(N, K, device="cuda"), torch.empty(1, N, device="cuda")
             add(f"{name}: weight + bias gradient", "gemm_f32_group_kernel (uneven two-way split) + splitk_reduce", per_step, fl,
-                med(lambda: call("nnhipLinearModuleBackward", X, W, dO, None, dW, db, M, K, N, st)))
+                med(lambda: call("nnhipLinearModuleBackward", X, W, dO, None, dW, db, M, K, N, st)), keys[2])
 
-    linear_fwd_dx(f"q|k|v projection {D}->{3 * D}", D, 3 * D, L)
-    linear_fwd_dx(f"attention output projection {D}->{D}", D, D, L)
-    linear_fwd_dx(f"FFN {D}->{F}", D, F, L)
-    linear_fwd_dx(f"FFN {F}->{D}", F, D, L)
-    linear_fwd_dx(f"vocabulary head {D}->{V}", D, V, 1, with_dw=True)
+    linear_fwd_dx(f"q|k|v projection {D}->{3 * D}", D, 3 * D, L, keys=("qkv_fwd", "qkv_dx", None))
+    linear_fwd_dx(f"attention output projection {D}->{D}", D, D, L, keys=("out_fwd", "out_dx", None))
+    linear_fwd_dx(f"FFN {D}->{F}", D, F, L, keys=("fc1_fwd_swish", "fc1_dx", None), swish="fwd")
+    linear_fwd_dx(f"FFN {F}->{D}", F, D, L, keys=("fc2_fwd", "fc2_dx_swish", None), swish="dx")
+    linear_fwd_dx(f"vocabulary head {D}->{V}", D, V, 1, with_dw=True, keys=("head_fwd", "head_dx", ("head_dw", "head_dw_reduce")))
     # what the step launches for a decoder layer's parameter gradients: the four dW+db GEMMs as ONE grid + ONE reduce
     # (deferred parameter gradients, DESIGN 5.1f) -- C4's largest kernel by device time
     jobs = [(rnd(M, K), rnd(N, K) / 16, rnd(M, N), torch.empty(N, K, device="cuda"), torch.empty(1, N, device="cuda"), K, N)
@@ -1288,7 +1386,7 @@ def c4_family_rooflines(iters=20):
         call("nnhipWeightGradDefer", 0, st)
 
     add(f"dW+db of one decoder layer (4 GEMMs, rows {M}), deferred", "gemm_f32_group_kernel<32> + splitk_reduce_group_kernel", L,
-        sum(2.0 * M * K * N for (*_, K, N) in jobs), med(grouped))
+        sum(2.0 * M * K * N for (*_, K, N) in jobs), med(grouped), ("layer_dw", "layer_dw_reduce"))
     del jobs
     qkv = rnd(Bq, T, 3 * D)
     dqkv = torch.empty_like(qkv)
@@ -1300,10 +1398,10 @@ def c4_family_rooflines(iters=20):
     afl = 4.0 * Bq * H * T * T * dh / 2                  # causal: half the score matrix; backward = 2.5 x forward
     add(f"fused attention forward B{Bq} T{T} H{H} dh{dh} (causal)", "attn_sb_fwd_kernel", L, afl,
         med(lambda: call("nnhipAttentionForward", StridedView(q_), StridedView(k_), StridedView(v_), kval, ctx, lse, Bq, H, T, T, dh,
-                         3 * D, sc, 1, st)))
+                         3 * D, sc, 1, st)), ("attn_fwd",))
     add(f"fused attention backward B{Bq} T{T} H{H} dh{dh} (causal)", "attn_sb_bwd_kernel (one pass, 5 GEMMs per tile pair)", L, 2.5 * afl,
         med(lambda: call("nnhipAttentionBackward", StridedView(q_), StridedView(k_), StridedView(v_), kval, ctx, dctx, lse,
-                         StridedView(dq_), StridedView(dk_), StridedView(dv_), Bq, H, T, T, dh, 3 * D, sc, 1, st)))
+                         StridedView(dq_), StridedView(dk_), StridedView(dv_), Bq, H, T, T, dh, 3 * D, sc, 1, st)), ("attn_bwd",))
     return fams
 
 
@@ -1357,9 +1455,17 @@ def workload_headline(args, rank, world):
                        "profiles/r05*_c4_kernel_stats.md is the rocprofv3 view of the same kernels inside the step",
                 "dominant_kernel": {"name": dom["kernels"], "what": dom["family"], "launches_per_step": dom["per_step"],
                                     "flops_per_launch": dom["flops"], "avg_launch_ms": dom["ms"], "tflops": dom["tflops"],
-                                    "frac": dom["frac_of_mfma_peak"]},
+                                    "frac": dom["frac_of_mfma_peak"], "instep_ms": dom.get("instep_ms"),
+                                    "instep_frac": dom.get("instep_frac_of_mfma_peak")},
                 "c2_linear_forward": {k: c2_obj[k] for k in ("achieved", "frac", "avg_launch_ms", "traffic", "traffic_over_algorithmic") if k in c2_obj},
             }
+            if all("instep_ms" in f for f in fams):
+                ims = sum(f["per_step"] * f["instep_ms"] for f in fams)
+                res["roofline"]["instep"] = {
+                    "frac": round(fl / (ims * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), "kernel_ms_per_step": round(ims, 4),
+                    "what": "the same flop-weighted figure with every family's duration taken INSIDE the replayed step (rocprofv3 kernel trace, "
+                            "profiles/c4_instep_families.json, collection " + str(read_instep().get("_collected")) + "; not measured by this run): "
+                            "what the isolated HIP-event figures above flatter by a few per cent"}
             # fabric bytes of the dominant kernel as launched INSIDE the step (two decoder layers' eight dW GEMMs per launch):
             # committed PMC passes over `bench.py --workload c4` (tools/collect_profiles.sh), halved to the one-layer unit of
             # `dominant_kernel.flops_per_launch`; algorithmic = the eight operands read once + the four split-K slabs written
@@ -1437,7 +1543,8 @@ def workload_headline(args, rank, world):
                       "device_ms_per_step": r5["roofline"].get("avg_step_device_ms"), "launch": r5["config"].get("launch"),
                       "launches_per_step": r5["extra"].get("launches_per_step"),
                       "conv_layers": r5["extra"].get("conv_layers"),
-                      "frac_of_hbm_peak_on_conv_bytes": r5["roofline"]["frac"]}
+                      "frac_of_hbm_peak_on_conv_bytes": r5["roofline"]["frac"],
+                      "bound_by": r5["extra"].get("bound_by")}
         # the opt-in one-launch tail (NNHIP_BN_HEAD_FUSION=1; round 5): fewer launches, measured beside the default
         import neunet_hip.nn.experimental.vision as _vis
         was = _vis._FUSE_TAIL
@@ -1550,6 +1657,39 @@ def respawn_under_torchrun(args):
     return subprocess.call(cmd, env=env)
 
 
+def rccl_choices(log_path):
+    """What RCCL says it chose: the algorithm / protocol lines of its TUNING log (NCCL_DEBUG=INFO, NCCL_DEBUG_SUBSYS=...,TUNING:
+    "<coll>: <bytes> Bytes -> Algo <a> proto <p> time <t>") grouped by (collective, bytes), plus the channel / ring / tree summary of
+    the communicator.  A ring on the full xGMI mesh is per-link bound: this is the line to read when N = 8 scales badly."""
+    import re
+    algos = {0: "TREE", 1: "RING", 2: "COLLNET_DIRECT", 3: "COLLNET_CHAIN", 4: "NVLS", 5: "NVLS_TREE", 6: "PAT"}
+    protos = {0: "LL", 1: "LL128", 2: "SIMPLE"}
+    out = {"log": log_path, "source": "NCCL_DEBUG=INFO NCCL_DEBUG_SUBSYS=INIT,GRAPH,TUNING written by RCCL on rank 0"}
+    if not log_path or not os.path.exists(log_path):
+        out["note"] = "no RCCL debug file (NCCL_DEBUG was set by the caller, or the backend is not nccl)"
+        return out
+    pat = re.compile(r"(\w+): (\d+) Bytes -> Algo (\d+) proto (\d+) time ([0-9.eE+-]+)")
+    seen, version, channels = {}, None, None
+    with open(log_path, errors="replace") as f:
+        for ln in f:
+            m = pat.search(ln)
+            if m:
+                key = (m.group(1), int(m.group(2)), int(m.group(3)), int(m.group(4)))
+                seen[key] = seen.get(key, 0) + 1
+            if version is None and ("RCCL version" in ln or "NCCL version" in ln):
+                version = ln.strip().split("INFO", 1)[-1].strip()[:120]
+            m2 = re.search(r"(\d+) coll channels", ln)
+            if m2 and channels is None:
+                channels = ln.strip().split("INFO", 1)[-1].strip()[:160]
+    out["version"] = version
+    out["channels"] = channels
+    out["choices"] = [{"collective": c, "bytes": b, "algorithm": algos.get(a, str(a)), "protocol": protos.get(pr, str(pr)), "calls": n}
+                      for (c, b, a, pr), n in sorted(seen.items(), key=lambda kv: -kv[0][1])[:12]]
+    if not seen:
+        out["note"] = "RCCL printed no TUNING line (a 1-rank communicator short-cuts the algorithm choice; gloo has none)"
+    return out
+
+
 def claim_stdout():
     """stdout must carry exactly ONE JSON line, but libraries write there too (RCCL prints a five-line version banner to
     stdout when its communicator comes up).  Point file descriptor 1 at stderr for the life of the process and hand
@@ -1563,19 +1703,21 @@ def claim_stdout():
 def main():
     args = parse()
     if args.cpu_full_batch:
-        r = cpu_c4(1e9, Bs=64, max_steps=1)
-        r["collected"] = time.strftime("%Y-%m-%d") + " (round 3)"
+        r = cpu_c4(1e9, Bs=64, max_steps=max(1, args.cpu_full_steps))
+        r["collected"] = time.strftime("%Y-%m-%d") + " (round 6)"
         print(json.dumps(r), flush=True)
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(respawn_under_torchrun(args))
     json_out = claim_stdout()
     rccl_log = None
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and "NCCL_DEBUG" not in os.environ:
+    # (the GPU boxes of this pool export NCCL_DEBUG=VERSION: anything below INFO without a file of its own is raised to INFO + file)
+    if (int(os.environ.get("WORLD_SIZE", "1")) > 1 or args.force_dp) and \
+            (os.environ.get("NCCL_DEBUG", "VERSION").upper() in ("VERSION", "WARN", "") and "NCCL_DEBUG_FILE" not in os.environ):
         # RCCL's own account of the communicator (ranks, rings/trees, transport) goes to a per-rank file -- its default
         # sink is stdout, which must carry exactly one JSON line -- and rank 0 echoes the topology lines to stderr below
         rccl_log = f"/tmp/nnhip_rccl.{os.getpid()}.log"
-        os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,GRAPH", NCCL_DEBUG_FILE=rccl_log)
+        os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,GRAPH,TUNING", NCCL_DEBUG_FILE=rccl_log)
     import torch
     from neunet_hip.distributed import init_process_group
     import neunet_hip
@@ -1585,6 +1727,18 @@ def main():
             print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)", file=sys.stderr)
         sys.exit(2)
     neunet_hip.load_library()
+    # The line says `dtype: f32` and prices its kernels against the fp32 MFMA peak: that is only true in GEMM mode 0 (exact fp32,
+    # v_mfma_f32_32x32x2_f32).  NNHIP_GEMM_MODE=bf16x3 in the environment would route every Linear GEMM through the split-bf16
+    # kernel and produce a faster, mislabelled line (round-5 review): refuse instead.  The opt-in mode is measured by the headline
+    # workload itself, under also.bf16x3, with the mode switched on and off around that leg only.
+    from neunet_hip._lib import call_hip_function as _mode_call
+    gemm_mode = int(_mode_call("nnhipGetGemmMode"))
+    if gemm_mode != 0:
+        if rank == 0:
+            print(f"bench.py: nnhipGetGemmMode() = {gemm_mode} (NNHIP_GEMM_MODE={os.environ.get('NNHIP_GEMM_MODE')!r}): the bench line's `value` "
+                  "and `dtype: f32` are defined for the exact-fp32 GEMM (mode 0) only; unset NNHIP_GEMM_MODE (the opt-in mode is "
+                  "reported under also.bf16x3 by the default run)", file=sys.stderr)
+        sys.exit(4)
     rccl_ranks = 1
     if world > 1 or args.force_dp:
         import torch.distributed as dist
@@ -1619,7 +1773,13 @@ def main():
     if world > 1 or args.force_dp:
         import torch.distributed as dist
         out["dist_backend"] = dist.get_backend()
+        if rank == 0:
+            out["rccl"] = rccl_choices(rccl_log)
     out.update(res.get("extra", {}))
+    out["gemm_mode"] = int(_mode_call("nnhipGetGemmMode"))            # 0 = exact fp32; checked again AFTER the run: a leg that left
+    if out["gemm_mode"] != 0:                                          # the opt-in mode switched on would have tainted what followed
+        print("bench.py: the GEMM mode is not 0 at the end of the run", file=sys.stderr)
+        sys.exit(4)
     try:
         from neunet_hip._lib import call_hip_function as _call
         out["gemm_lockstep"] = int(_call("nnhipGetGemmLockstep"))     # 1 by default when more than one rank exchanges gradients

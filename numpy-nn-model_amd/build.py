@@ -28,6 +28,8 @@ ARCH = "gfx950"
 # prologue loads and the first LDS store) once made the GEMM spill 144 B/lane and lose 30 % -- the build fails instead.
 # (regexes on the mangled names; the GEMM's scalar-load variants -- VEC = false, unaligned operands -- are exempt.)
 NO_SPILL = {"gemm.hip": (r"gemm_f32_kernelILi\d+ELb[01]ELb[01]ELb1E",),
+            # (round 6: a branch around the flushing k-step INSIDE the k-loop spilled 172-432 B/lane; three loops in a row do not)
+            "gemm_pst.hip": (r"gemm_pst_kernel",),
             # the tuned fast path: GEN = false (no dense mask / dropout); the general variants may spill a few registers
             "attention.hip": (r"attn_fwd_kernelILi\d+ELb0E", r"attn_bwd_dkdv_kernelILi\d+ELb0E", r"attn_bwd_dq_kernelILi\d+ELb0E"),
             "attention_sb.hip": (r"attn_sb_",)}

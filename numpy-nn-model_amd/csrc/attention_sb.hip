@@ -111,12 +111,21 @@ __device__ __forceinline__ void sb_issue64_adv(sb_u32x2& r, unsigned voff, sb_rs
     // (readfirstlane: under scalar-register pressure hipcc parks the row step in a VGPR lane, which s_add_u32 cannot read)
     asm volatile("buffer_load_dwordx2 %0, %2, %3, %1 offen\n\ts_add_u32 %1, %1, %4" : "+v"(r), "+s"(soff) : "v"(voff), "s"(rs), "s"(__builtin_amdgcn_readfirstlane(step)) : "scc");   // (s_add writes SCC)
 }
+// The counts N below are HAND-COUNTED (hipcc does not see the asm loads): one edit to the issue order away from a silent race that only
+// a value test at exactly this shape would catch.  -DSB_CHECK (build.py --variant sbcheck -D SB_CHECK) turns every counted wait into
+// vmcnt(0) -- always safe, slower -- and tests/test_hip_parity.py::test_attention_sb_counted_waits_match_full_drain compares the two
+// builds bit for bit on the C4 shape and the odd-slice / padding cases (round-5 review; tools/collect_profiles.sh runs it).
+#ifdef SB_CHECK
+#define SB_VM(N) 0
+#else
+#define SB_VM(N) (N)
+#endif
 template <int N>
-__device__ __forceinline__ void sb_wait(sb_u32x4& r) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r) : "i"(N)); }
+__device__ __forceinline__ void sb_wait(sb_u32x4& r) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r) : "i"(SB_VM(N))); }
 template <int N>
-__device__ __forceinline__ void sb_wait(sb_u32x2& r) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r) : "i"(N)); }
+__device__ __forceinline__ void sb_wait(sb_u32x2& r) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r) : "i"(SB_VM(N))); }
 template <int N>
-__device__ __forceinline__ void sb_wait2(sb_u32x4& r, sb_u32x4& q) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r), "+v"(q) : "i"(N)); }
+__device__ __forceinline__ void sb_wait2(sb_u32x4& r, sb_u32x4& q) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r), "+v"(q) : "i"(SB_VM(N))); }
 // 32 staged rows of 64 floats (LDS row stride SB_LD) -> 32 tensor rows starting at byte offset `soff` of the slice behind `rs`, as
 // whole 256-byte rows: 16 lanes per row, 4 rows per wave-store, the row step in the SCALAR offset (a 64-bit address per store is
 // 16 VGPRs that hipcc hoists out of the pair loop)
@@ -543,6 +552,9 @@ __device__ __forceinline__ void sb_bwd_pair(f32x16 (&dk)[2], f32x16 (&dv)[2], sb
         volatile int* vs = seq;
         while (*vs != turn) __builtin_amdgcn_s_sleep(1);
     }
+    // (acquire: no slot access below may be moved above the spin by the compiler -- the hardware keeps a wave's LDS accesses in
+    //  order, the compiler knows nothing of the protocol; advisor, round 5)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     SB_T(9);
     float* __restrict__ row = slot + l31 * SB_LD + 8 * lh;
 #ifdef SB_ABL_NOSLOT
@@ -566,6 +578,8 @@ __device__ __forceinline__ void sb_bwd_pair(f32x16 (&dk)[2], f32x16 (&dv)[2], sb
         sb_rows_out(slot, rdq, soQ_i, pitchQ, lane);
     }
     // LDS executes a wave's accesses in order: the count moves after this pair's writes (and, for the last one, its reads) of the slot
+    // (release: the compiler may not sink a slot store below the count's)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     *reinterpret_cast<volatile int*>(seq) = turn + 1;
     SB_T(8);
 }

@@ -43,6 +43,7 @@ struct PstParams {
     int64_t M, N, K, lda, ldb, ldc;
     float alpha, beta;
     int tiles_m, tiles_n, total;
+    int stagger;                                               // 1: the k-step under which a block flushes its pending tile depends on the block
 };
 
 // where the pending tile goes
@@ -246,6 +247,15 @@ __global__ __launch_bounds__(NT, 2) void gemm_pst_kernel(const PstParams p) {
 
     int cur = 0;
     PstStore ps = store_of(tm, tn);                               // placeholder until a tile is pending
+    // the k-step (0 .. nk - 2, minus one for the two-step flush of EPI 1) under which this block flushes: eight phases by the
+    // block's index inside its XCD (block b runs on XCD b % 8), the two blocks of a CU (index i and i + 32) half a
+    // tile apart; stagger == 0: step 0 for everybody (the round-2 schedule)
+    int flush_at = 0;
+    if (EPI != 2 && p.stagger) {
+        const int idx = (int)blockIdx.x >> 3, phase = (idx + 4 * (idx >> 5)) & 7;
+        const int last = nk - 2 - (EPI == 1 ? 1 : 0);
+        flush_at = __builtin_amdgcn_readfirstlane(last > 0 ? (phase * last) / 7 : 0);
+    }
     // one tile of the block's k-step stream.  PEND: a finished tile is waiting in `pend`; its stores go out under the first
     // k-step (EPI 1, twice the stores, and EPI 2: one row half under each of the first two).  Returns false after the block's
     // last tile.  (The first tile is peeled instead of testing a `have_pend` flag inside one loop: with the flag the kernel took
@@ -262,24 +272,38 @@ __global__ __launch_bounds__(NT, 2) void gemm_pst_kernel(const PstParams p) {
     pst_step<EPI, BKM, (PEND ? F : 0), (PEND || ZQ == 1 ? ZQ : 0)>(acc, ra, rb, smem, cur, RA, RB, (unsigned)(KT) * 128u, (unsigned)(KT) * kstep_b, \
         offa, offb, tid, wm, wn, l31, lh, pend, ps, mine, ZF, ZL, rc, rz, ldc4, p.alpha, p.beta); \
     cur ^= 1
-        // the first k-steps flush the pending tile: all of it (EPI 0), a row half each (EPI 1), a quarter each (EPI 2, which also
-        // fetches the NEXT quarter's z values a step ahead, the two z sets swapping roles)
-        int kt;
+        // Some k-steps of this tile flush the pending one: all of it under ONE step (EPI 0), a row half under each of TWO (EPI 1),
+        // a quarter under each of the first FOUR (EPI 2, which also fetches the NEXT quarter's z values a step ahead, the two z sets
+        // swapping roles).  WHICH step (EPI 0 / 1) depends on the block (round 6): the resident blocks start together and do equal
+        // work, so with a fixed flush step every block of the chip pushed its 64 KB tile into the fabric inside the same ~3 us --
+        // 33.5 MB per generation at 10 TB/s, which the store path answers by stalling the operand loads queued behind it.  With
+        // `flush_at` spread over the tile's k-steps by block the same bytes leave at the GEMM's average store rate (< 1 TB/s).
+        // (three loops in a row, not one loop with a branch around the flushing step: with the branch inside the loop hipcc
+        //  spilled 172-432 bytes per lane)
+        int kt = 0;
         if constexpr (EPI == 0) {
-            PST_STEP(0xF, 0, za, zb, rsa, rsb, 1);
-            kt = 1;
+            if constexpr (PEND) {
+                for (; kt < flush_at; ++kt) { PST_STEP(0, 0, za, zb, rsa, rsb, kt + 1); }
+                PST_STEP(0xF, 0, za, zb, rsa, rsb, kt + 1);
+                ++kt;
+            }
+            for (; kt + 1 < nk; ++kt) { PST_STEP(0, 0, za, zb, rsa, rsb, kt + 1); }
         } else if constexpr (EPI == 1) {
-            PST_STEP(0x3, 0, za, zb, rsa, rsb, 1);
-            PST_STEP(0xC, 0, za, zb, rsa, rsb, 2);
-            kt = 2;
+            if constexpr (PEND) {
+                for (; kt < flush_at; ++kt) { PST_STEP(0, 0, za, zb, rsa, rsb, kt + 1); }
+                PST_STEP(0x3, 0, za, zb, rsa, rsb, kt + 1);
+                ++kt;
+                PST_STEP(0xC, 0, za, zb, rsa, rsb, kt + 1);
+                ++kt;
+            }
+            for (; kt + 1 < nk; ++kt) { PST_STEP(0, 0, za, zb, rsa, rsb, kt + 1); }
         } else {
             PST_STEP(0x1, 2, za, zb, rsa, rsb, 1);
             PST_STEP(0x2, 3, zb, za, rsa, rsb, 2);
             PST_STEP(0x4, 4, za, zb, rsa, rsb, 3);
             PST_STEP(0x8, 0, zb, za, rsa, rsb, 4);
-            kt = 4;
+            for (kt = 4; kt + 1 < nk; ++kt) { PST_STEP(0, 0, za, zb, rsa, rsb, kt + 1); }
         }
-        for (; kt + 1 < nk; ++kt) { PST_STEP(0, 0, za, zb, rsa, rsb, kt + 1); }
         // last k-step: fetches the first k-tile of the next tile (or, with nothing left, re-reads this one's: never used) and
         // (EPI 2) the z values of this tile's quarter 0
         PST_STEP(0, 1, zb, za, rsan, rsbn, 0);
@@ -370,6 +394,8 @@ int gemm_pst(const float* A, const float* B, float* C, const float* bias, float*
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.alpha = alpha; p.beta = beta;
     p.tiles_m = (int)(M / 128); p.tiles_n = (int)ceil_div(N, 128); p.total = p.tiles_m * p.tiles_n;
+    static const int stagger = []() { const char* e = getenv("NNHIP_PST_STAGGER"); return e ? atoi(e) : 1; }();
+    p.stagger = stagger;
     const size_t lds = 2 * PSTAGE * sizeof(float);
     const dim3 grid((unsigned)pst_slots()), block(NT);
     if (epi == 2) hipLaunchKernelGGL((gemm_pst_kernel<2, false>), grid, block, lds, st, p);

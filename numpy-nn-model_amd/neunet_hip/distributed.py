@@ -92,6 +92,13 @@ class _StreamWork:
         torch.cuda.current_stream().wait_event(self.event)
 
 
+class _NoWork:
+    """Handle of an exchange that was not issued (GradBucket.mute)."""
+
+    def wait(self):
+        pass
+
+
 class NativeComm:
     """An RCCL communicator held through libneunet_hip.so's C ABI (nnhipCommUniqueId / nnhipCommInitRank /
     nnhipAllReduceSumF32 / nnhipBroadcastF32 / nnhipCommDestroy) -- the binding a reference-side caller with plain device
@@ -258,6 +265,9 @@ class GradBucket:
         self._seg_of = {}
         self._pending, self._works, self._launched = [], [], []
         self._capture_cb = None       # GraphedTrainStep: called instead of launching a segment's all-reduce (graph cut)
+        # mute = True: exchange() issues nothing (measurement only -- bench.py times the same step with and without its
+        # collectives to report the EXPOSED all-reduce time; replicas drift apart while it is set)
+        self.mute = False
         if overlap:
             hi, idxs = self.extra_offset, []
             for n, i in enumerate(reversed(self.layout)):
@@ -289,6 +299,8 @@ class GradBucket:
         """All-reduce flat[lo:hi] over the bucket's backend (a NativeComm or a torch process group); async_op=True returns a
         handle with wait().  The one place a collective is issued: eager steps, hooks and graph replays all come here."""
         group = group if group is not None else self.group
+        if self.mute:
+            return _NoWork() if async_op else None
         if isinstance(group, NativeComm):
             return group.all_reduce(self.flat[lo:hi], op=self.reduce_op, async_op=async_op)
         import torch.distributed as dist
@@ -296,6 +308,46 @@ class GradBucket:
             raise ValueError("GradBucket(reduce_op='avg'): gloo has no AVG reduction; use 'sum' (the optimizer's grad_scale "
                              "= 1/world gives the mean)")
         return dist.all_reduce(self.flat[lo:hi], op=self.op(), group=group, async_op=async_op)
+
+    def exchange_pieces(self):
+        """The (lo, hi) ranges one step exchanges: the overlap segments + the extra scalars, or the whole bucket."""
+        if self.overlap and self.segments:
+            out = [(lo, hi) for (lo, hi, _) in self.segments]
+            if self.extra is not None:
+                out.append((self.extra_offset, self.numel))
+            return out
+        return [(0, self.numel)]
+
+    def time_exchange_alone(self, repeats: int = 5):
+        """Every all-reduce of one step issued ON ITS OWN (no compute next to it), each bracketed by two events on the current
+        stream -- the collective's own stream starts after the first and the current stream joins it before the second, for both
+        backends -- `repeats` times; returns [(floats, median ms)] per piece.  Every rank must call it (they are collectives).
+        The contents of the bucket are multiplied by the world size each time (SUM): measurement only."""
+        import time
+        import torch
+        res = []
+        on_gpu = self.flat.is_cuda
+        for lo, hi in self.exchange_pieces():
+            spans = []
+            for _ in range(max(1, repeats)):
+                if on_gpu:
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    self.exchange(lo, hi)
+                    b.record()
+                    spans.append((a, b))
+                else:                         # gloo on host tensors (the CPU tests): the call blocks until the result is there
+                    t0 = time.perf_counter()
+                    self.exchange(lo, hi)
+                    spans.append((time.perf_counter() - t0) * 1e3)
+            if on_gpu:
+                torch.cuda.synchronize()
+                ms = sorted(x.elapsed_time(y) for x, y in spans)
+            else:
+                ms = sorted(spans)
+            res.append((hi - lo, ms[len(ms) // 2]))
+            self.flat[lo:hi].zero_()          # (SUM x repeats of random gradients: keep the values finite for the next call)
+        return res
 
     def _launch(self, k):
         import torch.distributed as dist

@@ -496,3 +496,13 @@ def test_bench_eight_ranks_on_one_gpu_rehearsal():
     assert weak["global_batch"] == 96 and weak["samples_per_s"] > 0
     assert d["also"]["c1"].get("samples_per_s", 0) > 0 or "error" in d["also"]["c1"]
     assert "bound" in d["roofline"] and "frac" in d["roofline"]
+    # round 6: the first multi-rank record has to explain itself -- the exchange timed on its own and what it adds to the step,
+    # RCCL's own account of its algorithm / protocol choice (gloo has none: the key is there and says so), the GEMM mode
+    ar = d["allreduce_ms"]
+    assert "error" not in ar, ar
+    assert ar["total"] > 0 and ar["exposed"] is not None and ar["exposed"] >= 0
+    assert len(ar["pieces"]) >= 1 and all(p_["ms_alone"] > 0 for p_ in ar["pieces"])
+    assert abs(ar["total"] - sum(p_["ms_alone"] for p_ in ar["pieces"])) < 1e-2
+    assert ar["ms_per_step_collectives_muted"] > 0
+    assert "rccl" in d and ("choices" in d["rccl"] or "note" in d["rccl"])
+    assert d["gemm_mode"] == 0 and d["dtype"] == "f32"

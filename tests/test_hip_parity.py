@@ -683,6 +683,7 @@ def test_mlp_backward_waiting_for_the_optimizer_is_unobservable(hip):
     def three_steps(toggle):
         m7, ps7, opt7 = build()
         for k in range(3):
+            opt7.zero_grad()
             backward(m7, T(hip, X if k != 1 else X2, requires_grad=False))
             if k == 1:
                 if toggle:
@@ -2377,6 +2378,37 @@ def test_attention_balanced_t256_kernels(hip, monkeypatch, B, H, ld3):
             assert_close_scaled(host(a), host(b), err_msg=tag + " d" + n)
             assert_close_scaled(host(c), host(b), err_msg=tag + " tiled d" + n)
             assert_close_scaled(host(d), host(b), err_msg=tag + " tiled backward on the balanced forward's statistics, d" + n)
+
+
+def test_attention_sb_counted_waits_match_full_drain(hip):
+    """csrc/attention_sb.hip orders its operand stream with hand-counted `s_waitcnt vmcnt(N)` around inline-asm buffer loads that
+    hipcc does not count -- correct today, one edit away from a silent race (round-5 review).  The -DSB_CHECK build
+    (lib/libneunet_hip.sbcheck.so, built by __graft_entry__.build()) replaces every counted wait by vmcnt(0): whatever the
+    default build computes with its counts must be what the fully drained build computes, BIT FOR BIT -- forward output, row
+    statistics and all three gradients, at the C4 shape (three launches), odd slice counts and the padding patterns
+    (tools/attn_sb_digest.py, one process per library)."""
+    import json
+    import subprocess
+    import sys
+    from neunet_hip import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    chk = os.path.join(os.path.dirname(_lib.DEFAULT_LIB), "libneunet_hip.sbcheck.so")
+    assert os.path.exists(chk), f"{chk} is missing: python -c 'import __graft_entry__ as g; g.build()' builds it"
+
+    def run(lib):
+        env = dict(os.environ)
+        env.pop(_lib.LIB_ENV, None)
+        if lib:
+            env[_lib.LIB_ENV] = lib
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "attn_sb_digest.py")], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads(r.stdout.strip().splitlines()[-1])
+
+    a, b = run(None), run(chk)
+    assert a.pop("lib") == "libneunet_hip.so" and b.pop("lib") == "libneunet_hip.sbcheck.so"
+    assert a.keys() == b.keys() and len(a) >= 20
+    bad = [k for k in a if a[k] != b[k]]
+    assert not bad, f"counted waits and full drains disagree: {bad}"
 
 
 def test_argmax_integer_tensors_and_upstream_broadcast(hip):

@@ -177,6 +177,19 @@ def _dp_worker(rank, world, port, q, overlap=False):
               and np.allclose(params[0].grad.numpy() / count, dW_full, rtol=1e-5, atol=1e-6)
               and np.allclose(params[1].grad.numpy() / count, db_full, rtol=1e-5, atol=1e-6)
               and params[0].grad.data_ptr() == bucket.views[0].data_ptr())
+        # round 6: what bench.py uses to report the exchange on its own -- every piece of a step's exchange timed alone (a
+        # collective per piece on every rank), and a muted bucket that issues nothing and leaves its contents alone
+        pieces = bucket.time_exchange_alone(2)
+        want = [(hi_ - lo_) for (lo_, hi_) in bucket.exchange_pieces()]
+        ok = ok and [n for n, _ in pieces] == want and all(ms >= 0.0 for _, ms in pieces) and sum(want) >= bucket.numel - 3
+        bucket.flat.fill_(float(rank + 1))
+        bucket.mute = True
+        w = bucket.exchange(0, bucket.numel, async_op=True)
+        w.wait()
+        ok = ok and bucket.exchange(0, bucket.numel) is None and bool((bucket.flat == float(rank + 1)).all())
+        bucket.mute = False
+        bucket.exchange(0, bucket.numel)
+        ok = ok and bool((bucket.flat == 3.0).all())          # 1 + 2: the collective is live again
         q.put((rank, bool(ok)))
     except Exception as exc:  # report instead of leaving the parent waiting on the queue
         q.put((rank, repr(exc)))
