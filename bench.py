@@ -1352,15 +1352,15 @@ def c4_family_rooflines(iters=20):
         fl = 2.0 * M * K * N
         if swish == "fwd":
             Z = torch.empty(M, N, device="cuda")
-            add(f"{name}: forward + Swish (z saved), rows {M}", "gemm_pst_kernel<1> (Swish epilogue, two outputs)", per_step, fl,
-                med(lambda: call("nnhipLinearSwishForward", X, W, b, O_, Z, M, K, N, 1.0, 1, st)), keys[0] and (keys[0],))
+            add(f"{name}: forward + Swish (swish'(z) saved for the backward pass), rows {M}", "gemm_pst_kernel<3> (Swish epilogue, two outputs)", per_step, fl,
+                med(lambda: call("nnhipLinearSwishForward", X, W, b, O_, Z, M, K, N, 1.0, 2, st)), keys[0] and (keys[0],))
         else:
             add(f"{name}: forward, rows {M}", "gemm_pst_kernel / gemm_f32_kernel (k-major, k-major)", per_step, fl,
                 med(lambda: call("nnhipLinearModuleForward", X, W, b, O_, M, K, N, st)), keys[0] and (keys[0],))
         if swish == "dx":
             Zin = rnd(M, K)
-            add(f"{name}: input gradient x swish'(z), in place over z", "gemm_pst_kernel<2> (Swish-backward epilogue)", per_step, fl,
-                med(lambda: call("nnhipLinearInputGradSwish", dO, W, Zin, Zin, M, K, N, 1.0, st)), keys[1] and (keys[1],))
+            add(f"{name}: input gradient x the saved swish'(z), in place over it", "gemm_pst_kernel<4> (multiply epilogue)", per_step, fl,
+                med(lambda: call("nnhipLinearInputGradScaled", dO, W, Zin, Zin, M, K, N, st)), keys[1] and (keys[1],))
         else:
             add(f"{name}: input gradient", "gemm_pst_kernel / gemm_f32_kernel (k-major, outer-major)", per_step, fl,
                 med(lambda: call("nnhipLinearModuleBackward", X, W, dO, dX, None, None, M, K, N, st)), keys[1] and (keys[1],))
@@ -1593,6 +1593,54 @@ def workload_headline(args, rank, world):
         also["nb"] = {"workload": rn["config"]["workload"], **rn["extra"]}
     if os.environ.get("NNHIP_BENCH_NB", "1") != "0":
         guarded("nb", run_nb)
+    def run_ls_sweep():
+        # The reference's own bench sweep (scripts/benchmark_linear_swish_cuda.py:127-138) with its methodology (:16-56, :59-118): module
+        # API, and INSIDE the timed loop a device copy of x, a fresh Tensor, the module call -- plus a fresh random upstream gradient and
+        # backward() for the f+b column; 20 warm-up + 60 timed iterations between two events (the reference: 50 + 200)
+        import torch
+        import neunet_hip
+        import neunet_hip.nn as nn
+        gsw = torch.Generator(device="cuda").manual_seed(5)
+        rows_out = []
+
+        def timed(fn, warm=20, iters=60):
+            for _ in range(warm):
+                fn()
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(iters):
+                fn()
+            b.record()
+            torch.cuda.synchronize()
+            return a.elapsed_time(b) / iters
+
+        for (Bn, I, Od) in [(32, 256, 512), (64, 256, 512), (128, 256, 512), (256, 512, 1024), (512, 512, 1024), (1024, 512, 1024),
+                            (1024, 1024, 2048), (2048, 1024, 2048), (4096, 1024, 4096)]:
+            np.random.seed(77)
+            fused = nn.LinearSwish(I, Od, swish_beta=1.0)
+            xd = torch.rand(Bn, I, device="cuda", generator=gsw) * 2 - 1
+
+            def fwd():
+                return fused(neunet_hip.Tensor(xd.clone(), device="cuda", requires_grad=False))
+
+            def fwd_bwd():
+                X = neunet_hip.Tensor(xd.clone(), device="cuda", requires_grad=True)
+                out = fused(X)
+                out.backward(torch.rand(Bn, Od, device="cuda", generator=gsw) * 2 - 1)
+                fused.weight.grad = None
+                fused.bias.grad = None
+
+            f, fb = timed(fwd), timed(fwd_bwd)
+            rows_out.append({"B": Bn, "in": I, "out": Od, "fwd_ms": round(f, 4), "fwd_bwd_ms": round(fb, 4),
+                             "fwd_tflops_incl_host": round(2.0 * Bn * I * Od / (f * 1e-3) / 1e12, 2)})
+        also["linear_swish_sweep"] = {
+            "what": "the reference's Linear->Swish bench sweep (scripts/benchmark_linear_swish_cuda.py:127-138) through HIPLinearSwish with the reference's "
+                    "methodology: per iteration a device copy of x, a fresh Tensor, the module call [+ random upstream gradient, backward()]; eager launches "
+                    "from Python, so the small sizes measure the host (~0.05 ms per call), not the kernel",
+            "rows": rows_out}
+    if os.environ.get("NNHIP_BENCH_LS_SWEEP", "1") != "0" and (rank == 0 or world == 1) and os.environ.get("NNHIP_BENCH_TOY", "0") != "1":
+        guarded("linear_swish_sweep", run_ls_sweep)
     # opt-in split-bf16 GEMM mode (fp32 operands split exactly into 3 bf16 pieces, 6 products on the bf16 matrix cores):
     # reported NEXT TO the exact-fp32 numbers above, never instead of them
     if os.environ.get("NNHIP_BENCH_BF16X3", "1") != "0":

@@ -118,12 +118,15 @@ int nnhipWeightGradPending(void);
 /* ---- a6 fused Linear -> Swish  (replaces cudaLinearSwishForward/Backward,
  *      linear_swish_cutlass_evt_full.cu:558-570, 680-695) ------------------------------------- */
 /* z = X*W^T + b ; O = z*sigmoid(beta*z).  If save_preactivation != 0, z is also written to
- * `preact` (must be non-NULL then). */
+ * `preact` (must be non-NULL then).  save_preactivation == 2 (ABI 210, no reference counterpart): `preact` receives
+ * swish'(z) = s + beta*O*(1 - s), s = sigmoid(beta*z), instead of z -- the same sigmoid serves both outputs, and the backward
+ * pass (nnhipLinearSwishBackward with recompute_preactivation = 2, nnhipLinearInputGradScaled, nnhipLinearModuleBackwardAct with
+ * act_grad = 3) only multiplies: in an fp32 MFMA kernel every vector instruction of an epilogue is paid in matrix-pipe time. */
 int nnhipLinearSwishForward(const float* X, const float* W, const float* b, float* O, float* preact,
                             int64_t M, int64_t K, int64_t N, float swish_beta,
                             int save_preactivation, nnhipStream_t stream);
-/* tmp[M,N]: if recompute_preactivation == 0 it holds z on entry (saved by the forward); otherwise
- * it is scratch and z is recomputed into it.  On exit tmp holds dZ (reference in-place contract,
+/* tmp[M,N]: if recompute_preactivation == 0 it holds z on entry (saved by the forward); 2: it holds swish'(z) (forward with
+ * save_preactivation = 2); otherwise (1) it is scratch and z is recomputed into it.  On exit tmp holds dZ (reference in-place contract,
  * ...evt_full.cu:707-711).  dX/dW/db may be NULL. */
 int nnhipLinearSwishBackward(const float* X, const float* W, const float* b, const float* dO,
                              float* tmp, float* dX, float* dW, float* db, int64_t M, int64_t K,
@@ -165,12 +168,18 @@ int nnhipReLUBackward(float* dIn, const float* dOut, const float* out, int64_t s
 int nnhipLinearInputGradSwish(const float* dO, const float* W, const float* Z, float* dZ, int64_t rows,
                               int64_t in_features, int64_t out_features, float swish_beta, nnhipStream_t stream);
 
+/* The same with the derivative in hand: dZ = (dO * W) (.) D, D = what nnhipLinearSwishForward(save_preactivation = 2) left in
+ * `preact`.  dZ may alias D.  ABI 210 */
+int nnhipLinearInputGradScaled(const float* dO, const float* W, const float* D, float* dZ, int64_t rows,
+                               int64_t in_features, int64_t out_features, nnhipStream_t stream);
+
 /* The same for h = relu(z): dZ = (dO * W) (.) [F > 0] with F = the ReLU's forward output (activations.py:44-45); dZ must
  * not alias F (F is still the Linear's input for its dW). */
 int nnhipLinearInputGradReLU(const float* dO, const float* W, const float* F, float* dZ, int64_t rows,
                              int64_t in_features, int64_t out_features, nnhipStream_t stream);
 /* Both of the above plus the parameter gradients in one call: dZ = (dO * W) (.) act'(act_arg) -- act_grad 1: swish'(act_arg = Z;
- * beta), dZ may alias Z; 2: [act_arg = F > 0], dZ must not alias F -- and dW = dO^T X, db = column sums of dO (either may be NULL),
+ * beta), dZ may alias Z; 2: [act_arg = F > 0], dZ must not alias F; 3 (ABI 210): act_arg is the saved derivative swish'(z) itself, a plain
+ * multiplier, dZ may alias it -- and dW = dO^T X, db = column sums of dO (either may be NULL),
  * i.e. _LinearTensor.grad_fn (linear.py:17-24) followed by the activation's backward.  A small layer (the README MLP's
  * 128 -> 10 head) gets dZ, dW and db from ONE launch. */
 int nnhipLinearModuleBackwardAct(const float* X, const float* W, const float* dO, const float* act_arg, int32_t act_grad,

@@ -170,6 +170,14 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 __device__ __forceinline__ float sigmoid_fast_(float x) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
+// h = z sigmoid(beta z) and d = dh/dz = s + beta h (1 - s) from ONE sigmoid: the forward epilogue that saves d instead of z
+// (ACT_SWISH_D) leaves the backward epilogue a single multiply -- in an fp32 MFMA kernel every VALU instruction is paid in
+// matrix-pipe time, and the sigmoid's two transcendentals are 32 of the ~64 cycles per element swish_grad_ costs.
+__device__ __forceinline__ void swish_fwd_d_(float z, float beta, float& h, float& d) {
+    const float s = sigmoid_fast_(beta * z);
+    h = z * s;
+    d = fmaf(beta * h, 1.0f - s, s);
+}
 __device__ __forceinline__ float swish_grad_(float z, float beta) {
     const float s = sigmoid_fast_(beta * z);
     const float f = z * s;

@@ -233,6 +233,7 @@ int fill_f32(float* p, float v, int64_t n, hipStream_t st) {
 }
 
 // internal: used by linear.hip for dZ = dY * swish'(z), in place over z
+int mul_f32(float* out, const float* a, const float* b, int64_t n, hipStream_t st) { return launch_map2(out, a, b, n, MulF{}, st, "mul"); }
 int swish_backward_inplace(float* z_inout, const float* dY, float beta, int64_t n, hipStream_t st) {
     return launch_map2(z_inout, dY, z_inout, n, SwishB{beta}, st, "swish_backward(inplace)");
 }

@@ -442,11 +442,15 @@ __device__ __forceinline__ void splitk_reduce_body(const ReduceArgs& r, const in
         if (addend) s += addend[m * ldc + n];
         if (dswish) {
             const float x = dswish[m * ldc + n];
-            s = dact == 2 ? (x > 0.f ? s : 0.f) : s * swish_grad_(x, beta);
+            s = dact == 2 ? (x > 0.f ? s : 0.f) : dact == 3 ? s * x : s * swish_grad_(x, beta);
         }
         if (act == ACT_SWISH) {
             if (preact) preact[m * ldc + n] = s;
             s = s * sigmoid_fast_(beta * s);
+        } else if (act == ACT_SWISH_D) {
+            float d;
+            swish_fwd_d_(s, beta, s, d);
+            if (preact) preact[m * ldc + n] = d;
         } else if (act == ACT_RELU) {
             s = fmaxf(s, 0.f);
         } else if (act == ACT_SIGMOID) {
@@ -594,10 +598,11 @@ int gemm_f32_linear_backward_small(const float* X, const float* W, const float* 
     return rc ? rc : 1;
 }
 
+// dact 1: C = (A B) * swish'(Z; beta); dact 3: C = (A B) * Z (Z holds the derivative the forward pass saved).  C may alias Z.
 int gemm_f32_dswish(const float* A, const float* B, float* C, const float* Z, float beta, int64_t M, int64_t N, int64_t K,
-                    int64_t lda, int64_t ldb, int64_t ldc, bool a_kmajor, bool b_kmajor, hipStream_t st) {
+                    int64_t lda, int64_t ldb, int64_t ldc, bool a_kmajor, bool b_kmajor, hipStream_t st, int dact) {
     return gemm_f32_ex(A, B, C, nullptr, nullptr, M, N, K, lda, ldb, ldc, a_kmajor, b_kmajor, 1, 0, 0, 0, 1, 0, 0, 0, 1.0f,
-                       ACT_NONE, beta, st, nullptr, nullptr, Z);
+                       ACT_NONE, beta, st, nullptr, nullptr, Z, dact);
 }
 
 // C = (A B) * [F > 0]: the input gradient of a Linear whose input was h = relu(z), F = h (C must not alias F).

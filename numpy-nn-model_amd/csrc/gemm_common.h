@@ -9,7 +9,8 @@ namespace nnhip {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { ACT_NONE = 0, ACT_SWISH = 1, ACT_RELU = 2, ACT_SIGMOID = 3 };
+enum { ACT_NONE = 0, ACT_SWISH = 1, ACT_RELU = 2, ACT_SIGMOID = 3,
+       ACT_SWISH_D = 4 };   // swish, and `preact` receives swish'(z) instead of z (the backward pass then only multiplies)
 
 struct GemmParams {
     const float* A;
@@ -33,7 +34,7 @@ struct GemmParams {
     int act;
     float beta;
     const float* dswish;  // [M, ldc] or null: C = (alpha*AB + bias + addend) * act'(dswish[m,n])  (may alias C); act' per `dact`
-    int dact;             // 1: swish'(z; beta), dswish = z;  2: relu'(f) = [f > 0], dswish = the forward OUTPUT f
+    int dact;             // 1: swish'(z; beta), dswish = z;  2: relu'(f) = [f > 0], dswish = the forward OUTPUT f;  3: a plain multiplier (the saved swish'(z))
     const float* addend;  // [M, ldc] or null: C = act(alpha*AB + bias + addend)  (residual / gradient accumulation)
     float* asum;          // CS variants: asum[m] = sum_k A[m,k] (Linear: db = column sums of dO, fused into dW = dO^T X)
     float* asum_slab;     // split-K partials [splitk][M]
@@ -242,6 +243,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[2][2], const GemmPar
                             } else if (p.dact == 2) {   // gradient through h = relu(z): mask by the forward output
                                 v.x = x.x > 0.f ? v.x : 0.f; v.y = x.y > 0.f ? v.y : 0.f;
                                 v.z = x.z > 0.f ? v.z : 0.f; v.w = x.w > 0.f ? v.w : 0.f;
+                            } else if (p.dact == 3) {   // the forward pass saved swish'(z) itself (ACT_SWISH_D)
+                                v.x *= x.x; v.y *= x.y; v.z *= x.z; v.w *= x.w;
                             } else {   // gradient through h = swish(z): the dX GEMM of the NEXT layer hands back dz
                                 v.x *= swish_grad_(x.x, p.beta); v.y *= swish_grad_(x.y, p.beta);
                                 v.z *= swish_grad_(x.z, p.beta); v.w *= swish_grad_(x.w, p.beta);
@@ -251,6 +254,11 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[2][2], const GemmPar
                             if (p.preact) *reinterpret_cast<float4*>(p.preact + c_off + row * ldc + col) = v;
                             v.x *= sigmoid_fast_(p.beta * v.x); v.y *= sigmoid_fast_(p.beta * v.y);
                             v.z *= sigmoid_fast_(p.beta * v.z); v.w *= sigmoid_fast_(p.beta * v.w);
+                        } else if (p.act == ACT_SWISH_D) {
+                            float4 d;
+                            swish_fwd_d_(v.x, p.beta, v.x, d.x); swish_fwd_d_(v.y, p.beta, v.y, d.y);
+                            swish_fwd_d_(v.z, p.beta, v.z, d.z); swish_fwd_d_(v.w, p.beta, v.w, d.w);
+                            if (p.preact) *reinterpret_cast<float4*>(p.preact + c_off + row * ldc + col) = d;
                         } else if (p.act == ACT_RELU) {
                             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                         } else if (p.act == ACT_SIGMOID) {
@@ -285,11 +293,15 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[2][2], const GemmPar
                     if (p.addend) v += p.addend[c_off + row * ldc + col];
                     if (p.dswish) {
                         const float x = p.dswish[c_off + row * ldc + col];
-                        v = p.dact == 2 ? (x > 0.f ? v : 0.f) : v * swish_grad_(x, p.beta);
+                        v = p.dact == 2 ? (x > 0.f ? v : 0.f) : p.dact == 3 ? v * x : v * swish_grad_(x, p.beta);
                     }
                     if (p.act == ACT_SWISH) {
                         if (p.preact) p.preact[c_off + row * ldc + col] = v;
                         v = v * sigmoid_fast_(p.beta * v);
+                    } else if (p.act == ACT_SWISH_D) {
+                        float d;
+                        swish_fwd_d_(v, p.beta, v, d);
+                        if (p.preact) p.preact[c_off + row * ldc + col] = d;
                     } else if (p.act == ACT_RELU) {
                         v = fmaxf(v, 0.f);
                     } else if (p.act == ACT_SIGMOID) {

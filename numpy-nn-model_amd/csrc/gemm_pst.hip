@@ -22,6 +22,9 @@
 // from a [M, ldc] tensor that C may alias -- linear_swish's in-place dZ contract): the pending tile goes out in quarters under
 // the next tile's first FOUR k-steps, and the z values of a quarter are fetched one k-step before the step that stores it
 // (quarter 0 under the tile's own last k-step), so neither their latency nor the stores are exposed.
+// EPI = 3 is EPI 1 with the z output replaced by swish'(z) (ACT_SWISH_D: one sigmoid serves both outputs) and EPI = 4 is EPI 2 with
+// the saved derivative as a plain multiplier (dact 3) -- round 6: the backward epilogue's sigmoid + polynomial (~64 matrix-pipe
+// cycles per element, 6 % of a K = 512 tile) becomes one multiply.
 // Conditions (gemm_pst_wanted): A k-major, 16-B aligned rows, K % 32 == 0, K >= 64 (96 with EPI 1, 160 with EPI 2),
 // M % 128 == 0, no split-K / batch / addend, C and the operand windows addressable with 32-bit byte offsets, more tiles than
 // resident slots.  Everything else takes gemm.hip.
@@ -106,9 +109,20 @@ __device__ __forceinline__ void pst_flush_q(int q, const f32x16 (&pend)[2][2], c
             v0 *= sigmoid_fast_(beta * v0);
             v1 *= sigmoid_fast_(beta * v1);
         }
+        if constexpr (EPI == 3) {
+            float d0, d1;
+            swish_fwd_d_(v0, beta, v0, d0);
+            swish_fwd_d_(v1, beta, v1, d1);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d0), rz, ps.vo0, so, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(d1), rz, ps.vo1, so, 0);
+        }
         if constexpr (EPI == 2) {
             v0 *= swish_grad_(z[0][j], beta);
             v1 *= swish_grad_(z[1][j], beta);
+        }
+        if constexpr (EPI == 4) {
+            v0 *= z[0][j];
+            v1 *= z[1][j];
         }
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), rc, ps.vo0, so, 0);
         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), rc, ps.vo1, so, 0);
@@ -128,10 +142,12 @@ __device__ __forceinline__ void pst_step(f32x16 (&acc)[2][2], float4 (&fa)[4], f
                                          int lh, const f32x16 (&pend)[2][2], const PstStore& ps, const PstStore& zs,
                                          const float (&zf)[2][8], float (&zl)[2][8], __amdgpu_buffer_rsrc_t rc,
                                          __amdgpu_buffer_rsrc_t rz, unsigned ldc4, float alpha, float beta) {
+    constexpr bool ZIN = EPI == 2 || EPI == 4;                  // the epilogue reads a [M, ldc] operand (z / the saved derivative)
+    constexpr bool TWO = EPI == 1 || EPI == 3;                  // the epilogue writes two outputs
     g2r_fast<PBK>(fa, rsa, koffa, offa);
     g2r_fast<PBK>(fb, rsb, koffb, offb);
-    if constexpr (EPI == 2 && ZQ == 1) pst_load_z(zl, 0, zs, rz, ldc4);
-    if constexpr (EPI == 2 && ZQ > 1) pst_load_z(zl, ZQ - 1, ps, rz, ldc4);
+    if constexpr (ZIN && ZQ == 1) pst_load_z(zl, 0, zs, rz, ldc4);
+    if constexpr (ZIN && ZQ > 1) pst_load_z(zl, ZQ - 1, ps, rz, ldc4);
     const float* As = smem + cur * PSTAGE;
     const float* Bs = As + PTile::SIZE;
 #pragma unroll
@@ -162,9 +178,9 @@ __device__ __forceinline__ void pst_step(f32x16 (&acc)[2][2], float4 (&fa)[4], f
     // issue order: the tile's 8 loads (and the 16 z loads) under the first MFMAs, the 8 LDS stores under the last ones, the NW
     // stores one per MFMA under the last NW.  The epilogue arithmetic goes wherever the scheduler likes: fp32 MFMAs and VALU
     // share the lanes, it overlaps with nothing.
-    constexpr bool ZLD = EPI == 2 && ZQ != 0;
+    constexpr bool ZLD = ZIN && ZQ != 0;
     constexpr int NQ = (FLUSH & 1) + ((FLUSH >> 1) & 1) + ((FLUSH >> 2) & 1) + ((FLUSH >> 3) & 1);
-    constexpr int NW = NQ * (EPI == 1 ? 32 : 16);
+    constexpr int NW = NQ * (TWO ? 32 : 16);
     static_assert(NW <= 64, "at most one store per MFMA");
 #pragma unroll
     for (int i = 0; i < 64; ++i) {
@@ -251,9 +267,9 @@ __global__ __launch_bounds__(NT, 2) void gemm_pst_kernel(const PstParams p) {
     // block's index inside its XCD (block b runs on XCD b % 8), the two blocks of a CU (index i and i + 32) half a
     // tile apart; stagger == 0: step 0 for everybody (the round-2 schedule)
     int flush_at = 0;
-    if (EPI != 2 && p.stagger) {
+    if (EPI != 2 && EPI != 4 && p.stagger) {
         const int idx = (int)blockIdx.x >> 3, phase = (idx + 4 * (idx >> 5)) & 7;
-        const int last = nk - 2 - (EPI == 1 ? 1 : 0);
+        const int last = nk - 2 - ((EPI == 1 || EPI == 3) ? 1 : 0);
         flush_at = __builtin_amdgcn_readfirstlane(last > 0 ? (phase * last) / 7 : 0);
     }
     // one tile of the block's k-step stream.  PEND: a finished tile is waiting in `pend`; its stores go out under the first
@@ -288,7 +304,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_pst_kernel(const PstParams p) {
                 ++kt;
             }
             for (; kt + 1 < nk; ++kt) { PST_STEP(0, 0, za, zb, rsa, rsb, kt + 1); }
-        } else if constexpr (EPI == 1) {
+        } else if constexpr (EPI == 1 || EPI == 3) {
             if constexpr (PEND) {
                 for (; kt < flush_at; ++kt) { PST_STEP(0, 0, za, zb, rsa, rsb, kt + 1); }
                 PST_STEP(0x3, 0, za, zb, rsa, rsb, kt + 1);
@@ -326,7 +342,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_pst_kernel(const PstParams p) {
     // the block's last tile: nothing left to hide its stores under
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        if (EPI == 2 && q > 0) pst_load_z(za, q, ps, rz, ldc4);
+        if ((EPI == 2 || EPI == 4) && q > 0) pst_load_z(za, q, ps, rz, ldc4);
         pst_flush_q<EPI>(q, pend, ps, za, rc, rz, ldc4, p.alpha, p.beta);
     }
 }
@@ -347,7 +363,8 @@ static int pst_slots_of() {
 // resident blocks of the whole chip (LDS admits two per CU for every variant), a multiple of the 8 XCDs
 static int pst_slots() {
     static const int slots = []() {
-        const int s = min(min(pst_slots_of<0, true>(), pst_slots_of<1, true>()), min(pst_slots_of<0, false>(), pst_slots_of<2, false>()));
+        const int s = min(min(min(pst_slots_of<0, true>(), pst_slots_of<1, true>()), min(pst_slots_of<0, false>(), pst_slots_of<2, false>())),
+                          min(pst_slots_of<3, true>(), pst_slots_of<4, false>()));
         return s > 0 ? (s & ~7) : -1;
     }();
     return slots;
@@ -355,8 +372,9 @@ static int pst_slots() {
 
 // which epilogue variant a request maps to, or -1
 static int pst_epi(bool b_kmajor, int act, const float* preact, const float* dswish, int dact) {
-    if (dswish) return (!b_kmajor && act == ACT_NONE && !preact && dact == 1) ? 2 : -1;
+    if (dswish) return (!b_kmajor && act == ACT_NONE && !preact && (dact == 1 || dact == 3)) ? (dact == 1 ? 2 : 4) : -1;
     if (act == ACT_SWISH) return b_kmajor ? 1 : -1;
+    if (act == ACT_SWISH_D) return (b_kmajor && preact) ? 3 : -1;
     return (act == ACT_NONE && !preact) ? 0 : -1;
 }
 
@@ -372,7 +390,7 @@ bool gemm_pst_wanted(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, 
     // prefetch is worth more (with a two-deep prefetch of its own this kernel draws level there, no better: not kept)
     if (on < 2 && K > 1024) return false;
     // (the flush of the Swish epilogues takes two / four k-steps before the tile's last one)
-    if ((K % PBK) != 0 || K < (epi == 2 ? 5 : epi == 1 ? 3 : 2) * PBK || (M % 128) != 0 || N <= 0) return false;
+    if ((K % PBK) != 0 || K < ((epi == 2 || epi == 4) ? 5 : (epi == 1 || epi == 3) ? 3 : 2) * PBK || (M % 128) != 0 || N <= 0) return false;
     if (!aligned16(A) || !aligned16(B) || (lda & 3) || (ldb & 3) ||
         ((reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(preact) | reinterpret_cast<uintptr_t>(dswish) | reinterpret_cast<uintptr_t>(bias)) & 3))
         return false;
@@ -390,7 +408,7 @@ int gemm_pst(const float* A, const float* B, float* C, const float* bias, float*
              hipStream_t st) {
     const int epi = pst_epi(b_kmajor, act, preact, dswish, dact);
     PstParams p;
-    p.A = A; p.B = B; p.C = C; p.bias = bias; p.preact = epi == 2 ? const_cast<float*>(dswish) : preact;
+    p.A = A; p.B = B; p.C = C; p.bias = bias; p.preact = (epi == 2 || epi == 4) ? const_cast<float*>(dswish) : preact;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.alpha = alpha; p.beta = beta;
     p.tiles_m = (int)(M / 128); p.tiles_n = (int)ceil_div(N, 128); p.total = p.tiles_m * p.tiles_n;
@@ -398,7 +416,9 @@ int gemm_pst(const float* A, const float* B, float* C, const float* bias, float*
     p.stagger = stagger;
     const size_t lds = 2 * PSTAGE * sizeof(float);
     const dim3 grid((unsigned)pst_slots()), block(NT);
-    if (epi == 2) hipLaunchKernelGGL((gemm_pst_kernel<2, false>), grid, block, lds, st, p);
+    if (epi == 4) hipLaunchKernelGGL((gemm_pst_kernel<4, false>), grid, block, lds, st, p);
+    else if (epi == 3) hipLaunchKernelGGL((gemm_pst_kernel<3, true>), grid, block, lds, st, p);
+    else if (epi == 2) hipLaunchKernelGGL((gemm_pst_kernel<2, false>), grid, block, lds, st, p);
     else if (epi == 1) hipLaunchKernelGGL((gemm_pst_kernel<1, true>), grid, block, lds, st, p);
     else if (b_kmajor) hipLaunchKernelGGL((gemm_pst_kernel<0, true>), grid, block, lds, st, p);
     else hipLaunchKernelGGL((gemm_pst_kernel<0, false>), grid, block, lds, st, p);

@@ -6,7 +6,7 @@
 namespace nnhip {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-enum { SG_ACT_NONE = 0, SG_ACT_SWISH = 1, SG_ACT_RELU = 2, SG_ACT_SIGMOID = 3 };
+enum { SG_ACT_NONE = 0, SG_ACT_SWISH = 1, SG_ACT_RELU = 2, SG_ACT_SIGMOID = 3, SG_ACT_SWISH_D = 4 };
 
 struct SmallGemmParams {
     const float* A;
@@ -143,11 +143,15 @@ __device__ __forceinline__ void sg_tile16(const SmallGemmParams& p, int bx, int 
             if (p.addend) v += e_add;
             if (p.dact_arg) {
                 const float x = e_dact;
-                v = p.dact == 2 ? (x > 0.f ? v : 0.f) : v * swish_grad_(x, p.beta);
+                v = p.dact == 2 ? (x > 0.f ? v : 0.f) : p.dact == 3 ? v * x : v * swish_grad_(x, p.beta);
             }
             if (p.act == SG_ACT_SWISH) {
                 if (p.preact) p.preact[row * p.ldc + col] = v;
                 v = v * sigmoid_fast_(p.beta * v);
+            } else if (p.act == SG_ACT_SWISH_D) {
+                float d;
+                swish_fwd_d_(v, p.beta, v, d);
+                if (p.preact) p.preact[row * p.ldc + col] = d;
             } else if (p.act == SG_ACT_RELU) {
                 v = fmaxf(v, 0.f);
             } else if (p.act == SG_ACT_SIGMOID) {

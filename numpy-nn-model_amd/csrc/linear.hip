@@ -16,7 +16,8 @@ int gemm_f32(const float* A, const float* B, float* C, const float* bias, float*
 int gemm_f32_add(const float* A, const float* B, float* C, const float* bias, const float* addend, int64_t M, int64_t N,
                  int64_t K, int64_t lda, int64_t ldb, int64_t ldc, bool a_kmajor, bool b_kmajor, hipStream_t st);
 int gemm_f32_dswish(const float* A, const float* B, float* C, const float* Z, float beta, int64_t M, int64_t N, int64_t K,
-                    int64_t lda, int64_t ldb, int64_t ldc, bool a_kmajor, bool b_kmajor, hipStream_t st);
+                    int64_t lda, int64_t ldb, int64_t ldc, bool a_kmajor, bool b_kmajor, hipStream_t st, int dact = 1);
+int mul_f32(float* out, const float* a, const float* b, int64_t n, hipStream_t st);       // elementwise.hip
 int gemm_f32_drelu(const float* A, const float* B, float* C, const float* F, int64_t M, int64_t N, int64_t K,
                    int64_t lda, int64_t ldb, int64_t ldc, bool a_kmajor, bool b_kmajor, hipStream_t st);
 int gemm_f32_asum(const float* A, const float* B, float* C, float* asum, int64_t M, int64_t N, int64_t K, int64_t lda,
@@ -36,7 +37,7 @@ int gemm_small_mlp_backward_adam(const float* X1, const float* H, const float* W
 int colsum(const float* X, int64_t rows, int64_t cols, int64_t ld, float* out, hipStream_t st);
 int swish_backward_inplace(float* z_inout, const float* dY, float beta, int64_t n, hipStream_t st);
 int fill_f32(float* p, float v, int64_t n, hipStream_t st);
-enum { ACT_NONE = 0, ACT_SWISH = 1, ACT_RELU = 2, ACT_SIGMOID = 3 };
+enum { ACT_NONE = 0, ACT_SWISH = 1, ACT_RELU = 2, ACT_SIGMOID = 3, ACT_SWISH_D = 4 };
 
 // ---- the deferred parameter-gradient queue (nnhipWeightGradDefer) ------------------------------------------------------------
 // While deferral is on, a dW (+db) GEMM that would not fill the chip on its own is not launched by the backward call that asks
@@ -84,7 +85,7 @@ static int linear_backward(const float* X, const float* W, const float* dO, floa
     //  tails on this part, they slow each other down: 16384x512->512 backward 148 -> 166 us, C4 step 22.24 -> 22.33 ms.)
     // dX[rows,in] = dO[rows,out] * W[out,in]         A k-major (k = out), B outer-major
     if (dX) {
-        if (dact_arg && dact == 1) rc = gemm_f32_dswish(dO, W, dX, dact_arg, beta, rows, in, out, out, in, in, true, false, st);
+        if (dact_arg && (dact == 1 || dact == 3)) rc = gemm_f32_dswish(dO, W, dX, dact_arg, beta, rows, in, out, out, in, in, true, false, st, dact);
         else if (dact_arg) rc = gemm_f32_drelu(dO, W, dX, dact_arg, rows, in, out, out, in, in, true, false, st);
         else rc = gemm_f32_add(dO, W, dX, nullptr, dX_addend, rows, in, out, out, in, in, true, false, st);
     }
@@ -184,8 +185,10 @@ extern "C" int nnhipLinearSwishForward(const float* X, const float* W, const flo
     NNHIP_CHECK_ARG(O != nullptr, NNHIP_EINVAL, "nnhipLinearSwishForward: null output");
     NNHIP_CHECK_ARG(!save_preactivation || preact, NNHIP_EINVAL,
                     "nnhipLinearSwishForward: save_preactivation set but preact is null");
+    NNHIP_CHECK_ARG(save_preactivation >= 0 && save_preactivation <= 2, NNHIP_EINVAL,
+                    "nnhipLinearSwishForward: save_preactivation must be 0, 1 (z) or 2 (swish'(z))");
     return gemm_f32(X, W, O, b, save_preactivation ? preact : nullptr, M, N, K, K, K, N, true, true, 1, 0,
-                    0, 0, ACT_SWISH, swish_beta, (hipStream_t)stream);
+                    0, 0, save_preactivation == 2 ? ACT_SWISH_D : ACT_SWISH, swish_beta, (hipStream_t)stream);
 }
 
 extern "C" int nnhipLinearSwishBackward(const float* X, const float* W, const float* b, const float* dO,
@@ -196,11 +199,14 @@ extern "C" int nnhipLinearSwishBackward(const float* X, const float* W, const fl
     hipStream_t st = (hipStream_t)stream;
     if (M == 0) return linear_backward(X, W, dO, dX, dW, db, M, K, N, st);
     NNHIP_CHECK_ARG(dO && tmp, NNHIP_EINVAL, "nnhipLinearSwishBackward: null dO/tmp");
+    NNHIP_CHECK_ARG(recompute_preactivation >= 0 && recompute_preactivation <= 2, NNHIP_EINVAL,
+                    "nnhipLinearSwishBackward: recompute_preactivation must be 0 (tmp = z), 1 (recompute z) or 2 (tmp = swish'(z))");
     int rc = 0;
-    if (recompute_preactivation)  // z = X W^T + b into tmp
+    if (recompute_preactivation == 1)  // z = X W^T + b into tmp
         rc = gemm_f32(X, W, tmp, b, nullptr, M, N, K, K, K, N, true, true, 1, 0, 0, 0, ACT_NONE, 1.f, st);
     if (rc) return rc;
-    rc = swish_backward_inplace(tmp, dO, swish_beta, M * N, st);  // tmp <- dZ = dO * swish'(z)
+    if (recompute_preactivation == 2) rc = mul_f32(tmp, dO, tmp, M * N, st);   // tmp holds swish'(z) (forward mode 2): dZ = dO * tmp
+    else rc = swish_backward_inplace(tmp, dO, swish_beta, M * N, st);  // tmp <- dZ = dO * swish'(z)
     if (rc) return rc;
     return linear_backward(X, W, tmp, dX, dW, db, M, K, N, st);
 }
@@ -219,6 +225,19 @@ extern "C" int nnhipLinearInputGradSwish(const float* dO, const float* W, const 
                            in_features, true, false, (hipStream_t)stream);
 }
 
+// The same with the derivative already in hand: dZ = (dO W) (.) D, D = the swish'(z) that nnhipLinearSwishForward(save_preactivation
+// = 2) left in `preact`.  dZ may alias D.
+extern "C" int nnhipLinearInputGradScaled(const float* dO, const float* W, const float* D, float* dZ, int64_t rows,
+                                          int64_t in_features, int64_t out_features, nnhipStream_t stream) {
+    NNHIP_CHECK_ARG(rows >= 0 && in_features >= 0 && out_features >= 0, NNHIP_EINVAL, "nnhipLinearInputGradScaled: negative size");
+    if (rows == 0 || in_features == 0) return 0;
+    NNHIP_CHECK_ARG(dO && W && D && dZ, NNHIP_EINVAL, "nnhipLinearInputGradScaled: null pointer");
+    NNHIP_CHECK_ARG(aligned4(dO) && aligned4(W) && aligned4(D) && aligned4(dZ), NNHIP_EALIGN,
+                    "nnhipLinearInputGradScaled: misaligned pointer");
+    return gemm_f32_dswish(dO, W, dZ, D, 1.f, rows, in_features, out_features, out_features, in_features,
+                           in_features, true, false, (hipStream_t)stream, 3);
+}
+
 // Backward of a Linear whose input was h = act(z) of the previous layer, in one call: dZ = (dO W) (.) act'(arg) -- act_grad 1:
 // swish'(arg = z; beta), dZ may alias arg; 2: relu mask [arg = h > 0], dZ must not alias arg -- plus dW = dO^T X and db.  What
 // nnhipLinearInputGradSwish / ReLU followed by nnhipLinearModuleBackward(dX = NULL) compute; small layers (the MNIST-MLP's
@@ -227,9 +246,9 @@ extern "C" int nnhipLinearModuleBackwardAct(const float* X, const float* W, cons
                                             int32_t act_grad, float beta, float* dZ, float* dW, float* db, int64_t rows,
                                             int64_t in_features, int64_t out_features, nnhipStream_t stream) {
     if (int rc = check_linear("nnhipLinearModuleBackwardAct", X, W, rows, in_features, out_features)) return rc;
-    NNHIP_CHECK_ARG(act_grad == 1 || act_grad == 2, NNHIP_EINVAL, "nnhipLinearModuleBackwardAct: act_grad must be 1 (swish) or 2 (relu)");
+    NNHIP_CHECK_ARG(act_grad >= 1 && act_grad <= 3, NNHIP_EINVAL, "nnhipLinearModuleBackwardAct: act_grad must be 1 (swish), 2 (relu) or 3 (act_arg is the saved derivative)");
     NNHIP_CHECK_ARG(rows == 0 || (dO && act_arg && dZ), NNHIP_EINVAL, "nnhipLinearModuleBackwardAct: null pointer");
-    NNHIP_CHECK_ARG(rows == 0 || act_grad == 1 || act_arg != dZ, NNHIP_EINVAL, "nnhipLinearModuleBackwardAct: dZ aliases the ReLU output");
+    NNHIP_CHECK_ARG(rows == 0 || act_grad != 2 || act_arg != dZ, NNHIP_EINVAL, "nnhipLinearModuleBackwardAct: dZ aliases the ReLU output");
     NNHIP_CHECK_ARG(aligned4(dO) && aligned4(act_arg) && aligned4(dZ) && aligned4(dW) && aligned4(db), NNHIP_EALIGN,
                     "nnhipLinearModuleBackwardAct: misaligned pointer");
     return linear_backward(X, W, dO, dZ, dW, db, rows, in_features, out_features, (hipStream_t)stream, nullptr, act_arg, act_grad, beta);

@@ -61,6 +61,7 @@ _SIGNATURES = {
     "nnhipWeightGradFlush": (ctypes.c_int, [c_void_p]),
     "nnhipWeightGradPending": (ctypes.c_int, []),
     "nnhipLinearInputGradSwish": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_float, c_void_p]),
+    "nnhipLinearInputGradScaled": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_void_p]),
     "nnhipLinearInputGradReLU": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_void_p]),
     "nnhipLinearReLULinearBackward": (ctypes.c_int, [P, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_void_p]),
     "nnhipLinearReLULinearBackwardAdam": (ctypes.c_int, [P, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_void_p,

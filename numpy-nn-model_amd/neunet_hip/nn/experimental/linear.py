@@ -54,6 +54,8 @@ def _plan_fold(X):
       * act_grad 1 -- X is the output of a fused Linear->Swish that saved its pre-activation z and nothing else consumes it
         (the FFN of examples/gpt.ipynb: fc_2(swish(fc_1(x)))): dz = (dO W) * swish'(z), in place over z -- no separate
         Swish-backward pass over the [rows, d_ff] tensor;
+      * act_grad 3 -- the same with the derivative swish'(z) saved by the forward epilogue in z's place (the default since round 6):
+        dz = (dO W) * saved, one multiply per element instead of a sigmoid and a polynomial in an MFMA kernel's epilogue;
       * act_grad 2 -- X is the output of a ReLU that nothing else consumes (README quick-start: l2(relu(l1(x)))):
         d(relu input) = (dO W) * [f > 0] -- the separate ReLU-backward launch (at MNIST-MLP scale one more ~5 us graph node)
         goes away."""
@@ -63,7 +65,8 @@ def _plan_fold(X):
         z, saved = X.args[7], X.args[8]
         if not saved or z is None:
             return None
-        return 1, z, z, float(X.args[6])
+        # saved == 2: the forward epilogue left swish'(z) there instead of z (linear_swish.py): the fold is a plain multiply
+        return (3 if saved == 2 else 1), z, z, float(X.args[6])
     if X.op == "relu":
         f_x = X.args[1]
         return 2, f_x, X.xp.empty_like(f_x, dtype=np.float32), 1.0
@@ -312,6 +315,9 @@ class _HIPLinearTensor(Tensor):
                     if kind == 1:
                         call_hip_function("nnhipLinearInputGradSwish", grad, weight.data, arg, dz, in_rows_num, in_features,
                                           out_features, beta, get_current_stream_ptr())
+                    elif kind == 3:
+                        call_hip_function("nnhipLinearInputGradScaled", grad, weight.data, arg, dz, in_rows_num, in_features,
+                                          out_features, get_current_stream_ptr())
                     else:
                         call_hip_function("nnhipLinearInputGradReLU", grad, weight.data, arg, dz, in_rows_num, in_features,
                                           out_features, get_current_stream_ptr())

@@ -4,6 +4,7 @@
 y = swish(X W^T + b) with the bias add and Swish fused into the MFMA GEMM epilogue (optionally also
 writing the pre-activation z).  fp32 MFMA throughout: unlike the reference's TF32 tensor-op path
 (linear_swish_cutlass_evt_full.cu:440) this meets the 1e-4 parity target."""
+import os
 import weakref
 from typing import Union
 
@@ -33,6 +34,14 @@ def hip_linear_swish_backward(X, weights, bias, grad_O, d_linear_tmp, grad_X, gr
                              int(recompute_preactivation), get_current_stream_ptr())
 
 
+# What `save_preactivation=True` keeps for the backward pass: the pre-activation z (the reference's contract,
+# linear_swish_cutlass.py:198-278) or -- the default here since round 6 -- swish'(z), which the forward epilogue gets from the
+# sigmoid it computes anyway.  Nothing but the Swish backward ever reads the saved tensor, and with the derivative in hand that
+# backward is one multiply: the sigmoid + polynomial it replaces cost ~6 % of the 16384 x 2048 x 512 input-gradient GEMM whose
+# epilogue carries it (fp32 MFMA and the vector ALU share lanes).  NNHIP_SWISH_SAVE_DERIVATIVE=0 keeps z.
+_SAVE_DERIVATIVE = os.environ.get("NNHIP_SWISH_SAVE_DERIVATIVE", "1") != "0"
+
+
 class _HIPLinearSwishTensor(Tensor):
     def __init__(self, data, args, op, device):
         super().__init__(data, args, op, device=device, _nocopy=True)
@@ -52,7 +61,7 @@ class _HIPLinearSwishTensor(Tensor):
                                            in_features, out_features)
             else:
                 if save_preactivation:
-                    d_linear_tmp, recompute = preactivation, False
+                    d_linear_tmp, recompute = preactivation, (2 if save_preactivation == 2 else 0)
                 else:
                     d_linear_tmp, recompute = X.xp.empty((in_rows_num, out_features), dtype=np.float32), True
                 hip_linear_swish_backward(X.data, weight.data, bias.data if bias is not None else None, grad,
@@ -94,11 +103,12 @@ class HIPLinearSwish(Module):
         output = X.xp.empty(out_shape, dtype=np.float32)
         preact = X.xp.empty(out_shape, dtype=np.float32) if self.save_preactivation else None
         rows = int(np.prod(X.shape[:-1]))
+        # 0: nothing saved (z is recomputed by the backward GEMM); 1: z; 2: swish'(z) in z's place
+        mode = (2 if _SAVE_DERIVATIVE else 1) if self.save_preactivation else 0
         hip_linear_swish_forward(X.data, self.weight.data, self.bias.data if self.bias is not None else None,
-                                 output, preact, rows, self.in_features, self.out_features, self.swish_beta,
-                                 self.save_preactivation)
+                                 output, preact, rows, self.in_features, self.out_features, self.swish_beta, mode)
         return _HIPLinearSwishTensor(output, (X, self.weight, self.bias, rows, self.in_features, self.out_features,
-                                              self.swish_beta, preact, self.save_preactivation),
+                                              self.swish_beta, preact, mode),
                                      "linear_swish", device=self.device)
 
 

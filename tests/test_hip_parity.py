@@ -246,6 +246,72 @@ def test_gemm_persistent_swish(hip, rows, inf, outf, beta, save):
         assert torch.equal(z, z2)
 
 
+@pytest.mark.parametrize("rows,inf,outf,beta", [(16384, 512, 2048, 1.0), (8192, 96, 1100, 1.3), (200, 64, 256, 0.8), (16384, 128, 128, 1.0)])
+def test_linear_swish_saved_derivative(hip, rows, inf, outf, beta):
+    """ABI 210: nnhipLinearSwishForward(save_preactivation = 2) leaves D = swish'(z) = s + beta z s (1 - s) in `preact` (the
+    reference saves z, linear_swish_cutlass.py:68-98; its backward -- activations.py:223-232 -- needs nothing but this product's
+    factor), and nnhipLinearInputGradScaled / nnhipLinearSwishBackward(recompute_preactivation = 2) multiply by it.  Against
+    float64; the persistent kernel's epilogues (EPI 3 / EPI 4, 16384-row cases) BIT-IDENTICAL to the classic kernel's (row chunks
+    under the slot count); the output O equal to the z-saving mode's bit for bit."""
+    from neunet_hip._lib import call_hip_function as call, get_current_stream_ptr
+    rng = np.random.default_rng(rows + inf + outf)
+    st = get_current_stream_ptr()
+    X = rng.standard_normal((rows, inf)).astype(np.float32)
+    W = (rng.standard_normal((outf, inf)) / np.sqrt(inf)).astype(np.float32)
+    b = rng.standard_normal((1, outf)).astype(np.float32)
+    x, w, bb = dev(X), dev(W), dev(b)
+    o, d = torch.full((rows, outf), float("nan"), device="cuda"), torch.full((rows, outf), float("nan"), device="cuda")
+    o1, z1 = torch.empty_like(o), torch.empty_like(o)
+    call("nnhipLinearSwishForward", x, w, bb, o, d, rows, inf, outf, beta, 2, st)
+    call("nnhipLinearSwishForward", x, w, bb, o1, z1, rows, inf, outf, beta, 1, st)
+    assert torch.equal(o, o1)
+    z64 = X.astype(np.float64) @ W.astype(np.float64).T + b
+    sig = 1.0 / (1.0 + np.exp(-beta * z64))
+    d64 = sig + beta * z64 * sig * (1 - sig)
+    zb = dot_bound(X, W.T) + 4 * U24 * np.abs(z64)
+    # |dD/dz| <= beta (2 + beta |z|) / 4 ... bounded by beta (1 + |beta z|): z's error carried through, plus a few ulp of the evaluation
+    assert_within(host(d), d64, zb * beta * (1 + np.abs(beta * z64)) + 32 * U24 * (1 + np.abs(d64)), "swish'(z)")
+    # chunks under the slot count take the classic kernel: same bits
+    tiles_n = -(-outf // 128)
+    chunk = max(128, (400 // tiles_n) * 128)
+    chunk = -(-(-(-rows // -(-rows // chunk))) // 128) * 128
+    o2, d2 = torch.empty_like(o), torch.empty_like(d)
+    for r0 in range(0, rows, chunk):
+        n = min(chunk, rows - r0)
+        call("nnhipLinearSwishForward", x[r0:r0 + n], w, bb, o2[r0:r0 + n], d2[r0:r0 + n], n, inf, outf, beta, 2, st)
+    assert torch.equal(o, o2) and torch.equal(d, d2)
+    # backward: the next layer's input gradient times D, in place over D (EPI 4 at 16384 rows) and out of place
+    outf2 = 512 if rows == 16384 and outf == 2048 else 96
+    dO = rng.standard_normal((rows, outf2)).astype(np.float32)
+    W2 = (rng.standard_normal((outf2, outf)) / np.sqrt(outf2)).astype(np.float32)
+    ddo, w2 = dev(dO), dev(W2)
+    dx64 = dO.astype(np.float64) @ W2.astype(np.float64)
+    want = dx64 * host(d).astype(np.float64)
+    inpl, outp = d.clone(), torch.empty_like(d)
+    call("nnhipLinearInputGradScaled", ddo, w2, inpl, inpl, rows, outf, outf2, st)
+    call("nnhipLinearInputGradScaled", ddo, w2, d, outp, rows, outf, outf2, st)
+    assert torch.equal(inpl, outp)
+    assert_within(host(outp), want, dot_bound(dO, W2) * np.abs(host(d)) + 8 * U24 * np.abs(want), "dX * D")
+    o3 = torch.empty_like(d)
+    tiles_n = -(-outf // 128)
+    chunk = max(128, (400 // tiles_n) * 128)
+    chunk = -(-(-(-rows // -(-rows // chunk))) // 128) * 128
+    for r0 in range(0, rows, chunk):
+        n = min(chunk, rows - r0)
+        call("nnhipLinearInputGradScaled", ddo[r0:r0 + n], w2, d[r0:r0 + n], o3[r0:r0 + n], n, outf, outf2, st)
+    assert torch.equal(outp, o3)
+    # ... and the unfolded backward entry with tmp = D equals the z-saving one to rounding (dZ = dO * swish'(z))
+    g = dev(rng.standard_normal((rows, outf)).astype(np.float32))
+    t2, t1 = d.clone(), z1.clone()
+    dX2, dW2, db2 = torch.empty_like(x), torch.empty_like(w), torch.empty_like(bb)
+    dX1, dW1, db1 = torch.empty_like(x), torch.empty_like(w), torch.empty_like(bb)
+    call("nnhipLinearSwishBackward", x, w, bb, g, t2, dX2, dW2, db2, rows, inf, outf, beta, 2, st)
+    call("nnhipLinearSwishBackward", x, w, bb, g, t1, dX1, dW1, db1, rows, inf, outf, beta, 0, st)
+    np.testing.assert_allclose(host(t2), host(t1), rtol=2e-5, atol=2e-6)
+    assert_close_scaled(host(dX2), host(dX1))
+    assert_close_scaled(host(dW2), host(dW1))
+
+
 @pytest.mark.parametrize("rows,inf,outf,inplace", [(8192, 1100, 160, True), (16384, 2048, 512, True), (8192, 1100, 192, False),
                                                    (4096, 2200, 992, True)])
 def test_gemm_persistent_input_grad(hip, rows, inf, outf, inplace):
@@ -421,12 +487,16 @@ def test_linear_entry_points_fuzz(hip):
         assert_within(host(zz), dzr, dot_bound(dO, W) * np.abs(sp) + 16 * U24 * np.abs(dXr) * spmag, tag + " dX*swish'")
 
 
-@pytest.mark.parametrize("rows,dm,dff,beta", [(200, 64, 256, 1.0), (16384, 128, 128, 1.0), (50, 30, 70, 1.7)])
-def test_ffn_swish_backward_folded_into_dx(hip, rows, dm, dff, beta):
+@pytest.mark.parametrize("save_derivative", [True, False])
+@pytest.mark.parametrize("rows,dm,dff,beta", [(200, 64, 256, 1.0), (16384, 128, 128, 1.0), (50, 30, 70, 1.7), (16384, 512, 2048, 1.0)])
+def test_ffn_swish_backward_folded_into_dx(hip, monkeypatch, rows, dm, dff, beta, save_derivative):
     """fc_2(LinearSwish fc_1(x)): fc_2's dX GEMM applies swish'(z) in its epilogue (nnhipLinearInputGradSwish, in place
     over the saved z; also through split-K and the scalar epilogue) and hands dz to fc_1 -- same gradients as the
     oracle's Linear -> Swish -> Linear chain; a second consumer of h disables the folding."""
     import neunet_hip.nn as nn
+    from neunet_hip.nn.experimental import linear_swish as LS
+    # what the forward keeps for the backward: swish'(z) (the default since round 6: the fold is one multiply) or z
+    monkeypatch.setattr(LS, "_SAVE_DERIVATIVE", save_derivative)
     rng = np.random.default_rng(rows + dff)
     fc1, fc2 = nn.LinearSwish(dm, dff, swish_beta=beta), nn.Linear(dff, dm)
     W1, b1, W2, b2 = [host(t.data) for t in (fc1.weight, fc1.bias, fc2.weight, fc2.bias)]
@@ -442,6 +512,7 @@ def test_ffn_swish_backward_folded_into_dx(hip, rows, dm, dff, beta):
             p.grad = None
         x = T(hip, X)
         hh = fc1(x)
+        assert hh.args[8] == (2 if save_derivative else 1)
         y = fc2(hh)
         if second_consumer:
             y2 = fc2(hh)                      # h consumed twice: plain path, gradients accumulate

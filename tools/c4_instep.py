@@ -18,7 +18,9 @@ import sys
 # key -> (kernel-name substring, grid or None, expected us, launches per step, divisor: how many family units one launch covers)
 FAMILIES = {
     "qkv_fwd": ("gemm_pst_kernel<0, true>", None, 190, 6, 1), "head_fwd": ("gemm_pst_kernel<0, true>", None, 1800, 1, 1),
-    "fc1_fwd_swish": ("gemm_pst_kernel<1, true>", None, 260, 6, 1), "fc2_dx_swish": ("gemm_pst_kernel<2, false>", None, 270, 6, 1),
+    # (round 6: the forward saves swish'(z), EPI 3, and the input gradient multiplies by it, EPI 4; "|" = either kernel name)
+    "fc1_fwd_swish": ("gemm_pst_kernel<3, true>|gemm_pst_kernel<1, true>", None, 260, 6, 1),
+    "fc2_dx_swish": ("gemm_pst_kernel<4, false>|gemm_pst_kernel<2, false>", None, 255, 6, 1),
     "out_fwd": ("gemm_f32_kernel<32, true, true, true, false>", None, 72, 6, 1),
     "fc2_fwd": ("gemm_f32_kernel<32, true, true, true, false>", None, 250, 6, 1),
     "out_dx": ("gemm_f32_kernel<32, true, false, true, false>", None, 68, 6, 1),
@@ -50,7 +52,8 @@ def main():
         for r in s:
             us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
             name, grid = r["Kernel_Name"], int(r.get("Grid_Size_X", r.get("Grid_Size", 0)))
-            cands = [(abs(math.log(us / e)), k) for k, (sub, g, e, _, _) in FAMILIES.items() if sub in name and (g is None or g == grid)]
+            cands = [(abs(math.log(us / e)), k) for k, (sub, g, e, _, _) in FAMILIES.items()
+                     if any(x in name for x in sub.split("|")) and (g is None or g == grid)]
             if cands:
                 per[min(cands)[1]].append(us)
     res = {"_collected": tag, "_steps": len(steps), "_dispatches_per_step": n_common, "_step_ms_mean": round(sum(step_ms) / len(step_ms), 4),

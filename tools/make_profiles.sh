@@ -14,7 +14,7 @@ done
 FF=$(find $G/pmc_fetch_c2 -name "*counter_collection.csv" | head -1); WW=$(find $G/pmc_write_c2 -name "*counter_collection.csv" | head -1)
 python tools/prof_summary.py traffic $FF $WW /tmp/t_c2.json "gemm_f32_kernel<32, true, true, true, false>=gemm_fwd_c2" "gemm_f32_kernel<32, true, false, true, false>=gemm_dx_c2" "gemm_f32_kernel<32, false, false, true, false>=gemm_dw_c2" "adamw_multi=adamw_c2" > /dev/null
 FF=$(find $G/pmc_fetch_c3 -name "*counter_collection.csv" | head -1); WW=$(find $G/pmc_write_c3 -name "*counter_collection.csv" | head -1)
-python tools/prof_summary.py traffic $FF $WW /tmp/t_c3.json "map1_kernel<SwishF>=swish_fwd_c3" "map2_kernel<SwishB>=swish_bwd_c3" "rmsnorm_fwd_rows=rmsnorm_fwd_c3" "rmsnorm_bwd_rows=rmsnorm_bwd_c3" "softmax_fwd_rows=softmax_fwd_c3" "softmax_bwd_rows=softmax_bwd_c3" "ce_rows_kernel=ce_c3" "adamw_multi@524288=adamw_c3" "adamw_multi@1638400=adamw_200x512x1024_c3" > /dev/null
+python tools/prof_summary.py traffic $FF $WW /tmp/t_c3.json "map1_kernel<SwishF>%0=swish_fwd_c3" "map2_kernel<SwishB>%0=swish_bwd_c3" "rmsnorm_fwd_rows%0=rmsnorm_fwd_c3" "rmsnorm_bwd_rows%0=rmsnorm_bwd_c3" "softmax_fwd_rows=softmax_fwd_c3" "softmax_bwd_rows=softmax_bwd_c3" "ce_rows_kernel=ce_c3" "adamw_multi@524288=adamw_c3" "adamw_multi@1638400=adamw_200x512x1024_c3" > /dev/null
 FF=$(find $G/pmc_fetch_c4 -name "*counter_collection.csv" 2>/dev/null | head -1); WW=$(find $G/pmc_write_c4 -name "*counter_collection.csv" 2>/dev/null | head -1)
 echo '{}' > /tmp/t_c4.json
 [ -n "$FF" ] && [ -n "$WW" ] && python tools/prof_summary.py traffic $FF $WW /tmp/t_c4.json "gemm_f32_group_kernel@393216=gemm_group_dw2_c4" "gemm_f32_group_kernel@241664=gemm_head_dw_c4" "attn_sb_fwd_kernel=attn_sb_fwd_c4" "attn_sb_bwd_kernel=attn_sb_bwd_c4" "ce_rows_kernel=ce_c4" > /dev/null

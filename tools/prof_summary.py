@@ -29,18 +29,43 @@ def stats(path, out, title="rocprofv3 --kernel-trace --stats"):
                     f"{float(r['Percentage']):.2f} |\n")
 
 
+def size_classes(durations, ratio=1.6):
+    """Dispatches of one (kernel, grid) that differ in PROBLEM SIZE: rocprofv3 records no kernel arguments, and a persistent kernel
+    uses one grid for every size (rmsnorm_bwd_rows: 131072 threads for the 8192-row and the 32768-row launches of `bench.py
+    --workload c3` -- round 5 averaged the two into a 1.22 GB "traffic" figure for a 403 MB kernel).  Durations under profiling
+    separate them: sorted, a jump by more than `ratio` starts a new class.  Returns {dispatch key: class index}, shortest first."""
+    order = sorted(durations.items(), key=lambda kv: kv[1])
+    cls, out, prev = 0, {}, None
+    for key, us in order:
+        if prev is not None and us > prev * ratio:
+            cls += 1
+        out[key] = cls
+        prev = us
+    return out
+
+
 def load_counters(paths):
-    d = collections.defaultdict(lambda: collections.defaultdict(list))
-    dur = collections.defaultdict(list)
-    seen = set()
+    """{(kernel, grid, size class): {counter: [values]}}, {same key: [durations us]} -- keyed on the problem size, not just the grid."""
+    rows_by = collections.defaultdict(list)
     for p in paths:
         for r in csv.DictReader(open(p)):
-            k = (short(r["Kernel_Name"], 90), int(r["Grid_Size"]))
-            d[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            grid = int(r["Grid_Size"]) if "Grid_Size" in r else int(r["Grid_Size_X"])
+            rows_by[(short(r["Kernel_Name"], 90), grid)].append((p, r))
+    d = collections.defaultdict(lambda: collections.defaultdict(list))
+    dur = collections.defaultdict(list)
+    for (name, grid), rows in rows_by.items():
+        dd = {}
+        for p, r in rows:
+            dd[(p, r["Dispatch_Id"])] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        cls = size_classes(dd)
+        seen = set()
+        for p, r in rows:
             key = (p, r["Dispatch_Id"])
+            k = (name, grid, cls[key])
+            d[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
             if key not in seen:
                 seen.add(key)
-                dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+                dur[k].append(dd[key])
     return d, dur
 
 
@@ -51,7 +76,9 @@ def pmc(paths, out):
         for k in sorted(d, key=lambda k: -sum(dur[k])):
             if not k[0].startswith(("gemm", "map", "colsum", "softmax", "rmsnorm", "ce_", "adamw", "conv", "swiglu", "splitk")):
                 continue
-            f.write(f"## `{k[0]}` grid={k[1]}  (n={len(dur[k])}, mean {sum(dur[k]) / len(dur[k]):.1f} us under profiling)\n\n")
+            ncls = 1 + max(kk[2] for kk in d if kk[:2] == k[:2])
+            f.write(f"## `{k[0]}` grid={k[1]}" + (f" size class {k[2]} of {ncls} (by duration)" if ncls > 1 else "") +
+                    f"  (n={len(dur[k])}, mean {sum(dur[k]) / len(dur[k]):.1f} us under profiling)\n\n")
             for c, v in sorted(d[k].items()):
                 f.write(f"- {c}: {sum(v) / len(v):.6g}\n")
             v = d[k]
@@ -69,14 +96,19 @@ def traffic(fetch_csv, write_csv, out, specs):
     res = {}
     for spec in specs:
         sub, tag = spec.split("=")
-        grid = None
+        grid, cls = None, None
+        if "%" in sub:                      # kernel[@grid]%k: the k-th size class (by duration, shortest first) of that kernel / grid
+            sub, cls = sub.split("%")
+            cls = int(cls)
         if "@" in sub:
             sub, grid = sub.split("@")
             grid = int(grid)
-        pick = lambda dd, c: [sum(v[c]) / len(v[c]) for k, v in dd.items() if sub in k[0] and (grid is None or k[1] == grid) and c in v]  # noqa: E731
+        pick = lambda dd, c: [sum(v[c]) / len(v[c]) for k, v in sorted(dd.items(), key=lambda kv: kv[0][2])  # noqa: E731
+                              if sub in k[0] and (grid is None or k[1] == grid) and (cls is None or k[2] == cls) and c in v]
         f, w = pick(fd, "FETCH_SIZE"), pick(wd, "WRITE_SIZE")
         if f and w:
             res[tag] = {"hbm_bytes_per_launch": (2 * f[0] + w[0]) * 1024, "FETCH_SIZE_KiB": f[0], "WRITE_SIZE_KiB": w[0],
+                        "size_classes_seen": len(f), "selected": spec.split("=")[0],
                         "formula": "(2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE half-count correction)"}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
