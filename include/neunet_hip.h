@@ -113,6 +113,11 @@ int nnhipLinearModuleBackwardEx(const float* X, const float* W, const float* dO,
  * the only caller until it has flushed (Tensor.backward() switches it on for the duration of its own tape walk only).  ABI 204 */
 int nnhipWeightGradDefer(int32_t enable, nnhipStream_t stream);
 int nnhipWeightGradFlush(nnhipStream_t stream);
+/* Only the queued dW/db GEMMs (one grouped launch + its reduce) on `stream`, which may be a SIDE stream: the caller orders it behind
+ * the producers of the queued calls' X / dO, keeps those alive until it has joined `stream` again, and reads dW / db only after the
+ * join.  The launch keeps its split-K slabs in a block of its own, so kernels of the main stream may run next to it.  Everything
+ * else a flush does (conv reduces, RMSNorm column sums) stays with nnhipWeightGradFlush.  ABI 210 */
+int nnhipWeightGradFlushGemms(nnhipStream_t stream);
 int nnhipWeightGradPending(void);
 
 /* ---- a6 fused Linear -> Swish  (replaces cudaLinearSwishForward/Backward,

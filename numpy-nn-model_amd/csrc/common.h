@@ -36,6 +36,7 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // Grow-only per-process device workspace (split-K slabs, column-sum partials).  Freed by
 // nnhipCleanup().  Growing it synchronises the device (hipFree) -- it happens at most a few times.
 void* workspace(size_t bytes);
+void* workspace_arena(int which, size_t bytes);   // 0 = the general block (== workspace), 1 = the grouped dW launch's slabs
 bool workspace_locked();               // nnhipWorkspaceLock(1): a captured hipGraph holds library-owned addresses -- nothing may move
 // Deferred parameter gradients (nnhipWeightGradDefer, linear.hip): on while Tensor.backward() walks the tape.  conv2d.hip queues the
 // REDUCE of a small-channel conv's per-image partial weight gradients behind it (the partials sit in an arena of their own, not

@@ -859,7 +859,7 @@ int gemm_f32_wgrad_group(const WgradJob* jobs, int n, hipStream_t st) {
         const int64_t kps = wgrad_chunk(j.K);
         floats += (size_t)ceil_div(j.K, kps) * (size_t)(j.M * j.N + (j.asum ? j.M : 0));
     }
-    float* slab = static_cast<float*>(workspace(floats * sizeof(float)));
+    float* slab = static_cast<float*>(workspace_arena(1, floats * sizeof(float)));
     if (!slab) { set_last_error("grouped dW workspace allocation failed"); return NNHIP_ENOMEM; }
     const float* zeros = zero_block();
     if (!zeros) { set_last_error("zero block allocation failed"); return NNHIP_ENOMEM; }

@@ -157,6 +157,15 @@ extern "C" int nnhipWeightGradFlush(nnhipStream_t stream) {
     if (int rc3 = nnhip::colsum_flush(stream)) rc = rc ? rc : rc3;
     return rc;
 }
+// Only the queued GEMMs (the grouped launch + its reduce), on `stream` -- which may be a side stream: the launch reads the queued
+// calls' X / dO (the caller orders `stream` behind their producers and keeps them alive until it has joined `stream` again), writes
+// its slabs to a block of its own and dW / db where the calls asked.  The conv reduces and RMSNorm column sums queued next to them
+// stay for nnhipWeightGradFlush on the stream their producers run on.  ABI 210
+extern "C" int nnhipWeightGradFlushGemms(nnhipStream_t stream) {
+    std::lock_guard<std::mutex> lk(g_wq_mu);
+    if (!g_wq.empty()) g_wq_stream = (hipStream_t)stream;
+    return wq_flush_locked();
+}
 extern "C" int nnhipWeightGradPending(void) {
     std::lock_guard<std::mutex> lk(g_wq_mu);
     return (int)g_wq.size();

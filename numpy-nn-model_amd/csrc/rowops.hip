@@ -434,8 +434,19 @@ static bool g_csq_vec = false;
 static hipStream_t g_csq_st = nullptr;
 static float* g_csq_arena = nullptr;
 static size_t g_csq_cap = 0, g_csq_used = 0;              // floats
+// The arena is ONE per process.  A flush launched on stream A may still be reading it when a backward pass on stream B starts
+// writing partials at offset 0 (advisor, round 5): every flush outside a graph capture records an event, and the first reservation
+// on another stream waits for it.  (Inside a capture the step is single-stream by construction, neunet_hip/graph.py.)
+static hipEvent_t g_csq_ev = nullptr;
+static hipStream_t g_csq_flush_st = nullptr;
+static bool g_csq_ev_live = false;
+static bool csq_capturing(hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return cs != hipStreamCaptureStatusNone;
+}
 static int csq_flush_locked(hipStream_t st) {
-    if (g_csq_n == 0) return 0;
+    if (g_csq_n == 0) { g_csq_used = 0; return 0; }         // (a reservation whose launch failed leaves nothing queued: give its floats back)
     ColsumGroup grp;
     int blocks = 0;
     for (int i = 0; i < CSQ_MAX; ++i) {
@@ -451,6 +462,11 @@ static int csq_flush_locked(hipStream_t st) {
     else { if (g_csq_sw == 8) CSG(8, false); else CSG(4, false); }
 #undef CSG
     NNHIP_LAUNCH_CHECK("colsum_group_kernel");
+    if (!csq_capturing(st)) {
+        if (!g_csq_ev && hipEventCreateWithFlags(&g_csq_ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); g_csq_ev = nullptr; }
+        if (g_csq_ev && hipEventRecord(g_csq_ev, st) == hipSuccess) { g_csq_flush_st = st; g_csq_ev_live = true; }
+        else (void)hipGetLastError();
+    }
     return 0;
 }
 int colsum_flush(void* stream) {
@@ -474,6 +490,10 @@ static float* colsum_partials(size_t floats, int njobs, int sw, bool vec, hipStr
     std::lock_guard<std::mutex> lk(g_csq_mu);
     if (g_csq_n && (g_csq_st != st || g_csq_n + njobs > CSQ_MAX || g_csq_used + floats > g_csq_cap || g_csq_sw != sw || g_csq_vec != vec))
         *rc = csq_flush_locked(g_csq_st);
+    if (g_csq_ev_live && g_csq_flush_st != st && !csq_capturing(st)) {      // the last flush ran on another stream: order behind it
+        if (hipStreamWaitEvent(st, g_csq_ev, 0) != hipSuccess) (void)hipGetLastError();
+        g_csq_flush_st = st;                                                // (this stream is now ordered behind that flush)
+    }
     if (floats > g_csq_cap && !workspace_locked()) {          // grow (nothing is queued here); never while a captured graph holds the address
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         (void)hipStreamIsCapturing(st, &cs);

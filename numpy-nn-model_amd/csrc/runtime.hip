@@ -24,37 +24,41 @@ int hip_status(hipError_t e, const char* what) {
 }
 
 static std::mutex g_ws_mu;
-static void* g_ws = nullptr;
-static size_t g_ws_bytes = 0;
-static bool g_ws_locked = false;   // nnhipWorkspaceLock: a captured hipGraph holds the block's address
+// Two grow-only blocks: 0 = the general workspace (split-K slabs, column-sum partials, ...), 1 = the slabs of the GROUPED parameter-
+// gradient launch (gemm.hip: gemm_f32_wgrad_group) -- its own block because that launch may run on a side stream next to kernels of
+// the main stream that use block 0 (neunet_hip/_lib.py: NNHIP_WGRAD_STREAM; round 6).
+static void* g_ws[2] = {nullptr, nullptr};
+static size_t g_ws_bytes[2] = {0, 0};
+static bool g_ws_locked = false;   // nnhipWorkspaceLock: a captured hipGraph holds the blocks' addresses
 
-void* workspace(size_t bytes) {
+void* workspace_arena(int which, size_t bytes) {
     std::lock_guard<std::mutex> lk(g_ws_mu);
-    if (bytes <= g_ws_bytes) return g_ws;
+    if (bytes <= g_ws_bytes[which]) return g_ws[which];
     if (g_ws_locked) {
         set_last_error("workspace is locked at %zu bytes (a captured hipGraph uses it) but %zu bytes were requested; "
-                       "run the new shape eagerly before capturing, or nnhipWorkspaceLock(0)", g_ws_bytes, bytes);
+                       "run the new shape eagerly before capturing, or nnhipWorkspaceLock(0)", g_ws_bytes[which], bytes);
         return nullptr;
     }
-    if (g_ws) {
+    if (g_ws[which]) {
         (void)hipDeviceSynchronize();  // kernels may still read the old block
-        (void)hipFree(g_ws);
-        g_ws = nullptr;
-        g_ws_bytes = 0;
+        (void)hipFree(g_ws[which]);
+        g_ws[which] = nullptr;
+        g_ws_bytes[which] = 0;
     }
     size_t want = bytes + (bytes >> 2);  // 25 % head-room: fewer regrowths
     want = (want + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
-    if (hipMalloc(&g_ws, want) != hipSuccess) {
-        g_ws = nullptr;
-        if (hipMalloc(&g_ws, bytes) != hipSuccess) {
-            g_ws = nullptr;
+    if (hipMalloc(&g_ws[which], want) != hipSuccess) {
+        g_ws[which] = nullptr;
+        if (hipMalloc(&g_ws[which], bytes) != hipSuccess) {
+            g_ws[which] = nullptr;
             return nullptr;
         }
         want = bytes;
     }
-    g_ws_bytes = want;
-    return g_ws;
+    g_ws_bytes[which] = want;
+    return g_ws[which];
 }
+void* workspace(size_t bytes) { return workspace_arena(0, bytes); }
 
 bool workspace_locked() { return g_ws_locked; }
 
@@ -187,12 +191,16 @@ extern "C" int nnhipCleanup(void) {
     nnhip::colsum_cleanup();
     std::lock_guard<std::mutex> lk(nnhip::g_ws_mu);
     nnhip::g_ws_locked = false;
-    if (nnhip::g_ws) {
-        (void)hipDeviceSynchronize();
-        hipError_t e = hipFree(nnhip::g_ws);
-        nnhip::g_ws = nullptr;
-        nnhip::g_ws_bytes = 0;
-        return nnhip::hip_status(e, "hipFree(workspace)");
+    int rc = 0;
+    bool synced = false;
+    for (int w = 0; w < 2; ++w) {
+        if (!nnhip::g_ws[w]) continue;
+        if (!synced) { (void)hipDeviceSynchronize(); synced = true; }
+        hipError_t e = hipFree(nnhip::g_ws[w]);
+        nnhip::g_ws[w] = nullptr;
+        nnhip::g_ws_bytes[w] = 0;
+        if (e != hipSuccess && !rc) rc = nnhip::hip_status(e, "hipFree(workspace)");
     }
+    if (rc) return rc;
     return 0;
 }

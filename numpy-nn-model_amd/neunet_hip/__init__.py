@@ -28,9 +28,11 @@ def argmax(x: Tensor, axis=None, keepdims=False):
     from ._lib import call_hip_function, get_current_stream_ptr
     d = x.data
     if d.dtype != torch.float32:
-        # np.argmax takes labels / ids / masks too (neunet/__init__.py:132-139).  Integers below 2^24 are exact in fp32: they ride on
-        # the library's kernel; anything else (wide integers, float64) keeps torch's argmax -- same first-maximum rule.
-        if d.dtype in (torch.int16, torch.int32, torch.int64, torch.uint8, torch.bool) and (d.numel() == 0 or int(d.abs().max() if d.dtype != torch.bool else 1) < (1 << 24)):
+        # np.argmax takes labels / ids / masks too (neunet/__init__.py:132-139).  The library's kernel compares fp32: integer types
+        # whose EVERY value is exact in fp32 (|v| < 2^24: bool, uint8, int16) ride on it; wider integers and float64 keep torch's
+        # argmax -- same first-maximum rule.  Decided from the dtype alone: a range test on the data (round 5: `d.abs().max()`)
+        # is a host read in the middle of a step and breaks hipGraph capture (advisor, round 5).
+        if d.dtype in (torch.int16, torch.uint8, torch.bool):
             d = d.to(torch.float32)
         else:
             out = torch.argmax(d) if axis is None else torch.argmax(d, dim=axis, keepdim=keepdims)

@@ -59,6 +59,7 @@ _SIGNATURES = {
     "nnhipLinearModuleBackward": (ctypes.c_int, [P, P, P, P, P, P, c_int64, c_int64, c_int64, c_void_p]),
     "nnhipWeightGradDefer": (ctypes.c_int, [ctypes.c_int32, c_void_p]),
     "nnhipWeightGradFlush": (ctypes.c_int, [c_void_p]),
+    "nnhipWeightGradFlushGemms": (ctypes.c_int, [c_void_p]),
     "nnhipWeightGradPending": (ctypes.c_int, []),
     "nnhipLinearInputGradSwish": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_float, c_void_p]),
     "nnhipLinearInputGradScaled": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_int64, c_void_p]),
@@ -268,7 +269,7 @@ def _wgrad_after_call(args):
         return
     _wgrad["keep"].append([a for a in args if hasattr(a, "data_ptr") or isinstance(a, StridedView)])
     if pending >= _wgrad["group"]:
-        wgrad_flush()
+        wgrad_flush(join=False)
 
 
 def wgrad_begin() -> bool:
@@ -280,19 +281,63 @@ def wgrad_begin() -> bool:
     return True
 
 
-def wgrad_flush():
-    """Launch what is queued (a layer's worth is there, a DP segment is about to be exchanged, or backward is over)."""
+# NNHIP_WGRAD_STREAM=1 (round 6, experimental): the grouped launch goes to a SIDE stream -- it depends on nothing the rest of the
+# backward pass produces later and nothing before the optimizer reads it, so it can fill the launch gaps and ramps of the ~100
+# dependent kernels of the main chain.  Fork: the side stream waits for an event recorded on the current stream (the queued calls'
+# dO / X are complete); join: wgrad_end() (or a flush whose caller reads gradients next) makes the current stream wait for the side
+# stream.  The queued calls' arrays stay referenced until the join.  Same kernels, same bits.
+_WGRAD_SIDE = os.environ.get("NNHIP_WGRAD_STREAM", "0") == "1"
+_side = {"stream": None, "busy": False, "keep": []}
+
+
+def _side_stream():
+    import torch
+    if _side["stream"] is None:
+        _side["stream"] = torch.cuda.Stream()
+    return _side["stream"]
+
+
+def wgrad_join():
+    """Order the current stream behind the side stream's grouped launches (no-op when none is outstanding)."""
+    if _side["busy"]:
+        import torch
+        done = torch.cuda.Event()
+        done.record(_side["stream"])
+        torch.cuda.current_stream().wait_event(done)
+        _side["busy"] = False
+        _side["keep"].clear()
+
+
+def wgrad_flush(join: bool = True):
+    """Launch what is queued (a layer's worth is there, a DP segment is about to be exchanged, or backward is over).
+    join=False (the queue's own size trigger): with NNHIP_WGRAD_STREAM=1 the GEMMs may keep running on the side stream."""
     if _wgrad["on"]:
+        if _WGRAD_SIDE and load_hip_function("nnhipWeightGradPending")() > 0:
+            import torch
+            side = _side_stream()
+            ready = torch.cuda.Event()
+            ready.record()
+            side.wait_event(ready)
+            call_hip_function("nnhipWeightGradFlushGemms", side.cuda_stream)
+            _side["busy"] = True
+            _side["keep"].extend(_wgrad["keep"])
         call_hip_function("nnhipWeightGradFlush", get_current_stream_ptr())
         _wgrad["keep"].clear()
+    if join:
+        wgrad_join()
 
 
 def wgrad_end():
     _wgrad["on"] = False
     try:
+        if _WGRAD_SIDE and load_hip_function("nnhipWeightGradPending")() > 0:
+            _wgrad["on"] = True
+            wgrad_flush(join=False)
+            _wgrad["on"] = False
         call_hip_function("nnhipWeightGradDefer", 0, get_current_stream_ptr())
     finally:
         _wgrad["keep"].clear()
+        wgrad_join()
 
 
 def exported_symbols():

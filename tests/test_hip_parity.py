@@ -4036,6 +4036,16 @@ def test_deferred_weight_grads_in_backward(hip, monkeypatch):
     g_on, l_on, n_on = run(4)
     g_off, l_off, n_off = run(0)
     assert l_on == l_off and n_on == n_off
+    # round 6, opt-in NNHIP_WGRAD_STREAM=1: the grouped launches on a side stream (fork at the flush, join at the end of backward();
+    # measured SLOWER on the C4 step -- EXPERIMENTS.md -- and kept as a tested switch): same kernels, same bits
+    monkeypatch.setattr(_lib, "_WGRAD_SIDE", True)
+    g_side, l_side, n_side = run(4)
+    monkeypatch.setattr(_lib, "_WGRAD_SIDE", False)
+    assert l_side == l_on and n_side == n_on and not _lib._side["busy"] and not _lib._side["keep"]
+    for a, b in zip(g_side, g_on):
+        assert (a is None) == (b is None)
+        if a is not None:
+            np.testing.assert_array_equal(a, b)
     scale = grad_list_scale([a for a in g_off if a is not None])
     for k, (a, b) in enumerate(zip(g_on, g_off)):
         assert (a is None) == (b is None)
