@@ -36,6 +36,7 @@ namespace nnhip {
 
 typedef unsigned sb_u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned sb_u32x4 __attribute__((ext_vector_type(4)));
+typedef float sb_f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int SB_T = 256;        // the sequence length these kernels are built for: 8 groups of 32 rows <-> 8 waves
 constexpr int SB_NG = 8;
@@ -370,6 +371,192 @@ __global__ __launch_bounds__(512, 2) void attn_sb_fwd_kernel(const AttnParams p)
         SB_T(6);
     }
     SB_PROF_STORE(wave);
+}
+
+
+// ---- round 6: two forwards that take their K / V operands from LDS tiles instead of streaming them into the MFMA registers ---------
+// Why they were tried: the streamed forward's counters show the texture addresser's FIFOs full for two thirds of the kernel
+// (SQ_VMEM_TA_ADDR_FIFO_FULL 2.4 M of 3.5 M busy cycles, matrix pipe busy 55 %; profiles/r05d_attention_pmc.md) -- a third of its
+// 24 operand loads per unit are "lane <-> key row" (32 rows of 256 B touched by one instruction).  Result (MI355X, B64 H8, same box):
+// streamed 55.2-58.9 us; BLOCK-SHARED tiles (all waves of a slice on the same key group per step, four tiles per step fetched once
+// per block, a two-deep ring, one block barrier per step) 65 us -- the barrier aligns the two waves of every SIMD and the wave that
+// finishes a row group holds the other seven up, nine times per block; WAVE-PRIVATE tiles (below: no barrier, whole-row loads one
+// unit ahead) 60-63 us -- the 16 + 24 LDS instructions per unit cost more than the texture addresser's queueing did.  The streamed
+// kernel stays the default; the wave-private variant is kept as a tested switch (NNHIP_ATTN_SB_FWD=pw), the block-shared one was
+// deleted (EXPERIMENTS.md, round 6).
+constexpr int SB_TILE = 32 * SB_LD;                       // floats of one staged tile
+
+// sb_store_rows with COMPILER barriers around the wave-private transposition: E reaches sb_rows_out as a second pointer, and neither
+// s_waitcnt nor wave_barrier orders memory accesses for hipcc -- inlined next to other LDS traffic the row reads were scheduled above
+// the writes they transpose (right statistics, scrambled output)
+__device__ __forceinline__ void sb_store_rows_fenced(float* E, const f32x16 (&acc)[2], float mul, sb_rsrc rs, unsigned soff, unsigned pitchB, int lane) {
+    const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        *reinterpret_cast<float4*>(&E[l31 * SB_LD + 16 * c + 8 * lh]) =
+            make_float4(acc[0][4 * c] * mul, acc[1][4 * c] * mul, acc[0][4 * c + 1] * mul, acc[1][4 * c + 1] * mul);
+        *reinterpret_cast<float4*>(&E[l31 * SB_LD + 16 * c + 8 * lh + 4]) =
+            make_float4(acc[0][4 * c + 2] * mul, acc[1][4 * c + 2] * mul, acc[0][4 * c + 3] * mul, acc[1][4 * c + 3] * mul);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    sb_rows_out(E, rs, soff, pitchB, lane);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <bool MASKED>
+__device__ __forceinline__ void sb_fwd_unit_lds(f32x16 (&o)[2], float& m, float& l, const float* __restrict__ Kt, const float* __restrict__ Vt,
+                                                const float (&qf)[8][4], const int l31, const int lh, const int lim_causal, const unsigned valid) {
+    f32x16 s;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e] = 0.f;
+    const float* __restrict__ krow = Kt + l31 * SB_LD + 4 * lh;          // lane <-> key row l31, columns 8 g + 4 lh .. + 3
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const float4 k4 = *reinterpret_cast<const float4*>(krow + 8 * g);
+        s = AT_MFMA(k4.x, qf[g][0], s);
+        s = AT_MFMA(k4.y, qf[g][1], s);
+        s = AT_MFMA(k4.z, qf[g][2], s);
+        s = AT_MFMA(k4.w, qf[g][3], s);
+    }
+    float mx = -INFINITY;
+    if constexpr (MASKED) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int r = sb_row(e);
+            if (r > lim_causal || !((valid >> r) & 1u)) s[e] = AT_MASKED2;
+            mx = fmaxf(mx, s[e]);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[e]);
+    }
+    mx = sb_pair_max(mx);
+    if (__ballot(mx > m + 8.0f) != 0ull) {                  // lazy running maximum (see sb_fwd_unit)
+        const float m_new = fmaxf(m, mx);
+        const float alpha = m_new == m ? 1.0f : __builtin_amdgcn_exp2f(m - m_new);
+        m = m_new;
+        l *= alpha;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { o[0][e] *= alpha; o[1][e] *= alpha; }
+    }
+    float ps = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        s[e] = __builtin_amdgcn_exp2f(s[e] - m);
+        ps += s[e];
+    }
+    l += ps;
+    const float* __restrict__ vcol = Vt + (4 * lh) * SB_LD + 2 * l31;    // lane <-> columns 2 l31, 2 l31 + 1 of row r(e) + 4 lh
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const float2 v2 = *reinterpret_cast<const float2*>(vcol + sb_row(e) * SB_LD);
+        o[0] = AT_MFMA(v2.x, s[e], o[0]);
+        o[1] = AT_MFMA(v2.y, s[e], o[1]);
+    }
+}
+
+
+// ---- forward with WAVE-PRIVATE K / V tiles in LDS (round 6; opt-in NNHIP_ATTN_SB_FWD=pw) --------------------------------------------------------
+// The streamed kernel's schedule (every wave free-running over its own key groups, no block barrier) with the operand path of the
+// LDS kernel: a wave fetches its next (K_j, V_j) pair with whole-row loads (8 + 8 float4 per lane, 4 rows x 256 B per instruction)
+// one unit ahead, parks it in its own [2][32][68] LDS tile pair and reads the MFMA fragments from there -- no "lane <-> key row"
+// loads (the texture addresser's problem), no barrier (the LDS kernel's problem).  The tile pair is single-buffered: the unit's
+// fragments are all in registers before the next pair is written.
+__global__ __launch_bounds__(512, 2) void attn_sb_fwd_pw_kernel(const AttnParams p) {
+    __shared__ __attribute__((aligned(16))) float smem[8 * 2 * SB_TILE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int BH = p.B * p.H;
+    const float qs = p.scale * AT_LOG2E;
+    float* Kt = smem + wave * 2 * SB_TILE;                  // (also the output staging rows at the end of an item)
+    float* Vt = Kt + SB_TILE;
+    const int64_t goff = (int64_t)(lane >> 4) * p.LQ + 4 * (lane & 15);      // this lane's float4 of rows (lane >> 4) + 4 it
+    const int loff = (lane >> 4) * SB_LD + 4 * (lane & 15);
+#pragma unroll 1
+    for (int item = 0; item < 2; ++item) {
+        const int bh = 2 * blockIdx.x + item;
+        if (bh >= BH) break;
+        const int rg = item == 0 ? SB_NG - 1 - wave : wave;
+        const int b = bh / p.H, h = bh - b * p.H;
+        const float* __restrict__ Qb = p.Q + ((int64_t)b * SB_T) * p.LQ + (int64_t)h * SB_DH;
+        const float* __restrict__ Kb = p.K + ((int64_t)b * SB_T) * p.LQ + (int64_t)h * SB_DH;
+        const float* __restrict__ Vb = p.V + ((int64_t)b * SB_T) * p.LQ + (int64_t)h * SB_DH;
+        float qf[8][4];
+        {
+            const float* qrow = Qb + (int64_t)(32 * rg + l31) * p.LQ + 4 * lh;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const float4 v = *reinterpret_cast<const float4*>(qrow + 8 * g);
+                qf[g][0] = v.x * qs; qf[g][1] = v.y * qs; qf[g][2] = v.z * qs; qf[g][3] = v.w * qs;
+            }
+        }
+        SbKeyBits kvbits = {~0ull, ~0ull, ~0ull, ~0ull};
+        int fv = 0;
+        if (p.key_valid) sb_key_bits(p.key_valid + (int64_t)b * SB_T, lane, kvbits, fv);
+        // a query with no visible real key is uniform over ALL keys: nothing above the diagonal may be skipped then
+        const int n_units = fv <= 32 * rg ? rg + 1 : SB_NG;
+        // the streamed kernel's order of the key groups (so that the two kernels agree bit for bit): the groups that need no masking,
+        // then the masked ones (padding inside; above the diagonal for a group with fully-masked rows), the diagonal group last
+        unsigned plain = 0u;
+#pragma unroll
+        for (int j = 0; j < SB_NG; ++j)
+            if (j < rg && sb_valid32(kvbits, j) == 0xFFFFFFFFu) plain |= 1u << j;
+        unsigned masked = (((1u << n_units) - 1u) & ~plain) & ~(1u << rg);
+        int j = plain ? (int)__builtin_ctz(plain) : masked ? (int)__builtin_ctz(masked) : rg;
+        sb_f32x4 nk[8], nv[8];               // (ext vectors: an array of HIP float4 structs went to scratch, 272 B per lane)
+        {
+            const int64_t ro = (int64_t)(32 * j) * p.LQ + goff;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                nk[it] = *reinterpret_cast<const sb_f32x4*>(Kb + ro + (int64_t)(4 * it) * p.LQ);
+                nv[it] = *reinterpret_cast<const sb_f32x4*>(Vb + ro + (int64_t)(4 * it) * p.LQ);
+            }
+        }
+        f32x16 o[2];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { o[0][e] = 0.f; o[1][e] = 0.f; }
+        float m = -INFINITY, l = 0.f;
+#pragma unroll 1
+        for (int u = 0; u < n_units; ++u) {
+            // park the pair that has arrived; the previous unit's fragments were read before its MFMAs (and the staging rows of the
+            // previous item's output before that item ended)
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                *reinterpret_cast<sb_f32x4*>(Kt + loff + 4 * it * SB_LD) = nk[it];
+                *reinterpret_cast<sb_f32x4*>(Vt + loff + 4 * it * SB_LD) = nv[it];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            // this unit's class, and the group after it: plain groups first, then the masked ones, the diagonal last
+            const bool is_plain = (plain >> j) & 1u;
+            if (is_plain) plain &= ~(1u << j); else masked &= ~(1u << j);
+            const int jn = plain ? (int)__builtin_ctz(plain) : masked ? (int)__builtin_ctz(masked) : rg;
+            if (u + 1 < n_units) {                           // the next pair on its way
+                const int64_t ro = (int64_t)(32 * jn) * p.LQ + goff;
+#pragma unroll
+                for (int it = 0; it < 8; ++it) {
+                    nk[it] = *reinterpret_cast<const sb_f32x4*>(Kb + ro + (int64_t)(4 * it) * p.LQ);
+                    nv[it] = *reinterpret_cast<const sb_f32x4*>(Vb + ro + (int64_t)(4 * it) * p.LQ);
+                }
+            }
+            const unsigned valid = sb_valid32(kvbits, j);
+            if (j == rg) sb_fwd_unit_lds<true>(o, m, l, Kt, Vt, qf, l31, lh, l31 - 4 * lh, valid >> (4 * lh));
+            else if (is_plain) sb_fwd_unit_lds<false>(o, m, l, Kt, Vt, qf, l31, lh, 0, 0u);
+            else sb_fwd_unit_lds<true>(o, m, l, Kt, Vt, qf, l31, lh, j < rg ? (1 << 20) : -1, valid >> (4 * lh));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the unit's fragment reads are done: the tile pair may be overwritten
+            __builtin_amdgcn_wave_barrier();
+            j = jn;
+        }
+        const float lt = sb_pair_sum(l);
+        const float inv = lt > 0.f ? 1.0f / lt : 0.f;
+        const int q0 = 32 * rg;
+        if (lh == 0) *reinterpret_cast<float2*>(p.LSE + 2 * ((int64_t)bh * SB_T + q0 + l31)) = make_float2(m, log2f(lt));
+        sb_store_rows_fenced(Kt, o, inv, sb_make_rsrc(p.O + ((int64_t)b * SB_T) * p.D + (int64_t)h * SB_DH, (unsigned)(((int64_t)(SB_T - 1) * p.D + SB_DH) * 4)),
+                      (unsigned)q0 * (unsigned)p.D * 4u, (unsigned)p.D * 4u, lane);
+    }
 }
 
 
@@ -809,6 +996,13 @@ int attn_sb_backward(const AttnBwdParams& p, hipStream_t st) {
 
 int attn_sb_forward(const AttnParams& p, hipStream_t st) {
     const int BH = p.B * p.H;
+    // NNHIP_ATTN_SB_FWD=pw: wave-private LDS tiles (round 6, measured 5-8 % slower than the streamed default; kept as a tested switch)
+    static const bool pw = []() { const char* e = getenv("NNHIP_ATTN_SB_FWD"); return e && e[0] == 'p'; }();
+    if (pw) {
+        hipLaunchKernelGGL(attn_sb_fwd_pw_kernel, dim3((unsigned)((BH + 1) / 2)), dim3(512), 0, st, p);
+        NNHIP_LAUNCH_CHECK("attn_sb_fwd_pw_kernel");
+        return 0;
+    }
     hipLaunchKernelGGL(attn_sb_fwd_kernel, dim3((unsigned)((BH + 1) / 2)), dim3(512), 0, st, p);
     NNHIP_LAUNCH_CHECK("attn_sb_fwd_kernel");
     return 0;

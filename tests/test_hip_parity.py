@@ -2482,6 +2482,32 @@ def test_attention_sb_counted_waits_match_full_drain(hip):
     assert not bad, f"counted waits and full drains disagree: {bad}"
 
 
+def test_attention_sb_forward_wave_private_tiles_variant(hip):
+    """Round 6: NNHIP_ATTN_SB_FWD=pw runs the balanced forward with its K / V operands parked in wave-private LDS tiles (whole-row
+    loads one unit ahead) instead of streamed into the MFMA registers -- measured 5-8 % slower on MI355X and therefore not the
+    default, but kept as a switch: same key-group order, same arithmetic, so everything the forward writes -- and with it every
+    gradient of the backward that consumes its statistics -- must be BIT-IDENTICAL to the default, padding patterns and odd slice
+    counts included (tools/attn_sb_digest.py, one process per setting: the switch is read once)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(mode):
+        env = dict(os.environ)
+        env.pop("NNHIP_ATTN_SB_FWD", None)
+        if mode:
+            env["NNHIP_ATTN_SB_FWD"] = mode
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "attn_sb_digest.py")], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads(r.stdout.strip().splitlines()[-1])
+
+    a, b = run(None), run("pw")
+    assert a.keys() == b.keys() and len(a) >= 20
+    bad = [k for k in a if a[k] != b[k]]
+    assert not bad, f"the wave-private-tile forward differs from the streamed one: {bad}"
+
+
 def test_argmax_integer_tensors_and_upstream_broadcast(hip):
     """neunet.argmax takes labels / ids / masks as well (np.argmax, neunet/__init__.py:132-139): integer device tensors give
     np.argmax's indices bit for bit; loss.backward(g) broadcasts g by SHAPE (a (D,) gradient against a (B, D) 'none' loss runs
