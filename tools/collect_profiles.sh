@@ -11,6 +11,12 @@ timeout 600 python tools/stream_roof.py > $O/stream_roof.txt 2>&1
 timeout 600 python tools/kbench.py --only gemm --gemm-mode 1 > $O/kbench_bf16x3.log 2>&1
 timeout 600 python tools/gemm_accuracy.py > $O/gemm_accuracy.txt 2>&1
 [ -x tools/probes/mfma_valu_probe ] && tools/probes/mfma_valu_probe > $O/mfma_valu_probe.txt 2>&1
+# round 6: what a plain R-read / W-write stream reaches at the footprints of the HBM-bound kernels (cold and warm)
+hipcc --offload-arch=gfx950 -O3 tools/probes/stream_nm_probe.hip -o /tmp/stream_nm_probe > /dev/null 2>&1 && timeout 300 /tmp/stream_nm_probe > $O/stream_nm_probe.txt 2>&1
+# round 6: the hand-counted waits of attention_sb.hip against the fully drained build (-DSB_CHECK), and the wave-private-tile forward
+timeout 900 python -m pytest tests/test_hip_parity.py -q -m gpu -k "counted_waits or wave_private" > $O/attn_sb_check.log 2>&1
+# round 6: the n = 3 collection of the full-batch NumPy-oracle step that every bench line's live n = 1 sample cites
+timeout 600 python bench.py --cpu-full-batch --cpu-full-steps 3 > $O/cpu_c4_full_batch.json 2> $O/cpu_c4_full_batch.err
 timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench_headline.json 2> $O/bench_headline.err
 timeout 600 python bench.py --workload c2 --steps 20 --warmup 5 > $O/bench_c2.json 2> $O/bench_c2.err
 timeout 600 python bench.py --workload c3 --steps 20 --warmup 5 > $O/bench_c3.json 2> $O/bench_c3.err
@@ -50,6 +56,7 @@ cd $R
 timeout 1500 bash tools/attn_sb_pmc.sh $TAG > $O/attn_pmc.log 2>&1      # -> $O/attn_pmc_summary.md (balanced T=256 kernels of attention_sb.hip)
 timeout 900 bash tools/gemm_pmc.sh ${TAG}_bf3 1 8192 4096 4096 > $O/gemm_pmc_bf3.txt 2>&1
 timeout 900 bash tools/gemm_pmc.sh ${TAG}_f32 0 8192 4096 4096 > $O/gemm_pmc_f32.txt 2>&1
+timeout 900 bash tools/gemm_pmc.sh ${TAG}_pst 0 16384 512 1536 > $O/gemm_pmc_pst.txt 2>&1      # the persistent K = 512 kernel (q|k|v forward of C4)
 cd /tmp
 # keep the merge under the 64 MiB limit: drop the raw traces, keep stats + counter CSVs
 timeout 600 python $R/tools/dp_timeline.py $(find $O/prof_dp -name "*_kernel_trace.csv" | head -1) $O/dp_timeline.md "C4 step, 1-rank nccl (RCCL) process group, collectives forced, --dp-op avg: RCCL kernels vs ours (rocprofv3 --kernel-trace)" > /dev/null 2>&1

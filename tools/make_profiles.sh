@@ -72,3 +72,10 @@ cp $G/stream_roof.txt $P/${TAG}_stream_roof.txt
 for f in kbench_bf16x3.log gemm_accuracy.txt mfma_valu_probe.txt; do [ -f $G/$f ] && grep -v amdgpu.ids $G/$f > $P/${TAG}_${f%.*}.txt; done
 # round 5: the balanced T = 256 attention kernels (attention_sb.hip): per-launch counter means (tools/attn_sb_pmc.sh)
 [ -f $G/attn_pmc_summary.md ] && cp $G/attn_pmc_summary.md $P/${TAG}_attention_pmc.md
+# round 6: in-step durations of the C4 families (bench.py prints them next to its isolated figures), the R/W stream probe, the n = 3 oracle step
+T4=$(find $G/prof_c4 -name "*_kernel_trace.csv" 2>/dev/null | head -1)
+[ -n "$T4" ] && python tools/c4_instep.py $T4 $P/c4_instep_families.json ${TAG} > /dev/null
+[ -f $G/stream_nm_probe.txt ] && grep -v amdgpu.ids $G/stream_nm_probe.txt > $P/${TAG}_stream_nm_probe.txt
+[ -s $G/cpu_c4_full_batch.json ] && python -c "import json,sys; json.load(open('$G/cpu_c4_full_batch.json'))" && cp $G/cpu_c4_full_batch.json $P/cpu_c4_full_batch.json
+[ -f $G/gemm_pmc_pst.txt ] && cp $G/gemm_pmc_pst.txt $P/${TAG}_gemm_pmc_pst.txt
+[ -f $G/attn_sb_check.log ] && tail -3 $G/attn_sb_check.log > $P/${TAG}_attn_sb_check.txt
