@@ -69,6 +69,14 @@ unsigned* device_error_word();                   // device-side address
 int device_error_status(const char* who);        // 0, or NNHIP_EDEVICE with the message set
 // Order this launch behind the previous user of the sync words / ticket partials when it arrives on another stream (runtime.hip).
 int serialize_shared_state(hipStream_t st);
+void shared_state_done(hipStream_t st);        // the user's launches are enqueued: leave an event for the next stream to wait on
+struct SharedStateUse {                         // RAII: construct after serialize_shared_state(), every return path reports the launches
+    hipStream_t st;
+    explicit SharedStateUse(hipStream_t s) : st(s) {}
+    ~SharedStateUse() { shared_state_done(st); }
+    SharedStateUse(const SharedStateUse&) = delete;
+    SharedStateUse& operator=(const SharedStateUse&) = delete;
+};
 
 // ---- device helpers ----------------------------------------------------------------------------
 // Wave64 all-reduce on the DPP lanes, no LDS traffic and no address registers: four row-local steps (quad_perm xor 1,

@@ -420,6 +420,7 @@ int gemm_small_mlp_backward_adam(const float* X1, const float* H, const float* W
     ad.err = device_error_word();
     if (int rc = device_error_status("nnhipLinearReLULinearBackwardAdam")) return rc;   // an earlier launch timed out: say so, do not pile on
     if (int rc = serialize_shared_state(st)) return rc;     // one arrival board per process (runtime.hip)
+    const SharedStateUse in_use(st);
     if (int rc = fused_optimizer_state(opt, step, &ad.dev_state, &ad.grad_div)) return rc;
     return gemm_small_mlp_backward(X1, H, W2, dO, dW2, db2, dW1, db1, rows, in1, hid, out2, st, &ad);
 }

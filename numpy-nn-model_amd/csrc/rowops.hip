@@ -1719,6 +1719,7 @@ static int ce_launch(CeArgs a, hipStream_t st) {
     unsigned* sync = sync_words();
     if (!sync) { set_last_error("cross entropy: sync words allocation failed"); return NNHIP_ENOMEM; }
     if (int rc = serialize_shared_state(st)) return rc;     // one ticket word / partial array per process: see runtime.hip
+    const SharedStateUse in_use(st);
     a.sync = sync + SYNC_CE;
     a.nt = row_streaming(a.rows, a.cols, a.ld);
     float* denom_scratch = reinterpret_cast<float*>(sync + SYNC_CE + 4);
@@ -1848,6 +1849,7 @@ extern "C" int nnhipLinearCrossEntropyLoss(const float* X, const float* W, const
         if (int rc = serialize_shared_state((hipStream_t)s)) return rc;
         a.sync = sync + SYNC_CE;
     }
+    const SharedStateUse in_use((hipStream_t)s);      // (harmless when the loss is not reduced: an event behind the launch)
     const bool vec = (in_features & 3) == 0 && aligned16(X) && aligned16(W);
     const bool nw8 = ((in_features + 15) >> 4) >= 8;       // gemm_small()'s choice
     hipStream_t st = (hipStream_t)s;
@@ -1900,6 +1902,7 @@ extern "C" int nnhipBatchNorm2dLinearSigmoidMSE(const float* X, const float* sta
     a.partial = static_cast<float*>(workspace((size_t)nblk * sizeof(float)));
     if (!sync || !a.partial) { set_last_error("nnhipBatchNorm2dLinearSigmoidMSE: workspace allocation failed"); return NNHIP_ENOMEM; }
     if (int rc = serialize_shared_state((hipStream_t)s)) return rc;
+    const SharedStateUse in_use((hipStream_t)s);
     a.sync = sync + SYNC_CE;
     hipLaunchKernelGGL((bn_linear_sigmoid_mse_kernel<8>), dim3(nblk), dim3(512), 0, (hipStream_t)s, p, h, a);
     NNHIP_LAUNCH_CHECK("bn_linear_sigmoid_mse_kernel");

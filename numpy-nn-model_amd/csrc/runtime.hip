@@ -81,15 +81,28 @@ const float* zero_block() {
 // process).  Costs a pointer compare when the stream is the same; a stream change is rare (a few per process) and pays a device
 // sync.  While `st` is being captured into a hipGraph nothing is inserted (a sync is illegal there; a captured step is
 // single-stream by construction, neunet_hip/graph.py), and a sync refused because ANOTHER stream is capturing is skipped likewise.
+static std::mutex g_ss_mu;
+static hipStream_t g_ss_last = nullptr;
+static bool g_ss_have_last = false;
+static hipEvent_t g_ss_ev = nullptr;        // recorded behind the last user's launches (shared_state_done), outside graph captures
+static bool g_ss_ev_live = false;
+static bool ss_capturing(hipStream_t st) {
+    hipStreamCaptureStatus a = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &a) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a != hipStreamCaptureStatusNone;
+}
 int serialize_shared_state(hipStream_t st) {
-    static std::mutex mu;
-    static hipStream_t last = nullptr;
-    static bool have_last = false;
-    std::lock_guard<std::mutex> lk(mu);
-    if (have_last && last != st) {
-        hipStreamCaptureStatus a = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(st, &a) != hipSuccess) { (void)hipGetLastError(); a = hipStreamCaptureStatusNone; }
-        if (a == hipStreamCaptureStatusNone) {
+    std::lock_guard<std::mutex> lk(g_ss_mu);
+    if (g_ss_have_last && g_ss_last != st && !ss_capturing(st)) {
+        // round 6 (advisor): the previous user left an EVENT behind its launches (a library-owned object; its stream handle is never
+        // touched again) -- the new stream waits for that event instead of the whole device.  No event (the previous user ran inside a
+        // graph capture, or event creation failed): the device sync of round 5.
+        bool ordered = false;
+        if (g_ss_ev_live) {
+            if (hipStreamWaitEvent(st, g_ss_ev, 0) == hipSuccess) ordered = true;
+            else (void)hipGetLastError();
+        }
+        if (!ordered) {
             const hipError_t e = hipDeviceSynchronize();
             if (e != hipSuccess) {
                 (void)hipGetLastError();          // e.g. a capture in progress elsewhere: nothing to order against, carry on
@@ -98,9 +111,17 @@ int serialize_shared_state(hipStream_t st) {
             }
         }
     }
-    last = st;
-    have_last = true;
+    g_ss_last = st;
+    g_ss_have_last = true;
     return 0;
+}
+// called (through SharedStateUse's destructor) after a user of the shared words has enqueued its launches on `st`
+void shared_state_done(hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_ss_mu);
+    if (ss_capturing(st)) { g_ss_ev_live = false; return; }      // (an event recorded into a capture is not one a later stream can wait on)
+    if (!g_ss_ev && hipEventCreateWithFlags(&g_ss_ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); g_ss_ev = nullptr; }
+    if (g_ss_ev && hipEventRecord(g_ss_ev, st) == hipSuccess) g_ss_ev_live = true;
+    else { (void)hipGetLastError(); g_ss_ev_live = false; }
 }
 
 static unsigned* g_deverr_host = nullptr;

@@ -2560,6 +2560,22 @@ def test_shared_state_guard_survives_a_destroyed_stream(hip):
         rows, _ = cross_entropy_forward_backward(dev(x), dev(y), "none", -100)     # back on the default stream
         torch.cuda.synchronize()
         np.testing.assert_allclose(host(rows), ref_rows, rtol=1e-5, atol=1e-5)
+    # round 6: a stream change waits for the previous user's EVENT (recorded behind its launches), not for the whole device.  Two live
+    # streams taking turns on the shared ticket words and loss partials, no host synchronisation in between: every 'mean' loss must
+    # be the reference's (an unordered pair of launches would mix their partial sums and tickets)
+    ref_mean, _ = O.cross_entropy_forward_backward(x, y, ignore_index=-100, reduction="mean")
+    big_x = dev(np.tile(x, (40, 1)))                                               # 12000 rows: long enough to overlap if unordered
+    big_y = dev(np.tile(y, 40))
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    losses = []
+    for k in range(12):
+        with torch.cuda.stream(s1 if k % 2 == 0 else s2):
+            loss, _ = cross_entropy_forward_backward(big_x, big_y, "mean", -100)
+            losses.append(loss)
+    torch.cuda.synchronize()
+    for l_ in losses:
+        np.testing.assert_allclose(float(host(l_).reshape(-1)[0]), float(ref_mean), rtol=2e-5)
 
 
 def test_gpt_step_fused_attention_equals_unfused(hip):
