@@ -25,7 +25,7 @@
 // EPI = 3 is EPI 1 with the z output replaced by swish'(z) (ACT_SWISH_D: one sigmoid serves both outputs) and EPI = 4 is EPI 2 with
 // the saved derivative as a plain multiplier (dact 3) -- round 6: the backward epilogue's sigmoid + polynomial (~64 matrix-pipe
 // cycles per element, 6 % of a K = 512 tile) becomes one multiply.
-// Conditions (gemm_pst_wanted): A k-major, 16-B aligned rows, K % 32 == 0, K >= 64 (96 with EPI 1, 160 with EPI 2),
+// Conditions (gemm_pst_wanted): A k-major, 16-B aligned rows, K % 32 == 0, K >= 96 (128 with EPI 1 / 3, 160 with EPI 2 / 4),
 // M % 128 == 0, no split-K / batch / addend, C and the operand windows addressable with 32-bit byte offsets, more tiles than
 // resident slots.  Everything else takes gemm.hip.
 #include <stdlib.h>
@@ -135,11 +135,15 @@ __device__ __forceinline__ void pst_flush_q(int q, const f32x16 (&pend)[2][2], c
 // zl -- of tile `zs` (quarter 0: the tile being finished) or of the pending tile (quarters 1-3).
 // (A two-deep variant -- a second register set, the k-tile after next in flight -- was measured: no change at K = 512, level
 // with gemm_f32_kernel at K = 4096; not kept.)
-template <int EPI, bool BKM, int FLUSH, int ZQ>
+// EDGE (round 6): 1 = the tile's FIRST k-step -- its first MFMA per accumulator takes C = 0 (an inline constant) instead of an
+// accumulator that 64 v_mov had to clear; 2 = the tile's LAST k-step -- its last MFMA per accumulator writes the PENDING set (D != C),
+// so the finished tile changes registers as part of the MFMA that completes it instead of through 64 more v_mov.  128 vector
+// instructions per tile and wave less, on lanes the MFMAs share; same products, same order: bit-identical.
+template <int EPI, bool BKM, int FLUSH, int ZQ, int EDGE = 0>
 __device__ __forceinline__ void pst_step(f32x16 (&acc)[2][2], float4 (&fa)[4], float4 (&fb)[4], float* __restrict__ smem, int cur,
                                          __amdgpu_buffer_rsrc_t rsa, __amdgpu_buffer_rsrc_t rsb, unsigned koffa, unsigned koffb,
                                          const unsigned (&offa)[4], const unsigned (&offb)[4], int tid, int wm, int wn, int l31,
-                                         int lh, const f32x16 (&pend)[2][2], const PstStore& ps, const PstStore& zs,
+                                         int lh, f32x16 (&pend)[2][2], const PstStore& ps, const PstStore& zs,
                                          const float (&zf)[2][8], float (&zl)[2][8], __amdgpu_buffer_rsrc_t rc,
                                          __amdgpu_buffer_rsrc_t rz, unsigned ldc4, float alpha, float beta) {
     constexpr bool ZIN = EPI == 2 || EPI == 4;                  // the epilogue reads a [M, ldc] operand (z / the saved derivative)
@@ -163,8 +167,22 @@ __device__ __forceinline__ void pst_step(f32x16 (&acc)[2][2], float4 (&fa)[4], f
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
+                for (int n = 0; n < 2; ++n) {
+                    if constexpr (EDGE == 1) {
+                        if (g == 0 && j == 0) {
+                            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                            acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[n][j], zero, 0, 0, 0);
+                            continue;
+                        }
+                    }
+                    if constexpr (EDGE == 2) {
+                        if (g == PBK / 8 - 1 && j == 3) {
+                            pend[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[n][j], acc[i][n], 0, 0, 0);
+                            continue;
+                        }
+                    }
                     acc[i][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][j], b[n][j], acc[i][n], 0, 0, 0);
+                }
     }
     if constexpr ((FLUSH & 1) != 0) pst_flush_q<EPI>(0, pend, ps, zf, rc, rz, ldc4, alpha, beta);
     if constexpr ((FLUSH & 2) != 0) pst_flush_q<EPI>(1, pend, ps, zf, rc, rz, ldc4, alpha, beta);
@@ -243,7 +261,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_pst_kernel(const PstParams p) {
 #pragma unroll
         for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) { acc[i][n][e] = 0.f; pend[i][n][e] = 0.f; }
+            for (int e = 0; e < 16; ++e) pend[i][n][e] = 0.f;       // (acc is defined by every tile's first k-step)
     float za[2][8], zb[2][8];                                      // EPI 2 only: z of the quarter being flushed / fetched
 #pragma unroll
     for (int n = 0; n < 2; ++n)
@@ -263,14 +281,14 @@ __global__ __launch_bounds__(NT, 2) void gemm_pst_kernel(const PstParams p) {
 
     int cur = 0;
     PstStore ps = store_of(tm, tn);                               // placeholder until a tile is pending
-    // the k-step (0 .. nk - 2, minus one for the two-step flush of EPI 1) under which this block flushes: eight phases by the
+    // the k-step (1 .. nk - 2, minus one for the two-step flush of EPI 1 / 3) under which this block flushes: eight phases by the
     // block's index inside its XCD (block b runs on XCD b % 8), the two blocks of a CU (index i and i + 32) half a
-    // tile apart; stagger == 0: step 0 for everybody (the round-2 schedule)
-    int flush_at = 0;
+    // tile apart; stagger == 0: step 1 for everybody
+    int flush_at = 1;
     if (EPI != 2 && EPI != 4 && p.stagger) {
         const int idx = (int)blockIdx.x >> 3, phase = (idx + 4 * (idx >> 5)) & 7;
-        const int last = nk - 2 - ((EPI == 1 || EPI == 3) ? 1 : 0);
-        flush_at = __builtin_amdgcn_readfirstlane(last > 0 ? (phase * last) / 7 : 0);
+        const int last = nk - 2 - ((EPI == 1 || EPI == 3) ? 1 : 0);      // the last k-step a flush may START under (>= 1: gemm_pst_wanted)
+        flush_at = __builtin_amdgcn_readfirstlane(1 + (phase * (last - 1)) / 7);
     }
     // one tile of the block's k-step stream.  PEND: a finished tile is waiting in `pend`; its stores go out under the first
     // k-step (EPI 1, twice the stores, and EPI 2: one row half under each of the first two).  Returns false after the block's
@@ -284,10 +302,11 @@ __global__ __launch_bounds__(NT, 2) void gemm_pst_kernel(const PstParams p) {
         if (has_next) pst_tile(vbn, p.total, p.tiles_m, p.tiles_n, tmn, tnn);
         const __amdgpu_buffer_rsrc_t rsan = rs_of(p.A, p.lda, p.M, (int64_t)tmn * 128), rsbn = rs_of_b((int64_t)tnn * 128);
         const PstStore mine = store_of(tm, tn);
-#define PST_STEP(F, ZQ, ZF, ZL, RA, RB, KT) \
-    pst_step<EPI, BKM, (PEND ? F : 0), (PEND || ZQ == 1 ? ZQ : 0)>(acc, ra, rb, smem, cur, RA, RB, (unsigned)(KT) * 128u, (unsigned)(KT) * kstep_b, \
+#define PST_STEP_E(F, ZQ, ZF, ZL, RA, RB, KT, EDGE) \
+    pst_step<EPI, BKM, (PEND ? F : 0), (PEND || ZQ == 1 ? ZQ : 0), EDGE>(acc, ra, rb, smem, cur, RA, RB, (unsigned)(KT) * 128u, (unsigned)(KT) * kstep_b, \
         offa, offb, tid, wm, wn, l31, lh, pend, ps, mine, ZF, ZL, rc, rz, ldc4, p.alpha, p.beta); \
     cur ^= 1
+#define PST_STEP(F, ZQ, ZF, ZL, RA, RB, KT) PST_STEP_E(F, ZQ, ZF, ZL, RA, RB, KT, 0)
         // Some k-steps of this tile flush the pending one: all of it under ONE step (EPI 0), a row half under each of TWO (EPI 1),
         // a quarter under each of the first FOUR (EPI 2, which also fetches the NEXT quarter's z values a step ahead, the two z sets
         // swapping roles).  WHICH step (EPI 0 / 1) depends on the block (round 6): the resident blocks start together and do equal
@@ -296,8 +315,12 @@ __global__ __launch_bounds__(NT, 2) void gemm_pst_kernel(const PstParams p) {
         // `flush_at` spread over the tile's k-steps by block the same bytes leave at the GEMM's average store rate (< 1 TB/s).
         // (three loops in a row, not one loop with a branch around the flushing step: with the branch inside the loop hipcc
         //  spilled 172-432 bytes per lane)
-        int kt = 0;
+        // step 0 is the tile's FIRST k-step (EDGE 1: the accumulators start from C = 0), with or without flush work
+        // (the FIRST step never flushes -- flush_at >= 1 -- so that it is ONE piece of code: a run-time choice between a flushing
+        //  and a plain first step spilled 40-84 B per lane, like the branch inside the loop did)
+        int kt = 1;
         if constexpr (EPI == 0) {
+            PST_STEP_E(0, 0, za, zb, rsa, rsb, 1, 1);
             if constexpr (PEND) {
                 for (; kt < flush_at; ++kt) { PST_STEP(0, 0, za, zb, rsa, rsb, kt + 1); }
                 PST_STEP(0xF, 0, za, zb, rsa, rsb, kt + 1);
@@ -305,6 +328,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_pst_kernel(const PstParams p) {
             }
             for (; kt + 1 < nk; ++kt) { PST_STEP(0, 0, za, zb, rsa, rsb, kt + 1); }
         } else if constexpr (EPI == 1 || EPI == 3) {
+            PST_STEP_E(0, 0, za, zb, rsa, rsb, 1, 1);
             if constexpr (PEND) {
                 for (; kt < flush_at; ++kt) { PST_STEP(0, 0, za, zb, rsa, rsb, kt + 1); }
                 PST_STEP(0x3, 0, za, zb, rsa, rsb, kt + 1);
@@ -314,7 +338,7 @@ __global__ __launch_bounds__(NT, 2) void gemm_pst_kernel(const PstParams p) {
             }
             for (; kt + 1 < nk; ++kt) { PST_STEP(0, 0, za, zb, rsa, rsb, kt + 1); }
         } else {
-            PST_STEP(0x1, 2, za, zb, rsa, rsb, 1);
+            PST_STEP_E(0x1, 2, za, zb, rsa, rsb, 1, 1);
             PST_STEP(0x2, 3, zb, za, rsa, rsb, 2);
             PST_STEP(0x4, 4, za, zb, rsa, rsb, 3);
             PST_STEP(0x8, 0, zb, za, rsa, rsb, 4);
@@ -322,17 +346,10 @@ __global__ __launch_bounds__(NT, 2) void gemm_pst_kernel(const PstParams p) {
         }
         // last k-step: fetches the first k-tile of the next tile (or, with nothing left, re-reads this one's: never used) and
         // (EPI 2) the z values of this tile's quarter 0
-        PST_STEP(0, 1, zb, za, rsan, rsbn, 0);
+        // (EDGE 2: the step's last MFMAs write `pend` -- the finished tile becomes the pending one without a copy)
+        PST_STEP_E(0, 1, zb, za, rsan, rsbn, 0, 2);
 #undef PST_STEP
-        // the finished tile becomes the pending one
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                pend[i][n] = acc[i][n];
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][n][e] = 0.f;
-            }
+#undef PST_STEP_E
         ps = mine;
         vb = vbn; tm = tmn; tn = tnn; rsa = rsan; rsb = rsbn;
         return has_next;
@@ -390,7 +407,7 @@ bool gemm_pst_wanted(int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, 
     // prefetch is worth more (with a two-deep prefetch of its own this kernel draws level there, no better: not kept)
     if (on < 2 && K > 1024) return false;
     // (the flush of the Swish epilogues takes two / four k-steps before the tile's last one)
-    if ((K % PBK) != 0 || K < ((epi == 2 || epi == 4) ? 5 : (epi == 1 || epi == 3) ? 3 : 2) * PBK || (M % 128) != 0 || N <= 0) return false;
+    if ((K % PBK) != 0 || K < ((epi == 2 || epi == 4) ? 5 : (epi == 1 || epi == 3) ? 4 : 3) * PBK || (M % 128) != 0 || N <= 0) return false;
     if (!aligned16(A) || !aligned16(B) || (lda & 3) || (ldb & 3) ||
         ((reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(preact) | reinterpret_cast<uintptr_t>(dswish) | reinterpret_cast<uintptr_t>(bias)) & 3))
         return false;
