@@ -14,7 +14,14 @@ MFMA peak".  The default workload ("headline") therefore measures, in ONE proces
   * also.c4_gemm        : GEMM-equivalent TFLOP/s of the whole C4 step;
   * also.c3 / also.c5   : every op of the fused micro-bench (rows 8192 x d 4096) with its HBM / MFMA fraction; the conv classifier step;
   * also.c4_strong      : (N > 1) the strong-scaling step next to the weak-scaling `value`;
-  * cpu_baseline        : the NumPy oracle's FULL GPT-tiny step (forward, backward, Adam) on a stated fraction of the batch.
+  * cpu_baseline        : the NumPy oracle's FULL GPT-tiny step (forward, backward, Adam): live n = 1 on the whole per-GPU batch + the
+                          committed n = 3 collection of the same step (profiles/cpu_c4_full_batch.json);
+  * gemm_mode           : 0 (exact fp32 MFMA) -- the run exits 4 otherwise: `dtype: f32` and `value` are defined for that mode only;
+  * also.c4_families    : every GEMM / attention launch of the step at its own shape, isolated (HIP events) and INSIDE the replayed step
+                          (`instep_ms`, from the committed rocprofv3 trace, profiles/c4_instep_families.json); roofline.instep likewise;
+  * allreduce_ms, rccl  : (N > 1 or --force-dp) the gradient exchange alone (`total`) and what it adds to the step (`exposed`), RCCL's own
+                          algorithm / protocol lines;
+  * also.linear_swish_sweep : the reference's Linear->Swish bench sweep (scripts/benchmark_linear_swish_cuda.py:127-138), its methodology.
 `--workload c1..c5` runs one BASELINE config on its own with the per-config detail (C3: per-op HBM fractions).
 
 `--gpus N` with no torchrun environment re-executes itself under torch.distributed.run with N ranks (one per GPU,
