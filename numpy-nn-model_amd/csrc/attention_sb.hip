@@ -473,7 +473,11 @@ __global__ __launch_bounds__(512, 2) void attn_sb_fwd_pw_kernel(const AttnParams
     const float qs = p.scale * AT_LOG2E;
     float* Kt = smem + wave * 2 * SB_TILE;                  // (also the output staging rows at the end of an item)
     float* Vt = Kt + SB_TILE;
-    const int64_t goff = (int64_t)(lane >> 4) * p.LQ + 4 * (lane & 15);      // this lane's float4 of rows (lane >> 4) + 4 it
+    // this lane's float4 of rows (lane >> 4) + 4 it: a per-lane byte offset computed ONCE; the group and the row step ride in the
+    // buffer load's scalar offset (64-bit address arithmetic per load was 0.8 VALU per MFMA on lanes the MFMAs share)
+    const unsigned pitchB = (unsigned)p.LQ * 4u;
+    const unsigned voffT = (unsigned)(lane >> 4) * pitchB + 16u * (unsigned)(lane & 15);
+    const unsigned slice_bytes = (unsigned)(((int64_t)(SB_T - 1) * p.LQ + SB_DH) * 4);
     const int loff = (lane >> 4) * SB_LD + 4 * (lane & 15);
 #pragma unroll 1
     for (int item = 0; item < 2; ++item) {
@@ -482,8 +486,8 @@ __global__ __launch_bounds__(512, 2) void attn_sb_fwd_pw_kernel(const AttnParams
         const int rg = item == 0 ? SB_NG - 1 - wave : wave;
         const int b = bh / p.H, h = bh - b * p.H;
         const float* __restrict__ Qb = p.Q + ((int64_t)b * SB_T) * p.LQ + (int64_t)h * SB_DH;
-        const float* __restrict__ Kb = p.K + ((int64_t)b * SB_T) * p.LQ + (int64_t)h * SB_DH;
-        const float* __restrict__ Vb = p.V + ((int64_t)b * SB_T) * p.LQ + (int64_t)h * SB_DH;
+        const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.K + ((int64_t)b * SB_T) * p.LQ + (int64_t)h * SB_DH), 0, (int)slice_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.V + ((int64_t)b * SB_T) * p.LQ + (int64_t)h * SB_DH), 0, (int)slice_bytes, 0x00020000);
         float qf[8][4];
         {
             const float* qrow = Qb + (int64_t)(32 * rg + l31) * p.LQ + 4 * lh;
@@ -508,11 +512,11 @@ __global__ __launch_bounds__(512, 2) void attn_sb_fwd_pw_kernel(const AttnParams
         int j = plain ? (int)__builtin_ctz(plain) : masked ? (int)__builtin_ctz(masked) : rg;
         sb_f32x4 nk[8], nv[8];               // (ext vectors: an array of HIP float4 structs went to scratch, 272 B per lane)
         {
-            const int64_t ro = (int64_t)(32 * j) * p.LQ + goff;
+            const unsigned so = (unsigned)(32 * j) * pitchB;
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
-                nk[it] = *reinterpret_cast<const sb_f32x4*>(Kb + ro + (int64_t)(4 * it) * p.LQ);
-                nv[it] = *reinterpret_cast<const sb_f32x4*>(Vb + ro + (int64_t)(4 * it) * p.LQ);
+                nk[it] = __builtin_bit_cast(sb_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, voffT, so + (unsigned)(4 * it) * pitchB, 0));
+                nv[it] = __builtin_bit_cast(sb_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, voffT, so + (unsigned)(4 * it) * pitchB, 0));
             }
         }
         f32x16 o[2];
@@ -535,11 +539,11 @@ __global__ __launch_bounds__(512, 2) void attn_sb_fwd_pw_kernel(const AttnParams
             if (is_plain) plain &= ~(1u << j); else masked &= ~(1u << j);
             const int jn = plain ? (int)__builtin_ctz(plain) : masked ? (int)__builtin_ctz(masked) : rg;
             if (u + 1 < n_units) {                           // the next pair on its way
-                const int64_t ro = (int64_t)(32 * jn) * p.LQ + goff;
+                const unsigned so = (unsigned)(32 * jn) * pitchB;
 #pragma unroll
                 for (int it = 0; it < 8; ++it) {
-                    nk[it] = *reinterpret_cast<const sb_f32x4*>(Kb + ro + (int64_t)(4 * it) * p.LQ);
-                    nv[it] = *reinterpret_cast<const sb_f32x4*>(Vb + ro + (int64_t)(4 * it) * p.LQ);
+                    nk[it] = __builtin_bit_cast(sb_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rk, voffT, so + (unsigned)(4 * it) * pitchB, 0));
+                    nv[it] = __builtin_bit_cast(sb_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rv, voffT, so + (unsigned)(4 * it) * pitchB, 0));
                 }
             }
             const unsigned valid = sb_valid32(kvbits, j);
