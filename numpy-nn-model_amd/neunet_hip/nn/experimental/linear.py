@@ -168,7 +168,12 @@ class _PendingMLPBackward:
     observable value is the one the eager sequence backward(); step() leaves -- only the launch count differs.
 
     The operands are the forward pass's buffers, held by reference; torch's version counters catch an in-place write to one of
-    them between backward() and the launch (a refilled input batch): that raises instead of computing from the wrong data."""
+    them between backward() and the launch (a refilled input batch): that raises instead of computing from the wrong data.
+    LIMIT of that guard (advisor, round 5): only writes torch knows about bump `_version`.  A buffer rewritten through a raw pointer
+    -- one of this library's nnhip* kernels called on `x.data` directly, a captured copy into a static slot during a graph replay
+    -- goes unnoticed, and the deferred launch differentiates the new contents.  GraphedTrainStep is safe by construction (it takes
+    the pending launch before it binds gradients, inside the same captured step); code that refills operands with library kernels
+    between backward() and step() must read a gradient first, or set NNHIP_AUTO_FUSE_STEP=0 (eager backward launch)."""
     __slots__ = ("ops", "versions", "params", "grads", "dims", "live", "adam_fits")
 
     def __init__(self, x, f_x, w2, grad, params, grads, rows, in1, hid, out2, adam_fits):
