@@ -79,3 +79,39 @@ def test_c4_instep_assigns_dispatches_to_families(tmp_path, monkeypatch):
     assert d["fc1_fwd_swish"]["n"] == 18
     assert abs(d["layer_dw"]["us"] - 725) < 1e-6 and d["layer_dw"]["units_per_launch"] == 2  # one launch covers two decoder layers
     assert d["head_dw"]["n"] == 3
+
+
+def test_bench_rccl_choices_and_device_time_guard(tmp_path):
+    """bench.py's readers of what it cannot measure itself: RCCL's TUNING lines (algorithm / protocol per collective size) and the
+    guard that drops a device-time figure which exceeds the wall time per step (host stalls inside the event pairs)."""
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    log = tmp_path / "rccl.log"
+    log.write_text("\n".join([
+        "runc:77:77 [0] NCCL INFO RCCL version : 2.26.6-HEAD:64f48b6",
+        "runc:77:99 [0] NCCL INFO 128 coll channels, 128 collnet channels, 0 nvls channels, 64 p2p channels, 128 p2p channels per peer",
+        "runc:77:99 [0] NCCL INFO AllReduce: 34980448 Bytes -> Algo 1 proto 2 time 412.500000",
+        "runc:77:99 [0] NCCL INFO AllReduce: 34980448 Bytes -> Algo 1 proto 2 time 412.500000",
+        "runc:77:99 [0] NCCL INFO AllReduce: 16 Bytes -> Algo 0 proto 0 time 9.100000",
+        "runc:77:99 [0] NCCL INFO Broadcast: 4 Bytes -> Algo 1 proto 0 time 5.0"]))
+    r = bench.rccl_choices(str(log))
+    assert "RCCL version" in r["version"] and "coll channels" in r["channels"]
+    big = r["choices"][0]
+    assert big == {"collective": "AllReduce", "bytes": 34980448, "algorithm": "RING", "protocol": "SIMPLE", "calls": 2}
+    assert {"collective": "AllReduce", "bytes": 16, "algorithm": "TREE", "protocol": "LL", "calls": 1} in r["choices"]
+    assert "note" in bench.rccl_choices(str(tmp_path / "missing.log")) and "note" in bench.rccl_choices(None)
+
+    class FakeEvent:
+        def __init__(self, t):
+            self.t = t
+
+        def elapsed_time(self, other):
+            return other.t - self.t
+    ev = bench.EventTimer()
+    for span in (0.020, 0.021, 0.019, 0.500):                # one pair caught a host stall
+        ev.pairs.append((FakeEvent(0.0), FakeEvent(span)))
+    assert abs(ev.median_ms() - 0.0205) < 1e-9 and ev.mean_ms() > 0.1
+    assert abs(bench.device_step_ms(ev, 1, 0.0215) - 0.0205) < 1e-9
+    assert bench.device_step_ms(ev, 1, 0.018) is None        # above the wall time per step by more than 5 %: dropped, not reported
+    assert bench.device_step_ms(bench.EventTimer(), 1, 1.0) is None
